@@ -1,0 +1,281 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python on CPU.
+
+Run in the dev container only (needs /root/reference):
+    python oracle/gen_golden.py
+
+The reference files are imported unmodified from where they lie; nothing of
+them is copied.  Three harness-side shims make the import possible
+(SURVEY.md section 8c):
+  1. MedTok/__init__.py pulls in dgl -> register a bare namespace package.
+  2. vector_quantization_soft_one_new.py:13 imports two helpers that
+     transformers 5.x no longer exports (dead imports) -> placeholders.
+  3. train mode on CPU: codebook_used is a buffer wrapping a leaf Parameter
+     (:118) and is written in place (:224) -> requires_grad_(False).
+Fixtures are data only: inputs (or the seeded recipe that regenerates them,
+oracle/synth.py) and the reference's outputs.
+"""
+from __future__ import annotations
+
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.dont_write_bytecode = True
+REF = Path("/root/reference")
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+GOLD = ROOT / "tests" / "golden"
+
+from oracle import synth  # noqa: E402
+
+
+def import_reference():
+    pkg = types.ModuleType("MedTok")
+    pkg.__path__ = [str(REF / "MedTok")]
+    sys.modules["MedTok"] = pkg
+    import transformers.modeling_utils as mu
+    for name in ("get_parameter_device", "get_parameter_dtype"):
+        if not hasattr(mu, name):
+            setattr(mu, name, lambda *a, **k: None)
+    import MedTok.norm_ema_quantizer as nq
+    import MedTok.loss as ls
+    import MedTok.vector_quantization_soft_one_new as sq
+    return sq, nq, ls
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    GOLD.mkdir(parents=True, exist_ok=True)
+    np.savez_compressed(GOLD / f"{name}.npz", **out)
+    print(f"wrote {name}.npz ({(GOLD / (name + '.npz')).stat().st_size / 1024:.1f} KiB)")
+
+
+def gaps64(xn, wn, k):
+    """fp64 distances: sorted top-(k+1) values per row (tests derive the gaps)."""
+    d = (xn.double() ** 2).sum(1, keepdim=True) + (wn.double() ** 2).sum(1) - 2 * xn.double() @ wn.double().t()
+    return torch.sort(d, dim=1).values[:, : k + 1]
+
+
+def make_soft(sq, n_e, e_dim, k=5, beta=0.25, seed=0, tag="vq"):
+    q = sq.VectorQuantizer(n_e, e_dim, beta, 0.0, True, True, [e_dim, e_dim], k=k)
+    q.load_state_dict(synth.det_state_dict(q, tag, seed))
+    q.codebook_used.requires_grad_(False)
+    for layer in q.cross_attn.model:      # deterministic train-mode fixtures
+        layer.multihead_attn.dropout = 0.0
+        layer.dropout.p = 0.0
+    return q
+
+
+def ref_tokens(q, x_proj, region):
+    """The (indices, weights) specific_embedding computes but never returns
+    (vector_quantization_soft_one_new.py:196-204), from the reference's own ops."""
+    n = q.codebook.weight.shape[0] // 3
+    W = q.codebook.weight[:n] if region == "text" else (q.codebook.weight[-n:] if region == "graph" else q.codebook.weight)
+    xn = F.normalize(x_proj, p=2, dim=-1)
+    wn = F.normalize(W, p=2, dim=-1)
+    d = q.get_distance(xn, wn)
+    v, i = torch.topk(d, k=q.k, largest=False)
+    return i, torch.softmax(-v, dim=1), v, gaps64(xn, wn, q.k)
+
+
+def fixture_specific(sq, name, N, D, n_e, seed):
+    q = make_soft(sq, n_e, D, seed=seed, tag=name)
+    x = synth.det_randn(name + ".x", (N, D), 1.0, seed)
+    out = {"x": x, "n_e": n_e, "e_dim": D, "k": q.k, "beta": q.beta, "seed": seed}
+    for types_ in ("text", "graph"):
+        proj = q.proj_text if types_ == "text" else q.proj_graph
+        # eval
+        q.eval()
+        with torch.no_grad():
+            zq, (vq, cm, xhat, zq2), usage = q.specific_embedding(x, types=types_)
+            idx, w, v, g = ref_tokens(q, proj(x), types_)
+        out.update({f"{types_}.eval.zq": zq, f"{types_}.eval.xhat": xhat, f"{types_}.eval.vq": vq,
+                    f"{types_}.eval.commit": cm, f"{types_}.idx": idx, f"{types_}.w": w,
+                    f"{types_}.dist": v, f"{types_}.gap64": g, f"{types_}.eval.usage": usage,
+                    f"{types_}.x_proj": proj(x)})
+        # train (+ grads)
+        q.train()
+        q.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        zq, (vq, cm, xhat, _), usage = q.specific_embedding(xg, types=types_)
+        # a scalar that exercises every path: losses + a fixed projection of the STE output
+        probe = synth.det_randn(name + ".probe", (N, D), 1.0, seed)
+        (vq + cm + (zq * probe).sum() / N).backward()
+        out.update({f"{types_}.train.zq": zq, f"{types_}.train.vq": vq, f"{types_}.train.commit": cm,
+                    f"{types_}.train.grad_x": xg.grad, f"{types_}.train.grad_codebook": q.codebook.weight.grad,
+                    f"{types_}.train.grad_proj_w_head": proj.weight.grad[:8].clone(),
+                    f"{types_}.train.grad_proj_w_colsum": proj.weight.grad.double().sum(0),
+                    f"{types_}.train.grad_proj_b": proj.bias.grad})
+    npz(name, **out)
+
+
+def fixture_forward(sq, name, B, L, max_nodes, D, n_e, seed, train_too=True, store_inputs=True):
+    q = make_soft(sq, n_e, D, seed=seed, tag=name)
+    text, mask, nodes, batch = synth.ragged_batch(name + ".batch", B, L, max_nodes, D, seed)
+    z = synth.det_randn(name + ".z", (B, 2 * D), 1.0, seed)
+    z_aug = synth.det_randn(name + ".z_aug", (B, 2 * D), 1.0, seed)
+    out = {"n_e": n_e, "e_dim": D, "k": q.k, "beta": q.beta, "seed": seed, "B": B, "L": L, "max_nodes": max_nodes}
+    if store_inputs:
+        out.update({"z": z, "z_aug": z_aug, "text": text, "mask": mask, "nodes": nodes, "batch": batch})
+    q.eval()
+    with torch.no_grad():
+        r = q(z, text, nodes, mask, batch, z_aug)
+        # the pooled cross-attention outputs the shared search runs on (:133-145)
+        zt, zg = [], []
+        for i in range(B):
+            t = text[i, : int(mask[i].sum())]
+            gph = nodes[(batch == i)]
+            a, b = q.cross_attn(t, gph)
+            zt.append(a[0]); zg.append(b.mean(0))
+        zt, zg = torch.stack(zt), torch.stack(zg)
+        st_i, st_w, st_v, st_g = ref_tokens(q, zt, "shared")
+        sg_i, sg_w, sg_v, sg_g = ref_tokens(q, zg, "shared")
+        zt_x, zg_x = torch.split(z, [D, D], dim=-1)
+        t_i, t_w, t_v, t_g = ref_tokens(q, q.proj_text(zt_x), "text")
+        g_i, g_w, g_v, g_g = ref_tokens(q, q.proj_graph(zg_x), "graph")
+
+    def put(prefix, r):
+        for k_, v_ in r.items():
+            if isinstance(v_, tuple):
+                for j, e in enumerate(v_):
+                    out[f"{prefix}.{k_}.{j}"] = e
+            elif v_ is not None:
+                out[f"{prefix}.{k_}"] = v_
+    if store_inputs:
+        put("eval", r)
+        out.update({"pooled_text": zt, "pooled_graph": zg})
+    else:  # big config: keep ids/weights, a slice and row sums of the embeddings
+        emb = torch.cat([r["specific_embedding_text"], r["specific_embedding_graph"],
+                         r["shared_text_embedding"], r["shared_graph_embedding"]], dim=-1)
+        out.update({"emb_head": emb[:8], "emb_rowsum": emb.double().sum(1), "emb_abs_rowsum": emb.double().abs().sum(1),
+                    "usage": np.array([r["shared_codebook_usage"], r["text_specific_usage"], r["graph_specific_usage"]])})
+    out.update({"shared_text.idx": st_i, "shared_text.w": st_w, "shared_text.dist": st_v, "shared_text.gap64": st_g,
+                "shared_graph.idx": sg_i, "shared_graph.w": sg_w, "shared_graph.dist": sg_v, "shared_graph.gap64": sg_g,
+                "text.idx": t_i, "text.w": t_w, "text.dist": t_v, "text.gap64": t_g,
+                "graph.idx": g_i, "graph.w": g_w, "graph.dist": g_v, "graph.gap64": g_g})
+    if train_too:
+        q.train()
+        q.codebook_used.zero_()
+        q.zero_grad()
+        zr = z.clone().requires_grad_(True)
+        tr = text.clone().requires_grad_(True)
+        nr = nodes.clone().requires_grad_(True)
+        r = q(zr, tr, nr, mask, batch, z_aug)
+        put("train", {k_: v_ for k_, v_ in r.items() if "usage" not in k_})
+        total = (r["shared_embed_loss"][0] + r["shared_embed_loss"][1] + r["text_specific_loss"][0] + r["text_specific_loss"][1]
+                 + r["graph_specific_loss"][0] + r["graph_specific_loss"][1])
+        probe = synth.det_randn(name + ".probe", (B, D), 1.0, seed)
+        total = total + ((r["shared_text_embedding"] + r["shared_graph_embedding"] + r["specific_embedding_text"]
+                          + r["specific_embedding_graph"] + r["specific_embedding_text_aug"]) * probe).sum() / B
+        total.backward()
+        out.update({"train.grad_z": zr.grad, "train.grad_text": tr.grad, "train.grad_nodes": nr.grad,
+                    "train.grad_codebook": q.codebook.weight.grad,
+                    "train.grad_in_proj0": q.cross_attn.model[0].multihead_attn.in_proj_weight.grad,
+                    "train.grad_proj_text_w": q.proj_text.weight.grad})
+    npz(name, **out)
+
+
+def fixture_norm_ema(nq, name, N, D, K, seed, steps=3, beta=0.25, decay=0.99, concentrate=False):
+    torch.manual_seed(seed)
+    q = nq.NormEMAVectorQuantizer(K, D, beta, decay)
+    E0 = F.normalize(synth.det_randn(name + ".E", (K, D), 1.0, seed), dim=-1)
+    q.embedding.weight.data.copy_(E0)
+    out = {"E0": E0, "K": K, "D": D, "beta": beta, "decay": decay, "steps": steps, "seed": seed}
+    q.train()
+    for s in range(steps):
+        z = synth.det_randn(f"{name}.z{s}", (N, D), 1.0, seed)
+        if concentrate:  # most codes unused -> zero_mask branch (:199-209)
+            z = E0[:3].repeat(N // 3 + 1, 1)[:N] + 0.05 * z
+        zn = F.normalize(z, dim=-1)
+        g = gaps64(zn, q.embedding.weight.data.clone(), 1)
+        zr = z.clone().requires_grad_(True)
+        zq, loss, idx = q(zr[:, :, None, None])
+        (loss + zq.square().sum() * 0.5).backward()
+        out.update({f"s{s}.z": z, f"s{s}.zq": zq[:, :, 0, 0], f"s{s}.loss": loss, f"s{s}.idx": idx, f"s{s}.gap64": g,
+                    f"s{s}.E": q.embedding.weight.data.clone(), f"s{s}.cluster_size": q.cluster_size.clone(),
+                    f"s{s}.grad_z": zr.grad})
+    q.eval()
+    z = synth.det_randn(f"{name}.zeval", (N, D), 1.0, seed)
+    with torch.no_grad():
+        g = gaps64(F.normalize(z, dim=-1), q.embedding.weight.data.clone(), 1)
+        zq, loss, idx = q(z[:, :, None, None])
+    out.update({"eval.z": z, "eval.zq": zq[:, :, 0, 0], "eval.loss": loss, "eval.idx": idx, "eval.gap64": g,
+                "eval.E": q.embedding.weight.data.clone(), "eval.cluster_size": q.cluster_size.clone()})
+    out["state_dict_keys"] = np.array(sorted(q.state_dict().keys()))
+    npz(name, **out)
+
+
+def fixture_losses(ls, name, B, D, seed):
+    t = {k: synth.det_randn(f"{name}.{k}", (B, D), 1.0, seed) for k in
+         ("z1", "z2", "x1", "x2", "z1_aug", "z2_aug", "z1_c", "z2_c")}
+    req = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+    s = ls.shared_loss(req["z1_c"], req["z2_c"], req["x1"], req["x2"])
+    p = ls.specific_loss(req["z1"], req["z1_aug"], req["z2"], req["z2_aug"], req["z1_c"], req["z2_c"])
+    codebook_loss = torch.tensor(0.375)
+    # loss assembly of train_MedTok.py:215-238 (beta = lamb = 0.1, :375-376)
+    total = codebook_loss + (s[0] - 0.1 * s[1]) + (s[2] - 0.1 * s[3]) + (p[0] + 0.1 * p[1]) + (p[2] + 0.1 * p[3])
+    total.backward()
+    out = dict(t)
+    out.update({"shared": torch.stack(s), "specific": torch.stack(p), "codebook_loss": codebook_loss, "total": total,
+                "nce_z1_z2": ls.info_nce_loss(t["z1"], t["z2"]), "align": ls.alignment_loss(t["x1"], t["x2"]),
+                "orth": ls.orthogonal_loss(t["z1"], t["z1_c"])})
+    out.update({f"grad.{k}": v.grad for k, v in req.items()})
+    npz(name, **out)
+
+
+def fixture_usage(sq, name, seed):
+    q = make_soft(sq, 96, 16, seed=seed, tag=name)
+    g = torch.Generator().manual_seed(seed)
+    out = {"n_e": 96, "window": 300000}
+    for i, (m, types_) in enumerate([(40, "shared"), (25, "text-specific"), (25, "graph-specific"), (3000, "shared")]):
+        ids = torch.randint(0, 96 if types_ == "shared" else 32, (m,), generator=g)
+        with torch.no_grad():
+            u = q.codebook_usage(ids, types=types_)
+        out[f"c{i}.ids"] = ids
+        out[f"c{i}.usage"] = u
+    out["final_tail"] = q.codebook_used[-4000:].detach().clone()
+    npz(name, **out)
+
+
+def fixture_ties(sq, name):
+    """Duplicated codebook rows: records what torch does here (topk tie order is
+    implementation-defined, argmin takes the first) next to the build's rule
+    (lowest index first); tests assert only the build's rule."""
+    W = synth.det_randn(name + ".W", (12, 8), 1.0, 0)
+    W[7] = W[3]; W[1] = W[3]; W[10] = W[4]
+    x = torch.stack([W[3] * 2.0, W[4] * 0.5, W[0]])
+    xn, wn = F.normalize(x, dim=-1), F.normalize(W, dim=-1)
+    d = (xn ** 2).sum(1, keepdim=True) + (wn ** 2).sum(1) - 2 * xn @ wn.t()
+    v, i = torch.topk(d, 5, largest=False)
+    npz(name, W=W, x=x, torch_topk_idx=i, torch_topk_val=v, torch_argmin=torch.argmin(d, 1),
+        build_rule_idx=np.array([[1, 3, 7], [4, 10, -1], [0, -1, -1]]))
+
+
+def main():
+    torch.set_num_threads(8)
+    sq, nq, ls = import_reference()
+    fixture_specific(sq, "f1_specific_d64", N=256, D=64, n_e=288, seed=1)
+    fixture_specific(sq, "f2_specific_d768", N=64, D=768, n_e=384, seed=2)
+    fixture_forward(sq, "f3_forward_d64", B=8, L=12, max_nodes=9, D=64, n_e=96, seed=3)
+    fixture_forward(sq, "f4_forward_d128", B=16, L=20, max_nodes=12, D=128, n_e=600, seed=4)
+    fixture_norm_ema(nq, "f5_normema_d32", N=512, D=32, K=64, seed=5)
+    fixture_norm_ema(nq, "f5_normema_d768", N=96, D=768, K=128, seed=6)
+    fixture_norm_ema(nq, "f6_normema_zero_usage", N=48, D=32, K=64, seed=7, concentrate=True)
+    fixture_losses(ls, "f7_losses", B=16, D=64, seed=8)
+    fixture_ties(sq, "f8_ties")
+    fixture_usage(sq, "f10_usage", seed=10)
+    # BASELINE config 1: 1k codes, 768-d, K=8192 -- inputs regenerated from the seeded recipe
+    fixture_forward(sq, "cfg1_inference_1k", B=1000, L=8, max_nodes=6, D=768, n_e=8192, seed=11,
+                    train_too=False, store_inputs=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,299 @@
+/*
+ * medtok_oracle.c -- CPU restatement of MedTok's vector-quantisation hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under medtok_amd/ may include, link or
+ * dlopen this file; it is the checker for tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function
+ * here against tests/golden/ (.npz), which oracle/gen_golden.py produced in the
+ * dev container by importing the reference's unmodified Python files on CPU.
+ *
+ * Reference algorithm (file:line under /root/reference):
+ *   l2 normalise            MedTok/norm_ema_quantizer.py:8-9, F.normalize eps=1e-12
+ *   distance                MedTok/vector_quantization_soft_one_new.py:120-125
+ *                           MedTok/norm_ema_quantizer.py:175-177
+ *   top-k / softmax / mix   MedTok/vector_quantization_soft_one_new.py:157-165,203-205
+ *   vq / commit loss, STE   MedTok/vector_quantization_soft_one_new.py:168-182,207-214
+ *   argmin + EMA update     MedTok/norm_ema_quantizer.py:179-214
+ *   codebook usage window   MedTok/vector_quantization_soft_one_new.py:219-236
+ *
+ * The reference evaluates  d = (|x|^2 + |e|^2) - 2 * (x . e)  with whatever
+ * summation order its BLAS picks.  This restatement fixes ONE order, chosen so
+ * the MI355X kernels can reproduce it bit for bit:
+ *   - x.e is a single fp32 fmaf chain over i = 0..D-1 starting from +0
+ *     (exactly what v_mfma_f32_32x32x2_f32 computes when fed k in order);
+ *   - |v|^2 is 64 strided fmaf chains (element i goes to chain (i/4)%64)
+ *     combined by an xor butterfly (offsets 32,16,8,4,2,1), i.e. one wavefront
+ *     reading float4 per lane;
+ *   - ties in the search resolve to the lowest code index (torch.argmin's
+ *     rule; torch.topk's tie order is implementation-defined).
+ * Near-ties (top-k gap below ~1e-6) may therefore order differently from the
+ * reference's BLAS; the golden fixtures carry fp64 gaps so tests can tell.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -ffp-contract=off, FMA clone).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#if defined(__x86_64__)
+#define ORACLE_CLONES __attribute__((target_clones("fma", "default")))
+#else
+#define ORACLE_CLONES
+#endif
+
+#define ORACLE_MAX_TOPK 16
+#define ORACLE_CODE_CHUNK 64
+
+/* ---- canonical |v|^2 : 64 strided fmaf chains + xor butterfly ------------ */
+static float canon_sumsq(const float *v, int d)
+{
+    float p[64], q[64];
+    for (int l = 0; l < 64; ++l) p[l] = 0.0f;
+    for (int i = 0; i < d; ++i) {
+        int l = (i >> 2) & 63;
+        p[l] = fmaf(v[i], v[i], p[l]);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ off];
+        memcpy(p, q, sizeof p);
+    }
+    return p[0];
+}
+
+/* F.normalize(p=2, dim=-1, eps=1e-12): x / max(||x||, eps); also returns the
+ * squared norm of the *output* row (the term get_distance re-derives). */
+int oracle_rownorm_f32(const float *x, int64_t n, int d, int normalize,
+                       float *xhat, float *sqn)
+{
+    for (int64_t r = 0; r < n; ++r) {
+        const float *src = x + r * d;
+        float *dst = xhat + r * d;
+        if (normalize) {
+            float nrm = sqrtf(canon_sumsq(src, d));
+            float den = nrm > 1e-12f ? nrm : 1e-12f;
+            for (int i = 0; i < d; ++i) dst[i] = src[i] / den;
+        } else if (dst != src) {
+            memcpy(dst, src, sizeof(float) * (size_t)d);
+        }
+        if (sqn) sqn[r] = canon_sumsq(dst, d);
+    }
+    return 0;
+}
+
+/* One row against a chunk of codes stored transposed ([d][chunk]) so the
+ * compiler can run one fmaf chain per SIMD lane; per-lane arithmetic is the
+ * scalar chain, so the result does not depend on the vector width. */
+ORACLE_CLONES
+static void dot_chunk(const float *xrow, const float *wt, int d, float *acc)
+{
+    float a[ORACLE_CODE_CHUNK];
+    for (int c = 0; c < ORACLE_CODE_CHUNK; ++c) a[c] = 0.0f;
+    for (int i = 0; i < d; ++i) {
+        const float xi = xrow[i];
+        const float *w = wt + (size_t)i * ORACLE_CODE_CHUNK;
+        for (int c = 0; c < ORACLE_CODE_CHUNK; ++c)
+            a[c] = fmaf(xi, w[c], a[c]);
+    }
+    for (int c = 0; c < ORACLE_CODE_CHUNK; ++c) acc[c] = a[c];
+}
+
+/* Nearest-code search: for each row the `topk` smallest
+ *   d = (xsq + wsq[c]) - 2 * dot(xhat, what[c])
+ * ascending, ties to the lowest code index.  idx is int64 like torch. */
+int oracle_topk_search_f32(const float *xhat, const float *xsq, int64_t n,
+                           const float *what, const float *wsq, int64_t k_codes,
+                           int d, int topk, int64_t *idx, float *dist)
+{
+    if (topk < 1 || topk > ORACLE_MAX_TOPK || topk > k_codes) return -1;
+    const int64_t n_chunks = (k_codes + ORACLE_CODE_CHUNK - 1) / ORACLE_CODE_CHUNK;
+    float *wt = (float *)calloc((size_t)n_chunks * d * ORACLE_CODE_CHUNK, sizeof(float));
+    if (!wt) return -2;
+    for (int64_t c = 0; c < k_codes; ++c) {
+        int64_t ch = c / ORACLE_CODE_CHUNK, lane = c % ORACLE_CODE_CHUNK;
+        for (int i = 0; i < d; ++i)
+            wt[((size_t)ch * d + i) * ORACLE_CODE_CHUNK + lane] = what[c * d + i];
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r) {
+        float bv[ORACLE_MAX_TOPK];
+        int64_t bi[ORACLE_MAX_TOPK];
+        float acc[ORACLE_CODE_CHUNK];
+        for (int j = 0; j < topk; ++j) { bv[j] = INFINITY; bi[j] = 0; }
+        const float *xr = xhat + r * d;
+        const float xn = xsq[r];
+        for (int64_t ch = 0; ch < n_chunks; ++ch) {
+            int64_t base = ch * ORACLE_CODE_CHUNK;
+            int cnt = (int)((k_codes - base) < ORACLE_CODE_CHUNK ? (k_codes - base) : ORACLE_CODE_CHUNK);
+            dot_chunk(xr, wt + (size_t)ch * d * ORACLE_CODE_CHUNK, d, acc);
+            for (int c = 0; c < cnt; ++c) {
+                float s = xn + wsq[base + c];
+                float t = 2.0f * acc[c];
+                float dv = s - t;
+                if (dv < bv[topk - 1]) {
+                    int j = topk - 1;
+                    while (j > 0 && dv < bv[j - 1]) { bv[j] = bv[j - 1]; bi[j] = bi[j - 1]; --j; }
+                    bv[j] = dv; bi[j] = base + c;
+                }
+            }
+        }
+        for (int j = 0; j < topk; ++j) { idx[r * topk + j] = bi[j]; dist[r * topk + j] = bv[j]; }
+    }
+    free(wt);
+    return 0;
+}
+
+/* Full distance matrix (small cases only): used to derive fp64 gaps and to
+ * cross-check the search above. */
+int oracle_distance_f32(const float *xhat, const float *xsq, int64_t n,
+                        const float *what, const float *wsq, int64_t k_codes,
+                        int d, float *out)
+{
+    for (int64_t r = 0; r < n; ++r)
+        for (int64_t c = 0; c < k_codes; ++c) {
+            float acc = 0.0f;
+            for (int i = 0; i < d; ++i) acc = fmaf(xhat[r * d + i], what[c * d + i], acc);
+            float s = xsq[r] + wsq[c];
+            float t = 2.0f * acc;
+            out[r * k_codes + c] = s - t;
+        }
+    return 0;
+}
+
+/* Soft assignment.  w = softmax(-dist) over the topk entries;
+ * zq = sum_j w_j * what[idx_j]; out = xref + (zq - xref) (straight-through
+ * forward value, vector_quantization_soft_one_new.py:181-182,214);
+ * row_sqerr[r] = sum_i (zq - xref)^2 (the un-normalised numerator of the vq
+ * and commitment losses, :169-173,208-209).
+ * hard != 0 selects the NormEMA form (topk==1, w=1, zq = what[idx]). */
+int oracle_soft_assign_f32(const float *xref, const float *what,
+                           const int64_t *idx, const float *dist, int64_t n,
+                           int d, int topk, int hard, float *w, float *zq_ste,
+                           float *row_sqerr)
+{
+    if (topk < 1 || topk > ORACLE_MAX_TOPK) return -1;
+    for (int64_t r = 0; r < n; ++r) {
+        float wj[ORACLE_MAX_TOPK];
+        if (hard) {
+            wj[0] = 1.0f;
+        } else {
+            float m = -dist[r * topk];
+            float sum = 0.0f;
+            for (int j = 0; j < topk; ++j) { wj[j] = expf(-dist[r * topk + j] - m); sum += wj[j]; }
+            for (int j = 0; j < topk; ++j) wj[j] = wj[j] / sum;
+        }
+        if (w) for (int j = 0; j < topk; ++j) w[r * topk + j] = wj[j];
+        double se = 0.0;
+        for (int i = 0; i < d; ++i) {
+            float acc = 0.0f;
+            if (hard) acc = what[idx[r] * d + i];
+            else for (int j = 0; j < topk; ++j) acc = fmaf(wj[j], what[idx[r * topk + j] * d + i], acc);
+            float xr = xref[r * d + i];
+            float diff = acc - xr;
+            if (zq_ste) zq_ste[r * d + i] = xr + diff;
+            se += (double)diff * (double)diff;
+        }
+        if (row_sqerr) row_sqerr[r] = (float)se;
+    }
+    return 0;
+}
+
+/* EMA statistics (norm_ema_quantizer.py:194,202): bins[c] = #rows assigned to
+ * c; embed_sum[c][:] = sum of those rows of zhat, added in increasing row
+ * order (layout [K,D]; the reference's [D,K] is its transpose). */
+int oracle_ema_stats_f32(const float *zhat, const int64_t *idx, int64_t n, int d,
+                         int64_t k_codes, float *bins, float *embed_sum)
+{
+    memset(bins, 0, sizeof(float) * (size_t)k_codes);
+    memset(embed_sum, 0, sizeof(float) * (size_t)k_codes * d);
+    for (int64_t r = 0; r < n; ++r) {
+        int64_t c = idx[r];
+        if (c < 0 || c >= k_codes) return -1;
+        bins[c] += 1.0f;
+        float *dst = embed_sum + c * d;
+        const float *src = zhat + r * d;
+        for (int i = 0; i < d; ++i) dst[i] = dst[i] + src[i];
+    }
+    return 0;
+}
+
+/* EMA apply (norm_ema_quantizer.py:197-210,136-138,11-12):
+ *   cluster_size <- decay*cluster_size + (1-decay)*bins
+ *   new = l2norm(embed_sum / max(bins,1)); rows with bins==0 keep E
+ *   E <- l2norm(decay*E + (1-decay)*new)
+ * one_minus_decay is passed in because the reference forms it in Python
+ * double precision (1 - 0.99) before it is cast to fp32. */
+int oracle_ema_apply_f32(float *E, float *cluster_size, const float *bins,
+                         const float *embed_sum, int64_t k_codes, int d,
+                         float decay, float one_minus_decay)
+{
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)d);
+    if (!tmp) return -2;
+    for (int64_t c = 0; c < k_codes; ++c) {
+        float b = bins[c];
+        float a0 = cluster_size[c] * decay;
+        float a1 = b * one_minus_decay;
+        cluster_size[c] = a0 + a1;
+        float *e = E + c * d;
+        if (b == 0.0f) {
+            memcpy(tmp, e, sizeof(float) * (size_t)d);
+        } else {
+            const float *s = embed_sum + c * d;
+            for (int i = 0; i < d; ++i) tmp[i] = s[i] / b;
+            float nrm = sqrtf(canon_sumsq(tmp, d));
+            float den = nrm > 1e-12f ? nrm : 1e-12f;
+            for (int i = 0; i < d; ++i) tmp[i] = tmp[i] / den;
+        }
+        for (int i = 0; i < d; ++i) {
+            float m0 = e[i] * decay;
+            float m1 = tmp[i] * one_minus_decay;
+            tmp[i] = m0 + m1;
+        }
+        float nrm = sqrtf(canon_sumsq(tmp, d));
+        float den = nrm > 1e-12f ? nrm : 1e-12f;
+        for (int i = 0; i < d; ++i) e[i] = tmp[i] / den;
+    }
+    free(tmp);
+    return 0;
+}
+
+/* Eval-mode branch (norm_ema_quantizer.py:185-189): only cluster_size moves. */
+int oracle_ema_cluster_size_f32(float *cluster_size, const float *bins,
+                                int64_t k_codes, float decay, float one_minus_decay)
+{
+    for (int64_t c = 0; c < k_codes; ++c) {
+        float a0 = cluster_size[c] * decay;
+        float a1 = bins[c] * one_minus_decay;
+        cluster_size[c] = a0 + a1;
+    }
+    return 0;
+}
+
+/* codebook_usage (vector_quantization_soft_one_new.py:219-236): slide the
+ * fp32 window left by m, append the new ids, count distinct values.
+ * Returns the distinct count (the reference divides it by n_e). When m exceeds
+ * the window the reference raises; here the last `window` ids are kept. */
+int64_t oracle_usage_update(float *window, int64_t wlen, const int64_t *ids,
+                            int64_t m, int64_t n_codes)
+{
+    if (m >= wlen) {
+        for (int64_t i = 0; i < wlen; ++i) window[i] = (float)ids[m - wlen + i];
+    } else {
+        memmove(window, window + m, sizeof(float) * (size_t)(wlen - m));
+        for (int64_t i = 0; i < m; ++i) window[wlen - m + i] = (float)ids[i];
+    }
+    unsigned char *seen = (unsigned char *)calloc((size_t)n_codes + 1, 1);
+    if (!seen) return -2;
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < wlen; ++i) {
+        int64_t v = (int64_t)window[i];
+        if (v < 0 || v >= n_codes) v = n_codes;
+        if (!seen[v]) { seen[v] = 1; ++cnt; }
+    }
+    free(seen);
+    return cnt;
+}
+
+int oracle_abi_version(void) { return 1; }

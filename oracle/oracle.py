@@ -1,0 +1,180 @@
+"""numpy front-end of the CPU oracle (oracle/medtok_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under medtok_amd/ imports this module.
+
+Each function mirrors one C-ABI entry point of the product library
+(include/medtok_vq.h) and cites the reference lines it restates; the
+arithmetic order is documented in medtok_oracle.c.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_SO = _HERE / "libmedtok_oracle.so"
+_lib = None
+
+_f32p = C.POINTER(C.c_float)
+_i64p = C.POINTER(C.c_int64)
+
+
+def build(force: bool = False) -> Path:
+    """Compile the C restatement with gcc (seconds)."""
+    src = _HERE / "medtok_oracle.c"
+    if force or not _SO.exists() or _SO.stat().st_mtime < src.stat().st_mtime:
+        subprocess.check_call(["make", "-C", str(_HERE), "-B", "libmedtok_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not _SO.exists():
+            build()
+        _lib = C.CDLL(str(_SO))
+        _lib.oracle_usage_update.restype = C.c_int64
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(_i64p)
+
+
+def rownorm(x, normalize=True):
+    """F.normalize(x, p=2, dim=-1) and |xhat|^2 (norm_ema_quantizer.py:8-9)."""
+    x, xp = _f(x)
+    n, d = x.shape
+    xhat = np.empty_like(x)
+    sqn = np.empty(n, np.float32)
+    rc = lib().oracle_rownorm_f32(xp, C.c_int64(n), d, int(bool(normalize)),
+                                  xhat.ctypes.data_as(_f32p), sqn.ctypes.data_as(_f32p))
+    assert rc == 0
+    return xhat, sqn
+
+
+def topk_search(xhat, xsq, what, wsq, topk):
+    """topk smallest get_distance() entries per row
+    (vector_quantization_soft_one_new.py:120-125,157,203; k=1 is
+    norm_ema_quantizer.py:175-179)."""
+    xhat, xp = _f(xhat); xsq, xsp = _f(xsq); what, wp = _f(what); wsq, wsp = _f(wsq)
+    n, d = xhat.shape
+    k = what.shape[0]
+    idx = np.empty((n, topk), np.int64)
+    dist = np.empty((n, topk), np.float32)
+    rc = lib().oracle_topk_search_f32(xp, xsp, C.c_int64(n), wp, wsp, C.c_int64(k), d, topk,
+                                      idx.ctypes.data_as(_i64p), dist.ctypes.data_as(_f32p))
+    assert rc == 0, rc
+    return idx, dist
+
+
+def distance(xhat, xsq, what, wsq):
+    xhat, xp = _f(xhat); xsq, xsp = _f(xsq); what, wp = _f(what); wsq, wsp = _f(wsq)
+    n, d = xhat.shape
+    k = what.shape[0]
+    out = np.empty((n, k), np.float32)
+    rc = lib().oracle_distance_f32(xp, xsp, C.c_int64(n), wp, wsp, C.c_int64(k), d,
+                                   out.ctypes.data_as(_f32p))
+    assert rc == 0
+    return out
+
+
+def soft_assign(xref, what, idx, dist, hard=False):
+    """softmax(-d) weights, weighted code mix, STE value, row squared error
+    (vector_quantization_soft_one_new.py:158-182,204-214; hard=True is
+    norm_ema_quantizer.py:181,212-214)."""
+    xref, xp = _f(xref); what, wp = _f(what); idx, ip = _i(idx); dist, dp = _f(dist)
+    n, d = xref.shape
+    topk = 1 if idx.ndim == 1 else idx.shape[1]
+    w = np.empty((n, topk), np.float32)
+    zq = np.empty((n, d), np.float32)
+    se = np.empty(n, np.float32)
+    rc = lib().oracle_soft_assign_f32(xp, wp, ip, dp, C.c_int64(n), d, topk, int(bool(hard)),
+                                      w.ctypes.data_as(_f32p), zq.ctypes.data_as(_f32p),
+                                      se.ctypes.data_as(_f32p))
+    assert rc == 0
+    return w, zq, se
+
+
+def ema_stats(zhat, idx, k_codes):
+    """bins and embed_sum ([K,D]) of norm_ema_quantizer.py:194,202."""
+    zhat, zp = _f(zhat); idx, ip = _i(idx)
+    n, d = zhat.shape
+    bins = np.empty(k_codes, np.float32)
+    es = np.empty((k_codes, d), np.float32)
+    rc = lib().oracle_ema_stats_f32(zp, ip, C.c_int64(n), d, C.c_int64(k_codes),
+                                    bins.ctypes.data_as(_f32p), es.ctypes.data_as(_f32p))
+    assert rc == 0
+    return bins, es
+
+
+def ema_apply(E, cluster_size, bins, embed_sum, decay):
+    """In-place codebook / cluster_size update of norm_ema_quantizer.py:197-210."""
+    assert E.dtype == np.float32 and E.flags.c_contiguous
+    assert cluster_size.dtype == np.float32 and cluster_size.flags.c_contiguous
+    bins, bp = _f(bins); embed_sum, ep = _f(embed_sum)
+    k, d = E.shape
+    rc = lib().oracle_ema_apply_f32(E.ctypes.data_as(_f32p), cluster_size.ctypes.data_as(_f32p),
+                                    bp, ep, C.c_int64(k), d, C.c_float(decay),
+                                    C.c_float(1 - decay))
+    assert rc == 0
+
+
+def ema_cluster_size(cluster_size, bins, decay):
+    assert cluster_size.dtype == np.float32 and cluster_size.flags.c_contiguous
+    bins, bp = _f(bins)
+    rc = lib().oracle_ema_cluster_size_f32(cluster_size.ctypes.data_as(_f32p), bp,
+                                           C.c_int64(cluster_size.shape[0]), C.c_float(decay),
+                                           C.c_float(1 - decay))
+    assert rc == 0
+
+
+def usage_update(window, ids, n_codes):
+    """codebook_usage() window slide + distinct count
+    (vector_quantization_soft_one_new.py:219-236). Returns used/n_codes."""
+    assert window.dtype == np.float32 and window.flags.c_contiguous
+    ids, ip = _i(np.asarray(ids).reshape(-1))
+    cnt = lib().oracle_usage_update(window.ctypes.data_as(_f32p), C.c_int64(window.shape[0]),
+                                    ip, C.c_int64(ids.shape[0]), C.c_int64(n_codes))
+    assert cnt >= 0
+    return cnt / n_codes
+
+
+# ---- composite restatements of the reference's module-level functions ------
+
+def specific_search(x, W_region, topk, x_is_projected=True):
+    """VectorQuantizer.specific_embedding without the Linear and the losses
+    (vector_quantization_soft_one_new.py:194-205,214)."""
+    xhat, xsq = rownorm(x, True)
+    what, wsq = rownorm(W_region, True)
+    idx, dist = topk_search(xhat, xsq, what, wsq, topk)
+    w, zq, se = soft_assign(x, what, idx, dist)
+    return dict(idx=idx, dist=dist, w=w, zq=zq, xhat=xhat, row_sqerr=se)
+
+
+def norm_ema_forward(z, E, cluster_size, beta, decay, training):
+    """NormEMAVectorQuantizer.forward on z [N,D] (norm_ema_quantizer.py:166-218).
+    Mutates E / cluster_size like the reference does."""
+    zhat, zsq = rownorm(z, True)
+    _, esq = rownorm(E, False)
+    idx, dist = topk_search(zhat, zsq, E, esq, 1)
+    _, zq, se = soft_assign(zhat, E, idx[:, 0], dist, hard=True)
+    bins, es = ema_stats(zhat, idx[:, 0], E.shape[0])
+    if training:
+        ema_apply(E, cluster_size, bins, es, decay)
+    else:
+        ema_cluster_size(cluster_size, bins, decay)
+    loss = np.float32(beta) * np.float32(se.astype(np.float64).sum() / zhat.size)
+    return zq, loss, idx[:, 0]
