@@ -1,0 +1,130 @@
+/*
+ * medtok_vq.h -- C ABI of the MI355X (gfx950) MedTok vector-quantisation library.
+ *
+ * This is the drop-in boundary for the hot path BASELINE.json:north_star names.
+ * The reference has no FFI of its own: its boundary is a set of Python classes
+ * that call ATen ops.  Each entry point below replaces one group of those ATen
+ * call sites (cited as file:line under the reference tree); the Python classes in
+ * medtok_amd/ bind them with ctypes exactly as INTEGRATION.md shows.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to a contiguous row-major buffer owned by
+ *     the caller; float buffers are 16-byte aligned and D % 4 == 0;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all
+ *     work is enqueued on it and nothing synchronises the host;
+ *   - functions return 0 on success, non-zero on error; the message is available
+ *     from medtok_last_error() (thread-local).  No exceptions cross the ABI;
+ *   - no global state: scratch memory comes from the caller (`ws`), sized by the
+ *     *_workspace_bytes() queries.  Calls are re-entrant across streams as long
+ *     as they use different workspaces.
+ *
+ * Arithmetic contract (identical to oracle/medtok_oracle.c, which tests use as
+ * the checker): x.e is one fp32 fmaf chain over i = 0..D-1; |v|^2 is 64 strided
+ * fmaf chains joined by an xor butterfly; d = (|x|^2 + |e|^2) - 2*(x.e); ties go
+ * to the lowest code index.  Search results are therefore bit-reproducible and
+ * independent of tile shape, code sharding and which search path ran.
+ */
+#ifndef MEDTOK_VQ_H
+#define MEDTOK_VQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MEDTOK_VQ_ABI_VERSION 1
+#define MEDTOK_MAX_TOPK 8
+
+/* search path selector for medtok_topk_search_f32 */
+#define MEDTOK_PATH_AUTO 0          /* library picks the fastest exact path          */
+#define MEDTOK_PATH_F32_MFMA 1      /* brute force on v_mfma_f32_32x32x2_f32          */
+#define MEDTOK_PATH_BF16_FILTER 2   /* bf16-MFMA shortlist + exact fp32 re-score      */
+
+int medtok_abi_version(void);
+const char *medtok_last_error(void);
+
+/* F.normalize(x, p=2, dim=-1, eps=1e-12) and the squared norm of the result.
+ * Replaces vector_quantization_soft_one_new.py:148,150-151,196,198,200 and
+ * norm_ema_quantizer.py:8-9,170 plus the two torch.sum(..**2) terms of
+ * get_distance (:121-122; norm_ema_quantizer.py:175-176).
+ * normalize == 0: rows are taken as they are (xhat may be NULL or == x).
+ * xhat may alias x.  sqn may be NULL. */
+int medtok_rownorm_f32(const float *x, int64_t n, int d, int normalize,
+                       float *xhat, float *sqn, void *stream);
+
+/* Scratch bytes medtok_topk_search_f32 needs for this problem size. */
+size_t medtok_search_workspace_bytes(int64_t n, int64_t k_codes, int d, int topk, int path);
+
+/* Nearest-code search.  For every row the `topk` smallest
+ *   d = (xsq[r] + wsq[c]) - 2 * <xhat[r], what[c]>
+ * ascending, ties to the lowest c.  Replaces get_distance + torch.topk
+ * (vector_quantization_soft_one_new.py:120-125,157,159,203) and
+ * the distance + torch.argmin of norm_ema_quantizer.py:175-179 (topk = 1).
+ * idx  [n, topk] int64 (indices local to `what`), dist [n, topk] fp32.
+ * The N x K distance matrix is never materialised. */
+int medtok_topk_search_f32(const float *xhat, const float *xsq, int64_t n,
+                           const float *what, const float *wsq, int64_t k_codes,
+                           int d, int topk, int64_t *idx, float *dist,
+                           void *ws, size_t ws_bytes, int path, void *stream);
+
+/* Soft assignment: w = softmax(-dist), zq = sum_j w_j * what[idx_j],
+ * zq_ste = xref + (zq - xref), row_sqerr[r] = sum_i (zq - xref)^2.
+ * Replaces vector_quantization_soft_one_new.py:158,160,164-165,169-173,181-182,
+ * 204-205,208-209,214.  hard != 0 is the NormEMA form (topk == 1, zq = what[idx];
+ * norm_ema_quantizer.py:181,212,214).  w and row_sqerr may be NULL.
+ * zq_ste may alias xref. */
+int medtok_soft_assign_f32(const float *xref, const float *what, const int64_t *idx,
+                           const float *dist, int64_t n, int d, int topk, int hard,
+                           float *w, float *zq_ste, float *row_sqerr, void *stream);
+
+/* out[0] = scale * sum(vals[0..n)), accumulated in fp64 in a fixed order
+ * (the mean of the squared error: :169-173,208-209; F.mse_loss at
+ * norm_ema_quantizer.py:212). */
+int medtok_sum_scale_f32(const float *vals, int64_t n, double scale, float *out, void *stream);
+
+/* EMA statistics of norm_ema_quantizer.py:183,194,202 without the one-hot:
+ * bins[c] = #rows with idx == c (exact), embed_sum[c][:] = sum of those rows of
+ * zhat added in increasing row order (deterministic).  embed_sum is [K, D]
+ * (the transpose of the reference's [D, K]; all-reduce is layout-agnostic). */
+size_t medtok_ema_stats_workspace_bytes(int64_t n, int64_t k_codes);
+int medtok_ema_stats_f32(const float *zhat, const int64_t *idx, int64_t n, int d,
+                         int64_t k_codes, float *bins, float *embed_sum,
+                         void *ws, size_t ws_bytes, void *stream);
+
+/* EMA apply of norm_ema_quantizer.py:197-210 (+ :11-12,136-138), in place:
+ * cluster_size <- decay*cs + (1-decay)*bins; rows with bins == 0 keep their
+ * code; E <- l2norm(decay*E + (1-decay)*l2norm(embed_sum/bins)). */
+int medtok_ema_apply_f32(float *E, float *cluster_size, const float *bins,
+                         const float *embed_sum, int64_t k_codes, int d,
+                         float decay, float one_minus_decay, void *stream);
+
+/* Eval-mode branch (norm_ema_quantizer.py:185-189): cluster_size only. */
+int medtok_ema_cluster_size_f32(float *cluster_size, const float *bins, int64_t k_codes,
+                                float decay, float one_minus_decay, void *stream);
+
+/* codebook_usage (vector_quantization_soft_one_new.py:219-236): slide the fp32
+ * window left by m, append ids, count distinct values into *count_out (device
+ * int32).  The caller divides by n_e. */
+size_t medtok_usage_workspace_bytes(int64_t window_len, int64_t n_codes);
+int medtok_usage_update(float *window, int64_t window_len, const int64_t *ids, int64_t m,
+                        int64_t n_codes, int32_t *count_out, void *ws, size_t ws_bytes,
+                        void *stream);
+
+/* One-call forward of VectorQuantizer.specific_embedding / the search half of
+ * get_shared_info (vector_quantization_soft_one_new.py:147-182,194-214) for
+ * rows x [n, d] against an already normalised codebook slice:
+ * rownorm(x) -> search -> soft assign.  Outputs as in the pieces above. */
+size_t medtok_soft_vq_workspace_bytes(int64_t n, int64_t k_codes, int d, int topk, int path);
+int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d,
+                               const float *what, const float *wsq, int64_t k_codes,
+                               int topk, int path,
+                               float *xhat, int64_t *idx, float *dist, float *w,
+                               float *zq_ste, float *row_sqerr,
+                               void *ws, size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEDTOK_VQ_H */

@@ -1,0 +1,73 @@
+"""ctypes binding of the gfx950 C-ABI library (include/medtok_vq.h).
+
+The library is the product; there is no CPU or eager-PyTorch fallback.  If the
+shared object is missing or an entry point fails, the caller gets an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_SO = Path(__file__).resolve().parent / "csrc" / "libmedtok_vq.so"
+_lib = None
+
+ABI_VERSION = 1
+MAX_TOPK = 8
+PATH_AUTO, PATH_F32_MFMA, PATH_BF16_FILTER = 0, 1, 2
+
+_vp, _i64, _int, _sz, _f, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float, C.c_double
+
+# name -> (restype, argtypes); mirrors include/medtok_vq.h one to one
+SIGNATURES = {
+    "medtok_abi_version": (_int, []),
+    "medtok_last_error": (C.c_char_p, []),
+    "medtok_rownorm_f32": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
+    "medtok_search_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int]),
+    "medtok_topk_search_f32": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _int, _vp]),
+    "medtok_soft_assign_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "medtok_sum_scale_f32": (_int, [_vp, _i64, _dbl, _vp, _vp]),
+    "medtok_ema_stats_workspace_bytes": (_sz, [_i64, _i64]),
+    "medtok_ema_stats_f32": (_int, [_vp, _vp, _i64, _int, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "medtok_ema_apply_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _f, _f, _vp]),
+    "medtok_ema_cluster_size_f32": (_int, [_vp, _vp, _i64, _f, _f, _vp]),
+    "medtok_usage_workspace_bytes": (_sz, [_i64, _i64]),
+    "medtok_usage_update": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "medtok_soft_vq_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int]),
+    "medtok_soft_vq_forward_f32": (_int, [_vp, _i64, _int, _vp, _vp, _i64, _int, _int,
+                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+
+class MedTokLibraryError(RuntimeError):
+    pass
+
+
+def library_path() -> Path:
+    return _SO
+
+
+def load():
+    """dlopen the HIP library and type its entry points. Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _SO.exists():
+        raise MedTokLibraryError(
+            f"{_SO} is missing: build it with `python medtok_amd/csrc/build.py` "
+            "(hipcc --offload-arch=gfx950). medtok_amd has no CPU fallback.")
+    lib = C.CDLL(str(_SO))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.medtok_abi_version()
+    if got != ABI_VERSION:
+        raise MedTokLibraryError(f"ABI version mismatch: library {got}, binding {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().medtok_last_error().decode(errors="replace")
+        raise MedTokLibraryError(f"{what} failed: {msg}")

@@ -1,0 +1,48 @@
+"""Compile the gfx950 C-ABI library in-tree (hipcc cross-compiles without a GPU).
+
+    python medtok_amd/csrc/build.py [--force]
+
+Output: medtok_amd/csrc/libmedtok_vq.so (git-ignored; travels to the GPU box
+with the gpurun snapshot).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+SRC = HERE / "medtok_vq.hip"
+OUT = HERE / "libmedtok_vq.so"
+HEADER = HERE.parents[1] / "include" / "medtok_vq.h"
+
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # every fused multiply-add in the kernels is written as fmaf(); nothing else may contract
+    "-ffp-contract=off",
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0 for gfx950)")
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    newest = max(SRC.stat().st_mtime, HEADER.stat().st_mtime, Path(__file__).stat().st_mtime)
+    if not force and OUT.exists() and OUT.stat().st_mtime >= newest:
+        return OUT
+    cmd = [hipcc(), *FLAGS, str(SRC), "-o", str(OUT)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,842 @@
+// medtok_vq.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI of the MedTok VQ hot path.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+// (see medtok_amd/csrc/build.py).  Wave size is 64 everywhere; no other target.
+//
+// Kernels (reference call sites in include/medtok_vq.h):
+//   rownorm_kernel        l2-normalise rows + |row|^2            HBM-bound
+//   search_f32_kernel     N x K nearest-code search, top-k       MFMA-bound (fp32 matrix pipe)
+//   merge_topk_kernel     joins per-code-split partial lists     tiny
+//   soft_assign_kernel    softmax(-d), code mix, STE, sq. error  HBM-bound
+//   sum_scale_kernel      fixed-order fp64 reduction             tiny
+//   ema_*                 histogram, stable radix sort by code, segmented row sum, apply
+//   usage_*               sliding id window + distinct count
+//
+// Arithmetic order is the one oracle/medtok_oracle.c documents; tests compare bit for bit.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/medtok_vq.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------- error plumbing
+static thread_local char g_err[512] = "";
+
+static int fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+static int fail(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+static int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int medtok_abi_version(void) { return MEDTOK_VQ_ABI_VERSION; }
+extern "C" const char *medtok_last_error(void) { return g_err; }
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline long lmin(long a, long b) { return a < b ? a : b; }
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float wave_butterfly_sum(float p)
+{
+    // xor butterfly, offsets 32..1: every lane ends with the same bits (a+b == b+a).
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    return p;
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// ================================================================= rownorm
+// One wavefront per row.  Lane l owns float4 #(l + 64 t): element i lands in chain
+// (i/4)%64 and each chain accumulates in increasing i -- the oracle's canon_sumsq.
+template <bool NORMALIZE>
+__global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ x, long n, int d,
+                                                      float *xhat, float *__restrict__ sqn)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *src = x + row * d;
+    float *dst = xhat ? xhat + row * d : nullptr;
+    float p = 0.f;
+    if (NORMALIZE) {
+        for (int i = lane * 4; i < d; i += 256) {
+            float4 v = ld4(src + i);
+            p = fmaf(v.x, v.x, p); p = fmaf(v.y, v.y, p); p = fmaf(v.z, v.z, p); p = fmaf(v.w, v.w, p);
+        }
+        const float nrm = sqrtf(wave_butterfly_sum(p));
+        const float den = fmaxf(nrm, 1e-12f);
+        p = 0.f;
+        for (int i = lane * 4; i < d; i += 256) {
+            float4 v = ld4(src + i);
+            v.x = v.x / den; v.y = v.y / den; v.z = v.z / den; v.w = v.w / den;
+            st4(dst + i, v);
+            p = fmaf(v.x, v.x, p); p = fmaf(v.y, v.y, p); p = fmaf(v.z, v.z, p); p = fmaf(v.w, v.w, p);
+        }
+    } else {
+        for (int i = lane * 4; i < d; i += 256) {
+            float4 v = ld4(src + i);
+            if (dst && dst != src) st4(dst + i, v);
+            p = fmaf(v.x, v.x, p); p = fmaf(v.y, v.y, p); p = fmaf(v.z, v.z, p); p = fmaf(v.w, v.w, p);
+        }
+    }
+    p = wave_butterfly_sum(p);
+    if (sqn && lane == 0) sqn[row] = p;
+}
+
+extern "C" int medtok_rownorm_f32(const float *x, int64_t n, int d, int normalize, float *xhat,
+                                  float *sqn, void *stream)
+{
+    if (n < 0 || d <= 0 || (d & 3)) return fail("rownorm: need n >= 0, d > 0, d %% 4 == 0 (n=%ld d=%d)", (long)n, d);
+    if (normalize && !xhat) return fail("rownorm: xhat required when normalize != 0");
+    if (n == 0) return 0;
+    dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (normalize) hipLaunchKernelGGL(rownorm_kernel<true>, grid, block, 0, s, x, (long)n, d, xhat, sqn);
+    else hipLaunchKernelGGL(rownorm_kernel<false>, grid, block, 0, s, x, (long)n, d, xhat, sqn);
+    return check_launch("rownorm");
+}
+
+// ================================================================= top-k list helpers
+// Sorted ascending by (value, index).  A lane meets its codes in increasing index order,
+// so a strict '<' on the value alone implements "ties -> lowest index" during the scan.
+template <int T>
+__device__ __forceinline__ void topk_insert(float (&bv)[T], int (&bi)[T], float v, int c)
+{
+    if (v < bv[T - 1]) {
+#pragma unroll
+        for (int j = T - 1; j >= 1; --j) {
+            const bool lt_prev = v < bv[j - 1];
+            const bool lt = v < bv[j];
+            bv[j] = lt_prev ? bv[j - 1] : (lt ? v : bv[j]);
+            bi[j] = lt_prev ? bi[j - 1] : (lt ? c : bi[j]);
+        }
+        const bool lt0 = v < bv[0];
+        bv[0] = lt0 ? v : bv[0];
+        bi[0] = lt0 ? c : bi[0];
+    }
+}
+
+__device__ __forceinline__ bool lex_lt(float v, int c, float bv, int bc)
+{
+    return v < bv || (v == bv && c < bc);
+}
+
+// Same, but for merging lists whose codes are not met in order: compare (value, index).
+template <int T>
+__device__ __forceinline__ void topk_insert_lex(float (&bv)[T], int (&bi)[T], float v, int c)
+{
+    if (lex_lt(v, c, bv[T - 1], bi[T - 1])) {
+#pragma unroll
+        for (int j = T - 1; j >= 1; --j) {
+            const bool lt_prev = lex_lt(v, c, bv[j - 1], bi[j - 1]);
+            const bool lt = lex_lt(v, c, bv[j], bi[j]);
+            const float nv = lt_prev ? bv[j - 1] : (lt ? v : bv[j]);
+            const int ni = lt_prev ? bi[j - 1] : (lt ? c : bi[j]);
+            bv[j] = nv; bi[j] = ni;
+        }
+        const bool lt0 = lex_lt(v, c, bv[0], bi[0]);
+        bv[0] = lt0 ? v : bv[0];
+        bi[0] = lt0 ? c : bi[0];
+    }
+}
+
+// ================================================================= fp32 MFMA search
+// Block = 4 waves, tile = 128 codes x 128 rows, BK = 32.  Codes are the MFMA "A" rows and
+// input rows the "B" columns, so after v_mfma_f32_32x32x2_f32 every lane holds 16 codes of
+// ONE input row: the running top-k is lane-local (no cross-lane traffic until the end).
+// Wave w owns input rows [32w, 32w+32) against all 128 codes (4 accumulator tiles).
+//
+// LDS holds each 8-wide k-group as [k0 k2 k4 k6 | k1 k3 k5 k7]: lane (i, h) reads one float4
+// at +4h and register c then carries k = 8g + 2c + h, which is exactly the operand pair MFMA #c
+// needs (half 0 -> k, half 1 -> k+1), so the accumulation visits k = 0,1,2,... in order and
+// equals the oracle's fmaf chain bit for bit.  Rows are padded to 36 floats: conflict-free
+// ds_read_b128 (16 lanes x stride 36 dwords hit 16 distinct 4-bank slots) and ds_write_b128.
+constexpr int S_BM = 128, S_BN = 128, S_BK = 32, S_LD = 36;
+constexpr int S_TILE = S_BM * S_LD;                       // floats per staged operand tile
+constexpr size_t S_LDS_BYTES = (size_t)4 * S_TILE * sizeof(float);   // A[2] + B[2]
+
+template <int TOPK, bool FINAL>
+__global__ __launch_bounds__(256, 2) void search_f32_kernel(
+    const float *__restrict__ xhat, const float *__restrict__ xsq, const float *__restrict__ what,
+    const float *__restrict__ wsq, long n, int k_codes, int d, int codes_per_split, int topk_out,
+    float *__restrict__ pval, int *__restrict__ pidx, int64_t *__restrict__ out_idx,
+    float *__restrict__ out_dist)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const long row0 = (long)blockIdx.x * S_BN;
+    const int split = blockIdx.y;
+    const int code_lo = split * codes_per_split;
+    const int code_hi = min(k_codes, code_lo + codes_per_split);
+    const int nct = (code_hi - code_lo + S_BM - 1) / S_BM;
+    const int nkb = (d + S_BK - 1) / S_BK;
+    const int nstage = nct * nkb;
+
+    const int srow = tid >> 2, sg = tid & 3;
+    float4 ra[2][2], rb[2][2];
+
+    auto gload = [&](int s) {
+        const int ct = s / nkb, kb = s - ct * nkb;
+        const int kofs = kb * S_BK + sg * 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int crow = min(code_lo + ct * S_BM + srow + 64 * j, k_codes - 1);
+            const float *p = what + (long)crow * d + kofs;
+            const long xr = min(row0 + srow + 64 * j, n - 1);
+            const float *q = xhat + xr * d + kofs;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[j][0] = (kofs < d) ? ld4(p) : z;
+            ra[j][1] = (kofs + 4 < d) ? ld4(p + 4) : z;
+            rb[j][0] = (kofs < d) ? ld4(q) : z;
+            rb[j][1] = (kofs + 4 < d) ? ld4(q + 4) : z;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float *A = smem + buf * S_TILE;
+        float *B = smem + 2 * S_TILE + buf * S_TILE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float *pa = A + (srow + 64 * j) * S_LD + sg * 8;
+            st4(pa, make_float4(ra[j][0].x, ra[j][0].z, ra[j][1].x, ra[j][1].z));
+            st4(pa + 4, make_float4(ra[j][0].y, ra[j][0].w, ra[j][1].y, ra[j][1].w));
+            float *pb = B + (srow + 64 * j) * S_LD + sg * 8;
+            st4(pb, make_float4(rb[j][0].x, rb[j][0].z, rb[j][1].x, rb[j][1].z));
+            st4(pb + 4, make_float4(rb[j][0].y, rb[j][0].w, rb[j][1].y, rb[j][1].w));
+        }
+    };
+
+    float bv[TOPK];
+    int bi[TOPK];
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j) { bv[j] = INFINITY; bi[j] = 0; }
+
+    const long myrow = row0 + wave * 32 + li;
+    const float xn = xsq[min(myrow, n - 1)];
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    gload(0);
+    int ct = 0, kb = 0;
+    for (int s = 0; s < nstage; ++s) {
+        const int buf = s & 1;
+        lstore(buf);
+        __syncthreads();
+        if (s + 1 < nstage) gload(s + 1);
+        const float *A = smem + buf * S_TILE + li * S_LD + lh * 4;
+        const float *B = smem + 2 * S_TILE + buf * S_TILE + (wave * 32 + li) * S_LD + lh * 4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float4 bf = ld4(B + kk * 8);
+            float4 af[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m] = ld4(A + m * 32 * S_LD + kk * 8);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf.x, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf.y, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf.z, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf.w, acc[m], 0, 0, 0);
+        }
+        if (++kb == nkb) {
+            // ---- epilogue: d = (|x|^2 + |e|^2) - 2 x.e for this lane's 64 codes, fold into the list
+            const int cbase = code_lo + ct * S_BM;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float en = wsq[min(code, k_codes - 1)];
+                    const float sum = xn + en;
+                    const float two = 2.0f * acc[m][r];
+                    float dv = sum - two;
+                    if (code >= code_hi) dv = INFINITY;
+                    topk_insert<TOPK>(bv, bi, dv, code);
+                    acc[m][r] = 0.f;
+                }
+            }
+            kb = 0;
+            ++ct;
+        }
+    }
+
+    // ---- join the two half-waves that share an input row (disjoint code sets)
+    float pv[TOPK];
+    int pi[TOPK];
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j) { pv[j] = __shfl_xor(bv[j], 32, 64); pi[j] = __shfl_xor(bi[j], 32, 64); }
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j) topk_insert_lex<TOPK>(bv, bi, pv[j], pi[j]);
+
+    if (lh == 0 && myrow < n) {
+        if (FINAL) {
+#pragma unroll
+            for (int j = 0; j < TOPK; ++j)
+                if (j < topk_out) { out_idx[myrow * topk_out + j] = bi[j]; out_dist[myrow * topk_out + j] = bv[j]; }
+        } else {
+            const long base = ((long)split * n + myrow) * TOPK;
+#pragma unroll
+            for (int j = 0; j < TOPK; ++j) { pval[base + j] = bv[j]; pidx[base + j] = bi[j]; }
+        }
+    }
+}
+
+// Joins the per-split candidate lists of one row (thread per row).
+template <int TOPK>
+__global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict__ pval, const int *__restrict__ pidx,
+                                                         long n, int splits, int topk_out,
+                                                         int64_t *__restrict__ out_idx, float *__restrict__ out_dist)
+{
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    float bv[TOPK];
+    int bi[TOPK];
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j) { bv[j] = INFINITY; bi[j] = 0x7fffffff; }
+    for (int s = 0; s < splits; ++s) {
+        const long base = ((long)s * n + row) * TOPK;
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) topk_insert_lex<TOPK>(bv, bi, pval[base + j], pidx[base + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j)
+        if (j < topk_out) { out_idx[row * topk_out + j] = bi[j]; out_dist[row * topk_out + j] = bv[j]; }
+}
+
+struct SearchPlan {
+    int tslots;          // list length the kernels are instantiated with (1, 5 or 8)
+    int splits;          // code-range splits (grid.y)
+    int codes_per_split; // multiple of 128
+    long row_tiles;
+};
+
+static SearchPlan plan_search(int64_t n, int64_t k_codes, int topk)
+{
+    SearchPlan p;
+    p.tslots = topk == 1 ? 1 : (topk <= 5 ? 5 : 8);
+    p.row_tiles = (n + S_BN - 1) / S_BN;
+    const long code_tiles = (k_codes + S_BM - 1) / S_BM;
+    // Fill ~2 blocks per CU on 256 CUs when the row count alone cannot.
+    long want = (512 + p.row_tiles - 1) / p.row_tiles;
+    if (want < 1) want = 1;
+    if (want > code_tiles) want = code_tiles;
+    if (want > 64) want = 64;
+    const long tiles_per_split = (code_tiles + want - 1) / want;
+    p.codes_per_split = (int)(tiles_per_split * S_BM);
+    p.splits = (int)((code_tiles + tiles_per_split - 1) / tiles_per_split);
+    return p;
+}
+
+extern "C" size_t medtok_search_workspace_bytes(int64_t n, int64_t k_codes, int d, int topk, int path)
+{
+    (void)d; (void)path;
+    if (n <= 0 || k_codes <= 0 || topk < 1 || topk > MEDTOK_MAX_TOPK) return 0;
+    SearchPlan p = plan_search(n, k_codes, topk);
+    if (p.splits == 1) return 256;
+    return align_up((size_t)p.splits * n * p.tslots * sizeof(float), 256) +
+           align_up((size_t)p.splits * n * p.tslots * sizeof(int), 256);
+}
+
+template <int T>
+static int launch_search(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
+                         int64_t k_codes, int d, int topk, int64_t *idx, float *dist, void *ws, size_t ws_bytes,
+                         const SearchPlan &p, hipStream_t s)
+{
+    dim3 grid((unsigned)p.row_tiles, (unsigned)p.splits), block(256);
+    if (p.splits == 1) {
+        (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
+        hipLaunchKernelGGL((search_f32_kernel<T, true>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
+                           (int)k_codes, d, p.codes_per_split, topk, (float *)nullptr, (int *)nullptr, idx, dist);
+        return check_launch("search_f32");
+    }
+    const size_t vbytes = align_up((size_t)p.splits * n * T * sizeof(float), 256);
+    const size_t ibytes = align_up((size_t)p.splits * n * T * sizeof(int), 256);
+    if (!ws || ws_bytes < vbytes + ibytes) return fail("search: workspace too small (%zu < %zu)", ws_bytes, vbytes + ibytes);
+    float *pval = (float *)ws;
+    int *pidx = (int *)((char *)ws + vbytes);
+    (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
+    hipLaunchKernelGGL((search_f32_kernel<T, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
+                       (int)k_codes, d, p.codes_per_split, topk, pval, pidx, (int64_t *)nullptr, (float *)nullptr);
+    if (check_launch("search_f32(split)")) return 1;
+    hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pval, pidx, (long)n,
+                       p.splits, topk, idx, dist);
+    return check_launch("merge_topk");
+}
+
+extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64_t n, const float *what,
+                                      const float *wsq, int64_t k_codes, int d, int topk, int64_t *idx, float *dist,
+                                      void *ws, size_t ws_bytes, int path, void *stream)
+{
+    if (n < 0 || k_codes <= 0 || d <= 0 || (d & 3)) return fail("search: bad shape n=%ld K=%ld d=%d (d %% 4 == 0)", (long)n, (long)k_codes, d);
+    if (topk < 1 || topk > MEDTOK_MAX_TOPK || topk > k_codes) return fail("search: topk=%d unsupported (1..%d, <= K)", topk, MEDTOK_MAX_TOPK);
+    if (k_codes >= (1ll << 31)) return fail("search: K too large");
+    if (path != MEDTOK_PATH_AUTO && path != MEDTOK_PATH_F32_MFMA) return fail("search: path %d not available in this build", path);
+    if (n == 0) return 0;
+    const SearchPlan p = plan_search(n, k_codes, topk);
+    hipStream_t s = (hipStream_t)stream;
+    switch (p.tslots) {
+    case 1: return launch_search<1>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
+    case 5: return launch_search<5>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
+    default: return launch_search<8>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
+    }
+}
+
+// ================================================================= soft assign
+// One wavefront per row; lanes stride the D axis in float4.
+template <int MAXK>
+__global__ __launch_bounds__(256) void soft_assign_kernel(const float *__restrict__ xref, const float *__restrict__ what,
+                                                          const int64_t *__restrict__ idx, const float *__restrict__ dist,
+                                                          long n, int d, int topk, int hard, float *__restrict__ w_out,
+                                                          float *zq_ste, float *__restrict__ row_sqerr)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float wj[MAXK];
+    long cj[MAXK];
+    if (hard) {
+        wj[0] = 1.f;
+        cj[0] = idx[row];
+    } else {
+        const float m = -dist[row * topk];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j)
+            if (j < topk) { wj[j] = expf(-dist[row * topk + j] - m); sum += wj[j]; cj[j] = idx[row * topk + j]; }
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j)
+            if (j < topk) wj[j] = wj[j] / sum;
+    }
+    if (w_out && lane < topk) {
+        float v = wj[0];
+#pragma unroll
+        for (int j = 1; j < MAXK; ++j) v = (lane == j) ? wj[j] : v;
+        w_out[row * topk + lane] = v;
+    }
+    const float *xr = xref + row * d;
+    float *out = zq_ste + row * d;
+    float se = 0.f;
+    for (int i = lane * 4; i < d; i += 256) {
+        float4 a;
+        if (hard) {
+            a = ld4(what + cj[0] * d + i);
+        } else {
+            a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < MAXK; ++j)
+                if (j < topk) {
+                    const float4 e = ld4(what + cj[j] * d + i);
+                    a.x = fmaf(wj[j], e.x, a.x); a.y = fmaf(wj[j], e.y, a.y);
+                    a.z = fmaf(wj[j], e.z, a.z); a.w = fmaf(wj[j], e.w, a.w);
+                }
+        }
+        const float4 x = ld4(xr + i);
+        float4 df;
+        df.x = a.x - x.x; df.y = a.y - x.y; df.z = a.z - x.z; df.w = a.w - x.w;
+        st4(out + i, make_float4(x.x + df.x, x.y + df.y, x.z + df.z, x.w + df.w));
+        se = fmaf(df.x, df.x, se); se = fmaf(df.y, df.y, se); se = fmaf(df.z, df.z, se); se = fmaf(df.w, df.w, se);
+    }
+    se = wave_butterfly_sum(se);
+    if (row_sqerr && lane == 0) row_sqerr[row] = se;
+}
+
+extern "C" int medtok_soft_assign_f32(const float *xref, const float *what, const int64_t *idx, const float *dist,
+                                      int64_t n, int d, int topk, int hard, float *w, float *zq_ste, float *row_sqerr,
+                                      void *stream)
+{
+    if (n < 0 || d <= 0 || (d & 3)) return fail("soft_assign: bad shape n=%ld d=%d", (long)n, d);
+    if (topk < 1 || topk > MEDTOK_MAX_TOPK) return fail("soft_assign: topk=%d unsupported", topk);
+    if (hard && topk != 1) return fail("soft_assign: hard assignment needs topk == 1");
+    if (!hard && !dist) return fail("soft_assign: dist required");
+    if (!zq_ste) return fail("soft_assign: zq_ste required");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL((soft_assign_kernel<MEDTOK_MAX_TOPK>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       xref, what, idx, dist, (long)n, d, topk, hard, w, zq_ste, row_sqerr);
+    return check_launch("soft_assign");
+}
+
+// ================================================================= fixed-order fp64 sum
+__global__ __launch_bounds__(1024) void sum_scale_kernel(const float *__restrict__ v, long n, double scale, float *out)
+{
+    __shared__ double sh[1024];
+    double a = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) a += (double)v[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(sh[0] * scale);
+}
+
+extern "C" int medtok_sum_scale_f32(const float *vals, int64_t n, double scale, float *out, void *stream)
+{
+    if (n < 0 || !out) return fail("sum_scale: bad args");
+    hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, vals, (long)n, scale, out);
+    return check_launch("sum_scale");
+}
+
+// ================================================================= EMA statistics
+// bins: integer histogram.  embed_sum: rows are ordered by (code, row) with a stable LSD radix
+// sort (8-bit digits), then one wavefront per code adds its rows in increasing row order.
+constexpr int SORT_BLOCKS = 256;       // x 4 waves = 1024 sorting waves
+constexpr int SORT_WAVES = SORT_BLOCKS * 4;
+
+// ids outside [0, K) are clamped (same clamp in the sort) so the layout stays consistent
+__device__ __forceinline__ uint32_t clamp_code(int64_t c, int k_codes)
+{
+    return (uint32_t)(c < 0 ? 0 : (c >= k_codes ? k_codes - 1 : c));
+}
+
+__global__ __launch_bounds__(256) void hist_kernel(const int64_t *__restrict__ idx, long n, int k_codes, int *__restrict__ counts)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        atomicAdd(&counts[clamp_code(idx[i], k_codes)], 1);
+}
+
+// exclusive scan of counts[0..k) -> offsets[0..k] (single block, fixed order)
+__global__ __launch_bounds__(1024) void scan_kernel(const int *__restrict__ counts, int k, int *__restrict__ offsets)
+{
+    __shared__ int part[1024];
+    const int per = (k + 1023) / 1024;
+    const int lo = min(k, (int)threadIdx.x * per), hi = min(k, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = ((int)threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - s;
+    for (int i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
+    if (threadIdx.x == 1023) offsets[k] = part[1023];
+}
+
+__device__ __forceinline__ void wave_chunk(long n, int gw, long &lo, long &hi)
+{
+    const long per = ((n + SORT_WAVES - 1) / SORT_WAVES + 63) / 64 * 64;
+    lo = min(n, (long)gw * per);
+    hi = min(n, lo + per);
+}
+
+// pass 0 reads keys from idx (payload = position); later passes read (key,payload) pairs
+template <bool FIRST>
+__global__ __launch_bounds__(256) void radix_count_kernel(const int64_t *__restrict__ idx, const uint32_t *__restrict__ keys_in,
+                                                          long n, int k_codes, int shift, int *__restrict__ wave_counts)
+{
+    __shared__ int cnt[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, gw = blockIdx.x * 4 + w;
+    for (int i = lane; i < 256; i += 64) cnt[w][i] = 0;
+    __syncthreads();
+    long lo, hi;
+    wave_chunk(n, gw, lo, hi);
+    for (long i = lo + lane; i < hi; i += 64) {
+        const uint32_t key = FIRST ? clamp_code(idx[i], k_codes) : keys_in[i];
+        atomicAdd(&cnt[w][(key >> shift) & 255], 1);
+    }
+    __syncthreads();
+    // digit-major so the scan below yields stable destinations
+    for (int i = lane; i < 256; i += 64) wave_counts[(long)i * SORT_WAVES + gw] = cnt[w][i];
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const int64_t *__restrict__ idx, const uint32_t *__restrict__ keys_in,
+                                                            const uint32_t *__restrict__ vals_in, long n, int k_codes, int shift,
+                                                            const int *__restrict__ wave_offsets, uint32_t *__restrict__ keys_out,
+                                                            uint32_t *__restrict__ vals_out)
+{
+    __shared__ int base[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, gw = blockIdx.x * 4 + w;
+    for (int i = lane; i < 256; i += 64) base[w][i] = wave_offsets[(long)i * SORT_WAVES + gw];
+    __syncthreads();
+    long lo, hi;
+    wave_chunk(n, gw, lo, hi);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (long i0 = lo; i0 < hi; i0 += 64) {
+        const long i = i0 + lane;
+        const bool live = i < hi;
+        uint32_t key = 0, val = 0;
+        if (live) { key = FIRST ? clamp_code(idx[i], k_codes) : keys_in[i]; val = FIRST ? (uint32_t)i : vals_in[i]; }
+        const uint32_t dg = (key >> shift) & 255;
+        unsigned long long eq = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bal = __ballot((dg >> b) & 1);
+            eq &= ((dg >> b) & 1) ? bal : ~bal;
+        }
+        const int rank = __popcll(eq & lt_mask);
+        const int total = __popcll(eq);
+        int dst = 0;
+        if (live) dst = base[w][dg] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (live && rank == total - 1) base[w][dg] += total;   // one lane per digit group
+        __builtin_amdgcn_wave_barrier();
+        if (live) { keys_out[dst] = key; vals_out[dst] = val; }
+    }
+}
+
+// One wavefront per code: add that code's rows in increasing row order.
+__global__ __launch_bounds__(256) void segsum_kernel(const float *__restrict__ zhat, const uint32_t *__restrict__ sorted_rows,
+                                                     const int *__restrict__ offsets, int k_codes, int d,
+                                                     float *__restrict__ bins, float *__restrict__ embed_sum)
+{
+    const int lane = threadIdx.x & 63;
+    for (long code = (long)blockIdx.x * 4 + (threadIdx.x >> 6); code < k_codes; code += (long)gridDim.x * 4) {
+        const int lo = offsets[code], hi = offsets[code + 1];
+        if (lane == 0) bins[code] = (float)(hi - lo);
+        for (int i = lane * 4; i < d; i += 256) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            int r = lo;
+            for (; r + 4 <= hi; r += 4) {      // 4 loads in flight, adds stay in row order
+                const float4 v0 = ld4(zhat + (long)sorted_rows[r] * d + i);
+                const float4 v1 = ld4(zhat + (long)sorted_rows[r + 1] * d + i);
+                const float4 v2 = ld4(zhat + (long)sorted_rows[r + 2] * d + i);
+                const float4 v3 = ld4(zhat + (long)sorted_rows[r + 3] * d + i);
+                a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+                a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+                a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+                a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+            }
+            for (; r < hi; ++r) {
+                const float4 v = ld4(zhat + (long)sorted_rows[r] * d + i);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            st4(embed_sum + code * d + i, a);
+        }
+    }
+}
+
+struct EmaWs {
+    int *counts, *offsets, *wave_counts, *wave_offsets;
+    uint32_t *keys[2], *vals[2];
+    size_t total;
+};
+
+static EmaWs ema_ws_layout(void *ws, int64_t n, int64_t k_codes)
+{
+    EmaWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *p = ws ? (char *)ws + off : nullptr; off += align_up(bytes, 256); return (void *)p; };
+    w.counts = (int *)take((size_t)k_codes * 4);
+    w.offsets = (int *)take((size_t)(k_codes + 1) * 4);
+    w.wave_counts = (int *)take((size_t)256 * SORT_WAVES * 4);
+    w.wave_offsets = (int *)take(((size_t)256 * SORT_WAVES + 1) * 4);
+    for (int i = 0; i < 2; ++i) { w.keys[i] = (uint32_t *)take((size_t)n * 4); w.vals[i] = (uint32_t *)take((size_t)n * 4); }
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t medtok_ema_stats_workspace_bytes(int64_t n, int64_t k_codes)
+{
+    if (n < 0 || k_codes <= 0) return 0;
+    return ema_ws_layout(nullptr, n, k_codes).total;
+}
+
+extern "C" int medtok_ema_stats_f32(const float *zhat, const int64_t *idx, int64_t n, int d, int64_t k_codes, float *bins,
+                                    float *embed_sum, void *ws, size_t ws_bytes, void *stream)
+{
+    if (n < 0 || d <= 0 || (d & 3) || k_codes <= 0 || k_codes >= (1ll << 31) || n >= (1ll << 31))
+        return fail("ema_stats: bad shape n=%ld d=%d K=%ld", (long)n, d, (long)k_codes);
+    EmaWs w = ema_ws_layout(ws, n, k_codes);
+    if (!ws || ws_bytes < w.total) return fail("ema_stats: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(w.counts, 0, (size_t)k_codes * 4, s) != hipSuccess) return fail("ema_stats: memset failed");
+    if (n > 0) {
+        hipLaunchKernelGGL(hist_kernel, dim3((unsigned)lmin(2048, (n + 255) / 256)), dim3(256), 0, s, idx, (long)n, (int)k_codes, w.counts);
+    }
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, w.counts, (int)k_codes, w.offsets);
+    int cur = 0;
+    bool first = true;
+    for (int shift = 0; n > 0 && (first || (k_codes - 1) >> shift); shift += 8) {
+        if (first) hipLaunchKernelGGL((radix_count_kernel<true>), dim3(SORT_BLOCKS), dim3(256), 0, s, idx, (const uint32_t *)nullptr, (long)n, (int)k_codes, shift, w.wave_counts);
+        else hipLaunchKernelGGL((radix_count_kernel<false>), dim3(SORT_BLOCKS), dim3(256), 0, s, idx, w.keys[cur], (long)n, (int)k_codes, shift, w.wave_counts);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, w.wave_counts, 256 * SORT_WAVES, w.wave_offsets);
+        if (first) hipLaunchKernelGGL((radix_scatter_kernel<true>), dim3(SORT_BLOCKS), dim3(256), 0, s, idx, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (long)n, (int)k_codes, shift, w.wave_offsets, w.keys[cur ^ 1], w.vals[cur ^ 1]);
+        else hipLaunchKernelGGL((radix_scatter_kernel<false>), dim3(SORT_BLOCKS), dim3(256), 0, s, idx, w.keys[cur], w.vals[cur], (long)n, (int)k_codes, shift, w.wave_offsets, w.keys[cur ^ 1], w.vals[cur ^ 1]);
+        cur ^= 1;
+        first = false;
+    }
+    hipLaunchKernelGGL(segsum_kernel, dim3((unsigned)lmin(4096, (k_codes + 3) / 4)), dim3(256), 0, s, zhat, w.vals[cur], w.offsets, (int)k_codes, d, bins, embed_sum);
+    return check_launch("ema_stats");
+}
+
+// ================================================================= EMA apply
+__global__ __launch_bounds__(256) void ema_apply_kernel(float *E, float *cluster_size, const float *__restrict__ bins,
+                                                        const float *__restrict__ embed_sum, int k_codes, int d, float decay, float omd)
+{
+    const int lane = threadIdx.x & 63;
+    const long code = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (code >= k_codes) return;
+    const float b = bins[code];
+    if (lane == 0) {
+        const float a0 = cluster_size[code] * decay;
+        const float a1 = b * omd;
+        cluster_size[code] = a0 + a1;
+    }
+    float *e = E + code * d;
+    const float *sm = embed_sum + code * d;
+    const bool keep = (b == 0.0f);
+    float den1 = 1.f;
+    if (!keep) {
+        float p = 0.f;
+        for (int i = lane * 4; i < d; i += 256) {
+            float4 v = ld4(sm + i);
+            v.x = v.x / b; v.y = v.y / b; v.z = v.z / b; v.w = v.w / b;
+            p = fmaf(v.x, v.x, p); p = fmaf(v.y, v.y, p); p = fmaf(v.z, v.z, p); p = fmaf(v.w, v.w, p);
+        }
+        den1 = fmaxf(sqrtf(wave_butterfly_sum(p)), 1e-12f);
+    }
+    auto mixed = [&](int i) {
+        float4 nw;
+        const float4 ev = ld4(e + i);
+        if (keep) nw = ev;
+        else {
+            nw = ld4(sm + i);
+            nw.x = (nw.x / b) / den1; nw.y = (nw.y / b) / den1; nw.z = (nw.z / b) / den1; nw.w = (nw.w / b) / den1;
+        }
+        float4 m;
+        float t0, t1;
+        t0 = ev.x * decay; t1 = nw.x * omd; m.x = t0 + t1;
+        t0 = ev.y * decay; t1 = nw.y * omd; m.y = t0 + t1;
+        t0 = ev.z * decay; t1 = nw.z * omd; m.z = t0 + t1;
+        t0 = ev.w * decay; t1 = nw.w * omd; m.w = t0 + t1;
+        return m;
+    };
+    float p = 0.f;
+    for (int i = lane * 4; i < d; i += 256) {
+        const float4 m = mixed(i);
+        p = fmaf(m.x, m.x, p); p = fmaf(m.y, m.y, p); p = fmaf(m.z, m.z, p); p = fmaf(m.w, m.w, p);
+    }
+    const float den2 = fmaxf(sqrtf(wave_butterfly_sum(p)), 1e-12f);
+    for (int i = lane * 4; i < d; i += 256) {
+        float4 m = mixed(i);
+        m.x = m.x / den2; m.y = m.y / den2; m.z = m.z / den2; m.w = m.w / den2;
+        st4(e + i, m);
+    }
+}
+
+extern "C" int medtok_ema_apply_f32(float *E, float *cluster_size, const float *bins, const float *embed_sum, int64_t k_codes,
+                                    int d, float decay, float one_minus_decay, void *stream)
+{
+    if (k_codes <= 0 || d <= 0 || (d & 3)) return fail("ema_apply: bad shape K=%ld d=%d", (long)k_codes, d);
+    hipLaunchKernelGGL(ema_apply_kernel, dim3((unsigned)((k_codes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, E, cluster_size, bins,
+                       embed_sum, (int)k_codes, d, decay, one_minus_decay);
+    return check_launch("ema_apply");
+}
+
+__global__ __launch_bounds__(256) void ema_cluster_size_kernel(float *cs, const float *__restrict__ bins, long k, float decay, float omd)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= k) return;
+    const float a0 = cs[i] * decay;
+    const float a1 = bins[i] * omd;
+    cs[i] = a0 + a1;
+}
+
+extern "C" int medtok_ema_cluster_size_f32(float *cluster_size, const float *bins, int64_t k_codes, float decay,
+                                           float one_minus_decay, void *stream)
+{
+    if (k_codes <= 0) return fail("ema_cluster_size: bad K");
+    hipLaunchKernelGGL(ema_cluster_size_kernel, dim3((unsigned)((k_codes + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       cluster_size, bins, (long)k_codes, decay, one_minus_decay);
+    return check_launch("ema_cluster_size");
+}
+
+// ================================================================= codebook usage window
+__global__ __launch_bounds__(256) void usage_shift_kernel(const float *__restrict__ win, long wlen, const int64_t *__restrict__ ids,
+                                                          long m, float *__restrict__ tmp)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < wlen; i += (long)gridDim.x * 256) {
+        float v;
+        if (m >= wlen) v = (float)ids[m - wlen + i];
+        else v = (i < wlen - m) ? win[i + m] : (float)ids[i - (wlen - m)];
+        tmp[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void usage_count_kernel(const float *__restrict__ tmp, long wlen, long n_codes, float *__restrict__ win,
+                                                          unsigned *__restrict__ bitmap, int *__restrict__ count)
+{
+    int local = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < wlen; i += (long)gridDim.x * 256) {
+        const float v = tmp[i];
+        win[i] = v;
+        long c = (long)v;
+        if (c < 0 || c >= n_codes) c = n_codes;
+        const unsigned bit = 1u << (c & 31);
+        const unsigned old = atomicOr(&bitmap[c >> 5], bit);
+        local += (old & bit) ? 0 : 1;
+    }
+    if (local) atomicAdd(count, local);
+}
+
+extern "C" size_t medtok_usage_workspace_bytes(int64_t window_len, int64_t n_codes)
+{
+    if (window_len <= 0 || n_codes <= 0) return 0;
+    return align_up((size_t)window_len * 4, 256) + align_up(((size_t)n_codes / 32 + 2) * 4, 256);
+}
+
+extern "C" int medtok_usage_update(float *window, int64_t window_len, const int64_t *ids, int64_t m, int64_t n_codes,
+                                   int32_t *count_out, void *ws, size_t ws_bytes, void *stream)
+{
+    if (window_len <= 0 || n_codes <= 0 || m < 0 || !count_out) return fail("usage_update: bad args");
+    const size_t need = medtok_usage_workspace_bytes(window_len, n_codes);
+    if (!ws || ws_bytes < need) return fail("usage_update: workspace too small (%zu < %zu)", ws_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    float *tmp = (float *)ws;
+    unsigned *bitmap = (unsigned *)((char *)ws + align_up((size_t)window_len * 4, 256));
+    if (hipMemsetAsync(bitmap, 0, ((size_t)n_codes / 32 + 2) * 4, s) != hipSuccess) return fail("usage_update: memset failed");
+    if (hipMemsetAsync(count_out, 0, 4, s) != hipSuccess) return fail("usage_update: memset failed");
+    const unsigned blocks = (unsigned)lmin(1024, (window_len + 255) / 256);
+    hipLaunchKernelGGL(usage_shift_kernel, dim3(blocks), dim3(256), 0, s, window, (long)window_len, ids, (long)m, tmp);
+    hipLaunchKernelGGL(usage_count_kernel, dim3(blocks), dim3(256), 0, s, tmp, (long)window_len, (long)n_codes, window, bitmap, count_out);
+    return check_launch("usage_update");
+}
+
+// ================================================================= one-call soft VQ forward
+extern "C" size_t medtok_soft_vq_workspace_bytes(int64_t n, int64_t k_codes, int d, int topk, int path)
+{
+    if (n <= 0) return 256;
+    return align_up((size_t)n * 4, 256) + medtok_search_workspace_bytes(n, k_codes, d, topk, path);
+}
+
+extern "C" int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d, const float *what, const float *wsq, int64_t k_codes,
+                                          int topk, int path, float *xhat, int64_t *idx, float *dist, float *w, float *zq_ste,
+                                          float *row_sqerr, void *ws, size_t ws_bytes, void *stream)
+{
+    if (n == 0) return 0;
+    const size_t need = medtok_soft_vq_workspace_bytes(n, k_codes, d, topk, path);
+    if (!ws || ws_bytes < need) return fail("soft_vq_forward: workspace too small (%zu < %zu)", ws_bytes, need);
+    float *xsq = (float *)ws;
+    void *sws = (char *)ws + align_up((size_t)n * 4, 256);
+    if (medtok_rownorm_f32(x, n, d, 1, xhat, xsq, stream)) return 1;
+    if (medtok_topk_search_f32(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, sws, ws_bytes - align_up((size_t)n * 4, 256), path, stream)) return 1;
+    return medtok_soft_assign_f32(x, what, idx, dist, n, d, topk, 0, w, zq_ste, row_sqerr, stream);
+}

@@ -1,0 +1,183 @@
+"""Tensor-level wrappers over the C ABI (include/medtok_vq.h).
+
+torch is used for device memory and the current HIP stream only; every
+computation below runs in the hand-written gfx950 kernels.  CPU tensors are
+rejected: there is no fallback path.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import PATH_AUTO, PATH_BF16_FILTER, PATH_F32_MFMA, MAX_TOPK  # noqa: F401
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.MedTokLibraryError(
+            f"{name}: expected a tensor on an MI355X (cuda/HIP) device, got "
+            f"{getattr(t, 'device', type(t))}; medtok_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _ws(nbytes: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
+
+
+def pad_dim(d: int) -> int:
+    """Kernels need D % 4 == 0; zero columns change neither norms nor dots."""
+    return (d + 3) // 4 * 4
+
+
+def rownorm(x: torch.Tensor, normalize: bool = True, want_xhat: bool = True):
+    """(xhat, |xhat|^2) of F.normalize(x, dim=-1). x: [n, d] fp32."""
+    x = _dev(x, "x")
+    n, d = x.shape
+    lib = _lib.load()
+    sqn = torch.empty(n, dtype=torch.float32, device=x.device)
+    if normalize:
+        xhat = torch.empty_like(x)
+    else:
+        xhat = x if want_xhat else None
+    with torch.cuda.device(x.device):
+        _lib.check(lib.medtok_rownorm_f32(x.data_ptr(), n, d, int(normalize), _ptr(xhat), sqn.data_ptr(),
+                                          _stream(x)), "medtok_rownorm_f32")
+    return xhat, sqn
+
+
+def topk_search(xhat, xsq, what, wsq, topk: int, path: int = PATH_AUTO):
+    """idx [n, topk] int64, dist [n, topk] fp32: the topk nearest codes per row."""
+    xhat, xsq = _dev(xhat, "xhat"), _dev(xsq, "xsq")
+    what, wsq = _dev(what, "what"), _dev(wsq, "wsq")
+    n, d = xhat.shape
+    k = what.shape[0]
+    if what.shape[1] != d or xsq.shape[0] != n or wsq.shape[0] != k:
+        raise ValueError("topk_search: shape mismatch")
+    lib = _lib.load()
+    idx = torch.empty((n, topk), dtype=torch.int64, device=xhat.device)
+    dist = torch.empty((n, topk), dtype=torch.float32, device=xhat.device)
+    nb = lib.medtok_search_workspace_bytes(n, k, d, topk, path)
+    ws = _ws(nb, xhat)
+    with torch.cuda.device(xhat.device):
+        _lib.check(lib.medtok_topk_search_f32(xhat.data_ptr(), xsq.data_ptr(), n, what.data_ptr(), wsq.data_ptr(),
+                                              k, d, topk, idx.data_ptr(), dist.data_ptr(), ws.data_ptr(),
+                                              ws.numel(), path, _stream(xhat)), "medtok_topk_search_f32")
+    return idx, dist
+
+
+def soft_assign(xref, what, idx, dist, hard: bool = False, want_w: bool = True, want_sqerr: bool = True):
+    """(w [n,k], zq_ste [n,d], row_sqerr [n])."""
+    xref, what = _dev(xref, "xref"), _dev(what, "what")
+    idx = _dev(idx, "idx", torch.int64)
+    n, d = xref.shape
+    topk = 1 if idx.dim() == 1 else idx.shape[1]
+    dist = None if hard and dist is None else _dev(dist, "dist")
+    lib = _lib.load()
+    w = torch.empty((n, topk), dtype=torch.float32, device=xref.device) if want_w else None
+    zq = torch.empty_like(xref)
+    se = torch.empty(n, dtype=torch.float32, device=xref.device) if want_sqerr else None
+    with torch.cuda.device(xref.device):
+        _lib.check(lib.medtok_soft_assign_f32(xref.data_ptr(), what.data_ptr(), idx.data_ptr(), _ptr(dist), n, d, topk,
+                                              int(hard), _ptr(w), zq.data_ptr(), _ptr(se), _stream(xref)),
+                   "medtok_soft_assign_f32")
+    return w, zq, se
+
+
+def sum_scale(vals: torch.Tensor, scale: float) -> torch.Tensor:
+    """0-dim fp32 tensor = scale * sum(vals) (fp64 accumulation, fixed order)."""
+    vals = _dev(vals, "vals")
+    out = torch.empty((), dtype=torch.float32, device=vals.device)
+    lib = _lib.load()
+    with torch.cuda.device(vals.device):
+        _lib.check(lib.medtok_sum_scale_f32(vals.data_ptr(), vals.numel(), float(scale), out.data_ptr(),
+                                            _stream(vals)), "medtok_sum_scale_f32")
+    return out
+
+
+def ema_stats(zhat, idx, k_codes: int):
+    """(bins [K] fp32, embed_sum [K, D] fp32)."""
+    zhat = _dev(zhat, "zhat")
+    idx = _dev(idx, "idx", torch.int64)
+    n, d = zhat.shape
+    lib = _lib.load()
+    bins = torch.empty(k_codes, dtype=torch.float32, device=zhat.device)
+    es = torch.empty((k_codes, d), dtype=torch.float32, device=zhat.device)
+    ws = _ws(lib.medtok_ema_stats_workspace_bytes(n, k_codes), zhat)
+    with torch.cuda.device(zhat.device):
+        _lib.check(lib.medtok_ema_stats_f32(zhat.data_ptr(), idx.data_ptr(), n, d, k_codes, bins.data_ptr(),
+                                            es.data_ptr(), ws.data_ptr(), ws.numel(), _stream(zhat)),
+                   "medtok_ema_stats_f32")
+    return bins, es
+
+
+def ema_apply_(E, cluster_size, bins, embed_sum, decay: float) -> None:
+    """In-place codebook + cluster_size update."""
+    for name, t in (("E", E), ("cluster_size", cluster_size)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise _lib.MedTokLibraryError(f"ema_apply_: {name} must be a contiguous fp32 device tensor")
+    bins, embed_sum = _dev(bins, "bins"), _dev(embed_sum, "embed_sum")
+    k, d = E.shape
+    lib = _lib.load()
+    with torch.cuda.device(E.device):
+        _lib.check(lib.medtok_ema_apply_f32(E.data_ptr(), cluster_size.data_ptr(), bins.data_ptr(), embed_sum.data_ptr(),
+                                            k, d, float(decay), float(1 - decay), _stream(E)), "medtok_ema_apply_f32")
+
+
+def ema_cluster_size_(cluster_size, bins, decay: float) -> None:
+    if not (cluster_size.is_cuda and cluster_size.dtype == torch.float32 and cluster_size.is_contiguous()):
+        raise _lib.MedTokLibraryError("ema_cluster_size_: cluster_size must be a contiguous fp32 device tensor")
+    bins = _dev(bins, "bins")
+    lib = _lib.load()
+    with torch.cuda.device(bins.device):
+        _lib.check(lib.medtok_ema_cluster_size_f32(cluster_size.data_ptr(), bins.data_ptr(), cluster_size.numel(),
+                                                   float(decay), float(1 - decay), _stream(bins)),
+                   "medtok_ema_cluster_size_f32")
+
+
+def usage_update_(window: torch.Tensor, ids: torch.Tensor, n_codes: int) -> torch.Tensor:
+    """Slide `window` (fp32, in place) by ids.numel(), append ids, return the
+    distinct-value count as a device int32 scalar (no host sync)."""
+    if not (window.is_cuda and window.dtype == torch.float32 and window.is_contiguous()):
+        raise _lib.MedTokLibraryError("usage_update_: window must be a contiguous fp32 device tensor")
+    ids = _dev(ids.reshape(-1), "ids", torch.int64)
+    lib = _lib.load()
+    count = torch.empty((), dtype=torch.int32, device=window.device)
+    ws = _ws(lib.medtok_usage_workspace_bytes(window.numel(), n_codes), window)
+    with torch.cuda.device(window.device):
+        _lib.check(lib.medtok_usage_update(window.data_ptr(), window.numel(), ids.data_ptr(), ids.numel(), n_codes,
+                                           count.data_ptr(), ws.data_ptr(), ws.numel(), _stream(window)),
+                   "medtok_usage_update")
+    return count
+
+
+def soft_vq_forward(x, what, wsq, topk: int, path: int = PATH_AUTO, want_sqerr: bool = True):
+    """rownorm -> search -> soft assign in one C call.
+    Returns dict(xhat, idx, dist, w, zq, row_sqerr)."""
+    x, what, wsq = _dev(x, "x"), _dev(what, "what"), _dev(wsq, "wsq")
+    n, d = x.shape
+    k = what.shape[0]
+    lib = _lib.load()
+    dev = x.device
+    xhat = torch.empty_like(x)
+    idx = torch.empty((n, topk), dtype=torch.int64, device=dev)
+    dist = torch.empty((n, topk), dtype=torch.float32, device=dev)
+    w = torch.empty((n, topk), dtype=torch.float32, device=dev)
+    zq = torch.empty_like(x)
+    se = torch.empty(n, dtype=torch.float32, device=dev) if want_sqerr else None
+    ws = _ws(lib.medtok_soft_vq_workspace_bytes(n, k, d, topk, path), x)
+    with torch.cuda.device(dev):
+        _lib.check(lib.medtok_soft_vq_forward_f32(x.data_ptr(), n, d, what.data_ptr(), wsq.data_ptr(), k, topk, path,
+                                                  xhat.data_ptr(), idx.data_ptr(), dist.data_ptr(), w.data_ptr(),
+                                                  zq.data_ptr(), _ptr(se), ws.data_ptr(), ws.numel(), _stream(x)),
+                   "medtok_soft_vq_forward_f32")
+    return dict(xhat=xhat, idx=idx, dist=dist, w=w, zq=zq, row_sqerr=se)

@@ -1,0 +1,184 @@
+"""HIP kernels vs the CPU oracle through the C ABI (bit-exact ids and distances)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("n,d", [(1, 4), (7, 64), (130, 768), (33, 100), (5, 1028)])
+def test_rownorm_bit_exact(oracle, dev, n, d):
+    from medtok_amd import ops
+    rng = np.random.default_rng(n * 1000 + d)
+    x = rng.standard_normal((n, d), dtype=np.float32) * 3
+    if n > 2:
+        x[1] = 0.0          # eps clamp branch
+    xh_o, sq_o = oracle.rownorm(x, True)
+    xh, sq = ops.rownorm(_t(x, dev), True)
+    assert np.array_equal(xh.cpu().numpy(), xh_o)
+    assert np.array_equal(sq.cpu().numpy(), sq_o)
+    _, sq2_o = oracle.rownorm(x, False)
+    _, sq2 = ops.rownorm(_t(x, dev), False)
+    assert np.array_equal(sq2.cpu().numpy(), sq2_o)
+
+
+@pytest.mark.parametrize("n,k,d,topk", [
+    (256, 384, 64, 5),       # reference-like small shape
+    (300, 1000, 768, 5),     # ragged row/code tails, code split path
+    (129, 257, 36, 1),       # argmin, D tail inside a BK block
+    (5000, 512, 64, 5),      # many row tiles
+    (64, 8192, 768, 8),      # 8-slot list
+    (1, 16, 4, 3),           # minimum sizes
+    (70000, 300, 32, 5),     # single split (FINAL kernel), ragged everything
+])
+def test_search_bit_exact(oracle, dev, n, k, d, topk):
+    from medtok_amd import ops
+    rng = np.random.default_rng(n + 7 * k + 13 * d)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    W = rng.standard_normal((k, d), dtype=np.float32)
+    xh, xs = oracle.rownorm(x)
+    wh, ws = oracle.rownorm(W)
+    idx_o, dist_o = oracle.topk_search(xh, xs, wh, ws, topk)
+    idx, dist = ops.topk_search(_t(xh, dev), _t(xs, dev), _t(wh, dev), _t(ws, dev), topk)
+    torch.cuda.synchronize()
+    assert np.array_equal(dist.cpu().numpy(), dist_o), "distances must be bit-identical to the fmaf-chain oracle"
+    assert np.array_equal(idx.cpu().numpy(), idx_o)
+
+
+def test_search_ties_lowest_index(oracle, dev, golden):
+    from medtok_amd import ops
+    g = golden("f8_ties")
+    W, x = g["W"], g["x"]
+    Wp = np.zeros((W.shape[0], 8), np.float32); Wp[:, :W.shape[1]] = W
+    xp = np.zeros((x.shape[0], 8), np.float32); xp[:, :x.shape[1]] = x
+    xh, xs = oracle.rownorm(xp); wh, ws = oracle.rownorm(Wp)
+    idx_o, _ = oracle.topk_search(xh, xs, wh, ws, 5)
+    idx, _ = ops.topk_search(_t(xh, dev), _t(xs, dev), _t(wh, dev), _t(ws, dev), 5)
+    idx = idx.cpu().numpy()
+    assert np.array_equal(idx, idx_o)
+    rule = g["build_rule_idx"]
+    for r in range(rule.shape[0]):
+        want = [v for v in rule[r] if v >= 0]
+        assert list(idx[r, :len(want)]) == want
+    # exact duplicates in a big codebook: every duplicate pair must come out lowest-index first
+    rng = np.random.default_rng(3)
+    W = rng.standard_normal((2048, 64), dtype=np.float32)
+    W[1024:] = W[:1024]
+    x = rng.standard_normal((200, 64), dtype=np.float32)
+    xh, xs = oracle.rownorm(x); wh, ws = oracle.rownorm(W)
+    idx_o, dist_o = oracle.topk_search(xh, xs, wh, ws, 5)
+    idx, dist = ops.topk_search(_t(xh, dev), _t(xs, dev), _t(wh, dev), _t(ws, dev), 5)
+    assert np.array_equal(idx.cpu().numpy(), idx_o)
+    assert np.array_equal(dist.cpu().numpy(), dist_o)
+    assert (idx_o[:, 0] < 1024).all() and (idx_o[:, 1] == idx_o[:, 0] + 1024).all()
+
+
+@pytest.mark.parametrize("n,k,d,topk,hard", [(200, 300, 64, 5, False), (65, 128, 768, 5, False), (77, 64, 32, 1, True), (9, 40, 100, 3, False)])
+def test_soft_assign(oracle, dev, n, k, d, topk, hard):
+    from medtok_amd import ops
+    rng = np.random.default_rng(n + k)
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    W = rng.standard_normal((k, d), dtype=np.float32)
+    xh, xs = oracle.rownorm(x); wh, ws = oracle.rownorm(W)
+    idx, dist = oracle.topk_search(xh, xs, wh, ws, topk)
+    xref = xh if hard else x
+    ii = idx[:, 0] if hard else idx
+    w_o, zq_o, se_o = oracle.soft_assign(xref, wh, ii, dist, hard)
+    w, zq, se = ops.soft_assign(_t(xref, dev), _t(wh, dev), _t(ii, dev), _t(dist, dev), hard)
+    # tolerance: 1e-5 relative (north_star); expf differs from glibc by <= 2 ulp
+    assert rel(w.cpu().numpy(), w_o) <= 1e-6
+    assert rel(zq.cpu().numpy(), zq_o) <= 1e-6
+    assert np.allclose(se.cpu().numpy(), se_o, rtol=1e-5, atol=0)
+    if hard:
+        assert np.array_equal(zq.cpu().numpy(), zq_o)
+
+
+def test_sum_scale(dev):
+    from medtok_amd import ops
+    rng = np.random.default_rng(0)
+    v = rng.random(100003, dtype=np.float32)
+    out = ops.sum_scale(_t(v, dev), 1.0 / v.size).item()
+    assert abs(out - v.astype(np.float64).mean()) <= 1e-7
+    assert ops.sum_scale(_t(v[:0], dev), 1.0).item() == 0.0
+
+
+@pytest.mark.parametrize("n,k,d", [(512, 64, 32), (1000, 300, 768), (5, 70000, 8), (3000, 2, 64), (100000, 8192, 64)])
+def test_ema_stats_bit_exact(oracle, dev, n, k, d):
+    from medtok_amd import ops
+    rng = np.random.default_rng(n + k + d)
+    z = rng.standard_normal((n, d), dtype=np.float32)
+    idx = rng.integers(0, k, n).astype(np.int64)
+    if n > 100:
+        idx[: n // 3] = k - 1       # one long segment
+    bins_o, es_o = oracle.ema_stats(z, idx, k)
+    bins, es = ops.ema_stats(_t(z, dev), _t(idx, dev), k)
+    assert np.array_equal(bins.cpu().numpy(), bins_o)
+    assert np.array_equal(es.cpu().numpy(), es_o), "row-ordered segmented sum must match the oracle bit for bit"
+
+
+@pytest.mark.parametrize("k,d", [(64, 32), (300, 768), (5, 100)])
+def test_ema_apply_bit_exact(oracle, dev, k, d):
+    from medtok_amd import ops
+    rng = np.random.default_rng(k + d)
+    E = oracle.rownorm(rng.standard_normal((k, d), dtype=np.float32))[0]
+    cs = rng.random(k, dtype=np.float32) * 10
+    bins = rng.integers(0, 4, k).astype(np.float32)
+    es = rng.standard_normal((k, d), dtype=np.float32) * bins[:, None]
+    E_o, cs_o = E.copy(), cs.copy()
+    oracle.ema_apply(E_o, cs_o, bins, es, 0.99)
+    E_d, cs_d = _t(E, dev), _t(cs, dev)
+    ops.ema_apply_(E_d, cs_d, _t(bins, dev), _t(es, dev), 0.99)
+    assert np.array_equal(cs_d.cpu().numpy(), cs_o)
+    assert np.array_equal(E_d.cpu().numpy(), E_o)
+    cs2_o = cs.copy(); oracle.ema_cluster_size(cs2_o, bins, 0.99)
+    cs2 = _t(cs, dev); ops.ema_cluster_size_(cs2, _t(bins, dev), 0.99)
+    assert np.array_equal(cs2.cpu().numpy(), cs2_o)
+
+
+def test_usage_window(oracle, dev, golden):
+    from medtok_amd import ops
+    g = golden("f10_usage")
+    n_e, wlen = int(g["n_e"]), int(g["window"])
+    win_o = np.zeros(wlen, np.float32)
+    win = torch.zeros(wlen, device=dev)
+    for c in range(4):
+        ids = g[f"c{c}.ids"]
+        u_o = oracle.usage_update(win_o, ids, n_e)
+        cnt = ops.usage_update_(win, _t(ids, dev), n_e)
+        assert cnt.item() / n_e == u_o == float(g[f"c{c}.usage"])
+    assert np.array_equal(win.cpu().numpy(), win_o)
+    assert np.array_equal(win_o[-4000:], g["final_tail"])
+    # more ids than the window holds: keep the newest
+    small_o = np.zeros(10, np.float32); small = torch.zeros(10, device=dev)
+    ids = np.arange(25, dtype=np.int64) % 7
+    assert ops.usage_update_(small, _t(ids, dev), 7).item() / 7 == oracle.usage_update(small_o, ids, 7)
+    assert np.array_equal(small.cpu().numpy(), small_o)
+
+
+def test_soft_vq_forward_one_call(oracle, dev):
+    from medtok_amd import ops
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((500, 128), dtype=np.float32) * 2
+    W = rng.standard_normal((700, 128), dtype=np.float32)
+    r_o = oracle.specific_search(x, W, 5)
+    what, wsq = ops.rownorm(_t(W, dev))
+    r = ops.soft_vq_forward(_t(x, dev), what, wsq, 5)
+    assert np.array_equal(r["idx"].cpu().numpy(), r_o["idx"])
+    assert np.array_equal(r["dist"].cpu().numpy(), r_o["dist"])
+    assert np.array_equal(r["xhat"].cpu().numpy(), r_o["xhat"])
+    assert rel(r["zq"].cpu().numpy(), r_o["zq"]) <= 1e-6
+    assert rel(r["w"].cpu().numpy(), r_o["w"]) <= 1e-6
+
+
+def test_cpu_tensors_are_rejected():
+    from medtok_amd import ops, _lib
+    with pytest.raises(_lib.MedTokLibraryError):
+        ops.rownorm(torch.zeros(4, 8))
