@@ -42,6 +42,10 @@ extern "C" {
 #define MEDTOK_PATH_F32_MFMA 1      /* brute force on v_mfma_f32_32x32x2_f32          */
 #define MEDTOK_PATH_BF16_FILTER 2   /* bf16-MFMA shortlist + exact fp32 re-score      */
 
+/* flags for medtok_soft_assign_f32 */
+#define MEDTOK_ASSIGN_HARD 1        /* NormEMA form: topk == 1, zq = what[idx]        */
+#define MEDTOK_ASSIGN_RAW 2         /* write zq itself instead of xref + (zq - xref)  */
+
 int medtok_abi_version(void);
 const char *medtok_last_error(void);
 
@@ -72,12 +76,13 @@ int medtok_topk_search_f32(const float *xhat, const float *xsq, int64_t n,
 /* Soft assignment: w = softmax(-dist), zq = sum_j w_j * what[idx_j],
  * zq_ste = xref + (zq - xref), row_sqerr[r] = sum_i (zq - xref)^2.
  * Replaces vector_quantization_soft_one_new.py:158,160,164-165,169-173,181-182,
- * 204-205,208-209,214.  hard != 0 is the NormEMA form (topk == 1, zq = what[idx];
- * norm_ema_quantizer.py:181,212,214).  w and row_sqerr may be NULL.
- * zq_ste may alias xref. */
+ * 204-205,208-209,214.  MEDTOK_ASSIGN_HARD is the NormEMA form (topk == 1,
+ * zq = what[idx]; norm_ema_quantizer.py:181,212,214); MEDTOK_ASSIGN_RAW stores zq
+ * (the tensor autograd differentiates) instead of the straight-through value.
+ * w and row_sqerr may be NULL.  zq_out may alias xref. */
 int medtok_soft_assign_f32(const float *xref, const float *what, const int64_t *idx,
-                           const float *dist, int64_t n, int d, int topk, int hard,
-                           float *w, float *zq_ste, float *row_sqerr, void *stream);
+                           const float *dist, int64_t n, int d, int topk, int flags,
+                           float *w, float *zq_out, float *row_sqerr, void *stream);
 
 /* out[0] = scale * sum(vals[0..n)), accumulated in fp64 in a fixed order
  * (the mean of the squared error: :169-173,208-209; F.mse_loss at
@@ -92,6 +97,11 @@ size_t medtok_ema_stats_workspace_bytes(int64_t n, int64_t k_codes);
 int medtok_ema_stats_f32(const float *zhat, const int64_t *idx, int64_t n, int d,
                          int64_t k_codes, float *bins, float *embed_sum,
                          void *ws, size_t ws_bytes, void *stream);
+
+/* bins only: the eval branch (norm_ema_quantizer.py:185-188) needs no embed_sum. */
+size_t medtok_code_histogram_workspace_bytes(int64_t k_codes);
+int medtok_code_histogram_f32(const int64_t *idx, int64_t n, int64_t k_codes, float *bins,
+                              void *ws, size_t ws_bytes, void *stream);
 
 /* EMA apply of norm_ema_quantizer.py:197-210 (+ :11-12,136-138), in place:
  * cluster_size <- decay*cs + (1-decay)*bins; rows with bins == 0 keep their

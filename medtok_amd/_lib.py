@@ -28,6 +28,8 @@ SIGNATURES = {
     "medtok_sum_scale_f32": (_int, [_vp, _i64, _dbl, _vp, _vp]),
     "medtok_ema_stats_workspace_bytes": (_sz, [_i64, _i64]),
     "medtok_ema_stats_f32": (_int, [_vp, _vp, _i64, _int, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "medtok_code_histogram_workspace_bytes": (_sz, [_i64]),
+    "medtok_code_histogram_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "medtok_ema_apply_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _f, _f, _vp]),
     "medtok_ema_cluster_size_f32": (_int, [_vp, _vp, _i64, _f, _f, _vp]),
     "medtok_usage_workspace_bytes": (_sz, [_i64, _i64]),

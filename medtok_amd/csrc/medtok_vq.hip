@@ -409,9 +409,10 @@ extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64
 template <int MAXK>
 __global__ __launch_bounds__(256) void soft_assign_kernel(const float *__restrict__ xref, const float *__restrict__ what,
                                                           const int64_t *__restrict__ idx, const float *__restrict__ dist,
-                                                          long n, int d, int topk, int hard, float *__restrict__ w_out,
+                                                          long n, int d, int topk, int flags, float *__restrict__ w_out,
                                                           float *zq_ste, float *__restrict__ row_sqerr)
 {
+    const bool hard = flags & MEDTOK_ASSIGN_HARD, raw = flags & MEDTOK_ASSIGN_RAW;
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(256) void soft_assign_kernel(const float *__restric
         const float4 x = ld4(xr + i);
         float4 df;
         df.x = a.x - x.x; df.y = a.y - x.y; df.z = a.z - x.z; df.w = a.w - x.w;
-        st4(out + i, make_float4(x.x + df.x, x.y + df.y, x.z + df.z, x.w + df.w));
+        st4(out + i, raw ? a : make_float4(x.x + df.x, x.y + df.y, x.z + df.z, x.w + df.w));
         se = fmaf(df.x, df.x, se); se = fmaf(df.y, df.y, se); se = fmaf(df.z, df.z, se); se = fmaf(df.w, df.w, se);
     }
     se = wave_butterfly_sum(se);
@@ -464,9 +465,10 @@ __global__ __launch_bounds__(256) void soft_assign_kernel(const float *__restric
 }
 
 extern "C" int medtok_soft_assign_f32(const float *xref, const float *what, const int64_t *idx, const float *dist,
-                                      int64_t n, int d, int topk, int hard, float *w, float *zq_ste, float *row_sqerr,
+                                      int64_t n, int d, int topk, int flags, float *w, float *zq_ste, float *row_sqerr,
                                       void *stream)
 {
+    const int hard = flags & MEDTOK_ASSIGN_HARD;
     if (n < 0 || d <= 0 || (d & 3)) return fail("soft_assign: bad shape n=%ld d=%d", (long)n, d);
     if (topk < 1 || topk > MEDTOK_MAX_TOPK) return fail("soft_assign: topk=%d unsupported", topk);
     if (hard && topk != 1) return fail("soft_assign: hard assignment needs topk == 1");
@@ -474,7 +476,7 @@ extern "C" int medtok_soft_assign_f32(const float *xref, const float *what, cons
     if (!zq_ste) return fail("soft_assign: zq_ste required");
     if (n == 0) return 0;
     hipLaunchKernelGGL((soft_assign_kernel<MEDTOK_MAX_TOPK>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       xref, what, idx, dist, (long)n, d, topk, hard, w, zq_ste, row_sqerr);
+                       xref, what, idx, dist, (long)n, d, topk, flags, w, zq_ste, row_sqerr);
     return check_launch("soft_assign");
 }
 
@@ -685,6 +687,31 @@ extern "C" int medtok_ema_stats_f32(const float *zhat, const int64_t *idx, int64
     }
     hipLaunchKernelGGL(segsum_kernel, dim3((unsigned)lmin(4096, (k_codes + 3) / 4)), dim3(256), 0, s, zhat, w.vals[cur], w.offsets, (int)k_codes, d, bins, embed_sum);
     return check_launch("ema_stats");
+}
+
+// bins only (eval branch of the reference, norm_ema_quantizer.py:185-188)
+__global__ __launch_bounds__(256) void counts_to_float_kernel(const int *__restrict__ counts, long k, float *__restrict__ bins)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < k) bins[i] = (float)counts[i];
+}
+
+extern "C" size_t medtok_code_histogram_workspace_bytes(int64_t k_codes)
+{
+    return k_codes > 0 ? align_up((size_t)k_codes * 4, 256) : 0;
+}
+
+extern "C" int medtok_code_histogram_f32(const int64_t *idx, int64_t n, int64_t k_codes, float *bins, void *ws, size_t ws_bytes,
+                                         void *stream)
+{
+    if (n < 0 || k_codes <= 0 || k_codes >= (1ll << 31)) return fail("code_histogram: bad shape n=%ld K=%ld", (long)n, (long)k_codes);
+    if (!ws || ws_bytes < (size_t)k_codes * 4) return fail("code_histogram: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    int *counts = (int *)ws;
+    if (hipMemsetAsync(counts, 0, (size_t)k_codes * 4, s) != hipSuccess) return fail("code_histogram: memset failed");
+    if (n > 0) hipLaunchKernelGGL(hist_kernel, dim3((unsigned)lmin(2048, (n + 255) / 256)), dim3(256), 0, s, idx, (long)n, (int)k_codes, counts);
+    hipLaunchKernelGGL(counts_to_float_kernel, dim3((unsigned)((k_codes + 255) / 256)), dim3(256), 0, s, counts, (long)k_codes, bins);
+    return check_launch("code_histogram");
 }
 
 // ================================================================= EMA apply

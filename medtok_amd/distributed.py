@@ -1,0 +1,79 @@
+"""Row-sharded multi-GPU driver for the VQ path: one process per GPU, RCCL over xGMI.
+
+The path shards by rows (codes to tokenize): every rank holds the whole codebook
+(25-151 MB) and searches its own slice of the input with NO communication, so
+token ids are identical to a single-GPU run by construction.  The only exchange
+step is the EMA training update, where the per-rank statistics [embed_sum | bins]
+are summed with one all-reduce (the reference issues two: norm_ema_quantizer.py:195,203)
+before every rank applies the same codebook update.
+
+Launch contract (reference MedTok/utils/distributed.py:20-58): env:// rendezvous,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from torchrun.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size); initialises the default process group when
+    WORLD_SIZE > 1.  backend defaults to nccl (= RCCL on ROCm) with a GPU, gloo without."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        use_gpu = torch.cuda.is_available()
+        if use_gpu:
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend or ("nccl" if use_gpu else "gloo"), init_method="env://",
+                                rank=rank, world_size=world)
+    return rank, local, world
+
+
+def row_shard(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced [lo, hi) slice of n rows for `rank` (sizes differ by <= 1)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_reduce_stats(stats: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place SUM of the fused EMA statistics buffer across ranks (no-op single-process)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+    return stats
+
+
+def max_over_ranks(value: float, device) -> float:
+    """Timing helper for bench.py: the slowest rank defines the step time."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Concatenate per-rank row shards (made with row_shard) back into [n_total, ...] on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    sizes = [row_shard(n_total, r, world) for r in range(world)]
+    longest = max(hi - lo for lo, hi in sizes)
+    pad = local.new_zeros((longest,) + tuple(local.shape[1:]))
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)

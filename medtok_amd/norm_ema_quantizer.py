@@ -1,0 +1,191 @@
+"""Norm-EMA vector quantiser of MedTok on MI355X.
+
+Drop-in for the live classes of the reference's MedTok/norm_ema_quantizer.py:
+`l2norm`, `ema_inplace`, `norm_ema_inplace`, `EmbeddingEMA`,
+`NormEMAVectorQuantizer` -- same constructor arguments, return values and
+state_dict keys (`cluster_size`, `embedding.weight`, `embedding.cluster_size`,
+`embedding.embed_avg`, `embedding.initted`).
+
+The forward pass (reference :166-218) runs as gfx950 kernels:
+normalise -> argmin search (no N x K matrix) -> gather -> histogram + row-ordered
+segmented sum (no one-hot, no second GEMM) -> all-reduce of [bins | embed_sum]
+-> fused EMA codebook update.  The classes the reference never instantiates
+(CVectorQuantiser, FeaturePool, lookup-only VectorQuantizer) are out of scope.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as distributed
+import torch.nn as nn
+
+from . import ops
+
+
+class _L2NormFunction(torch.autograd.Function):
+    """F.normalize(t, p=2, dim=-1) with the forward done by the rownorm kernel."""
+
+    @staticmethod
+    def forward(ctx, t):
+        flat = t.detach().reshape(-1, t.shape[-1]).float()
+        that, _ = ops.rownorm(flat)
+        ctx.save_for_backward(t, that)
+        return that.view(t.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        t, that = ctx.saved_tensors
+        that = that.view(t.shape)
+        nrm = t.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        return (g - that * (that * g).sum(-1, keepdim=True)) / nrm
+
+
+def l2norm(t):
+    """x / max(||x||, 1e-12) along the last dim (reference :8-9)."""
+    return _L2NormFunction.apply(t)
+
+
+def ema_inplace(moving_avg, new, decay):
+    """moving_avg <- decay * moving_avg + (1 - decay) * new (reference :11-12).
+    Plain torch: the only call sites left outside the fused kernels are [K]-sized."""
+    moving_avg.data.mul_(decay).add_(new, alpha=(1 - decay))
+
+
+def norm_ema_inplace(moving_avg, new, decay):
+    """EMA step followed by re-normalisation (reference :136-138)."""
+    moving_avg.data.mul_(decay).add_(new, alpha=(1 - decay))
+    moving_avg.data.copy_(l2norm(moving_avg.data))
+
+
+class EmbeddingEMA(nn.Module):
+    """Codebook state holder (reference :60-134)."""
+
+    def __init__(self, num_tokens, codebook_dim, decay=0.99, eps=1e-5, kmeans_init=True, codebook_init_path=""):
+        super().__init__()
+        self.num_tokens = num_tokens
+        self.codebook_dim = codebook_dim
+        self.decay = decay
+        self.eps = eps
+        if codebook_init_path == "":
+            if not kmeans_init:
+                weight = torch.nn.functional.normalize(torch.randn(num_tokens, codebook_dim), p=2, dim=-1)
+            else:
+                weight = torch.zeros(num_tokens, codebook_dim)
+            self.register_buffer("initted", torch.Tensor([not kmeans_init]))
+        else:
+            weight = torch.load(codebook_init_path, map_location="cpu").clone()
+            self.register_buffer("initted", torch.Tensor([True]))
+        self.weight = nn.Parameter(weight, requires_grad=False)
+        self.cluster_size = nn.Parameter(torch.zeros(num_tokens), requires_grad=False)
+        self.embed_avg = nn.Parameter(weight.clone(), requires_grad=False)
+        self.update = True
+
+    @torch.jit.ignore
+    def init_embed_(self, data):
+        if self.initted:
+            return
+        from .kmeans import kmeans
+        embed, cluster_size = kmeans(data, self.num_tokens, 10, use_cosine_sim=True)
+        self.weight.data.copy_(embed)
+        self.cluster_size.data.copy_(cluster_size)
+        self.initted.data.copy_(torch.Tensor([True]))
+
+    def forward(self, embed_id):
+        return torch.nn.functional.embedding(embed_id, self.weight)
+
+    def cluster_size_ema_update(self, new_cluster_size):
+        self.cluster_size.data.mul_(self.decay).add_(new_cluster_size, alpha=1 - self.decay)
+
+    def embed_avg_ema_update(self, new_embed_avg):
+        self.embed_avg.data.mul_(self.decay).add_(new_embed_avg, alpha=1 - self.decay)
+
+    def weight_update(self, num_tokens):
+        n = self.cluster_size.sum()
+        smoothed = (self.cluster_size + self.eps) / (n + num_tokens * self.eps) * n
+        self.weight.data.copy_(self.embed_avg / smoothed.unsqueeze(1))
+
+
+class NormEMAVectorQuantizer(nn.Module):
+    def __init__(self, n_embed, embedding_dim, beta, decay=0.99, eps=1e-5, statistic_code_usage=True,
+                 kmeans_init=False, codebook_init_path=""):
+        super().__init__()
+        if embedding_dim % 4:
+            raise ValueError("embedding_dim must be a multiple of 4 (float4 kernels)")
+        self.codebook_dim = embedding_dim
+        self.num_tokens = n_embed
+        self.beta = beta
+        self.decay = decay
+        self.search_path = ops.PATH_AUTO
+        self.embedding = EmbeddingEMA(self.num_tokens, self.codebook_dim, decay, eps, kmeans_init, codebook_init_path)
+        self.statistic_code_usage = statistic_code_usage
+        if statistic_code_usage:
+            self.register_buffer("cluster_size", torch.zeros(n_embed))
+        # like the reference (:155-159) the choice is made once, at construction time
+        if distributed.is_available() and distributed.is_initialized():
+            self.all_reduce_fn = distributed.all_reduce
+        else:
+            self.all_reduce_fn = nn.Identity()
+
+    def reset_cluster_size(self, device):
+        if self.statistic_code_usage:
+            self.register_buffer("cluster_size", torch.zeros(self.num_tokens))
+            self.cluster_size = self.cluster_size.to(device)
+
+    def forward(self, z):
+        b, c, h, w = z.shape
+        # 'b c h w -> b h w c' (reference :169); for the usual [N, D, 1, 1] input this is a view
+        z = z.permute(0, 2, 3, 1)
+        z = l2norm(z)
+        z_flat = z.reshape(-1, self.codebook_dim)
+        zd = z_flat.detach()
+        n = zd.shape[0]
+
+        self.embedding.init_embed_(zd)
+        E = self.embedding.weight.data                      # stored normalised, NOT re-normalised (:175-177)
+        _, esq = ops.rownorm(E, normalize=False, want_xhat=False)
+        _, zsq = ops.rownorm(zd, normalize=False, want_xhat=False)
+        idx2, _ = ops.topk_search(zd, zsq, E, esq, 1, self.search_path)
+        encoding_indices = idx2.view(-1)
+        # gather BEFORE the EMA update (:181)
+        need_grad = torch.is_grad_enabled() and z_flat.requires_grad
+        if need_grad:
+            _, zq, _ = ops.soft_assign(zd, E, encoding_indices, None, hard=True, want_w=False, want_sqerr=False, raw=True)
+        else:   # straight-through value and squared error in the same pass
+            _, zq_ste, row_sqerr = ops.soft_assign(zd, E, encoding_indices, None, hard=True, want_w=False)
+
+        k, d = self.num_tokens, self.codebook_dim
+        if not self.training:
+            bins = ops.code_histogram(encoding_indices, k)
+            self.all_reduce_fn(bins)
+            ops.ema_cluster_size_(self.cluster_size, bins, self.decay)
+        if self.training and self.embedding.update:
+            bins, embed_sum, stats = self._stats(zd, encoding_indices)
+            # one collective for both statistics (the reference issues two, :195,:203)
+            self.all_reduce_fn(stats)
+            ops.ema_apply_(E, self.cluster_size, bins, embed_sum, self.decay)
+
+        if need_grad:
+            loss = self.beta * torch.mean((zq - z_flat) ** 2)          # F.mse_loss(z_q.detach(), z)
+            z_q = z_flat + (zq - z_flat).detach()
+        else:
+            loss = self.beta * ops.sum_scale(row_sqerr, 1.0 / (n * d))
+            z_q = zq_ste
+        z_q = z_q.view(b, h, w, c).permute(0, 3, 1, 2)
+        return z_q, loss, encoding_indices
+
+    def _stats(self, zd, idx):
+        """bins [K] and embed_sum [K, D] as views of ONE buffer [embed_sum | bins] so a single
+        all-reduce covers both (embed_sum first keeps it 16-byte aligned)."""
+        from . import _lib
+        n, d = zd.shape
+        k = self.num_tokens
+        stats = torch.empty(k * (d + 1), dtype=torch.float32, device=zd.device)
+        embed_sum = stats[: k * d].view(k, d)
+        bins = stats[k * d:]
+        lib = _lib.load()
+        ws = torch.empty(max(lib.medtok_ema_stats_workspace_bytes(n, k), 256), dtype=torch.uint8, device=zd.device)
+        with torch.cuda.device(zd.device):
+            _lib.check(lib.medtok_ema_stats_f32(zd.data_ptr(), idx.data_ptr(), n, d, k, bins.data_ptr(),
+                                                embed_sum.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                torch.cuda.current_stream(zd.device).cuda_stream),
+                       "medtok_ema_stats_f32")
+        return bins, embed_sum, stats

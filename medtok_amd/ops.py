@@ -75,8 +75,9 @@ def topk_search(xhat, xsq, what, wsq, topk: int, path: int = PATH_AUTO):
     return idx, dist
 
 
-def soft_assign(xref, what, idx, dist, hard: bool = False, want_w: bool = True, want_sqerr: bool = True):
-    """(w [n,k], zq_ste [n,d], row_sqerr [n])."""
+def soft_assign(xref, what, idx, dist, hard: bool = False, want_w: bool = True, want_sqerr: bool = True,
+                raw: bool = False):
+    """(w [n,k], zq [n,d], row_sqerr [n]); zq is the straight-through value unless raw."""
     xref, what = _dev(xref, "xref"), _dev(what, "what")
     idx = _dev(idx, "idx", torch.int64)
     n, d = xref.shape
@@ -88,7 +89,7 @@ def soft_assign(xref, what, idx, dist, hard: bool = False, want_w: bool = True, 
     se = torch.empty(n, dtype=torch.float32, device=xref.device) if want_sqerr else None
     with torch.cuda.device(xref.device):
         _lib.check(lib.medtok_soft_assign_f32(xref.data_ptr(), what.data_ptr(), idx.data_ptr(), _ptr(dist), n, d, topk,
-                                              int(hard), _ptr(w), zq.data_ptr(), _ptr(se), _stream(xref)),
+                                              int(hard) | (2 if raw else 0), _ptr(w), zq.data_ptr(), _ptr(se), _stream(xref)),
                    "medtok_soft_assign_f32")
     return w, zq, se
 
@@ -118,6 +119,18 @@ def ema_stats(zhat, idx, k_codes: int):
                                             es.data_ptr(), ws.data_ptr(), ws.numel(), _stream(zhat)),
                    "medtok_ema_stats_f32")
     return bins, es
+
+
+def code_histogram(idx, k_codes: int) -> torch.Tensor:
+    """bins [K] fp32: number of rows assigned to each code (exact)."""
+    idx = _dev(idx.reshape(-1), "idx", torch.int64)
+    lib = _lib.load()
+    bins = torch.empty(k_codes, dtype=torch.float32, device=idx.device)
+    ws = _ws(lib.medtok_code_histogram_workspace_bytes(k_codes), idx)
+    with torch.cuda.device(idx.device):
+        _lib.check(lib.medtok_code_histogram_f32(idx.data_ptr(), idx.numel(), k_codes, bins.data_ptr(), ws.data_ptr(),
+                                                 ws.numel(), _stream(idx)), "medtok_code_histogram_f32")
+    return bins
 
 
 def ema_apply_(E, cluster_size, bins, embed_sum, decay: float) -> None:

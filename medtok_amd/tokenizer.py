@@ -1,0 +1,198 @@
+"""Quantise call sites of MedTok's tokenizer on MI355X.
+
+Covers what SURVEY.md section 8 puts on the hot path from the reference's
+MedTok/tokenizer.py: the construction of the quantiser (:124-126), quant()
+(:160-200), the eval-branch assembly of (embedding, tokens, weights) (:229-247)
+and tokenize() (:249-277) -- plus the README surface .tokenize/.encode/.embed
+keyed by medical-code strings (README.md:49-53,94-96), which the reference
+repository itself does not contain.
+
+The BERT text encoder and the GCN graph encoder are upstream of the path and
+out of scope: MultimodalTokenizer takes them as callables (any nn.Module with
+the documented signatures) or, when they are absent, reads pre-computed encoder
+outputs from the input object.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .vector_quantization_soft_one_new import VectorQuantizer
+
+
+def global_mean_pool(x: torch.Tensor, batch: torch.Tensor, size: Optional[int] = None) -> torch.Tensor:
+    """Per-graph mean of node features (what torch_geometric's helper of the same
+    name computes at tokenizer.py:216,218)."""
+    size = int(batch.max()) + 1 if size is None else size
+    out = x.new_zeros(size, x.shape[-1]).index_add_(0, batch, x)
+    cnt = torch.bincount(batch, minlength=size).clamp(min=1).to(x.dtype)
+    return out / cnt.unsqueeze(-1)
+
+
+class MultimodalTokenizer(nn.Module):
+    """text encoder + graph encoder -> soft VQ (reference tokenizer.py:47-277).
+
+    text_encoder(input_ids, attention_mask) -> [B, L, text_dim] token features
+    graph_encoder(x, edge_index, rel_index) -> [sum n_i, graph_dim] node features
+    Either may be None; then `inputs.text_features` / `inputs.graph_node_features`
+    (and the *_aug variants in training) must hold those tensors already.
+    """
+
+    def __init__(self, text_encoder: Optional[Callable] = None, graph_encoder: Optional[Callable] = None,
+                 text_dim: int = 768, graph_out_channels: int = 64, codebook_size: int = 21000,
+                 codebook_embed_dim: int = 64, codebook_l2_norm: bool = True, codebook_show_usage: bool = True,
+                 commit_loss_beta: float = 0.25, entropy_loss_ratio: float = 0.0, use_kmeans: bool = False,
+                 k: int = 5):
+        super().__init__()
+        self.text_model = text_encoder
+        self.graph_encoder = graph_encoder
+        self.text_code_dim = text_dim
+        self.vqgraph_code_dim = codebook_embed_dim
+        self.code_dim = 2 * codebook_embed_dim
+        self.embed_dim = self.code_dim
+        self.codebook_size = codebook_size
+        self.n_embed = codebook_size
+        # tokenizer.py:118: text features are mapped to the graph width before quantisation
+        self.text_mapped = nn.Linear(text_dim, graph_out_channels)
+        if graph_out_channels != codebook_embed_dim:
+            raise ValueError("graph_out_channels must equal codebook_embed_dim (the reference splits h in two "
+                             "e_dim halves, tokenizer.py:126)")
+        self.quantize = VectorQuantizer(n_e=codebook_size, e_dim=codebook_embed_dim, beta=commit_loss_beta,
+                                        entropy_loss_ratio=entropy_loss_ratio, l2_norm=codebook_l2_norm,
+                                        show_usage=codebook_show_usage,
+                                        split=[codebook_embed_dim, codebook_embed_dim], kmeans=use_kmeans, k=k)
+
+    # ---------------------------------------------------------------- encoders (pluggable)
+    def tokenize_text(self, inputs, aug=False):
+        if self.text_model is None:
+            return inputs.text_features_aug if aug and hasattr(inputs, "text_features_aug") else inputs.text_features
+        with torch.no_grad():
+            out = self.text_model(inputs.input_ids, inputs.attention_mask)
+        return getattr(out, "last_hidden_state", out)
+
+    def tokenize_graph(self, inputs, aug=False):
+        if self.graph_encoder is None:
+            return (inputs.graph_node_features_aug if aug and hasattr(inputs, "graph_node_features_aug")
+                    else inputs.graph_node_features)
+        edge = inputs.edge_index_aug if aug else inputs.edge_index
+        rel = inputs.rel_index_aug if aug else inputs.rel_index
+        out = self.graph_encoder(inputs.x, edge, rel)
+        return out[-1] if isinstance(out, (list, tuple)) else out
+
+    # ---------------------------------------------------------------- the quantise call site
+    def quant(self, text_features, graph_node_features, graph_features, text_features_aug, graph_node_features_aug,
+              graph_features_aug, text_attention_mask, batch):
+        """h = [CLS text feature | pooled graph feature] -> VectorQuantizer.forward (reference :160-200)."""
+        h = torch.cat((text_features[:, 0, :], graph_features), dim=-1)
+        h_aug = None
+        if text_features_aug is not None and graph_features_aug is not None:
+            h_aug = torch.cat((text_features_aug[:, 0, :], graph_features_aug), dim=-1)
+        return self.quantize(h, text_features, graph_node_features, text_attention_mask, batch, h_aug)
+
+    @staticmethod
+    def assemble(quantized_result):
+        """(embedding [B, 4*e_dim], tokens [B, 4, k] int64, weights [B, 4, k]) in the order
+        text, graph, shared_text, shared_graph (reference :229-247, inference.py:110)."""
+        r = quantized_result
+        tokens = torch.cat((r["text_tokens"], r["graph_tokens"], r["shared_text_tokens"], r["shared_graph_tokens"]), dim=-1)
+        weights = torch.cat((r["text_tokens_weights"], r["graph_tokens_weights"], r["shared_text_tokens_weights"],
+                             r["shared_graph_tokens_weights"]), dim=-1)
+        tokens = tokens.view(-1, 4, tokens.size(-1) // 4)
+        weights = weights.view(-1, 4, weights.size(-1) // 4)
+        embedding = torch.cat((r["specific_embedding_text"], r["specific_embedding_graph"],
+                               r["shared_text_embedding"], r["shared_graph_embedding"]), dim=-1)
+        return embedding, tokens, weights
+
+    def forward(self, inputs):
+        batch = inputs.batch
+        mask = inputs.attention_mask
+        bsz = mask.shape[0]
+        text = self.text_mapped(self.tokenize_text(inputs))
+        nodes = self.tokenize_graph(inputs)
+        pooled = global_mean_pool(nodes, batch, bsz)
+        text_aug = nodes_aug = pooled_aug = None
+        if self.training:
+            text_aug = self.text_mapped(self.tokenize_text(inputs, aug=True))
+            nodes_aug = self.tokenize_graph(inputs, aug=True)
+            pooled_aug = global_mean_pool(nodes_aug, batch, bsz)
+        result = self.quant(text, nodes, pooled, text_aug, nodes_aug, pooled_aug, mask, batch)
+        if self.training:
+            return result
+        return self.assemble(result)
+
+    @torch.no_grad()
+    def tokenize(self, inputs):
+        """Quantised multimodal embedding [B, 4*e_dim] (the evident intent of reference :249-277)."""
+        was_training = self.training
+        self.eval()
+        try:
+            embedding, _, _ = self.forward(inputs)
+        finally:
+            self.train(was_training)
+        return embedding
+
+
+def make_inputs(**kw) -> SimpleNamespace:
+    """Small stand-in for the PyG Batch object the reference passes around."""
+    return SimpleNamespace(**kw)
+
+
+class MedTokLookup:
+    """README surface: tokenizer.tokenize / .encode / .embed keyed by medical-code strings.
+
+    Backed by the three arrays inference.py writes (:136-138): embeddings_all.npy
+    [num_codes, 4*e_dim] fp32, tokens_all.npy [num_codes, 4, k] int64, weights_all.npy
+    [num_codes, 4, k] fp32, with rows in the order of `codes` (dataset_creator.py:255,273
+    orders them by the med_code table).
+    """
+
+    def __init__(self, codes: Sequence[str], embeddings: np.ndarray, tokens: np.ndarray, weights: np.ndarray,
+                 region_offsets: Sequence[int] = (0, 0, 0, 0)):
+        if not (len(codes) == embeddings.shape[0] == tokens.shape[0] == weights.shape[0]):
+            raise ValueError("codes / embeddings / tokens / weights disagree on the number of codes")
+        self.codes = list(codes)
+        self.row = {c: i for i, c in enumerate(self.codes)}
+        self.embeddings, self.tokens, self.weights = embeddings, tokens, weights
+        self.region_offsets = np.asarray(region_offsets, dtype=np.int64).reshape(1, 4, 1)
+
+    @classmethod
+    def from_dir(cls, path, codes: Sequence[str], region_offsets=(0, 0, 0, 0)):
+        from pathlib import Path
+        p = Path(path)
+        return cls(codes, np.load(p / "embeddings_all.npy"), np.load(p / "tokens_all.npy"),
+                   np.load(p / "weights_all.npy"), region_offsets)
+
+    def _rows(self, code):
+        single = isinstance(code, str)
+        keys = [code] if single else list(code)
+        try:
+            rows = np.array([self.row[c] for c in keys], dtype=np.int64)
+        except KeyError as e:
+            raise KeyError(f"unknown medical code {e.args[0]!r}") from None
+        return rows, single
+
+    def tokenize(self, code):
+        """Token ids of a code: [4, k] (text, graph, shared-text, shared-graph), global codebook rows."""
+        rows, single = self._rows(code)
+        out = self.tokens[rows] + self.region_offsets
+        return out[0] if single else out
+
+    def encode(self, code):
+        """Flat id sequence [4*k] plus the soft-assignment weights."""
+        rows, single = self._rows(code)
+        ids = (self.tokens[rows] + self.region_offsets).reshape(len(rows), -1)
+        w = self.weights[rows].reshape(len(rows), -1)
+        return (ids[0], w[0]) if single else (ids, w)
+
+    def embed(self, code):
+        """Quantised embedding [4*e_dim]."""
+        rows, single = self._rows(code)
+        out = self.embeddings[rows]
+        return out[0] if single else out
+
+    def __len__(self):
+        return len(self.codes)

@@ -167,12 +167,14 @@ int oracle_distance_f32(const float *xhat, const float *xsq, int64_t n,
  * forward value, vector_quantization_soft_one_new.py:181-182,214);
  * row_sqerr[r] = sum_i (zq - xref)^2 (the un-normalised numerator of the vq
  * and commitment losses, :169-173,208-209).
- * hard != 0 selects the NormEMA form (topk==1, w=1, zq = what[idx]). */
+ * flags bit0 selects the NormEMA form (topk==1, w=1, zq = what[idx]);
+ * bit1 stores zq itself instead of the straight-through value. */
 int oracle_soft_assign_f32(const float *xref, const float *what,
                            const int64_t *idx, const float *dist, int64_t n,
-                           int d, int topk, int hard, float *w, float *zq_ste,
+                           int d, int topk, int flags, float *w, float *zq_ste,
                            float *row_sqerr)
 {
+    const int hard = flags & 1, raw = flags & 2;
     if (topk < 1 || topk > ORACLE_MAX_TOPK) return -1;
     for (int64_t r = 0; r < n; ++r) {
         float wj[ORACLE_MAX_TOPK];
@@ -192,7 +194,7 @@ int oracle_soft_assign_f32(const float *xref, const float *what,
             else for (int j = 0; j < topk; ++j) acc = fmaf(wj[j], what[idx[r * topk + j] * d + i], acc);
             float xr = xref[r * d + i];
             float diff = acc - xr;
-            if (zq_ste) zq_ste[r * d + i] = xr + diff;
+            if (zq_ste) zq_ste[r * d + i] = raw ? acc : xr + diff;
             se += (double)diff * (double)diff;
         }
         if (row_sqerr) row_sqerr[r] = (float)se;

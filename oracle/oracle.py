@@ -91,7 +91,7 @@ def distance(xhat, xsq, what, wsq):
     return out
 
 
-def soft_assign(xref, what, idx, dist, hard=False):
+def soft_assign(xref, what, idx, dist, hard=False, raw=False):
     """softmax(-d) weights, weighted code mix, STE value, row squared error
     (vector_quantization_soft_one_new.py:158-182,204-214; hard=True is
     norm_ema_quantizer.py:181,212-214)."""
@@ -101,7 +101,7 @@ def soft_assign(xref, what, idx, dist, hard=False):
     w = np.empty((n, topk), np.float32)
     zq = np.empty((n, d), np.float32)
     se = np.empty(n, np.float32)
-    rc = lib().oracle_soft_assign_f32(xp, wp, ip, dp, C.c_int64(n), d, topk, int(bool(hard)),
+    rc = lib().oracle_soft_assign_f32(xp, wp, ip, dp, C.c_int64(n), d, topk, int(bool(hard)) | (2 if raw else 0),
                                       w.ctypes.data_as(_f32p), zq.ctypes.data_as(_f32p),
                                       se.ctypes.data_as(_f32p))
     assert rc == 0

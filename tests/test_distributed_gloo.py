@@ -1,0 +1,61 @@
+"""CPU, 2 processes over gloo: the N>1 path (row shards + one all-reduce of the EMA statistics).
+
+The kernels cannot run here, so each rank computes its shard's statistics with the oracle; what is
+under test is the host logic in medtok_amd/distributed.py: the row partition, the fused
+[embed_sum | bins] all-reduce, and that every rank ends with the same codebook as a single process
+(tolerance 1e-6: fp32 partial sums are associated differently)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n, k, d, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from medtok_amd import distributed as D
+    from oracle import oracle as O
+    r, _, w = D.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal((n, d), dtype=np.float32)
+    E0 = O.rownorm(rng.standard_normal((k, d), dtype=np.float32))[0]
+    lo, hi = D.row_shard(n, rank, world)
+    zh, zs = O.rownorm(z[lo:hi])
+    _, es = O.rownorm(E0, False)
+    idx, _ = O.topk_search(zh, zs, E0, es, 1)
+    bins, esum = O.ema_stats(zh, idx[:, 0], k)
+    stats = torch.from_numpy(np.concatenate([esum.reshape(-1), bins]))
+    D.all_reduce_stats(stats)
+    esum_g = stats[: k * d].view(k, d).numpy().copy(); bins_g = stats[k * d:].numpy().copy()
+    E, cs = E0.copy(), np.zeros(k, np.float32)
+    O.ema_apply(E, cs, bins_g, esum_g, 0.99)
+    ids_all = D.gather_rows(torch.from_numpy(idx[:, 0]), n).numpy()
+    slow = D.max_over_ranks(float(rank + 1), torch.device("cpu"))
+    D.barrier()
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), E=E, cs=cs, ids=ids_all, slow=slow)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_ema_step_equals_single_process(tmp_path, oracle):
+    n, k, d, world = 1001, 64, 32, 2
+    mp.spawn(_worker, args=(world, _free_port(), n, k, d, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal((n, d), dtype=np.float32)
+    E = oracle.rownorm(rng.standard_normal((k, d), dtype=np.float32))[0]
+    cs = np.zeros(k, np.float32)
+    _, _, ids = oracle.norm_ema_forward(z, E, cs, 0.25, 0.99, True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    assert np.array_equal(r0["ids"], ids) and np.array_equal(r1["ids"], ids)      # ids: bit-exact
+    assert np.array_equal(r0["E"], r1["E"]) and np.array_equal(r0["cs"], r1["cs"])  # ranks agree exactly
+    assert np.array_equal(r0["cs"], cs)                                           # integer counts: exact
+    assert np.abs(r0["E"] - E).max() <= 1e-6
+    assert float(r0["slow"]) == 2.0 == float(r1["slow"])

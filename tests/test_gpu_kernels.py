@@ -93,9 +93,14 @@ def test_soft_assign(oracle, dev, n, k, d, topk, hard):
     ii = idx[:, 0] if hard else idx
     w_o, zq_o, se_o = oracle.soft_assign(xref, wh, ii, dist, hard)
     w, zq, se = ops.soft_assign(_t(xref, dev), _t(wh, dev), _t(ii, dev), _t(dist, dev), hard)
-    # tolerance: 1e-5 relative (north_star); expf differs from glibc by <= 2 ulp
+    # tolerance: 1e-5 relative (north_star).  expf differs from glibc by <= 2 ulp, and the
+    # straight-through form x + (zq - x) re-rounds at ulp(|x|), which is larger than ulp(|zq|).
     assert rel(w.cpu().numpy(), w_o) <= 1e-6
-    assert rel(zq.cpu().numpy(), zq_o) <= 1e-6
+    assert rel(zq.cpu().numpy(), zq_o) <= 1e-5
+    if not hard:
+        _, zr_o, _ = oracle.soft_assign(xref, wh, ii, dist, hard, raw=True)
+        _, zr, _ = ops.soft_assign(_t(xref, dev), _t(wh, dev), _t(ii, dev), _t(dist, dev), hard, raw=True)
+        assert rel(zr.cpu().numpy(), zr_o) <= 1e-6
     assert np.allclose(se.cpu().numpy(), se_o, rtol=1e-5, atol=0)
     if hard:
         assert np.array_equal(zq.cpu().numpy(), zq_o)
@@ -174,7 +179,7 @@ def test_soft_vq_forward_one_call(oracle, dev):
     assert np.array_equal(r["idx"].cpu().numpy(), r_o["idx"])
     assert np.array_equal(r["dist"].cpu().numpy(), r_o["dist"])
     assert np.array_equal(r["xhat"].cpu().numpy(), r_o["xhat"])
-    assert rel(r["zq"].cpu().numpy(), r_o["zq"]) <= 1e-6
+    assert rel(r["zq"].cpu().numpy(), r_o["zq"]) <= 1e-5
     assert rel(r["w"].cpu().numpy(), r_o["w"]) <= 1e-6
 
 

@@ -1,0 +1,156 @@
+"""CPU: host-side mirror of the reference interfaces (no kernel launches)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+
+
+def rel(a, b):
+    a = a.detach().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_state_dict_keys_match_reference(golden):
+    from medtok_amd.norm_ema_quantizer import NormEMAVectorQuantizer
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    q = NormEMAVectorQuantizer(64, 32, 0.25)
+    assert sorted(q.state_dict().keys()) == list(golden("f5_normema_d32")["state_dict_keys"])
+    v = VectorQuantizer(96, 16, 0.25, 0.0, True, True, [16, 16])
+    keys = set(v.state_dict().keys())
+    want = {"codebook.weight", "codebook_used", "proj_text.weight", "proj_text.bias", "proj_graph.weight", "proj_graph.bias"}
+    for i in (0, 1):
+        for leaf in ("multihead_attn.in_proj_weight", "multihead_attn.in_proj_bias", "multihead_attn.out_proj.weight",
+                     "multihead_attn.out_proj.bias", "layer_norm.weight", "layer_norm.bias"):
+            want.add(f"cross_attn.model.{i}.{leaf}")
+    assert keys == want                      # SURVEY.md section 5 "Checkpoint" row, probed on the reference
+    assert v.state_dict()["codebook.weight"].shape == (96, 16)
+    assert v.state_dict()["codebook_used"].shape == (300000,)
+    assert torch.allclose(q.embedding.weight.norm(dim=-1), torch.ones(64), atol=1e-6)   # l2norm(randn) init (:69-70)
+    assert float(q.embedding.initted) == 1.0 and q.embedding.update is True
+
+
+def test_constructor_signatures_match_reference():
+    import inspect
+    from medtok_amd.norm_ema_quantizer import EmbeddingEMA, NormEMAVectorQuantizer
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    assert list(inspect.signature(VectorQuantizer.__init__).parameters)[1:] == [
+        "n_e", "e_dim", "beta", "entropy_loss_ratio", "l2_norm", "show_usage", "split", "kmeans", "num_head", "k"]
+    assert list(inspect.signature(NormEMAVectorQuantizer.__init__).parameters)[1:] == [
+        "n_embed", "embedding_dim", "beta", "decay", "eps", "statistic_code_usage", "kmeans_init", "codebook_init_path"]
+    assert list(inspect.signature(EmbeddingEMA.__init__).parameters)[1:] == [
+        "num_tokens", "codebook_dim", "decay", "eps", "kmeans_init", "codebook_init_path"]
+    assert list(inspect.signature(VectorQuantizer.forward).parameters)[1:] == [
+        "z", "text_features", "graph_node_features", "text_attention_mask", "batch", "z_aug"]
+
+
+def test_losses_match_reference_fixture(golden):
+    from medtok_amd import loss as L
+    g = golden("f7_losses")
+    t = {k: torch.from_numpy(g[k]).requires_grad_(True) for k in ("z1", "z2", "x1", "x2", "z1_aug", "z2_aug", "z1_c", "z2_c")}
+    s = L.shared_loss(t["z1_c"], t["z2_c"], t["x1"], t["x2"])
+    p = L.specific_loss(t["z1"], t["z1_aug"], t["z2"], t["z2_aug"], t["z1_c"], t["z2_c"])
+    assert rel(torch.stack(s), g["shared"]) <= 1e-5
+    assert rel(torch.stack(p), g["specific"]) <= 1e-5
+    total = torch.tensor(float(g["codebook_loss"])) + (s[0] - 0.1 * s[1]) + (s[2] - 0.1 * s[3]) + (p[0] + 0.1 * p[1]) + (p[2] + 0.1 * p[3])
+    assert abs(float(total) - float(g["total"])) <= 1e-5 * abs(float(g["total"]))
+    total.backward()
+    for k, v in t.items():
+        assert rel(v.grad, g[f"grad.{k}"]) <= 2e-5, k
+    assert abs(float(L.info_nce_loss(t["z1"], t["z2"])) - float(g["nce_z1_z2"])) <= 1e-5 * float(g["nce_z1_z2"])
+    assert abs(float(L.alignment_loss(t["x1"], t["x2"])) - float(g["align"])) <= 1e-5 * abs(float(g["align"]))
+    assert abs(float(L.orthogonal_loss(t["z1"], t["z1_c"])) - float(g["orth"])) <= 1e-5 * float(g["orth"])
+
+
+def test_total_loss_assembly(golden):
+    from medtok_amd import loss as L
+    g = golden("f7_losses")
+    t = {k: torch.from_numpy(g[k]) for k in ("z1", "z2", "x1", "x2", "z1_aug", "z2_aug", "z1_c", "z2_c")}
+    c = torch.tensor(float(g["codebook_loss"]) / 6)
+    r = {"shared_embed_loss": (c, c), "text_specific_loss": (c, c), "graph_specific_loss": (c, c),
+         "shared_text_embedding": t["z1_c"], "shared_graph_embedding": t["z2_c"], "text_feature": t["x1"], "graph_feature": t["x2"],
+         "specific_embedding_text": t["z1"], "specific_embedding_text_aug": t["z1_aug"],
+         "specific_embedding_graph": t["z2"], "specific_embedding_graph_aug": t["z2_aug"]}
+    loss, parts = L.total_loss(r)
+    assert abs(float(loss) - float(g["total"])) <= 1e-5 * abs(float(g["total"]))
+    assert set(parts) >= {"codebook_loss", "shared_loss", "specific_loss"}
+
+
+@pytest.mark.parametrize("name", ["f3_forward_d64", "f4_forward_d128"])
+def test_batched_cross_attention_equals_reference_loop(golden, name):
+    """CrossAttention.pooled (batched) vs the reference's per-code loop outputs (fixture)."""
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    g = golden(name)
+    D, n_e = int(g["e_dim"]), int(g["n_e"])
+    v = VectorQuantizer(n_e, D, 0.25, 0.0, True, True, [D, D])
+    v.load_state_dict(synth.det_state_dict(v, name, int(g["seed"])), strict=True)
+    v.eval()
+    with torch.no_grad():
+        pt, pg = v.cross_attn.pooled(torch.from_numpy(g["text"]), torch.from_numpy(g["mask"]),
+                                     torch.from_numpy(g["nodes"]), torch.from_numpy(g["batch"]))
+    assert rel(pt, g["pooled_text"]) <= 1e-5
+    assert rel(pg, g["pooled_graph"]) <= 1e-5
+    # shuffled node order must not matter (nodes of a code need not be contiguous)
+    perm = torch.randperm(g["nodes"].shape[0], generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        pt2, pg2 = v.cross_attn.pooled(torch.from_numpy(g["text"]), torch.from_numpy(g["mask"]),
+                                       torch.from_numpy(g["nodes"])[perm], torch.from_numpy(g["batch"])[perm])
+    assert rel(pt2, g["pooled_text"]) <= 1e-5 and rel(pg2, g["pooled_graph"]) <= 1e-5
+
+
+def test_regions_match_reference_slicing():
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    v = VectorQuantizer(21000, 64, 0.25, 0.0, True, False, [64, 64])
+    assert v._region("text") == (0, 7000) and v._region("graph") == (14000, 21000) and v._region("shared") == (0, 21000)
+    v = VectorQuantizer(8192, 64, 0.25, 0.0, True, False, [64, 64])
+    assert v._region("text") == (0, 2730) and v._region("graph") == (8192 - 2730, 8192)
+    assert torch.equal(v.global_token_ids(torch.tensor([0, 5]), "graph"), torch.tensor([5462, 5467]))
+
+
+def test_no_cpu_fallback():
+    from medtok_amd import _lib
+    from medtok_amd.norm_ema_quantizer import NormEMAVectorQuantizer
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    v = VectorQuantizer(96, 16, 0.25, 0.0, True, True, [16, 16]).eval()
+    with pytest.raises(_lib.MedTokLibraryError):
+        v.specific_embedding(torch.randn(4, 16), "text")
+    q = NormEMAVectorQuantizer(64, 32, 0.25)
+    with pytest.raises(_lib.MedTokLibraryError):
+        q(torch.randn(8, 32, 1, 1))
+
+
+def test_row_shard_partition():
+    from medtok_amd.distributed import row_shard
+    for n in (0, 1, 7, 600000, 600001):
+        for world in (1, 2, 3, 8):
+            parts = [row_shard(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_lookup_tokenizer_surface(tmp_path):
+    from medtok_amd.inference import save_outputs
+    from medtok_amd.tokenizer import MedTokLookup
+    codes = ["E11.9", "I10", "J45.909"]
+    emb = np.arange(3 * 8, dtype=np.float32).reshape(3, 8)
+    tok = np.arange(3 * 4 * 5, dtype=np.int64).reshape(3, 4, 5)
+    w = np.full((3, 4, 5), 0.2, np.float32)
+    save_outputs(tmp_path, emb, tok, w)
+    lk = MedTokLookup.from_dir(tmp_path, codes, region_offsets=(0, 100, 0, 0))
+    assert lk.tokenize("I10").shape == (4, 5) and lk.tokenize("I10")[1, 0] == tok[1, 1, 0] + 100
+    ids, ws = lk.encode("E11.9")
+    assert ids.shape == (20,) and ws.shape == (20,)
+    assert np.array_equal(lk.embed(["J45.909", "E11.9"]), emb[[2, 0]])
+    with pytest.raises(KeyError):
+        lk.embed("nope")
+    assert np.load(tmp_path / "tokens_all.npy").dtype == np.int64
+
+
+def test_global_mean_pool():
+    from medtok_amd.tokenizer import global_mean_pool
+    x = torch.tensor([[1.0, 2], [3, 4], [5, 6]])
+    out = global_mean_pool(x, torch.tensor([0, 0, 2]), 3)
+    assert torch.equal(out, torch.tensor([[2.0, 3], [0, 0], [5, 6]]))
