@@ -1,0 +1,273 @@
+"""GPU: the drop-in classes against golden vectors produced by the reference's own classes.
+
+Bar (BASELINE.json:north_star): token ids bit-exact, floats within 1e-5 relative.  Every fixture
+row carries its fp64 top-(k+1) gap; the fixtures were generated so that no row is a near-tie
+(asserted), hence ids must match on every row."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def same_ids(a, b):
+    return np.array_equal(a.cpu().numpy(), np.asarray(b))
+
+
+def make_vq(name, g, dev, dropout_off=True):
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    D, n_e = int(g["e_dim"]), int(g["n_e"])
+    v = VectorQuantizer(n_e, D, float(g["beta"]), 0.0, True, True, [D, D], k=int(g["k"]))
+    v.load_state_dict(synth.det_state_dict(v, name, int(g["seed"])), strict=True)
+    if dropout_off:
+        for layer in v.cross_attn.model:
+            layer.multihead_attn.dropout = 0.0
+            layer.dropout.p = 0.0
+    return v.to(dev)
+
+
+@pytest.mark.parametrize("name", ["f1_specific_d64", "f2_specific_d768"])
+def test_specific_embedding_eval_and_train(golden, dev, name):
+    g = golden(name)
+    v = make_vq(name, g, dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    N = x.shape[0]
+    probe = synth.det_randn(name + ".probe", tuple(g["x"].shape), 1.0, int(g["seed"])).to(dev)
+    for t in ("text", "graph"):
+        assert np.diff(g[f"{t}.gap64"], axis=1).min() > 1e-6
+        v.eval()
+        v.codebook_used.zero_()
+        with torch.no_grad():
+            zq, (vq, cm, xhat, zq2), usage = v.specific_embedding(x, types=t)
+        idx, w = v._last_specific
+        assert same_ids(idx, g[f"{t}.idx"])
+        assert rel(w, g[f"{t}.w"]) <= RTOL
+        assert rel(zq, g[f"{t}.eval.zq"]) <= RTOL and zq2 is zq
+        assert rel(xhat, g[f"{t}.eval.xhat"]) <= RTOL
+        assert float(vq) == 0.0 and float(cm) == 0.0 and vq.device.type == "cpu"     # reference quirk (:210-212)
+        assert isinstance(usage, float)
+        # train: forward values + gradients through the sparse backward
+        v.train()
+        v.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        zq, (vq, cm, xhat, _), usage = v.specific_embedding(xg, types=t)
+        assert rel(zq, g[f"{t}.train.zq"]) <= RTOL
+        assert abs(float(vq) - float(g[f"{t}.train.vq"])) <= RTOL * float(g[f"{t}.train.vq"])
+        assert abs(float(cm) - float(g[f"{t}.train.commit"])) <= RTOL * float(g[f"{t}.train.commit"])
+        (vq + cm + (zq * probe).sum() / N).backward()
+        proj = v.proj_text if t == "text" else v.proj_graph
+        assert rel(xg.grad, g[f"{t}.train.grad_x"]) <= 1e-4
+        assert rel(v.codebook.weight.grad, g[f"{t}.train.grad_codebook"]) <= 1e-4
+        assert rel(proj.bias.grad, g[f"{t}.train.grad_proj_b"]) <= 1e-4
+        assert rel(proj.weight.grad[:8], g[f"{t}.train.grad_proj_w_head"]) <= 1e-4
+        assert rel(proj.weight.grad.double().sum(0), g[f"{t}.train.grad_proj_w_colsum"]) <= 1e-4
+        # train-mode forward without autograd takes the fused kernel path: same numbers
+        with torch.no_grad():
+            zq_f, (vq_f, cm_f, _, _), _ = v.specific_embedding(x, types=t)
+        assert rel(zq_f, g[f"{t}.train.zq"]) <= RTOL
+        assert abs(float(vq_f) - float(g[f"{t}.train.vq"])) <= RTOL * float(g[f"{t}.train.vq"])
+
+
+@pytest.mark.parametrize("name", ["f3_forward_d64", "f4_forward_d128"])
+def test_full_forward_dict(golden, dev, name):
+    g = golden(name)
+    v = make_vq(name, g, dev)
+    D = int(g["e_dim"])
+    z, z_aug = torch.from_numpy(g["z"]).to(dev), torch.from_numpy(g["z_aug"]).to(dev)
+    text, mask = torch.from_numpy(g["text"]).to(dev), torch.from_numpy(g["mask"]).to(dev)
+    nodes, batch = torch.from_numpy(g["nodes"]).to(dev), torch.from_numpy(g["batch"]).to(dev)
+    for s in ("shared_text", "shared_graph", "text", "graph"):
+        assert np.diff(g[f"{s}.gap64"], axis=1).min() > 1e-6
+    v.eval()
+    with torch.no_grad():
+        r = v(z, text, nodes, mask, batch, z_aug)
+    ref_keys = ["graph_feature", "text_feature", "shared_text_embedding", "shared_graph_embedding", "shared_embed_loss",
+                "shared_codebook_usage", "specific_embedding_text", "text_specific_loss", "text_specific_usage",
+                "specific_embedding_graph", "graph_specific_loss", "graph_specific_usage",
+                "specific_embedding_text_aug", "specific_embedding_graph_aug"]
+    assert list(r)[:14] == ref_keys                     # the reference's 14 keys, same order (:256-271)
+    for key in ("shared_text_embedding", "shared_graph_embedding", "specific_embedding_text", "specific_embedding_graph",
+                "specific_embedding_text_aug", "specific_embedding_graph_aug", "graph_feature", "text_feature"):
+        assert rel(r[key], g[f"eval.{key}"]) <= RTOL, key
+    assert len(r["shared_embed_loss"]) == 6 and len(r["text_specific_loss"]) == 4
+    for j in (2, 3, 4, 5):
+        assert rel(r["shared_embed_loss"][j], g[f"eval.shared_embed_loss.{j}"]) <= RTOL
+    for key in ("shared_codebook_usage", "text_specific_usage", "graph_specific_usage"):
+        assert isinstance(r[key], float) and r[key] == float(g[f"eval.{key}"]), key
+    for s, key in (("text", "text_tokens"), ("graph", "graph_tokens"), ("shared_text", "shared_text_tokens"), ("shared_graph", "shared_graph_tokens")):
+        assert same_ids(r[key], g[f"{s}.idx"]), key
+        assert rel(r[key + "_weights"], g[f"{s}.w"]) <= RTOL
+        assert r[key].dtype == torch.int64 and r[key].shape == (z.shape[0], int(g["k"]))
+    # z_aug=None -> aug entries are None
+    with torch.no_grad():
+        r2 = v(z, text, nodes, mask, batch)
+    assert r2["specific_embedding_text_aug"] is None and r2["specific_embedding_graph_aug"] is None
+
+    # ---- train mode (dropout disabled in both implementations): values and gradients
+    v.train()
+    v.codebook_used.zero_()
+    v.zero_grad()
+    zr, tr, nr = z.clone().requires_grad_(True), text.clone().requires_grad_(True), nodes.clone().requires_grad_(True)
+    r = v(zr, tr, nr, mask, batch, z_aug)
+    for key in ("shared_text_embedding", "shared_graph_embedding", "specific_embedding_text", "specific_embedding_graph"):
+        assert rel(r[key], g[f"train.{key}"]) <= RTOL, key
+    for lk, cnt in (("shared_embed_loss", 2), ("text_specific_loss", 2), ("graph_specific_loss", 2)):
+        for j in range(cnt):
+            assert abs(float(r[lk][j]) - float(g[f"train.{lk}.{j}"])) <= RTOL * abs(float(g[f"train.{lk}.{j}"])), (lk, j)
+    total = (r["shared_embed_loss"][0] + r["shared_embed_loss"][1] + r["text_specific_loss"][0] + r["text_specific_loss"][1]
+             + r["graph_specific_loss"][0] + r["graph_specific_loss"][1])
+    probe = synth.det_randn(name + ".probe", (z.shape[0], D), 1.0, int(g["seed"])).to(dev)
+    total = total + ((r["shared_text_embedding"] + r["shared_graph_embedding"] + r["specific_embedding_text"]
+                      + r["specific_embedding_graph"] + r["specific_embedding_text_aug"]) * probe).sum() / z.shape[0]
+    total.backward()
+    assert rel(zr.grad, g["train.grad_z"]) <= 1e-4
+    assert rel(tr.grad, g["train.grad_text"]) <= 1e-4
+    assert rel(nr.grad, g["train.grad_nodes"]) <= 1e-4
+    assert rel(v.codebook.weight.grad, g["train.grad_codebook"]) <= 1e-4
+    assert rel(v.cross_attn.model[0].multihead_attn.in_proj_weight.grad, g["train.grad_in_proj0"]) <= 1e-4
+    assert rel(v.proj_text.weight.grad, g["train.grad_proj_text_w"]) <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["f5_normema_d32", "f5_normema_d768", "f6_normema_zero_usage"])
+def test_norm_ema_quantizer(golden, dev, name):
+    from medtok_amd.norm_ema_quantizer import NormEMAVectorQuantizer
+    g = golden(name)
+    K, D = int(g["K"]), int(g["D"])
+    q = NormEMAVectorQuantizer(K, D, float(g["beta"]), float(g["decay"]))
+    q.embedding.weight.data.copy_(torch.from_numpy(g["E0"]))
+    q = q.to(dev)
+    q.train()
+    for s in range(int(g["steps"])):
+        assert np.diff(g[f"s{s}.gap64"], axis=1).min() > 1e-6
+        zr = torch.from_numpy(g[f"s{s}.z"]).to(dev).requires_grad_(True)
+        zq, loss, idx = q(zr[:, :, None, None])
+        assert zq.shape == (zr.shape[0], D, 1, 1) and idx.dtype == torch.int64 and idx.shape == (zr.shape[0],)
+        assert same_ids(idx, g[f"s{s}.idx"])
+        assert rel(zq[:, :, 0, 0], g[f"s{s}.zq"]) <= RTOL
+        assert abs(float(loss) - float(g[f"s{s}.loss"])) <= RTOL * float(g[f"s{s}.loss"])
+        assert rel(q.embedding.weight, g[f"s{s}.E"]) <= RTOL
+        assert rel(q.cluster_size, g[f"s{s}.cluster_size"]) <= RTOL
+        (loss + zq.square().sum() * 0.5).backward()
+        assert rel(zr.grad, g[f"s{s}.grad_z"]) <= 1e-4
+    # the EmbeddingEMA side state is never touched by forward
+    assert float(q.embedding.cluster_size.abs().sum()) == 0.0
+    q.eval()
+    with torch.no_grad():
+        zq, loss, idx = q(torch.from_numpy(g["eval.z"]).to(dev)[:, :, None, None])
+    assert same_ids(idx, g["eval.idx"])
+    assert rel(zq[:, :, 0, 0], g["eval.zq"]) <= RTOL
+    assert abs(float(loss) - float(g["eval.loss"])) <= RTOL * float(g["eval.loss"])
+    assert rel(q.embedding.weight, g["eval.E"]) <= RTOL
+    assert rel(q.cluster_size, g["eval.cluster_size"]) <= RTOL
+    # [b, c, h, w] with h*w > 1: rows are (b, h, w) positions
+    z4 = torch.from_numpy(g["eval.z"]).to(dev)[:24].reshape(2, 3, 4, D).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        zq4, _, idx4 = q(z4)
+    assert zq4.shape == z4.shape and same_ids(idx4, g["eval.idx"][:24])
+
+
+def test_config1_inference_1k_codes(golden, dev, tmp_path):
+    """BASELINE config 1: 1k synthetic codes, 768-d, K=8192, through the tokenizer call sites and the
+    inference driver; expected values come from the reference's VectorQuantizer on the same recipe."""
+    from medtok_amd.inference import run_inference
+    from medtok_amd.tokenizer import MedTokLookup, MultimodalTokenizer, make_inputs
+    name = "cfg1_inference_1k"
+    g = golden(name)
+    B, L, M, D, n_e, seed = int(g["B"]), int(g["L"]), int(g["max_nodes"]), int(g["e_dim"]), int(g["n_e"]), int(g["seed"])
+    tok = MultimodalTokenizer(text_dim=D, graph_out_channels=D, codebook_size=n_e, codebook_embed_dim=D)
+    tok.quantize.load_state_dict(synth.det_state_dict(tok.quantize, name, seed), strict=True)
+    tok = tok.to(dev).eval()
+    text, mask, nodes, batch = synth.ragged_batch(name + ".batch", B, L, M, D, seed)
+    z = synth.det_randn(name + ".z", (B, 2 * D), 1.0, seed)
+    with torch.no_grad():
+        r = tok.quantize(z.to(dev), text.to(dev), nodes.to(dev), mask.to(dev), batch.to(dev), None)
+    emb, tokens, weights = MultimodalTokenizer.assemble(r)
+    assert emb.shape == (B, 4 * D) and tokens.shape == (B, 4, 5) and weights.shape == (B, 4, 5)
+    want_tok = np.stack([g["text.idx"], g["graph.idx"], g["shared_text.idx"], g["shared_graph.idx"]], 1)
+    want_w = np.stack([g["text.w"], g["graph.w"], g["shared_text.w"], g["shared_graph.w"]], 1)
+    gaps = np.stack([np.diff(g[f"{s}.gap64"], axis=1).min(1) for s in ("text", "graph", "shared_text", "shared_graph")], 1)
+    safe = gaps > 1e-5                       # SURVEY H1 protocol: rows whose fp64 gap exceeds tau must match exactly
+    got = tokens.cpu().numpy()
+    assert safe.mean() > 0.99
+    assert np.array_equal(got[safe], want_tok[safe])
+    for b, s in zip(*np.nonzero(~safe)):     # near-ties: same set of ids
+        assert set(got[b, s]) == set(want_tok[b, s])
+    assert rel(weights.cpu().numpy()[safe], want_w[safe]) <= RTOL
+    assert rel(emb[:8], g["emb_head"]) <= RTOL
+    assert np.allclose(emb.double().sum(1).cpu().numpy(), g["emb_rowsum"], atol=1e-5 * np.abs(g["emb_abs_rowsum"]).max())
+    assert [r["shared_codebook_usage"], r["text_specific_usage"], r["graph_specific_usage"]] == list(g["usage"])
+    # driver: batches in shuffled order -> arrays ordered by code index; files as inference.py:136-138
+    order = torch.randperm(B, generator=torch.Generator().manual_seed(1))
+    batches = []
+    for chunk in order.split(256):
+        sel = torch.isin(batch, chunk)
+        remap = torch.full((B,), -1, dtype=torch.long); remap[chunk] = torch.arange(len(chunk))
+        batches.append(make_inputs(text_features=text[chunk].to(dev), attention_mask=mask[chunk].to(dev),
+                                   graph_node_features=nodes[sel].to(dev), batch=remap[batch[sel]].to(dev), code_indices=chunk))
+    tok.text_mapped.weight.data.copy_(torch.eye(D)); tok.text_mapped.bias.data.zero_()
+    e2, t2, w2 = run_inference(tok, batches, tmp_path)
+    assert e2.shape == (B, 4 * D) and np.load(tmp_path / "tokens_all.npy").shape == (B, 4, 5)
+    assert np.array_equal(t2[:, 2:][safe[:, 2:]], want_tok[:, 2:][safe[:, 2:]])      # shared searches: same inputs as the fixture
+    lk = MedTokLookup.from_dir(tmp_path, [f"code{i}" for i in range(B)])
+    assert np.array_equal(lk.tokenize("code7"), t2[7]) and lk.embed("code7").shape == (4 * D,)
+
+
+def test_quantize_pooled_equals_forward_searches(dev):
+    """The config-3 entry point (cross-attention bypassed) runs the same four searches forward() runs."""
+    from medtok_amd.inference import quantize_pooled
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    torch.manual_seed(0)
+    v = VectorQuantizer(3 * 512, 128, 0.25, 0.0, True, False, [128, 128]).to(dev).eval()
+    h = torch.randn(777, 256, device=dev); pt = torch.randn(777, 128, device=dev); pg = torch.randn(777, 128, device=dev)
+    emb, tok, w = quantize_pooled(v, h, pt, pg)
+    assert emb.shape == (777, 512) and tok.shape == (777, 4, 5) and w.shape == (777, 4, 5)
+    zq, _, _ = v.specific_embedding(h[:, :128], "text")
+    assert torch.equal(zq, emb[:, :128]) and torch.equal(v._last_specific[0], tok[:, 0])
+    assert int(tok[:, :2].max()) < 512 and int(tok[:, 2:].max()) < 1536
+    assert torch.allclose(w.sum(-1), torch.ones_like(w.sum(-1)), atol=1e-6)
+
+
+def test_search_properties_at_config2_size(dev):
+    """BASELINE config 2 size (N=100k, D=768, K=8192): size-independent properties instead of an oracle run."""
+    from medtok_amd import ops
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(100000, 768, generator=g).to(dev)
+    E = torch.nn.functional.normalize(torch.randn(8192, 768, generator=g), dim=-1).to(dev)
+    zh, zs = ops.rownorm(z)
+    _, es = ops.rownorm(E, normalize=False, want_xhat=False)
+    idx, dist = ops.topk_search(zh, zs, E, es, 1)
+    # (1) permuting rows permutes results
+    perm = torch.randperm(100000, generator=g).to(dev)
+    idx_p, dist_p = ops.topk_search(zh[perm].contiguous(), zs[perm].contiguous(), E, es, 1)
+    assert torch.equal(idx_p, idx[perm]) and torch.equal(dist_p, dist[perm])
+    # (2) scaling a row does not change its id
+    idx_s, _ = ops.topk_search(*ops.rownorm(z * 3.0), E, es, 1)
+    assert (idx_s != idx).float().mean().item() < 1e-4
+    # (3) top-1 of the top-5 search is the argmin; lists ascend
+    idx5, dist5 = ops.topk_search(zh, zs, E, es, 5)
+    assert torch.equal(idx5[:, :1], idx) and torch.equal(dist5[:, :1], dist)
+    assert bool((dist5[:, 1:] >= dist5[:, :-1]).all())
+    # (4) a row equal to a code finds that code at distance ~0
+    idx_e, dist_e = ops.topk_search(E, es, E, es, 1)
+    assert torch.equal(idx_e.view(-1), torch.arange(8192, device=dev)) and float(dist_e.abs().max()) < 1e-5
+    # (5) sampled rows agree with a dense fp64 evaluation
+    sel = torch.arange(0, 100000, 997, device=dev)
+    d64 = (zh[sel].double() ** 2).sum(1, keepdim=True) + (E.double() ** 2).sum(1) - 2 * zh[sel].double() @ E.double().t()
+    top2 = torch.topk(d64, 2, largest=False)
+    clear = (top2.values[:, 1] - top2.values[:, 0]) > 1e-5
+    assert torch.equal(idx[sel].view(-1)[clear], top2.indices[:, 0][clear])
+    # (6) EMA statistics: histogram sums to N, embed_sum row sums match a dense check on one code
+    bins, es_sum = ops.ema_stats(zh, idx.view(-1), 8192)
+    assert float(bins.sum()) == 100000.0
+    c = int(idx[0])
+    dense = zh[idx.view(-1) == c].double().sum(0)
+    assert float((es_sum[c].double() - dense).abs().max()) < 1e-5
