@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: codes/sec tokenized (text+graph embeddings -> VQ token ids) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2] [--rows R]
+
+Workload (BASELINE.json configs[2], the one the >= 600k codes/s target is quoted on): the full MedTok
+soft VQ -- per code 4 nearest-code searches (text / graph over their 16384-row codebook thirds, shared
+text / graph over all 49152 rows), top-5, softmax weights, weighted code mix, straight-through value --
+on R = 600000 synthetic codes per GPU, D = 768, fp32, cross-attention pooling already applied.
+A "step" is one pass of that path over the rank's R rows, inputs resident in HBM.  Rows are
+independent, so N GPUs run N row shards with no data-path collective ("weak" scaling: R per GPU).
+
+One JSON line on rank 0 (contract in the task statement) plus:
+  roofline      -- the dominant kernel (fp32-MFMA search) timed live with HIP events on its launch
+                   stream; achieved = algorithmic flops (2*rows*K*D per launch) / kernel time.
+  cpu_baseline  -- the reference's op sequence (oracle/torch_port.py, pinned to golden vectors) timed
+                   on this box's host cores on a bounded row sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from medtok_amd import distributed as mdist  # noqa: E402
+from medtok_amd import ops  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, dense f32-input MFMA
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["cfg3", "cfg2"], default="cfg3")
+    ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default 600000 for cfg3, 100000 for cfg2)")
+    ap.add_argument("--path", type=int, default=ops.PATH_AUTO)
+    ap.add_argument("--cpu-rows", type=int, default=None, help="row sample for the CPU baseline (0 disables)")
+    return ap.parse_args()
+
+
+class Cfg3:
+    """Full soft VQ, one codebook of n_e = 3 * 16384 rows (text third, middle, graph third)."""
+    name = "cfg3"
+    D, REGION, TOPK = 768, 16384, 5
+    N_E = 3 * REGION
+
+    def __init__(self, rows, dev, seed, path):
+        from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+        self.rows, self.dev = rows, dev
+        D = self.D
+        torch.manual_seed(1234)                                                   # same weights on every rank
+        self.vq = VectorQuantizer(self.N_E, D, 0.25, 0.0, True, False, [D, D], k=self.TOPK).to(dev).eval()
+        self.vq.search_path = path
+        g = torch.Generator(device=dev).manual_seed(seed)
+        self.h = torch.randn(rows, 2 * D, device=dev, generator=g)              # [CLS text | pooled graph] (tokenizer.py:162-166)
+        self.pooled_text = torch.randn(rows, D, device=dev, generator=g)        # cross-attention outputs (bypassed; stated)
+        self.pooled_graph = torch.randn(rows, D, device=dev, generator=g)
+        self.description = (f"cfg3 full MedTok soft-VQ: {rows} codes/GPU x 4 searches (2 x K=16384 regions + 2 x K=49152 shared), "
+                            f"D=768, k=5, eval, fp32; proj Linear + normalise + search + softmax/mix/STE per code")
+
+    def flops_per_code(self):
+        return 2.0 * self.D * (2 * self.REGION + 2 * self.N_E)
+
+    def step(self):
+        from medtok_amd.inference import quantize_pooled
+        self.vq._norm_cache = None      # re-normalise the codebook every call, like the reference (:148,198,200)
+        return quantize_pooled(self.vq, self.h, self.pooled_text, self.pooled_graph)
+
+    def cpu_baseline(self, sample_rows):
+        """Reference op sequence on the host cores, `sample_rows` rows of this workload."""
+        from oracle import torch_port as P
+        torch.set_num_threads(os.cpu_count() or 1)
+        g = torch.Generator().manual_seed(0)
+        D = self.D
+        W = torch.randn(self.N_E, D, generator=g)
+        xs = [torch.randn(sample_rows, D, generator=g) for _ in range(4)]
+        P.full_tokenize(*[x[:256] for x in xs], W, self.TOPK)          # warm-up
+        t0 = time.perf_counter()
+        P.full_tokenize(*xs, W, self.TOPK)
+        dt = time.perf_counter() - t0
+        return dict(value=sample_rows / dt, unit="codes/s", cores=torch.get_num_threads(), kind="port",
+                    sample=f"{sample_rows} codes of the same workload (4 searches each, K=16384/49152, D=768), "
+                           f"reference op sequence in CPU PyTorch (oracle/torch_port.py), {dt:.1f} s")
+
+
+class Cfg2:
+    """Single-modality argmin + EMA train step (NormEMAVectorQuantizer), K = 8192."""
+    name = "cfg2"
+    D, K = 768, 8192
+
+    def __init__(self, rows, dev, seed, path):
+        from medtok_amd.norm_ema_quantizer import NormEMAVectorQuantizer
+        self.rows, self.dev = rows, dev
+        g = torch.Generator(device=dev).manual_seed(seed)
+        self.z = torch.randn(rows, self.D, 1, 1, device=dev, generator=g)
+        torch.manual_seed(1234)
+        self.q = NormEMAVectorQuantizer(self.K, self.D, 0.25).to(dev).train()   # picks RCCL all-reduce when WORLD_SIZE > 1
+        self.q.search_path = path
+        self.description = f"cfg2 NormEMA argmin + EMA codebook update (train): {rows} rows/GPU, D=768, K=8192, fp32"
+
+    def flops_per_code(self):
+        return 2.0 * self.K * self.D
+
+    def step(self):
+        with torch.no_grad():
+            return self.q(self.z)
+
+    def cpu_baseline(self, sample_rows):
+        from oracle import torch_port as P
+        torch.set_num_threads(os.cpu_count() or 1)
+        g = torch.Generator().manual_seed(0)
+        E = torch.nn.functional.normalize(torch.randn(self.K, self.D, generator=g), dim=-1)
+        z = torch.randn(sample_rows, self.D, generator=g)
+        cs = torch.zeros(self.K)
+        P.norm_ema_forward(z[:256], E.clone(), cs.clone(), 0.25, 0.99, True)
+        t0 = time.perf_counter()
+        P.norm_ema_forward(z, E, cs, 0.25, 0.99, True)
+        dt = time.perf_counter() - t0
+        return dict(value=sample_rows / dt, unit="codes/s", cores=torch.get_num_threads(), kind="port",
+                    sample=f"{sample_rows} rows, argmin + EMA train step, reference op sequence in CPU PyTorch, {dt:.1f} s")
+
+
+def pmc_traffic(workload):
+    """HBM bytes per search launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    f = ROOT / "profiles" / "pmc_traffic.json"
+    if f.exists():
+        try:
+            return json.loads(f.read_text()).get(workload)
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    args = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to benchmark)")
+    rank, local, world = mdist.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    rows = args.rows or (600000 if args.workload == "cfg3" else 100000)
+    wl = (Cfg3 if args.workload == "cfg3" else Cfg2)(rows, dev, seed=rank, path=args.path)
+
+    for _ in range(args.warmup):
+        wl.step()
+    torch.cuda.synchronize(dev)
+    mdist.barrier()
+    torch.cuda.synchronize(dev)
+    events = ops.SEARCH_TIMER = []       # HIP events around every search launch, on its launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    torch.cuda.synchronize(dev)
+    mdist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+
+    # dominant kernel: fp32-MFMA search, timed by the HIP events recorded on its launch stream
+    ops.SEARCH_TIMER = None
+    k_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
+    k_flops = sum(f for _, _, f in events)
+    launches = len(events)
+    achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+
+    if rank == 0:
+        total_codes = float(rows) * world * args.steps
+        value = total_codes / elapsed
+        line = {
+            "metric": "codes_per_sec_tokenized",
+            "value": value,
+            "unit": "codes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl.description, "rows_per_gpu": rows, "D": wl.D, "search_path": args.path,
+                       "parallelism": f"row-shard x{world}, codebook replicated, no data-path collective"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(wl.name),
+                         "kernel": "search_f32_kernel", "launches_timed": launches,
+                         "avg_launch_ms": k_ms / max(launches, 1),
+                         "algorithmic_flops_per_launch": k_flops / max(launches, 1),
+                         "search_share_of_step": k_ms / (elapsed * 1e3),
+                         "whole_step_tflops": wl.flops_per_code() * rows * args.steps / elapsed / 1e12,
+                         "hbm_frac_of_step": None},
+        }
+        cpu_rows = args.cpu_rows if args.cpu_rows is not None else (4096 if args.workload == "cfg3" else 16384)
+        if world == 1 and cpu_rows > 0:
+            line["cpu_baseline"] = wl.cpu_baseline(cpu_rows)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    mdist.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

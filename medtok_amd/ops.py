@@ -12,6 +12,11 @@ from . import _lib
 from ._lib import PATH_AUTO, PATH_BF16_FILTER, PATH_F32_MFMA, MAX_TOPK  # noqa: F401
 
 
+# Profiling hook (bench.py): when set to a list, every search launch is bracketed by HIP events on
+# its launch stream and (start, stop, algorithmic_flops) is appended.  None = no overhead.
+SEARCH_TIMER = None
+
+
 def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -68,10 +73,17 @@ def topk_search(xhat, xsq, what, wsq, topk: int, path: int = PATH_AUTO):
     dist = torch.empty((n, topk), dtype=torch.float32, device=xhat.device)
     nb = lib.medtok_search_workspace_bytes(n, k, d, topk, path)
     ws = _ws(nb, xhat)
+    timer = SEARCH_TIMER
     with torch.cuda.device(xhat.device):
+        if timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(lib.medtok_topk_search_f32(xhat.data_ptr(), xsq.data_ptr(), n, what.data_ptr(), wsq.data_ptr(),
                                               k, d, topk, idx.data_ptr(), dist.data_ptr(), ws.data_ptr(),
                                               ws.numel(), path, _stream(xhat)), "medtok_topk_search_f32")
+        if timer is not None:
+            e1.record()
+            timer.append((e0, e1, 2.0 * n * k * d))
     return idx, dist
 
 
@@ -179,6 +191,11 @@ def soft_vq_forward(x, what, wsq, topk: int, path: int = PATH_AUTO, want_sqerr: 
     x, what, wsq = _dev(x, "x"), _dev(what, "what"), _dev(wsq, "wsq")
     n, d = x.shape
     k = what.shape[0]
+    if SEARCH_TIMER is not None:         # same kernels, launched piecewise so the search can be bracketed
+        xhat, xsq = rownorm(x)
+        idx, dist = topk_search(xhat, xsq, what, wsq, topk, path)
+        w, zq, se = soft_assign(x, what, idx, dist, want_sqerr=want_sqerr)
+        return dict(xhat=xhat, idx=idx, dist=dist, w=w, zq=zq, row_sqerr=se)
     lib = _lib.load()
     dev = x.device
     xhat = torch.empty_like(x)

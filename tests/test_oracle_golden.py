@@ -101,3 +101,33 @@ def test_edge_cases(oracle):
     assert list(idx[0]) == [0, 1, 2, 3, 4]     # all-equal distances: lowest index first
     idx, dist = oracle.topk_search(xh[:0], xs[:0], W, np.ones(5, np.float32), 3)
     assert idx.shape == (0, 3)
+
+
+# ---- the torch op-sequence port used as bench.py's cpu_baseline is pinned to the same vectors
+@pytest.mark.parametrize("name", ["f1_specific_d64", "f2_specific_d768"])
+def test_torch_port_specific(golden, name):
+    import torch
+    from oracle import torch_port as P
+    g = golden(name)
+    n_e, D, k, seed = int(g["n_e"]), int(g["e_dim"]), int(g["k"]), int(g["seed"])
+    W = synth.det_randn(f"{name}.codebook.weight", (n_e, D), 1.0, seed)
+    region = n_e // 3
+    for t, Wr in (("text", W[:region]), ("graph", W[-region:])):
+        r = P.soft_search(torch.from_numpy(g[f"{t}.x_proj"]), Wr, k)
+        assert np.array_equal(r["idx"].numpy(), g[f"{t}.idx"])
+        assert rel(r["w"].numpy(), g[f"{t}.w"]) <= RTOL
+        assert rel(r["zq"].numpy(), g[f"{t}.eval.zq"]) <= RTOL
+        assert abs(float(r["mse"]) - g[f"{t}.train.vq"]) <= RTOL * g[f"{t}.train.vq"]
+
+
+@pytest.mark.parametrize("name", ["f5_normema_d32", "f6_normema_zero_usage"])
+def test_torch_port_norm_ema(golden, name):
+    import torch
+    from oracle import torch_port as P
+    g = golden(name)
+    E = torch.from_numpy(g["E0"].copy()); cs = torch.zeros(E.shape[0])
+    for s in range(int(g["steps"])):
+        zq, loss, idx = P.norm_ema_forward(torch.from_numpy(g[f"s{s}.z"]), E, cs, float(g["beta"]), float(g["decay"]), True)
+        assert np.array_equal(idx.numpy(), g[f"s{s}.idx"])
+        assert rel(E.numpy(), g[f"s{s}.E"]) <= RTOL and rel(cs.numpy(), g[f"s{s}.cluster_size"]) <= RTOL
+        assert abs(float(loss) - g[f"s{s}.loss"]) <= RTOL * g[f"s{s}.loss"]
