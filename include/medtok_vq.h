@@ -19,8 +19,9 @@
  *     as they use different workspaces.
  *
  * Arithmetic contract (identical to oracle/medtok_oracle.c, which tests use as
- * the checker): x.e is one fp32 fmaf chain over i = 0..D-1; |v|^2 is 64 strided
- * fmaf chains joined by an xor butterfly; d = (|x|^2 + |e|^2) - 2*(x.e); ties go
+ * the checker): x.e is one fp32 fmaf chain that visits each group of 8 elements in the
+ * order 0,4,1,5,2,6,3,7 (the order v_mfma_f32_32x32x2_f32 consumes two float4 halves);
+ * |v|^2 is 64 strided fmaf chains joined by an xor butterfly; d = (|x|^2 + |e|^2) - 2*(x.e); ties go
  * to the lowest code index.  Search results are therefore bit-reproducible and
  * independent of tile shape, code sharding and which search path ran.
  */

@@ -37,7 +37,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     newest = max(SRC.stat().st_mtime, HEADER.stat().st_mtime, Path(__file__).stat().st_mtime)
     if not force and OUT.exists() and OUT.stat().st_mtime >= newest:
         return OUT
-    cmd = [hipcc(), *FLAGS, str(SRC), "-o", str(OUT)]
+    extra = os.environ.get("MEDTOK_HIPCC_EXTRA", "").split()     # dev knob, e.g. -DMEDTOK_SEARCH_BK=16
+    cmd = [hipcc(), *FLAGS, *extra, str(SRC), "-o", str(OUT)]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

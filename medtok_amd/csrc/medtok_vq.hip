@@ -163,17 +163,27 @@ __device__ __forceinline__ void topk_insert_lex(float (&bv)[T], int (&bi)[T], fl
 // ONE input row: the running top-k is lane-local (no cross-lane traffic until the end).
 // Wave w owns input rows [32w, 32w+32) against all 128 codes (4 accumulator tiles).
 //
-// LDS holds each 8-wide k-group as [k0 k2 k4 k6 | k1 k3 k5 k7]: lane (i, h) reads one float4
-// at +4h and register c then carries k = 8g + 2c + h, which is exactly the operand pair MFMA #c
-// needs (half 0 -> k, half 1 -> k+1), so the accumulation visits k = 0,1,2,... in order and
-// equals the oracle's fmaf chain bit for bit.  Rows are padded to 36 floats: conflict-free
-// ds_read_b128 (16 lanes x stride 36 dwords hit 16 distinct 4-bank slots) and ds_write_b128.
-constexpr int S_BM = 128, S_BN = 128, S_BK = 32, S_LD = 36;
+// LDS keeps rows as they are in memory.  Lane (i, h) reads one float4 of each 8-wide k-group at
+// +4h; register c then carries element 8g + 4h + c, and MFMA #c consumes (half 0 -> 8g+c,
+// half 1 -> 8g+4+c).  The accumulation therefore visits each group as 0,4,1,5,2,6,3,7 -- the
+// canonical chain order of the arithmetic contract (oracle/medtok_oracle.c) -- with no data
+// permutation anywhere.  Rows are padded to 36 floats: conflict-free ds_read_b128 (16 lanes x
+// stride 36 dwords hit 16 distinct 4-bank slots) and ds_write_b128.
+constexpr int S_BM = 128, S_BN = 128;
+#ifndef MEDTOK_SEARCH_BK
+#define MEDTOK_SEARCH_BK 32
+#endif
+constexpr int S_BK = MEDTOK_SEARCH_BK;                    // 32: 2 blocks/CU (74 KB LDS); 16: 3 blocks/CU (41 KB)
+constexpr int S_LD = S_BK + 4;                            // row stride in floats (36 and 20 are both conflict-free)
 constexpr int S_TILE = S_BM * S_LD;                       // floats per staged operand tile
 constexpr size_t S_LDS_BYTES = (size_t)4 * S_TILE * sizeof(float);   // A[2] + B[2]
+constexpr int S_TPR = S_BK / 8;                           // staging threads per tile row (8 floats each)
+constexpr int S_RPP = 256 / S_TPR;                        // tile rows staged per pass
+constexpr int S_PASSES = S_BM / S_RPP;
+constexpr int S_WPS = S_BK == 32 ? 2 : 3;                 // waves per SIMD the register budget is sized for
 
-template <int TOPK, bool FINAL>
-__global__ __launch_bounds__(256, 2) void search_f32_kernel(
+template <int TOPK, bool FINAL, bool KTAIL>
+__global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
     const float *__restrict__ xhat, const float *__restrict__ xsq, const float *__restrict__ what,
     const float *__restrict__ wsq, long n, int k_codes, int d, int codes_per_split, int topk_out,
     float *__restrict__ pval, int *__restrict__ pidx, int64_t *__restrict__ out_idx,
@@ -190,36 +200,54 @@ __global__ __launch_bounds__(256, 2) void search_f32_kernel(
     const int nkb = (d + S_BK - 1) / S_BK;
     const int nstage = nct * nkb;
 
-    const int srow = tid >> 2, sg = tid & 3;
-    float4 ra[2][2], rb[2][2];
+    const int srow = tid / S_TPR, sg = tid % S_TPR;
+    float4 ra[S_PASSES][2], rb[S_PASSES][2];
+    int kvalid = 0;                 // bit0/bit1: which float4 of the staged k-group lies inside D
+    int pct = 0, pkb = 0;           // (code tile, k block) of the next stage to prefetch
 
-    auto gload = [&](int s) {
-        const int ct = s / nkb, kb = s - ct * nkb;
-        const int kofs = kb * S_BK + sg * 8;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int crow = min(code_lo + ct * S_BM + srow + 64 * j, k_codes - 1);
-            const float *p = what + (long)crow * d + kofs;
-            const long xr = min(row0 + srow + 64 * j, n - 1);
-            const float *q = xhat + xr * d + kofs;
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            ra[j][0] = (kofs < d) ? ld4(p) : z;
-            ra[j][1] = (kofs + 4 < d) ? ld4(p + 4) : z;
-            rb[j][0] = (kofs < d) ? ld4(q) : z;
-            rb[j][1] = (kofs + 4 < d) ? ld4(q + 4) : z;
+    // Loads are unconditional: branching around them makes hipcc drain vmcnt(0) per load.  KTAIL
+    // (D % 32 != 0) clamps the addresses into the row and zeroes the out-of-range float4 when it
+    // is written to LDS (zeros leave the fmaf chain untouched).
+    auto gload = [&]() {
+        const int kofs = pkb * S_BK + sg * 8;
+        int k0 = kofs, k1 = kofs + 4;
+        if (KTAIL) {
+            kvalid = (kofs < d ? 1 : 0) | (kofs + 4 < d ? 2 : 0);
+            k0 = min(k0, d - 4);
+            k1 = min(k1, d - 4);
         }
+#pragma unroll
+        for (int j = 0; j < S_PASSES; ++j) {
+            const int crow = min(code_lo + pct * S_BM + srow + S_RPP * j, k_codes - 1);
+            const float *p = what + (long)crow * d;
+            const long xr = min(row0 + srow + S_RPP * j, n - 1);
+            const float *q = xhat + xr * d;
+            ra[j][0] = ld4(p + k0);
+            ra[j][1] = ld4(p + k1);
+            rb[j][0] = ld4(q + k0);
+            rb[j][1] = ld4(q + k1);
+        }
+        if (++pkb == nkb) { pkb = 0; ++pct; }
     };
     auto lstore = [&](int buf) {
         float *A = smem + buf * S_TILE;
         float *B = smem + 2 * S_TILE + buf * S_TILE;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float *pa = A + (srow + 64 * j) * S_LD + sg * 8;
-            st4(pa, make_float4(ra[j][0].x, ra[j][0].z, ra[j][1].x, ra[j][1].z));
-            st4(pa + 4, make_float4(ra[j][0].y, ra[j][0].w, ra[j][1].y, ra[j][1].w));
-            float *pb = B + (srow + 64 * j) * S_LD + sg * 8;
-            st4(pb, make_float4(rb[j][0].x, rb[j][0].z, rb[j][1].x, rb[j][1].z));
-            st4(pb + 4, make_float4(rb[j][0].y, rb[j][0].w, rb[j][1].y, rb[j][1].w));
+        for (int j = 0; j < S_PASSES; ++j) {
+            float *pa = A + (srow + S_RPP * j) * S_LD + sg * 8;
+            float *pb = B + (srow + S_RPP * j) * S_LD + sg * 8;
+            if (KTAIL) {
+                st4(pa, (kvalid & 1) ? ra[j][0] : z);
+                st4(pa + 4, (kvalid & 2) ? ra[j][1] : z);
+                st4(pb, (kvalid & 1) ? rb[j][0] : z);
+                st4(pb + 4, (kvalid & 2) ? rb[j][1] : z);
+            } else {
+                st4(pa, ra[j][0]);
+                st4(pa + 4, ra[j][1]);
+                st4(pb, rb[j][0]);
+                st4(pb + 4, rb[j][1]);
+            }
         }
     };
 
@@ -237,17 +265,17 @@ __global__ __launch_bounds__(256, 2) void search_f32_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-    gload(0);
+    gload();
     int ct = 0, kb = 0;
     for (int s = 0; s < nstage; ++s) {
         const int buf = s & 1;
         lstore(buf);
         __syncthreads();
-        if (s + 1 < nstage) gload(s + 1);
+        if (s + 1 < nstage) gload();
         const float *A = smem + buf * S_TILE + li * S_LD + lh * 4;
         const float *B = smem + 2 * S_TILE + buf * S_TILE + (wave * 32 + li) * S_LD + lh * 4;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < S_BK / 8; ++kk) {
             const float4 bf = ld4(B + kk * 8);
             float4 af[4];
 #pragma unroll
@@ -339,8 +367,9 @@ static SearchPlan plan_search(int64_t n, int64_t k_codes, int topk)
     p.tslots = topk == 1 ? 1 : (topk <= 5 ? 5 : 8);
     p.row_tiles = (n + S_BN - 1) / S_BN;
     const long code_tiles = (k_codes + S_BM - 1) / S_BM;
-    // Fill ~2 blocks per CU on 256 CUs when the row count alone cannot.
-    long want = (512 + p.row_tiles - 1) / p.row_tiles;
+    // Blocks all cost the same and run 2-3 per CU on 256 CUs, so a launch of B blocks wastes up to
+    // one "round" of ~600; ask for >= 16384 blocks (tail <= ~4%) by splitting the code range.
+    long want = (16384 + p.row_tiles - 1) / p.row_tiles;
     if (want < 1) want = 1;
     if (want > code_tiles) want = code_tiles;
     if (want > 64) want = 64;
@@ -360,15 +389,15 @@ extern "C" size_t medtok_search_workspace_bytes(int64_t n, int64_t k_codes, int 
            align_up((size_t)p.splits * n * p.tslots * sizeof(int), 256);
 }
 
-template <int T>
+template <int T, bool KTAIL>
 static int launch_search(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
                          int64_t k_codes, int d, int topk, int64_t *idx, float *dist, void *ws, size_t ws_bytes,
                          const SearchPlan &p, hipStream_t s)
 {
     dim3 grid((unsigned)p.row_tiles, (unsigned)p.splits), block(256);
     if (p.splits == 1) {
-        (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
-        hipLaunchKernelGGL((search_f32_kernel<T, true>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
+        (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, true, KTAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
+        hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
                            (int)k_codes, d, p.codes_per_split, topk, (float *)nullptr, (int *)nullptr, idx, dist);
         return check_launch("search_f32");
     }
@@ -377,13 +406,22 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
     if (!ws || ws_bytes < vbytes + ibytes) return fail("search: workspace too small (%zu < %zu)", ws_bytes, vbytes + ibytes);
     float *pval = (float *)ws;
     int *pidx = (int *)((char *)ws + vbytes);
-    (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
-    hipLaunchKernelGGL((search_f32_kernel<T, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
+    (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, false, KTAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
+    hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
                        (int)k_codes, d, p.codes_per_split, topk, pval, pidx, (int64_t *)nullptr, (float *)nullptr);
     if (check_launch("search_f32(split)")) return 1;
     hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pval, pidx, (long)n,
                        p.splits, topk, idx, dist);
     return check_launch("merge_topk");
+}
+
+template <int T>
+static int launch_search_t(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
+                           int64_t k_codes, int d, int topk, int64_t *idx, float *dist, void *ws, size_t ws_bytes,
+                           const SearchPlan &p, hipStream_t s)
+{
+    if (d % S_BK) return launch_search<T, true>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
+    return launch_search<T, false>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
 }
 
 extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64_t n, const float *what,
@@ -398,9 +436,9 @@ extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64
     const SearchPlan p = plan_search(n, k_codes, topk);
     hipStream_t s = (hipStream_t)stream;
     switch (p.tslots) {
-    case 1: return launch_search<1>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
-    case 5: return launch_search<5>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
-    default: return launch_search<8>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
+    case 1: return launch_search_t<1>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
+    case 5: return launch_search_t<5>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
+    default: return launch_search_t<8>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
     }
 }
 

@@ -21,8 +21,11 @@
  * The reference evaluates  d = (|x|^2 + |e|^2) - 2 * (x . e)  with whatever
  * summation order its BLAS picks.  This restatement fixes ONE order, chosen so
  * the MI355X kernels can reproduce it bit for bit:
- *   - x.e is a single fp32 fmaf chain over i = 0..D-1 starting from +0
- *     (exactly what v_mfma_f32_32x32x2_f32 computes when fed k in order);
+ *   - x.e is a single fp32 fmaf chain starting from +0 that visits every group of 8
+ *     consecutive elements in the order 0,4,1,5,2,6,3,7 (indices >= D skipped).  That is
+ *     exactly what v_mfma_f32_32x32x2_f32 computes when each half-wave reads one float4 of
+ *     the group (lanes 0-31: elements 0-3, lanes 32-63: elements 4-7) and the four MFMAs
+ *     consume register 0,1,2,3 in turn: no data permutation anywhere on the GPU side;
  *   - |v|^2 is 64 strided fmaf chains (element i goes to chain (i/4)%64)
  *     combined by an xor butterfly (offsets 32,16,8,4,2,1), i.e. one wavefront
  *     reading float4 per lane;
@@ -45,6 +48,13 @@
 #endif
 
 #define ORACLE_MAX_TOPK 16
+
+/* position p of the canonical dot-product chain -> element index (see header) */
+static inline int chain_index(int p)
+{
+    static const int perm[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+    return (p & ~7) + perm[p & 7];
+}
 #define ORACLE_CODE_CHUNK 64
 
 /* ---- canonical |v|^2 : 64 strided fmaf chains + xor butterfly ------------ */
@@ -91,7 +101,10 @@ static void dot_chunk(const float *xrow, const float *wt, int d, float *acc)
 {
     float a[ORACLE_CODE_CHUNK];
     for (int c = 0; c < ORACLE_CODE_CHUNK; ++c) a[c] = 0.0f;
-    for (int i = 0; i < d; ++i) {
+    const int dpad = (d + 7) & ~7;
+    for (int p = 0; p < dpad; ++p) {
+        const int i = chain_index(p);
+        if (i >= d) continue;
         const float xi = xrow[i];
         const float *w = wt + (size_t)i * ORACLE_CODE_CHUNK;
         for (int c = 0; c < ORACLE_CODE_CHUNK; ++c)
@@ -154,7 +167,10 @@ int oracle_distance_f32(const float *xhat, const float *xsq, int64_t n,
     for (int64_t r = 0; r < n; ++r)
         for (int64_t c = 0; c < k_codes; ++c) {
             float acc = 0.0f;
-            for (int i = 0; i < d; ++i) acc = fmaf(xhat[r * d + i], what[c * d + i], acc);
+            for (int p = 0; p < ((d + 7) & ~7); ++p) {
+                const int i = chain_index(p);
+                if (i < d) acc = fmaf(xhat[r * d + i], what[c * d + i], acc);
+            }
             float s = xsq[r] + wsq[c];
             float t = 2.0f * acc;
             out[r * k_codes + c] = s - t;
