@@ -41,7 +41,7 @@ extern "C" {
 /* search path selector for medtok_topk_search_f32 */
 #define MEDTOK_PATH_AUTO 0          /* library picks the fastest exact path          */
 #define MEDTOK_PATH_F32_MFMA 1      /* brute force on v_mfma_f32_32x32x2_f32          */
-#define MEDTOK_PATH_BF16_FILTER 2   /* bf16-MFMA shortlist + exact fp32 re-score      */
+#define MEDTOK_PATH_F16_FILTER 2    /* fp16-MFMA shortlist + exact fp32 re-score: same bits, ~16x the matrix rate */
 
 /* flags for medtok_soft_assign_f32 */
 #define MEDTOK_ASSIGN_HARD 1        /* NormEMA form: topk == 1, zq = what[idx]        */
@@ -73,6 +73,13 @@ int medtok_topk_search_f32(const float *xhat, const float *xsq, int64_t n,
                            const float *what, const float *wsq, int64_t k_codes,
                            int d, int topk, int64_t *idx, float *dist,
                            void *ws, size_t ws_bytes, int path, void *stream);
+
+/* Test hook: the approximate scores s~ [n, k_codes] the fp16 filter works with, so the error
+ * bound it relies on (medtok_amd/csrc/filter_f16.h) can be measured. Not part of the product path. */
+size_t medtok_debug_filter_scores_workspace_bytes(int64_t n, int64_t k_codes, int d);
+int medtok_debug_filter_scores_f32(const float *xhat, const float *xsq, int64_t n,
+                                   const float *what, const float *wsq, int64_t k_codes, int d,
+                                   float *scores, void *ws, size_t ws_bytes, void *stream);
 
 /* Soft assignment: w = softmax(-dist), zq = sum_j w_j * what[idx_j],
  * zq_ste = xref + (zq - xref), row_sqerr[r] = sum_i (zq - xref)^2.

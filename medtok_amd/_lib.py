@@ -13,7 +13,7 @@ _lib = None
 
 ABI_VERSION = 1
 MAX_TOPK = 8
-PATH_AUTO, PATH_F32_MFMA, PATH_BF16_FILTER = 0, 1, 2
+PATH_AUTO, PATH_F32_MFMA, PATH_F16_FILTER = 0, 1, 2
 
 _vp, _i64, _int, _sz, _f, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float, C.c_double
 
@@ -24,6 +24,8 @@ SIGNATURES = {
     "medtok_rownorm_f32": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
     "medtok_search_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int]),
     "medtok_topk_search_f32": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _int, _vp]),
+    "medtok_debug_filter_scores_workspace_bytes": (_sz, [_i64, _i64, _int]),
+    "medtok_debug_filter_scores_f32": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "medtok_soft_assign_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "medtok_sum_scale_f32": (_int, [_vp, _i64, _dbl, _vp, _vp]),
     "medtok_ema_stats_workspace_bytes": (_sz, [_i64, _i64]),

@@ -182,17 +182,27 @@ constexpr int S_RPP = 256 / S_TPR;                        // tile rows staged pe
 constexpr int S_PASSES = S_BM / S_RPP;
 constexpr int S_WPS = S_BK == 32 ? 2 : 3;                 // waves per SIMD the register budget is sized for
 
-template <int TOPK, bool FINAL, bool KTAIL>
+// INDIRECT: the block's rows are row_list[row0 .. row0+128) (count read from *row_count on the
+// device) -- the exact fallback for rows the fp16 filter could not shortlist.
+template <int TOPK, bool FINAL, bool KTAIL, bool INDIRECT>
 __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
     const float *__restrict__ xhat, const float *__restrict__ xsq, const float *__restrict__ what,
     const float *__restrict__ wsq, long n, int k_codes, int d, int codes_per_split, int topk_out,
     float *__restrict__ pval, int *__restrict__ pidx, int64_t *__restrict__ out_idx,
-    float *__restrict__ out_dist)
+    float *__restrict__ out_dist, const int *__restrict__ row_list, const int *__restrict__ row_count)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const long row0 = (long)blockIdx.x * S_BN;
+    if (INDIRECT) {
+        n = *row_count;                     // rows in the list; uniform for the whole grid
+        if (row0 >= n) return;
+    }
+    auto actual_row = [&](long pos) -> long {
+        const long c = min(pos, n - 1);
+        return INDIRECT ? (long)row_list[c] : c;
+    };
     const int split = blockIdx.y;
     const int code_lo = split * codes_per_split;
     const int code_hi = min(k_codes, code_lo + codes_per_split);
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
         for (int j = 0; j < S_PASSES; ++j) {
             const int crow = min(code_lo + pct * S_BM + srow + S_RPP * j, k_codes - 1);
             const float *p = what + (long)crow * d;
-            const long xr = min(row0 + srow + S_RPP * j, n - 1);
+            const long xr = actual_row(row0 + srow + S_RPP * j);
             const float *q = xhat + xr * d;
             ra[j][0] = ld4(p + k0);
             ra[j][1] = ld4(p + k1);
@@ -256,8 +266,9 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
 #pragma unroll
     for (int j = 0; j < TOPK; ++j) { bv[j] = INFINITY; bi[j] = 0; }
 
-    const long myrow = row0 + wave * 32 + li;
-    const float xn = xsq[min(myrow, n - 1)];
+    const long mypos = row0 + wave * 32 + li;
+    const long myrow = actual_row(mypos);
+    const float xn = xsq[myrow];
 
     f32x16 acc[4];
 #pragma unroll
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
 #pragma unroll
     for (int j = 0; j < TOPK; ++j) topk_insert_lex<TOPK>(bv, bi, pv[j], pi[j]);
 
-    if (lh == 0 && myrow < n) {
+    if (lh == 0 && mypos < n) {
         if (FINAL) {
 #pragma unroll
             for (int j = 0; j < TOPK; ++j)
@@ -354,6 +365,8 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict
         if (j < topk_out) { out_idx[row * topk_out + j] = bi[j]; out_dist[row * topk_out + j] = bv[j]; }
 }
 
+#include "filter_f16.h"
+
 struct SearchPlan {
     int tslots;          // list length the kernels are instantiated with (1, 5 or 8)
     int splits;          // code-range splits (grid.y)
@@ -379,10 +392,74 @@ static SearchPlan plan_search(int64_t n, int64_t k_codes, int topk)
     return p;
 }
 
+// ---- fp16 filter path: plan + workspace layout
+struct FilterPlan {
+    long n_pad, k_pad, row_tiles;
+    int dp, splits, codes_per_split, own_total, tslots;
+};
+
+static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
+{
+    FilterPlan f;
+    f.tslots = topk == 1 ? 1 : (topk <= 5 ? 5 : 8);
+    f.n_pad = (n + F_BN - 1) / F_BN * F_BN;
+    f.k_pad = (k_codes + F_BM - 1) / F_BM * F_BM;
+    f.dp = (d + F_BK - 1) / F_BK * F_BK;
+    f.row_tiles = f.n_pad / F_BN;
+    const long code_tiles = f.k_pad / F_BM;
+    // every split adds 4 candidate lists per row, so split only as far as filling the chip needs
+    long want = f.row_tiles >= 8192 ? 1 : (f.row_tiles >= 1024 ? 2 : (2048 + f.row_tiles - 1) / f.row_tiles);
+    if (want > code_tiles) want = code_tiles;
+    if (want > 16) want = 16;
+    const long tiles_per_split = (code_tiles + want - 1) / want;
+    f.codes_per_split = (int)(tiles_per_split * F_BM);
+    f.splits = (int)((code_tiles + tiles_per_split - 1) / tiles_per_split);
+    f.own_total = f.splits * F_OWN_PER_SPLIT;
+    return f;
+}
+
+struct FilterWs {
+    _Float16 *xh, *wh;
+    float *en_max, *dump;
+    uint2 *cand;
+    int *cand_cnt, *fb_count, *fb_rows;
+    size_t total;
+};
+
+static FilterWs filter_ws_layout(void *ws, int64_t n, const FilterPlan &f)
+{
+    FilterWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *p = ws ? (char *)ws + off : nullptr; off += align_up(bytes, 256); return (void *)p; };
+    w.xh = (_Float16 *)take((size_t)f.n_pad * f.dp * 2);
+    w.wh = (_Float16 *)take((size_t)f.k_pad * f.dp * 2);
+    w.en_max = (float *)take(4);
+    w.fb_count = (int *)take(4);
+    w.fb_rows = (int *)take((size_t)n * 4);
+    w.cand_cnt = (int *)take((size_t)n * f.own_total * 4);
+    w.cand = (uint2 *)take((size_t)n * f.own_total * F_CAP * 8);
+    w.dump = nullptr;
+    w.total = off;
+    return w;
+}
+
+static bool filter_eligible(int64_t n, int64_t k_codes, int d, int topk)
+{
+    (void)d;
+    return n >= 256 && k_codes >= 1024 && topk <= MEDTOK_MAX_TOPK && n < (1ll << 31);
+}
+
+static int resolve_path(int path, int64_t n, int64_t k_codes, int d, int topk)
+{
+    if (path == MEDTOK_PATH_AUTO) return filter_eligible(n, k_codes, d, topk) ? MEDTOK_PATH_F16_FILTER : MEDTOK_PATH_F32_MFMA;
+    return path;
+}
+
 extern "C" size_t medtok_search_workspace_bytes(int64_t n, int64_t k_codes, int d, int topk, int path)
 {
-    (void)d; (void)path;
     if (n <= 0 || k_codes <= 0 || topk < 1 || topk > MEDTOK_MAX_TOPK) return 0;
+    if (resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER)
+        return filter_ws_layout(nullptr, n, plan_filter(n, k_codes, d, topk)).total;
     SearchPlan p = plan_search(n, k_codes, topk);
     if (p.splits == 1) return 256;
     return align_up((size_t)p.splits * n * p.tslots * sizeof(float), 256) +
@@ -396,9 +473,10 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
 {
     dim3 grid((unsigned)p.row_tiles, (unsigned)p.splits), block(256);
     if (p.splits == 1) {
-        (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, true, KTAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
-        hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
-                           (int)k_codes, d, p.codes_per_split, topk, (float *)nullptr, (int *)nullptr, idx, dist);
+        (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, true, KTAIL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
+        hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
+                           (int)k_codes, d, p.codes_per_split, topk, (float *)nullptr, (int *)nullptr, idx, dist,
+                           (const int *)nullptr, (const int *)nullptr);
         return check_launch("search_f32");
     }
     const size_t vbytes = align_up((size_t)p.splits * n * T * sizeof(float), 256);
@@ -406,9 +484,10 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
     if (!ws || ws_bytes < vbytes + ibytes) return fail("search: workspace too small (%zu < %zu)", ws_bytes, vbytes + ibytes);
     float *pval = (float *)ws;
     int *pidx = (int *)((char *)ws + vbytes);
-    (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, false, KTAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
-    hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
-                       (int)k_codes, d, p.codes_per_split, topk, pval, pidx, (int64_t *)nullptr, (float *)nullptr);
+    (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, false, KTAIL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
+    hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
+                       (int)k_codes, d, p.codes_per_split, topk, pval, pidx, (int64_t *)nullptr, (float *)nullptr,
+                       (const int *)nullptr, (const int *)nullptr);
     if (check_launch("search_f32(split)")) return 1;
     hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pval, pidx, (long)n,
                        p.splits, topk, idx, dist);
@@ -424,6 +503,42 @@ static int launch_search_t(const float *xhat, const float *xsq, int64_t n, const
     return launch_search<T, false>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
 }
 
+template <int T, bool KTAIL>
+static int launch_filter(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
+                         int64_t k_codes, int d, int topk, int64_t *idx, float *dist, void *ws, size_t ws_bytes,
+                         hipStream_t s)
+{
+    const FilterPlan f = plan_filter(n, k_codes, d, topk);
+    const FilterWs w = filter_ws_layout(ws, n, f);
+    if (!ws || ws_bytes < w.total) return fail("search(filter): workspace too small (%zu < %zu)", ws_bytes, w.total);
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.n_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, xhat, (long)n, d, f.n_pad, f.dp, w.xh);
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, w.wh);
+    hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, w.en_max);
+    if (hipMemsetAsync(w.fb_count, 0, 4, s) != hipSuccess) return fail("search(filter): memset failed");
+    (void)hipFuncSetAttribute((const void *)filter_f16_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
+    hipLaunchKernelGGL((filter_f16_kernel<T, false>), dim3((unsigned)f.row_tiles, (unsigned)f.splits), dim3(256), F_LDS_BYTES, s,
+                       w.xh, w.wh, xsq, wsq, w.en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
+                       w.cand, w.cand_cnt, (float *)nullptr);
+    if (check_launch("filter_f16")) return 1;
+    hipLaunchKernelGGL((rescore_kernel<T>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, w.cand, w.cand_cnt, f.own_total,
+                       xhat, xsq, what, wsq, w.en_max, (long)n, (int)k_codes, d, topk, idx, dist, w.fb_count, w.fb_rows);
+    if (check_launch("rescore")) return 1;
+    // exact redo of the rows the filter gave up on (normally none: the grid exits on *fb_count)
+    (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, true, KTAIL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
+    hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, true>), dim3((unsigned)((n + S_BN - 1) / S_BN), 1), dim3(256), S_LDS_BYTES, s,
+                       xhat, xsq, what, wsq, (long)n, (int)k_codes, d, (int)((k_codes + S_BM - 1) / S_BM * S_BM), topk,
+                       (float *)nullptr, (int *)nullptr, idx, dist, (const int *)w.fb_rows, (const int *)w.fb_count);
+    return check_launch("search_f32(fallback)");
+}
+
+template <int T>
+static int launch_filter_t(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
+                           int64_t k_codes, int d, int topk, int64_t *idx, float *dist, void *ws, size_t ws_bytes, hipStream_t s)
+{
+    if (d % S_BK) return launch_filter<T, true>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s);
+    return launch_filter<T, false>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s);
+}
+
 extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64_t n, const float *what,
                                       const float *wsq, int64_t k_codes, int d, int topk, int64_t *idx, float *dist,
                                       void *ws, size_t ws_bytes, int path, void *stream)
@@ -431,15 +546,52 @@ extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64
     if (n < 0 || k_codes <= 0 || d <= 0 || (d & 3)) return fail("search: bad shape n=%ld K=%ld d=%d (d %% 4 == 0)", (long)n, (long)k_codes, d);
     if (topk < 1 || topk > MEDTOK_MAX_TOPK || topk > k_codes) return fail("search: topk=%d unsupported (1..%d, <= K)", topk, MEDTOK_MAX_TOPK);
     if (k_codes >= (1ll << 31)) return fail("search: K too large");
-    if (path != MEDTOK_PATH_AUTO && path != MEDTOK_PATH_F32_MFMA) return fail("search: path %d not available in this build", path);
+    if (path != MEDTOK_PATH_AUTO && path != MEDTOK_PATH_F32_MFMA && path != MEDTOK_PATH_F16_FILTER) return fail("search: unknown path %d", path);
     if (n == 0) return 0;
-    const SearchPlan p = plan_search(n, k_codes, topk);
     hipStream_t s = (hipStream_t)stream;
-    switch (p.tslots) {
+    const int tslots = topk == 1 ? 1 : (topk <= 5 ? 5 : 8);
+    if (resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER) {
+        if (n >= (1ll << 31)) return fail("search(filter): n too large");
+        switch (tslots) {
+        case 1: return launch_filter_t<1>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s);
+        case 5: return launch_filter_t<5>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s);
+        default: return launch_filter_t<8>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s);
+        }
+    }
+    const SearchPlan p = plan_search(n, k_codes, topk);
+    switch (tslots) {
     case 1: return launch_search_t<1>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
     case 5: return launch_search_t<5>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
     default: return launch_search_t<8>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
     }
+}
+
+// Test hook: the filter's approximate scores s~ [n, k_codes] (same MFMA sequence as the search uses),
+// so tests can measure |s~ - s| against the bound filter_f16.h assumes.
+extern "C" size_t medtok_debug_filter_scores_workspace_bytes(int64_t n, int64_t k_codes, int d)
+{
+    if (n <= 0 || k_codes <= 0 || d <= 0) return 0;
+    FilterPlan f = plan_filter(n, k_codes, d, 5);
+    return align_up((size_t)f.n_pad * f.dp * 2, 256) + align_up((size_t)f.k_pad * f.dp * 2, 256) + 512;
+}
+
+extern "C" int medtok_debug_filter_scores_f32(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
+                                              int64_t k_codes, int d, float *scores, void *ws, size_t ws_bytes, void *stream)
+{
+    if (n <= 0 || k_codes <= 0 || d <= 0 || (d & 3)) return fail("debug_filter_scores: bad shape");
+    FilterPlan f = plan_filter(n, k_codes, d, 5);
+    const size_t xb = align_up((size_t)f.n_pad * f.dp * 2, 256), wb = align_up((size_t)f.k_pad * f.dp * 2, 256);
+    if (!ws || ws_bytes < xb + wb + 512) return fail("debug_filter_scores: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    _Float16 *xh = (_Float16 *)ws, *wh = (_Float16 *)((char *)ws + xb);
+    float *en_max = (float *)((char *)ws + xb + wb);
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.n_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, xhat, (long)n, d, f.n_pad, f.dp, xh);
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, wh);
+    hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, en_max);
+    (void)hipFuncSetAttribute((const void *)filter_f16_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
+    hipLaunchKernelGGL((filter_f16_kernel<5, true>), dim3((unsigned)f.row_tiles, 1), dim3(256), F_LDS_BYTES, s, xh, wh, xsq, wsq, en_max,
+                       (long)n, (int)k_codes, f.dp, d, (int)f.k_pad, F_OWN_PER_SPLIT, (uint2 *)nullptr, (int *)nullptr, scores);
+    return check_launch("filter_f16(dump)");
 }
 
 // ================================================================= soft assign

@@ -9,7 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import PATH_AUTO, PATH_BF16_FILTER, PATH_F32_MFMA, MAX_TOPK  # noqa: F401
+from ._lib import PATH_AUTO, PATH_F16_FILTER, PATH_F32_MFMA, MAX_TOPK  # noqa: F401
 
 
 # Profiling hook (bench.py): when set to a list, every search launch is bracketed by HIP events on
@@ -85,6 +85,21 @@ def topk_search(xhat, xsq, what, wsq, topk: int, path: int = PATH_AUTO):
             e1.record()
             timer.append((e0, e1, 2.0 * n * k * d))
     return idx, dist
+
+
+def debug_filter_scores(xhat, xsq, what, wsq):
+    """Test hook: approximate scores s~ [n, K] of the fp16 filter."""
+    xhat, xsq, what, wsq = _dev(xhat, "xhat"), _dev(xsq, "xsq"), _dev(what, "what"), _dev(wsq, "wsq")
+    n, d = xhat.shape
+    k = what.shape[0]
+    lib = _lib.load()
+    out = torch.empty((n, k), dtype=torch.float32, device=xhat.device)
+    ws = _ws(lib.medtok_debug_filter_scores_workspace_bytes(n, k, d), xhat)
+    with torch.cuda.device(xhat.device):
+        _lib.check(lib.medtok_debug_filter_scores_f32(xhat.data_ptr(), xsq.data_ptr(), n, what.data_ptr(), wsq.data_ptr(), k, d,
+                                                      out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(xhat)),
+                   "medtok_debug_filter_scores_f32")
+    return out
 
 
 def soft_assign(xref, what, idx, dist, hard: bool = False, want_w: bool = True, want_sqerr: bool = True,

@@ -178,6 +178,21 @@ int oracle_distance_f32(const float *xhat, const float *xsq, int64_t n,
     return 0;
 }
 
+/* The canonical chain scores s[r][c] themselves (small cases; used to measure the fp16 filter's error). */
+int oracle_scores_f32(const float *xhat, int64_t n, const float *what, int64_t k_codes, int d, float *out)
+{
+    for (int64_t r = 0; r < n; ++r)
+        for (int64_t c = 0; c < k_codes; ++c) {
+            float acc = 0.0f;
+            for (int p = 0; p < ((d + 7) & ~7); ++p) {
+                const int i = chain_index(p);
+                if (i < d) acc = fmaf(xhat[r * d + i], what[c * d + i], acc);
+            }
+            out[r * k_codes + c] = acc;
+        }
+    return 0;
+}
+
 /* Soft assignment.  w = softmax(-dist) over the topk entries;
  * zq = sum_j w_j * what[idx_j]; out = xref + (zq - xref) (straight-through
  * forward value, vector_quantization_soft_one_new.py:181-182,214);

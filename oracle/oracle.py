@@ -91,6 +91,17 @@ def distance(xhat, xsq, what, wsq):
     return out
 
 
+def scores(xhat, what):
+    """Canonical chain dot products [n, K] (small cases)."""
+    xhat, xp = _f(xhat); what, wp = _f(what)
+    n, d = xhat.shape
+    k = what.shape[0]
+    out = np.empty((n, k), np.float32)
+    rc = lib().oracle_scores_f32(xp, C.c_int64(n), wp, C.c_int64(k), d, out.ctypes.data_as(_f32p))
+    assert rc == 0
+    return out
+
+
 def soft_assign(xref, what, idx, dist, hard=False, raw=False):
     """softmax(-d) weights, weighted code mix, STE value, row squared error
     (vector_quantization_soft_one_new.py:158-182,204-214; hard=True is

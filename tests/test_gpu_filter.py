@@ -1,0 +1,113 @@
+"""GPU: the fp16-filter search path must return the SAME bits as the exact fp32 path (and the oracle)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def both_paths(xh, xs, wh, ws, topk):
+    from medtok_amd import ops
+    i1, d1 = ops.topk_search(xh, xs, wh, ws, topk, ops.PATH_F32_MFMA)
+    i2, d2 = ops.topk_search(xh, xs, wh, ws, topk, ops.PATH_F16_FILTER)
+    torch.cuda.synchronize()
+    return i1, d1, i2, d2
+
+
+def test_filter_score_error_bound(oracle, dev):
+    """|s~ - s| must stay far inside gamma*sqrt(xsq*wsq) (filter_f16.h), on random and on worst-case-sign data."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(0)
+    for d in (64, 768, 1000):
+        x = rng.standard_normal((96, d), dtype=np.float32)
+        W = rng.standard_normal((200, d), dtype=np.float32)
+        x[:8] = np.abs(x[:8]); W[:8] = np.abs(W[:8])                 # same-sign rows: sum|x e| = |x||e|-ish
+        x[8] = 1.0; W[8] = 1.0                                       # exactly aligned constant vectors
+        x[9, :] = 0; x[9, 0] = 1.0; W[9, :] = 0; W[9, 0] = 1.0       # one-hot
+        x[10] *= rng.random(d, dtype=np.float32) < 0.05              # sparse row with tiny elements elsewhere
+        xh, xs = oracle.rownorm(x); wh, ws = oracle.rownorm(W)
+        s_ref = oracle.scores(xh, wh)
+        s_apx = ops.debug_filter_scores(_t(xh, dev), _t(xs, dev), _t(wh, dev), _t(ws, dev)).cpu().numpy()
+        gamma = 2.0 ** -10 + 2.0 ** -20 + d * 2.0 ** -21
+        bound = gamma * np.sqrt(xs[:, None] * ws[None, :])
+        ratio = np.abs(s_apx - s_ref) / bound
+        assert ratio.max() < 0.6, (d, ratio.max())                   # rounding part alone can reach ~0.5 when aligned
+        # the accumulation budget (D * 2^-21) on its own: compare against fp64 dot of the ROUNDED operands
+        xr = (xh.astype(np.float16 if False else np.float32) * 256).astype(np.float16).astype(np.float64) / 256
+        wr = (wh * 256).astype(np.float16).astype(np.float64) / 256
+        acc_err = np.abs(s_apx - xr @ wr.T) / (np.abs(xr) @ np.abs(wr).T + 1e-30)
+        assert acc_err.max() < 0.25 * d * 2.0 ** -21, (d, acc_err.max())
+
+
+@pytest.mark.parametrize("n,k,d,topk", [
+    (300, 1100, 64, 5), (1000, 4096, 768, 5), (513, 3000, 100, 1), (2000, 2048, 128, 8),
+    (257, 1025, 36, 3), (70000, 2048, 64, 5), (4096, 8192, 768, 5),
+])
+def test_filter_equals_exact_random(oracle, dev, n, k, d, topk):
+    rng = np.random.default_rng(n + k + d)
+    x = rng.standard_normal((n, d), dtype=np.float32); W = rng.standard_normal((k, d), dtype=np.float32)
+    from medtok_amd import ops
+    xh, xs = ops.rownorm(_t(x, dev)); wh, ws = ops.rownorm(_t(W, dev))
+    i1, d1, i2, d2 = both_paths(xh, xs, wh, ws, topk)
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)
+    if n * k * d <= 4096 * 8192 * 64:
+        io, do = oracle.topk_search(xh.cpu().numpy(), xs.cpu().numpy(), wh.cpu().numpy(), ws.cpu().numpy(), topk)
+        assert np.array_equal(i2.cpu().numpy(), io) and np.array_equal(d2.cpu().numpy(), do)
+
+
+def test_filter_adversarial_codebooks(oracle, dev):
+    """Near-duplicate clusters (shortlists overflow -> exact fallback), exact duplicates (tie rule),
+    and rows equal to codes; all must match the exact path bit for bit."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(7)
+    d, k, n = 128, 4096, 1500
+    centers = rng.standard_normal((8, d), dtype=np.float32)
+    W = centers[rng.integers(0, 8, k)] + 1e-3 * rng.standard_normal((k, d), dtype=np.float32)   # 8 tight clusters of ~512 codes
+    W[2000:2100] = W[100:200]                                                                    # exact duplicates
+    x = centers[rng.integers(0, 8, n)] + 1e-3 * rng.standard_normal((n, d), dtype=np.float32)
+    x[:50] = W[100:150]                                                                          # rows that ARE codes
+    xh, xs = ops.rownorm(_t(x, dev)); wh, ws = ops.rownorm(_t(W, dev))
+    i1, d1, i2, d2 = both_paths(xh, xs, wh, ws, 5)
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)
+    io, do = oracle.topk_search(xh.cpu().numpy(), xs.cpu().numpy(), wh.cpu().numpy(), ws.cpu().numpy(), 5)
+    assert np.array_equal(i2.cpu().numpy(), io) and np.array_equal(d2.cpu().numpy(), do)
+    assert (io[:50, 0] == np.arange(100, 150)).all() and (io[:50, 1] == np.arange(2000, 2050)).all()
+
+
+def test_filter_out_of_range_norms_fall_back(oracle, dev):
+    """Un-normalised operands (|x|^2 or |e|^2 > 4) leave the range the error bound assumes: exact path takes over."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((600, 64), dtype=np.float32) * 3
+    W = rng.standard_normal((2048, 64), dtype=np.float32)
+    xd, Wd = _t(x, dev), _t(W, dev)
+    _, xs = ops.rownorm(xd, normalize=False); wh, ws = ops.rownorm(Wd)
+    i1, d1, i2, d2 = both_paths(xd, xs, wh, ws, 5)            # big rows, unit codes
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)
+    xh, xs = ops.rownorm(xd); _, ws = ops.rownorm(Wd * 5, normalize=False)
+    i1, d1, i2, d2 = both_paths(xh, xs, (Wd * 5).contiguous(), ws, 5)   # unit rows, big codes
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)
+    # some rows huge, some unit, some zero
+    xm = x.copy(); xm[::3] /= np.linalg.norm(xm[::3], axis=1, keepdims=True); xm[5] = 0
+    xmd = _t(xm, dev); _, xs = ops.rownorm(xmd, normalize=False)
+    i1, d1, i2, d2 = both_paths(xmd, xs, wh, ops.rownorm(wh, normalize=False)[1], 5)
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)
+
+
+def test_auto_path_matches_exact_in_modules(dev):
+    """The drop-in classes use PATH_AUTO; forcing the exact path must not change a single output bit."""
+    from medtok_amd import ops
+    from medtok_amd.inference import quantize_pooled
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    torch.manual_seed(0)
+    v = VectorQuantizer(3 * 2048, 128, 0.25, 0.0, True, False, [128, 128]).to(dev).eval()
+    h = torch.randn(3000, 256, device=dev); pt = torch.randn(3000, 128, device=dev); pg = torch.randn(3000, 128, device=dev)
+    a = quantize_pooled(v, h, pt, pg)
+    v.search_path = ops.PATH_F32_MFMA
+    b = quantize_pooled(v, h, pt, pg)
+    for u, w in zip(a, b):
+        assert torch.equal(u, w)
