@@ -29,16 +29,22 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
-constexpr int F_BM = 128, F_BN = 128, F_BK = 64;              // codes x rows x k (fp16 elements) per stage
-constexpr int F_ROWB = F_BK * 2;                              // bytes per staged tile row (128)
+constexpr int F_BM = 256, F_BN = 256, F_BK = 32;              // codes x rows x k (fp16 elements) per stage
+constexpr int F_THREADS = 512;                                // 8 waves: 2 code-side x 4 row-side, wave tile 128 x 64
+constexpr int F_ROWB = F_BK * 2;                              // bytes per staged tile row (64)
 constexpr int F_TILEB = F_BM * F_ROWB;                        // 16 KB per operand tile
-constexpr int F_STAGEB = 2 * F_TILEB;                         // A + B
-constexpr size_t F_LDS_BYTES = 2 * F_STAGEB;                  // double buffered: 64 KB -> 2 blocks / CU
+constexpr int F_STAGEB = 2 * F_TILEB;                         // A + B = 32 KB
+constexpr int F_RING = 4;                                     // stages in the LDS ring: 3 in flight while 1 is computed on
+constexpr size_t F_LDS_BYTES = (size_t)F_RING * F_STAGEB;     // 128 KB -> 1 block (8 waves) / CU
+constexpr size_t F_SMEM_BYTES = F_LDS_BYTES + 256 * sizeof(float);   // + per-row shared thresholds
+constexpr int F_GLDS_PER_STAGE = 4;                           // LDS-DMA instructions each wave issues per stage
 constexpr int F_CAP = 64;                                     // candidate slots per (row, owner)
 constexpr int F_OWN_PER_SPLIT = 4;                            // 2 half-waves x 2 code-side waves
 constexpr float F_PRESCALE = 256.0f;                          // 2^8 on both operands
 constexpr float F_UNSCALE = 1.0f / 65536.0f;
 constexpr float F_NORM_LIMIT = 4.0f;                          // |x|^2, |e|^2 above this -> exact path
+constexpr int R_ROWS = 16;                                    // rows per re-score block (16 lanes each)
+constexpr int R_SURV = 64;                                    // survivors per row the re-score kernel can hold
 
 __host__ __device__ inline float filter_gamma(int d) { return 0x1p-10f + 0x1p-20f + (float)d * 0x1p-21f; }
 
@@ -116,23 +122,25 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 }
 
 // ---------------------------------------------------------------- the filter kernel
-// Block = 4 waves (2 code-side x 2 row-side), tile 128 codes x 128 rows, each wave 64 x 64 = 2 x 2 MFMA
-// tiles of 32x32x16.  Operands arrive by LDS-DMA (global_load_lds, 16 B/lane) into a double buffer; a
-// tile row is 128 B = 8 chunks, stored at chunk position c ^ ((row >> 1) & 7) so that the 16 rows a
-// ds_read_b128 lane group touches land on 16 distinct 16-byte bank slots (the permutation is applied
-// to the per-lane SOURCE address; the LDS image itself is lane-linear as the DMA requires).
+// Block = 8 waves (2 code-side x 4 row-side), tile 256 codes x 256 rows, wave tile 128 x 64 = 4 x 2 MFMA
+// tiles of 32x32x16 (L2->LDS traffic per flop halves against a 128^2 tile; at fp16 rates that is what
+// binds).  Operands arrive by LDS-DMA (global_load_lds, 16 B/lane) into a double buffer; a tile row is
+// 128 B = 8 chunks, stored at chunk position c ^ ((row >> 1) & 7) so that the 16 rows a ds_read_b128
+// lane group touches land on 16 distinct 16-byte bank slots (the permutation is applied to the
+// per-lane SOURCE address; the LDS image itself is lane-linear as the DMA requires).
 // As in the fp32 kernel, codes are the A rows: a lane ends up with 16 codes of one input row per tile,
-// so thresholds and candidate appends are lane-local.
+// so thresholds and candidate appends are lane-local.  wsqp is a 16-byte aligned copy of wsq padded
+// with +inf to a multiple of 256, so the epilogue reads it as float4 with no bounds checks.
 template <int TOPK, bool DUMP>
-__global__ __launch_bounds__(256, 2) void filter_f16_kernel(
+__global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     const _Float16 *__restrict__ xh, const _Float16 *__restrict__ wh, const float *__restrict__ xsq,
-    const float *__restrict__ wsq, const float *__restrict__ en_max_ptr, long n, int k_codes, int dp, int d,
+    const float *__restrict__ wsqp, const float *__restrict__ en_max_ptr, long n, int k_codes, int dp, int d,
     int codes_per_split, int own_total, uint2 *__restrict__ cand, int *__restrict__ cand_cnt,
     float *__restrict__ dump)
 {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 31, lh = lane >> 5;
     const long row0 = (long)blockIdx.x * F_BN;
     const int split = blockIdx.y;
@@ -142,124 +150,197 @@ __global__ __launch_bounds__(256, 2) void filter_f16_kernel(
     const int nkb = dp / F_BK;
     const int nstage = nct * nkb;
 
-    // ---- staging: wave w DMA-copies tile rows [32w, 32w+32) of A and of B, 8 rows per instruction
-    const int s_r = lane >> 3, s_c = lane & 7;
+    // ---- staging: wave w DMA-copies tile rows [32w, 32w+32) of A and of B, 16 rows (of 64 B) per instruction.
+    // A tile row holds 4 chunks of 16 B, stored at chunk position c ^ ((row >> 2) & 3).
+    const int s_r = lane >> 2, s_c = lane & 3;
     int pct = 0, pkb = 0;
-    auto stage = [&](int buf) {
-        char *base = fsm + buf * F_STAGEB;
+    auto stage = [&](int slot) {
+        char *base = fsm + slot * F_STAGEB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = wave * 32 + q * 8 + s_r;                       // tile row this lane feeds
-            const int c = s_c ^ ((r >> 1) & 7);                          // source chunk for LDS chunk s_c
+        for (int q = 0; q < 2; ++q) {
+            const int r = wave * 32 + q * 16 + s_r;                      // tile row this lane feeds
+            const int c = s_c ^ ((r >> 2) & 3);                          // source chunk for LDS chunk s_c
             const long koff = (long)pkb * F_BK + c * 8;
             const _Float16 *ga = wh + (long)(code_lo + pct * F_BM + r) * dp + koff;
             const _Float16 *gb = xh + (row0 + r) * dp + koff;
-            glds16(ga, base + (wave * 32 + q * 8) * F_ROWB);
-            glds16(gb, base + F_TILEB + (wave * 32 + q * 8) * F_ROWB);
+            glds16(ga, base + (wave * 32 + q * 16) * F_ROWB);
+            glds16(gb, base + F_TILEB + (wave * 32 + q * 16) * F_ROWB);
         }
         if (++pkb == nkb) { pkb = 0; ++pct; }
     };
 
     // ---- per-lane state: for each of the wave's two 32-row column tiles, the k smallest d~ so far
-    float tv[2][TOPK];
+    float tv[2][TOPK], lim[2], xn[2], win[2];
+    float pend[2][4];                       // values appended during the current code tile, folded into tv at its end
     int cnt[2] = {0, 0};
-#pragma unroll
-    for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-        for (int j = 0; j < TOPK; ++j) tv[nn][j] = INFINITY;
     long xrow[2];
-    float xn[2], win[2];
+    uint2 *cptr[2];                         // next free candidate slot of this (row, owner)
+    float *thr_share = reinterpret_cast<float *>(fsm + F_LDS_BYTES);    // [F_BN] per-row min of the owners' thresholds
     const float en_max = en_max_ptr[0];
-    bool sane = en_max <= F_NORM_LIMIT;
+    const bool sane = en_max <= F_NORM_LIMIT;
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) tv[nn][j] = INFINITY;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pend[nn][q] = INFINITY;
+        lim[nn] = INFINITY;
         xrow[nn] = row0 + wn * 64 + nn * 32 + li;
         xn[nn] = xsq[min(xrow[nn], n - 1)];
         win[nn] = 2.0f * filter_eps(xn[nn], en_max, d);
     }
     const int owner = split * F_OWN_PER_SPLIT + wm * 2 + lh;
-
-    f32x16 acc[2][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int nn = 0; nn < 2; ++nn) cptr[nn] = cand + ((long)min(xrow[nn], n - 1) * own_total + owner) * F_CAP;
+    if (tid < F_BN) thr_share[tid] = INFINITY;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
 
-    // fragment addresses: row i of the tile, chunk (2t + lh) ^ ((i >> 1) & 7)
-    int a_off[2], b_off[2], a_sw[2], b_sw[2];
+    // fragment addresses: row i of the tile, chunk (2t + lh) ^ ((i >> 2) & 3)
+    int a_off[4], a_sw[4], b_off[2], b_sw[2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int ia = wm * 64 + m * 32 + li, ib = wn * 64 + m * 32 + li;
-        a_off[m] = ia * F_ROWB; a_sw[m] = (ia >> 1) & 7;
-        b_off[m] = F_TILEB + ib * F_ROWB; b_sw[m] = (ib >> 1) & 7;
+    for (int m = 0; m < 4; ++m) {
+        const int ia = wm * 128 + m * 32 + li;
+        a_off[m] = ia * F_ROWB; a_sw[m] = (ia >> 2) & 3;
+    }
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+        const int ib = wn * 64 + nn * 32 + li;
+        b_off[nn] = F_TILEB + ib * F_ROWB; b_sw[nn] = (ib >> 2) & 3;
     }
 
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // ---- software pipeline.  LDS ring of 4 stages; MFMA operands double-buffered in registers so the
+    // ds_reads of the NEXT k16-step are in flight while the MFMAs of the current one issue:
+    //   iteration s:  read frags(s, t1)  | MFMA(s, t0)
+    //                 vmcnt (own part of stage s+1 landed) -> raw barrier (everyone's has; slot s-1 is free)
+    //                 LDS-DMA stage s+3  | read frags(s+1, t0) | MFMA(s, t1)
+    // __syncthreads() would drain vmcnt(0) here (an LDS-DMA is a pending LDS write), hence the raw barrier.
+    auto load_frags = [&](half8 (&fa)[4], half8 (&fb)[2], int slot, int t) {
+        const char *base = fsm + slot * F_STAGEB;
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) fb[nn] = *reinterpret_cast<const half8 *>(base + b_off[nn] + (((2 * t + lh) ^ b_sw[nn]) << 4));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const half8 *>(base + a_off[m] + (((2 * t + lh) ^ a_sw[m]) << 4));
+    };
+    auto mfma_group = [&](const half8 (&fa)[4], const half8 (&fb)[2]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb[nn], acc[m][nn], 0, 0, 0);
+    };
+    half8 fa0[4], fb0[2], fa1[4], fb1[2];
+#pragma unroll
+    for (int p = 0; p < F_RING - 1; ++p)
+        if (p < nstage) stage(p);
+    if (nstage >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nstage == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(fa0, fb0, 0, 0);
     int ct = 0, kb = 0;
     for (int s = 0; s < nstage; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nstage) stage(buf ^ 1);
-        const char *base = fsm + buf * F_STAGEB;
-#pragma unroll
-        for (int t = 0; t < F_BK / 16; ++t) {
-            half8 af[2], bf[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                af[m] = *reinterpret_cast<const half8 *>(base + a_off[m] + (((2 * t + lh) ^ a_sw[m]) << 4));
-                bf[m] = *reinterpret_cast<const half8 *>(base + b_off[m] + (((2 * t + lh) ^ b_sw[m]) << 4));
-            }
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int nn = 0; nn < 2; ++nn)
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m], bf[nn], acc[m][nn], 0, 0, 0);
-        }
+        const int slot = s % F_RING;
+        load_frags(fa1, fb1, slot, 1);
+        mfma_group(fa0, fb0);
+        // stage s+1 must be visible before its fragments are read; stage s+2 may stay in flight
+        if (s + 2 < nstage) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 3 < nstage) stage((s + 3) % F_RING);
+        load_frags(fa0, fb0, (s + 1) % F_RING, 0);      // (past the last stage this reads stale LDS, never used)
+        mfma_group(fa1, fb1);
+#ifdef MEDTOK_FILTER_NOEPI      // dev experiment: main loop only (results are garbage)
         if (++kb == nkb) {
-            const int cbase = code_lo + ct * F_BM + wm * 64 + 4 * lh;
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn) {
-                float dv[2][16];
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int nn = 0; nn < 2; ++nn) {
+                    asm volatile("" ::"v"(acc[m][nn]));
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2);
-                        const float en = wsq[min(code, k_codes - 1)];
-                        const float sum = xn[nn] + en;
-                        const float two = 2.0f * (acc[m][nn][r] * F_UNSCALE);
-                        float v = sum - two;
-                        if (code >= code_hi) v = INFINITY;
-                        if (DUMP) {
-                            if (code < code_hi && xrow[nn] < n) dump[xrow[nn] * k_codes + code] = acc[m][nn][r] * F_UNSCALE;
-                        }
-                        dv[m][r] = v;
-                        thr_insert<TOPK>(tv[nn], v);
-                        acc[m][nn][r] = 0.f;
-                    }
-                if (!DUMP) {
-                    const float lim = tv[nn][TOPK - 1] + win[nn];
-                    uint2 *slot = cand + ((long)xrow[nn] * own_total + owner) * F_CAP;
+                    for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+                }
+            kb = 0; ++ct;
+        }
+        continue;
+#endif
+        if (++kb == nkb) {
+            // ---- epilogue.  d~ = (xn + en) - 2 * 2^-16 * acc, one fmaf; a 16-wide min rejects whole tiles.
+            const int cbase = code_lo + ct * F_BM + wm * 128 + 4 * lh;
+            const bool warm = (ct == 0);
+            if (!DUMP && warm) {
+                // First code tile: learn the thresholds from all 128 codes BEFORE appending anything, so the
+                // candidate lists do not fill up with the loose early threshold (appends only ever need T >= t~).
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2);
-                            if (dv[m][r] <= lim && code < code_hi) {
-                                if (cnt[nn] < F_CAP && xrow[nn] < n) slot[cnt[nn]] = make_uint2(__float_as_uint(dv[m][r]), (unsigned)code);
-                                ++cnt[nn];
-                            }
+                            const float en = wsqp[cbase + 32 * m + (r & 3) + 8 * (r >> 2)];
+                            thr_insert<TOPK>(tv[nn], fmaf(acc[m][nn][r], -0x1p-15f, xn[nn] + en));
                         }
+                }
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) lim[nn] = tv[nn][TOPK - 1] + win[nn];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float4 en4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) en4[g] = ld4(wsqp + cbase + 32 * m + 8 * g);
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float en = (r & 3) == 0 ? en4[r >> 2].x : (r & 3) == 1 ? en4[r >> 2].y : (r & 3) == 2 ? en4[r >> 2].z : en4[r >> 2].w;
+                        const float v = fmaf(acc[m][nn][r], -0x1p-15f, xn[nn] + en);
+                        const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2);
+                        if (DUMP) {
+                            if (code < code_hi && xrow[nn] < n) dump[xrow[nn] * k_codes + code] = acc[m][nn][r] * F_UNSCALE;
+                        } else if (v <= lim[nn] && v < INFINITY) {
+                            // rare per lane (about 6/m after m codes) but not per wave: keep this body minimal.
+                            // Threshold upkeep is deferred: any T >= t~ is valid, a stale one only appends a bit more.
+                            if (cnt[nn] < F_CAP && xrow[nn] < n) *cptr[nn] = make_uint2(__float_as_uint(v), (unsigned)code);
+                            ++cptr[nn];
+                            ++cnt[nn];
+                            if (!warm) { pend[nn][3] = pend[nn][2]; pend[nn][2] = pend[nn][1]; pend[nn][1] = pend[nn][0]; pend[nn][0] = v; }
+                        }
+                        acc[m][nn][r] = 0.f;
+                    }
+                }
+            }
+            if (!DUMP) {
+                // fold what this tile appended into the k-smallest list (a 5th arrival in one tile pushed the oldest
+                // out: dropping a value keeps T valid, merely looser), then share: the row's k-th best over all codes
+                // seen by ANY owner is <= every owner's own k-th best, so the minimum of the owners' values is valid.
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { thr_insert<TOPK>(tv[nn], pend[nn][q]); pend[nn][q] = INFINITY; }
+                    float t = tv[nn][TOPK - 1];
+                    t = fminf(t, __shfl_xor(t, 32, 64));
+                    float *sh = thr_share + wn * 64 + nn * 32 + li;
+                    if (lh == 0 && t < INFINITY) {
+                        // non-negative floats order like their bit patterns; clamping at 0 only loosens T
+                        const unsigned old = atomicMin(reinterpret_cast<unsigned *>(sh), __float_as_uint(fmaxf(t, 0.f)));
+                        t = fminf(fmaxf(t, 0.f), __uint_as_float(old));
+                    }
+                    t = fminf(t, __shfl_xor(t, 32, 64));
+                    lim[nn] = t + win[nn];
                 }
             }
             kb = 0;
             ++ct;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
     if (!DUMP) {
 #pragma unroll
@@ -272,9 +353,11 @@ __global__ __launch_bounds__(256, 2) void filter_f16_kernel(
 }
 
 // ---------------------------------------------------------------- exact re-score
-// 16 lanes per row.  Phase 1: the row's true t~ (k-th smallest d~ over all owners' candidates).
-// Phase 2: every candidate with d~ <= t~ + 2 eps is re-scored with the canonical fp32 chain and merged
-// into an exact (d, index) top-k.  Overflowed rows are appended to the fallback list.
+// Block = 16 rows x 16 lanes.  Phase 1 (per row, 16 lanes): the row's true t~ = k-th smallest d~ over
+// all owners' candidates.  Phase 2a: candidates with d~ <= t~ + 2 eps are compacted into an LDS list.
+// Phase 2b: the block's survivors (about 7 per row) are spread densely over all 256 threads and each is
+// re-scored with the canonical fp32 chain -- x rows come from LDS (staged once per block), code rows
+// from L2.  Phase 3 (per row): exact (d, index) top-k of the row's survivors.
 template <int TOPK>
 __global__ __launch_bounds__(256) void rescore_kernel(
     const uint2 *__restrict__ cand, const int *__restrict__ cand_cnt, int own_total,
@@ -282,77 +365,116 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     const float *__restrict__ wsq, const float *__restrict__ en_max_ptr, long n, int k_codes, int d, int topk_out,
     int64_t *__restrict__ out_idx, float *__restrict__ out_dist, int *__restrict__ fb_count, int *__restrict__ fb_rows)
 {
-    const int l16 = threadIdx.x & 15;
-    const long pos = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    extern __shared__ __attribute__((aligned(16))) char rsm[];
+    float *xs = reinterpret_cast<float *>(rsm);                                   // [R_ROWS][d]
+    int *s_code = reinterpret_cast<int *>(rsm + (size_t)R_ROWS * d * 4);          // [R_ROWS][R_SURV]
+    float *s_d = reinterpret_cast<float *>(s_code + R_ROWS * R_SURV);             // [R_ROWS][R_SURV]
+    int *s_cnt = reinterpret_cast<int *>(s_d + R_ROWS * R_SURV);                  // [R_ROWS] survivors, [R_ROWS] offsets
+    const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    const long pos = (long)blockIdx.x * R_ROWS + g;
     const long row = min(pos, n - 1);
+    if (threadIdx.x < R_ROWS) s_cnt[threadIdx.x] = 0;
+    // stage the block's x rows (coalesced)
+    {
+        const long r0 = (long)blockIdx.x * R_ROWS;
+        const int per_row = d / 4;
+        for (int t = threadIdx.x; t < R_ROWS * per_row; t += 256) {
+            const int rr = t / per_row, c = t - rr * per_row;
+            st4(xs + rr * d + c * 4, ld4(xhat + min(r0 + rr, n - 1) * d + c * 4));
+        }
+    }
     const float xn = xsq[row];
     const float win = 2.0f * filter_eps(xn, en_max_ptr[0], d);
     const uint2 *rc = cand + row * own_total * F_CAP;
     const int *cc = cand_cnt + row * own_total;
 
-    // ---- phase 1
-    float tv[TOPK];
-#pragma unroll
-    for (int j = 0; j < TOPK; ++j) tv[j] = INFINITY;
     bool overflow = false;
     for (int o = 0; o < own_total; ++o) overflow |= cc[o] > F_CAP;
-    if (overflow) {
-        // shortlist incomplete (buffer full, or the filter refused the row): the exact kernel redoes it.
-        // The whole 16-lane group takes this branch together, so the width-16 shuffles below stay safe.
+    __syncthreads();
+    // ---- phase 1 + 2a (skipped for rows the filter gave up on; the 16-lane group branches together)
+    if (!overflow) {
+        float tv[TOPK];
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) tv[j] = INFINITY;
+        for (int o = 0; o < own_total; ++o) {
+            const int m = cc[o];
+            for (int sidx = l16; sidx < m; sidx += 16) thr_insert<TOPK>(tv, __uint_as_float(rc[o * F_CAP + sidx].x));
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            float pv[TOPK];
+#pragma unroll
+            for (int j = 0; j < TOPK; ++j) pv[j] = __shfl_xor(tv[j], off, 16);
+#pragma unroll
+            for (int j = 0; j < TOPK; ++j) thr_insert<TOPK>(tv, pv[j]);
+        }
+        float kth = tv[0];
+#pragma unroll
+        for (int j = 1; j < TOPK; ++j) kth = (j < topk_out) ? tv[j] : kth;
+        const float lim = kth + win;
+        for (int o = 0; o < own_total; ++o) {
+            const int m = cc[o];
+            for (int sidx = l16; sidx < m; sidx += 16) {
+                const uint2 e = rc[o * F_CAP + sidx];
+                if (__uint_as_float(e.x) <= lim && e.y < (unsigned)k_codes) {
+                    const int p = atomicAdd(&s_cnt[g], 1);
+                    if (p < R_SURV) s_code[g * R_SURV + p] = (int)e.y;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // rows with more survivors than the list holds also go to the exact path
+    if (threadIdx.x < R_ROWS && s_cnt[threadIdx.x] > R_SURV) s_cnt[threadIdx.x] = -1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int r = 0; r < R_ROWS; ++r) { s_cnt[R_ROWS + r] = run; run += max(s_cnt[r], 0); }
+        s_cnt[2 * R_ROWS] = run;
+    }
+    __syncthreads();
+    // ---- phase 2b: dense exact chains
+    const int total = s_cnt[2 * R_ROWS];
+    for (int wi = threadIdx.x; wi < total; wi += 256) {
+        int rr = 0;
+#pragma unroll
+        for (int r = 1; r < R_ROWS; ++r) rr += (wi >= s_cnt[R_ROWS + r]) ? 1 : 0;
+        const int j = wi - s_cnt[R_ROWS + rr];
+        const int code = s_code[rr * R_SURV + j];
+        const float *xr = xs + rr * d;
+        const float *wr = what + (long)code * d;
+        float accv = 0.f;
+        int i = 0;
+        for (; i + 8 <= d; i += 8) {                 // canonical order within a group: 0,4,1,5,2,6,3,7
+            const float4 x0 = ld4(xr + i), x1 = ld4(xr + i + 4);
+            const float4 w0 = ld4(wr + i), w1 = ld4(wr + i + 4);
+            accv = fmaf(x0.x, w0.x, accv); accv = fmaf(x1.x, w1.x, accv);
+            accv = fmaf(x0.y, w0.y, accv); accv = fmaf(x1.y, w1.y, accv);
+            accv = fmaf(x0.z, w0.z, accv); accv = fmaf(x1.z, w1.z, accv);
+            accv = fmaf(x0.w, w0.w, accv); accv = fmaf(x1.w, w1.w, accv);
+        }
+        if (i < d) {                                  // D % 8 == 4: the last half group
+            const float4 x0 = ld4(xr + i), w0 = ld4(wr + i);
+            accv = fmaf(x0.x, w0.x, accv); accv = fmaf(x0.y, w0.y, accv);
+            accv = fmaf(x0.z, w0.z, accv); accv = fmaf(x0.w, w0.w, accv);
+        }
+        const long arow = min((long)blockIdx.x * R_ROWS + rr, n - 1);
+        const float sum = xsq[arow] + wsq[code];
+        const float two = 2.0f * accv;
+        s_d[rr * R_SURV + j] = sum - two;
+    }
+    __syncthreads();
+    // ---- phase 3: exact top-k of the row's survivors
+    const int mine = s_cnt[g];
+    if (overflow || mine < 0) {
         if (l16 == 0 && pos < n) fb_rows[atomicAdd(fb_count, 1)] = (int)row;
         return;
     }
-    for (int o = 0; o < own_total; ++o) {
-        const int m = cc[o];
-        for (int sidx = l16; sidx < m; sidx += 16) thr_insert<TOPK>(tv, __uint_as_float(rc[o * F_CAP + sidx].x));
-    }
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-        float pv[TOPK];
-#pragma unroll
-        for (int j = 0; j < TOPK; ++j) pv[j] = __shfl_xor(tv[j], off, 16);
-#pragma unroll
-        for (int j = 0; j < TOPK; ++j) thr_insert<TOPK>(tv, pv[j]);
-    }
-    float kth = tv[0];
-#pragma unroll
-    for (int j = 1; j < TOPK; ++j) kth = (j < topk_out) ? tv[j] : kth;
-    const float lim = kth + win;
-
-    // ---- phase 2
     float bv[TOPK];
     int bi[TOPK];
 #pragma unroll
     for (int j = 0; j < TOPK; ++j) { bv[j] = INFINITY; bi[j] = 0x7fffffff; }
-    const float *xr = xhat + row * d;
-    for (int o = 0; o < own_total; ++o) {
-        const int m = cc[o];
-        for (int sidx = l16; sidx < m; sidx += 16) {
-            const uint2 e = rc[o * F_CAP + sidx];
-            if (__uint_as_float(e.x) <= lim && e.y < (unsigned)k_codes) {
-                const int code = (int)e.y;
-                const float *wr = what + (long)code * d;
-                float accv = 0.f;
-                int i = 0;
-                for (; i + 8 <= d; i += 8) {                 // canonical order within a group: 0,4,1,5,2,6,3,7
-                    const float4 x0 = ld4(xr + i), x1 = ld4(xr + i + 4);
-                    const float4 w0 = ld4(wr + i), w1 = ld4(wr + i + 4);
-                    accv = fmaf(x0.x, w0.x, accv); accv = fmaf(x1.x, w1.x, accv);
-                    accv = fmaf(x0.y, w0.y, accv); accv = fmaf(x1.y, w1.y, accv);
-                    accv = fmaf(x0.z, w0.z, accv); accv = fmaf(x1.z, w1.z, accv);
-                    accv = fmaf(x0.w, w0.w, accv); accv = fmaf(x1.w, w1.w, accv);
-                }
-                if (i < d) {                                  // D % 8 == 4: the last half group
-                    const float4 x0 = ld4(xr + i), w0 = ld4(wr + i);
-                    accv = fmaf(x0.x, w0.x, accv); accv = fmaf(x0.y, w0.y, accv);
-                    accv = fmaf(x0.z, w0.z, accv); accv = fmaf(x0.w, w0.w, accv);
-                }
-                const float sum = xn + wsq[code];
-                const float two = 2.0f * accv;
-                topk_insert_lex<TOPK>(bv, bi, sum - two, code);
-            }
-        }
-    }
+    for (int j = l16; j < mine; j += 16) topk_insert_lex<TOPK>(bv, bi, s_d[g * R_SURV + j], s_code[g * R_SURV + j]);
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) {
         float pv[TOPK];
@@ -367,4 +489,11 @@ __global__ __launch_bounds__(256) void rescore_kernel(
         for (int j = 0; j < TOPK; ++j)
             if (j < topk_out) { out_idx[row * topk_out + j] = bi[j]; out_dist[row * topk_out + j] = bv[j]; }
     }
+}
+
+// padded, aligned copy of wsq: [k_pad] with +inf beyond k_codes
+__global__ __launch_bounds__(256) void pad_wsq_kernel(const float *__restrict__ wsq, int k, int k_pad, float *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < k_pad) out[i] = i < k ? wsq[i] : INFINITY;
 }

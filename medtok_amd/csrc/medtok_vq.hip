@@ -408,7 +408,8 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
     f.row_tiles = f.n_pad / F_BN;
     const long code_tiles = f.k_pad / F_BM;
     // every split adds 4 candidate lists per row, so split only as far as filling the chip needs
-    long want = f.row_tiles >= 8192 ? 1 : (f.row_tiles >= 1024 ? 2 : (2048 + f.row_tiles - 1) / f.row_tiles);
+    // one 8-wave block per CU: a launch of B equal blocks wastes up to one round of 256
+    long want = f.row_tiles >= 4096 ? 1 : (f.row_tiles >= 1024 ? 2 : (1024 + f.row_tiles - 1) / f.row_tiles);
     if (want > code_tiles) want = code_tiles;
     if (want > 16) want = 16;
     const long tiles_per_split = (code_tiles + want - 1) / want;
@@ -420,7 +421,7 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
 
 struct FilterWs {
     _Float16 *xh, *wh;
-    float *en_max, *dump;
+    float *en_max, *wsqp, *dump;
     uint2 *cand;
     int *cand_cnt, *fb_count, *fb_rows;
     size_t total;
@@ -434,6 +435,7 @@ static FilterWs filter_ws_layout(void *ws, int64_t n, const FilterPlan &f)
     w.xh = (_Float16 *)take((size_t)f.n_pad * f.dp * 2);
     w.wh = (_Float16 *)take((size_t)f.k_pad * f.dp * 2);
     w.en_max = (float *)take(4);
+    w.wsqp = (float *)take((size_t)f.k_pad * 4);
     w.fb_count = (int *)take(4);
     w.fb_rows = (int *)take((size_t)n * 4);
     w.cand_cnt = (int *)take((size_t)n * f.own_total * 4);
@@ -445,8 +447,7 @@ static FilterWs filter_ws_layout(void *ws, int64_t n, const FilterPlan &f)
 
 static bool filter_eligible(int64_t n, int64_t k_codes, int d, int topk)
 {
-    (void)d;
-    return n >= 256 && k_codes >= 1024 && topk <= MEDTOK_MAX_TOPK && n < (1ll << 31);
+    return n >= 256 && k_codes >= 1024 && d <= 2048 && topk <= MEDTOK_MAX_TOPK && n < (1ll << 31);
 }
 
 static int resolve_path(int path, int64_t n, int64_t k_codes, int d, int topk)
@@ -514,13 +515,16 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.n_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, xhat, (long)n, d, f.n_pad, f.dp, w.xh);
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, w.wh);
     hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, w.en_max);
+    hipLaunchKernelGGL(pad_wsq_kernel, dim3((unsigned)((f.k_pad + 255) / 256)), dim3(256), 0, s, wsq, (int)k_codes, (int)f.k_pad, w.wsqp);
     if (hipMemsetAsync(w.fb_count, 0, 4, s) != hipSuccess) return fail("search(filter): memset failed");
-    (void)hipFuncSetAttribute((const void *)filter_f16_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
-    hipLaunchKernelGGL((filter_f16_kernel<T, false>), dim3((unsigned)f.row_tiles, (unsigned)f.splits), dim3(256), F_LDS_BYTES, s,
-                       w.xh, w.wh, xsq, wsq, w.en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
+    (void)hipFuncSetAttribute((const void *)filter_f16_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM_BYTES);
+    hipLaunchKernelGGL((filter_f16_kernel<T, false>), dim3((unsigned)f.row_tiles, (unsigned)f.splits), dim3(F_THREADS), F_SMEM_BYTES, s,
+                       w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
                        w.cand, w.cand_cnt, (float *)nullptr);
     if (check_launch("filter_f16")) return 1;
-    hipLaunchKernelGGL((rescore_kernel<T>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, w.cand, w.cand_cnt, f.own_total,
+    const size_t rs_lds = (size_t)R_ROWS * d * 4 + (size_t)R_ROWS * R_SURV * 8 + (2 * R_ROWS + 1) * 4;
+    (void)hipFuncSetAttribute((const void *)rescore_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
+    hipLaunchKernelGGL((rescore_kernel<T>), dim3((unsigned)((n + R_ROWS - 1) / R_ROWS)), dim3(256), rs_lds, s, w.cand, w.cand_cnt, f.own_total,
                        xhat, xsq, what, wsq, w.en_max, (long)n, (int)k_codes, d, topk, idx, dist, w.fb_count, w.fb_rows);
     if (check_launch("rescore")) return 1;
     // exact redo of the rows the filter gave up on (normally none: the grid exits on *fb_count)
@@ -572,7 +576,7 @@ extern "C" size_t medtok_debug_filter_scores_workspace_bytes(int64_t n, int64_t 
 {
     if (n <= 0 || k_codes <= 0 || d <= 0) return 0;
     FilterPlan f = plan_filter(n, k_codes, d, 5);
-    return align_up((size_t)f.n_pad * f.dp * 2, 256) + align_up((size_t)f.k_pad * f.dp * 2, 256) + 512;
+    return align_up((size_t)f.n_pad * f.dp * 2, 256) + align_up((size_t)f.k_pad * f.dp * 2, 256) + 512 + align_up((size_t)f.k_pad * 4, 256);
 }
 
 extern "C" int medtok_debug_filter_scores_f32(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
@@ -581,15 +585,17 @@ extern "C" int medtok_debug_filter_scores_f32(const float *xhat, const float *xs
     if (n <= 0 || k_codes <= 0 || d <= 0 || (d & 3)) return fail("debug_filter_scores: bad shape");
     FilterPlan f = plan_filter(n, k_codes, d, 5);
     const size_t xb = align_up((size_t)f.n_pad * f.dp * 2, 256), wb = align_up((size_t)f.k_pad * f.dp * 2, 256);
-    if (!ws || ws_bytes < xb + wb + 512) return fail("debug_filter_scores: workspace too small");
+    if (!ws || ws_bytes < xb + wb + 512 + (size_t)f.k_pad * 4) return fail("debug_filter_scores: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     _Float16 *xh = (_Float16 *)ws, *wh = (_Float16 *)((char *)ws + xb);
     float *en_max = (float *)((char *)ws + xb + wb);
+    float *wsqp = (float *)((char *)ws + xb + wb + 512);
+    hipLaunchKernelGGL(pad_wsq_kernel, dim3((unsigned)((f.k_pad + 255) / 256)), dim3(256), 0, s, wsq, (int)k_codes, (int)f.k_pad, wsqp);
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.n_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, xhat, (long)n, d, f.n_pad, f.dp, xh);
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, wh);
     hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, en_max);
-    (void)hipFuncSetAttribute((const void *)filter_f16_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
-    hipLaunchKernelGGL((filter_f16_kernel<5, true>), dim3((unsigned)f.row_tiles, 1), dim3(256), F_LDS_BYTES, s, xh, wh, xsq, wsq, en_max,
+    (void)hipFuncSetAttribute((const void *)filter_f16_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM_BYTES);
+    hipLaunchKernelGGL((filter_f16_kernel<5, true>), dim3((unsigned)f.row_tiles, 1), dim3(F_THREADS), F_SMEM_BYTES, s, xh, wh, xsq, wsqp, en_max,
                        (long)n, (int)k_codes, f.dp, d, (int)f.k_pad, F_OWN_PER_SPLIT, (uint2 *)nullptr, (int *)nullptr, scores);
     return check_launch("filter_f16(dump)");
 }

@@ -30,7 +30,9 @@ def test_library_loads_and_reports_version():
     assert lib.medtok_abi_version() == _lib.ABI_VERSION
     # size queries are host-only arithmetic: safe without a GPU
     assert lib.medtok_search_workspace_bytes(1000, 8192, 768, 5, 0) > 0
-    assert lib.medtok_search_workspace_bytes(3000000, 16384, 768, 5, 0) == 256     # enough row tiles: single split, no scratch
+    assert lib.medtok_search_workspace_bytes(3000000, 16384, 768, 5, _lib.PATH_F32_MFMA) == 256   # exact path, single split: no scratch
+    assert lib.medtok_search_workspace_bytes(100000, 8192, 768, 5, _lib.PATH_F16_FILTER) > 100000 * 768 * 2   # fp16 copy + candidate lists
+    assert lib.medtok_search_workspace_bytes(100, 64, 32, 5, _lib.PATH_AUTO) == lib.medtok_search_workspace_bytes(100, 64, 32, 5, _lib.PATH_F32_MFMA)
     assert lib.medtok_ema_stats_workspace_bytes(100000, 8192) > 8 * 100000
     assert lib.medtok_usage_workspace_bytes(300000, 21000) >= 300000 * 4
 
