@@ -34,6 +34,7 @@ from medtok_amd import distributed as mdist  # noqa: E402
 from medtok_amd import ops  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, dense f32-input MFMA
+F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md, dense BF16/FP16 MFMA (the 5 PF headline figure is 2:1 sparse)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -46,6 +47,7 @@ def parse():
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default 600000 for cfg3, 100000 for cfg2)")
     ap.add_argument("--path", type=int, default=ops.PATH_AUTO)
     ap.add_argument("--cpu-rows", type=int, default=None, help="row sample for the CPU baseline (0 disables)")
+    ap.add_argument("--exact-steps", type=int, default=1, help="extra steps on the exact fp32-MFMA path for comparison (0 disables)")
     return ap.parse_args()
 
 
@@ -71,6 +73,9 @@ class Cfg3:
 
     def flops_per_code(self):
         return 2.0 * self.D * (2 * self.REGION + 2 * self.N_E)
+
+    def set_path(self, path):
+        self.vq.search_path = path
 
     def step(self):
         from medtok_amd.inference import quantize_pooled
@@ -112,6 +117,9 @@ class Cfg2:
     def flops_per_code(self):
         return 2.0 * self.K * self.D
 
+    def set_path(self, path):
+        self.q.search_path = path
+
     def step(self):
         with torch.no_grad():
             return self.q(self.z)
@@ -131,12 +139,12 @@ class Cfg2:
                     sample=f"{sample_rows} rows, argmin + EMA train step, reference op sequence in CPU PyTorch, {dt:.1f} s")
 
 
-def pmc_traffic(workload):
-    """HBM bytes per search launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
+def pmc_traffic(workload, kernel):
+    """Fabric bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or None."""
     f = ROOT / "profiles" / "pmc_traffic.json"
     if f.exists():
         try:
-            return json.loads(f.read_text()).get(workload)
+            return json.loads(f.read_text()).get(workload, {}).get(kernel)
         except Exception:
             return None
     return None
@@ -159,7 +167,7 @@ def main():
     torch.cuda.synchronize(dev)
     mdist.barrier()
     torch.cuda.synchronize(dev)
-    events = ops.SEARCH_TIMER = []       # HIP events around every search launch, on its launch stream
+    ops.profile_begin()                  # library brackets each search-kernel launch with HIP events on its stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
@@ -167,13 +175,33 @@ def main():
     mdist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+    prof = ops.profile_end()
 
-    # dominant kernel: fp32-MFMA search, timed by the HIP events recorded on its launch stream
-    ops.SEARCH_TIMER = None
-    k_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in events)
-    k_flops = sum(f for _, _, f in events)
-    launches = len(events)
-    achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    # the exact fp32-MFMA path on the same workload (1 step): the filter path returns the same bits, faster
+    exact = None
+    if args.path == ops.PATH_AUTO and args.exact_steps > 0:
+        wl.set_path(ops.PATH_F32_MFMA)
+        wl.step()
+        torch.cuda.synchronize(dev)
+        ops.profile_begin()
+        t1 = time.perf_counter()
+        for _ in range(args.exact_steps):
+            wl.step()
+        torch.cuda.synchronize(dev)
+        e_elapsed = time.perf_counter() - t1
+        e_prof = ops.profile_end()["search_f32_kernel"]
+        e_ach = e_prof["flops"] / (e_prof["ms"] * 1e-3) / 1e12 if e_prof["ms"] > 0 else 0.0
+        exact = {"value": rows * args.exact_steps / e_elapsed, "unit": "codes/s per GPU", "steps": args.exact_steps,
+                 "roofline": {"bound": "mfma", "kernel": "search_f32_kernel", "achieved": e_ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": e_ach / FP32_MFMA_PEAK_TFLOPS,
+                              "avg_launch_ms": e_prof["ms"] / max(e_prof["launches"], 1)}}
+        wl.set_path(args.path)
+
+    # dominant kernel = the search kernel with the most time in the timed region
+    kname = max(prof, key=lambda k: prof[k]["ms"])
+    kp = prof[kname]
+    peak = F16_MFMA_PEAK_TFLOPS if kname == "filter_f16_kernel" else FP32_MFMA_PEAK_TFLOPS
+    achieved = kp["flops"] / (kp["ms"] * 1e-3) / 1e12 if kp["ms"] > 0 else 0.0
 
     if rank == 0:
         total_codes = float(rows) * world * args.steps
@@ -192,15 +220,19 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl.description, "rows_per_gpu": rows, "D": wl.D, "search_path": args.path,
+                       "search": ("fp16-MFMA shortlist with a proven error bound + exact fp32 re-score: token ids and distances are "
+                                  "bit-identical to the fp32-MFMA path (tests/test_gpu_filter.py)" if kname == "filter_f16_kernel"
+                                  else "exact fp32 MFMA"),
                        "parallelism": f"row-shard x{world}, codebook replicated, no data-path collective"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(wl.name),
-                         "kernel": "search_f32_kernel", "launches_timed": launches,
-                         "avg_launch_ms": k_ms / max(launches, 1),
-                         "algorithmic_flops_per_launch": k_flops / max(launches, 1),
-                         "search_share_of_step": k_ms / (elapsed * 1e3),
-                         "whole_step_tflops": wl.flops_per_code() * rows * args.steps / elapsed / 1e12,
-                         "hbm_frac_of_step": None},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": pmc_traffic(wl.name, kname), "kernel": kname,
+                         "peak_note": ("dense f16 MFMA" if kname == "filter_f16_kernel" else "dense f32-input MFMA") + " (MI355X_MICROARCH.md)",
+                         "launches_timed": kp["launches"], "avg_launch_ms": kp["ms"] / max(kp["launches"], 1),
+                         "algorithmic_flops_per_launch": kp["flops"] / max(kp["launches"], 1),
+                         "kernel_share_of_step": kp["ms"] / (elapsed * 1e3),
+                         "achieved_over_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "whole_step_tflops": wl.flops_per_code() * rows * args.steps / elapsed / 1e12},
+            "exact_fp32_path": exact,
         }
         cpu_rows = args.cpu_rows if args.cpu_rows is not None else (4096 if args.workload == "cfg3" else 16384)
         if world == 1 and cpu_rows > 0:

@@ -50,6 +50,13 @@ extern "C" {
 int medtok_abi_version(void);
 const char *medtok_last_error(void);
 
+/* Optional self-profiling for bench.py: between _begin and _end every search-kernel launch is
+ * bracketed by HIP events on its launch stream (no host sync until _end).  _end fills, for
+ * kind 0 = filter_f16_kernel and kind 1 = search_f32_kernel: total milliseconds, total
+ * algorithmic flops (2*n*K*D per launch) and the number of launches.  Thread-local. */
+int medtok_profile_begin(void);
+int medtok_profile_end(double ms[2], double flops[2], int launches[2]);
+
 /* F.normalize(x, p=2, dim=-1, eps=1e-12) and the squared norm of the result.
  * Replaces vector_quantization_soft_one_new.py:148,150-151,196,198,200 and
  * norm_ema_quantizer.py:8-9,170 plus the two torch.sum(..**2) terms of

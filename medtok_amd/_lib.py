@@ -21,6 +21,8 @@ _vp, _i64, _int, _sz, _f, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c
 SIGNATURES = {
     "medtok_abi_version": (_int, []),
     "medtok_last_error": (C.c_char_p, []),
+    "medtok_profile_begin": (_int, []),
+    "medtok_profile_end": (_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "medtok_rownorm_f32": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
     "medtok_search_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int]),
     "medtok_topk_search_f32": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _int, _vp]),

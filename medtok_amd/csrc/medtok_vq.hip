@@ -20,6 +20,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/medtok_vq.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -46,6 +48,45 @@ static int check_launch(const char *what)
 
 extern "C" int medtok_abi_version(void) { return MEDTOK_VQ_ABI_VERSION; }
 extern "C" const char *medtok_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------- optional self-profiling (bench.py)
+// Between medtok_profile_begin() and medtok_profile_end() every launch of a search kernel is
+// bracketed by HIP events recorded on its own launch stream; nothing synchronises until _end().
+struct ProfRec { hipEvent_t a, b; double flops; int kind; };   // kind 0 = filter_f16_kernel, 1 = search_f32_kernel
+static thread_local bool g_prof_on = false;
+static thread_local std::vector<ProfRec> g_prof;
+
+static hipEvent_t prof_mark(hipStream_t s)
+{
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    (void)hipEventRecord(e, s);
+    return e;
+}
+
+extern "C" int medtok_profile_begin(void)
+{
+    for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = true;
+    return 0;
+}
+
+extern "C" int medtok_profile_end(double *ms, double *flops, int *launches)
+{
+    g_prof_on = false;
+    for (int k = 0; k < 2; ++k) { ms[k] = 0.0; flops[k] = 0.0; launches[k] = 0; }
+    for (auto &r : g_prof) {
+        float t = 0.f;
+        if (r.a && r.b && hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            ms[r.kind] += t; flops[r.kind] += r.flops; launches[r.kind] += 1;
+        }
+        if (r.a) (void)hipEventDestroy(r.a);
+        if (r.b) (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return 0;
+}
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline long lmin(long a, long b) { return a < b ? a : b; }
@@ -473,11 +514,14 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
                          const SearchPlan &p, hipStream_t s)
 {
     dim3 grid((unsigned)p.row_tiles, (unsigned)p.splits), block(256);
+    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+    const double pflops = 2.0 * (double)n * (double)k_codes * (double)d;
     if (p.splits == 1) {
         (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, true, KTAIL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
         hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
                            (int)k_codes, d, p.codes_per_split, topk, (float *)nullptr, (int *)nullptr, idx, dist,
                            (const int *)nullptr, (const int *)nullptr);
+        if (pa) g_prof.push_back({pa, prof_mark(s), pflops, 1});
         return check_launch("search_f32");
     }
     const size_t vbytes = align_up((size_t)p.splits * n * T * sizeof(float), 256);
@@ -489,6 +533,7 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
     hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
                        (int)k_codes, d, p.codes_per_split, topk, pval, pidx, (int64_t *)nullptr, (float *)nullptr,
                        (const int *)nullptr, (const int *)nullptr);
+    if (pa) g_prof.push_back({pa, prof_mark(s), pflops, 1});
     if (check_launch("search_f32(split)")) return 1;
     hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pval, pidx, (long)n,
                        p.splits, topk, idx, dist);
@@ -518,9 +563,11 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     hipLaunchKernelGGL(pad_wsq_kernel, dim3((unsigned)((f.k_pad + 255) / 256)), dim3(256), 0, s, wsq, (int)k_codes, (int)f.k_pad, w.wsqp);
     if (hipMemsetAsync(w.fb_count, 0, 4, s) != hipSuccess) return fail("search(filter): memset failed");
     (void)hipFuncSetAttribute((const void *)filter_f16_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM_BYTES);
+    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
     hipLaunchKernelGGL((filter_f16_kernel<T, false>), dim3((unsigned)f.row_tiles, (unsigned)f.splits), dim3(F_THREADS), F_SMEM_BYTES, s,
                        w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
                        w.cand, w.cand_cnt, (float *)nullptr);
+    if (pa) g_prof.push_back({pa, prof_mark(s), 2.0 * (double)n * (double)k_codes * (double)d, 0});
     if (check_launch("filter_f16")) return 1;
     const size_t rs_lds = (size_t)R_ROWS * d * 4 + (size_t)R_ROWS * R_SURV * 8 + (2 * R_ROWS + 1) * 4;
     (void)hipFuncSetAttribute((const void *)rescore_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);

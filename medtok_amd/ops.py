@@ -12,9 +12,23 @@ from . import _lib
 from ._lib import PATH_AUTO, PATH_F16_FILTER, PATH_F32_MFMA, MAX_TOPK  # noqa: F401
 
 
-# Profiling hook (bench.py): when set to a list, every search launch is bracketed by HIP events on
-# its launch stream and (start, stop, algorithmic_flops) is appended.  None = no overhead.
+# Profiling hook (bench.py): when set to a list, every search CALL (all of its kernels) is bracketed
+# by HIP events on its launch stream and (start, stop, algorithmic_flops) is appended.  None = no overhead.
 SEARCH_TIMER = None
+
+
+def profile_begin() -> None:
+    """Start the library's own per-kernel timing (HIP events around each search-kernel launch)."""
+    _lib.check(_lib.load().medtok_profile_begin(), "medtok_profile_begin")
+
+
+def profile_end() -> dict:
+    """Stop it; returns {kernel: dict(ms, flops, launches)} (synchronises on the recorded events)."""
+    import ctypes as C
+    ms, fl, ln = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int * 2)()
+    _lib.check(_lib.load().medtok_profile_end(ms, fl, ln), "medtok_profile_end")
+    names = ("filter_f16_kernel", "search_f32_kernel")
+    return {names[i]: dict(ms=ms[i], flops=fl[i], launches=ln[i]) for i in range(2)}
 
 
 def _stream(t: torch.Tensor) -> int:
