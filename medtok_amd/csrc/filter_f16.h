@@ -53,7 +53,7 @@ __device__ __forceinline__ float filter_eps(float xn, float en_max, int d)
 {
     const float mag = sqrtf(xn * en_max);
     const float flush = 0x1p-21f * sqrtf((float)d) * sqrtf(fmaxf(xn, en_max));
-    const float ulps = 0x1p-21f * (xn + en_max + 2.0f * mag);
+    const float ulps = 0x1p-20f * (xn + en_max + 2.0f * mag);      // a handful of fp32 roundings of d-sized values
     return 2.0f * filter_gamma(d) * mag * 1.0001f + 2.0f * flush + ulps;
 }
 
@@ -151,27 +151,44 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     const int nstage = nct * nkb;
 
     // ---- staging: wave w DMA-copies tile rows [32w, 32w+32) of A and of B, 16 rows (of 64 B) per instruction.
-    // A tile row holds 4 chunks of 16 B, stored at chunk position c ^ ((row >> 2) & 3).
+    // A tile row holds 4 chunks of 16 B, stored at chunk position c ^ ((row >> 2) & 3).  The per-lane part of
+    // the source address is a loop-invariant 32-bit offset; everything that moves (code tile, k block, the
+    // block's row base) is wave-uniform and stays in SGPRs, so a stage costs no per-lane address arithmetic.
     const int s_r = lane >> 2, s_c = lane & 3;
-    int pct = 0, pkb = 0;
-    auto stage = [&](int slot) {
-        char *base = fsm + slot * F_STAGEB;
+    unsigned lane_off[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = wave * 32 + q * 16 + s_r;                          // tile row this lane feeds
+        const int c = s_c ^ ((r >> 2) & 3);                              // source chunk for LDS chunk s_c
+        lane_off[q] = (unsigned)(r * dp + c * 8) * 2u;
+    }
+    const char *wbase = reinterpret_cast<const char *>(wh) + (long)code_lo * dp * 2;
+    const char *xbase = reinterpret_cast<const char *>(xh) + row0 * dp * 2;
+    const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 32 * F_ROWB);
+    int pct = 0, pkb = 0, pidx = 0;         // next stage to issue: (code tile, k block, linear index)
+    // Issues stage `pidx` into ring slot pidx % 4 and advances -- except past the end, where it re-issues the
+    // LAST stage into the slot that already holds it (same bytes, harmless) so the steady-state loop body has
+    // no branch around its DMA and one instruction schedule fits every iteration.
+    auto stage = [&]() {
+        char *base = fsm + (pidx & (F_RING - 1)) * F_STAGEB + wave_lds;
+        const long ua = ((long)pct * F_BM * dp + (long)pkb * F_BK) * 2;  // uniform
+        const long ub = (long)pkb * F_BK * 2;                             // uniform
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int r = wave * 32 + q * 16 + s_r;                      // tile row this lane feeds
-            const int c = s_c ^ ((r >> 2) & 3);                          // source chunk for LDS chunk s_c
-            const long koff = (long)pkb * F_BK + c * 8;
-            const _Float16 *ga = wh + (long)(code_lo + pct * F_BM + r) * dp + koff;
-            const _Float16 *gb = xh + (row0 + r) * dp + koff;
-            glds16(ga, base + (wave * 32 + q * 16) * F_ROWB);
-            glds16(gb, base + F_TILEB + (wave * 32 + q * 16) * F_ROWB);
+            glds16(wbase + ua + lane_off[q], base + q * 16 * F_ROWB);
+            glds16(xbase + ub + lane_off[q], base + F_TILEB + q * 16 * F_ROWB);
         }
-        if (++pkb == nkb) { pkb = 0; ++pct; }
+        const bool more = pidx + 1 < nstage;
+        const bool wrap = pkb + 1 == nkb;
+        pidx += more ? 1 : 0;
+        pct += (more && wrap) ? 1 : 0;
+        pkb = more ? (wrap ? 0 : pkb + 1) : pkb;
     };
 
     // ---- per-lane state: for each of the wave's two 32-row column tiles, the k smallest d~ so far
     float tv[2][TOPK], lim[2], xn[2], win[2];
-    float pend[2][4];                       // values appended during the current code tile, folded into tv at its end
+    float pu[2][2];                         // candidates found during the current code tile wait here (value, code) and are
+    int pc[2][2], np[2] = {0, 0};           // written out once per tile: scattered stores inside the value loop stall the wave
     int cnt[2] = {0, 0};
     long xrow[2];
     uint2 *cptr[2];                         // next free candidate slot of this (row, owner)
@@ -182,17 +199,23 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     for (int nn = 0; nn < 2; ++nn) {
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) tv[nn][j] = INFINITY;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pend[nn][q] = INFINITY;
-        lim[nn] = INFINITY;
+        pu[nn][0] = pu[nn][1] = INFINITY;
+        pc[nn][0] = pc[nn][1] = 0;
+        lim[nn] = -INFINITY;                 // nothing is appended before the warm-up pass has set a finite limit
         xrow[nn] = row0 + wn * 64 + nn * 32 + li;
         xn[nn] = xsq[min(xrow[nn], n - 1)];
         win[nn] = 2.0f * filter_eps(xn[nn], en_max, d);
     }
+    const bool live[2] = {xrow[0] < n, xrow[1] < n};     // padding rows never append (their limit stays -inf)
     const int owner = split * F_OWN_PER_SPLIT + wm * 2 + lh;
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) cptr[nn] = cand + ((long)min(xrow[nn], n - 1) * own_total + owner) * F_CAP;
-    if (tid < F_BN) thr_share[tid] = INFINITY;
+    auto put = [&](int nn, float u, int code) {       // append (d~, code) to this lane's candidate list
+        if (cnt[nn] < F_CAP) *cptr[nn] = make_uint2(__float_as_uint(u + xn[nn]), (unsigned)code);
+        ++cptr[nn];
+        ++cnt[nn];
+    };
+    if (tid < F_BN) reinterpret_cast<unsigned *>(thr_share)[tid] = 0xFFFFFFFFu;     // order-preserving key of +inf is 0xFF800000; all-ones is above it
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -202,17 +225,14 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
 
-    // fragment addresses: row i of the tile, chunk (2t + lh) ^ ((i >> 2) & 3)
-    int a_off[4], a_sw[4], b_off[2], b_sw[2];
+    // fragment addresses within a stage: row i of the tile, chunk (2t + lh) ^ ((i >> 2) & 3).  Rows 32 apart
+    // share the swizzle term, so one address per (operand, t) plus compile-time row offsets covers all tiles.
+    int a_adr[2], b_adr[2];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int ia = wm * 128 + m * 32 + li;
-        a_off[m] = ia * F_ROWB; a_sw[m] = (ia >> 2) & 3;
-    }
-#pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
-        const int ib = wn * 64 + nn * 32 + li;
-        b_off[nn] = F_TILEB + ib * F_ROWB; b_sw[nn] = (ib >> 2) & 3;
+    for (int t = 0; t < 2; ++t) {
+        const int ia = wm * 128 + li, ib = wn * 64 + li;
+        a_adr[t] = ia * F_ROWB + (((2 * t + lh) ^ ((ia >> 2) & 3)) << 4);
+        b_adr[t] = F_TILEB + ib * F_ROWB + (((2 * t + lh) ^ ((ib >> 2) & 3)) << 4);
     }
 
     // ---- software pipeline.  LDS ring of 4 stages; MFMA operands double-buffered in registers so the
@@ -222,42 +242,69 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     //                 LDS-DMA stage s+3  | read frags(s+1, t0) | MFMA(s, t1)
     // __syncthreads() would drain vmcnt(0) here (an LDS-DMA is a pending LDS write), hence the raw barrier.
     auto load_frags = [&](half8 (&fa)[4], half8 (&fb)[2], int slot, int t) {
-        const char *base = fsm + slot * F_STAGEB;
+#ifdef MEDTOK_FILTER_NOLDS        // dev experiment: operands stay whatever they were
+        if (slot >= 0) return;
+#endif
+        const char *pa = fsm + slot * F_STAGEB + a_adr[t];
+        const char *pb = fsm + slot * F_STAGEB + b_adr[t];
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn) fb[nn] = *reinterpret_cast<const half8 *>(base + b_off[nn] + (((2 * t + lh) ^ b_sw[nn]) << 4));
+        for (int nn = 0; nn < 2; ++nn) fb[nn] = *reinterpret_cast<const half8 *>(pb + nn * 32 * F_ROWB);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const half8 *>(base + a_off[m] + (((2 * t + lh) ^ a_sw[m]) << 4));
+        for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const half8 *>(pa + m * 32 * F_ROWB);
     };
     auto mfma_group = [&](const half8 (&fa)[4], const half8 (&fb)[2]) {
+#ifdef MEDTOK_FILTER_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef MEDTOK_FILTER_NOMFMA      // dev experiment: keep the operand reads alive, skip the matrix work
+#pragma unroll
+        for (int m = 0; m < 4; ++m) asm volatile("" ::"v"(fa[m]));
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) asm volatile("" ::"v"(fb[nn]));
+        return;
+#endif
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int nn = 0; nn < 2; ++nn)
                 acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb[nn], acc[m][nn], 0, 0, 0);
+#ifdef MEDTOK_FILTER_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
     half8 fa0[4], fb0[2], fa1[4], fb1[2];
-#pragma unroll
-    for (int p = 0; p < F_RING - 1; ++p)
-        if (p < nstage) stage(p);
-    if (nstage >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nstage == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int LGKM0 = 0xC07F;           // s_waitcnt lgkmcnt(0) only (vmcnt / expcnt fields at their maxima)
+    stage(); stage(); stage();              // stages 0..2 (clamped when the block has fewer)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     load_frags(fa0, fb0, 0, 0);
     int ct = 0, kb = 0;
     for (int s = 0; s < nstage; ++s) {
-        const int slot = s % F_RING;
-        load_frags(fa1, fb1, slot, 1);
+        load_frags(fa1, fb1, s & (F_RING - 1), 1);
         mfma_group(fa0, fb0);
-        // stage s+1 must be visible before its fragments are read; stage s+2 may stay in flight
-        if (s + 2 < nstage) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // interleave: the 6 operand reads of the next k16-step ride between the first MFMAs
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        // fa1/fb1 have landed (free: 8 MFMAs went by); own part of stage s+1 has landed; then everyone's has
+        __builtin_amdgcn_s_waitcnt(LGKM0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#ifndef MEDTOK_FILTER_NOBAR       // dev experiment
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
-        if (s + 3 < nstage) stage((s + 3) % F_RING);
-        load_frags(fa0, fb0, (s + 1) % F_RING, 0);      // (past the last stage this reads stale LDS, never used)
+#ifndef MEDTOK_FILTER_NODMA       // dev experiment: without it the ring keeps its prologue contents
+        stage();                            // stage s+3 (slot s-1: everyone is past reading it)
+#endif
+        load_frags(fa0, fb0, (s + 1) & (F_RING - 1), 0);      // (past the last stage this reads stale LDS, never used)
         mfma_group(fa1, fb1);
+        // after the barrier the matrix pipe restarts at once; DMA issue and operand reads ride between MFMAs
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #ifdef MEDTOK_FILTER_NOEPI      // dev experiment: main loop only (results are garbage)
         if (++kb == nkb) {
 #pragma unroll
@@ -273,24 +320,31 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         continue;
 #endif
         if (++kb == nkb) {
-            // ---- epilogue.  d~ = (xn + en) - 2 * 2^-16 * acc, one fmaf; a 16-wide min rejects whole tiles.
+            // ---- epilogue.  Everything is kept relative to the lane's own |x|^2:  u = en - 2 s~ (one fmaf per
+            // value, shared by nothing else), thresholds and limits in the same u scale; d~ = u + xn is formed only
+            // for the few values that are stored.
             const int cbase = code_lo + ct * F_BM + wm * 128 + 4 * lh;
             const bool warm = (ct == 0);
             if (!DUMP && warm) {
                 // First code tile: learn the thresholds from all 128 codes BEFORE appending anything, so the
                 // candidate lists do not fill up with the loose early threshold (appends only ever need T >= t~).
+                float4 wen[4][4];           // all 16 vector loads first: one wait instead of one per value
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) wen[m][g] = ld4(wsqp + cbase + 32 * m + 8 * g);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
 #pragma unroll
-                    for (int nn = 0; nn < 2; ++nn)
+                    for (int r = 0; r < 16; ++r) {
+                        const float4 e4 = wen[m][r >> 2];
+                        const float en = (r & 3) == 0 ? e4.x : (r & 3) == 1 ? e4.y : (r & 3) == 2 ? e4.z : e4.w;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float en = wsqp[cbase + 32 * m + (r & 3) + 8 * (r >> 2)];
-                            thr_insert<TOPK>(tv[nn], fmaf(acc[m][nn][r], -0x1p-15f, xn[nn] + en));
-                        }
+                        for (int nn = 0; nn < 2; ++nn) thr_insert<TOPK>(tv[nn], fmaf(acc[m][nn][r], -0x1p-15f, en));
+                    }
                 }
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn) lim[nn] = tv[nn][TOPK - 1] + win[nn];
+                for (int nn = 0; nn < 2; ++nn) lim[nn] = live[nn] ? fminf(tv[nn][TOPK - 1] + win[nn], 3.0e38f) : -INFINITY;
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -302,46 +356,57 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float en = (r & 3) == 0 ? en4[r >> 2].x : (r & 3) == 1 ? en4[r >> 2].y : (r & 3) == 2 ? en4[r >> 2].z : en4[r >> 2].w;
-                        const float v = fmaf(acc[m][nn][r], -0x1p-15f, xn[nn] + en);
-                        const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2);
+                        const float u = fmaf(acc[m][nn][r], -0x1p-15f, en);      // padded codes carry en = +inf
                         if (DUMP) {
+                            const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2);
                             if (code < code_hi && xrow[nn] < n) dump[xrow[nn] * k_codes + code] = acc[m][nn][r] * F_UNSCALE;
-                        } else if (v <= lim[nn] && v < INFINITY) {
-                            // rare per lane (about 6/m after m codes) but not per wave: keep this body minimal.
-                            // Threshold upkeep is deferred: any T >= t~ is valid, a stale one only appends a bit more.
-                            if (cnt[nn] < F_CAP && xrow[nn] < n) *cptr[nn] = make_uint2(__float_as_uint(v), (unsigned)code);
-                            ++cptr[nn];
-                            ++cnt[nn];
-                            if (!warm) { pend[nn][3] = pend[nn][2]; pend[nn][2] = pend[nn][1]; pend[nn][1] = pend[nn][0]; pend[nn][0] = v; }
+                        } else if (u <= lim[nn]) {                                 // lim is finite, so +inf never passes
+                            // rare per lane (about 6/m after m codes) but not per wave: keep this body minimal -- park the
+                            // candidate in registers; only a third hit within one code tile pays for a store right here.
+                            if (np[nn] == 2) put(nn, pu[nn][1], pc[nn][1]);
+                            pu[nn][1] = pu[nn][0]; pc[nn][1] = pc[nn][0];
+                            pu[nn][0] = u; pc[nn][0] = cbase + 32 * m + (r & 3) + 8 * (r >> 2);
+                            np[nn] = min(np[nn] + 1, 2);
                         }
                         acc[m][nn][r] = 0.f;
                     }
                 }
             }
             if (!DUMP) {
-                // fold what this tile appended into the k-smallest list (a 5th arrival in one tile pushed the oldest
-                // out: dropping a value keeps T valid, merely looser), then share: the row's k-th best over all codes
+                // per tile: flush, update the threshold (a value stored early by the third-hit path never enters the
+                // k-smallest list: that keeps T valid, merely looser), then share: the row's k-th best over all codes
                 // seen by ANY owner is <= every owner's own k-th best, so the minimum of the owners' values is valid.
 #pragma unroll
                 for (int nn = 0; nn < 2; ++nn) {
+                    // write out the parked candidates (at most two store instructions per tile) and fold them into the
+                    // k-smallest list; the warm-up pass already counted the first tile's values
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { thr_insert<TOPK>(tv[nn], pend[nn][q]); pend[nn][q] = INFINITY; }
+                    for (int q = 0; q < 2; ++q) {
+                        if (q < np[nn]) {
+                            put(nn, pu[nn][q], pc[nn][q]);
+                            if (!warm) thr_insert<TOPK>(tv[nn], pu[nn][q]);
+                        }
+                    }
+                    np[nn] = 0;
                     float t = tv[nn][TOPK - 1];
                     t = fminf(t, __shfl_xor(t, 32, 64));
-                    float *sh = thr_share + wn * 64 + nn * 32 + li;
-                    if (lh == 0 && t < INFINITY) {
-                        // non-negative floats order like their bit patterns; clamping at 0 only loosens T
-                        const unsigned old = atomicMin(reinterpret_cast<unsigned *>(sh), __float_as_uint(fmaxf(t, 0.f)));
-                        t = fminf(fmaxf(t, 0.f), __uint_as_float(old));
+                    unsigned *sh = reinterpret_cast<unsigned *>(thr_share) + wn * 64 + nn * 32 + li;
+                    if (lh == 0) {
+                        // order-preserving float -> uint key so a plain integer atomicMin works for any sign
+                        const unsigned b = __float_as_uint(t);
+                        const unsigned key = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+                        const unsigned old = min(atomicMin(sh, key), key);
+                        t = __uint_as_float(old ^ ((old >> 31) ? 0x80000000u : 0xFFFFFFFFu));
                     }
                     t = fminf(t, __shfl_xor(t, 32, 64));
-                    lim[nn] = t + win[nn];
+                    lim[nn] = live[nn] ? fminf(t + win[nn], 3.0e38f) : -INFINITY;
                 }
             }
             kb = 0;
             ++ct;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail re-issues may still be in flight
     if (!DUMP) {
 #pragma unroll
         for (int nn = 0; nn < 2; ++nn) {
