@@ -94,10 +94,12 @@ int medtok_debug_filter_scores_f32(const float *xhat, const float *xsq, int64_t 
  * 204-205,208-209,214.  MEDTOK_ASSIGN_HARD is the NormEMA form (topk == 1,
  * zq = what[idx]; norm_ema_quantizer.py:181,212,214); MEDTOK_ASSIGN_RAW stores zq
  * (the tensor autograd differentiates) instead of the straight-through value.
- * w and row_sqerr may be NULL.  zq_out may alias xref. */
+ * w and row_sqerr may be NULL.  zq_out may alias xref; zq_stride is its row stride in floats
+ * (0 = d), so four searches can write straight into the columns of one [n, 4d] embedding
+ * (the torch.cat of tokenizer.py:246). */
 int medtok_soft_assign_f32(const float *xref, const float *what, const int64_t *idx,
                            const float *dist, int64_t n, int d, int topk, int flags,
-                           float *w, float *zq_out, float *row_sqerr, void *stream);
+                           float *w, float *zq_out, int64_t zq_stride, float *row_sqerr, void *stream);
 
 /* out[0] = scale * sum(vals[0..n)), accumulated in fp64 in a fixed order
  * (the mean of the squared error: :169-173,208-209; F.mse_loss at
@@ -146,7 +148,7 @@ int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d,
                                const float *what, const float *wsq, int64_t k_codes,
                                int topk, int path,
                                float *xhat, int64_t *idx, float *dist, float *w,
-                               float *zq_ste, float *row_sqerr,
+                               float *zq_ste, int64_t zq_stride, float *row_sqerr,
                                void *ws, size_t ws_bytes, void *stream);
 
 #ifdef __cplusplus

@@ -28,7 +28,7 @@ SIGNATURES = {
     "medtok_topk_search_f32": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _int, _vp]),
     "medtok_debug_filter_scores_workspace_bytes": (_sz, [_i64, _i64, _int]),
     "medtok_debug_filter_scores_f32": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
-    "medtok_soft_assign_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "medtok_soft_assign_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _i64, _vp, _vp]),
     "medtok_sum_scale_f32": (_int, [_vp, _i64, _dbl, _vp, _vp]),
     "medtok_ema_stats_workspace_bytes": (_sz, [_i64, _i64]),
     "medtok_ema_stats_f32": (_int, [_vp, _vp, _i64, _int, _i64, _vp, _vp, _vp, _sz, _vp]),
@@ -40,7 +40,7 @@ SIGNATURES = {
     "medtok_usage_update": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "medtok_soft_vq_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int]),
     "medtok_soft_vq_forward_f32": (_int, [_vp, _i64, _int, _vp, _vp, _i64, _int, _int,
-                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                          _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
 }
 
 

@@ -36,14 +36,14 @@ constexpr int F_TILEB = F_BM * F_ROWB;                        // 16 KB per opera
 constexpr int F_STAGEB = 2 * F_TILEB;                         // A + B = 32 KB
 constexpr int F_RING = 4;                                     // stages in the LDS ring: 3 in flight while 1 is computed on
 constexpr size_t F_LDS_BYTES = (size_t)F_RING * F_STAGEB;     // 128 KB -> 1 block (8 waves) / CU
-constexpr size_t F_SMEM_BYTES = F_LDS_BYTES + 256 * sizeof(float);   // + per-row shared thresholds
+constexpr size_t F_SMEM_BYTES = F_LDS_BYTES + 256 * sizeof(float) + 512 * 32;   // + per-row shared thresholds + candidate parking (2 x 2 x 8 B per lane)
 constexpr int F_GLDS_PER_STAGE = 4;                           // LDS-DMA instructions each wave issues per stage
-constexpr int F_CAP = 64;                                     // candidate slots per (row, owner)
+constexpr int F_CAP = 96;                                     // candidate slots per (row, owner): ~25-30 used on random data
 constexpr int F_OWN_PER_SPLIT = 4;                            // 2 half-waves x 2 code-side waves
 constexpr float F_PRESCALE = 256.0f;                          // 2^8 on both operands
 constexpr float F_UNSCALE = 1.0f / 65536.0f;
 constexpr float F_NORM_LIMIT = 4.0f;                          // |x|^2, |e|^2 above this -> exact path
-constexpr int R_ROWS = 16;                                    // rows per re-score block (16 lanes each)
+constexpr int R_ROWS = 32;                                    // rows per re-score block (8 lanes each)
 constexpr int R_SURV = 64;                                    // survivors per row the re-score kernel can hold
 
 __host__ __device__ inline float filter_gamma(int d) { return 0x1p-10f + 0x1p-20f + (float)d * 0x1p-21f; }
@@ -187,32 +187,27 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 
     // ---- per-lane state: for each of the wave's two 32-row column tiles, the k smallest d~ so far
     float tv[2][TOPK], lim[2], xn[2], win[2];
-    float pu[2][2];                         // candidates found during the current code tile wait here (value, code) and are
-    int pc[2][2], np[2] = {0, 0};           // written out once per tile: scattered stores inside the value loop stall the wave
-    int cnt[2] = {0, 0};
-    long xrow[2];
-    uint2 *cptr[2];                         // next free candidate slot of this (row, owner)
+    // Candidates found during a code tile are parked in a lane-private LDS slot pair (value, code) and written out
+    // once per tile: scattered global stores inside the value loop stall the wave, and registers are scarce here.
+    int np[2] = {0, 0}, cnt[2] = {0, 0};
     float *thr_share = reinterpret_cast<float *>(fsm + F_LDS_BYTES);    // [F_BN] per-row min of the owners' thresholds
+    uint2 *park = reinterpret_cast<uint2 *>(fsm + F_LDS_BYTES + 256 * sizeof(float)) + tid * 4;   // [nn][slot]
+    auto xrow_of = [&](int nn) -> long { return row0 + wn * 64 + nn * 32 + li; };
     const float en_max = en_max_ptr[0];
     const bool sane = en_max <= F_NORM_LIMIT;
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) tv[nn][j] = INFINITY;
-        pu[nn][0] = pu[nn][1] = INFINITY;
-        pc[nn][0] = pc[nn][1] = 0;
         lim[nn] = -INFINITY;                 // nothing is appended before the warm-up pass has set a finite limit
-        xrow[nn] = row0 + wn * 64 + nn * 32 + li;
-        xn[nn] = xsq[min(xrow[nn], n - 1)];
+        xn[nn] = xsq[min(xrow_of(nn), n - 1)];
         win[nn] = 2.0f * filter_eps(xn[nn], en_max, d);
     }
-    const bool live[2] = {xrow[0] < n, xrow[1] < n};     // padding rows never append (their limit stays -inf)
+    const bool live[2] = {xrow_of(0) < n, xrow_of(1) < n};     // padding rows never append (their limit stays -inf)
     const int owner = split * F_OWN_PER_SPLIT + wm * 2 + lh;
-#pragma unroll
-    for (int nn = 0; nn < 2; ++nn) cptr[nn] = cand + ((long)min(xrow[nn], n - 1) * own_total + owner) * F_CAP;
-    auto put = [&](int nn, float u, int code) {       // append (d~, code) to this lane's candidate list
-        if (cnt[nn] < F_CAP) *cptr[nn] = make_uint2(__float_as_uint(u + xn[nn]), (unsigned)code);
-        ++cptr[nn];
+    auto put = [&](int nn, float u, int code) {       // append (d~, code) to this lane's candidate list (live rows only)
+        if (cnt[nn] < F_CAP)
+            cand[(xrow_of(nn) * own_total + owner) * F_CAP + cnt[nn]] = make_uint2(__float_as_uint(u + xn[nn]), (unsigned)code);
         ++cnt[nn];
     };
     if (tid < F_BN) reinterpret_cast<unsigned *>(thr_share)[tid] = 0xFFFFFFFFu;     // order-preserving key of +inf is 0xFF800000; all-ones is above it
@@ -328,16 +323,14 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
             if (!DUMP && warm) {
                 // First code tile: learn the thresholds from all 128 codes BEFORE appending anything, so the
                 // candidate lists do not fill up with the loose early threshold (appends only ever need T >= t~).
-                float4 wen[4][4];           // all 16 vector loads first: one wait instead of one per value
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) wen[m][g] = ld4(wsqp + cbase + 32 * m + 8 * g);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
+                    float4 wen[4];          // vector loads, one wait per 16 values (a load per value drains the DMA ring each time)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) wen[g] = ld4(wsqp + cbase + 32 * m + 8 * g);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float4 e4 = wen[m][r >> 2];
+                        const float4 e4 = wen[r >> 2];
                         const float en = (r & 3) == 0 ? e4.x : (r & 3) == 1 ? e4.y : (r & 3) == 2 ? e4.z : e4.w;
 #pragma unroll
                         for (int nn = 0; nn < 2; ++nn) thr_insert<TOPK>(tv[nn], fmaf(acc[m][nn][r], -0x1p-15f, en));
@@ -359,23 +352,22 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
                         const float u = fmaf(acc[m][nn][r], -0x1p-15f, en);      // padded codes carry en = +inf
                         if (DUMP) {
                             const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2);
-                            if (code < code_hi && xrow[nn] < n) dump[xrow[nn] * k_codes + code] = acc[m][nn][r] * F_UNSCALE;
+                            if (code < code_hi && xrow_of(nn) < n) dump[xrow_of(nn) * k_codes + code] = acc[m][nn][r] * F_UNSCALE;
                         } else if (u <= lim[nn]) {                                 // lim is finite, so +inf never passes
                             // rare per lane (about 6/m after m codes) but not per wave: keep this body minimal -- park the
-                            // candidate in registers; only a third hit within one code tile pays for a store right here.
-                            if (np[nn] == 2) put(nn, pu[nn][1], pc[nn][1]);
-                            pu[nn][1] = pu[nn][0]; pc[nn][1] = pc[nn][0];
-                            pu[nn][0] = u; pc[nn][0] = cbase + 32 * m + (r & 3) + 8 * (r >> 2);
-                            np[nn] = min(np[nn] + 1, 2);
+                            // candidate in LDS; only a third hit within one code tile pays for a global store right here
+                            // (that one skips the k-smallest list: T stays valid, a touch looser).
+                            const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2);
+                            if (np[nn] < 2) { park[nn * 2 + np[nn]] = make_uint2(__float_as_uint(u), (unsigned)code); ++np[nn]; }
+                            else put(nn, u, code);
                         }
                         acc[m][nn][r] = 0.f;
                     }
                 }
             }
             if (!DUMP) {
-                // per tile: flush, update the threshold (a value stored early by the third-hit path never enters the
-                // k-smallest list: that keeps T valid, merely looser), then share: the row's k-th best over all codes
-                // seen by ANY owner is <= every owner's own k-th best, so the minimum of the owners' values is valid.
+                // per tile: flush, update the threshold, then share: the row's k-th best over all codes seen by ANY
+                // owner is <= every owner's own k-th best, so the minimum of the owners' values is a valid T.
 #pragma unroll
                 for (int nn = 0; nn < 2; ++nn) {
                     // write out the parked candidates (at most two store instructions per tile) and fold them into the
@@ -383,8 +375,9 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         if (q < np[nn]) {
-                            put(nn, pu[nn][q], pc[nn][q]);
-                            if (!warm) thr_insert<TOPK>(tv[nn], pu[nn][q]);
+                            const uint2 e = park[nn * 2 + q];
+                            put(nn, __uint_as_float(e.x), (int)e.y);
+                            if (!warm) thr_insert<TOPK>(tv[nn], __uint_as_float(e.x));
                         }
                     }
                     np[nn] = 0;
@@ -412,17 +405,18 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         for (int nn = 0; nn < 2; ++nn) {
             // rows outside the range the bound assumes are forced onto the exact path
             const bool ok = sane && xn[nn] <= F_NORM_LIMIT;
-            if (xrow[nn] < n) cand_cnt[xrow[nn] * own_total + owner] = ok ? cnt[nn] : F_CAP + 1;
+            if (live[nn]) cand_cnt[xrow_of(nn) * own_total + owner] = ok ? cnt[nn] : F_CAP + 1;
         }
     }
 }
 
 // ---------------------------------------------------------------- exact re-score
-// Block = 16 rows x 16 lanes.  Phase 1 (per row, 16 lanes): the row's true t~ = k-th smallest d~ over
-// all owners' candidates.  Phase 2a: candidates with d~ <= t~ + 2 eps are compacted into an LDS list.
-// Phase 2b: the block's survivors (about 7 per row) are spread densely over all 256 threads and each is
-// re-scored with the canonical fp32 chain -- x rows come from LDS (staged once per block), code rows
-// from L2.  Phase 3 (per row): exact (d, index) top-k of the row's survivors.
+// Block = 32 rows x 8 lanes.  Phase 1 (per row, 8 lanes): the row's true t~ = k-th smallest d~ over all
+// owners' candidates.  Phase 2a: candidates with d~ <= t~ + 2 eps are compacted into an LDS list.
+// Phase 2b: the block's survivors (about 7 per row, so ~220 for 256 threads) are spread densely over the
+// threads and each is re-scored with the canonical fp32 chain; x and code rows stream from L1/L2 (the
+// survivors of a row run side by side, so its x row is fetched once).  Phase 3 (per row): exact
+// (d, index) top-k of the row's survivors.
 template <int TOPK>
 __global__ __launch_bounds__(256) void rescore_kernel(
     const uint2 *__restrict__ cand, const int *__restrict__ cand_cnt, int own_total,
@@ -430,24 +424,13 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     const float *__restrict__ wsq, const float *__restrict__ en_max_ptr, long n, int k_codes, int d, int topk_out,
     int64_t *__restrict__ out_idx, float *__restrict__ out_dist, int *__restrict__ fb_count, int *__restrict__ fb_rows)
 {
-    extern __shared__ __attribute__((aligned(16))) char rsm[];
-    float *xs = reinterpret_cast<float *>(rsm);                                   // [R_ROWS][d]
-    int *s_code = reinterpret_cast<int *>(rsm + (size_t)R_ROWS * d * 4);          // [R_ROWS][R_SURV]
-    float *s_d = reinterpret_cast<float *>(s_code + R_ROWS * R_SURV);             // [R_ROWS][R_SURV]
-    int *s_cnt = reinterpret_cast<int *>(s_d + R_ROWS * R_SURV);                  // [R_ROWS] survivors, [R_ROWS] offsets
-    const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    __shared__ int s_code[R_ROWS * R_SURV];
+    __shared__ float s_d[R_ROWS * R_SURV];
+    __shared__ int s_cnt[2 * R_ROWS + 1];                 // [R_ROWS] survivors, [R_ROWS] offsets, total
+    const int g = threadIdx.x >> 3, l8 = threadIdx.x & 7;
     const long pos = (long)blockIdx.x * R_ROWS + g;
     const long row = min(pos, n - 1);
     if (threadIdx.x < R_ROWS) s_cnt[threadIdx.x] = 0;
-    // stage the block's x rows (coalesced)
-    {
-        const long r0 = (long)blockIdx.x * R_ROWS;
-        const int per_row = d / 4;
-        for (int t = threadIdx.x; t < R_ROWS * per_row; t += 256) {
-            const int rr = t / per_row, c = t - rr * per_row;
-            st4(xs + rr * d + c * 4, ld4(xhat + min(r0 + rr, n - 1) * d + c * 4));
-        }
-    }
     const float xn = xsq[row];
     const float win = 2.0f * filter_eps(xn, en_max_ptr[0], d);
     const uint2 *rc = cand + row * own_total * F_CAP;
@@ -456,20 +439,20 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     bool overflow = false;
     for (int o = 0; o < own_total; ++o) overflow |= cc[o] > F_CAP;
     __syncthreads();
-    // ---- phase 1 + 2a (skipped for rows the filter gave up on; the 16-lane group branches together)
+    // ---- phase 1 + 2a (skipped for rows the filter gave up on; the 8-lane group branches together)
     if (!overflow) {
         float tv[TOPK];
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) tv[j] = INFINITY;
         for (int o = 0; o < own_total; ++o) {
             const int m = cc[o];
-            for (int sidx = l16; sidx < m; sidx += 16) thr_insert<TOPK>(tv, __uint_as_float(rc[o * F_CAP + sidx].x));
+            for (int sidx = l8; sidx < m; sidx += 8) thr_insert<TOPK>(tv, __uint_as_float(rc[o * F_CAP + sidx].x));
         }
 #pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) {
+        for (int off = 4; off >= 1; off >>= 1) {
             float pv[TOPK];
 #pragma unroll
-            for (int j = 0; j < TOPK; ++j) pv[j] = __shfl_xor(tv[j], off, 16);
+            for (int j = 0; j < TOPK; ++j) pv[j] = __shfl_xor(tv[j], off, 8);
 #pragma unroll
             for (int j = 0; j < TOPK; ++j) thr_insert<TOPK>(tv, pv[j]);
         }
@@ -479,7 +462,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(
         const float lim = kth + win;
         for (int o = 0; o < own_total; ++o) {
             const int m = cc[o];
-            for (int sidx = l16; sidx < m; sidx += 16) {
+            for (int sidx = l8; sidx < m; sidx += 8) {
                 const uint2 e = rc[o * F_CAP + sidx];
                 if (__uint_as_float(e.x) <= lim && e.y < (unsigned)k_codes) {
                     const int p = atomicAdd(&s_cnt[g], 1);
@@ -506,11 +489,24 @@ __global__ __launch_bounds__(256) void rescore_kernel(
         for (int r = 1; r < R_ROWS; ++r) rr += (wi >= s_cnt[R_ROWS + r]) ? 1 : 0;
         const int j = wi - s_cnt[R_ROWS + rr];
         const int code = s_code[rr * R_SURV + j];
-        const float *xr = xs + rr * d;
+        const long arow = min((long)blockIdx.x * R_ROWS + rr, n - 1);
+        const float *xr = xhat + arow * d;
         const float *wr = what + (long)code * d;
         float accv = 0.f;
         int i = 0;
-        for (; i + 8 <= d; i += 8) {                 // canonical order within a group: 0,4,1,5,2,6,3,7
+        for (; i + 16 <= d; i += 16) {               // canonical order within a group of 8: 0,4,1,5,2,6,3,7
+            const float4 x0 = ld4(xr + i), x1 = ld4(xr + i + 4), x2 = ld4(xr + i + 8), x3 = ld4(xr + i + 12);
+            const float4 w0 = ld4(wr + i), w1 = ld4(wr + i + 4), w2 = ld4(wr + i + 8), w3 = ld4(wr + i + 12);
+            accv = fmaf(x0.x, w0.x, accv); accv = fmaf(x1.x, w1.x, accv);
+            accv = fmaf(x0.y, w0.y, accv); accv = fmaf(x1.y, w1.y, accv);
+            accv = fmaf(x0.z, w0.z, accv); accv = fmaf(x1.z, w1.z, accv);
+            accv = fmaf(x0.w, w0.w, accv); accv = fmaf(x1.w, w1.w, accv);
+            accv = fmaf(x2.x, w2.x, accv); accv = fmaf(x3.x, w3.x, accv);
+            accv = fmaf(x2.y, w2.y, accv); accv = fmaf(x3.y, w3.y, accv);
+            accv = fmaf(x2.z, w2.z, accv); accv = fmaf(x3.z, w3.z, accv);
+            accv = fmaf(x2.w, w2.w, accv); accv = fmaf(x3.w, w3.w, accv);
+        }
+        for (; i + 8 <= d; i += 8) {
             const float4 x0 = ld4(xr + i), x1 = ld4(xr + i + 4);
             const float4 w0 = ld4(wr + i), w1 = ld4(wr + i + 4);
             accv = fmaf(x0.x, w0.x, accv); accv = fmaf(x1.x, w1.x, accv);
@@ -523,7 +519,6 @@ __global__ __launch_bounds__(256) void rescore_kernel(
             accv = fmaf(x0.x, w0.x, accv); accv = fmaf(x0.y, w0.y, accv);
             accv = fmaf(x0.z, w0.z, accv); accv = fmaf(x0.w, w0.w, accv);
         }
-        const long arow = min((long)blockIdx.x * R_ROWS + rr, n - 1);
         const float sum = xsq[arow] + wsq[code];
         const float two = 2.0f * accv;
         s_d[rr * R_SURV + j] = sum - two;
@@ -532,24 +527,24 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     // ---- phase 3: exact top-k of the row's survivors
     const int mine = s_cnt[g];
     if (overflow || mine < 0) {
-        if (l16 == 0 && pos < n) fb_rows[atomicAdd(fb_count, 1)] = (int)row;
+        if (l8 == 0 && pos < n) fb_rows[atomicAdd(fb_count, 1)] = (int)row;
         return;
     }
     float bv[TOPK];
     int bi[TOPK];
 #pragma unroll
     for (int j = 0; j < TOPK; ++j) { bv[j] = INFINITY; bi[j] = 0x7fffffff; }
-    for (int j = l16; j < mine; j += 16) topk_insert_lex<TOPK>(bv, bi, s_d[g * R_SURV + j], s_code[g * R_SURV + j]);
+    for (int j = l8; j < mine; j += 8) topk_insert_lex<TOPK>(bv, bi, s_d[g * R_SURV + j], s_code[g * R_SURV + j]);
 #pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
+    for (int off = 4; off >= 1; off >>= 1) {
         float pv[TOPK];
         int pi[TOPK];
 #pragma unroll
-        for (int j = 0; j < TOPK; ++j) { pv[j] = __shfl_xor(bv[j], off, 16); pi[j] = __shfl_xor(bi[j], off, 16); }
+        for (int j = 0; j < TOPK; ++j) { pv[j] = __shfl_xor(bv[j], off, 8); pi[j] = __shfl_xor(bi[j], off, 8); }
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) topk_insert_lex<TOPK>(bv, bi, pv[j], pi[j]);
     }
-    if (l16 == 0 && pos < n) {
+    if (l8 == 0 && pos < n) {
 #pragma unroll
         for (int j = 0; j < TOPK; ++j)
             if (j < topk_out) { out_idx[row * topk_out + j] = bi[j]; out_dist[row * topk_out + j] = bv[j]; }

@@ -230,14 +230,18 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
     const float *__restrict__ xhat, const float *__restrict__ xsq, const float *__restrict__ what,
     const float *__restrict__ wsq, long n, int k_codes, int d, int codes_per_split, int topk_out,
     float *__restrict__ pval, int *__restrict__ pidx, int64_t *__restrict__ out_idx,
-    float *__restrict__ out_dist, const int *__restrict__ row_list, const int *__restrict__ row_count)
+    float *__restrict__ out_dist, const int *__restrict__ row_list, const int *__restrict__ row_count,
+    int list_begin, int list_end)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const long row0 = (long)blockIdx.x * S_BN;
+    long row0 = (long)blockIdx.x * S_BN;
+    const long part_rows = INDIRECT ? (long)(list_end - list_begin) : n;     // row extent of the partial-result buffers
     if (INDIRECT) {
-        n = *row_count;                     // rows in the list; uniform for the whole grid
+        // this launch covers list positions [list_begin, min(*row_count, list_end)); uniform for the whole grid
+        n = min((long)*row_count, (long)list_end);
+        row0 += list_begin;
         if (row0 >= n) return;
     }
     auto actual_row = [&](long pos) -> long {
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
             for (int j = 0; j < TOPK; ++j)
                 if (j < topk_out) { out_idx[myrow * topk_out + j] = bi[j]; out_dist[myrow * topk_out + j] = bv[j]; }
         } else {
-            const long base = ((long)split * n + myrow) * TOPK;
+            const long base = ((long)split * part_rows + (INDIRECT ? mypos - list_begin : myrow)) * TOPK;
 #pragma unroll
             for (int j = 0; j < TOPK; ++j) { pval[base + j] = bv[j]; pidx[base + j] = bi[j]; }
         }
@@ -388,10 +392,13 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
 template <int TOPK>
 __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict__ pval, const int *__restrict__ pidx,
                                                          long n, int splits, int topk_out,
-                                                         int64_t *__restrict__ out_idx, float *__restrict__ out_dist)
+                                                         int64_t *__restrict__ out_idx, float *__restrict__ out_dist,
+                                                         const int *__restrict__ row_list, const int *__restrict__ row_count)
 {
-    const long row = (long)blockIdx.x * 256 + threadIdx.x;
-    if (row >= n) return;
+    // with a row list: partial lists are indexed by list position (extent n), results go to row_list[position]
+    const long pos = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pos >= n || (row_list && pos >= *row_count)) return;
+    const long row = pos;
     float bv[TOPK];
     int bi[TOPK];
 #pragma unroll
@@ -401,9 +408,10 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) topk_insert_lex<TOPK>(bv, bi, pval[base + j], pidx[base + j]);
     }
+    const long orow = row_list ? (long)row_list[pos] : row;
 #pragma unroll
     for (int j = 0; j < TOPK; ++j)
-        if (j < topk_out) { out_idx[row * topk_out + j] = bi[j]; out_dist[row * topk_out + j] = bv[j]; }
+        if (j < topk_out) { out_idx[orow * topk_out + j] = bi[j]; out_dist[orow * topk_out + j] = bv[j]; }
 }
 
 #include "filter_f16.h"
@@ -464,9 +472,15 @@ struct FilterWs {
     _Float16 *xh, *wh;
     float *en_max, *wsqp, *dump;
     uint2 *cand;
-    int *cand_cnt, *fb_count, *fb_rows;
+    int *cand_cnt, *fb_count, *fb_rows, *fb_pidx;
+    float *fb_pval;
     size_t total;
 };
+
+// Exact redo of the few rows the filter gives up on: the first FB_ROWS list entries are searched with the
+// code range split FB_SPLITS ways (a handful of rows would otherwise crawl through all K codes in one
+// block); anything beyond that many rows is plentiful enough for the plain one-block-per-128-rows form.
+constexpr int FB_ROWS = 8192, FB_SPLITS = 32;
 
 static FilterWs filter_ws_layout(void *ws, int64_t n, const FilterPlan &f)
 {
@@ -479,6 +493,8 @@ static FilterWs filter_ws_layout(void *ws, int64_t n, const FilterPlan &f)
     w.wsqp = (float *)take((size_t)f.k_pad * 4);
     w.fb_count = (int *)take(4);
     w.fb_rows = (int *)take((size_t)n * 4);
+    w.fb_pval = (float *)take((size_t)FB_SPLITS * FB_ROWS * MEDTOK_MAX_TOPK * 4);
+    w.fb_pidx = (int *)take((size_t)FB_SPLITS * FB_ROWS * MEDTOK_MAX_TOPK * 4);
     w.cand_cnt = (int *)take((size_t)n * f.own_total * 4);
     w.cand = (uint2 *)take((size_t)n * f.own_total * F_CAP * 8);
     w.dump = nullptr;
@@ -488,7 +504,7 @@ static FilterWs filter_ws_layout(void *ws, int64_t n, const FilterPlan &f)
 
 static bool filter_eligible(int64_t n, int64_t k_codes, int d, int topk)
 {
-    return n >= 256 && k_codes >= 1024 && d <= 2048 && topk <= MEDTOK_MAX_TOPK && n < (1ll << 31);
+    return n >= 256 && k_codes >= 1024 && topk <= MEDTOK_MAX_TOPK && n < (1ll << 31);
 }
 
 static int resolve_path(int path, int64_t n, int64_t k_codes, int d, int topk)
@@ -520,7 +536,7 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
         (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, true, KTAIL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
         hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
                            (int)k_codes, d, p.codes_per_split, topk, (float *)nullptr, (int *)nullptr, idx, dist,
-                           (const int *)nullptr, (const int *)nullptr);
+                           (const int *)nullptr, (const int *)nullptr, 0, 0);
         if (pa) g_prof.push_back({pa, prof_mark(s), pflops, 1});
         return check_launch("search_f32");
     }
@@ -532,11 +548,11 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
     (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, false, KTAIL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
     hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
                        (int)k_codes, d, p.codes_per_split, topk, pval, pidx, (int64_t *)nullptr, (float *)nullptr,
-                       (const int *)nullptr, (const int *)nullptr);
+                       (const int *)nullptr, (const int *)nullptr, 0, 0);
     if (pa) g_prof.push_back({pa, prof_mark(s), pflops, 1});
     if (check_launch("search_f32(split)")) return 1;
     hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pval, pidx, (long)n,
-                       p.splits, topk, idx, dist);
+                       p.splits, topk, idx, dist, (const int *)nullptr, (const int *)nullptr);
     return check_launch("merge_topk");
 }
 
@@ -569,16 +585,27 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
                        w.cand, w.cand_cnt, (float *)nullptr);
     if (pa) g_prof.push_back({pa, prof_mark(s), 2.0 * (double)n * (double)k_codes * (double)d, 0});
     if (check_launch("filter_f16")) return 1;
-    const size_t rs_lds = (size_t)R_ROWS * d * 4 + (size_t)R_ROWS * R_SURV * 8 + (2 * R_ROWS + 1) * 4;
-    (void)hipFuncSetAttribute((const void *)rescore_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
-    hipLaunchKernelGGL((rescore_kernel<T>), dim3((unsigned)((n + R_ROWS - 1) / R_ROWS)), dim3(256), rs_lds, s, w.cand, w.cand_cnt, f.own_total,
+    hipLaunchKernelGGL((rescore_kernel<T>), dim3((unsigned)((n + R_ROWS - 1) / R_ROWS)), dim3(256), 0, s, w.cand, w.cand_cnt, f.own_total,
                        xhat, xsq, what, wsq, w.en_max, (long)n, (int)k_codes, d, topk, idx, dist, w.fb_count, w.fb_rows);
     if (check_launch("rescore")) return 1;
-    // exact redo of the rows the filter gave up on (normally none: the grid exits on *fb_count)
-    (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, true, KTAIL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
-    hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, true>), dim3((unsigned)((n + S_BN - 1) / S_BN), 1), dim3(256), S_LDS_BYTES, s,
-                       xhat, xsq, what, wsq, (long)n, (int)k_codes, d, (int)((k_codes + S_BM - 1) / S_BM * S_BM), topk,
-                       (float *)nullptr, (int *)nullptr, idx, dist, (const int *)w.fb_rows, (const int *)w.fb_count);
+    // exact redo of the rows the filter gave up on (normally none: every block exits on *fb_count)
+    const long code_tiles = (k_codes + S_BM - 1) / S_BM;
+    const int fb_splits = (int)lmin(FB_SPLITS, code_tiles);
+    const int fb_cps = (int)((code_tiles + fb_splits - 1) / fb_splits * S_BM);
+    const int fb_nsplit = (int)((code_tiles * S_BM + fb_cps - 1) / fb_cps);
+    const int head = (int)lmin(n, FB_ROWS);
+    (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, false, KTAIL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
+    hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL, true>), dim3((unsigned)((head + S_BN - 1) / S_BN), (unsigned)fb_nsplit), dim3(256), S_LDS_BYTES, s,
+                       xhat, xsq, what, wsq, (long)n, (int)k_codes, d, fb_cps, topk, w.fb_pval, w.fb_pidx, (int64_t *)nullptr, (float *)nullptr,
+                       (const int *)w.fb_rows, (const int *)w.fb_count, 0, head);
+    hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((head + 255) / 256)), dim3(256), 0, s, w.fb_pval, w.fb_pidx, (long)head,
+                       fb_nsplit, topk, idx, dist, (const int *)w.fb_rows, (const int *)w.fb_count);
+    if (n > head) {
+        (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, true, KTAIL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
+        hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, true>), dim3((unsigned)((n - head + S_BN - 1) / S_BN), 1), dim3(256), S_LDS_BYTES, s,
+                           xhat, xsq, what, wsq, (long)n, (int)k_codes, d, (int)(code_tiles * S_BM), topk,
+                           (float *)nullptr, (int *)nullptr, idx, dist, (const int *)w.fb_rows, (const int *)w.fb_count, head, (int)n);
+    }
     return check_launch("search_f32(fallback)");
 }
 
@@ -653,7 +680,7 @@ template <int MAXK>
 __global__ __launch_bounds__(256) void soft_assign_kernel(const float *__restrict__ xref, const float *__restrict__ what,
                                                           const int64_t *__restrict__ idx, const float *__restrict__ dist,
                                                           long n, int d, int topk, int flags, float *__restrict__ w_out,
-                                                          float *zq_ste, float *__restrict__ row_sqerr)
+                                                          float *zq_ste, long zq_stride, float *__restrict__ row_sqerr)
 {
     const bool hard = flags & MEDTOK_ASSIGN_HARD, raw = flags & MEDTOK_ASSIGN_RAW;
     const int lane = threadIdx.x & 63;
@@ -681,7 +708,7 @@ __global__ __launch_bounds__(256) void soft_assign_kernel(const float *__restric
         w_out[row * topk + lane] = v;
     }
     const float *xr = xref + row * d;
-    float *out = zq_ste + row * d;
+    float *out = zq_ste + row * zq_stride;
     float se = 0.f;
     for (int i = lane * 4; i < d; i += 256) {
         float4 a;
@@ -708,9 +735,11 @@ __global__ __launch_bounds__(256) void soft_assign_kernel(const float *__restric
 }
 
 extern "C" int medtok_soft_assign_f32(const float *xref, const float *what, const int64_t *idx, const float *dist,
-                                      int64_t n, int d, int topk, int flags, float *w, float *zq_ste, float *row_sqerr,
-                                      void *stream)
+                                      int64_t n, int d, int topk, int flags, float *w, float *zq_ste, int64_t zq_stride,
+                                      float *row_sqerr, void *stream)
 {
+    if (zq_stride == 0) zq_stride = d;
+    if (zq_stride < d || (zq_stride & 3)) return fail("soft_assign: zq_stride must be >= d and a multiple of 4");
     const int hard = flags & MEDTOK_ASSIGN_HARD;
     if (n < 0 || d <= 0 || (d & 3)) return fail("soft_assign: bad shape n=%ld d=%d", (long)n, d);
     if (topk < 1 || topk > MEDTOK_MAX_TOPK) return fail("soft_assign: topk=%d unsupported", topk);
@@ -719,7 +748,7 @@ extern "C" int medtok_soft_assign_f32(const float *xref, const float *what, cons
     if (!zq_ste) return fail("soft_assign: zq_ste required");
     if (n == 0) return 0;
     hipLaunchKernelGGL((soft_assign_kernel<MEDTOK_MAX_TOPK>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       xref, what, idx, dist, (long)n, d, topk, flags, w, zq_ste, row_sqerr);
+                       xref, what, idx, dist, (long)n, d, topk, flags, w, zq_ste, (long)zq_stride, row_sqerr);
     return check_launch("soft_assign");
 }
 
@@ -1099,7 +1128,7 @@ extern "C" size_t medtok_soft_vq_workspace_bytes(int64_t n, int64_t k_codes, int
 
 extern "C" int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d, const float *what, const float *wsq, int64_t k_codes,
                                           int topk, int path, float *xhat, int64_t *idx, float *dist, float *w, float *zq_ste,
-                                          float *row_sqerr, void *ws, size_t ws_bytes, void *stream)
+                                          int64_t zq_stride, float *row_sqerr, void *ws, size_t ws_bytes, void *stream)
 {
     if (n == 0) return 0;
     const size_t need = medtok_soft_vq_workspace_bytes(n, k_codes, d, topk, path);
@@ -1108,5 +1137,5 @@ extern "C" int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d, cons
     void *sws = (char *)ws + align_up((size_t)n * 4, 256);
     if (medtok_rownorm_f32(x, n, d, 1, xhat, xsq, stream)) return 1;
     if (medtok_topk_search_f32(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, sws, ws_bytes - align_up((size_t)n * 4, 256), path, stream)) return 1;
-    return medtok_soft_assign_f32(x, what, idx, dist, n, d, topk, 0, w, zq_ste, row_sqerr, stream);
+    return medtok_soft_assign_f32(x, what, idx, dist, n, d, topk, 0, w, zq_ste, zq_stride, row_sqerr, stream);
 }

@@ -29,13 +29,15 @@ def quantize_pooled(vq: VectorQuantizer, h: torch.Tensor, pooled_text: torch.Ten
     vq.eval()
     try:
         h_text, h_graph = torch.split(h, vq.split, dim=-1)
-        zq_t, _, _, _, idx_t, w_t = vq._search(vq.proj_text(h_text), "text", False)
-        zq_g, _, _, _, idx_g, w_g = vq._search(vq.proj_graph(h_graph), "graph", False)
-        zq_st, _, _, _, idx_st, w_st = vq._search(pooled_text, "shared", False)
-        zq_sg, _, _, _, idx_sg, w_sg = vq._search(pooled_graph, "shared", False)
+        e = vq.e_dim
+        # the four searches write straight into their column block of the result (the reference's torch.cat, :246)
+        embedding = torch.empty((h.shape[0], 4 * e), dtype=torch.float32, device=h.device)
+        _, _, _, _, idx_t, w_t = vq._search(vq.proj_text(h_text), "text", False, out=embedding[:, 0:e])
+        _, _, _, _, idx_g, w_g = vq._search(vq.proj_graph(h_graph), "graph", False, out=embedding[:, e:2 * e])
+        _, _, _, _, idx_st, w_st = vq._search(pooled_text, "shared", False, out=embedding[:, 2 * e:3 * e])
+        _, _, _, _, idx_sg, w_sg = vq._search(pooled_graph, "shared", False, out=embedding[:, 3 * e:4 * e])
     finally:
         vq.train(was_training)
-    embedding = torch.cat((zq_t, zq_g, zq_st, zq_sg), dim=-1)
     tokens = torch.stack((idx_t, idx_g, idx_st, idx_sg), dim=1)
     weights = torch.stack((w_t, w_g, w_st, w_sg), dim=1)
     return embedding, tokens, weights

@@ -116,9 +116,20 @@ def debug_filter_scores(xhat, xsq, what, wsq):
     return out
 
 
+def _zq_out(out, n, d, like):
+    """Output buffer for zq: a fresh [n, d] tensor, or the caller's column block of a wider row-major tensor."""
+    if out is None:
+        return torch.empty((n, d), dtype=torch.float32, device=like.device), d
+    if not (out.is_cuda and out.dtype == torch.float32 and out.shape == (n, d) and out.stride(1) == 1 and out.stride(0) % 4 == 0
+            and out.data_ptr() % 16 == 0):
+        raise ValueError("out must be an fp32 [n, d] device view with unit column stride and 16-byte aligned rows")
+    return out, out.stride(0)
+
+
 def soft_assign(xref, what, idx, dist, hard: bool = False, want_w: bool = True, want_sqerr: bool = True,
-                raw: bool = False):
-    """(w [n,k], zq [n,d], row_sqerr [n]); zq is the straight-through value unless raw."""
+                raw: bool = False, out=None):
+    """(w [n,k], zq [n,d], row_sqerr [n]); zq is the straight-through value unless raw.
+    `out` may be a column block of a wider tensor (e.g. emb[:, d:2*d])."""
     xref, what = _dev(xref, "xref"), _dev(what, "what")
     idx = _dev(idx, "idx", torch.int64)
     n, d = xref.shape
@@ -126,11 +137,11 @@ def soft_assign(xref, what, idx, dist, hard: bool = False, want_w: bool = True, 
     dist = None if hard and dist is None else _dev(dist, "dist")
     lib = _lib.load()
     w = torch.empty((n, topk), dtype=torch.float32, device=xref.device) if want_w else None
-    zq = torch.empty_like(xref)
+    zq, zstride = _zq_out(out, n, d, xref)
     se = torch.empty(n, dtype=torch.float32, device=xref.device) if want_sqerr else None
     with torch.cuda.device(xref.device):
         _lib.check(lib.medtok_soft_assign_f32(xref.data_ptr(), what.data_ptr(), idx.data_ptr(), _ptr(dist), n, d, topk,
-                                              int(hard) | (2 if raw else 0), _ptr(w), zq.data_ptr(), _ptr(se), _stream(xref)),
+                                              int(hard) | (2 if raw else 0), _ptr(w), zq.data_ptr(), zstride, _ptr(se), _stream(xref)),
                    "medtok_soft_assign_f32")
     return w, zq, se
 
@@ -214,16 +225,16 @@ def usage_update_(window: torch.Tensor, ids: torch.Tensor, n_codes: int) -> torc
     return count
 
 
-def soft_vq_forward(x, what, wsq, topk: int, path: int = PATH_AUTO, want_sqerr: bool = True):
+def soft_vq_forward(x, what, wsq, topk: int, path: int = PATH_AUTO, want_sqerr: bool = True, out=None):
     """rownorm -> search -> soft assign in one C call.
-    Returns dict(xhat, idx, dist, w, zq, row_sqerr)."""
+    Returns dict(xhat, idx, dist, w, zq, row_sqerr); `out` as in soft_assign."""
     x, what, wsq = _dev(x, "x"), _dev(what, "what"), _dev(wsq, "wsq")
     n, d = x.shape
     k = what.shape[0]
     if SEARCH_TIMER is not None:         # same kernels, launched piecewise so the search can be bracketed
         xhat, xsq = rownorm(x)
         idx, dist = topk_search(xhat, xsq, what, wsq, topk, path)
-        w, zq, se = soft_assign(x, what, idx, dist, want_sqerr=want_sqerr)
+        w, zq, se = soft_assign(x, what, idx, dist, want_sqerr=want_sqerr, out=out)
         return dict(xhat=xhat, idx=idx, dist=dist, w=w, zq=zq, row_sqerr=se)
     lib = _lib.load()
     dev = x.device
@@ -231,12 +242,12 @@ def soft_vq_forward(x, what, wsq, topk: int, path: int = PATH_AUTO, want_sqerr: 
     idx = torch.empty((n, topk), dtype=torch.int64, device=dev)
     dist = torch.empty((n, topk), dtype=torch.float32, device=dev)
     w = torch.empty((n, topk), dtype=torch.float32, device=dev)
-    zq = torch.empty_like(x)
+    zq, zstride = _zq_out(out, n, d, x)
     se = torch.empty(n, dtype=torch.float32, device=dev) if want_sqerr else None
     ws = _ws(lib.medtok_soft_vq_workspace_bytes(n, k, d, topk, path), x)
     with torch.cuda.device(dev):
         _lib.check(lib.medtok_soft_vq_forward_f32(x.data_ptr(), n, d, what.data_ptr(), wsq.data_ptr(), k, topk, path,
                                                   xhat.data_ptr(), idx.data_ptr(), dist.data_ptr(), w.data_ptr(),
-                                                  zq.data_ptr(), _ptr(se), ws.data_ptr(), ws.numel(), _stream(x)),
+                                                  zq.data_ptr(), zstride, _ptr(se), ws.data_ptr(), ws.numel(), _stream(x)),
                    "medtok_soft_vq_forward_f32")
     return dict(xhat=xhat, idx=idx, dist=dist, w=w, zq=zq, row_sqerr=se)

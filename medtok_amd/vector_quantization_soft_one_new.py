@@ -203,7 +203,7 @@ class VectorQuantizer(nn.Module):
         return torch.sum(x ** 2, dim=1, keepdim=True) + torch.sum(y ** 2, dim=1) - 2 * x @ y.t()
 
     # ------------------------------------------------------------------ one search
-    def _search(self, x, types, training):
+    def _search(self, x, types, training, out=None):
         lo, hi = self._region(types)
         n = x.shape[0]
         x = x.float()                   # autocast callers hand over fp16/bf16; the search is fp32
@@ -215,7 +215,7 @@ class VectorQuantizer(nn.Module):
             return zq, vq, commit, xhat, idx, w
         what, wsq = self._normalised_codebook()
         r = ops.soft_vq_forward(x.detach().float(), what[lo:hi], wsq[lo:hi].contiguous(), self.k, self.search_path,
-                                want_sqerr=training)
+                                want_sqerr=training, out=out)
         if training:
             vq = ops.sum_scale(r["row_sqerr"], 1.0 / (n * x.shape[1]))
             commit = self.beta * vq

@@ -111,3 +111,21 @@ def test_auto_path_matches_exact_in_modules(dev):
     b = quantize_pooled(v, h, pt, pg)
     for u, w in zip(a, b):
         assert torch.equal(u, w)
+
+
+def test_filter_fallback_sizes(oracle, dev):
+    """Few rows falling back (split-code redo) and many rows falling back (> FB_ROWS: plain redo) both stay exact."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(21)
+    d, k = 64, 2048
+    W = rng.standard_normal((k, d), dtype=np.float32)
+    wh, ws = ops.rownorm(_t(W, dev))
+    for n, n_big in ((3000, 7), (20000, 12000)):
+        x = rng.standard_normal((n, d), dtype=np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        sel = rng.choice(n, n_big, replace=False)
+        x[sel] *= 3.0                                   # |x|^2 = 9 > 4: these rows must take the exact path
+        xd = _t(x, dev)
+        _, xs = ops.rownorm(xd, normalize=False)
+        i1, d1, i2, d2 = both_paths(xd, xs, wh, ws, 5)
+        assert torch.equal(i1, i2) and torch.equal(d1, d2)
