@@ -777,7 +777,7 @@ extern "C" int medtok_sum_scale_f32(const float *vals, int64_t n, double scale, 
 // ================================================================= EMA statistics
 // bins: integer histogram.  embed_sum: rows are ordered by (code, row) with a stable LSD radix
 // sort (8-bit digits), then one wavefront per code adds its rows in increasing row order.
-constexpr int SORT_BLOCKS = 256;       // x 4 waves = 1024 sorting waves
+constexpr int SORT_BLOCKS = 64;        // x 4 waves = 256 sorting waves (the digit x wave count table is scanned by ONE block)
 constexpr int SORT_WAVES = SORT_BLOCKS * 4;
 
 // ids outside [0, K) are clamped (same clamp in the sort) so the layout stays consistent
@@ -792,14 +792,18 @@ __global__ __launch_bounds__(256) void hist_kernel(const int64_t *__restrict__ i
         atomicAdd(&counts[clamp_code(idx[i], k_codes)], 1);
 }
 
-// exclusive scan of counts[0..k) -> offsets[0..k] (single block, fixed order)
+// exclusive scan of counts[0..k) -> offsets[0..k] (single block, fixed order).  Each thread owns a contiguous
+// chunk (a multiple of 4 entries, read as int4) so the two passes over the table are wide loads.
 __global__ __launch_bounds__(1024) void scan_kernel(const int *__restrict__ counts, int k, int *__restrict__ offsets)
 {
     __shared__ int part[1024];
-    const int per = (k + 1023) / 1024;
+    const int per = ((k + 1023) / 1024 + 3) & ~3;
     const int lo = min(k, (int)threadIdx.x * per), hi = min(k, lo + per);
+    const bool vec = ((reinterpret_cast<uintptr_t>(counts) | reinterpret_cast<uintptr_t>(offsets)) & 15) == 0;
     int s = 0;
-    for (int i = lo; i < hi; ++i) s += counts[i];
+    int i = lo;
+    if (vec) for (; i + 4 <= hi; i += 4) { const int4 v = *reinterpret_cast<const int4 *>(counts + i); s += v.x + v.y + v.z + v.w; }
+    for (; i < hi; ++i) s += counts[i];
     part[threadIdx.x] = s;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -809,7 +813,14 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int *__restrict__ coun
         __syncthreads();
     }
     int run = part[threadIdx.x] - s;
-    for (int i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
+    i = lo;
+    if (vec) for (; i + 4 <= hi; i += 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(counts + i);
+        int4 o; o.x = run; o.y = run + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
+        run = o.w + v.w;
+        *reinterpret_cast<int4 *>(offsets + i) = o;
+    }
+    for (; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
     if (threadIdx.x == 1023) offsets[k] = part[1023];
 }
 
