@@ -504,7 +504,10 @@ static FilterWs filter_ws_layout(void *ws, int64_t n, const FilterPlan &f)
 
 static bool filter_eligible(int64_t n, int64_t k_codes, int d, int topk)
 {
-    return n >= 256 && k_codes >= 1024 && topk <= MEDTOK_MAX_TOPK && n < (1ll << 31);
+    // the filter path has ~0.1-0.2 ms of fixed cost (operand conversion, three extra launches); measured
+    // crossover against the exact kernel on MI355X is around 1e10 flop (tools/path_crossover.py)
+    return n >= 512 && k_codes >= 1024 && 2.0 * (double)n * (double)k_codes * (double)d >= 1.0e10 &&
+           topk <= MEDTOK_MAX_TOPK && n < (1ll << 31);
 }
 
 static int resolve_path(int path, int64_t n, int64_t k_codes, int d, int topk)

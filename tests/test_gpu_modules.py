@@ -271,3 +271,47 @@ def test_search_properties_at_config2_size(dev):
     c = int(idx[0])
     dense = zh[idx.view(-1) == c].double().sum(0)
     assert float((es_sum[c].double() - dense).abs().max()) < 1e-5
+
+
+def test_config3_full_size_properties(dev):
+    """BASELINE config 3 at full width (D=768, n_e=49152, k=5) on a 40k-row slice of the 600k workload, default
+    (fp16-filter) path vs exact path plus size-independent properties; bench.py runs the full 600k rows."""
+    from medtok_amd import ops
+    from medtok_amd.inference import quantize_pooled
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    torch.manual_seed(1234)
+    D, region = 768, 16384
+    v = VectorQuantizer(3 * region, D, 0.25, 0.0, True, False, [D, D]).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(0)
+    n = 40000
+    h = torch.randn(n, 2 * D, device=dev, generator=g)
+    pt = torch.randn(n, D, device=dev, generator=g); pg = torch.randn(n, D, device=dev, generator=g)
+    emb, tok, w = quantize_pooled(v, h, pt, pg)
+    assert emb.shape == (n, 4 * D) and tok.shape == (n, 4, 5) and tok.dtype == torch.int64
+    # (1) exact path: identical bits
+    v.search_path = ops.PATH_F32_MFMA
+    emb2, tok2, w2 = quantize_pooled(v, h, pt, pg)
+    assert torch.equal(tok, tok2) and torch.equal(w, w2) and torch.equal(emb, emb2)
+    v.search_path = ops.PATH_AUTO
+    # (2) row permutation permutes outputs (rows are independent: the property multi-GPU sharding relies on)
+    perm = torch.randperm(n, device=dev, generator=g)
+    emb_p, tok_p, w_p = quantize_pooled(v, h[perm].contiguous(), pt[perm].contiguous(), pg[perm].contiguous())
+    assert torch.equal(tok_p, tok[perm]) and torch.equal(emb_p, emb[perm])
+    # (3) row shards give the same rows (what bench.py --gpus N does per rank)
+    from medtok_amd.distributed import row_shard
+    lo, hi = row_shard(n, 3, 8)
+    emb_s, tok_s, _ = quantize_pooled(v, h[lo:hi].contiguous(), pt[lo:hi].contiguous(), pg[lo:hi].contiguous())
+    assert torch.equal(tok_s, tok[lo:hi]) and torch.equal(emb_s, emb[lo:hi])
+    # (4) ranges, ordering, weights
+    assert int(tok[:, :2].max()) < region and int(tok[:, 2:].max()) < 3 * region and int(tok.min()) >= 0
+    assert torch.allclose(w.sum(-1), torch.ones(n, 4, device=dev), atol=1e-6)
+    assert bool((w[..., :-1] >= w[..., 1:]).all())          # ascending distance = descending weight
+    # (5) sampled rows against a dense fp64 evaluation of the reference formula
+    what, wsq = v._normalised_codebook()
+    sel = torch.arange(0, n, 1999, device=dev)
+    xn = torch.nn.functional.normalize(pt[sel].double(), dim=-1)
+    d64 = (xn ** 2).sum(1, keepdim=True) + (what.double() ** 2).sum(1) - 2 * xn @ what.double().t()
+    top = torch.topk(d64, 6, largest=False)
+    clear = (top.values[:, 1:] - top.values[:, :-1]).min(1).values > 1e-5
+    assert clear.float().mean() > 0.9
+    assert torch.equal(tok[sel, 2][clear], top.indices[:, :5][clear])
