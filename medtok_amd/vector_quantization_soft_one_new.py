@@ -79,6 +79,9 @@ class CrossAttention(nn.Module):
         text side only evaluates its CLS query.
         """
         bsz = text.shape[0]
+        if nodes.dtype != text.dtype:                      # autocast hands over bf16 text features and fp32 node features
+            common = torch.promote_types(nodes.dtype, text.dtype)
+            nodes, text = nodes.to(common), text.to(common)
         valid = text_mask.to(torch.bool)
         batch = batch.reshape(-1).to(torch.long)
         counts = torch.bincount(batch, minlength=bsz)
