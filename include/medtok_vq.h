@@ -81,6 +81,13 @@ int medtok_topk_search_f32(const float *xhat, const float *xsq, int64_t n,
                            int d, int topk, int64_t *idx, float *dist,
                            void *ws, size_t ws_bytes, int path, void *stream);
 
+/* Exact merge of per-shard results of a code-sharded search: dist_parts / idx_parts are
+ * [parts, n, topk] (idx already global code ids), output is the top-k of the union by (d, index).
+ * Because the arithmetic contract does not depend on where a code lives, this equals the
+ * single-GPU result bit for bit. */
+int medtok_merge_topk_lists_f32(const float *dist_parts, const int64_t *idx_parts, int64_t n,
+                                int parts, int topk, int64_t *idx, float *dist, void *stream);
+
 /* Test hook: the approximate scores s~ [n, k_codes] the fp16 filter works with, so the error
  * bound it relies on (medtok_amd/csrc/filter_f16.h) can be measured. Not part of the product path. */
 size_t medtok_debug_filter_scores_workspace_bytes(int64_t n, int64_t k_codes, int d);

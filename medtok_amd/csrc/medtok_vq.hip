@@ -677,6 +677,48 @@ extern "C" int medtok_debug_filter_scores_f32(const float *xhat, const float *xs
     return check_launch("filter_f16(dump)");
 }
 
+// ================================================================= merge of per-shard top-k lists
+// Code-sharded search (SURVEY 8e variant): every shard returns, for the same rows, its own top-k over its slice of
+// the codebook (global code ids); the exact top-k over the union is the (d, index)-lexicographic merge.
+__global__ __launch_bounds__(256) void merge_lists_kernel(const float *__restrict__ dist_parts, const int64_t *__restrict__ idx_parts,
+                                                          long n, int parts, int topk, int64_t *__restrict__ out_idx,
+                                                          float *__restrict__ out_dist)
+{
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    float bv[MEDTOK_MAX_TOPK];
+    long bi[MEDTOK_MAX_TOPK];
+#pragma unroll
+    for (int j = 0; j < MEDTOK_MAX_TOPK; ++j) { bv[j] = INFINITY; bi[j] = 0x7fffffffffffffffl; }
+    for (int p = 0; p < parts; ++p)
+        for (int j = 0; j < topk; ++j) {
+            const float v = dist_parts[((long)p * n + row) * topk + j];
+            const long c = idx_parts[((long)p * n + row) * topk + j];
+            // insertion by (value, index); the lists are short (parts * topk entries)
+#pragma unroll
+            for (int q = MEDTOK_MAX_TOPK - 1; q >= 0; --q) {
+                const bool before = v < bv[q] || (v == bv[q] && c < bi[q]);
+                if (before) {
+                    if (q + 1 < MEDTOK_MAX_TOPK) { bv[q + 1] = bv[q]; bi[q + 1] = bi[q]; }
+                    bv[q] = v; bi[q] = c;
+                }
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < MEDTOK_MAX_TOPK; ++j)
+        if (j < topk) { out_idx[row * topk + j] = bi[j]; out_dist[row * topk + j] = bv[j]; }
+}
+
+extern "C" int medtok_merge_topk_lists_f32(const float *dist_parts, const int64_t *idx_parts, int64_t n, int parts, int topk,
+                                           int64_t *idx, float *dist, void *stream)
+{
+    if (n < 0 || parts < 1 || topk < 1 || topk > MEDTOK_MAX_TOPK) return fail("merge_topk_lists: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(merge_lists_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dist_parts, idx_parts,
+                       (long)n, parts, topk, idx, dist);
+    return check_launch("merge_topk_lists");
+}
+
 // ================================================================= soft assign
 // One wavefront per row; lanes stride the D axis in float4.
 template <int MAXK>

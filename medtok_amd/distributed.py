@@ -77,3 +77,35 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+
+
+def code_shard(k_codes: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) slice of the codebook for `rank` (same balancing rule as row_shard)."""
+    return row_shard(k_codes, rank, world)
+
+
+def code_sharded_search(xhat: torch.Tensor, xsq: torch.Tensor, what_local: torch.Tensor, wsq_local: torch.Tensor,
+                        code_lo: int, topk: int, group=None, search_fn=None, merge_fn=None):
+    """The variant north_star names: every rank holds a slice [code_lo, code_lo + K_local) of the codebook and ALL rows.
+    Local top-k over the slice -> all-gather of the (distance, global id) lists (n * k * 12 bytes per rank over xGMI)
+    -> exact (d, index) merge.  Identical bits to a single-GPU search because the contract's dot-product order does
+    not depend on where a code lives.  `search_fn` / `merge_fn` default to the HIP ops; the CPU gloo test passes the
+    oracle's so the exchange logic runs without a GPU."""
+    if search_fn is None or merge_fn is None:
+        from . import ops
+        search_fn = search_fn or (lambda a, b, c, d, k: ops.topk_search(a, b, c, d, k))
+        merge_fn = merge_fn or ops.merge_topk_lists
+    idx, dist = search_fn(xhat, xsq, what_local, wsq_local, topk)
+    idx = idx + code_lo
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()) or torch.distributed.get_world_size(group) == 1:
+        return idx, dist
+    world = torch.distributed.get_world_size(group)
+    d_parts = [torch.empty_like(dist) for _ in range(world)]
+    i_parts = [torch.empty_like(idx) for _ in range(world)]
+    torch.distributed.all_gather(d_parts, dist.contiguous(), group=group)
+    torch.distributed.all_gather(i_parts, idx.contiguous(), group=group)
+    return merge_fn(torch.stack(d_parts), torch.stack(i_parts))
+
+
+def dist_is_on() -> bool:
+    return dist.is_available() and dist.is_initialized()

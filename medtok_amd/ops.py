@@ -101,6 +101,19 @@ def topk_search(xhat, xsq, what, wsq, topk: int, path: int = PATH_AUTO):
     return idx, dist
 
 
+def merge_topk_lists(dist_parts, idx_parts):
+    """Exact top-k of the union of per-shard lists: dist_parts [P, n, k] fp32, idx_parts [P, n, k] int64 (global ids)."""
+    dist_parts, idx_parts = _dev(dist_parts, "dist_parts"), _dev(idx_parts, "idx_parts", torch.int64)
+    parts, n, k = dist_parts.shape
+    lib = _lib.load()
+    idx = torch.empty((n, k), dtype=torch.int64, device=dist_parts.device)
+    dist = torch.empty((n, k), dtype=torch.float32, device=dist_parts.device)
+    with torch.cuda.device(dist_parts.device):
+        _lib.check(lib.medtok_merge_topk_lists_f32(dist_parts.data_ptr(), idx_parts.data_ptr(), n, parts, k, idx.data_ptr(),
+                                                   dist.data_ptr(), _stream(dist_parts)), "medtok_merge_topk_lists_f32")
+    return idx, dist
+
+
 def debug_filter_scores(xhat, xsq, what, wsq):
     """Test hook: approximate scores s~ [n, K] of the fp16 filter."""
     xhat, xsq, what, wsq = _dev(xhat, "xhat"), _dev(xsq, "xsq"), _dev(what, "what"), _dev(wsq, "wsq")

@@ -59,3 +59,45 @@ def test_two_rank_ema_step_equals_single_process(tmp_path, oracle):
     assert np.array_equal(r0["cs"], cs)                                           # integer counts: exact
     assert np.abs(r0["E"] - E).max() <= 1e-6
     assert float(r0["slow"]) == 2.0 == float(r1["slow"])
+
+
+def _code_shard_worker(rank, world, port, n, k, d, topk, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from medtok_amd import distributed as D
+    from oracle import oracle as O
+    D.init_distributed("gloo")
+    rng = np.random.default_rng(1)
+    xh, xs = O.rownorm(rng.standard_normal((n, d), dtype=np.float32))
+    W = rng.standard_normal((k, d), dtype=np.float32)
+    W[k // 2 + 3] = W[5]                                    # a duplicate that straddles the shard boundary: tie rule across ranks
+    wh, ws = O.rownorm(W)
+    lo, hi = D.code_shard(k, rank, world)
+
+    def search(a, b, c, e, kk):
+        i, dd = O.topk_search(a.numpy(), b.numpy(), c.numpy(), e.numpy(), kk)
+        return torch.from_numpy(i), torch.from_numpy(dd)
+
+    def merge(dp, ip):                                       # numpy stand-in for the HIP merge kernel: (d, index) lexicographic
+        P, nn, kk = dp.shape
+        dflat = dp.permute(1, 0, 2).reshape(nn, P * kk).numpy(); iflat = ip.permute(1, 0, 2).reshape(nn, P * kk).numpy()
+        order = np.lexsort((iflat, dflat), axis=1)[:, :kk]
+        return torch.from_numpy(np.take_along_axis(iflat, order, 1)), torch.from_numpy(np.take_along_axis(dflat, order, 1))
+
+    idx, dist_ = D.code_sharded_search(torch.from_numpy(xh), torch.from_numpy(xs), torch.from_numpy(wh[lo:hi]), torch.from_numpy(ws[lo:hi]),
+                                       lo, topk, search_fn=search, merge_fn=merge)
+    np.savez(os.path.join(out_dir, f"c{rank}.npz"), idx=idx.numpy(), dist=dist_.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_code_sharded_search_equals_single_process(tmp_path, oracle):
+    n, k, d, topk, world = 300, 1000, 64, 5, 2
+    mp.spawn(_code_shard_worker, args=(world, _free_port(), n, k, d, topk, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(1)
+    xh, xs = oracle.rownorm(rng.standard_normal((n, d), dtype=np.float32))
+    W = rng.standard_normal((k, d), dtype=np.float32); W[k // 2 + 3] = W[5]
+    wh, ws = oracle.rownorm(W)
+    idx, dd = oracle.topk_search(xh, xs, wh, ws, topk)
+    for r in range(world):
+        got = np.load(tmp_path / f"c{r}.npz")
+        assert np.array_equal(got["idx"], idx) and np.array_equal(got["dist"], dd)       # bit-exact, tie across the boundary included

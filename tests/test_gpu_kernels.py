@@ -187,3 +187,22 @@ def test_cpu_tensors_are_rejected():
     from medtok_amd import ops, _lib
     with pytest.raises(_lib.MedTokLibraryError):
         ops.rownorm(torch.zeros(4, 8))
+
+
+def test_code_sharded_merge_is_bit_exact(oracle, dev):
+    """8 code shards searched separately (either path) and merged == one search over the whole codebook."""
+    from medtok_amd import ops
+    from medtok_amd.distributed import code_shard
+    rng = np.random.default_rng(33)
+    n, k, d = 3000, 16384, 64
+    x = rng.standard_normal((n, d), dtype=np.float32); W = rng.standard_normal((k, d), dtype=np.float32)
+    W[9000] = W[17]                                          # cross-shard duplicate
+    xh, xs = ops.rownorm(_t(x, dev)); wh, ws = ops.rownorm(_t(W, dev))
+    idx, dist = ops.topk_search(xh, xs, wh, ws, 5)
+    dparts, iparts = [], []
+    for r in range(8):
+        lo, hi = code_shard(k, r, 8)
+        i_r, d_r = ops.topk_search(xh, xs, wh[lo:hi], ws[lo:hi], 5)
+        dparts.append(d_r); iparts.append(i_r + lo)
+    idx_m, dist_m = ops.merge_topk_lists(torch.stack(dparts), torch.stack(iparts))
+    assert torch.equal(idx_m, idx) and torch.equal(dist_m, dist)
