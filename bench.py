@@ -77,6 +77,14 @@ class Cfg3:
     def set_path(self, path):
         self.vq.search_path = path
 
+    def paths_agree(self):
+        self.set_path(ops.PATH_AUTO)
+        a = self.step()
+        self.set_path(ops.PATH_F32_MFMA)
+        b = self.step()
+        self.set_path(ops.PATH_AUTO)
+        return all(torch.equal(u, v) for u, v in zip(a, b))
+
     def step(self):
         from medtok_amd.inference import quantize_pooled
         self.vq._norm_cache = None      # re-normalise the codebook every call, like the reference (:148,198,200)
@@ -119,6 +127,17 @@ class Cfg2:
 
     def set_path(self, path):
         self.q.search_path = path
+
+    def paths_agree(self):
+        keep = (self.q.embedding.weight.data.clone(), self.q.cluster_size.clone())
+        outs = []
+        for path in (ops.PATH_AUTO, ops.PATH_F32_MFMA):
+            self.q.embedding.weight.data.copy_(keep[0]); self.q.cluster_size.copy_(keep[1])
+            self.set_path(path)
+            zq, loss, idx = self.step()
+            outs.append((zq.clone(), loss.clone(), idx.clone(), self.q.embedding.weight.data.clone(), self.q.cluster_size.clone()))
+        self.set_path(ops.PATH_AUTO)
+        return all(torch.equal(u, v) for u, v in zip(*outs))
 
     def step(self):
         with torch.no_grad():
@@ -180,6 +199,7 @@ def main():
     # the exact fp32-MFMA path on the same workload (1 step): the filter path returns the same bits, faster
     exact = None
     if args.path == ops.PATH_AUTO and args.exact_steps > 0:
+        agree = wl.paths_agree()             # same state, same inputs, both paths: every output tensor must be bit-identical
         wl.set_path(ops.PATH_F32_MFMA)
         wl.step()
         torch.cuda.synchronize(dev)
@@ -192,6 +212,7 @@ def main():
         e_prof = ops.profile_end()["search_f32_kernel"]
         e_ach = e_prof["flops"] / (e_prof["ms"] * 1e-3) / 1e12 if e_prof["ms"] > 0 else 0.0
         exact = {"value": rows * args.exact_steps / e_elapsed, "unit": "codes/s per GPU", "steps": args.exact_steps,
+                 "outputs_bit_identical_to_default_path": bool(agree),
                  "roofline": {"bound": "mfma", "kernel": "search_f32_kernel", "achieved": e_ach, "peak": FP32_MFMA_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": e_ach / FP32_MFMA_PEAK_TFLOPS,
                               "avg_launch_ms": e_prof["ms"] / max(e_prof["launches"], 1)}}
