@@ -1136,26 +1136,39 @@ __global__ __launch_bounds__(256) void usage_shift_kernel(const float *__restric
     }
 }
 
-__global__ __launch_bounds__(256) void usage_count_kernel(const float *__restrict__ tmp, long wlen, long n_codes, float *__restrict__ win,
-                                                          unsigned *__restrict__ bitmap, int *__restrict__ count)
+// Distinct count without atomics on the hot words: every window entry stores 1 into its code's flag byte (all
+// writers write the same value, so the race is benign), then one block sums the n_codes + 1 flags.  (300 000 atomicOr
+// operations on a 21 000-bit map serialise on ~650 words: 1.6 ms; this form takes microseconds.)
+__global__ __launch_bounds__(256) void usage_mark_kernel(const float *__restrict__ tmp, long wlen, long n_codes, float *__restrict__ win,
+                                                         unsigned char *__restrict__ flags)
 {
-    int local = 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < wlen; i += (long)gridDim.x * 256) {
         const float v = tmp[i];
         win[i] = v;
         long c = (long)v;
         if (c < 0 || c >= n_codes) c = n_codes;
-        const unsigned bit = 1u << (c & 31);
-        const unsigned old = atomicOr(&bitmap[c >> 5], bit);
-        local += (old & bit) ? 0 : 1;
+        flags[c] = 1;
     }
-    if (local) atomicAdd(count, local);
+}
+
+__global__ __launch_bounds__(1024) void usage_sum_kernel(const unsigned char *__restrict__ flags, long n, int *__restrict__ count)
+{
+    __shared__ int sh[1024];
+    int a = 0;
+    for (long i = threadIdx.x; i < n; i += 1024) a += flags[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[0] = sh[0];
 }
 
 extern "C" size_t medtok_usage_workspace_bytes(int64_t window_len, int64_t n_codes)
 {
     if (window_len <= 0 || n_codes <= 0) return 0;
-    return align_up((size_t)window_len * 4, 256) + align_up(((size_t)n_codes / 32 + 2) * 4, 256);
+    return align_up((size_t)window_len * 4, 256) + align_up((size_t)n_codes + 1, 256);
 }
 
 extern "C" int medtok_usage_update(float *window, int64_t window_len, const int64_t *ids, int64_t m, int64_t n_codes,
@@ -1166,12 +1179,12 @@ extern "C" int medtok_usage_update(float *window, int64_t window_len, const int6
     if (!ws || ws_bytes < need) return fail("usage_update: workspace too small (%zu < %zu)", ws_bytes, need);
     hipStream_t s = (hipStream_t)stream;
     float *tmp = (float *)ws;
-    unsigned *bitmap = (unsigned *)((char *)ws + align_up((size_t)window_len * 4, 256));
-    if (hipMemsetAsync(bitmap, 0, ((size_t)n_codes / 32 + 2) * 4, s) != hipSuccess) return fail("usage_update: memset failed");
-    if (hipMemsetAsync(count_out, 0, 4, s) != hipSuccess) return fail("usage_update: memset failed");
+    unsigned char *flags = (unsigned char *)ws + align_up((size_t)window_len * 4, 256);
+    if (hipMemsetAsync(flags, 0, (size_t)n_codes + 1, s) != hipSuccess) return fail("usage_update: memset failed");
     const unsigned blocks = (unsigned)lmin(1024, (window_len + 255) / 256);
     hipLaunchKernelGGL(usage_shift_kernel, dim3(blocks), dim3(256), 0, s, window, (long)window_len, ids, (long)m, tmp);
-    hipLaunchKernelGGL(usage_count_kernel, dim3(blocks), dim3(256), 0, s, tmp, (long)window_len, (long)n_codes, window, bitmap, count_out);
+    hipLaunchKernelGGL(usage_mark_kernel, dim3(blocks), dim3(256), 0, s, tmp, (long)window_len, (long)n_codes, window, flags);
+    hipLaunchKernelGGL(usage_sum_kernel, dim3(1), dim3(1024), 0, s, flags, (long)n_codes + 1, count_out);
     return check_launch("usage_update");
 }
 
