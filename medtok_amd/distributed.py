@@ -95,17 +95,13 @@ def code_sharded_search(xhat: torch.Tensor, xsq: torch.Tensor, what_local: torch
         from . import ops
         search_fn = search_fn or (lambda a, b, c, d, k: ops.topk_search(a, b, c, d, k))
         merge_fn = merge_fn or ops.merge_topk_lists
-    idx, dist = search_fn(xhat, xsq, what_local, wsq_local, topk)
+    idx, d_local = search_fn(xhat, xsq, what_local, wsq_local, topk)
     idx = idx + code_lo
-    if not (torch.distributed.is_available() and torch.distributed.is_initialized()) or torch.distributed.get_world_size(group) == 1:
-        return idx, dist
-    world = torch.distributed.get_world_size(group)
-    d_parts = [torch.empty_like(dist) for _ in range(world)]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return idx, d_local
+    world = dist.get_world_size(group)
+    d_parts = [torch.empty_like(d_local) for _ in range(world)]
     i_parts = [torch.empty_like(idx) for _ in range(world)]
-    torch.distributed.all_gather(d_parts, dist.contiguous(), group=group)
-    torch.distributed.all_gather(i_parts, idx.contiguous(), group=group)
+    dist.all_gather(d_parts, d_local.contiguous(), group=group)
+    dist.all_gather(i_parts, idx.contiguous(), group=group)
     return merge_fn(torch.stack(d_parts), torch.stack(i_parts))
-
-
-def dist_is_on() -> bool:
-    return dist.is_available() and dist.is_initialized()

@@ -28,7 +28,6 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 from .norm_ema_quantizer import EmbeddingEMA
