@@ -129,3 +129,18 @@ def test_filter_fallback_sizes(oracle, dev):
         _, xs = ops.rownorm(xd, normalize=False)
         i1, d1, i2, d2 = both_paths(xd, xs, wh, ws, 5)
         assert torch.equal(i1, i2) and torch.equal(d1, d2)
+
+
+def test_filter_race_screen(dev):
+    """Repeated large launches against the exact path: the LDS-DMA ring is ordered only by counted vmcnt waits and
+    raw barriers, and a misplaced wait shows up as rare wrong tiles that come and go with shape and memory load."""
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    shapes = [(150000, 8192, 768), (90000, 16384, 768), (300000, 4096, 256), (60000, 49152, 768), (200000, 21000, 64)]
+    for rep in range(3):
+        for n, k, d in shapes:
+            x = torch.randn(n, d, device=dev, generator=g); W = torch.randn(k, d, device=dev, generator=g)
+            xh, xs = ops.rownorm(x); wh, ws = ops.rownorm(W)
+            i2, d2 = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
+            i1, d1 = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F32_MFMA)
+            assert torch.equal(i1, i2) and torch.equal(d1, d2), (rep, n, k, d)

@@ -315,3 +315,29 @@ def test_config3_full_size_properties(dev):
     clear = (top.values[:, 1:] - top.values[:, :-1]).min(1).values > 1e-5
     assert clear.float().mean() > 0.9
     assert torch.equal(tok[sel, 2][clear], top.indices[:, :5][clear])
+
+
+def test_kmeans_init_path(dev):
+    """norm_ema_quantizer.py:85-93 / :24-57: first forward of a kmeans-initialised quantiser clusters the batch.
+    Parity with the reference is statistical only (its initial means come from torch.randperm): check the invariants."""
+    from medtok_amd.norm_ema_quantizer import NormEMAVectorQuantizer
+    torch.manual_seed(0)
+    K, D, N = 32, 64, 4096
+    centers = torch.nn.functional.normalize(torch.randn(K, D), dim=-1)
+    z = (centers[torch.randint(0, K, (N,))] + 0.05 * torch.randn(N, D)).to(dev)
+    q = NormEMAVectorQuantizer(K, D, 0.25, kmeans_init=True).to(dev).train()
+    assert float(q.embedding.initted) == 0.0 and float(q.embedding.weight.abs().sum()) == 0.0
+    with torch.no_grad():
+        zq, loss, idx = q(z[:, :, None, None])
+    assert float(q.embedding.initted) == 1.0
+    w = q.embedding.weight.data
+    assert torch.allclose(w.norm(dim=-1), torch.ones(K, device=dev), atol=1e-5)
+    assert float(q.embedding.cluster_size.sum()) == N           # bins of the last k-means iteration
+    assert float(loss) < 0.25 * 0.01                             # tight clusters: quantisation error far below a random codebook's
+    assert idx.min() >= 0 and idx.max() < K
+    # a second forward must not re-initialise
+    w_before = w.clone()
+    q.eval()
+    with torch.no_grad():
+        q(z[:, :, None, None])
+    assert torch.equal(q.embedding.weight.data, w_before)
