@@ -6,9 +6,11 @@ shared object is missing or an entry point fails, the caller gets an exception.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
-_SO = Path(__file__).resolve().parent / "csrc" / "libmedtok_vq.so"
+# MEDTOK_VQ_LIB: dev knob to A/B an alternative build of the same ABI (still a HIP library, never a fallback)
+_SO = Path(os.environ.get("MEDTOK_VQ_LIB") or Path(__file__).resolve().parent / "csrc" / "libmedtok_vq.so")
 _lib = None
 
 ABI_VERSION = 1

@@ -39,7 +39,14 @@ constexpr size_t F_LDS_BYTES = (size_t)F_RING * F_STAGEB;     // 128 KB -> 1 blo
 constexpr size_t F_SMEM_BYTES = F_LDS_BYTES + 256 * sizeof(float) + 512 * 32;   // + per-row shared thresholds + candidate parking (2 x 2 x 8 B per lane)
 constexpr int F_GLDS_PER_STAGE = 4;                           // LDS-DMA instructions each wave issues per stage
 constexpr int F_CAP = 96;                                     // candidate slots per (row, owner): ~25-30 used on random data
-constexpr int F_OWN_PER_SPLIT = 4;                            // 2 half-waves x 2 code-side waves
+#ifndef MEDTOK_FILTER_WM
+#define MEDTOK_FILTER_WM 2
+#endif
+constexpr int F_WM = MEDTOK_FILTER_WM;                        // code-side waves (2: wave tile 128 x 64; 1: wave tile 256 x 32)
+constexpr int F_WN = 8 / F_WM;                                // row-side waves
+constexpr int F_MT = 8 / F_WM;                                // 32-code MFMA tiles per wave
+constexpr int F_NT = 8 / F_WN;                                // 32-row MFMA tiles per wave
+constexpr int F_OWN_PER_SPLIT = 2 * F_WM;                     // candidate lists per row and split: 2 half-waves x code-side waves
 constexpr float F_PRESCALE = 256.0f;                          // 2^8 on both operands
 constexpr float F_UNSCALE = 1.0f / 65536.0f;
 constexpr float F_NORM_LIMIT = 4.0f;                          // |x|^2, |e|^2 above this -> exact path
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / F_WN, wn = wave % F_WN;
     const int li = lane & 31, lh = lane >> 5;
     const long row0 = (long)blockIdx.x * F_BN;
     const int split = blockIdx.y;
@@ -186,24 +193,26 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     };
 
     // ---- per-lane state: for each of the wave's two 32-row column tiles, the k smallest d~ so far
-    float tv[2][TOPK], lim[2], xn[2], win[2];
+    float tv[F_NT][TOPK], lim[F_NT], xn[F_NT], win[F_NT];
     // Candidates found during a code tile are parked in a lane-private LDS slot pair (value, code) and written out
     // once per tile: scattered global stores inside the value loop stall the wave, and registers are scarce here.
-    int np[2] = {0, 0}, cnt[2] = {0, 0};
+    int np[F_NT] = {}, cnt[F_NT] = {};
     float *thr_share = reinterpret_cast<float *>(fsm + F_LDS_BYTES);    // [F_BN] per-row min of the owners' thresholds
     uint2 *park = reinterpret_cast<uint2 *>(fsm + F_LDS_BYTES + 256 * sizeof(float)) + tid * 4;   // [nn][slot]
-    auto xrow_of = [&](int nn) -> long { return row0 + wn * 64 + nn * 32 + li; };
+    auto xrow_of = [&](int nn) -> long { return row0 + wn * (32 * F_NT) + nn * 32 + li; };
     const float en_max = en_max_ptr[0];
     const bool sane = en_max <= F_NORM_LIMIT;
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
+    for (int nn = 0; nn < F_NT; ++nn) {
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) tv[nn][j] = INFINITY;
         lim[nn] = -INFINITY;                 // nothing is appended before the warm-up pass has set a finite limit
         xn[nn] = xsq[min(xrow_of(nn), n - 1)];
         win[nn] = 2.0f * filter_eps(xn[nn], en_max, d);
     }
-    const bool live[2] = {xrow_of(0) < n, xrow_of(1) < n};     // padding rows never append (their limit stays -inf)
+    bool live[F_NT];                                         // padding rows never append (their limit stays -inf)
+#pragma unroll
+    for (int nn = 0; nn < F_NT; ++nn) live[nn] = xrow_of(nn) < n;
     const int owner = split * F_OWN_PER_SPLIT + wm * 2 + lh;
     auto put = [&](int nn, float u, int code) {       // append (d~, code) to this lane's candidate list (live rows only)
         if (cnt[nn] < F_CAP)
@@ -212,11 +221,11 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     };
     if (tid < F_BN) reinterpret_cast<unsigned *>(thr_share)[tid] = 0xFFFFFFFFu;     // order-preserving key of +inf is 0xFF800000; all-ones is above it
 
-    f32x16 acc[4][2];
+    f32x16 acc[F_MT][F_NT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < F_MT; ++m)
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
+        for (int nn = 0; nn < F_NT; ++nn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
 
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     int a_adr[2], b_adr[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int ia = wm * 128 + li, ib = wn * 64 + li;
+        const int ia = wm * (32 * F_MT) + li, ib = wn * (32 * F_NT) + li;
         a_adr[t] = ia * F_ROWB + (((2 * t + lh) ^ ((ia >> 2) & 3)) << 4);
         b_adr[t] = F_TILEB + ib * F_ROWB + (((2 * t + lh) ^ ((ib >> 2) & 3)) << 4);
     }
@@ -236,38 +245,38 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     //                 vmcnt (own part of stage s+1 landed) -> raw barrier (everyone's has; slot s-1 is free)
     //                 LDS-DMA stage s+3  | read frags(s+1, t0) | MFMA(s, t1)
     // __syncthreads() would drain vmcnt(0) here (an LDS-DMA is a pending LDS write), hence the raw barrier.
-    auto load_frags = [&](half8 (&fa)[4], half8 (&fb)[2], int slot, int t) {
+    auto load_frags = [&](half8 (&fa)[F_MT], half8 (&fb)[F_NT], int slot, int t) {
 #ifdef MEDTOK_FILTER_NOLDS        // dev experiment: operands stay whatever they were
         if (slot >= 0) return;
 #endif
         const char *pa = fsm + slot * F_STAGEB + a_adr[t];
         const char *pb = fsm + slot * F_STAGEB + b_adr[t];
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn) fb[nn] = *reinterpret_cast<const half8 *>(pb + nn * 32 * F_ROWB);
+        for (int nn = 0; nn < F_NT; ++nn) fb[nn] = *reinterpret_cast<const half8 *>(pb + nn * 32 * F_ROWB);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const half8 *>(pa + m * 32 * F_ROWB);
+        for (int m = 0; m < F_MT; ++m) fa[m] = *reinterpret_cast<const half8 *>(pa + m * 32 * F_ROWB);
     };
-    auto mfma_group = [&](const half8 (&fa)[4], const half8 (&fb)[2]) {
+    auto mfma_group = [&](const half8 (&fa)[F_MT], const half8 (&fb)[F_NT]) {
 #ifdef MEDTOK_FILTER_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
 #ifdef MEDTOK_FILTER_NOMFMA      // dev experiment: keep the operand reads alive, skip the matrix work
 #pragma unroll
-        for (int m = 0; m < 4; ++m) asm volatile("" ::"v"(fa[m]));
+        for (int m = 0; m < F_MT; ++m) asm volatile("" ::"v"(fa[m]));
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn) asm volatile("" ::"v"(fb[nn]));
+        for (int nn = 0; nn < F_NT; ++nn) asm volatile("" ::"v"(fb[nn]));
         return;
 #endif
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < F_MT; ++m)
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn)
+            for (int nn = 0; nn < F_NT; ++nn)
                 acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb[nn], acc[m][nn], 0, 0, 0);
 #ifdef MEDTOK_FILTER_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
     };
-    half8 fa0[4], fb0[2], fa1[4], fb1[2];
+    half8 fa0[F_MT], fb0[F_NT], fa1[F_MT], fb1[F_NT];
     constexpr int LGKM0 = 0xC07F;           // s_waitcnt lgkmcnt(0) only (vmcnt / expcnt fields at their maxima)
     stage(); stage(); stage();              // stages 0..2 (clamped when the block has fewer)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -279,9 +288,11 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         load_frags(fa1, fb1, s & (F_RING - 1), 1);
         mfma_group(fa0, fb0);
         // interleave: the 6 operand reads of the next k16-step ride between the first MFMAs
+        constexpr int NRD = F_MT + F_NT;     // operand reads per k16-step (8 MFMAs)
 #pragma unroll
         for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NRD - 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         // fa1/fb1 have landed (free: 8 MFMAs went by); own part of stage s+1 has landed; then everyone's has
         __builtin_amdgcn_s_waitcnt(LGKM0);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -296,16 +307,16 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         mfma_group(fa1, fb1);
         // after the barrier the matrix pipe restarts at once; DMA issue and operand reads ride between MFMAs
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+        for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NRD / 3, 0); }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #ifdef MEDTOK_FILTER_NOEPI      // dev experiment: main loop only (results are garbage)
         if (++kb == nkb) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < F_MT; ++m)
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn) {
+                for (int nn = 0; nn < F_NT; ++nn) {
                     asm volatile("" ::"v"(acc[m][nn]));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
@@ -318,13 +329,13 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
             // ---- epilogue.  Everything is kept relative to the lane's own |x|^2:  u = en - 2 s~ (one fmaf per
             // value, shared by nothing else), thresholds and limits in the same u scale; d~ = u + xn is formed only
             // for the few values that are stored.
-            const int cbase = code_lo + ct * F_BM + wm * 128 + 4 * lh;
+            const int cbase = code_lo + ct * F_BM + wm * (32 * F_MT) + 4 * lh;
             const bool warm = (ct == 0);
             if (!DUMP && warm) {
                 // First code tile: learn the thresholds from all 128 codes BEFORE appending anything, so the
                 // candidate lists do not fill up with the loose early threshold (appends only ever need T >= t~).
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < F_MT; ++m) {
                     float4 wen[4];          // vector loads, one wait per 16 values (a load per value drains the DMA ring each time)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) wen[g] = ld4(wsqp + cbase + 32 * m + 8 * g);
@@ -333,19 +344,19 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
                         const float4 e4 = wen[r >> 2];
                         const float en = (r & 3) == 0 ? e4.x : (r & 3) == 1 ? e4.y : (r & 3) == 2 ? e4.z : e4.w;
 #pragma unroll
-                        for (int nn = 0; nn < 2; ++nn) thr_insert<TOPK>(tv[nn], fmaf(acc[m][nn][r], -0x1p-15f, en));
+                        for (int nn = 0; nn < F_NT; ++nn) thr_insert<TOPK>(tv[nn], fmaf(acc[m][nn][r], -0x1p-15f, en));
                     }
                 }
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn) lim[nn] = live[nn] ? fminf(tv[nn][TOPK - 1] + win[nn], 3.0e38f) : -INFINITY;
+                for (int nn = 0; nn < F_NT; ++nn) lim[nn] = live[nn] ? fminf(tv[nn][TOPK - 1] + win[nn], 3.0e38f) : -INFINITY;
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < F_MT; ++m) {
                 float4 en4[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) en4[g] = ld4(wsqp + cbase + 32 * m + 8 * g);
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn) {
+                for (int nn = 0; nn < F_NT; ++nn) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float en = (r & 3) == 0 ? en4[r >> 2].x : (r & 3) == 1 ? en4[r >> 2].y : (r & 3) == 2 ? en4[r >> 2].z : en4[r >> 2].w;
@@ -369,7 +380,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
                 // per tile: flush, update the threshold, then share: the row's k-th best over all codes seen by ANY
                 // owner is <= every owner's own k-th best, so the minimum of the owners' values is a valid T.
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn) {
+                for (int nn = 0; nn < F_NT; ++nn) {
                     // write out the parked candidates (at most two store instructions per tile) and fold them into the
                     // k-smallest list; the warm-up pass already counted the first tile's values
 #pragma unroll
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
                     np[nn] = 0;
                     float t = tv[nn][TOPK - 1];
                     t = fminf(t, __shfl_xor(t, 32, 64));
-                    unsigned *sh = reinterpret_cast<unsigned *>(thr_share) + wn * 64 + nn * 32 + li;
+                    unsigned *sh = reinterpret_cast<unsigned *>(thr_share) + wn * (32 * F_NT) + nn * 32 + li;
                     if (lh == 0) {
                         // order-preserving float -> uint key so a plain integer atomicMin works for any sign
                         const unsigned b = __float_as_uint(t);
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail re-issues may still be in flight
     if (!DUMP) {
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn) {
+        for (int nn = 0; nn < F_NT; ++nn) {
             // rows outside the range the bound assumes are forced onto the exact path
             const bool ok = sane && xn[nn] <= F_NORM_LIMIT;
             if (live[nn]) cand_cnt[xrow_of(nn) * own_total + owner] = ok ? cnt[nn] : F_CAP + 1;
