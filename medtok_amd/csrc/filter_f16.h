@@ -352,15 +352,22 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
             }
 #pragma unroll
             for (int m = 0; m < F_MT; ++m) {
-                float4 en4[4];
+                f32x16 env;                  // |e|^2 of this lane's 16 codes of the tile, in accumulator-register order
 #pragma unroll
-                for (int g = 0; g < 4; ++g) en4[g] = ld4(wsqp + cbase + 32 * m + 8 * g);
+                for (int g = 0; g < 4; ++g) {
+                    const float4 e4 = ld4(wsqp + cbase + 32 * m + 8 * g);
+                    env[4 * g] = e4.x; env[4 * g + 1] = e4.y; env[4 * g + 2] = e4.z; env[4 * g + 3] = e4.w;
+                }
 #pragma unroll
                 for (int nn = 0; nn < F_NT; ++nn) {
+#ifdef MEDTOK_FILTER_EPI_ROLLED
+                    // rolled over the 16 values (uniform dynamic register index): 16x less epilogue code in the I-cache
+#pragma nounroll
+#else
 #pragma unroll
+#endif
                     for (int r = 0; r < 16; ++r) {
-                        const float en = (r & 3) == 0 ? en4[r >> 2].x : (r & 3) == 1 ? en4[r >> 2].y : (r & 3) == 2 ? en4[r >> 2].z : en4[r >> 2].w;
-                        const float u = fmaf(acc[m][nn][r], -0x1p-15f, en);      // padded codes carry en = +inf
+                        const float u = fmaf(acc[m][nn][r], -0x1p-15f, env[r]);      // padded codes carry en = +inf
                         if (DUMP) {
                             const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2);
                             if (code < code_hi && xrow_of(nn) < n) dump[xrow_of(nn) * k_codes + code] = acc[m][nn][r] * F_UNSCALE;
@@ -372,8 +379,9 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
                             if (np[nn] < 2) { park[nn * 2 + np[nn]] = make_uint2(__float_as_uint(u), (unsigned)code); ++np[nn]; }
                             else put(nn, u, code);
                         }
-                        acc[m][nn][r] = 0.f;
                     }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
                 }
             }
             if (!DUMP) {

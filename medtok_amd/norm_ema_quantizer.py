@@ -158,7 +158,7 @@ class NormEMAVectorQuantizer(nn.Module):
             self.all_reduce_fn(bins)
             ops.ema_cluster_size_(self.cluster_size, bins, self.decay)
         if self.training and self.embedding.update:
-            bins, embed_sum, stats = self._stats(zd, encoding_indices)
+            bins, embed_sum, stats = ops.ema_stats(zd, encoding_indices, k, fused=True)
             # one collective for both statistics (the reference issues two, :195,:203)
             self.all_reduce_fn(stats)
             ops.ema_apply_(E, self.cluster_size, bins, embed_sum, self.decay)
@@ -171,21 +171,3 @@ class NormEMAVectorQuantizer(nn.Module):
             z_q = zq_ste
         z_q = z_q.view(b, h, w, c).permute(0, 3, 1, 2)
         return z_q, loss, encoding_indices
-
-    def _stats(self, zd, idx):
-        """bins [K] and embed_sum [K, D] as views of ONE buffer [embed_sum | bins] so a single
-        all-reduce covers both (embed_sum first keeps it 16-byte aligned)."""
-        from . import _lib
-        n, d = zd.shape
-        k = self.num_tokens
-        stats = torch.empty(k * (d + 1), dtype=torch.float32, device=zd.device)
-        embed_sum = stats[: k * d].view(k, d)
-        bins = stats[k * d:]
-        lib = _lib.load()
-        ws = torch.empty(max(lib.medtok_ema_stats_workspace_bytes(n, k), 256), dtype=torch.uint8, device=zd.device)
-        with torch.cuda.device(zd.device):
-            _lib.check(lib.medtok_ema_stats_f32(zd.data_ptr(), idx.data_ptr(), n, d, k, bins.data_ptr(),
-                                                embed_sum.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                torch.cuda.current_stream(zd.device).cuda_stream),
-                       "medtok_ema_stats_f32")
-        return bins, embed_sum, stats

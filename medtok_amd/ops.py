@@ -170,20 +170,23 @@ def sum_scale(vals: torch.Tensor, scale: float) -> torch.Tensor:
     return out
 
 
-def ema_stats(zhat, idx, k_codes: int):
-    """(bins [K] fp32, embed_sum [K, D] fp32)."""
+def ema_stats(zhat, idx, k_codes: int, fused: bool = False):
+    """(bins [K] fp32, embed_sum [K, D] fp32).  With fused=True both are views of ONE buffer
+    [embed_sum | bins], returned as a third value, so a single all-reduce covers both statistics
+    (embed_sum first keeps it 16-byte aligned)."""
     zhat = _dev(zhat, "zhat")
     idx = _dev(idx, "idx", torch.int64)
     n, d = zhat.shape
     lib = _lib.load()
-    bins = torch.empty(k_codes, dtype=torch.float32, device=zhat.device)
-    es = torch.empty((k_codes, d), dtype=torch.float32, device=zhat.device)
+    stats = torch.empty(k_codes * (d + 1), dtype=torch.float32, device=zhat.device)
+    es = stats[: k_codes * d].view(k_codes, d)
+    bins = stats[k_codes * d:]
     ws = _ws(lib.medtok_ema_stats_workspace_bytes(n, k_codes), zhat)
     with torch.cuda.device(zhat.device):
         _lib.check(lib.medtok_ema_stats_f32(zhat.data_ptr(), idx.data_ptr(), n, d, k_codes, bins.data_ptr(),
                                             es.data_ptr(), ws.data_ptr(), ws.numel(), _stream(zhat)),
                    "medtok_ema_stats_f32")
-    return bins, es
+    return (bins, es, stats) if fused else (bins, es)
 
 
 def code_histogram(idx, k_codes: int) -> torch.Tensor:
