@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["cfg3", "cfg2"], default="cfg3")
+    ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg5"], default="cfg3",
+                    help="cfg3: full soft VQ (headline); cfg2: argmin+EMA train step, 100k rows, K=8192; cfg5: the same step on 600k rows "
+                         "TOTAL (split over the GPUs: strong scaling), K=16384, with the RCCL all-reduce of the EMA statistics")
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default 600000 for cfg3, 100000 for cfg2)")
     ap.add_argument("--path", type=int, default=ops.PATH_AUTO)
     ap.add_argument("--cpu-rows", type=int, default=None, help="row sample for the CPU baseline (0 disables)")
@@ -112,7 +114,9 @@ class Cfg2:
     name = "cfg2"
     D, K = 768, 8192
 
-    def __init__(self, rows, dev, seed, path):
+    def __init__(self, rows, dev, seed, path, k_codes=None):
+        if k_codes:
+            self.K = k_codes
         from medtok_amd.norm_ema_quantizer import NormEMAVectorQuantizer
         self.rows, self.dev = rows, dev
         g = torch.Generator(device=dev).manual_seed(seed)
@@ -120,7 +124,7 @@ class Cfg2:
         torch.manual_seed(1234)
         self.q = NormEMAVectorQuantizer(self.K, self.D, 0.25).to(dev).train()   # picks RCCL all-reduce when WORLD_SIZE > 1
         self.q.search_path = path
-        self.description = f"cfg2 NormEMA argmin + EMA codebook update (train): {rows} rows/GPU, D=768, K=8192, fp32"
+        self.description = f"{self.name} NormEMA argmin + EMA codebook update (train): {rows} rows/GPU, D=768, K={self.K}, fp32"
 
     def flops_per_code(self):
         return 2.0 * self.K * self.D
@@ -178,8 +182,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    rows = args.rows or (600000 if args.workload == "cfg3" else 100000)
-    wl = (Cfg3 if args.workload == "cfg3" else Cfg2)(rows, dev, seed=rank, path=args.path)
+    if args.workload == "cfg5":
+        # BASELINE config 5 (EMA variant): 600k rows in total, row-sharded over the GPUs, one all-reduce of [embed_sum | bins] per step
+        total_rows = args.rows or 600000
+        lo, hi = mdist.row_shard(total_rows, rank, world)
+        rows = hi - lo
+        wl = Cfg2(rows, dev, seed=rank, path=args.path, k_codes=16384)
+        wl.name = "cfg5"
+        wl.description = (f"cfg5 NormEMA argmin + EMA update (train): {total_rows} rows total row-sharded x{world} ({rows}/GPU), D=768, "
+                          f"K=16384, one all-reduce of [embed_sum | bins] = {16384 * 769 * 4 / 1e6:.1f} MB per step")
+    else:
+        rows = args.rows or (600000 if args.workload == "cfg3" else 100000)
+        wl = (Cfg3 if args.workload == "cfg3" else Cfg2)(rows, dev, seed=rank, path=args.path)
 
     for _ in range(args.warmup):
         wl.step()
@@ -225,7 +239,7 @@ def main():
     achieved = kp["flops"] / (kp["ms"] * 1e-3) / 1e12 if kp["ms"] > 0 else 0.0
 
     if rank == 0:
-        total_codes = float(rows) * world * args.steps
+        total_codes = (float(args.rows or 600000) if args.workload == "cfg5" else float(rows) * world) * args.steps
         value = total_codes / elapsed
         line = {
             "metric": "codes_per_sec_tokenized",
@@ -236,7 +250,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.workload == "cfg5" else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
