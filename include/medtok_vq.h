@@ -113,6 +113,42 @@ int medtok_soft_assign_f32(const float *xref, const float *what, const int64_t *
  * norm_ema_quantizer.py:212). */
 int medtok_sum_scale_f32(const float *vals, int64_t n, double scale, float *out, void *stream);
 
+/* ---- training half ------------------------------------------------------------------------------
+ * Sparse backward of the soft top-k assignment (the reference back-propagates through a dense
+ * N x K distance matrix built at vector_quantization_soft_one_new.py:120-125,157-182,203-214; only
+ * the k selected columns are non-zero).  With e_j = what[idx_j], zq = sum_j w_j e_j:
+ *   geff = g_zq + (*g_vq) * vq_scale * (zq - x)
+ *   gx   = dF.normalize^T[ d(dist)/d(xhat)^T . dsoftmax^T . (geff . e_j)  + g_xhat ] + g_out
+ *          - (*g_commit) * commit_scale * (zq - x)
+ *   g_code[row*topk + j, :] = gradient w.r.t. the NORMALISED code e_j
+ * g_zq / g_xhat / g_out are [n, d] or NULL (= zero); g_vq / g_commit are DEVICE scalars or NULL, so
+ * the upstream loss gradients never visit the host.  For the reference losses vq_scale = 2/(n d)
+ * and commit_scale = 2 beta/(n d).  gx or g_code may be NULL when not wanted.  Sum g_code per code
+ * id with medtok_ema_stats_f32 (row order, deterministic), then medtok_normalize_backward_f32
+ * takes the result to codebook.weight. */
+int medtok_soft_vq_backward_f32(const float *x, const float *xhat, const float *what,
+                                const int64_t *idx, const float *w, int64_t n, int d, int topk,
+                                const float *g_zq, const float *g_xhat, const float *g_out,
+                                const float *g_vq, const float *g_commit,
+                                float vq_scale, float commit_scale,
+                                float *gx, float *g_code, void *stream);
+
+/* Backward of F.normalize(v, p=2, dim=-1, eps=1e-12) (:148-151,196-200):
+ * out = (g - vhat (vhat . g)) / max(|v|, 1e-12), row-wise. */
+int medtok_normalize_backward_f32(const float *g, const float *vhat, const float *v,
+                                  int64_t n, int d, float *out, void *stream);
+
+/* info_nce_loss (loss.py:40-56): cross entropy of [positive | off-diagonal negatives] / T with
+ * label 0 over normalised q, k [b, d]  ==  CE(qhat khat^T / T, diagonal).  loss is a device
+ * scalar; prob [b, b] (softmax rows) and the workspace (qhat | khat | row losses) are what
+ * medtok_info_nce_backward_f32 needs to produce gq, gk [b, d] from the device scalar g_loss. */
+size_t medtok_info_nce_workspace_bytes(int64_t b, int d);
+int medtok_info_nce_forward_f32(const float *q, const float *k, int64_t b, int d, float temperature,
+                                float *loss, float *prob, void *ws, size_t ws_bytes, void *stream);
+int medtok_info_nce_backward_f32(const float *q, const float *k, const float *prob,
+                                 const float *g_loss, int64_t b, int d, float temperature,
+                                 float *gq, float *gk, const void *ws, size_t ws_bytes, void *stream);
+
 /* EMA statistics of norm_ema_quantizer.py:183,194,202 without the one-hot:
  * bins[c] = #rows with idx == c (exact), embed_sum[c][:] = sum of those rows of
  * zhat added in increasing row order (deterministic).  embed_sum is [K, D]

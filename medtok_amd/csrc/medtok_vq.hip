@@ -819,6 +819,70 @@ extern "C" int medtok_sum_scale_f32(const float *vals, int64_t n, double scale, 
     return check_launch("sum_scale");
 }
 
+// ================================================================= training half: sparse backward, normalize backward, InfoNCE
+#include "train_kernels.h"
+
+extern "C" int medtok_soft_vq_backward_f32(const float *x, const float *xhat, const float *what, const int64_t *idx, const float *w,
+                                           int64_t n, int d, int topk, const float *g_zq, const float *g_xhat, const float *g_out,
+                                           const float *g_vq, const float *g_commit, float vq_scale, float commit_scale,
+                                           float *gx, float *g_code, void *stream)
+{
+    if (n < 0 || d <= 0 || (d & 3)) return fail("soft_vq_backward: bad shape n=%ld d=%d", (long)n, d);
+    if (topk < 1 || topk > MEDTOK_MAX_TOPK) return fail("soft_vq_backward: topk=%d unsupported", topk);
+    if (!x || !xhat || !what || !idx || !w) return fail("soft_vq_backward: x, xhat, what, idx and w are required");
+    if (!gx && !g_code) return fail("soft_vq_backward: nothing to compute (gx and g_code are both NULL)");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL((soft_vq_backward_kernel<MEDTOK_MAX_TOPK>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, xhat, what, idx, w, (long)n, d, topk, g_zq, g_xhat, g_out, g_vq, g_commit, vq_scale, commit_scale, gx, g_code);
+    return check_launch("soft_vq_backward");
+}
+
+extern "C" int medtok_normalize_backward_f32(const float *g, const float *vhat, const float *v, int64_t n, int d, float *out, void *stream)
+{
+    if (n < 0 || d <= 0 || (d & 3)) return fail("normalize_backward: bad shape n=%ld d=%d", (long)n, d);
+    if (!g || !vhat || !v || !out) return fail("normalize_backward: NULL argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(normalize_backward_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, vhat, v, (long)n, d, out);
+    return check_launch("normalize_backward");
+}
+
+static size_t info_nce_lds_bytes(int64_t b, int d) { return ((size_t)b + (size_t)d + 4) * sizeof(float); }
+
+extern "C" size_t medtok_info_nce_workspace_bytes(int64_t b, int d)
+{
+    return (2 * (size_t)b * (size_t)d + (size_t)b) * sizeof(float);     // qhat | khat | row_loss
+}
+
+extern "C" int medtok_info_nce_forward_f32(const float *q, const float *k, int64_t b, int d, float temperature, float *loss, float *prob,
+                                           void *ws, size_t ws_bytes, void *stream)
+{
+    if (b <= 0 || d <= 0 || (d & 3)) return fail("info_nce: bad shape b=%ld d=%d", (long)b, d);
+    if (!(temperature > 0.f)) return fail("info_nce: temperature must be positive");
+    if (!q || !k || !loss || !prob || !ws) return fail("info_nce: NULL argument");
+    if (ws_bytes < medtok_info_nce_workspace_bytes(b, d)) return fail("info_nce: workspace too small");
+    if (info_nce_lds_bytes(b, d) > 64 * 1024) return fail("info_nce: b + d = %ld exceeds the 64 KB LDS row budget", (long)(b + d));
+    hipStream_t s = (hipStream_t)stream;
+    float *qhat = (float *)ws, *khat = qhat + b * d, *row_loss = khat + b * d;
+    hipLaunchKernelGGL(info_nce_prepare_kernel, dim3((unsigned)((2 * b + 3) / 4)), dim3(256), 0, s, q, k, (long)b, d, qhat, khat);
+    hipLaunchKernelGGL(info_nce_forward_kernel, dim3((unsigned)b), dim3(256), info_nce_lds_bytes(b, d), s, qhat, khat, (int)b, d,
+                       1.f / temperature, prob, row_loss);
+    hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(1024), 0, s, row_loss, (long)b, 1.0 / (double)b, loss);
+    return check_launch("info_nce_forward");
+}
+
+extern "C" int medtok_info_nce_backward_f32(const float *q, const float *k, const float *prob, const float *g_loss, int64_t b, int d,
+                                            float temperature, float *gq, float *gk, const void *ws, size_t ws_bytes, void *stream)
+{
+    if (b <= 0 || d <= 0 || (d & 3)) return fail("info_nce_backward: bad shape b=%ld d=%d", (long)b, d);
+    if (!q || !k || !prob || !g_loss || !gq || !gk || !ws) return fail("info_nce_backward: NULL argument");
+    if (ws_bytes < medtok_info_nce_workspace_bytes(b, d)) return fail("info_nce_backward: workspace too small");
+    if (info_nce_lds_bytes(b, d) > 64 * 1024) return fail("info_nce_backward: b + d = %ld exceeds the 64 KB LDS row budget", (long)(b + d));
+    const float *qhat = (const float *)ws, *khat = qhat + b * d;
+    hipLaunchKernelGGL(info_nce_backward_kernel, dim3((unsigned)(2 * b)), dim3(256), info_nce_lds_bytes(b, d), (hipStream_t)stream,
+                       q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk);
+    return check_launch("info_nce_backward");
+}
+
 // ================================================================= EMA statistics
 // bins: integer histogram.  embed_sum: rows are ordered by (code, row) with a stable LSD radix
 // sort (8-bit digits), then one wavefront per code adds its rows in increasing row order.

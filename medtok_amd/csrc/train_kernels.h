@@ -1,0 +1,264 @@
+// train_kernels.h -- gfx950 kernels of the training half of the VQ path: the sparse backward of the soft
+// top-k assignment, the backward of F.normalize, and InfoNCE (forward + backward) of loss.py.
+// Included by medtok_vq.hip after its helpers (ld4 / st4 / wave_butterfly_sum / fail / check_launch).
+//
+// All of these are HBM/L2-bound row kernels: one wavefront per row, lanes stride the D axis in float4,
+// wave reductions by xor butterfly.  Nothing here is GEMM-shaped enough to pay for MFMA at training
+// batch sizes (B = 256 rows/GPU, vector_quantization_soft_one_new.py callers in train_MedTok.py:196-238).
+#pragma once
+
+// ================================================================= soft top-k assignment: backward
+// Forward (vector_quantization_soft_one_new.py:157-182,203-214), per row:
+//   xhat = x / max(|x|, 1e-12);  d_j = |xhat|^2 + |e_j|^2 - 2 xhat.e_j  (e_j = what[idx_j]);
+//   w = softmax(-d);  zq = sum_j w_j e_j;
+//   vq = mean((zq - sg(x))^2);  commit = beta * mean((sg(zq) - x)^2);  out = x + sg(zq - x).
+// The reference differentiates a dense N x K distance matrix; only the k selected columns are non-zero.
+// Given upstream gradients  g_out (w.r.t. out), g_xhat, and the scalars g_vq / g_commit, this kernel forms
+//   geff   = g_zq + cv * (zq - x)                       cv = g_vq * 2 / (n d)
+//   gw_j   = geff . e_j ;   gd_j = -w_j (gw_j - sum_i w_i gw_i)          (softmax(-d) backward)
+//   gxh    = 2 (sum_j gd_j) xhat - 2 sum_j gd_j e_j + g_xhat
+//   gx     = (gxh - xhat (xhat . gxh)) / max(|x|, 1e-12) + g_out - cc * (zq - x)     cc = g_commit * 2 beta / (n d)
+//   g_code[row, j, :] = w_j geff + 2 gd_j (e_j - xhat)   (gradient w.r.t. the NORMALISED code e_j)
+// g_code rows are then segment-summed by code id in row order (medtok_ema_stats_f32) -- deterministic,
+// no atomics -- and pushed through normalize_backward_kernel to reach codebook.weight.
+template <int MAXK>
+__global__ __launch_bounds__(256) void soft_vq_backward_kernel(
+    const float *__restrict__ x, const float *__restrict__ xhat, const float *__restrict__ what,
+    const int64_t *__restrict__ idx, const float *__restrict__ w, long n, int d, int topk,
+    const float *__restrict__ g_zq, const float *__restrict__ g_xhat, const float *__restrict__ g_out,
+    const float *__restrict__ g_vq, const float *__restrict__ g_commit, float vq_scale, float commit_scale,
+    float *__restrict__ gx, float *__restrict__ g_code)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float cv = g_vq ? vq_scale * g_vq[0] : 0.f;
+    const float cc = g_commit ? commit_scale * g_commit[0] : 0.f;
+    float wj[MAXK], gw[MAXK], gd[MAXK];
+    const float *ej[MAXK];
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        wj[j] = 0.f; gw[j] = 0.f; gd[j] = 0.f; ej[j] = what;
+        if (j < topk) { wj[j] = w[row * topk + j]; ej[j] = what + idx[row * topk + j] * (long)d; }
+    }
+    const float *xr = x + row * d, *xh = xhat + row * d;
+    const float *gz = g_zq ? g_zq + row * d : nullptr;
+    const float *gh = g_xhat ? g_xhat + row * d : nullptr;
+    const float *go = g_out ? g_out + row * d : nullptr;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // zq, diff = zq - x and geff for one float4 column group (same fmaf order as soft_assign_kernel)
+    auto column = [&](int i, float4 e[MAXK], float4 &diff, float4 &geff) {
+        float4 a = zero4;
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j)
+            if (j < topk) {
+                e[j] = ld4(ej[j] + i);
+                a.x = fmaf(wj[j], e[j].x, a.x); a.y = fmaf(wj[j], e[j].y, a.y);
+                a.z = fmaf(wj[j], e[j].z, a.z); a.w = fmaf(wj[j], e[j].w, a.w);
+            }
+        const float4 xv = ld4(xr + i);
+        diff = make_float4(a.x - xv.x, a.y - xv.y, a.z - xv.z, a.w - xv.w);
+        const float4 g = gz ? ld4(gz + i) : zero4;
+        geff = make_float4(fmaf(cv, diff.x, g.x), fmaf(cv, diff.y, g.y), fmaf(cv, diff.z, g.z), fmaf(cv, diff.w, g.w));
+    };
+
+    // pass 1: gw_j = geff . e_j and |x|^2
+    float xx = 0.f;
+    for (int i = lane * 4; i < d; i += 256) {
+        float4 e[MAXK], diff, geff;
+        column(i, e, diff, geff);
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j)
+            if (j < topk) {
+                gw[j] = fmaf(geff.x, e[j].x, gw[j]); gw[j] = fmaf(geff.y, e[j].y, gw[j]);
+                gw[j] = fmaf(geff.z, e[j].z, gw[j]); gw[j] = fmaf(geff.w, e[j].w, gw[j]);
+            }
+        const float4 xv = ld4(xr + i);
+        xx = fmaf(xv.x, xv.x, xx); xx = fmaf(xv.y, xv.y, xx); xx = fmaf(xv.z, xv.z, xx); xx = fmaf(xv.w, xv.w, xx);
+    }
+    xx = wave_butterfly_sum(xx);
+    float sw = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j)
+        if (j < topk) { gw[j] = wave_butterfly_sum(gw[j]); sw = fmaf(wj[j], gw[j], sw); }
+    float sd = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j)
+        if (j < topk) { gd[j] = -wj[j] * (gw[j] - sw); sd += gd[j]; }
+
+    // gxh for one column group
+    auto gxh_of = [&](int i, const float4 e[MAXK]) {
+        const float4 h = ld4(xh + i);
+        float4 acc = zero4;
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j)
+            if (j < topk) {
+                acc.x = fmaf(gd[j], e[j].x, acc.x); acc.y = fmaf(gd[j], e[j].y, acc.y);
+                acc.z = fmaf(gd[j], e[j].z, acc.z); acc.w = fmaf(gd[j], e[j].w, acc.w);
+            }
+        const float4 g = gh ? ld4(gh + i) : zero4;
+        return make_float4(fmaf(2.f, sd * h.x - acc.x, g.x), fmaf(2.f, sd * h.y - acc.y, g.y),
+                           fmaf(2.f, sd * h.z - acc.z, g.z), fmaf(2.f, sd * h.w - acc.w, g.w));
+    };
+
+    // pass 2: per-slot code gradients, and xhat . gxh
+    float dp = 0.f;
+    for (int i = lane * 4; i < d; i += 256) {
+        float4 e[MAXK], diff, geff;
+        column(i, e, diff, geff);
+        const float4 h = ld4(xh + i);
+        if (g_code) {
+#pragma unroll
+            for (int j = 0; j < MAXK; ++j)
+                if (j < topk) {
+                    const float t = 2.f * gd[j];
+                    st4(g_code + (row * topk + j) * (long)d + i,
+                        make_float4(fmaf(wj[j], geff.x, t * (e[j].x - h.x)), fmaf(wj[j], geff.y, t * (e[j].y - h.y)),
+                                    fmaf(wj[j], geff.z, t * (e[j].z - h.z)), fmaf(wj[j], geff.w, t * (e[j].w - h.w))));
+                }
+        }
+        const float4 q = gxh_of(i, e);
+        dp = fmaf(h.x, q.x, dp); dp = fmaf(h.y, q.y, dp); dp = fmaf(h.z, q.z, dp); dp = fmaf(h.w, q.w, dp);
+    }
+    if (!gx) return;
+    dp = wave_butterfly_sum(dp);
+    const float inv = 1.f / fmaxf(sqrtf(xx), 1e-12f);
+
+    // pass 3: through F.normalize, plus the straight-through and commitment terms
+    for (int i = lane * 4; i < d; i += 256) {
+        float4 e[MAXK], diff, geff;
+        column(i, e, diff, geff);
+        const float4 h = ld4(xh + i);
+        const float4 q = gxh_of(i, e);
+        const float4 g = go ? ld4(go + i) : zero4;
+        st4(gx + row * d + i, make_float4(fmaf(q.x - h.x * dp, inv, g.x) - cc * diff.x, fmaf(q.y - h.y * dp, inv, g.y) - cc * diff.y,
+                                          fmaf(q.z - h.z * dp, inv, g.z) - cc * diff.z, fmaf(q.w - h.w * dp, inv, g.w) - cc * diff.w));
+    }
+}
+
+// Backward of F.normalize(v, dim=-1, eps=1e-12): out = (g - vhat (vhat . g)) / max(|v|, 1e-12).  One wave per row.
+__global__ __launch_bounds__(256) void normalize_backward_kernel(const float *__restrict__ g, const float *__restrict__ vhat,
+                                                                 const float *__restrict__ v, long n, int d, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *gr = g + row * d, *hr = vhat + row * d, *vr = v + row * d;
+    float dp = 0.f, vv = 0.f;
+    for (int i = lane * 4; i < d; i += 256) {
+        const float4 a = ld4(gr + i), h = ld4(hr + i), b = ld4(vr + i);
+        dp = fmaf(h.x, a.x, dp); dp = fmaf(h.y, a.y, dp); dp = fmaf(h.z, a.z, dp); dp = fmaf(h.w, a.w, dp);
+        vv = fmaf(b.x, b.x, vv); vv = fmaf(b.y, b.y, vv); vv = fmaf(b.z, b.z, vv); vv = fmaf(b.w, b.w, vv);
+    }
+    dp = wave_butterfly_sum(dp);
+    vv = wave_butterfly_sum(vv);
+    const float inv = 1.f / fmaxf(sqrtf(vv), 1e-12f);
+    for (int i = lane * 4; i < d; i += 256) {
+        const float4 a = ld4(gr + i), h = ld4(hr + i);
+        st4(out + row * d + i, make_float4((a.x - h.x * dp) * inv, (a.y - h.y * dp) * inv, (a.z - h.z * dp) * inv, (a.w - h.w * dp) * inv));
+    }
+}
+
+// ================================================================= InfoNCE (loss.py:40-56)
+// loss = CE([pos | off-diagonal negatives] / T, label 0) over normalised q, k  ==  CE(qhat khat^T / T, diagonal).
+// Forward: one block per query row i; its 4 waves walk the key rows; logits stay in LDS.
+//   row_loss[i] = logsumexp_j(l_ij) - l_ii,  prob[i, j] = softmax_j(l_ij)  (kept for the backward)
+// qhat / khat / the inverse norms are written once by info_nce_prepare_kernel.
+__global__ __launch_bounds__(256) void info_nce_prepare_kernel(const float *__restrict__ q, const float *__restrict__ k, long b, int d,
+                                                               float *__restrict__ qhat, float *__restrict__ khat)
+{
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= 2 * b) return;
+    const float *src = r < b ? q + r * d : k + (r - b) * d;
+    float *dst = r < b ? qhat + r * d : khat + (r - b) * d;
+    float p = 0.f;
+    for (int i = lane * 4; i < d; i += 256) {
+        const float4 a = ld4(src + i);
+        p = fmaf(a.x, a.x, p); p = fmaf(a.y, a.y, p); p = fmaf(a.z, a.z, p); p = fmaf(a.w, a.w, p);
+    }
+    const float nrm = fmaxf(sqrtf(wave_butterfly_sum(p)), 1e-12f);
+    for (int i = lane * 4; i < d; i += 256) {
+        const float4 a = ld4(src + i);
+        st4(dst + i, make_float4(a.x / nrm, a.y / nrm, a.z / nrm, a.w / nrm));
+    }
+}
+
+__device__ __forceinline__ float block256_reduce(float v, float *sh, bool is_max)
+{
+    // xor butterfly inside the wave, then the 4 wave results through LDS; every thread gets the result
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float o = __shfl_xor(v, off, 64);
+        v = is_max ? fmaxf(v, o) : v + o;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float a = sh[0], b2 = sh[1], c = sh[2], e = sh[3];
+    return is_max ? fmaxf(fmaxf(a, b2), fmaxf(c, e)) : (a + b2) + (c + e);
+}
+
+__global__ __launch_bounds__(256) void info_nce_forward_kernel(const float *__restrict__ qhat, const float *__restrict__ khat, int b, int d,
+                                                               float inv_temp, float *__restrict__ prob, float *__restrict__ row_loss)
+{
+    extern __shared__ float sm[];          // [d] query row, [b] logits, [4] reduction scratch
+    float *qs = sm, *lg = sm + d, *red = lg + b;
+    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x * 4; c < d; c += 1024) st4(qs + c, ld4(qhat + (long)i * d + c));
+    __syncthreads();
+    for (int j = wave; j < b; j += 4) {
+        const float *kr = khat + (long)j * d;
+        float p = 0.f;
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 a = ld4(kr + c), q4 = *reinterpret_cast<const float4 *>(qs + c);
+            p = fmaf(a.x, q4.x, p); p = fmaf(a.y, q4.y, p); p = fmaf(a.z, q4.z, p); p = fmaf(a.w, q4.w, p);
+        }
+        p = wave_butterfly_sum(p);
+        if (lane == 0) lg[j] = p * inv_temp;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < b; j += 256) m = fmaxf(m, lg[j]);
+    m = block256_reduce(m, red, true);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < b; j += 256) s += expf(lg[j] - m);
+    s = block256_reduce(s, red, false);
+    const float lse = m + logf(s);
+    for (int j = threadIdx.x; j < b; j += 256) prob[(long)i * b + j] = expf(lg[j] - lse);
+    if (threadIdx.x == 0) row_loss[i] = lse - lg[i];
+}
+
+// Backward: dl_ij = g (prob_ij - [i == j]) / b.  Blocks [0, b) produce g_q rows, blocks [b, 2b) g_k rows:
+//   g_qhat_i = (1/T) sum_j dl_ij khat_j,   g_khat_j = (1/T) sum_i dl_ij qhat_i,   then through F.normalize.
+__global__ __launch_bounds__(256) void info_nce_backward_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                                const float *__restrict__ qhat, const float *__restrict__ khat,
+                                                                const float *__restrict__ prob, const float *__restrict__ g_loss,
+                                                                int b, int d, float inv_temp, float *__restrict__ gq, float *__restrict__ gk)
+{
+    extern __shared__ float sm[];          // [b] coefficients, [d] gradient w.r.t. the normalised row, [4] scratch
+    float *cf = sm, *gh = sm + b, *red = gh + d;
+    const bool qside = (int)blockIdx.x < b;
+    const int r = qside ? blockIdx.x : blockIdx.x - b;
+    const float scale = g_loss[0] * inv_temp / (float)b;
+    for (int j = threadIdx.x; j < b; j += 256) {
+        const float p = qside ? prob[(long)r * b + j] : prob[(long)j * b + r];
+        cf[j] = scale * (p - (j == r ? 1.f : 0.f));
+    }
+    __syncthreads();
+    const float *other = qside ? khat : qhat;
+    const float *mine_hat = (qside ? qhat : khat) + (long)r * d, *mine = (qside ? q : k) + (long)r * d;
+    float dp = 0.f, vv = 0.f;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float a = 0.f;
+        for (int j = 0; j < b; ++j) a = fmaf(cf[j], other[(long)j * d + c], a);
+        gh[c] = a;
+        dp = fmaf(mine_hat[c], a, dp);
+        vv = fmaf(mine[c], mine[c], vv);
+    }
+    dp = block256_reduce(dp, red, false);
+    vv = block256_reduce(vv, red, false);
+    const float inv = 1.f / fmaxf(sqrtf(vv), 1e-12f);
+    float *out = (qside ? gq : gk) + (long)r * d;
+    for (int c = threadIdx.x; c < d; c += 256) out[c] = (gh[c] - mine_hat[c] * dp) * inv;
+}

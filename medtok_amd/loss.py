@@ -1,15 +1,39 @@
 """Cross-modal losses of MedTok (drop-in for the reference's MedTok/loss.py:40-110).
 
 Same function names, arguments and return structures (4-tuples of 0-dim fp32
-tensors, differentiable).  These are B x B / B x D problems at the per-GPU batch
-size (B = 256 in the reference's run.sh) -- microseconds of rocBLAS -- so they
-stay device-agnostic torch code; the GAN losses of loss.py:5-37 have no caller
-in the reference and are out of scope.
+tensors, differentiable).  InfoNCE -- four calls per training step -- runs on the
+library's gfx950 kernels (forward and backward); the alignment and orthogonality
+terms are one reduction / one D x D product each and stay torch code.  The GAN
+losses of loss.py:5-37 have no caller in the reference and are out of scope.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn.functional as F
+
+from . import ops
+
+
+class _InfoNCEFunction(torch.autograd.Function):
+    """InfoNCE on the gfx950 kernels (medtok_info_nce_forward_f32 / _backward_f32): normalise, B x B logits,
+    log-softmax against the diagonal and the mean in three launches; the backward is one launch and reads the
+    softmax rows the forward kept.  fp32 throughout (the reference's autocast also runs normalize and
+    cross_entropy in fp32; only its B x B matmul drops to bf16)."""
+
+    @staticmethod
+    def forward(ctx, q, k, temperature):
+        qf, kf = q.detach().float().contiguous(), k.detach().float().contiguous()
+        loss, prob, ws = ops.info_nce_forward(qf, kf, temperature)
+        ctx.save_for_backward(qf, kf, prob, ws)
+        ctx.temperature = temperature
+        ctx.in_dtypes = (q.dtype, k.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        qf, kf, prob, ws = ctx.saved_tensors
+        gq, gk = ops.info_nce_backward(qf, kf, prob, ws, g_loss.float().contiguous(), ctx.temperature)
+        return gq.to(ctx.in_dtypes[0]), gk.to(ctx.in_dtypes[1]), None
 
 
 def info_nce_loss(q, k, temperature=0.07):
@@ -17,13 +41,13 @@ def info_nce_loss(q, k, temperature=0.07):
 
     The reference concatenates [positive | off-diagonal negatives] and takes
     cross-entropy against column 0; that is the cross-entropy of the full
-    similarity matrix against its diagonal, evaluated here without the masked
-    copy and the concatenation."""
-    q = F.normalize(q.float(), dim=-1)
-    k = F.normalize(k.float(), dim=-1)
-    logits = q @ k.t() / temperature
-    target = torch.arange(q.size(0), device=q.device)
-    return F.cross_entropy(logits, target)
+    similarity matrix against its diagonal, which the HIP kernels evaluate
+    without the masked copy and the concatenation.  Device tensors only: like
+    the rest of the package there is no CPU path (MedTokLibraryError)."""
+    if q.shape[-1] % 4:                                  # kernels stride float4; zero columns change nothing
+        pad = 4 - q.shape[-1] % 4
+        q, k = F.pad(q, (0, pad)), F.pad(k, (0, pad))
+    return _InfoNCEFunction.apply(q, k, float(temperature))
 
 
 def alignment_loss(mu1, mu2):

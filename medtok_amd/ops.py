@@ -159,6 +159,71 @@ def soft_assign(xref, what, idx, dist, hard: bool = False, want_w: bool = True, 
     return w, zq, se
 
 
+def soft_vq_backward(x, xhat, what, idx, w, g_zq=None, g_xhat=None, g_out=None, g_vq=None, g_commit=None,
+                     vq_scale: float = 0.0, commit_scale: float = 0.0, want_gx: bool = True, want_g_code: bool = True):
+    """Sparse backward of the soft top-k assignment: (gx [n, d], g_code [n*k, d]).
+
+    g_zq / g_xhat / g_out: [n, d] upstream gradients w.r.t. the code mix, the normalised rows and the
+    straight-through output (None = zero); g_vq / g_commit: 0-dim DEVICE tensors, the upstream gradients of
+    mean((zq - x)^2) seen from zq and from x, scaled by vq_scale / commit_scale inside the kernel.
+    g_code[r*k + j] is the gradient w.r.t. the normalised code what[idx[r, j]]."""
+    x, xhat, what, w = _dev(x, "x"), _dev(xhat, "xhat"), _dev(what, "what"), _dev(w, "w")
+    idx = _dev(idx, "idx", torch.int64)
+    n, d = x.shape
+    topk = idx.shape[1]
+    opt = [None if t is None else _dev(t, nm) for t, nm in ((g_zq, "g_zq"), (g_xhat, "g_xhat"), (g_out, "g_out"),
+                                                            (g_vq, "g_vq"), (g_commit, "g_commit"))]
+    gx = torch.empty((n, d), dtype=torch.float32, device=x.device) if want_gx else None
+    g_code = torch.empty((n * topk, d), dtype=torch.float32, device=x.device) if want_g_code else None
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        _lib.check(lib.medtok_soft_vq_backward_f32(x.data_ptr(), xhat.data_ptr(), what.data_ptr(), idx.data_ptr(), w.data_ptr(),
+                                                   n, d, topk, *[_ptr(t) for t in opt], float(vq_scale), float(commit_scale),
+                                                   _ptr(gx), _ptr(g_code), _stream(x)), "medtok_soft_vq_backward_f32")
+    return gx, g_code
+
+
+def normalize_backward(g, vhat, v):
+    """Backward of F.normalize(v, dim=-1): (g - vhat (vhat . g)) / max(|v|, 1e-12), row-wise."""
+    g, vhat, v = _dev(g, "g"), _dev(vhat, "vhat"), _dev(v, "v")
+    n, d = v.shape
+    out = torch.empty_like(v)
+    lib = _lib.load()
+    with torch.cuda.device(v.device):
+        _lib.check(lib.medtok_normalize_backward_f32(g.data_ptr(), vhat.data_ptr(), v.data_ptr(), n, d, out.data_ptr(), _stream(v)),
+                   "medtok_normalize_backward_f32")
+    return out
+
+
+def info_nce_forward(q, k, temperature: float):
+    """(loss 0-dim, prob [b, b], ws): InfoNCE of loss.py:40-56; prob and ws feed info_nce_backward."""
+    q, k = _dev(q, "q"), _dev(k, "k")
+    b, d = q.shape
+    if k.shape != q.shape:
+        raise ValueError("info_nce: q and k must have the same shape")
+    lib = _lib.load()
+    loss = torch.empty((), dtype=torch.float32, device=q.device)
+    prob = torch.empty((b, b), dtype=torch.float32, device=q.device)
+    ws = _ws(lib.medtok_info_nce_workspace_bytes(b, d), q)
+    with torch.cuda.device(q.device):
+        _lib.check(lib.medtok_info_nce_forward_f32(q.data_ptr(), k.data_ptr(), b, d, float(temperature), loss.data_ptr(),
+                                                   prob.data_ptr(), ws.data_ptr(), ws.numel(), _stream(q)), "medtok_info_nce_forward_f32")
+    return loss, prob, ws
+
+
+def info_nce_backward(q, k, prob, ws, g_loss, temperature: float):
+    """(gq, gk) [b, d] from the forward's prob / ws and the upstream 0-dim device gradient."""
+    q, k, prob, g_loss = _dev(q, "q"), _dev(k, "k"), _dev(prob, "prob"), _dev(g_loss, "g_loss")
+    b, d = q.shape
+    gq, gk = torch.empty_like(q), torch.empty_like(k)
+    lib = _lib.load()
+    with torch.cuda.device(q.device):
+        _lib.check(lib.medtok_info_nce_backward_f32(q.data_ptr(), k.data_ptr(), prob.data_ptr(), g_loss.data_ptr(), b, d,
+                                                    float(temperature), gq.data_ptr(), gk.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                    _stream(q)), "medtok_info_nce_backward_f32")
+    return gq, gk
+
+
 def sum_scale(vals: torch.Tensor, scale: float) -> torch.Tensor:
     """0-dim fp32 tensor = scale * sum(vals) (fp64 accumulation, fixed order)."""
     vals = _dev(vals, "vals")

@@ -231,6 +231,16 @@ def fixture_losses(ls, name, B, D, seed):
     npz(name, **out)
 
 
+def fixture_info_nce(ls, name, B, D, seed, temperature=0.07, upstream=1.7):
+    """info_nce_loss (loss.py:40-56) alone, with its gradients for a non-unit upstream gradient."""
+    q = synth.det_randn(name + ".q", (B, D), 1.0, seed).requires_grad_(True)
+    k = synth.det_randn(name + ".k", (B, D), 1.0, seed).requires_grad_(True)
+    loss = ls.info_nce_loss(q, k, temperature)
+    (loss * upstream).backward()
+    npz(name, q=q.detach(), k=k.detach(), loss=loss.detach(), grad_q=q.grad, grad_k=k.grad,
+        temperature=temperature, upstream=upstream)
+
+
 def fixture_usage(sq, name, seed):
     q = make_soft(sq, 96, 16, seed=seed, tag=name)
     g = torch.Generator().manual_seed(seed)
@@ -262,6 +272,10 @@ def fixture_ties(sq, name):
 def main():
     torch.set_num_threads(8)
     sq, nq, ls = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "--info-nce-only":      # added after the first batch: the rest are unchanged
+        fixture_info_nce(ls, "f11_info_nce", B=24, D=48, seed=12)
+        fixture_info_nce(ls, "f11_info_nce_wide", B=40, D=256, seed=13, temperature=0.2, upstream=0.5)
+        return
     fixture_specific(sq, "f1_specific_d64", N=256, D=64, n_e=288, seed=1)
     fixture_specific(sq, "f2_specific_d768", N=64, D=768, n_e=384, seed=2)
     fixture_forward(sq, "f3_forward_d64", B=8, L=12, max_nodes=9, D=64, n_e=96, seed=3)
@@ -272,6 +286,8 @@ def main():
     fixture_losses(ls, "f7_losses", B=16, D=64, seed=8)
     fixture_ties(sq, "f8_ties")
     fixture_usage(sq, "f10_usage", seed=10)
+    fixture_info_nce(ls, "f11_info_nce", B=24, D=48, seed=12)
+    fixture_info_nce(ls, "f11_info_nce_wide", B=40, D=256, seed=13, temperature=0.2, upstream=0.5)
     # BASELINE config 1: 1k codes, 768-d, K=8192 -- inputs regenerated from the seeded recipe
     fixture_forward(sq, "cfg1_inference_1k", B=1000, L=8, max_nodes=6, D=768, n_e=8192, seed=11,
                     train_too=False, store_inputs=False)

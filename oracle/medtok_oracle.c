@@ -233,6 +233,125 @@ int oracle_soft_assign_f32(const float *xref, const float *what,
     return 0;
 }
 
+/* Backward of the soft assignment (what autograd does to the graph the reference builds at
+ * vector_quantization_soft_one_new.py:157-182,203-214, restricted to the k selected codes -- every
+ * other column of the N x K distance matrix receives an exactly-zero gradient).  Per row, with
+ * e_j = what[idx_j], zq = sum_j w_j e_j, cv = g_vq * vq_scale, cc = g_commit * commit_scale:
+ *   geff = g_zq + cv (zq - x);  gw_j = geff . e_j;  gd_j = -w_j (gw_j - sum_i w_i gw_i)
+ *   gxh  = 2 (sum_j gd_j) xhat - 2 sum_j gd_j e_j + g_xhat
+ *   gx   = (gxh - xhat (xhat . gxh)) / max(|x|, 1e-12) + g_out - cc (zq - x)
+ *   g_code[r*topk + j] = w_j geff + 2 gd_j (e_j - xhat)
+ * Reductions are accumulated in double: this is a tolerance checker (1e-5), not a bit oracle. */
+int oracle_soft_vq_backward_f32(const float *x, const float *xhat, const float *what, const int64_t *idx,
+                                const float *w, int64_t n, int d, int topk, const float *g_zq,
+                                const float *g_xhat, const float *g_out, float g_vq, float g_commit,
+                                float vq_scale, float commit_scale, float *gx, float *g_code)
+{
+    if (topk < 1 || topk > ORACLE_MAX_TOPK) return -1;
+    const double cv = (double)g_vq * vq_scale, cc = (double)g_commit * commit_scale;
+    double *geff = (double *)malloc(sizeof(double) * d), *diff = (double *)malloc(sizeof(double) * d);
+    double *gxh = (double *)malloc(sizeof(double) * d);
+    for (int64_t r = 0; r < n; ++r) {
+        const float *xr = x + r * d, *hr = xhat + r * d;
+        double gw[ORACLE_MAX_TOPK], gd[ORACLE_MAX_TOPK], xx = 0.0, sw = 0.0, sd = 0.0, dp = 0.0;
+        for (int i = 0; i < d; ++i) {
+            double zq = 0.0;
+            for (int j = 0; j < topk; ++j) zq += (double)w[r * topk + j] * what[idx[r * topk + j] * d + i];
+            diff[i] = zq - xr[i];
+            geff[i] = (g_zq ? g_zq[r * d + i] : 0.0) + cv * diff[i];
+            xx += (double)xr[i] * xr[i];
+        }
+        for (int j = 0; j < topk; ++j) {
+            const float *e = what + idx[r * topk + j] * d;
+            gw[j] = 0.0;
+            for (int i = 0; i < d; ++i) gw[j] += geff[i] * e[i];
+            sw += (double)w[r * topk + j] * gw[j];
+        }
+        for (int j = 0; j < topk; ++j) { gd[j] = -(double)w[r * topk + j] * (gw[j] - sw); sd += gd[j]; }
+        for (int i = 0; i < d; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < topk; ++j) acc += gd[j] * what[idx[r * topk + j] * d + i];
+            gxh[i] = 2.0 * (sd * hr[i] - acc) + (g_xhat ? g_xhat[r * d + i] : 0.0);
+            dp += (double)hr[i] * gxh[i];
+        }
+        double nrm = sqrt(xx);
+        if (nrm < 1e-12) nrm = 1e-12;
+        if (gx)
+            for (int i = 0; i < d; ++i)
+                gx[r * d + i] = (float)((gxh[i] - hr[i] * dp) / nrm + (g_out ? g_out[r * d + i] : 0.0) - cc * diff[i]);
+        if (g_code)
+            for (int j = 0; j < topk; ++j) {
+                const float *e = what + idx[r * topk + j] * d;
+                for (int i = 0; i < d; ++i)
+                    g_code[(r * topk + j) * d + i] = (float)((double)w[r * topk + j] * geff[i] + 2.0 * gd[j] * ((double)e[i] - hr[i]));
+            }
+    }
+    free(geff); free(diff); free(gxh);
+    return 0;
+}
+
+/* Backward of F.normalize(v, dim=-1, eps=1e-12): (g - vhat (vhat . g)) / max(|v|, 1e-12). */
+int oracle_normalize_backward_f32(const float *g, const float *vhat, const float *v, int64_t n, int d, float *out)
+{
+    for (int64_t r = 0; r < n; ++r) {
+        double dp = 0.0, vv = 0.0;
+        for (int i = 0; i < d; ++i) { dp += (double)vhat[r * d + i] * g[r * d + i]; vv += (double)v[r * d + i] * v[r * d + i]; }
+        double nrm = sqrt(vv);
+        if (nrm < 1e-12) nrm = 1e-12;
+        for (int i = 0; i < d; ++i) out[r * d + i] = (float)(((double)g[r * d + i] - vhat[r * d + i] * dp) / nrm);
+    }
+    return 0;
+}
+
+/* info_nce_loss (loss.py:40-56): normalise q and k, logits = [q.k_pos | q.k_neg (off-diagonal)] / T,
+ * cross entropy against column 0 -- restated literally (positive first, then the negatives in
+ * column order), plus its gradient w.r.t. q and k for upstream gradient g_loss. */
+int oracle_info_nce_f32(const float *q, const float *k, int64_t b, int d, float temperature, float g_loss,
+                        float *loss, float *gq, float *gk)
+{
+    double *qh = (double *)malloc(sizeof(double) * b * d), *kh = (double *)malloc(sizeof(double) * b * d);
+    double *qn = (double *)malloc(sizeof(double) * b), *kn = (double *)malloc(sizeof(double) * b);
+    double *gqh = (double *)calloc((size_t)b * d, sizeof(double)), *gkh = (double *)calloc((size_t)b * d, sizeof(double));
+    double *lg = (double *)malloc(sizeof(double) * b);
+    for (int64_t r = 0; r < b; ++r) {
+        double a = 0.0, c = 0.0;
+        for (int i = 0; i < d; ++i) { a += (double)q[r * d + i] * q[r * d + i]; c += (double)k[r * d + i] * k[r * d + i]; }
+        qn[r] = sqrt(a) < 1e-12 ? 1e-12 : sqrt(a);
+        kn[r] = sqrt(c) < 1e-12 ? 1e-12 : sqrt(c);
+        for (int i = 0; i < d; ++i) { qh[r * d + i] = q[r * d + i] / qn[r]; kh[r * d + i] = k[r * d + i] / kn[r]; }
+    }
+    double total = 0.0;
+    for (int64_t i = 0; i < b; ++i) {
+        /* column 0 = positive, then negatives j != i */
+        double m = -INFINITY;
+        for (int64_t j = 0; j < b; ++j) {
+            double s = 0.0;
+            for (int c = 0; c < d; ++c) s += qh[i * d + c] * kh[j * d + c];
+            lg[j] = s / temperature;
+            if (lg[j] > m) m = lg[j];
+        }
+        double se = exp(lg[i] - m);
+        for (int64_t j = 0; j < b; ++j) if (j != i) se += exp(lg[j] - m);
+        const double lse = m + log(se);
+        total += lse - lg[i];
+        for (int64_t j = 0; j < b; ++j) {
+            const double dl = (double)g_loss * (exp(lg[j] - lse) - (j == i ? 1.0 : 0.0)) / (double)b / temperature;
+            for (int c = 0; c < d; ++c) { gqh[i * d + c] += dl * kh[j * d + c]; gkh[j * d + c] += dl * qh[i * d + c]; }
+        }
+    }
+    if (loss) *loss = (float)(total / (double)b);
+    for (int64_t r = 0; r < b; ++r) {
+        double dq = 0.0, dk = 0.0;
+        for (int i = 0; i < d; ++i) { dq += qh[r * d + i] * gqh[r * d + i]; dk += kh[r * d + i] * gkh[r * d + i]; }
+        for (int i = 0; i < d; ++i) {
+            if (gq) gq[r * d + i] = (float)((gqh[r * d + i] - qh[r * d + i] * dq) / qn[r]);
+            if (gk) gk[r * d + i] = (float)((gkh[r * d + i] - kh[r * d + i] * dk) / kn[r]);
+        }
+    }
+    free(qh); free(kh); free(qn); free(kn); free(gqh); free(gkh); free(lg);
+    return 0;
+}
+
 /* EMA statistics (norm_ema_quantizer.py:194,202): bins[c] = #rows assigned to
  * c; embed_sum[c][:] = sum of those rows of zhat, added in increasing row
  * order (layout [K,D]; the reference's [D,K] is its transpose). */

@@ -119,6 +119,49 @@ def soft_assign(xref, what, idx, dist, hard=False, raw=False):
     return w, zq, se
 
 
+def _fopt(a):
+    if a is None:
+        return None, None
+    return _f(a)
+
+
+def soft_vq_backward(x, xhat, what, idx, w, g_zq=None, g_xhat=None, g_out=None, g_vq=0.0, g_commit=0.0,
+                     vq_scale=0.0, commit_scale=0.0):
+    """(gx [n,d], g_code [n*k,d]): the gradient autograd sends through the k selected columns of the graph
+    built at vector_quantization_soft_one_new.py:157-182,203-214 (tolerance checker, double accumulation)."""
+    x, xp = _f(x); xhat, hp = _f(xhat); what, wp = _f(what); idx, ip = _i(idx); w, wtp = _f(w)
+    g_zq, gzp = _fopt(g_zq); g_xhat, ghp = _fopt(g_xhat); g_out, gop = _fopt(g_out)
+    n, d = x.shape
+    topk = idx.shape[1]
+    gx = np.empty((n, d), np.float32)
+    gc = np.empty((n * topk, d), np.float32)
+    rc = lib().oracle_soft_vq_backward_f32(xp, hp, wp, ip, wtp, C.c_int64(n), d, topk, gzp, ghp, gop,
+                                           C.c_float(g_vq), C.c_float(g_commit), C.c_float(vq_scale), C.c_float(commit_scale),
+                                           gx.ctypes.data_as(_f32p), gc.ctypes.data_as(_f32p))
+    assert rc == 0
+    return gx, gc
+
+
+def normalize_backward(g, vhat, v):
+    g, gp = _f(g); vhat, hp = _f(vhat); v, vp = _f(v)
+    out = np.empty_like(v)
+    rc = lib().oracle_normalize_backward_f32(gp, hp, vp, C.c_int64(v.shape[0]), v.shape[1], out.ctypes.data_as(_f32p))
+    assert rc == 0
+    return out
+
+
+def info_nce(q, k, temperature=0.07, g_loss=1.0):
+    """(loss, gq, gk) of loss.py:40-56 and its gradient."""
+    q, qp = _f(q); k, kp = _f(k)
+    b, d = q.shape
+    loss = np.empty(1, np.float32)
+    gq, gk = np.empty_like(q), np.empty_like(k)
+    rc = lib().oracle_info_nce_f32(qp, kp, C.c_int64(b), d, C.c_float(temperature), C.c_float(g_loss),
+                                   loss.ctypes.data_as(_f32p), gq.ctypes.data_as(_f32p), gk.ctypes.data_as(_f32p))
+    assert rc == 0
+    return float(loss[0]), gq, gk
+
+
 def ema_stats(zhat, idx, k_codes):
     """bins and embed_sum ([K,D]) of norm_ema_quantizer.py:194,202."""
     zhat, zp = _f(zhat); idx, ip = _i(idx)

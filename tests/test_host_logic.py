@@ -45,36 +45,17 @@ def test_constructor_signatures_match_reference():
         "z", "text_features", "graph_node_features", "text_attention_mask", "batch", "z_aug"]
 
 
-def test_losses_match_reference_fixture(golden):
+def test_torch_side_losses_match_reference_fixture(golden):
+    """alignment / orthogonality terms (torch code) against the reference's values; InfoNCE is a HIP kernel and is
+    checked on the GPU (tests/test_gpu_train_kernels.py) -- on CPU tensors it must refuse loudly."""
     from medtok_amd import loss as L
+    from medtok_amd._lib import MedTokLibraryError
     g = golden("f7_losses")
-    t = {k: torch.from_numpy(g[k]).requires_grad_(True) for k in ("z1", "z2", "x1", "x2", "z1_aug", "z2_aug", "z1_c", "z2_c")}
-    s = L.shared_loss(t["z1_c"], t["z2_c"], t["x1"], t["x2"])
-    p = L.specific_loss(t["z1"], t["z1_aug"], t["z2"], t["z2_aug"], t["z1_c"], t["z2_c"])
-    assert rel(torch.stack(s), g["shared"]) <= 1e-5
-    assert rel(torch.stack(p), g["specific"]) <= 1e-5
-    total = torch.tensor(float(g["codebook_loss"])) + (s[0] - 0.1 * s[1]) + (s[2] - 0.1 * s[3]) + (p[0] + 0.1 * p[1]) + (p[2] + 0.1 * p[3])
-    assert abs(float(total) - float(g["total"])) <= 1e-5 * abs(float(g["total"]))
-    total.backward()
-    for k, v in t.items():
-        assert rel(v.grad, g[f"grad.{k}"]) <= 2e-5, k
-    assert abs(float(L.info_nce_loss(t["z1"], t["z2"])) - float(g["nce_z1_z2"])) <= 1e-5 * float(g["nce_z1_z2"])
+    t = {k: torch.from_numpy(g[k]) for k in ("z1", "z2", "x1", "x2", "z1_c")}
     assert abs(float(L.alignment_loss(t["x1"], t["x2"])) - float(g["align"])) <= 1e-5 * abs(float(g["align"]))
     assert abs(float(L.orthogonal_loss(t["z1"], t["z1_c"])) - float(g["orth"])) <= 1e-5 * float(g["orth"])
-
-
-def test_total_loss_assembly(golden):
-    from medtok_amd import loss as L
-    g = golden("f7_losses")
-    t = {k: torch.from_numpy(g[k]) for k in ("z1", "z2", "x1", "x2", "z1_aug", "z2_aug", "z1_c", "z2_c")}
-    c = torch.tensor(float(g["codebook_loss"]) / 6)
-    r = {"shared_embed_loss": (c, c), "text_specific_loss": (c, c), "graph_specific_loss": (c, c),
-         "shared_text_embedding": t["z1_c"], "shared_graph_embedding": t["z2_c"], "text_feature": t["x1"], "graph_feature": t["x2"],
-         "specific_embedding_text": t["z1"], "specific_embedding_text_aug": t["z1_aug"],
-         "specific_embedding_graph": t["z2"], "specific_embedding_graph_aug": t["z2_aug"]}
-    loss, parts = L.total_loss(r)
-    assert abs(float(loss) - float(g["total"])) <= 1e-5 * abs(float(g["total"]))
-    assert set(parts) >= {"codebook_loss", "shared_loss", "specific_loss"}
+    with pytest.raises(MedTokLibraryError):
+        L.info_nce_loss(t["z1"], t["z2"])
 
 
 @pytest.mark.parametrize("name", ["f3_forward_d64", "f4_forward_d128"])
@@ -97,6 +78,12 @@ def test_batched_cross_attention_equals_reference_loop(golden, name):
         pt2, pg2 = v.cross_attn.pooled(torch.from_numpy(g["text"]), torch.from_numpy(g["mask"]),
                                        torch.from_numpy(g["nodes"])[perm], torch.from_numpy(g["batch"])[perm])
     assert rel(pt2, g["pooled_text"]) <= 1e-5 and rel(pg2, g["pooled_graph"]) <= 1e-5
+    # both forms of the graph side (projected keys / projections folded into the queries) are the same function
+    for fold in (False, True):
+        with torch.no_grad():
+            pt3, pg3 = v.cross_attn.pooled(torch.from_numpy(g["text"]), torch.from_numpy(g["mask"]),
+                                           torch.from_numpy(g["nodes"]), torch.from_numpy(g["batch"]), fold=fold)
+        assert rel(pt3, g["pooled_text"]) <= 1e-5 and rel(pg3, g["pooled_graph"]) <= 1e-5, fold
 
 
 def test_regions_match_reference_slicing():

@@ -131,3 +131,40 @@ def test_torch_port_norm_ema(golden, name):
         assert np.array_equal(idx.numpy(), g[f"s{s}.idx"])
         assert rel(E.numpy(), g[f"s{s}.E"]) <= RTOL and rel(cs.numpy(), g[f"s{s}.cluster_size"]) <= RTOL
         assert abs(float(loss) - g[f"s{s}.loss"]) <= RTOL * g[f"s{s}.loss"]
+
+
+@pytest.mark.parametrize("name", ["f1_specific_d64", "f2_specific_d768"])
+def test_soft_backward_matches_reference_gradients(oracle, golden, name):
+    """oracle.soft_vq_backward + segment sum + normalize_backward == the gradients the reference's autograd
+    produced for loss = vq + commit + (zq_ste * probe).sum() / N (oracle/gen_golden.py::fixture_specific)."""
+    g = golden(name)
+    n_e, D, k, seed, beta = int(g["n_e"]), int(g["e_dim"]), int(g["k"]), int(g["seed"]), float(g["beta"])
+    W = synth.det_randn(f"{name}.codebook.weight", (n_e, D), 1.0, seed).numpy()
+    region = n_e // 3
+    N = g["x"].shape[0]
+    probe = synth.det_randn(name + ".probe", (N, D), 1.0, seed).numpy()
+    for t, lo in (("text", 0), ("graph", n_e - region)):
+        Wr = W[lo:lo + region]
+        Wp = synth.det_randn(f"{name}.proj_{t}.weight", (D, D), 1.0 / D ** 0.5, seed).numpy()
+        xp = g[f"{t}.x_proj"]
+        xhat, _ = oracle.rownorm(xp)
+        what, _ = oracle.rownorm(Wr)
+        gx, gc = oracle.soft_vq_backward(xp, xhat, what, g[f"{t}.idx"], g[f"{t}.w"], g_out=probe / N, g_vq=1.0, g_commit=1.0,
+                                         vq_scale=2.0 / (N * D), commit_scale=2.0 * beta / (N * D))
+        assert rel(gx.astype(np.float64).sum(0), g[f"{t}.train.grad_proj_b"]) <= 1e-4
+        assert rel(gx.astype(np.float64) @ Wp.astype(np.float64), g[f"{t}.train.grad_x"]) <= 1e-4
+        _, g_what = oracle.ema_stats(gc, g[f"{t}.idx"].reshape(-1), region)
+        gW = oracle.normalize_backward(g_what, what, Wr)
+        ref = g[f"{t}.train.grad_codebook"]
+        assert rel(gW, ref[lo:lo + region]) <= 1e-4
+        outside = np.ones(n_e, bool); outside[lo:lo + region] = False
+        assert not ref[outside].any()            # codes outside the searched region get no gradient
+
+
+@pytest.mark.parametrize("name", ["f11_info_nce", "f11_info_nce_wide"])
+def test_info_nce_matches_reference(oracle, golden, name):
+    g = golden(name)
+    loss, gq, gk = oracle.info_nce(g["q"], g["k"], float(g["temperature"]), float(g["upstream"]))
+    assert abs(loss - float(g["loss"])) <= RTOL * abs(float(g["loss"]))
+    assert rel(gq, g["grad_q"]) <= 2e-5
+    assert rel(gk, g["grad_k"]) <= 2e-5
