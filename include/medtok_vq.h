@@ -149,6 +149,21 @@ int medtok_info_nce_backward_f32(const float *q, const float *k, const float *pr
                                  const float *g_loss, int64_t b, int d, float temperature,
                                  float *gq, float *gk, const void *ws, size_t ws_bytes, void *stream);
 
+/* Cross-attention core of get_shared_info (vector_quantization_soft_one_new.py:17-88,133-142) for ragged
+ * batches.  With nn.MultiheadAttention's key/value projections folded into the queries on the host
+ * (q_h.(Wk_h t + bk_h) = (Wk_h^T q_h).t + const;  sum_j p_j (Wv_h t_j + bv_h) = Wv_h (sum_j p_j t_j) + bv_h)
+ * what remains per medical code b is
+ *     out[r, :] = softmax_j( scale * <q[r, :], kv[j, :]> ) . kv
+ * over the code's own query rows [q_start[b], +q_len[b]) of q and key rows [kv_start[b], +kv_len[b]) of kv
+ * (raw rows of the other modality; every head is just another query row).  Nothing is padded and the
+ * rows x keys matrix never reaches memory.  max_q_len >= max_b q_len[b] sizes the grid (rows beyond a
+ * code's q_len cost nothing); d % 128 == 0, d <= 768.  A code with kv_len == 0 yields NaN rows, as
+ * softmax over an empty set does in the reference.  q_start/q_len/kv_start/kv_len are DEVICE int64[n_codes]. */
+int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const int64_t *q_len,
+                                   const float *kv, const int64_t *kv_start, const int64_t *kv_len,
+                                   int64_t n_codes, int64_t max_q_len, int d, float scale,
+                                   float *out, void *stream);
+
 /* EMA statistics of norm_ema_quantizer.py:183,194,202 without the one-hot:
  * bins[c] = #rows with idx == c (exact), embed_sum[c][:] = sum of those rows of
  * zhat added in increasing row order (deterministic).  embed_sum is [K, D]

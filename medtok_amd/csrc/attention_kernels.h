@@ -1,0 +1,207 @@
+// attention_kernels.h -- variable-length "shared key/value" attention core for get_shared_info's cross-attention
+// (vector_quantization_soft_one_new.py:17-88,133-142).  Included by medtok_vq.hip; gfx950 only.
+//
+// The host folds nn.MultiheadAttention's key/value projections into the query side (see
+// CrossAttention._folded_layer), which leaves, per medical code b,
+//     out[r, :] = softmax_j( scale * <q[r, :], kv[j, :]> ) . kv            r in the code's query rows, j in its key rows
+// with the RAW rows of the other modality as both keys and values, shared by all heads (a head is just another
+// query row).  Rows are ragged: code b owns q rows [q_start[b], +q_len[b]) and kv rows [kv_start[b], +kv_len[b]);
+// nothing is padded, nothing of size rows x keys reaches memory.
+//
+// Block = (32 query rows of one code) x all of its keys, W = 8 waves (D % 256 == 0) or 4 waves, one block per CU.  Both products run on the exact
+// fp32 matrix pipe (v_mfma_f32_32x32x2_f32, 157 TF peak) -- fp16/bf16 inputs would break the 1e-5 parity bar:
+//   keys   : a chunk of 32 key rows is fetched with fully coalesced 16-byte loads (a thread's MFMA operands would be
+//            16 B out of every 128-byte line, re-fetching each line four times through a thrashing L1) and parked in
+//            LDS (row stride D + 4 floats: conflict-free for both operand shapes below) where both products read it.
+//            The next chunk's fetch is issued before the softmax step and stays in flight under the second product
+//            (barriers inside the loop are LDS-only: s_waitcnt lgkmcnt(0) + s_barrier, never a vmcnt drain);
+//   scores : each wave owns D / W columns, keeps its slice of the 32 query rows in registers for the block's lifetime
+//            and accumulates a partial 32 x 32 score tile per chunk; the W partials meet in LDS;
+//   softmax: online (running max / sum per row), 8 threads per row, exact expf;
+//   output : each wave owns D / W output columns = NT tiles of 32, accumulators rescaled per chunk by exp(m_old - m_new).
+#pragma once
+
+// Eight waves keep the per-lane state (query slice + output tiles + key fetch = 12 NT registers each) inside the 256
+// architectural VGPRs; with four waves at D = 768 hipcc parks the query slice in AGPRs and serialises the fetch.
+template <int W, int NT>      // waves per block, output column tiles per wave; D = 32 * W * NT
+__global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
+    const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
+    const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
+    float scale, float *__restrict__ out)
+{
+    constexpr int D = 32 * W * NT, LD = D + 4;     // LDS row stride in floats
+    constexpr int THREADS = 64 * W;
+    constexpr int EPT = 1024 / THREADS;            // score elements per thread in the softmax step (4 or 2)
+    constexpr int TPR = 32 / EPT;                  // threads per score row (8 or 16)
+    extern __shared__ __attribute__((aligned(16))) float att_sm[];
+    float *kvs = att_sm;                                                              // [32][LD] current key chunk
+    float (*part)[32][33] = reinterpret_cast<float (*)[32][33]>(kvs + 32 * LD);       // [W][32][33] per-wave partial scores [row][key]
+    float (*pt)[33] = reinterpret_cast<float (*)[33]>(kvs + 32 * LD + W * 32 * 33);   // [32][33] probabilities, transposed [key][row]
+    float *alpha_s = kvs + 32 * LD + (W + 1) * 32 * 33, *l_s = alpha_s + 32;
+    const int b = blockIdx.y, qt = blockIdx.x;
+    const int ql = (int)q_len[b];
+    if (qt * 32 >= ql) return;
+    const long qs = q_start[b], ks = kv_start[b];
+    const int kl = (int)kv_len[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int slice = wave * 32 * NT;      // this wave's D columns [slice, slice + 32 NT)
+
+    // key chunk fetch: thread t owns float4 column (t % 32) + 32 ci of rows (t / 32) + 2W ri -- 32 consecutive threads read
+    // 512 contiguous bytes, and every LDS / global offset below is a compile-time constant off one per-thread base;
+    // rows past the code's last key are clamped (their probabilities are zero)
+    constexpr int RI = 16 / W, CI = D / 128, NF = RI * CI;      // NF = 4 NT float4 per thread per chunk
+    const int f_r0 = tid >> 5, f_c = (tid & 31) * 4;
+    float4 kf[NF];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri) {
+            const float *src = kv + (ks + min(k0 + f_r0 + 2 * W * ri, kl - 1)) * (long)D + f_c;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) kf[ri * CI + ci] = ld4(src + 128 * ci);
+        }
+    };
+    auto park = [&]() {
+        float *dst = kvs + f_r0 * LD + f_c;
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) *reinterpret_cast<float4 *>(dst + 2 * W * ri * LD + 128 * ci) = kf[ri * CI + ci];
+    };
+    // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the key fetch that is meant to stay in
+    // flight under the second product
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    if (kl > 0) fetch(0);
+
+    // query slice of row (qt*32 + li): element 8g + 4 lh + j feeds MFMA step 4g + j (k index lh); keys use the same map
+    float4 qf[4 * NT];
+    {
+        const float *qrow = q + (qs + min(qt * 32 + li, ql - 1)) * (long)D + slice + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4 * NT; ++g) qf[g] = ld4(qrow + 8 * g);
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float m_run = -INFINITY, l_run = 0.f;          // online-softmax state of row tid / TPR, replicated in its TPR threads
+    for (int k0 = 0; k0 < kl; k0 += 32) {
+        park();                                    // this chunk: registers -> LDS (the previous chunk's readers are past the loop-end barrier)
+        lds_barrier();
+
+        // ---- partial scores over this wave's D / W columns
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        {
+            // operands four groups (16 MFMAs ~ 1000 cycles of pipe) ahead of their use; the empty asm keeps hipcc from
+            // hoisting every ds_read of the fully unrolled loop to the top
+            const float *krow = kvs + li * LD + slice + 4 * lh;
+            float4 cur[4], nxt[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[j] = *reinterpret_cast<const float4 *>(krow + 8 * j);
+#pragma unroll
+            for (int gb = 0; gb < NT; ++gb) {
+                if (gb + 1 < NT) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nxt[j] = *reinterpret_cast<const float4 *>(krow + 8 * (4 * (gb + 1) + j));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int g = 4 * gb + j;
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g].x, cur[j].x, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g].y, cur[j].y, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g].z, cur[j].z, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g].w, cur[j].w, s, 0, 0, 0);
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
+        lds_barrier();
+        if (k0 + 32 < kl) fetch(k0 + 32);          // next chunk: in flight under the softmax step and the second product
+
+        // ---- join the W partials, online softmax: thread -> row tid / TPR, keys EPT (tid % TPR) .. + EPT - 1
+        {
+            const int row = tid / TPR, kq = (tid % TPR) * EPT;
+            float v[EPT], mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                float sc = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < W; ++w2) sc += part[w2][row][kq + j];
+                sc *= scale;
+                v[j] = (k0 + kq + j < kl) ? sc : -INFINITY;
+                mx = fmaxf(mx, v[j]);
+            }
+#pragma unroll
+            for (int off = 1; off < TPR; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            const float m_new = fmaxf(m_run, mx);           // finite: every chunk holds at least one valid key
+            float ps = 0.f;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const float p = expf(v[j] - m_new);         // exp(-inf) = 0 for masked keys
+                pt[kq + j][row] = p;
+                ps += p;
+            }
+#pragma unroll
+            for (int off = 1; off < TPR; off <<= 1) ps += __shfl_xor(ps, off, 64);
+            const float a = expf(m_run - m_new);            // 0 on the first chunk (m_run = -inf)
+            l_run = fmaf(l_run, a, ps);
+            m_run = m_new;
+            if (tid % TPR == 0) alpha_s[row] = a;
+        }
+        lds_barrier();
+
+        // ---- out = alpha * out + P . KV  on this wave's NT column tiles
+        {
+            float a16[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a16[r] = alpha_s[(r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] *= a16[r];
+            const float *kcol = kvs + lh * LD + slice + li;
+            float pc, pn = 0.f, kc[NT], kn[NT];
+            pc = pt[lh][li];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { kc[t] = kcol[32 * t]; kn[t] = 0.f; }
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                if (s2 + 1 < 16) {
+                    pn = pt[2 * (s2 + 1) + lh][li];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) kn[t] = kcol[2 * (s2 + 1) * LD + 32 * t];
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pc, kc[t], acc[t], 0, 0, 0);
+                asm volatile("" ::: "memory");
+                pc = pn;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) kc[t] = kn[t];
+            }
+        }
+        lds_barrier();                             // all reads of this chunk's keys / probabilities are done
+    }
+    if (tid % TPR == 0) l_s[tid / TPR] = l_run;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (qt * 32 + row < ql) {
+            const float inv = 1.f / l_s[row];
+            float *o = out + (qs + qt * 32 + row) * (long)D + slice + li;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o[32 * t] = acc[t][r] * inv;
+        }
+    }
+}

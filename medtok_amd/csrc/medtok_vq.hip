@@ -883,6 +883,41 @@ extern "C" int medtok_info_nce_backward_f32(const float *q, const float *k, cons
     return check_launch("info_nce_backward");
 }
 
+// ================================================================= cross-attention core (ragged, shared key/value rows)
+#include "attention_kernels.h"
+
+extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
+                                              const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
+                                              int d, float scale, float *out, void *stream)
+{
+    if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
+    if (d <= 0 || d % 128 || d > 768) return fail("shared_kv_attention: d=%d must be a multiple of 128, at most 768", d);
+    if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out) return fail("shared_kv_attention: NULL argument");
+    if (n_codes == 0 || max_q_len == 0) return 0;
+    if (n_codes > 65535) return fail("shared_kv_attention: at most 65535 codes per call (got %ld)", (long)n_codes);
+    const dim3 grid((unsigned)((max_q_len + 31) / 32), (unsigned)n_codes);
+    hipStream_t s = (hipStream_t)stream;
+    const int waves = d % 256 == 0 ? 8 : 4;
+    const size_t lds = ((size_t)32 * (d + 4) + (waves + 1) * 32 * 33 + 64) * sizeof(float);   // key chunk + per-wave partial scores + probabilities + row state
+#define MEDTOK_ATT(W, NT)                                                                                                        \
+    do {                                                                                                                         \
+        if (lds > 64 * 1024 &&                                                                                                   \
+            hipFuncSetAttribute((const void *)shared_kv_attention_kernel<W, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return fail("shared_kv_attention: cannot reserve %zu bytes of LDS", lds);                                            \
+        hipLaunchKernelGGL((shared_kv_attention_kernel<W, NT>), grid, dim3(64 * W), lds, s, q, q_start, q_len, kv, kv_start, kv_len, scale, out); \
+    } while (0)
+    switch (d / 128) {
+    case 1: MEDTOK_ATT(4, 1); break;
+    case 2: MEDTOK_ATT(8, 1); break;
+    case 3: MEDTOK_ATT(4, 3); break;
+    case 4: MEDTOK_ATT(8, 2); break;
+    case 5: MEDTOK_ATT(4, 5); break;
+    default: MEDTOK_ATT(8, 3); break;
+    }
+#undef MEDTOK_ATT
+    return check_launch("shared_kv_attention");
+}
+
 // ================================================================= EMA statistics
 // bins: integer histogram.  embed_sum: rows are ordered by (code, row) with a stable LSD radix
 // sort (8-bit digits), then one wavefront per code adds its rows in increasing row order.

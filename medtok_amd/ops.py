@@ -224,6 +224,21 @@ def info_nce_backward(q, k, prob, ws, g_loss, temperature: float):
     return gq, gk
 
 
+def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, scale: float):
+    """out[r] = softmax_j(scale * <q[r], kv[j]>) . kv over each code's own (ragged) query and key rows.
+    q [Rq, d], kv [Rk, d] fp32; *_start / *_len int64 [n_codes] on the device; d % 128 == 0."""
+    q, kv = _dev(q, "q"), _dev(kv, "kv")
+    qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
+    ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
+    out = torch.empty_like(q)
+    lib = _lib.load()
+    with torch.cuda.device(q.device):
+        _lib.check(lib.medtok_shared_kv_attention_f32(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(),
+                                                      kl.data_ptr(), qs.numel(), int(max_q_len), q.shape[1], float(scale),
+                                                      out.data_ptr(), _stream(q)), "medtok_shared_kv_attention_f32")
+    return out
+
+
 def sum_scale(vals: torch.Tensor, scale: float) -> torch.Tensor:
     """0-dim fp32 tensor = scale * sum(vals) (fp64 accumulation, fixed order)."""
     vals = _dev(vals, "vals")

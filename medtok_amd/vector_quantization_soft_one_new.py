@@ -9,9 +9,12 @@ reference checkpoint loads with strict=True.
 What runs where
   - normalise / distance / top-k / softmax / code mix / straight-through /
     squared error / usage window: gfx950 kernels through medtok_amd.ops;
-  - the two nn.Linear projections and the cross-attention layers: stock torch
-    modules on the device (rocBLAS), evaluated batched instead of the
-    reference's per-sample Python loop (:133-142);
+  - cross-attention (:17-88,133-142): batched over the codes instead of the
+    reference's per-sample Python loop, with the key/value projections folded
+    into the queries; at inference the ragged attention core is a gfx950 kernel
+    (ops.shared_kv_attention), the small per-row projections stay nn.Linear /
+    einsum on rocBLAS; training keeps the padded torch form for autograd;
+  - the two nn.Linear projections proj_text / proj_graph: stock torch modules;
   - backward: autograd.Function around ONE sparse gfx950 kernel that only touches
     the k selected codes per row (the reference back-propagates through a dense
     N x K matrix); the code gradients are summed per code without atomics.
@@ -101,7 +104,47 @@ class CrossAttention(nn.Module):
         attended = mha.out_proj(attended)
         return layer.layer_norm(query + layer.dropout(attended))
 
-    def pooled(self, text, text_mask, nodes, batch, fold=None):
+    @staticmethod
+    def _folded_rows(layer, rows, attend):
+        """_folded_layer for PACKED query rows [R, D] (no batch axis, nothing padded): the attention core is
+        `attend(qf [R*heads, D]) -> ctx [R*heads, D]`, i.e. the ragged gfx950 kernel (ops.shared_kv_attention).
+        Inference form: dropout is the identity here (callers only take this path in eval mode)."""
+        mha = layer.multihead_attn
+        n_rows, dim = rows.shape
+        heads, hd = mha.num_heads, mha.head_dim
+        wq, wk, wv = mha.in_proj_weight.chunk(3)
+        bq, _, bv = mha.in_proj_bias.chunk(3)
+        q = torch.nn.functional.linear(rows, wq, bq).view(n_rows, heads, hd)
+        qf = torch.einsum("rhd,hdk->rhk", q, wk.view(heads, hd, dim)).reshape(n_rows * heads, dim)
+        ctx = attend(qf.contiguous()).view(n_rows, heads, dim)
+        attended = torch.einsum("rhk,hdk->rhd", ctx, wv.view(heads, hd, dim)).reshape(n_rows, dim) + bv
+        return layer.layer_norm(rows + mha.out_proj(attended))
+
+    def _pooled_packed(self, text, valid_len, nodes_sorted, batch_sorted, slot, counts, starts, max_nodes, core):
+        """Inference path of `pooled` with no padding anywhere: packed query rows, ragged attention core.
+        `core(q, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale)` is ops.shared_kv_attention."""
+        bsz, seq_len, dim = text.shape
+        mha = self.model[0].multihead_attn
+        heads, scale = mha.num_heads, mha.head_dim ** -0.5
+        dev = text.device
+        code = torch.arange(bsz, device=dev, dtype=torch.long)
+        text_flat = text.reshape(bsz * seq_len, dim)
+        # text side: the CLS row of every code queries that code's nodes
+        t_start, t_len = code * heads, torch.full((bsz,), heads, device=dev, dtype=torch.long)
+        cur = text[:, 0].contiguous()
+        for layer in self.model:
+            cur = self._folded_rows(layer, cur, lambda qf: core(qf, t_start, t_len, nodes_sorted, starts, counts, heads, scale))
+        # graph side: every node queries the valid text tokens of its code
+        g_start, g_len, tok_start = starts * heads, counts * heads, code * seq_len
+        g = nodes_sorted
+        for layer in self.model:
+            g = self._folded_rows(layer, g, lambda qf: core(qf, g_start, g_len, text_flat, tok_start, valid_len,
+                                                            max_nodes * heads, scale))
+        padded = g.new_zeros(bsz, max_nodes, dim)
+        padded[batch_sorted, slot] = g                     # deterministic mean (no atomics): pad, sum, divide
+        return cur, padded.sum(1) / counts.clamp(min=1).unsqueeze(-1).to(g.dtype)
+
+    def pooled(self, text, text_mask, nodes, batch, fold=None, core=None):
         """Batched equivalent of the reference's per-code loop (:133-142).
 
         text [B, L, D] with a left-aligned mask [B, L]; nodes [sum n_i, D] with a
@@ -109,7 +152,9 @@ class CrossAttention(nn.Module):
         mean of the attended graph nodes [B, D]).  Queries never interact, so the
         text side only evaluates its CLS query.  `fold` forces (True) or forbids (False)
         the folded-projection form for the graph side; None picks the cheaper one from
-        the padded shapes (no host sync).
+        the padded shapes (no host sync).  In eval mode without autograd, fp32, D % 128 == 0
+        and folding on, everything runs packed on the ragged gfx950 attention kernel
+        (`core`, default ops.shared_kv_attention; tests inject the oracle's restatement).
         """
         bsz = text.shape[0]
         if nodes.dtype != text.dtype:                      # autocast hands over bf16 text features and fp32 node features
@@ -123,6 +168,19 @@ class CrossAttention(nn.Module):
         # nodes of one code need not be contiguous in `batch`: rank them with a stable sort
         order = torch.argsort(batch, stable=True)
         slot = torch.arange(batch.numel(), device=batch.device) - starts[batch[order]]
+
+        seq_len, dim = text.shape[1], text.shape[2]
+        heads = self.model[0].multihead_attn.num_heads
+        if fold is None:        # flops: 4 n D^2 + 4 n H T D folded  vs  4 T D^2 + 4 n T D projected
+            fold = max_nodes * (dim + (heads - 1) * seq_len) < seq_len * dim
+        needs_grad = torch.is_grad_enabled() and (text.requires_grad or nodes.requires_grad
+                                                  or any(p.requires_grad for p in self.parameters()))
+        packed = (fold and not self.training and not needs_grad and dim % 128 == 0 and dim <= 768 and text.dtype == torch.float32
+                  and not torch.is_autocast_enabled() and max_nodes > 0 and (core is not None or text.is_cuda))
+        if packed:
+            return self._pooled_packed(text.contiguous(), valid.sum(1), nodes[order].contiguous(), batch[order], slot, counts, starts,
+                                       max_nodes, core or ops.shared_kv_attention)
+
         padded = text.new_zeros(bsz, max_nodes, text.shape[-1])
         padded[batch[order], slot] = nodes[order]
         node_valid = torch.arange(max_nodes, device=batch.device)[None, :] < counts[:, None]
@@ -134,10 +192,6 @@ class CrossAttention(nn.Module):
         pooled_text = q_text[:, 0]
 
         # graph side: the nodes of a code query its text tokens
-        seq_len, dim = text.shape[1], text.shape[2]
-        heads = self.model[0].multihead_attn.num_heads
-        if fold is None:        # flops: 4 n D^2 + 4 n H T D folded  vs  4 T D^2 + 4 n T D projected
-            fold = max_nodes * (dim + (heads - 1) * seq_len) < seq_len * dim
         if fold:
             q_graph = padded
             for layer in self.model:

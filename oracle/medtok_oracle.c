@@ -352,6 +352,37 @@ int oracle_info_nce_f32(const float *q, const float *k, int64_t b, int d, float 
     return 0;
 }
 
+/* Ragged shared-key/value attention core: out[r] = softmax_j(scale <q[r], kv[j]>) . kv over each code's own
+ * query rows [q_start[b], +q_len[b]) and key rows [kv_start[b], +kv_len[b]).  This is what
+ * nn.MultiheadAttention (vector_quantization_soft_one_new.py:30,45) computes once its key/value projections are
+ * folded into the queries; double accumulation (tolerance checker). */
+int oracle_shared_kv_attention_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
+                                   const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int d, float scale,
+                                   float *out)
+{
+    for (int64_t b = 0; b < n_codes; ++b) {
+        const int64_t kl = kv_len[b];
+        double *sc = (double *)malloc(sizeof(double) * (kl > 0 ? kl : 1));
+        for (int64_t r = q_start[b]; r < q_start[b] + q_len[b]; ++r) {
+            double m = -INFINITY, l = 0.0;
+            for (int64_t j = 0; j < kl; ++j) {
+                double a = 0.0;
+                for (int i = 0; i < d; ++i) a += (double)q[r * d + i] * kv[(kv_start[b] + j) * d + i];
+                sc[j] = a * scale;
+                if (sc[j] > m) m = sc[j];
+            }
+            for (int64_t j = 0; j < kl; ++j) { sc[j] = exp(sc[j] - m); l += sc[j]; }
+            for (int i = 0; i < d; ++i) {
+                double a = 0.0;
+                for (int64_t j = 0; j < kl; ++j) a += sc[j] * kv[(kv_start[b] + j) * d + i];
+                out[r * d + i] = (float)(a / l);
+            }
+        }
+        free(sc);
+    }
+    return 0;
+}
+
 /* EMA statistics (norm_ema_quantizer.py:194,202): bins[c] = #rows assigned to
  * c; embed_sum[c][:] = sum of those rows of zhat, added in increasing row
  * order (layout [K,D]; the reference's [D,K] is its transpose). */

@@ -162,6 +162,17 @@ def info_nce(q, k, temperature=0.07, g_loss=1.0):
     return float(loss[0]), gq, gk
 
 
+def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, scale):
+    """Ragged attention core with raw rows as keys and values (folded nn.MultiheadAttention, :30,45)."""
+    q, qp = _f(q); kv, kp = _f(kv)
+    qs, qsp = _i(q_start); ql, qlp = _i(q_len); ks, ksp = _i(kv_start); kl, klp = _i(kv_len)
+    out = np.full_like(q, np.nan)
+    rc = lib().oracle_shared_kv_attention_f32(qp, qsp, qlp, kp, ksp, klp, C.c_int64(len(qs)), q.shape[1], C.c_float(scale),
+                                              out.ctypes.data_as(_f32p))
+    assert rc == 0
+    return out
+
+
 def ema_stats(zhat, idx, k_codes):
     """bins and embed_sum ([K,D]) of norm_ema_quantizer.py:194,202."""
     zhat, zp = _f(zhat); idx, ip = _i(idx)

@@ -206,3 +206,40 @@ def test_code_sharded_merge_is_bit_exact(oracle, dev):
         dparts.append(d_r); iparts.append(i_r + lo)
     idx_m, dist_m = ops.merge_topk_lists(torch.stack(dparts), torch.stack(iparts))
     assert torch.equal(idx_m, idx) and torch.equal(dist_m, dist)
+
+
+@pytest.mark.parametrize("d,heads,seed", [(128, 4, 0), (768, 4, 1), (512, 2, 2), (384, 1, 3), (640, 4, 4), (256, 4, 5)])
+def test_shared_kv_attention_matches_oracle(oracle, dev, d, heads, seed):
+    """Ragged attention core vs the oracle's restatement (double accumulation): ragged query/key counts that are not
+    multiples of the 32-row tiles, empty query sets, single keys, a key spike that forces the online-softmax rescale."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(seed)
+    q_len = np.array([0, 1, 31, 32, 33, 80, 4, 200 * heads % 97 + 1, 64], np.int64) * 1
+    kv_len = np.array([5, 1, 33, 512, 31, 260, 7, 64, 96], np.int64)
+    q_start = np.cumsum(q_len) - q_len + 3                   # rows before/between the codes must stay untouched
+    kv_start = (np.cumsum(kv_len) - kv_len)[::-1].copy()     # key blocks in a different order than the codes
+    kv_start = np.cumsum(kv_len[::-1])[::-1] - kv_len        # contiguous, reversed order
+    nq, nk = int(q_start[-1] + q_len[-1]) + 2, int(kv_len.sum())
+    q = (rng.standard_normal((nq, d)) * 0.3).astype(np.float32)
+    kv = rng.standard_normal((nk, d)).astype(np.float32)
+    # spike: one late key of code 3 aligned with one query row -> the running max jumps in a later chunk
+    kv[kv_start[3] + 300] = q[q_start[3] + 5] * 40.0
+    scale = (d // heads) ** -0.5
+    want = oracle.shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, scale)
+    T = lambda a: torch.from_numpy(a).to(dev)
+    got = ops.shared_kv_attention(T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len), int(q_len.max()), scale).cpu().numpy()
+    touched = ~np.isnan(want).all(1)
+    assert touched.sum() == q_len.sum()
+    err = np.abs(got[touched].astype(np.float64) - want[touched]).max() / np.abs(want[touched]).max()
+    assert err <= 1e-5, err
+    # deterministic
+    again = ops.shared_kv_attention(T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len), int(q_len.max()), scale).cpu().numpy()
+    assert np.array_equal(got[touched], again[touched])
+
+
+def test_shared_kv_attention_rejects_bad_shapes(dev):
+    from medtok_amd import ops
+    from medtok_amd._lib import MedTokLibraryError
+    z = torch.zeros(1, dtype=torch.int64, device=dev)
+    with pytest.raises(MedTokLibraryError):
+        ops.shared_kv_attention(torch.zeros(4, 64, device=dev), z, z + 4, torch.zeros(4, 64, device=dev), z, z + 4, 4, 1.0)

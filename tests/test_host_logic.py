@@ -78,6 +78,18 @@ def test_batched_cross_attention_equals_reference_loop(golden, name):
         pt2, pg2 = v.cross_attn.pooled(torch.from_numpy(g["text"]), torch.from_numpy(g["mask"]),
                                        torch.from_numpy(g["nodes"])[perm], torch.from_numpy(g["batch"])[perm])
     assert rel(pt2, g["pooled_text"]) <= 1e-5 and rel(pg2, g["pooled_graph"]) <= 1e-5
+    # packed inference path (D % 128 == 0 only) with the oracle's restatement of the ragged attention core injected:
+    # pins that restatement, and the packing logic around it, to the reference's per-code loop
+    if D % 128 == 0:
+        from oracle import oracle as O
+
+        def core(q, qs, ql, kv, ks, kl, max_q_len, scale):
+            assert int(ql.max()) <= max_q_len
+            return torch.from_numpy(O.shared_kv_attention(q.numpy(), qs.numpy(), ql.numpy(), kv.numpy(), ks.numpy(), kl.numpy(), scale))
+        with torch.no_grad():
+            pt4, pg4 = v.cross_attn.pooled(torch.from_numpy(g["text"]), torch.from_numpy(g["mask"]),
+                                           torch.from_numpy(g["nodes"])[perm], torch.from_numpy(g["batch"])[perm], fold=True, core=core)
+        assert rel(pt4, g["pooled_text"]) <= 1e-5 and rel(pg4, g["pooled_graph"]) <= 1e-5
     # both forms of the graph side (projected keys / projections folded into the queries) are the same function
     for fold in (False, True):
         with torch.no_grad():

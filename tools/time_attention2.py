@@ -1,0 +1,20 @@
+"""Dev tool: per-chunk latency / throughput regimes of ops.shared_kv_attention (uniform shapes)."""
+import sys, time
+sys.path.insert(0, ".")
+import torch
+from medtok_amd import ops
+dev = torch.device("cuda:0")
+D, H = int(sys.argv[1]) if len(sys.argv) > 1 else 768, 4
+def run(B, rows, T, reps=20):
+    q = torch.randn(B * rows, D, device=dev) * 0.05
+    kv = torch.randn(B * T, D, device=dev)
+    code = torch.arange(B, device=dev)
+    a = (q, code * rows, torch.full((B,), rows, device=dev), kv, code * T, torch.full((B,), T, device=dev), rows, 192 ** -0.5)
+    for _ in range(3): ops.shared_kv_attention(*a)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): ops.shared_kv_attention(*a)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+    fl = B * rows * T * D * 4.0
+    tiles = B * ((rows + 31) // 32); chunks = (T + 31) // 32
+    print(f"B={B:5d} rows={rows:4d} T={T:4d}: {dt*1e6:8.1f} us  {fl/dt/1e12:6.1f} TF  | blocks {tiles:6d} x {chunks:3d} chunks -> {dt*1e6/chunks/max(1, tiles/256):.2f} us per chunk-round", flush=True)
+run(256, 32, 512); run(256, 32, 32); run(256, 32, 64); run(256, 32, 128); run(512, 32, 512); run(2048, 32, 512); run(256, 160, 512); run(2048, 96, 256)
