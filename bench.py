@@ -19,6 +19,7 @@ One JSON line on rank 0 (contract in the task statement) plus:
 from __future__ import annotations
 
 import argparse
+import copy
 import json
 import os
 import sys
@@ -43,8 +44,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg5"], default="cfg3",
-                    help="cfg3: full soft VQ (headline); cfg2: argmin+EMA train step, 100k rows, K=8192; cfg5: the same step on 600k rows "
+    ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg5", "full"], default="cfg3",
+                    help="cfg3: full soft VQ (headline); full: cfg3 plus the ragged cross-attention of get_shared_info in front of it; cfg2: argmin+EMA train step, 100k rows, K=8192; cfg5: the same step on 600k rows "
                          "TOTAL (split over the GPUs: strong scaling), K=16384, with the RCCL all-reduce of the EMA statistics")
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default 600000 for cfg3, 100000 for cfg2)")
     ap.add_argument("--path", type=int, default=ops.PATH_AUTO)
@@ -107,6 +108,73 @@ class Cfg3:
         return dict(value=sample_rows / dt, unit="codes/s", cores=torch.get_num_threads(), kind="port",
                     sample=f"{sample_rows} codes of the same workload (4 searches each, K=16384/49152, D=768), "
                            f"reference op sequence in CPU PyTorch (oracle/torch_port.py), {dt:.1f} s")
+
+
+class Full(Cfg3):
+    """VectorQuantizer.forward end to end (vector_quantization_soft_one_new.py:238-271): ragged cross-attention over the text tokens
+    and graph nodes of every code -> pooled rows -> the four searches of cfg3.  Inputs are the encoders' outputs, resident in HBM."""
+    name = "full"
+    L, MAX_NODES = 512, 40
+
+    def __init__(self, rows, dev, seed, path):
+        super().__init__(rows, dev, seed, path)
+        D = self.D
+        g = torch.Generator(device=dev).manual_seed(seed + 77)
+        self.text = torch.randn(rows, self.L, D, device=dev, generator=g)
+        self.tok = torch.randint(1, self.L + 1, (rows,), device=dev, generator=g)                       # valid tokens per code
+        self.mask = (torch.arange(self.L, device=dev)[None, :] < self.tok[:, None]).to(torch.int64)
+        self.n_nodes = torch.randint(1, self.MAX_NODES + 1, (rows,), device=dev, generator=g)
+        self.batch = torch.repeat_interleave(torch.arange(rows, device=dev), self.n_nodes)
+        self.nodes = torch.randn(int(self.n_nodes.sum()), D, device=dev, generator=g)
+        heads = self.vq.cross_attn.model[0].multihead_attn.num_heads
+        layers = len(self.vq.cross_attn.model)
+        # algorithmic flops of the attention core per step: 2 products x 2 flops x D per (query row, key) pair
+        pairs = float((self.n_nodes * heads * self.tok).sum()) + float((heads * self.n_nodes).sum())
+        self.attention_flops = 4.0 * D * pairs * layers
+        self.description = (f"full VectorQuantizer.forward: {rows} codes/GPU/step, ragged cross-attention (<= {self.L} tokens x <= "
+                            f"{self.MAX_NODES} nodes per code, 4 heads, 2 layers per direction, D=768) + the 4 searches of cfg3 "
+                            f"(n_e = 49152, k=5), eval, fp32")
+
+    def step(self):
+        self.vq._norm_cache = None
+        with torch.no_grad():
+            return self.vq(self.h, self.text, self.nodes, self.mask, self.batch)
+
+    def paths_agree(self):
+        outs = []
+        for path in (ops.PATH_AUTO, ops.PATH_F32_MFMA):
+            self.set_path(path)
+            r = self.step()
+            outs.append([r[k] for k in sorted(r) if isinstance(r[k], torch.Tensor)])
+        self.set_path(ops.PATH_AUTO)
+        return all(torch.equal(u, v) for u, v in zip(*outs))
+
+    def cpu_baseline(self, sample_rows):
+        """The reference's own form on the host cores: per-code Python loop over nn.MultiheadAttention layers (:133-142), then the
+        dense searches."""
+        from oracle import torch_port as P
+        # the loop issues thousands of small ops: more than a few threads only adds fork/join cost
+        threads = min(16, os.cpu_count() or 1)
+        torch.set_num_threads(threads)
+        n = min(sample_rows, self.rows)
+        ca = copy.deepcopy(self.vq.cross_attn).cpu().eval()
+        text, tok, nn_, nodes = self.text[:n].cpu(), self.tok[:n].cpu(), self.n_nodes[:n].cpu(), self.nodes[: int(self.n_nodes[:n].sum())].cpu()
+        W = self.vq.codebook.weight.detach().cpu()
+        h = self.h[:n].cpu()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            pt, pg, off = [], [], 0
+            for i in range(n):
+                a, b = ca(text[i, : int(tok[i])], nodes[off: off + int(nn_[i])])
+                off += int(nn_[i])
+                pt.append(a[0]); pg.append(b.mean(0))
+                if time.perf_counter() - t0 > 20.0:          # bounded sample: stop after ~20 s of loop
+                    break
+            n = len(pt)
+            P.full_tokenize(h[:n, : self.D], h[:n, self.D:], torch.stack(pt), torch.stack(pg), W, self.TOPK)
+        dt = time.perf_counter() - t0
+        return dict(value=n / dt, unit="codes/s", cores=threads, kind="port",
+                    sample=f"{n} codes: per-code cross-attention loop (the reference's form) + 4 dense searches in CPU PyTorch, {dt:.1f} s")
 
 
 class Cfg2:
@@ -192,8 +260,8 @@ def main():
         wl.description = (f"cfg5 NormEMA argmin + EMA update (train): {total_rows} rows total row-sharded x{world} ({rows}/GPU), D=768, "
                           f"K=16384, one all-reduce of [embed_sum | bins] = {16384 * 769 * 4 / 1e6:.1f} MB per step")
     else:
-        rows = args.rows or (600000 if args.workload == "cfg3" else 100000)
-        wl = (Cfg3 if args.workload == "cfg3" else Cfg2)(rows, dev, seed=rank, path=args.path)
+        rows = args.rows or {"cfg3": 600000, "full": 4096}.get(args.workload, 100000)
+        wl = {"cfg3": Cfg3, "full": Full}.get(args.workload, Cfg2)(rows, dev, seed=rank, path=args.path)
 
     for _ in range(args.warmup):
         wl.step()
@@ -223,7 +291,7 @@ def main():
             wl.step()
         torch.cuda.synchronize(dev)
         e_elapsed = time.perf_counter() - t1
-        e_prof = ops.profile_end()["search_f32_kernel"]
+        e_prof = ops.profile_end()["search_f32_kernel"]      # (for the `full` workload this block reports the search part only)
         e_ach = e_prof["flops"] / (e_prof["ms"] * 1e-3) / 1e12 if e_prof["ms"] > 0 else 0.0
         exact = {"value": rows * args.exact_steps / e_elapsed, "unit": "codes/s per GPU", "steps": args.exact_steps,
                  "outputs_bit_identical_to_default_path": bool(agree),
@@ -232,7 +300,9 @@ def main():
                               "avg_launch_ms": e_prof["ms"] / max(e_prof["launches"], 1)}}
         wl.set_path(args.path)
 
-    # dominant kernel = the search kernel with the most time in the timed region
+    # dominant kernel = the matrix-pipe kernel with the most time in the timed region
+    if hasattr(wl, "attention_flops"):       # the ragged counts live on the device; the workload knows them
+        prof["shared_kv_attention_kernel"]["flops"] = wl.attention_flops * args.steps
     kname = max(prof, key=lambda k: prof[k]["ms"])
     kp = prof[kname]
     peak = F16_MFMA_PEAK_TFLOPS if kname == "filter_f16_kernel" else FP32_MFMA_PEAK_TFLOPS
@@ -266,10 +336,13 @@ def main():
                          "algorithmic_flops_per_launch": kp["flops"] / max(kp["launches"], 1),
                          "kernel_share_of_step": kp["ms"] / (elapsed * 1e3),
                          "achieved_over_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "whole_step_tflops": wl.flops_per_code() * rows * args.steps / elapsed / 1e12},
+                         "whole_step_tflops": wl.flops_per_code() * rows * args.steps / elapsed / 1e12,
+                         "other_kernels": {k: {"ms_per_step": v["ms"] / args.steps, "launches": v["launches"],
+                                               "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)}
+                                           for k, v in prof.items() if k != kname and v["launches"]}},
             "exact_fp32_path": exact,
         }
-        cpu_rows = args.cpu_rows if args.cpu_rows is not None else (4096 if args.workload == "cfg3" else 16384)
+        cpu_rows = args.cpu_rows if args.cpu_rows is not None else {"cfg3": 4096, "full": 512}.get(args.workload, 16384)
         if world == 1 and cpu_rows > 0:
             line["cpu_baseline"] = wl.cpu_baseline(cpu_rows)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -50,12 +50,15 @@ extern "C" {
 int medtok_abi_version(void);
 const char *medtok_last_error(void);
 
-/* Optional self-profiling for bench.py: between _begin and _end every search-kernel launch is
- * bracketed by HIP events on its launch stream (no host sync until _end).  _end fills, for
- * kind 0 = filter_f16_kernel and kind 1 = search_f32_kernel: total milliseconds, total
- * algorithmic flops (2*n*K*D per launch) and the number of launches.  Thread-local. */
+/* Optional self-profiling for bench.py: between _begin and _end every launch of the three matrix-pipe
+ * kernels is bracketed by HIP events on its launch stream (no host sync until _end).  _end fills, for
+ * kind 0 = filter_f16_kernel, 1 = search_f32_kernel, 2 = shared_kv_attention_kernel: total
+ * milliseconds, total algorithmic flops (2*n*K*D per search launch; 0 for kind 2, whose ragged
+ * row/key counts live on the device -- the caller prices it) and the number of launches.  Thread-local. */
+#define MEDTOK_PROFILE_KINDS 3
 int medtok_profile_begin(void);
-int medtok_profile_end(double ms[2], double flops[2], int launches[2]);
+int medtok_profile_end(double ms[MEDTOK_PROFILE_KINDS], double flops[MEDTOK_PROFILE_KINDS],
+                       int launches[MEDTOK_PROFILE_KINDS]);
 
 /* F.normalize(x, p=2, dim=-1, eps=1e-12) and the squared norm of the result.
  * Replaces vector_quantization_soft_one_new.py:148,150-151,196,198,200 and

@@ -52,7 +52,7 @@ extern "C" const char *medtok_last_error(void) { return g_err; }
 // ---------------------------------------------------------------- optional self-profiling (bench.py)
 // Between medtok_profile_begin() and medtok_profile_end() every launch of a search kernel is
 // bracketed by HIP events recorded on its own launch stream; nothing synchronises until _end().
-struct ProfRec { hipEvent_t a, b; double flops; int kind; };   // kind 0 = filter_f16_kernel, 1 = search_f32_kernel
+struct ProfRec { hipEvent_t a, b; double flops; int kind; };   // kind 0 = filter_f16_kernel, 1 = search_f32_kernel, 2 = shared_kv_attention_kernel
 static thread_local bool g_prof_on = false;
 static thread_local std::vector<ProfRec> g_prof;
 
@@ -75,7 +75,7 @@ extern "C" int medtok_profile_begin(void)
 extern "C" int medtok_profile_end(double *ms, double *flops, int *launches)
 {
     g_prof_on = false;
-    for (int k = 0; k < 2; ++k) { ms[k] = 0.0; flops[k] = 0.0; launches[k] = 0; }
+    for (int k = 0; k < MEDTOK_PROFILE_KINDS; ++k) { ms[k] = 0.0; flops[k] = 0.0; launches[k] = 0; }
     for (auto &r : g_prof) {
         float t = 0.f;
         if (r.a && r.b && hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
@@ -897,6 +897,7 @@ extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_s
     if (n_codes > 65535) return fail("shared_kv_attention: at most 65535 codes per call (got %ld)", (long)n_codes);
     const dim3 grid((unsigned)((max_q_len + 31) / 32), (unsigned)n_codes);
     hipStream_t s = (hipStream_t)stream;
+    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
     const int waves = d % 256 == 0 ? 8 : 4;
     const size_t lds = ((size_t)32 * (d + 4) + (waves + 1) * 32 * 33 + 64) * sizeof(float);   // key chunk + per-wave partial scores + probabilities + row state
 #define MEDTOK_ATT(W, NT)                                                                                                        \
@@ -915,6 +916,7 @@ extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_s
     default: MEDTOK_ATT(8, 3); break;
     }
 #undef MEDTOK_ATT
+    if (pa) g_prof.push_back({pa, prof_mark(s), 0.0, 2});      // the row / key counts live on the device: the caller prices the launch
     return check_launch("shared_kv_attention");
 }
 

@@ -25,10 +25,10 @@ def profile_begin() -> None:
 def profile_end() -> dict:
     """Stop it; returns {kernel: dict(ms, flops, launches)} (synchronises on the recorded events)."""
     import ctypes as C
-    ms, fl, ln = (C.c_double * 2)(), (C.c_double * 2)(), (C.c_int * 2)()
+    ms, fl, ln = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int * 3)()
     _lib.check(_lib.load().medtok_profile_end(ms, fl, ln), "medtok_profile_end")
-    names = ("filter_f16_kernel", "search_f32_kernel")
-    return {names[i]: dict(ms=ms[i], flops=fl[i], launches=ln[i]) for i in range(2)}
+    names = ("filter_f16_kernel", "search_f32_kernel", "shared_kv_attention_kernel")
+    return {names[i]: dict(ms=ms[i], flops=fl[i], launches=ln[i]) for i in range(3)}
 
 
 def _stream(t: torch.Tensor) -> int:
