@@ -143,14 +143,26 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     const _Float16 *__restrict__ xh, const _Float16 *__restrict__ wh, const float *__restrict__ xsq,
     const float *__restrict__ wsqp, const float *__restrict__ en_max_ptr, long n, int k_codes, int dp, int d,
     int codes_per_split, int own_total, uint2 *__restrict__ cand, int *__restrict__ cand_cnt,
-    float *__restrict__ dump)
+    float *__restrict__ dump, int xcd_rows, int n_splits)
 {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / F_WN, wn = wave % F_WN;
     const int li = lane & 31, lh = lane >> 5;
-    const long row0 = (long)blockIdx.x * F_BN;
-    const int split = blockIdx.y;
+    // Block -> (row tile, code split).  Plain: grid (row tiles, splits).  XCD-aware (xcd_rows > 0): consecutive block ids
+    // go round-robin to the 8 XCDs and each XCD runs 32 of its blocks at a time, so block j of XCD x is made
+    // (row tile (32/S of them per chunk), split j % S): the CUs of one XCD then share 32/S x tiles (L2-resident)
+    // and S code streams instead of streaming 32 different x tiles through a 4 MB L2.  (A non-temporal hint on the
+    // code-side loads, meant to protect the x tiles further, measured 25 % slower.)
+    long row_tile = blockIdx.x;
+    int split = blockIdx.y;
+    if (xcd_rows > 0) {
+        const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3, c = j >> 5, i = j & 31;
+        split = i % n_splits;
+        row_tile = (long)(c * 8 + xcd) * xcd_rows + i / n_splits;
+        if (row_tile * F_BN >= n) return;
+    }
+    const long row0 = row_tile * F_BN;
     const int code_lo = split * codes_per_split;
     const int code_hi = min(k_codes, code_lo + codes_per_split);
     const int nct = (code_hi - code_lo + F_BM - 1) / F_BM;

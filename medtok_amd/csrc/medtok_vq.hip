@@ -18,6 +18,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -445,6 +446,7 @@ static SearchPlan plan_search(int64_t n, int64_t k_codes, int topk)
 struct FilterPlan {
     long n_pad, k_pad, row_tiles;
     int dp, splits, codes_per_split, own_total, tslots;
+    int xcd_rows;      // > 0: XCD-aware block order with this many row tiles per XCD at a time (32 / splits)
 };
 
 static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
@@ -458,13 +460,23 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
     const long code_tiles = f.k_pad / F_BM;
     // every split adds 4 candidate lists per row, so split only as far as filling the chip needs
     // one 8-wave block per CU: a launch of B equal blocks wastes up to one round of 256
-    long want = f.row_tiles >= 4096 ? 1 : (f.row_tiles >= 1024 ? 2 : (1024 + f.row_tiles - 1) / f.row_tiles);
+    long want = f.row_tiles >= 1024 ? 2 : (1024 + f.row_tiles - 1) / f.row_tiles;
+    // With >= 1024 row tiles the blocks are ordered XCD-aware (see filter_f16_kernel): the 32 CUs of an XCD share
+    // 32/splits x tiles, which then stay in its 4 MB L2 (393 KB each at D = 768) instead of being re-streamed from
+    // the Infinity Cache once per code tile.  Measured at N = 600k: K = 49152 54.2 -> 50.0 ms with 4 splits,
+    // K = 16384 18.9 -> 17.9 ms with 2 (more splits loosen the per-split thresholds: more candidates).
+    bool xcd = f.row_tiles >= 1024;
+    if (xcd && code_tiles >= 128) want = 4;
+    if (const char *e = getenv("MEDTOK_FILTER_SPLITS")) want = atol(e);      // dev knobs (tools/xcd_experiment.py)
+    if (const char *e = getenv("MEDTOK_FILTER_XCD")) xcd = atoi(e) != 0;
     if (want > code_tiles) want = code_tiles;
     if (want > 16) want = 16;
+    if (want < 1) want = 1;
     const long tiles_per_split = (code_tiles + want - 1) / want;
     f.codes_per_split = (int)(tiles_per_split * F_BM);
     f.splits = (int)((code_tiles + tiles_per_split - 1) / tiles_per_split);
     f.own_total = f.splits * F_OWN_PER_SPLIT;
+    f.xcd_rows = (xcd && f.splits >= 2 && 32 % f.splits == 0) ? 32 / f.splits : 0;
     return f;
 }
 
@@ -583,9 +595,11 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     if (hipMemsetAsync(w.fb_count, 0, 4, s) != hipSuccess) return fail("search(filter): memset failed");
     (void)hipFuncSetAttribute((const void *)filter_f16_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM_BYTES);
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
-    hipLaunchKernelGGL((filter_f16_kernel<T, false>), dim3((unsigned)f.row_tiles, (unsigned)f.splits), dim3(F_THREADS), F_SMEM_BYTES, s,
+    dim3 fgrid((unsigned)f.row_tiles, (unsigned)f.splits);
+    if (f.xcd_rows) fgrid = dim3((unsigned)(((f.row_tiles + 8 * f.xcd_rows - 1) / (8 * f.xcd_rows)) * 256), 1);
+    hipLaunchKernelGGL((filter_f16_kernel<T, false>), fgrid, dim3(F_THREADS), F_SMEM_BYTES, s,
                        w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
-                       w.cand, w.cand_cnt, (float *)nullptr);
+                       w.cand, w.cand_cnt, (float *)nullptr, f.xcd_rows, f.splits);
     if (pa) g_prof.push_back({pa, prof_mark(s), 2.0 * (double)n * (double)k_codes * (double)d, 0});
     if (check_launch("filter_f16")) return 1;
     hipLaunchKernelGGL((rescore_kernel<T>), dim3((unsigned)((n + R_ROWS - 1) / R_ROWS)), dim3(256), 0, s, w.cand, w.cand_cnt, f.own_total,
@@ -673,7 +687,7 @@ extern "C" int medtok_debug_filter_scores_f32(const float *xhat, const float *xs
     hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, en_max);
     (void)hipFuncSetAttribute((const void *)filter_f16_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM_BYTES);
     hipLaunchKernelGGL((filter_f16_kernel<5, true>), dim3((unsigned)f.row_tiles, 1), dim3(F_THREADS), F_SMEM_BYTES, s, xh, wh, xsq, wsqp, en_max,
-                       (long)n, (int)k_codes, f.dp, d, (int)f.k_pad, F_OWN_PER_SPLIT, (uint2 *)nullptr, (int *)nullptr, scores);
+                       (long)n, (int)k_codes, f.dp, d, (int)f.k_pad, F_OWN_PER_SPLIT, (uint2 *)nullptr, (int *)nullptr, scores, 0, 1);
     return check_launch("filter_f16(dump)");
 }
 

@@ -144,3 +144,19 @@ def test_filter_race_screen(dev):
             i2, d2 = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
             i1, d1 = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F32_MFMA)
             assert torch.equal(i1, i2) and torch.equal(d1, d2), (rep, n, k, d)
+
+
+@pytest.mark.parametrize("splits", [2, 4, 8])
+def test_xcd_block_order_gives_the_same_bits(dev, splits, monkeypatch):
+    """The XCD-aware block order (default from 1024 row tiles up) forced at a small size: every (row tile, split) pair must be
+    visited exactly once -- ids and distances equal the exact path, including a row count that leaves XCD chunks partly empty."""
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(splits)
+    n, K, D = 256 * 37 + 11, 256 * 24, 256
+    xh, xs = ops.rownorm(torch.randn(n, D, device=dev, generator=g))
+    wh, ws = ops.rownorm(torch.randn(K, D, device=dev, generator=g))
+    i_ref, d_ref = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F32_MFMA)
+    monkeypatch.setenv("MEDTOK_FILTER_SPLITS", str(splits))
+    monkeypatch.setenv("MEDTOK_FILTER_XCD", "1")
+    i_x, d_x = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
+    assert torch.equal(i_x, i_ref) and torch.equal(d_x, d_ref)
