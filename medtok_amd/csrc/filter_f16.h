@@ -66,6 +66,8 @@ __device__ __forceinline__ float filter_eps(float xn, float en_max, int d)
 
 // ---------------------------------------------------------------- operand preparation
 // fp32 rows -> prescaled fp16 rows in a zero-padded [n_pad, dp] image (dp % 64 == 0, n_pad % 128 == 0).
+// (A k-blocked image [n/16][dp/32][16][32], which makes every LDS-DMA instruction read 8 full 128-byte lines instead of
+// 16 half-used ones, measured 5-9 % SLOWER: with row-major rows the second stage that touches a line finds it in the L2.)
 __global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ src, long n, int d, long n_pad, int dp,
                                                       _Float16 *__restrict__ dst)
 {
@@ -129,6 +131,10 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
 }
 
 // ---------------------------------------------------------------- the filter kernel
+// (Rejected variant, measured 14-24 % slower: 4-wave blocks of 256 codes x 128 rows, two per CU, hoping that co-resident
+// blocks drifting apart overlap one block's epilogue / DMA issue with the other's MFMAs -- it moves 1.5 x the L2 -> LDS
+// bytes per flop, and operand delivery is what binds this kernel.  The ring could also be 3 stages deep instead of 4:
+// the slot of stage s is free after the mid-iteration barrier of s.)
 // Block = 8 waves (2 code-side x 4 row-side), tile 256 codes x 256 rows, wave tile 128 x 64 = 4 x 2 MFMA
 // tiles of 32x32x16 (L2->LDS traffic per flop halves against a 128^2 tile; at fp16 rates that is what
 // binds).  Operands arrive by LDS-DMA (global_load_lds, 16 B/lane) into a double buffer; a tile row is
