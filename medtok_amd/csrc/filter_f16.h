@@ -123,13 +123,6 @@ __device__ __forceinline__ void thr_insert(float (&tv)[T], float v)
     }
 }
 
-__device__ __forceinline__ void glds16(const void *gsrc, void *lds_dst)
-{
-    // async global -> LDS, 16 B per lane; the LDS address is wave-uniform base + lane * 16
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
-}
-
 // ---------------------------------------------------------------- the filter kernel
 // (Rejected variant, measured 14-24 % slower: 4-wave blocks of 256 codes x 128 rows, two per CU, hoping that co-resident
 // blocks drifting apart overlap one block's epilogue / DMA issue with the other's MFMAs -- it moves 1.5 x the L2 -> LDS
@@ -194,14 +187,21 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // Issues stage `pidx` into ring slot pidx % 4 and advances -- except past the end, where it re-issues the
     // LAST stage into the slot that already holds it (same bytes, harmless) so the steady-state loop body has
     // no branch around its DMA and one instruction schedule fits every iteration.
+    // buffer-addressed LDS-DMA (buffer_load_dwordx4 ... offen lds): SGPR descriptor + loop-invariant 32-bit lane offset +
+    // SGPR stage offset -- no per-lane 64-bit address arithmetic per instruction (+3 % over global_load_lds here)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wbase, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)xbase, 0, -1, 0x00020000);
     auto stage = [&]() {
         char *base = fsm + (pidx & (F_RING - 1)) * F_STAGEB + wave_lds;
-        const long ua = ((long)pct * F_BM * dp + (long)pkb * F_BK) * 2;  // uniform
-        const long ub = (long)pkb * F_BK * 2;                             // uniform
+        // readfirstlane: hipcc otherwise keeps the stage counters in VGPRs and wraps every buffer load in a waterfall loop
+        const int ua = __builtin_amdgcn_readfirstlane((pct * F_BM * dp + pkb * F_BK) * 2);    // a code split's fp16 image is < 2 GB
+        const int ub = __builtin_amdgcn_readfirstlane(pkb * F_BK * 2);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            glds16(wbase + ua + lane_off[q], base + q * 16 * F_ROWB);
-            glds16(xbase + ub + lane_off[q], base + F_TILEB + q * 16 * F_ROWB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(base + q * 16 * F_ROWB), 16,
+                                                     (int)lane_off[q], ua, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(base + F_TILEB + q * 16 * F_ROWB), 16,
+                                                     (int)lane_off[q], ub, 0, 0);
         }
         const bool more = pidx + 1 < nstage;
         const bool wrap = pkb + 1 == nkb;

@@ -518,13 +518,15 @@ static bool filter_eligible(int64_t n, int64_t k_codes, int d, int topk)
 {
     // the filter path has ~0.1-0.2 ms of fixed cost (operand conversion, three extra launches); measured
     // crossover against the exact kernel on MI355X is around 1e10 flop (tools/path_crossover.py)
+    // (k_codes * d < 2^29: the kernel addresses a code split's fp16 image with a 32-bit buffer offset)
     return n >= 512 && k_codes >= 1024 && 2.0 * (double)n * (double)k_codes * (double)d >= 1.0e10 &&
-           topk <= MEDTOK_MAX_TOPK && n < (1ll << 31);
+           topk <= MEDTOK_MAX_TOPK && n < (1ll << 31) && (double)k_codes * (double)(d + 64) < 536870912.0;
 }
 
 static int resolve_path(int path, int64_t n, int64_t k_codes, int d, int topk)
 {
     if (path == MEDTOK_PATH_AUTO) return filter_eligible(n, k_codes, d, topk) ? MEDTOK_PATH_F16_FILTER : MEDTOK_PATH_F32_MFMA;
+    if (path == MEDTOK_PATH_F16_FILTER && (double)k_codes * (double)(d + 64) >= 536870912.0) return MEDTOK_PATH_F32_MFMA;
     return path;
 }
 
