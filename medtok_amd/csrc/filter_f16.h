@@ -302,7 +302,13 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     asm volatile("" ::: "memory");
     load_frags(fa0, fb0, 0, 0);
     int ct = 0, kb = 0;
+    // The two waves of a SIMD (w and w + 4) issue their LDS-DMA at different points of the stage: an issuing wave is
+    // held for ~100 cycles per instruction, and in lockstep both would leave the matrix pipe idle at the same time
+    // (+2.5-3 % measured).  Either way a wave has issued all of stage s+3 between the waits of iterations s and s+1,
+    // so the counted vmcnt below is the same for both halves.
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
     for (int s = 0; s < nstage; ++s) {
+        if (late && s > 0) stage();         // waves 4-7: stage s+2 (slot s-2, free since the barrier of iteration s-1)
         load_frags(fa1, fb1, s & (F_RING - 1), 1);
         mfma_group(fa0, fb0);
         // interleave: the 6 operand reads of the next k16-step ride between the first MFMAs
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 #endif
         asm volatile("" ::: "memory");
 #ifndef MEDTOK_FILTER_NODMA       // dev experiment: without it the ring keeps its prologue contents
-        stage();                            // stage s+3 (slot s-1: everyone is past reading it)
+        if (!late) stage();                 // waves 0-3: stage s+3 (slot s-1: everyone is past reading it)
 #endif
         load_frags(fa0, fb0, (s + 1) & (F_RING - 1), 0);      // (past the last stage this reads stale LDS, never used)
         mfma_group(fa1, fb1);
