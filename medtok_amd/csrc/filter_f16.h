@@ -309,10 +309,10 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
     for (int s = 0; s < nstage; ++s) {
         if (late && s > 0) stage();         // waves 4-7: stage s+2 (slot s-2, free since the barrier of iteration s-1)
+        constexpr int NRD = F_MT + F_NT;     // operand reads per k16-step (8 MFMAs)
         load_frags(fa1, fb1, s & (F_RING - 1), 1);
         mfma_group(fa0, fb0);
         // interleave: the 6 operand reads of the next k16-step ride between the first MFMAs
-        constexpr int NRD = F_MT + F_NT;     // operand reads per k16-step (8 MFMAs)
 #pragma unroll
         for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NRD - 6, 0);
@@ -384,12 +384,34 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
                 }
 #pragma unroll
                 for (int nn = 0; nn < F_NT; ++nn) {
-#ifdef MEDTOK_FILTER_EPI_ROLLED
-                    // rolled over the 16 values (uniform dynamic register index): 16x less epilogue code in the I-cache
-#pragma nounroll
-#else
+#ifndef MEDTOK_FILTER_EPI_SCALAR
+                    // Four values per test: two packed fmas (bit-identical to fmaf per element), a 4-way min, ONE compare
+                    // and branch; only a quad that holds a passing value in some lane is scanned value by value.  A hit
+                    // is rare per lane but not per wave (64 lanes x 4 values at p ~ 2e-3: a third of the quads).  (+1 % over
+                    // the per-value form below; clearing the accumulators by a C = 0 first MFMA instead of 128 v_movs was
+                    // tried too: the per-stage branch it needs costs more than the moves.)
+                    if (!DUMP) {
 #pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            const f32x2 cc = {-0x1p-15f, -0x1p-15f};
+                            const f32x2 a01 = {acc[m][nn][4 * g], acc[m][nn][4 * g + 1]}, a23 = {acc[m][nn][4 * g + 2], acc[m][nn][4 * g + 3]};
+                            const f32x2 e01 = {env[4 * g], env[4 * g + 1]}, e23 = {env[4 * g + 2], env[4 * g + 3]};
+                            const f32x2 u01 = __builtin_elementwise_fma(a01, cc, e01), u23 = __builtin_elementwise_fma(a23, cc, e23);
+                            const float uq[4] = {u01.x, u01.y, u23.x, u23.y};
+                            if (fminf(fminf(uq[0], uq[1]), fminf(uq[2], uq[3])) <= lim[nn]) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (uq[j] <= lim[nn]) {
+                                        const int code = cbase + 32 * m + j + 8 * g;
+                                        if (np[nn] < 2) { park[nn * 2 + np[nn]] = make_uint2(__float_as_uint(uq[j]), (unsigned)code); ++np[nn]; }
+                                        else put(nn, uq[j], code);
+                                    }
+                            }
+                        }
+                    } else
 #endif
+#pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float u = fmaf(acc[m][nn][r], -0x1p-15f, env[r]);      // padded codes carry en = +inf
                         if (DUMP) {
