@@ -36,7 +36,8 @@ constexpr int F_TILEB = F_BM * F_ROWB;                        // 16 KB per opera
 constexpr int F_STAGEB = 2 * F_TILEB;                         // A + B = 32 KB
 constexpr int F_RING = 4;                                     // stages in the LDS ring: 3 in flight while 1 is computed on
 constexpr size_t F_LDS_BYTES = (size_t)F_RING * F_STAGEB;     // 128 KB -> 1 block (8 waves) / CU
-constexpr size_t F_SMEM_BYTES = F_LDS_BYTES + 256 * sizeof(float) + 512 * 32;   // + per-row shared thresholds + candidate parking (2 x 2 x 8 B per lane)
+constexpr size_t F_THR_BYTES = 256 * 2 * 5 * sizeof(float);  // per row: the k <= 5 smallest d~ of each code-side wave pair
+constexpr size_t F_SMEM_BYTES = F_LDS_BYTES + F_THR_BYTES + 512 * 32;   // + thresholds + candidate parking (2 x 2 x 8 B per lane)
 constexpr int F_GLDS_PER_STAGE = 4;                           // LDS-DMA instructions each wave issues per stage
 constexpr int F_CAP = 96;                                     // candidate slots per (row, owner): ~25-30 used on random data
 #ifndef MEDTOK_FILTER_WM
@@ -215,8 +216,8 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // Candidates found during a code tile are parked in a lane-private LDS slot pair (value, code) and written out
     // once per tile: scattered global stores inside the value loop stall the wave, and registers are scarce here.
     int np[F_NT] = {}, cnt[F_NT] = {};
-    float *thr_share = reinterpret_cast<float *>(fsm + F_LDS_BYTES);    // [F_BN] per-row min of the owners' thresholds
-    uint2 *park = reinterpret_cast<uint2 *>(fsm + F_LDS_BYTES + 256 * sizeof(float)) + tid * 4;   // [nn][slot]
+    float *thr_share = reinterpret_cast<float *>(fsm + F_LDS_BYTES);    // [F_BN][2 code-side waves][5]: sorted k-smallest lists
+    uint2 *park = reinterpret_cast<uint2 *>(fsm + F_LDS_BYTES + F_THR_BYTES) + tid * 4;   // [nn][slot]
     auto xrow_of = [&](int nn) -> long { return row0 + wn * (32 * F_NT) + nn * 32 + li; };
     const float en_max = en_max_ptr[0];
     const bool sane = en_max <= F_NORM_LIMIT;
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
             cand[(xrow_of(nn) * own_total + owner) * F_CAP + cnt[nn]] = make_uint2(__float_as_uint(u + xn[nn]), (unsigned)code);
         ++cnt[nn];
     };
-    if (tid < F_BN) reinterpret_cast<unsigned *>(thr_share)[tid] = 0xFFFFFFFFu;     // order-preserving key of +inf is 0xFF800000; all-ones is above it
+    constexpr int TL = TOPK < 5 ? TOPK : 5;       // list length shared per (row, code-side wave)
+    for (int i = tid; i < F_BN * 2 * 5; i += F_THREADS) thr_share[i] = INFINITY;
 
     f32x16 acc[F_MT][F_NT];
 #pragma unroll
@@ -431,8 +433,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
                 }
             }
             if (!DUMP) {
-                // per tile: flush, update the threshold, then share: the row's k-th best over all codes seen by ANY
-                // owner is <= every owner's own k-th best, so the minimum of the owners' values is a valid T.
+                // per tile: flush, update the lane's k-smallest list, then combine the row's four owners into one threshold
 #pragma unroll
                 for (int nn = 0; nn < F_NT; ++nn) {
                     // write out the parked candidates (at most two store instructions per tile) and fold them into the
@@ -446,17 +447,35 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
                         }
                     }
                     np[nn] = 0;
-                    float t = tv[nn][TOPK - 1];
-                    t = fminf(t, __shfl_xor(t, 32, 64));
-                    unsigned *sh = reinterpret_cast<unsigned *>(thr_share) + wn * (32 * F_NT) + nn * 32 + li;
-                    if (lh == 0) {
-                        // order-preserving float -> uint key so a plain integer atomicMin works for any sign
-                        const unsigned b = __float_as_uint(t);
-                        const unsigned key = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-                        const unsigned old = min(atomicMin(sh, key), key);
-                        t = __uint_as_float(old ^ ((old >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+                    // The row's k-th best over ALL codes seen so far, exactly: merge the sorted k-lists of the row's four
+                    // owners.  (The minimum of the owners' own k-th bests -- the old rule -- is only about the 4k-th best
+                    // of the union: 2-3 x the candidates.)  Two sorted lists a, b: {min(a_i, b_{k-1-i})} are the k smallest
+                    // of their union.  The lh partner comes by shuffle; the other code-side wave publishes its merged list
+                    // in LDS -- possibly one tile old, which is still a list of values of real codes, so T stays valid.
+                    float t;
+                    if (TOPK <= 5) {
+                        float c[TL];
+#pragma unroll
+                        for (int i = 0; i < TL; ++i) c[i] = fminf(tv[nn][i], __shfl_xor(tv[nn][TL - 1 - i], 32, 64));
+#pragma unroll
+                        for (int pass = 0; pass < TL; ++pass)              // odd-even transposition: c ascending
+#pragma unroll
+                            for (int i = pass & 1; i + 1 < TL; i += 2) {
+                                const float lo = fminf(c[i], c[i + 1]), hi = fmaxf(c[i], c[i + 1]);
+                                c[i] = lo; c[i + 1] = hi;
+                            }
+                        float *lst = thr_share + (size_t)(wn * (32 * F_NT) + nn * 32 + li) * 10;
+                        if (lh == 0) {
+#pragma unroll
+                            for (int i = 0; i < TL; ++i) lst[wm * 5 + i] = c[i];
+                        }
+                        t = -INFINITY;
+#pragma unroll
+                        for (int i = 0; i < TL; ++i) t = fmaxf(t, fminf(c[i], lst[(wm ^ 1) * 5 + TL - 1 - i]));
+                    } else {                 // k = 8: the lists would not fit beside the ring; the pair's looser min rule
+                        t = tv[nn][TOPK - 1];
+                        t = fminf(t, __shfl_xor(t, 32, 64));
                     }
-                    t = fminf(t, __shfl_xor(t, 32, 64));
                     lim[nn] = live[nn] ? fminf(t + win[nn], 3.0e38f) : -INFINITY;
                 }
             }

@@ -463,10 +463,9 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
     long want = f.row_tiles >= 1024 ? 2 : (1024 + f.row_tiles - 1) / f.row_tiles;
     // With >= 1024 row tiles the blocks are ordered XCD-aware (see filter_f16_kernel): the 32 CUs of an XCD share
     // 32/splits x tiles, which then stay in its 4 MB L2 (393 KB each at D = 768) instead of being re-streamed from
-    // the Infinity Cache once per code tile.  Measured at N = 600k: K = 49152 54.2 -> 50.0 ms with 4 splits,
-    // K = 16384 18.9 -> 17.9 ms with 2 (more splits loosen the per-split thresholds: more candidates).
+    // the Infinity Cache once per code tile (measured at N = 600k, K = 49152: 6-8 % on the kernel).  Two splits: more
+    // would keep more of the x tiles resident but loosen the per-split thresholds (4: +3.6 %, 8: +7.7 % kernel time).
     bool xcd = f.row_tiles >= 1024;
-    if (xcd && code_tiles >= 128) want = 4;
     if (const char *e = getenv("MEDTOK_FILTER_SPLITS")) want = atol(e);      // dev knobs (tools/xcd_experiment.py)
     if (const char *e = getenv("MEDTOK_FILTER_XCD")) xcd = atoi(e) != 0;
     if (want > code_tiles) want = code_tiles;
