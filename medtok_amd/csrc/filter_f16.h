@@ -452,6 +452,8 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
                     // of the union: 2-3 x the candidates.)  Two sorted lists a, b: {min(a_i, b_{k-1-i})} are the k smallest
                     // of their union.  The lh partner comes by shuffle; the other code-side wave publishes its merged list
                     // in LDS -- possibly one tile old, which is still a list of values of real codes, so T stays valid.
+                    // (Extending the union across code splits through agent-scope global lists was measured 10 % SLOWER:
+                    // the extra global loads/stores in the epilogue cost more than the candidates they save.)
                     float t;
                     if (TOPK <= 5) {
                         float c[TL];
