@@ -62,7 +62,10 @@ def max_over_ranks(value: float, device) -> float:
 
 def barrier():
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":        # name the device: RCCL otherwise guesses it from the rank
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
