@@ -1,0 +1,35 @@
+"""GPU: bench.py prints ONE JSON line that carries the driver's contract fields plus `roofline` and `cpu_baseline`
+(reduced row counts so the test takes seconds; the numbers themselves are not checked here)."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+@pytest.mark.parametrize("args", [["--rows", "20000", "--cpu-rows", "256"],
+                                  ["--workload", "cfg2", "--rows", "20000", "--cpu-rows", "512"],
+                                  ["--workload", "full", "--rows", "256", "--cpu-rows", "8"]])
+def test_bench_prints_one_contract_line(dev, args):
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", *args],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert REQUIRED <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["value"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and r["bound"] in ("hbm", "mfma")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] in ("port", "reference") and c["value"] > 0
+    e = d["exact_fp32_path"]
+    assert e is None or e["outputs_bit_identical_to_default_path"] is True
