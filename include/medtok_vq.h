@@ -160,7 +160,7 @@ int medtok_info_nce_backward_f32(const float *q, const float *k, const float *pr
  * over the code's own query rows [q_start[b], +q_len[b]) of q and key rows [kv_start[b], +kv_len[b]) of kv
  * (raw rows of the other modality; every head is just another query row).  Nothing is padded and the
  * rows x keys matrix never reaches memory.  max_q_len >= max_b q_len[b] sizes the grid (rows beyond a
- * code's q_len cost nothing); d % 128 == 0, d <= 768.  A code with kv_len == 0 yields NaN rows, as
+ * code's q_len cost nothing); d = 64 or d % 128 == 0, d <= 768.  A code with kv_len == 0 yields NaN rows, as
  * softmax over an empty set does in the reference.  q_start/q_len/kv_start/kv_len are DEVICE int64[n_codes]. */
 int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const int64_t *q_len,
                                    const float *kv, const int64_t *kv_start, const int64_t *kv_len,

@@ -8,7 +8,7 @@
 // query row).  Rows are ragged: code b owns q rows [q_start[b], +q_len[b]) and kv rows [kv_start[b], +kv_len[b]);
 // nothing is padded, nothing of size rows x keys reaches memory.
 //
-// Block = (32 query rows of one code) x all of its keys, W = 8 waves (D % 256 == 0) or 4 waves, one block per CU.  Both products run on the exact
+// Block = (32 query rows of one code) x all of its keys, W = 8 waves (D % 256 == 0), 4 waves (other multiples of 128) or 2 waves (D = 64).  Both products run on the exact
 // fp32 matrix pipe (v_mfma_f32_32x32x2_f32, 157 TF peak) -- fp16/bf16 inputs would break the 1e-5 parity bar:
 //   keys   : a chunk of 32 key rows is fetched with fully coalesced 16-byte loads (a thread's MFMA operands would be
 //            16 B out of every 128-byte line, re-fetching each line four times through a thrashing L1) and parked in
@@ -46,18 +46,18 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int slice = wave * 32 * NT;      // this wave's D columns [slice, slice + 32 NT)
 
-    // key chunk fetch: thread t owns float4 column (t % 32) + 32 ci of rows (t / 32) + 2W ri -- 32 consecutive threads read
-    // 512 contiguous bytes, and every LDS / global offset below is a compile-time constant off one per-thread base;
-    // rows past the code's last key are clamped (their probabilities are zero)
-    constexpr int RI = 16 / W, CI = D / 128, NF = RI * CI;      // NF = 4 NT float4 per thread per chunk
-    const int f_r0 = tid >> 5, f_c = (tid & 31) * 4;
+    // key chunk fetch: FT = min(32, D/4) consecutive threads read one row's 16-byte columns (512 contiguous bytes at
+    // D >= 128), thread t owns columns (t % FT) + FT ci of rows (t / FT) + RP ri; every LDS / global offset below is a
+    // compile-time constant off one per-thread base; rows past the code's last key are clamped (their probabilities are zero)
+    constexpr int FT = D / 4 < 32 ? D / 4 : 32, CI = D / 4 / FT, RP = THREADS / FT, RI = 32 / RP, NF = RI * CI;
+    const int f_r0 = tid / FT, f_c = (tid % FT) * 4;
     float4 kf[NF];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri) {
-            const float *src = kv + (ks + min(k0 + f_r0 + 2 * W * ri, kl - 1)) * (long)D + f_c;
+            const float *src = kv + (ks + min(k0 + f_r0 + RP * ri, kl - 1)) * (long)D + f_c;
 #pragma unroll
-            for (int ci = 0; ci < CI; ++ci) kf[ri * CI + ci] = ld4(src + 128 * ci);
+            for (int ci = 0; ci < CI; ++ci) kf[ri * CI + ci] = ld4(src + 4 * FT * ci);
         }
     };
     auto park = [&]() {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri)
 #pragma unroll
-            for (int ci = 0; ci < CI; ++ci) *reinterpret_cast<float4 *>(dst + 2 * W * ri * LD + 128 * ci) = kf[ri * CI + ci];
+            for (int ci = 0; ci < CI; ++ci) *reinterpret_cast<float4 *>(dst + RP * ri * LD + 4 * FT * ci) = kf[ri * CI + ci];
     };
     // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the key fetch that is meant to stay in
     // flight under the second product

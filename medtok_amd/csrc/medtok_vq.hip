@@ -906,14 +906,14 @@ extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_s
                                               int d, float scale, float *out, void *stream)
 {
     if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
-    if (d <= 0 || d % 128 || d > 768) return fail("shared_kv_attention: d=%d must be a multiple of 128, at most 768", d);
+    if (d != 64 && (d <= 0 || d % 128 || d > 768)) return fail("shared_kv_attention: d=%d must be 64 or a multiple of 128, at most 768", d);
     if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out) return fail("shared_kv_attention: NULL argument");
     if (n_codes == 0 || max_q_len == 0) return 0;
     if (n_codes > 65535) return fail("shared_kv_attention: at most 65535 codes per call (got %ld)", (long)n_codes);
     const dim3 grid((unsigned)((max_q_len + 31) / 32), (unsigned)n_codes);
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
-    const int waves = d % 256 == 0 ? 8 : 4;
+    const int waves = d == 64 ? 2 : (d % 256 == 0 ? 8 : 4);
     const size_t lds = ((size_t)32 * (d + 4) + (waves + 1) * 32 * 33 + 64) * sizeof(float);   // key chunk + per-wave partial scores + probabilities + row state
 #define MEDTOK_ATT(W, NT)                                                                                                        \
     do {                                                                                                                         \
@@ -923,6 +923,7 @@ extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_s
         hipLaunchKernelGGL((shared_kv_attention_kernel<W, NT>), grid, dim3(64 * W), lds, s, q, q_start, q_len, kv, kv_start, kv_len, scale, out); \
     } while (0)
     switch (d / 128) {
+    case 0: MEDTOK_ATT(2, 1); break;      // d = 64, the reference's default e_dim
     case 1: MEDTOK_ATT(4, 1); break;
     case 2: MEDTOK_ATT(8, 1); break;
     case 3: MEDTOK_ATT(4, 3); break;

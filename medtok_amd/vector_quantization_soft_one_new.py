@@ -171,12 +171,16 @@ class CrossAttention(nn.Module):
 
         seq_len, dim = text.shape[1], text.shape[2]
         heads = self.model[0].multihead_attn.num_heads
-        if fold is None:        # flops: 4 n D^2 + 4 n H T D folded  vs  4 T D^2 + 4 n T D projected
-            fold = max_nodes * (dim + (heads - 1) * seq_len) < seq_len * dim
         needs_grad = torch.is_grad_enabled() and (text.requires_grad or nodes.requires_grad
                                                   or any(p.requires_grad for p in self.parameters()))
-        packed = (fold and not self.training and not needs_grad and dim % 128 == 0 and dim <= 768 and text.dtype == torch.float32
-                  and not torch.is_autocast_enabled() and max_nodes > 0 and (core is not None or text.is_cuda))
+        kernel_ok = (not self.training and not needs_grad and (dim == 64 or (dim % 128 == 0 and dim <= 768))
+                     and text.dtype == torch.float32 and not torch.is_autocast_enabled() and max_nodes > 0
+                     and (core is not None or text.is_cuda))
+        if fold is None:
+            # flops: 4 n D^2 + 4 n H T D folded  vs  4 T D^2 + 4 n T D projected; where the ragged kernel can run the folded,
+            # packed form wins regardless (D = 64, B = 1024: 1.1 vs 2.4 ms -- no padding, a fraction of the launches)
+            fold = kernel_ok or max_nodes * (dim + (heads - 1) * seq_len) < seq_len * dim
+        packed = fold and kernel_ok
         if packed:
             return self._pooled_packed(text.contiguous(), valid.sum(1), nodes[order].contiguous(), batch[order], slot, counts, starts,
                                        max_nodes, core or ops.shared_kv_attention)

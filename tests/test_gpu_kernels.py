@@ -208,7 +208,7 @@ def test_code_sharded_merge_is_bit_exact(oracle, dev):
     assert torch.equal(idx_m, idx) and torch.equal(dist_m, dist)
 
 
-@pytest.mark.parametrize("d,heads,seed", [(128, 4, 0), (768, 4, 1), (512, 2, 2), (384, 1, 3), (640, 4, 4), (256, 4, 5)])
+@pytest.mark.parametrize("d,heads,seed", [(128, 4, 0), (768, 4, 1), (512, 2, 2), (384, 1, 3), (640, 4, 4), (256, 4, 5), (64, 4, 6)])
 def test_shared_kv_attention_matches_oracle(oracle, dev, d, heads, seed):
     """Ragged attention core vs the oracle's restatement (double accumulation): ragged query/key counts that are not
     multiples of the 32-row tiles, empty query sets, single keys, a key spike that forces the online-softmax rescale."""
@@ -242,4 +242,4 @@ def test_shared_kv_attention_rejects_bad_shapes(dev):
     from medtok_amd._lib import MedTokLibraryError
     z = torch.zeros(1, dtype=torch.int64, device=dev)
     with pytest.raises(MedTokLibraryError):
-        ops.shared_kv_attention(torch.zeros(4, 64, device=dev), z, z + 4, torch.zeros(4, 64, device=dev), z, z + 4, 4, 1.0)
+        ops.shared_kv_attention(torch.zeros(4, 96, device=dev), z, z + 4, torch.zeros(4, 96, device=dev), z, z + 4, 4, 1.0)

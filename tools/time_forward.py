@@ -20,4 +20,12 @@ for B, L, M, D, n_e in ((256, 512, 40, 64, 21000), (1024, 512, 40, 64, 21000), (
         t1 = time.perf_counter()
         for _ in range(20): v.cross_attn.pooled(args[1], args[3], args[2], args[4])
         torch.cuda.synchronize(); dc = (time.perf_counter() - t1) / 20
-    print(f"B={B} L={L} D={D} n_e={n_e}: forward {dt*1e3:.2f} ms ({B/dt:.0f} codes/s), cross-attention part {dc*1e3:.2f} ms", flush=True)
+        for _ in range(3): v.cross_attn.pooled(args[1], args[3], args[2], args[4], fold=True)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(20): v.cross_attn.pooled(args[1], args[3], args[2], args[4], fold=True)
+        torch.cuda.synchronize(); df = (time.perf_counter() - t1) / 20
+        for _ in range(3): v.cross_attn.pooled(args[1], args[3], args[2], args[4], fold=False)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(20): v.cross_attn.pooled(args[1], args[3], args[2], args[4], fold=False)
+        torch.cuda.synchronize(); dn = (time.perf_counter() - t1) / 20
+    print(f"B={B} L={L} D={D} n_e={n_e}: forward {dt*1e3:.2f} ms ({B/dt:.0f} codes/s), cross-attention part {dc*1e3:.2f} ms (forced fold/packed {df*1e3:.2f}, projected keys {dn*1e3:.2f})", flush=True)
