@@ -70,6 +70,11 @@ def load():
         raise MedTokLibraryError(
             f"{_SO} is missing: build it with `python medtok_amd/csrc/build.py` "
             "(hipcc --offload-arch=gfx950). medtok_amd has no CPU fallback.")
+    # Load order matters: PyTorch-ROCm ships its own libamdhip64 with the same soname as /opt/rocm's.  Whichever is
+    # mapped first serves BOTH this library and torch; if ours pulled in /opt/rocm's copy before torch was imported,
+    # torch would later run on a runtime it was not built against ("no ROCm-capable device is detected").  torch owns
+    # the device memory and streams this library works on, so its runtime goes first.
+    import torch  # noqa: F401
     lib = C.CDLL(str(_SO))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale

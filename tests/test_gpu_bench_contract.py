@@ -33,3 +33,11 @@ def test_bench_prints_one_contract_line(dev, args):
     assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] in ("port", "reference") and c["value"] > 0
     e = d["exact_fp32_path"]
     assert e is None or e["outputs_bit_identical_to_default_path"] is True
+
+
+def test_build_then_smoke_in_one_process(dev):
+    """The driver may call build() and smoke() from the same interpreter: the library is then loaded before anything
+    touched torch.cuda, which once left two HIP runtimes fighting over the device."""
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, (out.stdout + out.stderr)[-2000:]
