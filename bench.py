@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg5", "full"], default="cfg3",
-                    help="cfg3: full soft VQ (headline); full: cfg3 plus the ragged cross-attention of get_shared_info in front of it; cfg2: argmin+EMA train step, 100k rows, K=8192; cfg5: the same step on 600k rows "
+    ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg5", "full", "codeshard"], default="cfg3",
+                    help="cfg3: full soft VQ (headline); full: cfg3 plus the ragged cross-attention of get_shared_info in front of it; cfg2: argmin+EMA train step, 100k rows, K=8192; codeshard: one K=49152 soft top-5 search with the CODEBOOK sharded over the GPUs (every rank scores all rows "
+                         "against its slice; all-gather of the k-lists + exact merge); cfg5: the same step on 600k rows "
                          "TOTAL (split over the GPUs: strong scaling), K=16384, with the RCCL all-reduce of the EMA statistics")
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default 600000 for cfg3, 100000 for cfg2)")
     ap.add_argument("--path", type=int, default=ops.PATH_AUTO)
@@ -177,6 +178,56 @@ class Full(Cfg3):
                     sample=f"{n} codes: per-code cross-attention loop (the reference's form) + 4 dense searches in CPU PyTorch, {dt:.1f} s")
 
 
+class CodeShard:
+    """SURVEY 8e variant: the codebook is sharded over the ranks, every rank holds all rows.  A step = local top-k over the
+    rank's slice (HIP search) -> all-gather of (distance, global id) lists over RCCL -> exact merge -> soft assignment."""
+    name = "codeshard"
+    D, K, TOPK = 768, 49152, 5
+
+    def __init__(self, rows, dev, seed, path, rank, world):
+        self.rows, self.dev, self.path = rows, dev, path
+        g = torch.Generator(device=dev).manual_seed(4321)                       # the SAME rows and codebook on every rank
+        self.x = torch.randn(rows, self.D, device=dev, generator=g)
+        W = torch.randn(self.K, self.D, device=dev, generator=g)
+        self.what, self.wsq = ops.rownorm(W)
+        self.lo, self.hi = mdist.code_shard(self.K, rank, world)
+        self.description = (f"one soft top-5 search, {rows} rows (replicated) x K=49152 codes sharded x{world} "
+                            f"({self.hi - self.lo} codes/GPU), D=768; all-gather of the k-lists + exact merge")
+
+    def flops_per_code(self):
+        return 2.0 * self.D * self.K
+
+    def set_path(self, path):
+        self.path = path
+
+    def step(self):
+        xhat, xsq = ops.rownorm(self.x)
+        idx, dist_ = mdist.code_sharded_search(xhat, xsq, self.what[self.lo:self.hi], self.wsq[self.lo:self.hi].contiguous(), self.lo,
+                                               self.TOPK, search_fn=lambda a, b, c, d, k: ops.topk_search(a, b, c, d, k, self.path))
+        w, zq, _ = ops.soft_assign(self.x, self.what, idx, dist_, want_sqerr=False)
+        return idx, dist_, w, zq
+
+    def paths_agree(self):
+        outs = []
+        for path in (ops.PATH_AUTO, ops.PATH_F32_MFMA):
+            self.set_path(path)
+            outs.append(self.step())
+        self.set_path(ops.PATH_AUTO)
+        return all(torch.equal(u, v) for u, v in zip(*outs))
+
+    def cpu_baseline(self, sample_rows):
+        from oracle import torch_port as P
+        torch.set_num_threads(os.cpu_count() or 1)
+        g = torch.Generator().manual_seed(0)
+        W = torch.randn(self.K, self.D, generator=g); x = torch.randn(sample_rows, self.D, generator=g)
+        P.soft_search(x[:256], W, self.TOPK)
+        t0 = time.perf_counter()
+        P.soft_search(x, W, self.TOPK)
+        dt = time.perf_counter() - t0
+        return dict(value=sample_rows / dt, unit="codes/s", cores=torch.get_num_threads(), kind="port",
+                    sample=f"{sample_rows} rows, one dense K=49152 search + soft assignment in CPU PyTorch, {dt:.1f} s")
+
+
 class Cfg2:
     """Single-modality argmin + EMA train step (NormEMAVectorQuantizer), K = 8192."""
     name = "cfg2"
@@ -259,6 +310,9 @@ def main():
         wl.name = "cfg5"
         wl.description = (f"cfg5 NormEMA argmin + EMA update (train): {total_rows} rows total row-sharded x{world} ({rows}/GPU), D=768, "
                           f"K=16384, one all-reduce of [embed_sum | bins] = {16384 * 769 * 4 / 1e6:.1f} MB per step")
+    elif args.workload == "codeshard":
+        rows = args.rows or 600000
+        wl = CodeShard(rows, dev, seed=0, path=args.path, rank=rank, world=world)
     else:
         rows = args.rows or {"cfg3": 600000, "full": 4096}.get(args.workload, 100000)
         wl = {"cfg3": Cfg3, "full": Full}.get(args.workload, Cfg2)(rows, dev, seed=rank, path=args.path)
@@ -309,7 +363,7 @@ def main():
     achieved = kp["flops"] / (kp["ms"] * 1e-3) / 1e12 if kp["ms"] > 0 else 0.0
 
     if rank == 0:
-        total_codes = (float(args.rows or 600000) if args.workload == "cfg5" else float(rows) * world) * args.steps
+        total_codes = (float(args.rows or 600000) if args.workload in ("cfg5", "codeshard") else float(rows) * world) * args.steps
         value = total_codes / elapsed
         line = {
             "metric": "codes_per_sec_tokenized",
@@ -320,7 +374,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if args.workload == "cfg5" else "weak",
+            "scaling": "strong" if args.workload in ("cfg5", "codeshard") else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -328,7 +382,9 @@ def main():
                        "search": ("fp16-MFMA shortlist with a proven error bound + exact fp32 re-score: token ids and distances are "
                                   "bit-identical to the fp32-MFMA path (tests/test_gpu_filter.py)" if kname == "filter_f16_kernel"
                                   else "exact fp32 MFMA"),
-                       "parallelism": f"row-shard x{world}, codebook replicated, no data-path collective"},
+                       "parallelism": (f"code-shard x{world}: all-gather of the per-rank k-lists (n*k*12 B per rank) + exact merge"
+                                       if args.workload == "codeshard" else
+                                       f"row-shard x{world}, codebook replicated, no data-path collective")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic(wl.name, kname), "kernel": kname,
                          "peak_note": ("dense f16 MFMA" if kname == "filter_f16_kernel" else "dense f32-input MFMA") + " (MI355X_MICROARCH.md)",
