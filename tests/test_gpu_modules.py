@@ -341,3 +341,21 @@ def test_kmeans_init_path(dev):
     with torch.no_grad():
         q(z[:, :, None, None])
     assert torch.equal(q.embedding.weight.data, w_before)
+
+
+@pytest.mark.parametrize("B,L,M,D", [(48, 512, 40, 768), (64, 512, 40, 64), (32, 100, 200, 256)])
+def test_packed_cross_attention_equals_projected_form_at_full_dims(dev, B, L, M, D):
+    """BASELINE-sized ragged batch: the packed path (folded projections + ragged gfx950 attention kernel) against the padded
+    nn.MultiheadAttention form with projected keys -- two different evaluation orders of the reference's layers."""
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    from oracle import synth
+    torch.manual_seed(0)
+    v = VectorQuantizer(96, D, 0.25, 0.0, True, False, [D, D]).to(dev).eval()
+    text, mask, nodes, batch = synth.ragged_batch(f"full.{D}", B, L, M, D, 0)
+    perm = torch.randperm(nodes.shape[0], generator=torch.Generator().manual_seed(1))
+    a = [t.to(dev) for t in (text, mask, nodes[perm], batch[perm])]
+    with torch.no_grad():
+        pt_k, pg_k = v.cross_attn.pooled(*a)                 # packed + HIP kernel (eval, no grad, fp32)
+        pt_p, pg_p = v.cross_attn.pooled(*a, fold=False)     # padded, projected keys
+    for x, y in ((pt_k, pt_p), (pg_k, pg_p)):
+        assert float((x - y).abs().max() / y.abs().max()) <= 1e-5
