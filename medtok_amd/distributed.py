@@ -31,9 +31,13 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         use_gpu = torch.cuda.is_available()
         if use_gpu:
+            local = local % torch.cuda.device_count()   # (dev: several ranks may share one GPU under the gloo backend)
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend or ("nccl" if use_gpu else "gloo"), init_method="env://",
-                                rank=rank, world_size=world)
+        # MEDTOK_DIST_BACKEND=gloo: dev knob to run the N > 1 code paths on a single-GPU box (RCCL needs one GPU per rank)
+        backend = backend or os.environ.get("MEDTOK_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        local = local % max(torch.cuda.device_count(), 1)
     return rank, local, world
 
 

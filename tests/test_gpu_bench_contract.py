@@ -41,3 +41,22 @@ def test_build_then_smoke_in_one_process(dev):
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0 and "smoke ok" in out.stdout, (out.stdout + out.stderr)[-2000:]
+
+
+@pytest.mark.parametrize("workload", ["cfg3", "cfg5", "codeshard"])
+def test_two_rank_bench_on_one_gpu(dev, workload):
+    """The N > 1 code paths of bench.py (barrier, max-over-ranks timing, the EMA all-reduce, the k-list all-gather) with two
+    ranks sharing this box's GPU over gloo (MEDTOK_DIST_BACKEND: RCCL itself needs one GPU per rank)."""
+    import os
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MEDTOK_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--workload", workload, "--rows", "20000"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["cpu_baseline"] is None
+    assert d["scaling"] == ("weak" if workload == "cfg3" else "strong")
