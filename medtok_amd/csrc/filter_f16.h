@@ -309,6 +309,10 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // (+2.5-3 % measured).  Either way a wave has issued all of stage s+3 between the waits of iterations s and s+1,
     // so the counted vmcnt below is the same for both halves.
     const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+    // The second-dispatched half of the block loses issue arbitration to the older half at every segment start
+    // (priority, then age): one static priority bump for it, no flips inside the loop (+1.5-2 %; flips around the MFMA
+    // groups measured -1 %).
+    if (late) __builtin_amdgcn_s_setprio(1);
     for (int s = 0; s < nstage; ++s) {
         if (late && s > 0) stage();         // waves 4-7: stage s+2 (slot s-2, free since the barrier of iteration s-1)
         constexpr int NRD = F_MT + F_NT;     // operand reads per k16-step (8 MFMAs)
