@@ -34,7 +34,9 @@ def hipcc() -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    newest = max(SRC.stat().st_mtime, HEADER.stat().st_mtime, Path(__file__).stat().st_mtime)
+    # every source the translation unit includes (medtok_vq.hip pulls in the *.h next to it)
+    deps = [SRC, HEADER, Path(__file__), *HERE.glob("*.h")]
+    newest = max(p.stat().st_mtime for p in deps)
     if not force and OUT.exists() and OUT.stat().st_mtime >= newest:
         return OUT
     extra = os.environ.get("MEDTOK_HIPCC_EXTRA", "").split()     # dev knob, e.g. -DMEDTOK_SEARCH_BK=16
