@@ -310,8 +310,8 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // so the counted vmcnt below is the same for both halves.
     const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
     // The second-dispatched half of the block loses issue arbitration to the older half at every segment start
-    // (priority, then age): one static priority bump for it, no flips inside the loop (+3-4 % at the highest level,
-    // +1.5-2 % at level 1, -1.5 % when given to the older half instead; flips around the MFMA groups measured -1 %).
+    // (priority, then age): one static priority bump for it, no flips inside the loop (+2 %, levels 1 and 3 alike;
+    // -1.5 % when given to the older half instead; flips around the MFMA groups measured -1 %).
     if (late) __builtin_amdgcn_s_setprio(3);
     for (int s = 0; s < nstage; ++s) {
         if (late && s > 0) stage();         // waves 4-7: stage s+2 (slot s-2, free since the barrier of iteration s-1)
