@@ -861,7 +861,15 @@ extern "C" int medtok_normalize_backward_f32(const float *g, const float *vhat, 
     return check_launch("normalize_backward");
 }
 
-static size_t info_nce_lds_bytes(int64_t b, int d) { return ((size_t)b + (size_t)d + 4) * sizeof(float); }
+// rows per block of the InfoNCE kernels: sharing a fetched key row among 8 / 4 / 2 rows cuts the L2 traffic, but only once
+// there are enough rows to keep >= 256 blocks (at the training batch of 256, one row per block: parallelism wins)
+static int info_nce_rows(int64_t b, int d)
+{
+    for (int rt = 8; rt > 1; rt >>= 1)
+        if (b / rt >= 256 && ((size_t)rt * ((size_t)b + (size_t)d) + 4) * sizeof(float) <= 64 * 1024) return rt;
+    return 1;
+}
+static size_t info_nce_lds_bytes(int64_t b, int d, int rt) { return ((size_t)rt * ((size_t)b + (size_t)d) + 4) * sizeof(float); }
 
 extern "C" size_t medtok_info_nce_workspace_bytes(int64_t b, int d)
 {
@@ -875,12 +883,19 @@ extern "C" int medtok_info_nce_forward_f32(const float *q, const float *k, int64
     if (!(temperature > 0.f)) return fail("info_nce: temperature must be positive");
     if (!q || !k || !loss || !prob || !ws) return fail("info_nce: NULL argument");
     if (ws_bytes < medtok_info_nce_workspace_bytes(b, d)) return fail("info_nce: workspace too small");
-    if (info_nce_lds_bytes(b, d) > 64 * 1024) return fail("info_nce: b + d = %ld exceeds the 64 KB LDS row budget", (long)(b + d));
+    const int rt = info_nce_rows(b, d);
+    if (info_nce_lds_bytes(b, d, rt) > 64 * 1024) return fail("info_nce: b + d = %ld exceeds the 64 KB LDS row budget", (long)(b + d));
     hipStream_t s = (hipStream_t)stream;
     float *qhat = (float *)ws, *khat = qhat + b * d, *row_loss = khat + b * d;
     hipLaunchKernelGGL(info_nce_prepare_kernel, dim3((unsigned)((2 * b + 3) / 4)), dim3(256), 0, s, q, k, (long)b, d, qhat, khat);
-    hipLaunchKernelGGL(info_nce_forward_kernel, dim3((unsigned)b), dim3(256), info_nce_lds_bytes(b, d), s, qhat, khat, (int)b, d,
-                       1.f / temperature, prob, row_loss);
+    const dim3 fgrid((unsigned)((b + rt - 1) / rt));
+    const size_t lds = info_nce_lds_bytes(b, d, rt);
+    switch (rt) {
+    case 8: hipLaunchKernelGGL(info_nce_forward_kernel<8>, fgrid, dim3(256), lds, s, qhat, khat, (int)b, d, 1.f / temperature, prob, row_loss); break;
+    case 4: hipLaunchKernelGGL(info_nce_forward_kernel<4>, fgrid, dim3(256), lds, s, qhat, khat, (int)b, d, 1.f / temperature, prob, row_loss); break;
+    case 2: hipLaunchKernelGGL(info_nce_forward_kernel<2>, fgrid, dim3(256), lds, s, qhat, khat, (int)b, d, 1.f / temperature, prob, row_loss); break;
+    default: hipLaunchKernelGGL(info_nce_forward_kernel<1>, fgrid, dim3(256), lds, s, qhat, khat, (int)b, d, 1.f / temperature, prob, row_loss); break;
+    }
     hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(1024), 0, s, row_loss, (long)b, 1.0 / (double)b, loss);
     return check_launch("info_nce_forward");
 }
@@ -891,10 +906,18 @@ extern "C" int medtok_info_nce_backward_f32(const float *q, const float *k, cons
     if (b <= 0 || d <= 0 || (d & 3)) return fail("info_nce_backward: bad shape b=%ld d=%d", (long)b, d);
     if (!q || !k || !prob || !g_loss || !gq || !gk || !ws) return fail("info_nce_backward: NULL argument");
     if (ws_bytes < medtok_info_nce_workspace_bytes(b, d)) return fail("info_nce_backward: workspace too small");
-    if (info_nce_lds_bytes(b, d) > 64 * 1024) return fail("info_nce_backward: b + d = %ld exceeds the 64 KB LDS row budget", (long)(b + d));
+    const int rt = info_nce_rows(b, d);
+    if (info_nce_lds_bytes(b, d, rt) > 64 * 1024) return fail("info_nce_backward: b + d = %ld exceeds the 64 KB LDS row budget", (long)(b + d));
     const float *qhat = (const float *)ws, *khat = qhat + b * d;
-    hipLaunchKernelGGL(info_nce_backward_kernel, dim3((unsigned)(2 * b)), dim3(256), info_nce_lds_bytes(b, d), (hipStream_t)stream,
-                       q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk);
+    const dim3 bgrid((unsigned)(2 * ((b + rt - 1) / rt)));
+    const size_t lds = info_nce_lds_bytes(b, d, rt);
+    hipStream_t s = (hipStream_t)stream;
+    switch (rt) {
+    case 8: hipLaunchKernelGGL(info_nce_backward_kernel<8>, bgrid, dim3(256), lds, s, q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk); break;
+    case 4: hipLaunchKernelGGL(info_nce_backward_kernel<4>, bgrid, dim3(256), lds, s, q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk); break;
+    case 2: hipLaunchKernelGGL(info_nce_backward_kernel<2>, bgrid, dim3(256), lds, s, q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk); break;
+    default: hipLaunchKernelGGL(info_nce_backward_kernel<1>, bgrid, dim3(256), lds, s, q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk); break;
+    }
     return check_launch("info_nce_backward");
 }
 

@@ -199,66 +199,117 @@ __device__ __forceinline__ float block256_reduce(float v, float *sh, bool is_max
     return is_max ? fmaxf(fmaxf(a, b2), fmaxf(c, e)) : (a + b2) + (c + e);
 }
 
+// RT query rows per block: every key row fetched from L2 serves RT dot products (one block per row re-read the whole
+// key matrix, B x D x 4 bytes, B times: 400 MB of L2 traffic at B = 256, D = 1536 -- 90 us for 0.2 GFLOP).
+template <int RT>
 __global__ __launch_bounds__(256) void info_nce_forward_kernel(const float *__restrict__ qhat, const float *__restrict__ khat, int b, int d,
                                                                float inv_temp, float *__restrict__ prob, float *__restrict__ row_loss)
 {
-    extern __shared__ float sm[];          // [d] query row, [b] logits, [4] reduction scratch
-    float *qs = sm, *lg = sm + d, *red = lg + b;
-    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = threadIdx.x * 4; c < d; c += 1024) st4(qs + c, ld4(qhat + (long)i * d + c));
-    __syncthreads();
-    for (int j = wave; j < b; j += 4) {
-        const float *kr = khat + (long)j * d;
-        float p = 0.f;
-        for (int c = lane * 4; c < d; c += 256) {
-            const float4 a = ld4(kr + c), q4 = *reinterpret_cast<const float4 *>(qs + c);
-            p = fmaf(a.x, q4.x, p); p = fmaf(a.y, q4.y, p); p = fmaf(a.z, q4.z, p); p = fmaf(a.w, q4.w, p);
-        }
-        p = wave_butterfly_sum(p);
-        if (lane == 0) lg[j] = p * inv_temp;
+    extern __shared__ float sm[];          // [RT][d] query rows, [RT][b] logits, [4] reduction scratch
+    float *qs = sm, *lg = sm + RT * d, *red = lg + RT * b;
+    const int i0 = blockIdx.x * RT, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = threadIdx.x * 4; t < RT * d; t += 1024) {
+        const int r = t / d, c = t - r * d;
+        st4(qs + t, ld4(qhat + (long)min(i0 + r, b - 1) * d + c));
     }
     __syncthreads();
-    float m = -INFINITY;
-    for (int j = threadIdx.x; j < b; j += 256) m = fmaxf(m, lg[j]);
-    m = block256_reduce(m, red, true);
-    float s = 0.f;
-    for (int j = threadIdx.x; j < b; j += 256) s += expf(lg[j] - m);
-    s = block256_reduce(s, red, false);
-    const float lse = m + logf(s);
-    for (int j = threadIdx.x; j < b; j += 256) prob[(long)i * b + j] = expf(lg[j] - lse);
-    if (threadIdx.x == 0) row_loss[i] = lse - lg[i];
+    // KU key rows per step: their loads are independent, so one L2 round trip covers KU dot products
+    constexpr int KU = 4;
+    for (int j0 = wave * KU; j0 < b; j0 += 4 * KU) {
+        float p[RT][KU];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int u = 0; u < KU; ++u) p[r][u] = 0.f;
+        for (int c = lane * 4; c < d; c += 256) {
+            float4 a[KU];
+#pragma unroll
+            for (int u = 0; u < KU; ++u) a[u] = ld4(khat + (long)min(j0 + u, b - 1) * d + c);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(qs + r * d + c);
+#pragma unroll
+                for (int u = 0; u < KU; ++u) {
+                    p[r][u] = fmaf(a[u].x, q4.x, p[r][u]); p[r][u] = fmaf(a[u].y, q4.y, p[r][u]);
+                    p[r][u] = fmaf(a[u].z, q4.z, p[r][u]); p[r][u] = fmaf(a[u].w, q4.w, p[r][u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const float v = wave_butterfly_sum(p[r][u]);
+                if (lane == 0 && j0 + u < b) lg[r * b + j0 + u] = v * inv_temp;
+            }
+    }
+    __syncthreads();
+    for (int r = 0; r < RT; ++r) {          // (uniform trip count: block256_reduce holds barriers)
+        const int i = i0 + r;
+        const float *l = lg + r * b;
+        float m = -INFINITY;
+        for (int j = threadIdx.x; j < b; j += 256) m = fmaxf(m, l[j]);
+        m = block256_reduce(m, red, true);
+        float sum = 0.f;
+        for (int j = threadIdx.x; j < b; j += 256) sum += expf(l[j] - m);
+        sum = block256_reduce(sum, red, false);
+        const float lse = m + logf(sum);
+        if (i < b) {
+            for (int j = threadIdx.x; j < b; j += 256) prob[(long)i * b + j] = expf(l[j] - lse);
+            if (threadIdx.x == 0) row_loss[i] = lse - l[i];
+        }
+    }
 }
 
-// Backward: dl_ij = g (prob_ij - [i == j]) / b.  Blocks [0, b) produce g_q rows, blocks [b, 2b) g_k rows:
+// Backward: dl_ij = g (prob_ij - [i == j]) / b.  Blocks [0, nb) produce g_q rows, blocks [nb, 2 nb) g_k rows (RT rows each):
 //   g_qhat_i = (1/T) sum_j dl_ij khat_j,   g_khat_j = (1/T) sum_i dl_ij qhat_i,   then through F.normalize.
+template <int RT>
 __global__ __launch_bounds__(256) void info_nce_backward_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                 const float *__restrict__ qhat, const float *__restrict__ khat,
                                                                 const float *__restrict__ prob, const float *__restrict__ g_loss,
                                                                 int b, int d, float inv_temp, float *__restrict__ gq, float *__restrict__ gk)
 {
-    extern __shared__ float sm[];          // [b] coefficients, [d] gradient w.r.t. the normalised row, [4] scratch
-    float *cf = sm, *gh = sm + b, *red = gh + d;
-    const bool qside = (int)blockIdx.x < b;
-    const int r = qside ? blockIdx.x : blockIdx.x - b;
+    extern __shared__ float sm[];          // [RT][b] coefficients, [RT][d] gradients w.r.t. the normalised rows, [4] scratch
+    float *cf = sm, *gh = sm + RT * b, *red = gh + RT * d;
+    const int nb = (b + RT - 1) / RT;
+    const bool qside = (int)blockIdx.x < nb;
+    const int r0 = (qside ? blockIdx.x : blockIdx.x - nb) * RT;
     const float scale = g_loss[0] * inv_temp / (float)b;
-    for (int j = threadIdx.x; j < b; j += 256) {
+    for (int t = threadIdx.x; t < RT * b; t += 256) {
+        const int rr = t / b, j = t - rr * b, r = min(r0 + rr, b - 1);
         const float p = qside ? prob[(long)r * b + j] : prob[(long)j * b + r];
-        cf[j] = scale * (p - (j == r ? 1.f : 0.f));
+        cf[t] = scale * (p - (j == r ? 1.f : 0.f));
     }
     __syncthreads();
     const float *other = qside ? khat : qhat;
-    const float *mine_hat = (qside ? qhat : khat) + (long)r * d, *mine = (qside ? q : k) + (long)r * d;
-    float dp = 0.f, vv = 0.f;
     for (int c = threadIdx.x; c < d; c += 256) {
-        float a = 0.f;
-        for (int j = 0; j < b; ++j) a = fmaf(cf[j], other[(long)j * d + c], a);
-        gh[c] = a;
-        dp = fmaf(mine_hat[c], a, dp);
-        vv = fmaf(mine[c], mine[c], vv);
+        float a[RT];
+#pragma unroll
+        for (int rr = 0; rr < RT; ++rr) a[rr] = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < b; ++j) {            // (unrolled: eight independent loads per L2 round trip)
+            const float o = other[(long)j * d + c];
+#pragma unroll
+            for (int rr = 0; rr < RT; ++rr) a[rr] = fmaf(cf[rr * b + j], o, a[rr]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < RT; ++rr) gh[rr * d + c] = a[rr];
     }
-    dp = block256_reduce(dp, red, false);
-    vv = block256_reduce(vv, red, false);
-    const float inv = 1.f / fmaxf(sqrtf(vv), 1e-12f);
-    float *out = (qside ? gq : gk) + (long)r * d;
-    for (int c = threadIdx.x; c < d; c += 256) out[c] = (gh[c] - mine_hat[c] * dp) * inv;
+    __syncthreads();
+    for (int rr = 0; rr < RT; ++rr) {
+        const int r = min(r0 + rr, b - 1);
+        const float *mine_hat = (qside ? qhat : khat) + (long)r * d, *mine = (qside ? q : k) + (long)r * d;
+        float dp = 0.f, vv = 0.f;
+        for (int c = threadIdx.x; c < d; c += 256) {
+            dp = fmaf(mine_hat[c], gh[rr * d + c], dp);
+            vv = fmaf(mine[c], mine[c], vv);
+        }
+        dp = block256_reduce(dp, red, false);
+        vv = block256_reduce(vv, red, false);
+        const float inv = 1.f / fmaxf(sqrtf(vv), 1e-12f);
+        if (r0 + rr < b) {
+            float *out = (qside ? gq : gk) + (long)r * d;
+            for (int c = threadIdx.x; c < d; c += 256) out[c] = (gh[rr * d + c] - mine_hat[c] * dp) * inv;
+        }
+    }
 }
