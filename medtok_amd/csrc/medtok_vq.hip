@@ -389,7 +389,9 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
     }
 }
 
-// Joins the per-split candidate lists of one row (thread per row).
+// Joins the per-split candidate lists of one row: 8 lanes per row, each folds every 8th split, then three shuffle rounds.
+// (d, index) is a total order, so the result does not depend on who inserts what when.  (A thread per row walked
+// up to 64 splits x k entries serially: 90 us for a 256-row batch.)
 template <int TOPK>
 __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict__ pval, const int *__restrict__ pidx,
                                                          long n, int splits, int topk_out,
@@ -397,18 +399,29 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict
                                                          const int *__restrict__ row_list, const int *__restrict__ row_count)
 {
     // with a row list: partial lists are indexed by list position (extent n), results go to row_list[position]
-    const long pos = (long)blockIdx.x * 256 + threadIdx.x;
-    if (pos >= n || (row_list && pos >= *row_count)) return;
-    const long row = pos;
+    const int l8 = threadIdx.x & 7;
+    const long pos = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const long limit = row_list ? min(n, (long)*row_count) : n;
+    const long row = min(pos, n - 1);                    // lanes past the end keep shuffling with their group, write nothing
     float bv[TOPK];
     int bi[TOPK];
 #pragma unroll
     for (int j = 0; j < TOPK; ++j) { bv[j] = INFINITY; bi[j] = 0x7fffffff; }
-    for (int s = 0; s < splits; ++s) {
+    for (int s = l8; s < splits; s += 8) {
         const long base = ((long)s * n + row) * TOPK;
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) topk_insert_lex<TOPK>(bv, bi, pval[base + j], pidx[base + j]);
     }
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) {
+        float pv[TOPK];
+        int pi[TOPK];
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) { pv[j] = __shfl_xor(bv[j], off, 8); pi[j] = __shfl_xor(bi[j], off, 8); }
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) topk_insert_lex<TOPK>(bv, bi, pv[j], pi[j]);
+    }
+    if (l8 != 0 || pos >= limit) return;
     const long orow = row_list ? (long)row_list[pos] : row;
 #pragma unroll
     for (int j = 0; j < TOPK; ++j)
@@ -567,7 +580,7 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
                        (const int *)nullptr, (const int *)nullptr, 0, 0);
     if (pa) g_prof.push_back({pa, prof_mark(s), pflops, 1});
     if (check_launch("search_f32(split)")) return 1;
-    hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pval, pidx, (long)n,
+    hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, pval, pidx, (long)n,
                        p.splits, topk, idx, dist, (const int *)nullptr, (const int *)nullptr);
     return check_launch("merge_topk");
 }
@@ -616,7 +629,7 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL, true>), dim3((unsigned)((head + S_BN - 1) / S_BN), (unsigned)fb_nsplit), dim3(256), S_LDS_BYTES, s,
                        xhat, xsq, what, wsq, (long)n, (int)k_codes, d, fb_cps, topk, w.fb_pval, w.fb_pidx, (int64_t *)nullptr, (float *)nullptr,
                        (const int *)w.fb_rows, (const int *)w.fb_count, 0, head);
-    hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((head + 255) / 256)), dim3(256), 0, s, w.fb_pval, w.fb_pidx, (long)head,
+    hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((head + 31) / 32)), dim3(256), 0, s, w.fb_pval, w.fb_pidx, (long)head,
                        fb_nsplit, topk, idx, dist, (const int *)w.fb_rows, (const int *)w.fb_count);
     if (n > head) {
         (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, true, KTAIL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
