@@ -448,7 +448,11 @@ static SearchPlan plan_search(int64_t n, int64_t k_codes, int topk)
     long want = (16384 + p.row_tiles - 1) / p.row_tiles;
     if (want < 1) want = 1;
     if (want > code_tiles) want = code_tiles;
-    if (want > 64) want = 64;
+    // at most 64 splits -- except for one or two row tiles (batches of <= 256 rows), where 64 splits would leave half
+    // the CUs without a block: n = 256, K = 49152: 463 -> 276 us with 128 splits; n = 64: 459 -> 202 us with 256
+    long cap = p.row_tiles <= 2 ? 256 / p.row_tiles : 64;
+    if (const char *e = getenv("MEDTOK_SEARCH_MAXSPLITS")) cap = atol(e);      // dev knob (tools/small_batch_search.py)
+    if (want > cap) want = cap;
     const long tiles_per_split = (code_tiles + want - 1) / want;
     p.codes_per_split = (int)(tiles_per_split * S_BM);
     p.splits = (int)((code_tiles + tiles_per_split - 1) / tiles_per_split);
