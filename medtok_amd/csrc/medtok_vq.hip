@@ -486,7 +486,7 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
     if (const char *e = getenv("MEDTOK_FILTER_SPLITS")) want = atol(e);      // dev knobs (tools/xcd_experiment.py)
     if (const char *e = getenv("MEDTOK_FILTER_XCD")) xcd = atoi(e) != 0;
     if (want > code_tiles) want = code_tiles;
-    if (want > 16) want = 16;
+    if (want > 16) want = 16;      // (more splits for small batches were measured: slower from 32 up)
     if (want < 1) want = 1;
     const long tiles_per_split = (code_tiles + want - 1) / want;
     f.codes_per_split = (int)(tiles_per_split * F_BM);
@@ -535,8 +535,18 @@ static bool filter_eligible(int64_t n, int64_t k_codes, int d, int topk)
     // the filter path has ~0.1-0.2 ms of fixed cost (operand conversion, three extra launches); measured
     // crossover against the exact kernel on MI355X is around 1e10 flop (tools/path_crossover.py)
     // (k_codes * d < 2^29: the kernel addresses a code split's fp16 image with a 32-bit buffer offset)
-    return n >= 512 && k_codes >= 1024 && 2.0 * (double)n * (double)k_codes * (double)d >= 1.0e10 &&
-           topk <= MEDTOK_MAX_TOPK && n < (1ll << 31) && (double)k_codes * (double)(d + 64) < 536870912.0;
+    const double flops = 2.0 * (double)n * (double)k_codes * (double)d;
+    if (!(n >= 512 && k_codes >= 1024 && flops >= 1.0e10 && topk <= MEDTOK_MAX_TOPK && n < (1ll << 31) &&
+          (double)k_codes * (double)(d + 64) < 536870912.0))
+        return false;
+    // Few rows: the filter's floor is converting the codebook plus one block walking K/16 codes (about 1.1 us per
+    // 256-code tile and k block), the exact kernel runs at about 100 TFLOP/s once D is a few hundred
+    // (tools/path_crossover.py, tools/small_batch_filter.py: D = 768, K = 8192, N = 1024: exact 150 us, filter 229 us).
+    if (d >= 256) {
+        const double filter_floor = 0.17e-3 + ((double)k_codes / 4096.0) * ((double)d / 32.0) * 1.1e-6;
+        if (flops / 1.0e14 < filter_floor) return false;
+    }
+    return true;
 }
 
 static int resolve_path(int path, int64_t n, int64_t k_codes, int d, int topk)
