@@ -203,7 +203,8 @@ int medtok_usage_update(float *window, int64_t window_len, const int64_t *ids, i
 /* One-call forward of VectorQuantizer.specific_embedding / the search half of
  * get_shared_info (vector_quantization_soft_one_new.py:147-182,194-214) for
  * rows x [n, d] against an already normalised codebook slice:
- * rownorm(x) -> search -> soft assign.  Outputs as in the pieces above. */
+ * rownorm(x) -> search -> soft assign.  Outputs as in the pieces above (on the filter path without row_sqerr the
+ * assignment is fused into the re-score kernel: same bits, one gather of the top-k code rows less). */
 size_t medtok_soft_vq_workspace_bytes(int64_t n, int64_t k_codes, int d, int topk, int path);
 int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d,
                                const float *what, const float *wsq, int64_t k_codes,

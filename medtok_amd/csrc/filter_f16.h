@@ -513,7 +513,8 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     const uint2 *__restrict__ cand, const int *__restrict__ cand_cnt, int own_total,
     const float *__restrict__ xhat, const float *__restrict__ xsq, const float *__restrict__ what,
     const float *__restrict__ wsq, const float *__restrict__ en_max_ptr, long n, int k_codes, int d, int topk_out,
-    int64_t *__restrict__ out_idx, float *__restrict__ out_dist, int *__restrict__ fb_count, int *__restrict__ fb_rows)
+    int64_t *__restrict__ out_idx, float *__restrict__ out_dist, int *__restrict__ fb_count, int *__restrict__ fb_rows,
+    const float *__restrict__ xref, float *__restrict__ w_out, float *zq_out, long zq_stride)
 {
     __shared__ int s_code[R_ROWS * R_SURV];
     __shared__ float s_d[R_ROWS * R_SURV];
@@ -639,6 +640,39 @@ __global__ __launch_bounds__(256) void rescore_kernel(
 #pragma unroll
         for (int j = 0; j < TOPK; ++j)
             if (j < topk_out) { out_idx[row * topk_out + j] = bi[j]; out_dist[row * topk_out + j] = bv[j]; }
+    }
+    // ---- phase 4 (one-call forward only): the soft assignment of soft_assign_kernel, same arithmetic, while the top-k
+    // code rows this block has just re-scored are still hot in the L2 (a separate launch re-gathers them from the
+    // Infinity Cache: 9 GB per 600k-row search).  The row's 8 lanes all hold the merged (bv, bi) lists.
+    if (zq_out && pos < n) {
+        float wj[TOPK];
+        const float m = -bv[0];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j)
+            if (j < topk_out) { wj[j] = expf(-bv[j] - m); sum += wj[j]; }
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j)
+            if (j < topk_out) wj[j] = wj[j] / sum;
+        if (w_out && l8 == 0) {
+#pragma unroll
+            for (int j = 0; j < TOPK; ++j)
+                if (j < topk_out) w_out[row * topk_out + j] = wj[j];
+        }
+        const float *xr = xref + row * d;
+        float *o = zq_out + row * zq_stride;
+        for (int i = l8 * 4; i < d; i += 32) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < TOPK; ++j)
+                if (j < topk_out) {
+                    const float4 e = ld4(what + (long)bi[j] * d + i);
+                    a.x = fmaf(wj[j], e.x, a.x); a.y = fmaf(wj[j], e.y, a.y);
+                    a.z = fmaf(wj[j], e.z, a.z); a.w = fmaf(wj[j], e.w, a.w);
+                }
+            const float4 x = ld4(xr + i);
+            st4(o + i, make_float4(x.x + (a.x - x.x), x.y + (a.y - x.y), x.z + (a.z - x.z), x.w + (a.w - x.w)));
+        }
     }
 }
 

@@ -608,6 +608,11 @@ static int launch_search_t(const float *xhat, const float *xsq, int64_t n, const
     return launch_search<T, false>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
 }
 
+// Set by medtok_soft_vq_forward_f32 around its search call: when the filter path runs, its re-score kernel also does the
+// soft assignment (and the exact-path leftovers get it from soft_assign_kernel through the row list).
+struct FuseAssign { const float *xref; float *w; float *zq; long zq_stride; bool done; const int *fb_rows, *fb_count; };
+static thread_local FuseAssign *g_fuse = nullptr;
+
 template <int T, bool KTAIL>
 static int launch_filter(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
                          int64_t k_codes, int d, int topk, int64_t *idx, float *dist, void *ws, size_t ws_bytes,
@@ -631,7 +636,9 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     if (pa) g_prof.push_back({pa, prof_mark(s), 2.0 * (double)n * (double)k_codes * (double)d, 0});
     if (check_launch("filter_f16")) return 1;
     hipLaunchKernelGGL((rescore_kernel<T>), dim3((unsigned)((n + R_ROWS - 1) / R_ROWS)), dim3(256), 0, s, w.cand, w.cand_cnt, f.own_total,
-                       xhat, xsq, what, wsq, w.en_max, (long)n, (int)k_codes, d, topk, idx, dist, w.fb_count, w.fb_rows);
+                       xhat, xsq, what, wsq, w.en_max, (long)n, (int)k_codes, d, topk, idx, dist, w.fb_count, w.fb_rows,
+                       g_fuse ? g_fuse->xref : (const float *)nullptr, g_fuse ? g_fuse->w : (float *)nullptr,
+                       g_fuse ? g_fuse->zq : (float *)nullptr, g_fuse ? g_fuse->zq_stride : 0L);
     if (check_launch("rescore")) return 1;
     // exact redo of the rows the filter gave up on (normally none: every block exits on *fb_count)
     const long code_tiles = (k_codes + S_BM - 1) / S_BM;
@@ -651,6 +658,7 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
                            xhat, xsq, what, wsq, (long)n, (int)k_codes, d, (int)(code_tiles * S_BM), topk,
                            (float *)nullptr, (int *)nullptr, idx, dist, (const int *)w.fb_rows, (const int *)w.fb_count, head, (int)n);
     }
+    if (g_fuse) { g_fuse->done = true; g_fuse->fb_rows = w.fb_rows; g_fuse->fb_count = w.fb_count; }
     return check_launch("search_f32(fallback)");
 }
 
@@ -767,12 +775,17 @@ template <int MAXK>
 __global__ __launch_bounds__(256) void soft_assign_kernel(const float *__restrict__ xref, const float *__restrict__ what,
                                                           const int64_t *__restrict__ idx, const float *__restrict__ dist,
                                                           long n, int d, int topk, int flags, float *__restrict__ w_out,
-                                                          float *zq_ste, long zq_stride, float *__restrict__ row_sqerr)
+                                                          float *zq_ste, long zq_stride, float *__restrict__ row_sqerr,
+                                                          const int *__restrict__ row_list, const int *__restrict__ row_count)
 {
     const bool hard = flags & MEDTOK_ASSIGN_HARD, raw = flags & MEDTOK_ASSIGN_RAW;
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
+    if (row_list) {                    // only the listed rows (the filter's exact-path leftovers after a fused assignment)
+        if (row >= *row_count) return;
+        row = row_list[row];
+    }
     float wj[MAXK];
     long cj[MAXK];
     if (hard) {
@@ -835,7 +848,8 @@ extern "C" int medtok_soft_assign_f32(const float *xref, const float *what, cons
     if (!zq_ste) return fail("soft_assign: zq_ste required");
     if (n == 0) return 0;
     hipLaunchKernelGGL((soft_assign_kernel<MEDTOK_MAX_TOPK>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       xref, what, idx, dist, (long)n, d, topk, flags, w, zq_ste, (long)zq_stride, row_sqerr);
+                       xref, what, idx, dist, (long)n, d, topk, flags, w, zq_ste, (long)zq_stride, row_sqerr,
+                       (const int *)nullptr, (const int *)nullptr);
     return check_launch("soft_assign");
 }
 
@@ -1372,6 +1386,18 @@ extern "C" int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d, cons
     float *xsq = (float *)ws;
     void *sws = (char *)ws + align_up((size_t)n * 4, 256);
     if (medtok_rownorm_f32(x, n, d, 1, xhat, xsq, stream)) return 1;
-    if (medtok_topk_search_f32(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, sws, ws_bytes - align_up((size_t)n * 4, 256), path, stream)) return 1;
-    return medtok_soft_assign_f32(x, what, idx, dist, n, d, topk, 0, w, zq_ste, zq_stride, row_sqerr, stream);
+    // Without the squared-error output (its summation order is the stand-alone kernel's) the filter path's re-score kernel
+    // does the soft assignment itself, bit for bit the same, while the top-k code rows are hot in the L2.
+    if (zq_stride == 0) zq_stride = d;
+    FuseAssign fuse = {x, w, zq_ste, (long)zq_stride, false, nullptr, nullptr};
+    const bool try_fuse = !row_sqerr && zq_ste && zq_stride >= d && !(zq_stride & 3) && topk <= MEDTOK_MAX_TOPK;
+    g_fuse = try_fuse ? &fuse : nullptr;
+    const int rc = medtok_topk_search_f32(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, sws, ws_bytes - align_up((size_t)n * 4, 256), path, stream);
+    g_fuse = nullptr;
+    if (rc) return 1;
+    if (!fuse.done) return medtok_soft_assign_f32(x, what, idx, dist, n, d, topk, 0, w, zq_ste, zq_stride, row_sqerr, stream);
+    // rows the filter handed to the exact kernel: assignment through the device-side row list (normally empty)
+    hipLaunchKernelGGL((soft_assign_kernel<MEDTOK_MAX_TOPK>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, what, idx, dist, (long)n, d, topk, 0, w, zq_ste, (long)zq_stride, (float *)nullptr, fuse.fb_rows, fuse.fb_count);
+    return check_launch("soft_assign(list)");
 }

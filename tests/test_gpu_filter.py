@@ -160,3 +160,34 @@ def test_xcd_block_order_gives_the_same_bits(dev, splits, monkeypatch):
     monkeypatch.setenv("MEDTOK_FILTER_XCD", "1")
     i_x, d_x = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
     assert torch.equal(i_x, i_ref) and torch.equal(d_x, d_ref)
+
+
+@pytest.mark.parametrize("case", ["plain", "all_rows_to_exact_path", "some_rows_overflow", "strided_out"])
+def test_fused_assignment_equals_separate_kernels(dev, case):
+    """One-call forward on the filter path: the re-score kernel does the soft assignment itself (rows the filter hands to the
+    exact kernel get it through the device-side row list).  Everything must equal the exact path + stand-alone kernel bit for bit."""
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    n, K, D = 3000, 2048, 128
+    x = torch.randn(n, D, device=dev, generator=g)
+    W = torch.randn(K, D, device=dev, generator=g)
+    what, wsq = ops.rownorm(W)
+    if case == "all_rows_to_exact_path":
+        what = what * 3.0                                    # |e|^2 = 9 > the range the error bound covers
+        wsq = ops.rownorm(what, normalize=False)[1]
+    if case == "some_rows_overflow":
+        what[:1500] = what[0]                                # 1500 identical codes: rows near them overflow their candidate lists
+        wsq = ops.rownorm(what, normalize=False)[1]
+        x[::3] = what[0] + 0.01 * x[::3]
+    out_a = out_b = None
+    if case == "strided_out":
+        out_a = torch.zeros(n, 3 * D, device=dev); out_b = torch.zeros(n, 3 * D, device=dev)
+    a = ops.soft_vq_forward(x, what, wsq, 5, ops.PATH_F16_FILTER, want_sqerr=False, out=None if out_a is None else out_a[:, D:2 * D])
+    b = ops.soft_vq_forward(x, what, wsq, 5, ops.PATH_F32_MFMA, want_sqerr=False, out=None if out_b is None else out_b[:, D:2 * D])
+    for k in ("idx", "dist", "w", "zq", "xhat"):
+        assert torch.equal(a[k], b[k]), k
+    if out_a is not None:
+        assert torch.equal(out_a, out_b) and not out_a[:, :D].any() and not out_a[:, 2 * D:].any()
+    # with the squared error requested the stand-alone kernel runs: same values again
+    c = ops.soft_vq_forward(x, what, wsq, 5, ops.PATH_F16_FILTER, want_sqerr=True)
+    assert torch.equal(c["zq"], b["zq"] if out_b is None else b["zq"]) and torch.equal(c["w"], b["w"])
