@@ -107,9 +107,12 @@ __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<floa
 // ================================================================= rownorm
 // One wavefront per row.  Lane l owns float4 #(l + 64 t): element i lands in chain
 // (i/4)%64 and each chain accumulates in increasing i -- the oracle's canon_sumsq.
+typedef _Float16 rn_half4 __attribute__((ext_vector_type(4)));
+// xh (optional, NORMALIZE only): the fp16 filter's operand image of the normalised rows, [*, dp] prescaled by 2^8 exactly as
+// to_half_kernel writes it -- the one-call forward saves that kernel's pass over xhat.
 template <bool NORMALIZE>
 __global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ x, long n, int d,
-                                                      float *xhat, float *__restrict__ sqn)
+                                                      float *xhat, float *__restrict__ sqn, _Float16 *__restrict__ xh = nullptr, int dp = 0)
 {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -129,7 +132,17 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ 
             float4 v = ld4(src + i);
             v.x = v.x / den; v.y = v.y / den; v.z = v.z / den; v.w = v.w / den;
             st4(dst + i, v);
+            if (xh) {
+                rn_half4 h;
+                h[0] = (_Float16)(v.x * 256.0f); h[1] = (_Float16)(v.y * 256.0f); h[2] = (_Float16)(v.z * 256.0f); h[3] = (_Float16)(v.w * 256.0f);
+                *reinterpret_cast<rn_half4 *>(xh + row * dp + i) = h;
+            }
             p = fmaf(v.x, v.x, p); p = fmaf(v.y, v.y, p); p = fmaf(v.z, v.z, p); p = fmaf(v.w, v.w, p);
+        }
+        if (xh) {
+            rn_half4 z;
+            z[0] = z[1] = z[2] = z[3] = (_Float16)0.f;
+            for (int i = d + lane * 4; i < dp; i += 256) *reinterpret_cast<rn_half4 *>(xh + row * dp + i) = z;
         }
     } else {
         for (int i = lane * 4; i < d; i += 256) {
@@ -610,7 +623,7 @@ static int launch_search_t(const float *xhat, const float *xsq, int64_t n, const
 
 // Set by medtok_soft_vq_forward_f32 around its search call: when the filter path runs, its re-score kernel also does the
 // soft assignment (and the exact-path leftovers get it from soft_assign_kernel through the row list).
-struct FuseAssign { const float *xref; float *w; float *zq; long zq_stride; bool done; const int *fb_rows, *fb_count; };
+struct FuseAssign { const float *xref; float *w; float *zq; long zq_stride; bool done; const int *fb_rows, *fb_count; bool xh_done; };
 static thread_local FuseAssign *g_fuse = nullptr;
 
 template <int T, bool KTAIL>
@@ -621,7 +634,8 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     const FilterPlan f = plan_filter(n, k_codes, d, topk);
     const FilterWs w = filter_ws_layout(ws, n, f);
     if (!ws || ws_bytes < w.total) return fail("search(filter): workspace too small (%zu < %zu)", ws_bytes, w.total);
-    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.n_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, xhat, (long)n, d, f.n_pad, f.dp, w.xh);
+    if (!(g_fuse && g_fuse->xh_done))      // (the one-call forward's rownorm has already written the fp16 image of x)
+        hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.n_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, xhat, (long)n, d, f.n_pad, f.dp, w.xh);
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, w.wh);
     hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, w.en_max);
     hipLaunchKernelGGL(pad_wsq_kernel, dim3((unsigned)((f.k_pad + 255) / 256)), dim3(256), 0, s, wsq, (int)k_codes, (int)f.k_pad, w.wsqp);
@@ -1385,12 +1399,25 @@ extern "C" int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d, cons
     if (!ws || ws_bytes < need) return fail("soft_vq_forward: workspace too small (%zu < %zu)", ws_bytes, need);
     float *xsq = (float *)ws;
     void *sws = (char *)ws + align_up((size_t)n * 4, 256);
-    if (medtok_rownorm_f32(x, n, d, 1, xhat, xsq, stream)) return 1;
     // Without the squared-error output (its summation order is the stand-alone kernel's) the filter path's re-score kernel
     // does the soft assignment itself, bit for bit the same, while the top-k code rows are hot in the L2.
     if (zq_stride == 0) zq_stride = d;
-    FuseAssign fuse = {x, w, zq_ste, (long)zq_stride, false, nullptr, nullptr};
+    FuseAssign fuse = {x, w, zq_ste, (long)zq_stride, false, nullptr, nullptr, false};
     const bool try_fuse = !row_sqerr && zq_ste && zq_stride >= d && !(zq_stride & 3) && topk <= MEDTOK_MAX_TOPK;
+    const bool filter_path = topk >= 1 && topk <= MEDTOK_MAX_TOPK && resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER;
+    if (try_fuse && filter_path && xhat && !(d & 3)) {
+        // the filter's fp16 image of the normalised rows comes out of the same pass that normalises them
+        const FilterPlan f = plan_filter(n, k_codes, d, topk);
+        const FilterWs fw = filter_ws_layout(sws, n, f);
+        hipStream_t s = (hipStream_t)stream;
+        hipLaunchKernelGGL(rownorm_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, (long)n, d, xhat, xsq, fw.xh, f.dp);
+        if (f.n_pad > n && hipMemsetAsync(fw.xh + (size_t)n * f.dp, 0, (size_t)(f.n_pad - n) * f.dp * 2, s) != hipSuccess)
+            return fail("soft_vq_forward: memset failed");
+        if (check_launch("rownorm(+fp16)")) return 1;
+        fuse.xh_done = true;
+    } else if (medtok_rownorm_f32(x, n, d, 1, xhat, xsq, stream)) {
+        return 1;
+    }
     g_fuse = try_fuse ? &fuse : nullptr;
     const int rc = medtok_topk_search_f32(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, sws, ws_bytes - align_up((size_t)n * 4, 256), path, stream);
     g_fuse = nullptr;
