@@ -143,7 +143,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     const _Float16 *__restrict__ xh, const _Float16 *__restrict__ wh, const float *__restrict__ xsq,
     const float *__restrict__ wsqp, const float *__restrict__ en_max_ptr, long n, int k_codes, int dp, int d,
     int codes_per_split, int own_total, uint2 *__restrict__ cand, int *__restrict__ cand_cnt,
-    float *__restrict__ dump, int xcd_rows, int n_splits)
+    float *__restrict__ dump, int xcd_rows, int n_splits, int row_tile_base, int row_tile_end)
 {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -154,14 +154,17 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // (row tile (32/S of them per chunk), split j % S): the CUs of one XCD then share 32/S x tiles (L2-resident)
     // and S code streams instead of streaming 32 different x tiles through a 4 MB L2.  (A non-temporal hint on the
     // code-side loads, meant to protect the x tiles further, measured 25 % slower.)
+    // A launch covers row tiles [row_tile_base, row_tile_end): the tail of a large search (the last, partly filled round of
+    // blocks) is launched separately with more, shorter code splits.
     long row_tile = blockIdx.x;
     int split = blockIdx.y;
     if (xcd_rows > 0) {
         const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3, c = j >> 5, i = j & 31;
         split = i % n_splits;
         row_tile = (long)(c * 8 + xcd) * xcd_rows + i / n_splits;
-        if (row_tile * F_BN >= n) return;
     }
+    row_tile += row_tile_base;
+    if (row_tile >= row_tile_end) return;
     const long row0 = row_tile * F_BN;
     const int code_lo = split * codes_per_split;
     const int code_hi = min(k_codes, code_lo + codes_per_split);
@@ -511,6 +514,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 template <int TOPK>
 __global__ __launch_bounds__(256) void rescore_kernel(
     const uint2 *__restrict__ cand, const int *__restrict__ cand_cnt, int own_total,
+    const uint2 *__restrict__ cand_tail, const int *__restrict__ cnt_tail, int own_tail, long tail_start,
     const float *__restrict__ xhat, const float *__restrict__ xsq, const float *__restrict__ what,
     const float *__restrict__ wsq, const float *__restrict__ en_max_ptr, long n, int k_codes, int d, int topk_out,
     int64_t *__restrict__ out_idx, float *__restrict__ out_dist, int *__restrict__ fb_count, int *__restrict__ fb_rows,
@@ -525,8 +529,11 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     if (threadIdx.x < R_ROWS) s_cnt[threadIdx.x] = 0;
     const float xn = xsq[row];
     const float win = 2.0f * filter_eps(xn, en_max_ptr[0], d);
-    const uint2 *rc = cand + row * own_total * F_CAP;
-    const int *cc = cand_cnt + row * own_total;
+    // rows from tail_start on were filtered by the tail launch: its own lists, own_tail of them per row
+    const bool in_tail = row >= tail_start;
+    if (in_tail) own_total = own_tail;
+    const uint2 *rc = in_tail ? cand_tail + (row - tail_start) * own_total * F_CAP : cand + row * own_total * F_CAP;
+    const int *cc = in_tail ? cnt_tail + (row - tail_start) * own_total : cand_cnt + row * own_total;
 
     bool overflow = false;
     for (int o = 0; o < own_total; ++o) overflow |= cc[o] > F_CAP;

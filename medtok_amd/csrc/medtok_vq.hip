@@ -477,6 +477,9 @@ struct FilterPlan {
     long n_pad, k_pad, row_tiles;
     int dp, splits, codes_per_split, own_total, tslots;
     int xcd_rows;      // > 0: XCD-aware block order with this many row tiles per XCD at a time (32 / splits)
+    // tail launch: the last main_tiles..row_tiles row tiles with more, shorter splits (0 tiles = none)
+    long main_tiles;
+    int tail_splits, tail_codes_per_split, own_tail;
 };
 
 static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
@@ -506,13 +509,36 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
     f.splits = (int)((code_tiles + tiles_per_split - 1) / tiles_per_split);
     f.own_total = f.splits * F_OWN_PER_SPLIT;
     f.xcd_rows = (xcd && f.splits >= 2 && 32 % f.splits == 0) ? 32 / f.splits : 0;
+    // One 8-wave block per CU and equal-cost blocks: B blocks take ceil(B / 256) rounds, the last one however few blocks it
+    // holds (N = 600k: 4688 blocks = 18.3 rounds -> 19).  The row tiles of that last round go into a second launch
+    // with enough splits to be ONE round of short blocks (N = 600k: 40 row tiles x 6 splits, a third of a round).
+    f.main_tiles = f.row_tiles; f.tail_splits = 0; f.tail_codes_per_split = 0; f.own_tail = 0;
+    const long blocks = f.row_tiles * f.splits;
+    long tail_min_blocks = 8 * 256;
+    if (const char *e = getenv("MEDTOK_FILTER_TAIL")) tail_min_blocks = atol(e) > 0 ? atol(e) : (1L << 60);   // dev knob: 0 = off
+    const bool tail = blocks >= tail_min_blocks && f.splits <= 4 && code_tiles >= 4L * f.splits;
+    if (tail) {
+        const long main_blocks = blocks / 256 * 256;
+        const long main_tiles = main_blocks / f.splits;             // 256 % splits == 0
+        // as many splits as make the tail ONE round of short blocks (at most 16: every split costs candidates)
+        const long tail_tiles = f.row_tiles - main_tiles;
+        const long ts = tail_tiles > 0 ? lmin(lmin(16, code_tiles), 256 / tail_tiles) : 0;
+        if (ts >= 2L * f.splits) {
+            const long tps = (code_tiles + ts - 1) / ts;
+            f.main_tiles = main_tiles;
+            f.tail_codes_per_split = (int)(tps * F_BM);
+            f.tail_splits = (int)((code_tiles + tps - 1) / tps);
+            f.own_tail = f.tail_splits * F_OWN_PER_SPLIT;
+        }
+    }
     return f;
 }
 
 struct FilterWs {
     _Float16 *xh, *wh;
     float *en_max, *wsqp, *dump;
-    uint2 *cand;
+    uint2 *cand, *cand_tail;
+    int *cnt_tail;
     int *cand_cnt, *fb_count, *fb_rows, *fb_pidx;
     float *fb_pval;
     size_t total;
@@ -536,8 +562,11 @@ static FilterWs filter_ws_layout(void *ws, int64_t n, const FilterPlan &f)
     w.fb_rows = (int *)take((size_t)n * 4);
     w.fb_pval = (float *)take((size_t)FB_SPLITS * FB_ROWS * MEDTOK_MAX_TOPK * 4);
     w.fb_pidx = (int *)take((size_t)FB_SPLITS * FB_ROWS * MEDTOK_MAX_TOPK * 4);
-    w.cand_cnt = (int *)take((size_t)n * f.own_total * 4);
-    w.cand = (uint2 *)take((size_t)n * f.own_total * F_CAP * 8);
+    const size_t n_main = (size_t)lmin(n, f.main_tiles * F_BN), n_tail = (size_t)n - n_main;
+    w.cand_cnt = (int *)take(n_main * f.own_total * 4);
+    w.cand = (uint2 *)take(n_main * f.own_total * F_CAP * 8);
+    w.cnt_tail = (int *)take(n_tail * f.own_tail * 4);
+    w.cand_tail = (uint2 *)take(n_tail * f.own_tail * F_CAP * 8);
     w.dump = nullptr;
     w.total = off;
     return w;
@@ -642,14 +671,23 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     if (hipMemsetAsync(w.fb_count, 0, 4, s) != hipSuccess) return fail("search(filter): memset failed");
     (void)hipFuncSetAttribute((const void *)filter_f16_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM_BYTES);
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
-    dim3 fgrid((unsigned)f.row_tiles, (unsigned)f.splits);
-    if (f.xcd_rows) fgrid = dim3((unsigned)(((f.row_tiles + 8 * f.xcd_rows - 1) / (8 * f.xcd_rows)) * 256), 1);
+    dim3 fgrid((unsigned)f.main_tiles, (unsigned)f.splits);
+    if (f.xcd_rows) fgrid = dim3((unsigned)(((f.main_tiles + 8 * f.xcd_rows - 1) / (8 * f.xcd_rows)) * 256), 1);
     hipLaunchKernelGGL((filter_f16_kernel<T, false>), fgrid, dim3(F_THREADS), F_SMEM_BYTES, s,
                        w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
-                       w.cand, w.cand_cnt, (float *)nullptr, f.xcd_rows, f.splits);
+                       w.cand, w.cand_cnt, (float *)nullptr, f.xcd_rows, f.splits, 0, (int)f.main_tiles);
+    const long tail_start = f.main_tiles * F_BN;
+    if (f.main_tiles < f.row_tiles) {
+        // the kernel indexes its lists by absolute row: bias the tail region's base pointers accordingly
+        hipLaunchKernelGGL((filter_f16_kernel<T, false>), dim3((unsigned)(f.row_tiles - f.main_tiles), (unsigned)f.tail_splits), dim3(F_THREADS),
+                           F_SMEM_BYTES, s, w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.tail_codes_per_split, f.own_tail,
+                           w.cand_tail - tail_start * f.own_tail * F_CAP, w.cnt_tail - tail_start * f.own_tail, (float *)nullptr, 0, f.tail_splits,
+                           (int)f.main_tiles, (int)f.row_tiles);
+    }
     if (pa) g_prof.push_back({pa, prof_mark(s), 2.0 * (double)n * (double)k_codes * (double)d, 0});
     if (check_launch("filter_f16")) return 1;
     hipLaunchKernelGGL((rescore_kernel<T>), dim3((unsigned)((n + R_ROWS - 1) / R_ROWS)), dim3(256), 0, s, w.cand, w.cand_cnt, f.own_total,
+                       w.cand_tail, w.cnt_tail, f.own_tail, f.main_tiles < f.row_tiles ? tail_start : (long)n,
                        xhat, xsq, what, wsq, w.en_max, (long)n, (int)k_codes, d, topk, idx, dist, w.fb_count, w.fb_rows,
                        g_fuse ? g_fuse->xref : (const float *)nullptr, g_fuse ? g_fuse->w : (float *)nullptr,
                        g_fuse ? g_fuse->zq : (float *)nullptr, g_fuse ? g_fuse->zq_stride : 0L);
@@ -737,7 +775,8 @@ extern "C" int medtok_debug_filter_scores_f32(const float *xhat, const float *xs
     hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, en_max);
     (void)hipFuncSetAttribute((const void *)filter_f16_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM_BYTES);
     hipLaunchKernelGGL((filter_f16_kernel<5, true>), dim3((unsigned)f.row_tiles, 1), dim3(F_THREADS), F_SMEM_BYTES, s, xh, wh, xsq, wsqp, en_max,
-                       (long)n, (int)k_codes, f.dp, d, (int)f.k_pad, F_OWN_PER_SPLIT, (uint2 *)nullptr, (int *)nullptr, scores, 0, 1);
+                       (long)n, (int)k_codes, f.dp, d, (int)f.k_pad, F_OWN_PER_SPLIT, (uint2 *)nullptr, (int *)nullptr, scores, 0, 1,
+                       0, (int)f.row_tiles);
     return check_launch("filter_f16(dump)");
 }
 

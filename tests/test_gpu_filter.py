@@ -191,3 +191,24 @@ def test_fused_assignment_equals_separate_kernels(dev, case):
     # with the squared error requested the stand-alone kernel runs: same values again
     c = ops.soft_vq_forward(x, what, wsq, 5, ops.PATH_F16_FILTER, want_sqerr=True)
     assert torch.equal(c["zq"], b["zq"] if out_b is None else b["zq"]) and torch.equal(c["w"], b["w"])
+
+
+@pytest.mark.parametrize("splits,tiles", [(2, 131), (4, 70), (1, 260)])
+def test_tail_launch_gives_the_same_bits(dev, splits, tiles, monkeypatch):
+    """Large searches launch the row tiles of the last, partly filled round of blocks separately with more code splits (their own
+    candidate lists, a second region the re-score kernel reads by row range).  Forced here at a small size."""
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(tiles)
+    n, K, D = 256 * tiles - 77, 256 * 40, 128
+    xh, xs = ops.rownorm(torch.randn(n, D, device=dev, generator=g))
+    wh, ws = ops.rownorm(torch.randn(K, D, device=dev, generator=g))
+    i_ref, d_ref = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F32_MFMA)
+    monkeypatch.setenv("MEDTOK_FILTER_SPLITS", str(splits))
+    monkeypatch.setenv("MEDTOK_FILTER_TAIL", "256")
+    for xcd in ("0", "1"):
+        monkeypatch.setenv("MEDTOK_FILTER_XCD", xcd)
+        i_t, d_t = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
+        assert torch.equal(i_t, i_ref) and torch.equal(d_t, d_ref), xcd
+    r = ops.soft_vq_forward(xh, wh, ws, 5, ops.PATH_F16_FILTER, want_sqerr=False)      # fused assignment over both regions
+    r0 = ops.soft_vq_forward(xh, wh, ws, 5, ops.PATH_F32_MFMA, want_sqerr=False)
+    assert all(torch.equal(r[k], r0[k]) for k in ("idx", "dist", "w", "zq"))
