@@ -55,6 +55,34 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_protocol(run, rows_full, unit_rows, what):
+    """SURVEY 8d / BASELINE.md section 3 protocol, bounded to ~20 s: `run(rows, threads)` executes the reference op sequence
+    on the first `rows` rows of a 16384-row chunk.  Thread count = the best of {16, 64, all host threads} on a short probe
+    (all threads oversubscribe this op mix on a 256-thread host); then one warm-up + the median of 3 timed passes over the
+    chunk -- cut to what fits ~6 s per pass when the host is slow, and the cut is stated."""
+    import statistics
+    ncpu = os.cpu_count() or 1
+    probe_rows = min(1024, rows_full)
+    cands = sorted({min(16, ncpu), min(64, ncpu), ncpu})
+    probe = {}
+    for th in cands:
+        run(min(256, probe_rows), th)                      # page in / spin up the pool
+        t0 = time.perf_counter(); run(probe_rows, th); probe[th] = probe_rows / (time.perf_counter() - t0)
+    best = max(probe, key=probe.get)
+    rows = int(min(rows_full, max(probe_rows, probe[best] * 6.0)))
+    run(min(rows, 2048), best)                             # warm-up
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter(); run(rows, best); times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    info = " ".join(torch.__config__.parallel_info().split())[:400]
+    return dict(value=rows / dt * unit_rows, unit="codes/s", cores=best, kind="port",
+                sample=(f"{rows} rows of a {rows_full}-row chunk of the same workload ({what}); reference op sequence in CPU PyTorch "
+                        f"(oracle/torch_port.py); warm-up + median of 3 passes ({dt:.2f} s each); threads = best of "
+                        + ", ".join(f"{t}: {v:.0f} codes/s" for t, v in probe.items()) + f" on a {probe_rows}-row probe; host has {ncpu} threads"),
+                parallel_info=info)
+
+
 class Cfg3:
     """Full soft VQ, one codebook of n_e = 3 * 16384 rows (text third, middle, graph third)."""
     name = "cfg3"
@@ -78,6 +106,10 @@ class Cfg3:
     def flops_per_code(self):
         return 2.0 * self.D * (2 * self.REGION + 2 * self.N_E)
 
+    def bytes_per_code(self):
+        # 4 searches x (x row in + zq row out) + ids (8 B) and weights (4 B) for 4 x k tokens  ~ 24.8 KB
+        return 4 * (4 * self.D + 4 * self.D) + 4 * self.TOPK * 12
+
     def set_path(self, path):
         self.vq.search_path = path
 
@@ -97,18 +129,15 @@ class Cfg3:
     def cpu_baseline(self, sample_rows):
         """Reference op sequence on the host cores, `sample_rows` rows of this workload."""
         from oracle import torch_port as P
-        torch.set_num_threads(os.cpu_count() or 1)
         g = torch.Generator().manual_seed(0)
         D = self.D
         W = torch.randn(self.N_E, D, generator=g)
         xs = [torch.randn(sample_rows, D, generator=g) for _ in range(4)]
-        P.full_tokenize(*[x[:256] for x in xs], W, self.TOPK)          # warm-up
-        t0 = time.perf_counter()
-        P.full_tokenize(*xs, W, self.TOPK)
-        dt = time.perf_counter() - t0
-        return dict(value=sample_rows / dt, unit="codes/s", cores=torch.get_num_threads(), kind="port",
-                    sample=f"{sample_rows} codes of the same workload (4 searches each, K=16384/49152, D=768), "
-                           f"reference op sequence in CPU PyTorch (oracle/torch_port.py), {dt:.1f} s")
+
+        def run(rows, threads):
+            torch.set_num_threads(threads)
+            P.full_tokenize(*[x[:rows] for x in xs], W, self.TOPK)
+        return cpu_protocol(run, sample_rows, 1, "4 searches per code, K=16384/49152, D=768")
 
 
 class Full(Cfg3):
@@ -197,6 +226,9 @@ class CodeShard:
     def flops_per_code(self):
         return 2.0 * self.D * self.K
 
+    def bytes_per_code(self):
+        return 8 * self.D + self.TOPK * 12 + self.K * self.D * 4 / max(self.rows, 1)
+
     def set_path(self, path):
         self.path = path
 
@@ -217,15 +249,13 @@ class CodeShard:
 
     def cpu_baseline(self, sample_rows):
         from oracle import torch_port as P
-        torch.set_num_threads(os.cpu_count() or 1)
         g = torch.Generator().manual_seed(0)
         W = torch.randn(self.K, self.D, generator=g); x = torch.randn(sample_rows, self.D, generator=g)
-        P.soft_search(x[:256], W, self.TOPK)
-        t0 = time.perf_counter()
-        P.soft_search(x, W, self.TOPK)
-        dt = time.perf_counter() - t0
-        return dict(value=sample_rows / dt, unit="codes/s", cores=torch.get_num_threads(), kind="port",
-                    sample=f"{sample_rows} rows, one dense K=49152 search + soft assignment in CPU PyTorch, {dt:.1f} s")
+
+        def run(rows, threads):
+            torch.set_num_threads(threads)
+            P.soft_search(x[:rows], W, self.TOPK)
+        return cpu_protocol(run, sample_rows, 1, "one dense K=49152 search + soft assignment")
 
 
 class Cfg2:
@@ -248,6 +278,10 @@ class Cfg2:
     def flops_per_code(self):
         return 2.0 * self.K * self.D
 
+    def bytes_per_code(self):
+        # SURVEY 8d cfg 2: z in + z_q out + id, plus the codebook-sized state (3 K D + 2 K floats) amortised over the rows
+        return 8 * self.D + 8 + (3 * self.K * self.D * 4 + 2 * self.K * 4) / max(self.rows, 1)
+
     def set_path(self, path):
         self.q.search_path = path
 
@@ -268,32 +302,64 @@ class Cfg2:
 
     def cpu_baseline(self, sample_rows):
         from oracle import torch_port as P
-        torch.set_num_threads(os.cpu_count() or 1)
         g = torch.Generator().manual_seed(0)
         E = torch.nn.functional.normalize(torch.randn(self.K, self.D, generator=g), dim=-1)
         z = torch.randn(sample_rows, self.D, generator=g)
-        cs = torch.zeros(self.K)
-        P.norm_ema_forward(z[:256], E.clone(), cs.clone(), 0.25, 0.99, True)
-        t0 = time.perf_counter()
-        P.norm_ema_forward(z, E, cs, 0.25, 0.99, True)
-        dt = time.perf_counter() - t0
-        return dict(value=sample_rows / dt, unit="codes/s", cores=torch.get_num_threads(), kind="port",
-                    sample=f"{sample_rows} rows, argmin + EMA train step, reference op sequence in CPU PyTorch, {dt:.1f} s")
+
+        def run(rows, threads):
+            torch.set_num_threads(threads)
+            P.norm_ema_forward(z[:rows], E.clone(), torch.zeros(self.K), 0.25, 0.99, True)
+        return cpu_protocol(run, sample_rows, 1, f"argmin + EMA train step, K={self.K}, D=768")
 
 
-def pmc_traffic(workload, kernel):
-    """Fabric bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or None."""
+def pmc_traffic(workload, kernel, rows):
+    """(bytes, source): fabric bytes per launch of `kernel`.  PMC counters cannot be read from inside this process (they need their
+    own rocprofv3 --pmc passes, tools/pmc_traffic.sh), so the figure is the one RECORDED in profiles/pmc_traffic.json -- returned
+    only when this run has the workload and row count that file was taken at, and always with its provenance; otherwise null."""
     f = ROOT / "profiles" / "pmc_traffic.json"
-    if f.exists():
-        try:
-            return json.loads(f.read_text()).get(workload, {}).get(kernel)
-        except Exception:
-            return None
-    return None
+    try:
+        rec = json.loads(f.read_text())
+        meta = rec.get("_meta", {})
+        if meta.get("rows", {}).get(workload) != rows:
+            return None, None
+        val = rec.get(workload, {}).get(kernel)
+        if val is None:
+            return None, None
+        return val, (f"recorded, not measured in this run: profiles/pmc_traffic.json ({meta.get('taken', '?')}; rocprofv3 --pmc FETCH_SIZE x2 + "
+                     f"WRITE_SIZE per MI355X_MICROARCH.md; {workload} at {rows} rows/GPU)")
+    except Exception:
+        return None, None
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N fresh rank processes (one per GPU, env://
+    rendezvous on 127.0.0.1 -- the launch contract of MedTok/utils/distributed.py:20-58), relay rank 0's JSON line and
+    return the worst exit code.  This parent never touches the GPU (no torch.cuda call that initialises HIP), and the
+    children are new processes, not an exec of this one."""
+    import socket
+    import subprocess
+    backend = os.environ.get("MEDTOK_DIST_BACKEND") or "nccl"
+    have = torch.cuda.device_count()              # counting devices does not initialise the runtime
+    if backend == "nccl" and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible (RCCL needs one GPU per rank)", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:                      # the ranks' stdout: only the JSON line goes to ours
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to benchmark)")
     rank, local, world = mdist.init_distributed()
@@ -361,6 +427,9 @@ def main():
     kp = prof[kname]
     peak = F16_MFMA_PEAK_TFLOPS if kname == "filter_f16_kernel" else FP32_MFMA_PEAK_TFLOPS
     achieved = kp["flops"] / (kp["ms"] * 1e-3) / 1e12 if kp["ms"] > 0 else 0.0
+    traffic, traffic_source = pmc_traffic(wl.name, kname, rows)
+    alg_bytes_step = float(wl.bytes_per_code()) * rows                # SURVEY 8d per-code figure x the codes one step processes (per GPU)
+    hbm_gbs = alg_bytes_step * args.steps / elapsed / 1e9
 
     if rank == 0:
         total_codes = (float(args.rows or 600000) if args.workload in ("cfg5", "codeshard") else float(rows) * world) * args.steps
@@ -376,8 +445,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.workload in ("cfg5", "codeshard") else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": ("f32 results (bit-identical to the fp32-MFMA path); f16-MFMA shortlist + exact f32 re-score"
+                      if kname == "filter_f16_kernel" else "f32"),
             "data": "synthetic",
+            "n_ranks_seen": (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
             "config": {"workload": wl.description, "rows_per_gpu": rows, "D": wl.D, "search_path": args.path,
                        "search": ("fp16-MFMA shortlist with a proven error bound + exact fp32 re-score: token ids and distances are "
                                   "bit-identical to the fp32-MFMA path (tests/test_gpu_filter.py)" if kname == "filter_f16_kernel"
@@ -386,7 +457,10 @@ def main():
                                        if args.workload == "codeshard" else
                                        f"row-shard x{world}, codebook replicated, no data-path collective")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(wl.name, kname), "kernel": kname,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kname,
+                         "hbm_frac": hbm_gbs / HBM_PEAK_GBS, "hbm_achieved_gbs": hbm_gbs, "hbm_peak_gbs": HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_step": alg_bytes_step,
+                         "binding_roof": "mfma (arithmetic intensity K/4 flop/B >> ridge; the HBM fraction is reported because BASELINE.json asks for it)",
                          "peak_note": ("dense f16 MFMA" if kname == "filter_f16_kernel" else "dense f32-input MFMA") + " (MI355X_MICROARCH.md)",
                          "launches_timed": kp["launches"], "avg_launch_ms": kp["ms"] / max(kp["launches"], 1),
                          "algorithmic_flops_per_launch": kp["flops"] / max(kp["launches"], 1),
@@ -398,7 +472,7 @@ def main():
                                            for k, v in prof.items() if k != kname and v["launches"]}},
             "exact_fp32_path": exact,
         }
-        cpu_rows = args.cpu_rows if args.cpu_rows is not None else {"cfg3": 4096, "full": 512}.get(args.workload, 16384)
+        cpu_rows = args.cpu_rows if args.cpu_rows is not None else {"full": 512}.get(args.workload, 16384)
         if world == 1 and cpu_rows > 0:
             line["cpu_baseline"] = wl.cpu_baseline(cpu_rows)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -98,6 +98,13 @@ int medtok_debug_filter_scores_f32(const float *xhat, const float *xsq, int64_t 
                                    const float *what, const float *wsq, int64_t k_codes, int d,
                                    float *scores, void *ws, size_t ws_bytes, void *stream);
 
+/* Test hook: force plan branches the default heuristics only take at very large shapes (code-range splits, the XCD-aware
+ * block order, the tail launch, the staggered epilogue of the filter kernel; the split cap of the exact kernel), so that
+ * small parity tests cover them.  Process-wide; -1 restores the default for that field.  The product path never reads
+ * environment variables.  Results are bit-identical under every plan (tests/test_gpu_filter.py). */
+int medtok_debug_plan_override(int64_t filter_splits, int64_t filter_xcd, int64_t filter_tail_min_blocks,
+                               int64_t search_max_splits, int64_t filter_stagger);
+
 /* Soft assignment: w = softmax(-dist), zq = sum_j w_j * what[idx_j],
  * zq_ste = xref + (zq - xref), row_sqerr[r] = sum_i (zq - xref)^2.
  * Replaces vector_quantization_soft_one_new.py:158,160,164-165,169-173,181-182,
@@ -106,7 +113,8 @@ int medtok_debug_filter_scores_f32(const float *xhat, const float *xsq, int64_t 
  * (the tensor autograd differentiates) instead of the straight-through value.
  * w and row_sqerr may be NULL.  zq_out may alias xref; zq_stride is its row stride in floats
  * (0 = d), so four searches can write straight into the columns of one [n, 4d] embedding
- * (the torch.cat of tokenizer.py:246). */
+ * (the torch.cat of tokenizer.py:246).  idx entries must lie in [0, K) like F.embedding's; the ids the
+ * search entry points produce always do, also for rows whose distances are NaN or infinite. */
 int medtok_soft_assign_f32(const float *xref, const float *what, const int64_t *idx,
                            const float *dist, int64_t n, int d, int topk, int flags,
                            float *w, float *zq_out, int64_t zq_stride, float *row_sqerr, void *stream);

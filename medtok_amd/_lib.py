@@ -9,8 +9,16 @@ import ctypes as C
 import os
 from pathlib import Path
 
-# MEDTOK_VQ_LIB: dev knob to A/B an alternative build of the same ABI (still a HIP library, never a fallback)
-_SO = Path(os.environ.get("MEDTOK_VQ_LIB") or Path(__file__).resolve().parent / "csrc" / "libmedtok_vq.so")
+_SO = Path(__file__).resolve().parent / "csrc" / "libmedtok_vq.so"
+
+
+def use_library(path) -> None:
+    """Dev tools only (tools/ab_filter.py ...): bind an alternative BUILD of the same ABI before the first load().
+    Still a HIP library, never a fallback; the product never reads an environment variable for this."""
+    global _SO, _lib
+    if _lib is not None:
+        raise MedTokLibraryError("use_library() must be called before the library is first loaded")
+    _SO = Path(path)
 _lib = None
 
 ABI_VERSION = 1
@@ -31,6 +39,7 @@ SIGNATURES = {
     "medtok_merge_topk_lists_f32": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
     "medtok_debug_filter_scores_workspace_bytes": (_sz, [_i64, _i64, _int]),
     "medtok_debug_filter_scores_f32": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
+    "medtok_debug_plan_override": (_int, [_i64, _i64, _i64, _i64, _i64]),
     "medtok_soft_assign_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _i64, _vp, _vp]),
     "medtok_sum_scale_f32": (_int, [_vp, _i64, _dbl, _vp, _vp]),
     "medtok_soft_vq_backward_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),

@@ -27,7 +27,7 @@ template <int W, int NT>      // waves per block, output column tiles per wave; 
 __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
     const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
     const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
-    float scale, float *__restrict__ out)
+    float scale, float *__restrict__ out, int q_tiles)
 {
     constexpr int D = 32 * W * NT, LD = D + 4;     // LDS row stride in floats
     constexpr int THREADS = 64 * W;
@@ -38,7 +38,9 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
     float (*part)[32][33] = reinterpret_cast<float (*)[32][33]>(kvs + 32 * LD);       // [W][32][33] per-wave partial scores [row][key]
     float (*pt)[33] = reinterpret_cast<float (*)[33]>(kvs + 32 * LD + W * 32 * 33);   // [32][33] probabilities, transposed [key][row]
     float *alpha_s = kvs + 32 * LD + (W + 1) * 32 * 33, *l_s = alpha_s + 32;
-    const int b = blockIdx.y, qt = blockIdx.x;
+    // 1-D grid: block id = code * q_tiles + query tile (the tiles of one code stay adjacent: they share its keys in the L2;
+    // grid.y would cap a call at 65535 codes)
+    const int b = (int)(blockIdx.x / (unsigned)q_tiles), qt = (int)(blockIdx.x % (unsigned)q_tiles);
     const int ql = (int)q_len[b];
     if (qt * 32 >= ql) return;
     const long qs = q_start[b], ks = kv_start[b];
@@ -198,7 +200,8 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (qt * 32 + row < ql) {
-            const float inv = 1.f / l_s[row];
+            const float lsum = l_s[row];
+            const float inv = lsum > 0.f ? 1.f / lsum : 0.f;     // a code with no key rows (empty graph / empty text) attends to nothing: context 0, not 0/0
             float *o = out + (qs + qt * 32 + row) * (long)D + slice + li;
 #pragma unroll
             for (int t = 0; t < NT; ++t) o[32 * t] = acc[t][r] * inv;

@@ -646,8 +646,10 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     if (l8 == 0 && pos < n) {
 #pragma unroll
         for (int j = 0; j < TOPK; ++j)
-            if (j < topk_out) { out_idx[row * topk_out + j] = bi[j]; out_dist[row * topk_out + j] = bv[j]; }
+            if (j < topk_out) { out_idx[row * topk_out + j] = valid_code(bi[j], j, k_codes); out_dist[row * topk_out + j] = bv[j]; }
     }
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j) bi[j] = valid_code(bi[j], j, k_codes);       // the fused assignment below gathers with these
     // ---- phase 4 (one-call forward only): the soft assignment of soft_assign_kernel, same arithmetic, while the top-k
     // code rows this block has just re-scored are still hot in the L2 (a separate launch re-gathers them from the
     // Infinity Cache: 9 GB per 600k-row search).  The row's 8 lanes all hold the merged (bv, bi) lists.

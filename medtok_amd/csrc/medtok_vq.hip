@@ -57,18 +57,28 @@ struct ProfRec { hipEvent_t a, b; double flops; int kind; };   // kind 0 = filte
 static thread_local bool g_prof_on = false;
 static thread_local std::vector<ProfRec> g_prof;
 
+// Events come from a pool that medtok_profile_begin() fills BEFORE the timed region: recording is all a launch pays.
+static thread_local std::vector<hipEvent_t> g_event_pool;
+constexpr size_t PROF_POOL = 2048;
+
 static hipEvent_t prof_mark(hipStream_t s)
 {
     hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    if (!g_event_pool.empty()) { e = g_event_pool.back(); g_event_pool.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) return nullptr;
     (void)hipEventRecord(e, s);
     return e;
 }
 
 extern "C" int medtok_profile_begin(void)
 {
-    for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto &r : g_prof) { if (r.a) g_event_pool.push_back(r.a); if (r.b) g_event_pool.push_back(r.b); }
     g_prof.clear();
+    while (g_event_pool.size() < PROF_POOL) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return fail("profile_begin: hipEventCreate failed");
+        g_event_pool.push_back(e);
+    }
     g_prof_on = true;
     return 0;
 }
@@ -82,11 +92,25 @@ extern "C" int medtok_profile_end(double *ms, double *flops, int *launches)
         if (r.a && r.b && hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
             ms[r.kind] += t; flops[r.kind] += r.flops; launches[r.kind] += 1;
         }
-        if (r.a) (void)hipEventDestroy(r.a);
-        if (r.b) (void)hipEventDestroy(r.b);
+        if (r.a) g_event_pool.push_back(r.a);
+        if (r.b) g_event_pool.push_back(r.b);
     }
     g_prof.clear();
     return 0;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of the launch: set it once per instantiation
+// (and device), not before every launch.
+template <auto Kernel>
+static bool set_lds_once(size_t bytes)
+{
+    static thread_local int done_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (done_dev == dev) return true;
+    if (hipFuncSetAttribute((const void *)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    done_dev = dev;
+    return true;
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -192,6 +216,11 @@ __device__ __forceinline__ bool lex_lt(float v, int c, float bv, int bc)
 {
     return v < bv || (v == bv && c < bc);
 }
+
+// A row whose distances are NaN never inserts anything and its list keeps the sentinel index.  Token ids leave the library
+// in range regardless -- slot j falls back to code j (torch.topk / argmin also return valid indices for such rows, so the
+// reference's AMP loop survives an overflowed step; the gathers downstream index the codebook with these ids).
+__device__ __forceinline__ int valid_code(int c, int j, int k_codes) { return (unsigned)c < (unsigned)k_codes ? c : j % k_codes; }
 
 // Same, but for merging lists whose codes are not met in order: compare (value, index).
 template <int T>
@@ -409,7 +438,7 @@ template <int TOPK>
 __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict__ pval, const int *__restrict__ pidx,
                                                          long n, int splits, int topk_out,
                                                          int64_t *__restrict__ out_idx, float *__restrict__ out_dist,
-                                                         const int *__restrict__ row_list, const int *__restrict__ row_count)
+                                                         const int *__restrict__ row_list, const int *__restrict__ row_count, int k_codes)
 {
     // with a row list: partial lists are indexed by list position (extent n), results go to row_list[position]
     const int l8 = threadIdx.x & 7;
@@ -438,10 +467,26 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict
     const long orow = row_list ? (long)row_list[pos] : row;
 #pragma unroll
     for (int j = 0; j < TOPK; ++j)
-        if (j < topk_out) { out_idx[orow * topk_out + j] = bi[j]; out_dist[orow * topk_out + j] = bv[j]; }
+        if (j < topk_out) { out_idx[orow * topk_out + j] = valid_code(bi[j], j, k_codes); out_dist[orow * topk_out + j] = bv[j]; }
 }
 
 #include "filter_f16.h"
+
+// Test / dev hook (medtok_debug_plan_override): force plan branches that the default heuristics only take at very large
+// shapes, so small tests can cover them.  Process-wide, -1 = default; the product path never reads the environment.
+struct PlanOverride { long filter_splits = -1, filter_xcd = -1, filter_tail_min_blocks = -1, search_max_splits = -1, filter_stagger = -1; };
+static PlanOverride g_plan_override;
+
+extern "C" int medtok_debug_plan_override(int64_t filter_splits, int64_t filter_xcd, int64_t filter_tail_min_blocks, int64_t search_max_splits,
+                                          int64_t filter_stagger)
+{
+    g_plan_override.filter_splits = (long)filter_splits;
+    g_plan_override.filter_xcd = (long)filter_xcd;
+    g_plan_override.filter_tail_min_blocks = (long)filter_tail_min_blocks;
+    g_plan_override.search_max_splits = (long)search_max_splits;
+    g_plan_override.filter_stagger = (long)filter_stagger;
+    return 0;
+}
 
 struct SearchPlan {
     int tslots;          // list length the kernels are instantiated with (1, 5 or 8)
@@ -464,7 +509,7 @@ static SearchPlan plan_search(int64_t n, int64_t k_codes, int topk)
     // at most 64 splits -- except for one or two row tiles (batches of <= 256 rows), where 64 splits would leave half
     // the CUs without a block: n = 256, K = 49152: 463 -> 276 us with 128 splits; n = 64: 459 -> 202 us with 256
     long cap = p.row_tiles <= 2 ? 256 / p.row_tiles : 64;
-    if (const char *e = getenv("MEDTOK_SEARCH_MAXSPLITS")) cap = atol(e);      // dev knob (tools/small_batch_search.py)
+    if (g_plan_override.search_max_splits > 0) cap = g_plan_override.search_max_splits;
     if (want > cap) want = cap;
     const long tiles_per_split = (code_tiles + want - 1) / want;
     p.codes_per_split = (int)(tiles_per_split * S_BM);
@@ -499,8 +544,8 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
     // the Infinity Cache once per code tile (measured at N = 600k, K = 49152: 6-8 % on the kernel).  Two splits: more
     // would keep more of the x tiles resident but loosen the per-split thresholds (4: +3.6 %, 8: +7.7 % kernel time).
     bool xcd = f.row_tiles >= 1024;
-    if (const char *e = getenv("MEDTOK_FILTER_SPLITS")) want = atol(e);      // dev knobs (tools/xcd_experiment.py)
-    if (const char *e = getenv("MEDTOK_FILTER_XCD")) xcd = atoi(e) != 0;
+    if (g_plan_override.filter_splits > 0) want = g_plan_override.filter_splits;
+    if (g_plan_override.filter_xcd >= 0) xcd = g_plan_override.filter_xcd != 0;
     if (want > code_tiles) want = code_tiles;
     if (want > 16) want = 16;      // (more splits for small batches were measured: slower from 32 up)
     if (want < 1) want = 1;
@@ -515,7 +560,8 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
     f.main_tiles = f.row_tiles; f.tail_splits = 0; f.tail_codes_per_split = 0; f.own_tail = 0;
     const long blocks = f.row_tiles * f.splits;
     long tail_min_blocks = 8 * 256;
-    if (const char *e = getenv("MEDTOK_FILTER_TAIL")) tail_min_blocks = atol(e) > 0 ? atol(e) : (1L << 60);   // dev knob: 0 = off
+    if (g_plan_override.filter_tail_min_blocks >= 0)
+        tail_min_blocks = g_plan_override.filter_tail_min_blocks > 0 ? g_plan_override.filter_tail_min_blocks : (1L << 60);   // 0 = off
     const bool tail = blocks >= tail_min_blocks && f.splits <= 4 && code_tiles >= 4L * f.splits;
     if (tail) {
         const long main_blocks = blocks / 256 * 256;
@@ -618,7 +664,7 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
     const double pflops = 2.0 * (double)n * (double)k_codes * (double)d;
     if (p.splits == 1) {
-        (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, true, KTAIL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
+        (void)set_lds_once<search_f32_kernel<T, true, KTAIL, false>>(S_LDS_BYTES);
         hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
                            (int)k_codes, d, p.codes_per_split, topk, (float *)nullptr, (int *)nullptr, idx, dist,
                            (const int *)nullptr, (const int *)nullptr, 0, 0);
@@ -630,14 +676,14 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
     if (!ws || ws_bytes < vbytes + ibytes) return fail("search: workspace too small (%zu < %zu)", ws_bytes, vbytes + ibytes);
     float *pval = (float *)ws;
     int *pidx = (int *)((char *)ws + vbytes);
-    (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, false, KTAIL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
+    (void)set_lds_once<search_f32_kernel<T, false, KTAIL, false>>(S_LDS_BYTES);
     hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
                        (int)k_codes, d, p.codes_per_split, topk, pval, pidx, (int64_t *)nullptr, (float *)nullptr,
                        (const int *)nullptr, (const int *)nullptr, 0, 0);
     if (pa) g_prof.push_back({pa, prof_mark(s), pflops, 1});
     if (check_launch("search_f32(split)")) return 1;
     hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, pval, pidx, (long)n,
-                       p.splits, topk, idx, dist, (const int *)nullptr, (const int *)nullptr);
+                       p.splits, topk, idx, dist, (const int *)nullptr, (const int *)nullptr, (int)k_codes);
     return check_launch("merge_topk");
 }
 
@@ -650,26 +696,25 @@ static int launch_search_t(const float *xhat, const float *xsq, int64_t n, const
     return launch_search<T, false>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
 }
 
-// Set by medtok_soft_vq_forward_f32 around its search call: when the filter path runs, its re-score kernel also does the
+// Handed by medtok_soft_vq_forward_f32 to its search call: when the filter path runs, its re-score kernel also does the
 // soft assignment (and the exact-path leftovers get it from soft_assign_kernel through the row list).
 struct FuseAssign { const float *xref; float *w; float *zq; long zq_stride; bool done; const int *fb_rows, *fb_count; bool xh_done; };
-static thread_local FuseAssign *g_fuse = nullptr;
 
 template <int T, bool KTAIL>
 static int launch_filter(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
                          int64_t k_codes, int d, int topk, int64_t *idx, float *dist, void *ws, size_t ws_bytes,
-                         hipStream_t s)
+                         hipStream_t s, FuseAssign *fuse)
 {
     const FilterPlan f = plan_filter(n, k_codes, d, topk);
     const FilterWs w = filter_ws_layout(ws, n, f);
     if (!ws || ws_bytes < w.total) return fail("search(filter): workspace too small (%zu < %zu)", ws_bytes, w.total);
-    if (!(g_fuse && g_fuse->xh_done))      // (the one-call forward's rownorm has already written the fp16 image of x)
+    if (!(fuse && fuse->xh_done))      // (the one-call forward's rownorm has already written the fp16 image of x)
         hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.n_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, xhat, (long)n, d, f.n_pad, f.dp, w.xh);
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, w.wh);
     hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, w.en_max);
     hipLaunchKernelGGL(pad_wsq_kernel, dim3((unsigned)((f.k_pad + 255) / 256)), dim3(256), 0, s, wsq, (int)k_codes, (int)f.k_pad, w.wsqp);
     if (hipMemsetAsync(w.fb_count, 0, 4, s) != hipSuccess) return fail("search(filter): memset failed");
-    (void)hipFuncSetAttribute((const void *)filter_f16_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM_BYTES);
+    (void)set_lds_once<filter_f16_kernel<T, false>>(F_SMEM_BYTES);
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
     dim3 fgrid((unsigned)f.main_tiles, (unsigned)f.splits);
     if (f.xcd_rows) fgrid = dim3((unsigned)(((f.main_tiles + 8 * f.xcd_rows - 1) / (8 * f.xcd_rows)) * 256), 1);
@@ -689,8 +734,8 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     hipLaunchKernelGGL((rescore_kernel<T>), dim3((unsigned)((n + R_ROWS - 1) / R_ROWS)), dim3(256), 0, s, w.cand, w.cand_cnt, f.own_total,
                        w.cand_tail, w.cnt_tail, f.own_tail, f.main_tiles < f.row_tiles ? tail_start : (long)n,
                        xhat, xsq, what, wsq, w.en_max, (long)n, (int)k_codes, d, topk, idx, dist, w.fb_count, w.fb_rows,
-                       g_fuse ? g_fuse->xref : (const float *)nullptr, g_fuse ? g_fuse->w : (float *)nullptr,
-                       g_fuse ? g_fuse->zq : (float *)nullptr, g_fuse ? g_fuse->zq_stride : 0L);
+                       fuse ? fuse->xref : (const float *)nullptr, fuse ? fuse->w : (float *)nullptr,
+                       fuse ? fuse->zq : (float *)nullptr, fuse ? fuse->zq_stride : 0L);
     if (check_launch("rescore")) return 1;
     // exact redo of the rows the filter gave up on (normally none: every block exits on *fb_count)
     const long code_tiles = (k_codes + S_BM - 1) / S_BM;
@@ -698,33 +743,35 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     const int fb_cps = (int)((code_tiles + fb_splits - 1) / fb_splits * S_BM);
     const int fb_nsplit = (int)((code_tiles * S_BM + fb_cps - 1) / fb_cps);
     const int head = (int)lmin(n, FB_ROWS);
-    (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, false, KTAIL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
+    (void)set_lds_once<search_f32_kernel<T, false, KTAIL, true>>(S_LDS_BYTES);
     hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL, true>), dim3((unsigned)((head + S_BN - 1) / S_BN), (unsigned)fb_nsplit), dim3(256), S_LDS_BYTES, s,
                        xhat, xsq, what, wsq, (long)n, (int)k_codes, d, fb_cps, topk, w.fb_pval, w.fb_pidx, (int64_t *)nullptr, (float *)nullptr,
                        (const int *)w.fb_rows, (const int *)w.fb_count, 0, head);
     hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((head + 31) / 32)), dim3(256), 0, s, w.fb_pval, w.fb_pidx, (long)head,
-                       fb_nsplit, topk, idx, dist, (const int *)w.fb_rows, (const int *)w.fb_count);
+                       fb_nsplit, topk, idx, dist, (const int *)w.fb_rows, (const int *)w.fb_count, (int)k_codes);
     if (n > head) {
-        (void)hipFuncSetAttribute((const void *)search_f32_kernel<T, true, KTAIL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS_BYTES);
+        (void)set_lds_once<search_f32_kernel<T, true, KTAIL, true>>(S_LDS_BYTES);
         hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, true>), dim3((unsigned)((n - head + S_BN - 1) / S_BN), 1), dim3(256), S_LDS_BYTES, s,
                            xhat, xsq, what, wsq, (long)n, (int)k_codes, d, (int)(code_tiles * S_BM), topk,
                            (float *)nullptr, (int *)nullptr, idx, dist, (const int *)w.fb_rows, (const int *)w.fb_count, head, (int)n);
     }
-    if (g_fuse) { g_fuse->done = true; g_fuse->fb_rows = w.fb_rows; g_fuse->fb_count = w.fb_count; }
+    if (fuse) { fuse->done = true; fuse->fb_rows = w.fb_rows; fuse->fb_count = w.fb_count; }
     return check_launch("search_f32(fallback)");
 }
 
 template <int T>
 static int launch_filter_t(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
-                           int64_t k_codes, int d, int topk, int64_t *idx, float *dist, void *ws, size_t ws_bytes, hipStream_t s)
+                           int64_t k_codes, int d, int topk, int64_t *idx, float *dist, void *ws, size_t ws_bytes, hipStream_t s,
+                           FuseAssign *fuse)
 {
-    if (d % S_BK) return launch_filter<T, true>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s);
-    return launch_filter<T, false>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s);
+    if (d % S_BK) return launch_filter<T, true>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse);
+    return launch_filter<T, false>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse);
 }
 
-extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64_t n, const float *what,
-                                      const float *wsq, int64_t k_codes, int d, int topk, int64_t *idx, float *dist,
-                                      void *ws, size_t ws_bytes, int path, void *stream)
+// `fuse` (internal callers only): when the filter path runs, its re-score kernel also does the soft assignment described there
+static int search_impl(const float *xhat, const float *xsq, int64_t n, const float *what,
+                       const float *wsq, int64_t k_codes, int d, int topk, int64_t *idx, float *dist,
+                       void *ws, size_t ws_bytes, int path, void *stream, FuseAssign *fuse)
 {
     if (n < 0 || k_codes <= 0 || d <= 0 || (d & 3)) return fail("search: bad shape n=%ld K=%ld d=%d (d %% 4 == 0)", (long)n, (long)k_codes, d);
     if (topk < 1 || topk > MEDTOK_MAX_TOPK || topk > k_codes) return fail("search: topk=%d unsupported (1..%d, <= K)", topk, MEDTOK_MAX_TOPK);
@@ -736,9 +783,9 @@ extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64
     if (resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER) {
         if (n >= (1ll << 31)) return fail("search(filter): n too large");
         switch (tslots) {
-        case 1: return launch_filter_t<1>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s);
-        case 5: return launch_filter_t<5>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s);
-        default: return launch_filter_t<8>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s);
+        case 1: return launch_filter_t<1>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse);
+        case 5: return launch_filter_t<5>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse);
+        default: return launch_filter_t<8>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse);
         }
     }
     const SearchPlan p = plan_search(n, k_codes, topk);
@@ -747,6 +794,13 @@ extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64
     case 5: return launch_search_t<5>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
     default: return launch_search_t<8>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
     }
+}
+
+extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64_t n, const float *what,
+                                      const float *wsq, int64_t k_codes, int d, int topk, int64_t *idx, float *dist,
+                                      void *ws, size_t ws_bytes, int path, void *stream)
+{
+    return search_impl(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, path, stream, nullptr);
 }
 
 // Test hook: the filter's approximate scores s~ [n, k_codes] (same MFMA sequence as the search uses),
@@ -773,7 +827,7 @@ extern "C" int medtok_debug_filter_scores_f32(const float *xhat, const float *xs
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.n_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, xhat, (long)n, d, f.n_pad, f.dp, xh);
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, wh);
     hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, en_max);
-    (void)hipFuncSetAttribute((const void *)filter_f16_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_SMEM_BYTES);
+    (void)set_lds_once<filter_f16_kernel<5, true>>(F_SMEM_BYTES);
     hipLaunchKernelGGL((filter_f16_kernel<5, true>), dim3((unsigned)f.row_tiles, 1), dim3(F_THREADS), F_SMEM_BYTES, s, xh, wh, xsq, wsqp, en_max,
                        (long)n, (int)k_codes, f.dp, d, (int)f.k_pad, F_OWN_PER_SPLIT, (uint2 *)nullptr, (int *)nullptr, scores, 0, 1,
                        0, (int)f.row_tiles);
@@ -809,7 +863,7 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float *__restric
         }
 #pragma unroll
     for (int j = 0; j < MEDTOK_MAX_TOPK; ++j)
-        if (j < topk) { out_idx[row * topk + j] = bi[j]; out_dist[row * topk + j] = bv[j]; }
+        if (j < topk) { out_idx[row * topk + j] = bi[j] == 0x7fffffffffffffffl ? (long)j : bi[j]; out_dist[row * topk + j] = bv[j]; }   // NaN rows: in range
 }
 
 extern "C" int medtok_merge_topk_lists_f32(const float *dist_parts, const int64_t *idx_parts, int64_t n, int parts, int topk,
@@ -1026,18 +1080,18 @@ extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_s
     if (d != 64 && (d <= 0 || d % 128 || d > 768)) return fail("shared_kv_attention: d=%d must be 64 or a multiple of 128, at most 768", d);
     if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out) return fail("shared_kv_attention: NULL argument");
     if (n_codes == 0 || max_q_len == 0) return 0;
-    if (n_codes > 65535) return fail("shared_kv_attention: at most 65535 codes per call (got %ld)", (long)n_codes);
-    const dim3 grid((unsigned)((max_q_len + 31) / 32), (unsigned)n_codes);
+    const int64_t q_tiles = (max_q_len + 31) / 32;
+    if (q_tiles * n_codes >= (1ll << 31)) return fail("shared_kv_attention: n_codes * ceil(max_q_len / 32) = %ld exceeds the grid limit", (long)(q_tiles * n_codes));
+    const dim3 grid((unsigned)(q_tiles * n_codes));
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
     const int waves = d == 64 ? 2 : (d % 256 == 0 ? 8 : 4);
     const size_t lds = ((size_t)32 * (d + 4) + (waves + 1) * 32 * 33 + 64) * sizeof(float);   // key chunk + per-wave partial scores + probabilities + row state
 #define MEDTOK_ATT(W, NT)                                                                                                        \
     do {                                                                                                                         \
-        if (lds > 64 * 1024 &&                                                                                                   \
-            hipFuncSetAttribute((const void *)shared_kv_attention_kernel<W, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        if (lds > 64 * 1024 && !set_lds_once<shared_kv_attention_kernel<W, NT>>(lds))                                            \
             return fail("shared_kv_attention: cannot reserve %zu bytes of LDS", lds);                                            \
-        hipLaunchKernelGGL((shared_kv_attention_kernel<W, NT>), grid, dim3(64 * W), lds, s, q, q_start, q_len, kv, kv_start, kv_len, scale, out); \
+        hipLaunchKernelGGL((shared_kv_attention_kernel<W, NT>), grid, dim3(64 * W), lds, s, q, q_start, q_len, kv, kv_start, kv_len, scale, out, (int)q_tiles); \
     } while (0)
     switch (d / 128) {
     case 0: MEDTOK_ATT(2, 1); break;      // d = 64, the reference's default e_dim
@@ -1457,9 +1511,8 @@ extern "C" int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d, cons
     } else if (medtok_rownorm_f32(x, n, d, 1, xhat, xsq, stream)) {
         return 1;
     }
-    g_fuse = try_fuse ? &fuse : nullptr;
-    const int rc = medtok_topk_search_f32(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, sws, ws_bytes - align_up((size_t)n * 4, 256), path, stream);
-    g_fuse = nullptr;
+    const int rc = search_impl(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, sws, ws_bytes - align_up((size_t)n * 4, 256), path, stream,
+                               try_fuse ? &fuse : nullptr);
     if (rc) return 1;
     if (!fuse.done) return medtok_soft_assign_f32(x, what, idx, dist, n, d, topk, 0, w, zq_ste, zq_stride, row_sqerr, stream);
     // rows the filter handed to the exact kernel: assignment through the device-side row list (normally empty)

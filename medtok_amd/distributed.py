@@ -18,6 +18,10 @@ from typing import Optional, Tuple
 import torch
 import torch.distributed as dist
 
+# dmabuf IPC is the only kind the host driver supports; must be in the environment before the HIP runtime starts,
+# i.e. before the first torch.cuda call of the process (importing this module is early enough; launchers export it too)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 
 def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, local_rank, world_size); initialises the default process group when
@@ -28,13 +32,17 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         use_gpu = torch.cuda.is_available()
-        if use_gpu:
-            local = local % torch.cuda.device_count()   # (dev: several ranks may share one GPU under the gloo backend)
-            torch.cuda.set_device(local)
-        # MEDTOK_DIST_BACKEND=gloo: dev knob to run the N > 1 code paths on a single-GPU box (RCCL needs one GPU per rank)
+        # MEDTOK_DIST_BACKEND=gloo: run the N > 1 code paths on a single-GPU box (RCCL needs one GPU per rank)
         backend = backend or os.environ.get("MEDTOK_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+        if use_gpu:
+            n_dev = torch.cuda.device_count()
+            if backend == "gloo":
+                local = local % n_dev                   # several ranks may share one GPU under gloo only
+            elif local >= n_dev:
+                raise RuntimeError(f"LOCAL_RANK={local} but only {n_dev} GPU(s) are visible: RCCL needs one GPU per rank "
+                                   f"(oversubscribed launch or wrong LOCAL_RANK)")
+            torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
     elif torch.cuda.is_available():
         local = local % max(torch.cuda.device_count(), 1)

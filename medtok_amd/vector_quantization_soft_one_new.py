@@ -97,6 +97,7 @@ class CrossAttention(nn.Module):
         scores = torch.bmm(qf, kv.transpose(1, 2)) * (hd ** -0.5)
         scores = scores.masked_fill(~key_valid[:, None, :], float("-inf"))
         prob = torch.softmax(scores, dim=-1)
+        prob = prob.masked_fill(~key_valid.any(-1)[:, None, None], 0.0)     # no valid key at all: attend to nothing (not NaN)
         if layer.training and mha.dropout > 0.0:
             prob = torch.nn.functional.dropout(prob, mha.dropout)
         ctx = torch.bmm(prob.to(kv.dtype), kv).view(bsz, rows, heads, dim)
@@ -152,7 +153,9 @@ class CrossAttention(nn.Module):
         mean of the attended graph nodes [B, D]).  Queries never interact, so the
         text side only evaluates its CLS query.  `fold` forces (True) or forbids (False)
         the folded-projection form for the graph side; None picks the cheaper one from
-        the padded shapes (no host sync).  In eval mode without autograd, fp32, D % 128 == 0
+        the padded shapes.  One host sync per call (the largest node count sizes the padded / packed launch; the same
+        read validates `batch`).  A code with no nodes, or no valid token, attends to nothing: its context is zero
+        (the reference's per-code loop would take a softmax over an empty row there).  In eval mode without autograd, fp32, D % 128 == 0
         and folding on, everything runs packed on the ragged gfx950 attention kernel
         (`core`, default ops.shared_kv_attention; tests inject the oracle's restatement).
         """
@@ -162,8 +165,10 @@ class CrossAttention(nn.Module):
             nodes, text = nodes.to(common), text.to(common)
         valid = text_mask.to(torch.bool)
         batch = batch.reshape(-1).to(torch.long)
-        counts = torch.bincount(batch, minlength=bsz)
-        max_nodes = int(counts.max()) if counts.numel() else 0
+        counts = torch.bincount(batch, minlength=bsz) if batch.numel() else torch.zeros(bsz, dtype=torch.long, device=text.device)
+        if counts.numel() != bsz:           # bincount grows past minlength when an id is >= B (and raises on negative ids)
+            raise ValueError(f"pooled(): `batch` must hold code ids in [0, {bsz}); largest id seen: {counts.numel() - 1}")
+        max_nodes = int(counts.max()) if counts.numel() else 0          # the one host sync of this call
         starts = torch.cumsum(counts, 0) - counts
         # nodes of one code need not be contiguous in `batch`: rank them with a stable sort
         order = torch.argsort(batch, stable=True)
@@ -293,12 +298,31 @@ class VectorQuantizer(nn.Module):
             return self.n_e - region, self.n_e
         return 0, self.n_e
 
+    def invalidate_codebook_cache(self):
+        """Drop the cached normalised codebook.  Call after writing the weight in a way autograd's version counter
+        does not see (`codebook.weight.data.copy_()/.uniform_()`, a master-weight copy-back): such writes leave
+        `_version` unchanged, so an eval-mode cache cannot notice them by itself."""
+        self._norm_cache = None
+
+    def train(self, mode: bool = True):
+        self._norm_cache = None              # a mode switch is where weights typically change hands
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._norm_cache = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def _normalised_codebook(self):
-        """normalize(codebook.weight) and its row norms, cached until the weight changes
-        (the reference re-normalises on every call, :148,198,200)."""
+        """normalize(codebook.weight) and its row norms.  The reference re-normalises on every call (:148,198,200);
+        so does this in training mode (one K x D pass, ~60 us at n_e = 49152, D = 768 -- and every optimizer step
+        changes the weight anyway).  In eval mode the result is cached per forward() / per (storage, version) and
+        dropped on train()/eval() switches, load_state_dict and invalidate_codebook_cache()."""
         wt = self.codebook.weight
-        key = (wt.data_ptr(), wt._version, wt.device)
-        if self._norm_cache is None or self._norm_cache[0] != key:
+        key = (wt.data_ptr(), wt._version, wt.device, wt.shape)
+        fresh = self._norm_cache is not None and self._norm_cache[0] == key
+        if fresh and self.training and not getattr(self, "_in_forward", False):
+            fresh = False                    # training: at most one forward() shares a normalisation
+        if not fresh:
             what, wsq = ops.rownorm(wt.detach())
             self._norm_cache = (key, what, wsq)
         return self._norm_cache[1], self._norm_cache[2]
@@ -366,6 +390,9 @@ class VectorQuantizer(nn.Module):
 
     def forward(self, z, text_features, graph_node_features, text_attention_mask, batch, z_aug=None):
         self._defer_usage = []          # collect the usage counts on device, sync once at the end
+        if self.training:
+            self._norm_cache = None     # training: re-normalise once per forward (the 4-6 searches of one forward share it)
+        self._in_forward = True
         try:
             shared_embedding, shared_embed_loss, u_shared = self.get_shared_info(
                 text_features, graph_node_features, text_attention_mask, batch)
@@ -387,6 +414,7 @@ class VectorQuantizer(nn.Module):
             deferred = self._defer_usage[:3]
         finally:
             self._defer_usage = None
+            self._in_forward = False
         if self.show_usage and deferred:
             u_shared, u_text, u_graph = (torch.stack(deferred).cpu().double() / self.n_e).tolist()
         out = {

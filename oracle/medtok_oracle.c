@@ -375,7 +375,7 @@ int oracle_shared_kv_attention_f32(const float *q, const int64_t *q_start, const
             for (int i = 0; i < d; ++i) {
                 double a = 0.0;
                 for (int64_t j = 0; j < kl; ++j) a += sc[j] * kv[(kv_start[b] + j) * d + i];
-                out[r * d + i] = (float)(a / l);
+                out[r * d + i] = l > 0.0 ? (float)(a / l) : 0.0f;      /* no key rows: the code attends to nothing (build's rule) */
             }
         }
         free(sc);

@@ -27,7 +27,9 @@ def test_bench_prints_one_contract_line(dev, args):
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and r["bound"] in ("hbm", "mfma")
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "hbm_frac", "algorithmic_bytes_per_step"} <= set(r)
+    assert r["bound"] in ("hbm", "mfma") and (r["traffic"] is None) == (r["traffic_source"] is None)
+    assert r["traffic"] is None              # reduced row counts: the recorded PMC figure does not apply, so none is printed
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] in ("port", "reference") and c["value"] > 0
@@ -60,3 +62,20 @@ def test_two_rank_bench_on_one_gpu(dev, workload):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["cpu_baseline"] is None
     assert d["scaling"] == ("weak" if workload == "cfg3" else "strong")
+
+
+def test_bench_gpus_2_starts_its_own_ranks(dev):
+    """The driver's command line -- `python bench.py --gpus N`, no torchrun in front -- must launch the ranks itself (fresh child
+    processes started before the parent touches the GPU).  Two ranks share this box's one GPU over gloo."""
+    import os
+    env = dict(os.environ, MEDTOK_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "20000"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["rows_per_gpu"] == 20000

@@ -146,8 +146,16 @@ def test_filter_race_screen(dev):
             assert torch.equal(i1, i2) and torch.equal(d1, d2), (rep, n, k, d)
 
 
+@pytest.fixture
+def plan():
+    """ops.debug_plan_override with a guaranteed reset (the override is process-wide)."""
+    from medtok_amd import ops
+    yield ops.debug_plan_override
+    ops.debug_plan_override()
+
+
 @pytest.mark.parametrize("splits", [2, 4, 8])
-def test_xcd_block_order_gives_the_same_bits(dev, splits, monkeypatch):
+def test_xcd_block_order_gives_the_same_bits(dev, splits, plan):
     """The XCD-aware block order (default from 1024 row tiles up) forced at a small size: every (row tile, split) pair must be
     visited exactly once -- ids and distances equal the exact path, including a row count that leaves XCD chunks partly empty."""
     from medtok_amd import ops
@@ -156,8 +164,7 @@ def test_xcd_block_order_gives_the_same_bits(dev, splits, monkeypatch):
     xh, xs = ops.rownorm(torch.randn(n, D, device=dev, generator=g))
     wh, ws = ops.rownorm(torch.randn(K, D, device=dev, generator=g))
     i_ref, d_ref = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F32_MFMA)
-    monkeypatch.setenv("MEDTOK_FILTER_SPLITS", str(splits))
-    monkeypatch.setenv("MEDTOK_FILTER_XCD", "1")
+    plan(filter_splits=splits, filter_xcd=1)
     i_x, d_x = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
     assert torch.equal(i_x, i_ref) and torch.equal(d_x, d_ref)
 
@@ -194,7 +201,7 @@ def test_fused_assignment_equals_separate_kernels(dev, case):
 
 
 @pytest.mark.parametrize("splits,tiles", [(2, 131), (4, 70), (1, 260)])
-def test_tail_launch_gives_the_same_bits(dev, splits, tiles, monkeypatch):
+def test_tail_launch_gives_the_same_bits(dev, splits, tiles, plan):
     """Large searches launch the row tiles of the last, partly filled round of blocks separately with more code splits (their own
     candidate lists, a second region the re-score kernel reads by row range).  Forced here at a small size."""
     from medtok_amd import ops
@@ -203,10 +210,8 @@ def test_tail_launch_gives_the_same_bits(dev, splits, tiles, monkeypatch):
     xh, xs = ops.rownorm(torch.randn(n, D, device=dev, generator=g))
     wh, ws = ops.rownorm(torch.randn(K, D, device=dev, generator=g))
     i_ref, d_ref = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F32_MFMA)
-    monkeypatch.setenv("MEDTOK_FILTER_SPLITS", str(splits))
-    monkeypatch.setenv("MEDTOK_FILTER_TAIL", "256")
-    for xcd in ("0", "1"):
-        monkeypatch.setenv("MEDTOK_FILTER_XCD", xcd)
+    for xcd in (0, 1):
+        plan(filter_splits=splits, filter_tail_min_blocks=256, filter_xcd=xcd)
         i_t, d_t = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
         assert torch.equal(i_t, i_ref) and torch.equal(d_t, d_ref), xcd
     r = ops.soft_vq_forward(xh, wh, ws, 5, ops.PATH_F16_FILTER, want_sqerr=False)      # fused assignment over both regions

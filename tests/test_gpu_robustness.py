@@ -1,0 +1,102 @@
+"""GPU: behaviour the reference gets for free from ATen and a fused path has to earn -- valid token ids for non-finite rows,
+a codebook cache that cannot go stale silently, attention over empty key sets."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("path_name", ["exact", "filter"])
+@pytest.mark.parametrize("topk", [1, 5])
+def test_non_finite_rows_keep_token_ids_in_range(dev, path_name, topk):
+    """NaN / Inf / all-zero input rows (an overflowed AMP activation, a pooled row of an empty graph): torch.topk and argmin
+    return valid indices for them and the reference's GradScaler loop survives the step.  Here: ids in [0, K) on both search
+    paths, no memory fault in the gathers (assignment, fused assignment, sparse backward), healthy rows untouched."""
+    from medtok_amd import ops
+    path = ops.PATH_F32_MFMA if path_name == "exact" else ops.PATH_F16_FILTER
+    g = torch.Generator(device=dev).manual_seed(3)
+    n, K, D = 6000, 4096, 128
+    x = torch.randn(n, D, device=dev, generator=g)
+    W = torch.randn(K, D, device=dev, generator=g)
+    bad_nan, bad_inf, bad_zero = [5, 257, 5999], [6, 300], [7, 4000]
+    x_bad = x.clone()
+    x_bad[bad_nan, 3] = float("nan"); x_bad[bad_inf, 0] = float("inf"); x_bad[bad_zero] = 0.0
+    what, wsq = ops.rownorm(W)
+    good = ops.soft_vq_forward(x, what, wsq, topk, path, want_sqerr=False)
+    for want_sqerr in (False, True):                  # fused assignment in the re-score kernel / stand-alone kernel
+        r = ops.soft_vq_forward(x_bad, what, wsq, topk, path, want_sqerr=want_sqerr)
+        torch.cuda.synchronize()
+        idx = r["idx"]
+        assert int(idx.min()) >= 0 and int(idx.max()) < K
+        keep = torch.ones(n, dtype=torch.bool, device=dev); keep[bad_nan + bad_inf + bad_zero] = False
+        assert torch.equal(idx[keep], good["idx"][keep]) and torch.equal(r["zq"][keep], good["zq"][keep])
+        assert torch.isfinite(r["zq"][bad_zero]).all()      # zero rows normalise to zero: a perfectly good query
+    gx, gc = ops.soft_vq_backward(x_bad, r["xhat"], what, r["idx"], r["w"], g_zq=torch.ones_like(x))
+    torch.cuda.synchronize()
+    assert gx.shape == x.shape and gc.shape == (n * topk, D)
+    # the argmin + EMA module on the same rows
+    from medtok_amd.norm_ema_quantizer import NormEMAVectorQuantizer
+    q = NormEMAVectorQuantizer(K, D, 0.25).to(dev).train()
+    q.search_path = path
+    with torch.no_grad():
+        _, _, ids = q(x_bad[:, :, None, None])
+    torch.cuda.synchronize()
+    assert int(ids.min()) >= 0 and int(ids.max()) < K
+
+
+def test_codebook_cache_follows_data_writes(dev):
+    """`.data` writes do not bump autograd's version counter.  Training mode re-normalises every call; eval mode caches and is
+    told through invalidate_codebook_cache() / load_state_dict / train()-eval() switches."""
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    torch.manual_seed(0)
+    D = 64
+    v = VectorQuantizer(3 * 512, D, 0.25, 0.0, True, False, [D, D]).to(dev)
+    x = torch.randn(300, D, device=dev)
+    fresh = torch.randn_like(v.codebook.weight)
+
+    def ids():
+        with torch.no_grad():
+            v.specific_embedding(x, "text")
+        return v._last_specific[0].clone()
+
+    v.train()
+    a = ids()
+    v.codebook.weight.data.copy_(fresh)                  # invisible to _version
+    b = ids()
+    w2 = VectorQuantizer(3 * 512, D, 0.25, 0.0, True, False, [D, D]).to(dev).train()
+    w2.load_state_dict(v.state_dict())
+    with torch.no_grad():
+        w2.specific_embedding(x, "text")
+    assert torch.equal(b, w2._last_specific[0]) and not torch.equal(a, b)
+    v.eval()
+    c = ids()
+    assert torch.equal(c, b)                             # the mode switch dropped the cache
+    v.codebook.weight.data.mul_(-1.0)
+    v.invalidate_codebook_cache()
+    d = ids()
+    assert not torch.equal(d, c)
+    sd = {k: t.clone() for k, t in v.state_dict().items()}
+    sd["codebook.weight"] = fresh
+    v.load_state_dict(sd)
+    assert torch.equal(ids(), b)
+
+
+def test_attention_kernel_with_empty_key_sets_and_many_codes(oracle, dev):
+    """Codes without key rows give a zero context (not 0/0); more than 65535 codes in one call (the old grid.y limit)."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(0)
+    d, n_codes = 128, 70000
+    q_len = rng.integers(1, 4, n_codes).astype(np.int64)
+    kv_len = rng.integers(0, 5, n_codes).astype(np.int64)
+    kv_len[[0, 17, n_codes - 1]] = 0
+    q_start, kv_start = np.cumsum(q_len) - q_len, np.cumsum(kv_len) - kv_len
+    q = (rng.standard_normal((int(q_len.sum()), d)) * 0.3).astype(np.float32)
+    kv = rng.standard_normal((max(int(kv_len.sum()), 1), d)).astype(np.float32)
+    T = lambda a: torch.from_numpy(a).to(dev)
+    out = ops.shared_kv_attention(T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len), int(q_len.max()), 0.25).cpu().numpy()
+    ref = oracle.shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, 0.25)
+    assert np.isfinite(out).all()
+    assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
+    empty_rows = np.concatenate([np.arange(q_start[b], q_start[b] + q_len[b]) for b in np.nonzero(kv_len == 0)[0]])
+    assert not out[empty_rows].any()

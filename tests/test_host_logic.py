@@ -153,3 +153,63 @@ def test_global_mean_pool():
     x = torch.tensor([[1.0, 2], [3, 4], [5, 6]])
     out = global_mean_pool(x, torch.tensor([0, 0, 2]), 3)
     assert torch.equal(out, torch.tensor([[2.0, 3], [0, 0], [5, 6]]))
+
+
+def test_pooled_edge_cases_empty_graph_and_bad_batch():
+    """A code without graph nodes (or without a valid token) attends to nothing: finite outputs, every form agrees; a `batch`
+    id outside [0, B) is rejected where it enters."""
+    from medtok_amd.vector_quantization_soft_one_new import CrossAttention
+    from oracle import oracle as O
+    torch.manual_seed(0)
+    D, B, L = 64, 5, 12
+    ca = CrossAttention(D, 4).eval()
+    text = torch.randn(B, L, D)
+    mask = torch.ones(B, L, dtype=torch.long); mask[1, 3:] = 0; mask[4, :] = 0          # code 4: no valid token at all
+    batch = torch.tensor([0, 0, 0, 1, 3, 3, 4])                                          # code 2: no nodes
+    nodes = torch.randn(batch.numel(), D)
+
+    def core(q, qs, ql, kv, ks, kl, max_q_len, scale):
+        return torch.from_numpy(O.shared_kv_attention(q.numpy(), qs.numpy(), ql.numpy(), kv.numpy(), ks.numpy(), kl.numpy(), scale))
+    with torch.no_grad():
+        outs = [ca.pooled(text, mask, nodes, batch, fold=f, core=c) for f, c in ((False, None), (True, None), (True, core))]
+    for pt, pg in outs:
+        assert torch.isfinite(pt).all() and torch.isfinite(pg).all()
+        assert float(pg[2].abs().max()) == 0.0                        # mean over no nodes
+    for pt, pg in outs[1:]:
+        assert rel(pt, outs[0][0].numpy()) <= 1e-5 and rel(pg, outs[0][1].numpy()) <= 1e-5
+    with pytest.raises(ValueError, match="batch"):
+        ca.pooled(text, mask, nodes, torch.tensor([0, 0, 0, 1, 3, 3, 5]))
+
+
+def test_bench_parent_spawns_ranks_without_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE: the parent starts torch.distributed.run children on 127.0.0.1 and relays
+    their exit code; with RCCL it refuses up front when fewer GPUs are visible than ranks (here: none)."""
+    import importlib.util
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    spec = importlib.util.spec_from_file_location("bench_mod", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    seen = {}
+
+    class FakeProc:
+        stdout = iter(['noise\n', '{"metric": "x"}\n'])
+        def wait(self): return 7
+
+    def fake_popen(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return FakeProc()
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1"])
+    monkeypatch.setenv("MEDTOK_DIST_BACKEND", "gloo")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    rc = bench.spawn_ranks(bench.parse())
+    assert rc == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.delenv("MEDTOK_DIST_BACKEND")
+    if torch.cuda.device_count() < 2:
+        assert bench.spawn_ranks(bench.parse()) == 2          # RCCL: one GPU per rank, checked before anything is started

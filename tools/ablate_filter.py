@@ -1,6 +1,9 @@
-"""Dev tool: filter kernel time only (results are garbage under the ablation macros) for the library in MEDTOK_VQ_LIB."""
+"""Dev tool: filter kernel time only (results are garbage under the ablation macros) for the library in MEDTOK_TOOL_LIB."""
 import sys, time
 sys.path.insert(0, ".")
+import os as _os
+if _os.environ.get("MEDTOK_TOOL_LIB"):            # dev A/B: an alternative build of the same ABI
+    from medtok_amd import _lib as _l; _l.use_library(_os.environ["MEDTOK_TOOL_LIB"])
 import torch
 from medtok_amd import ops
 dev = torch.device("cuda:0")

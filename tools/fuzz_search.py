@@ -25,9 +25,8 @@ for c in range(cases):
     norm = kind != 3
     xh, xs = ops.rownorm(x); wh, ws = ops.rownorm(W, normalize=norm) if not norm else ops.rownorm(W)
     if not norm: wh = W.contiguous()
-    for env in ({}, {"MEDTOK_FILTER_SPLITS": str(int(rng.choice([1, 2, 4, 8]))), "MEDTOK_FILTER_XCD": "1"}):
-        for kk in ("MEDTOK_FILTER_SPLITS", "MEDTOK_FILTER_XCD"): os.environ.pop(kk, None)
-        os.environ.update(env)
+    for env in ({}, dict(filter_splits=int(rng.choice([1, 2, 4, 8])), filter_xcd=1), dict(filter_stagger=1), dict(filter_stagger=0)):
+        ops.debug_plan_override(**env)
         i0, d0 = ops.topk_search(xh, xs, wh, ws, k, ops.PATH_F32_MFMA)
         i1, d1 = ops.topk_search(xh, xs, wh, ws, k, ops.PATH_F16_FILTER)
         ok = torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32))

@@ -11,7 +11,7 @@ for n, K in ((256, 49152), (256, 16384), (1024, 49152), (64, 49152)):
     xh, xs = ops.rownorm(x); wh, ws = ops.rownorm(W)
     ref = None
     for cap in (64, 128, 192, 384):
-        os.environ["MEDTOK_SEARCH_MAXSPLITS"] = str(cap)
+        ops.debug_plan_override(search_max_splits=cap)
         for _ in range(3): i, d = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F32_MFMA)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(50): i, d = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F32_MFMA)

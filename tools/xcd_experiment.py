@@ -1,4 +1,4 @@
-"""Dev tool: filter_f16_kernel time vs code splits / XCD-aware block order (env knobs are read per launch by the library)."""
+"""Dev tool: filter_f16_kernel time vs code splits / XCD-aware block order (plan forced through ops.debug_plan_override)."""
 import os, sys
 sys.path.insert(0, ".")
 import torch
@@ -10,9 +10,7 @@ x = torch.randn(N, D, device=dev, generator=g); W = torch.randn(K, D, device=dev
 xh, xs = ops.rownorm(x); wh, ws = ops.rownorm(W)
 ref = None
 for splits, xcd in ((0, 0), (2, 1), (4, 0), (4, 1), (8, 0), (8, 1), (16, 1)):
-    if splits: os.environ["MEDTOK_FILTER_SPLITS"] = str(splits)
-    else: os.environ.pop("MEDTOK_FILTER_SPLITS", None)
-    os.environ["MEDTOK_FILTER_XCD"] = str(xcd)
+    ops.debug_plan_override(filter_splits=splits or -1, filter_xcd=xcd)
     for _ in range(2): idx, dist = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
     torch.cuda.synchronize()
     ops.profile_begin()
