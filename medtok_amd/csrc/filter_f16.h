@@ -36,8 +36,8 @@ constexpr int F_TILEB = F_BM * F_ROWB;                        // 16 KB per opera
 constexpr int F_STAGEB = 2 * F_TILEB;                         // A + B = 32 KB
 constexpr int F_RING = 4;                                     // stages in the LDS ring: 3 in flight while 1 is computed on
 constexpr size_t F_LDS_BYTES = (size_t)F_RING * F_STAGEB;     // 128 KB -> 1 block (8 waves) / CU
-constexpr size_t F_THR_BYTES = 256 * 2 * 5 * sizeof(float);  // per row: the k <= 5 smallest d~ of each code-side wave pair
-constexpr size_t F_SMEM_BYTES = F_LDS_BYTES + F_THR_BYTES + 512 * 32;   // + thresholds + candidate parking (2 x 2 x 8 B per lane)
+constexpr size_t F_THR_BYTES = 256 * 64;                      // per row: the k <= 5 smallest d~ of each code-side wave pair (2 x 32 B)
+constexpr size_t F_SMEM_BYTES = F_LDS_BYTES + F_THR_BYTES;    // 144 KB
 constexpr int F_GLDS_PER_STAGE = 4;                           // LDS-DMA instructions each wave issues per stage
 constexpr int F_CAP = 96;                                     // candidate slots per (row, owner): ~25-30 used on random data
 #ifndef MEDTOK_FILTER_WM
@@ -62,7 +62,11 @@ __device__ __forceinline__ float filter_eps(float xn, float en_max, int d)
     const float mag = sqrtf(xn * en_max);
     const float flush = 0x1p-21f * sqrtf((float)d) * sqrtf(fmaxf(xn, en_max));
     const float ulps = 0x1p-20f * (xn + en_max + 2.0f * mag);      // a handful of fp32 roundings of d-sized values
-    return 2.0f * filter_gamma(d) * mag * 1.0001f + 2.0f * flush + ulps;
+    // the accumulators start at -2^15 |e|^2 instead of 0: every one of the <= d + 63 additions of the chain rounds a value of
+    // magnitude <= 2^15 (|e|^2 + 2 mag), i.e. 2^-24 (|e|^2 + 2 mag) in d units; the 2 mag part is inside gamma's D 2^-21,
+    // the |e|^2 part is budgeted here with the same factor 8 over the one-ulp-per-addition model
+    const float start = (float)(d + 64) * 0x1p-21f * en_max;
+    return 2.0f * filter_gamma(d) * mag * 1.0001f + 2.0f * flush + ulps + start;
 }
 
 // ---------------------------------------------------------------- operand preparation
@@ -124,30 +128,216 @@ __device__ __forceinline__ void thr_insert(float (&tv)[T], float v)
     }
 }
 
+// thr_insert without branches: one min/max pair per slot carries the displaced value down the list.  (In the scan every
+// instruction of a dependent, branchy insert is exposed latency; NaN never gets here -- a NaN fails the >= test -- and the
+// warm-up pass maps it to +inf first.)
+template <int T>
+__device__ __forceinline__ void thr_insert_bf(float (&tv)[T], float v)
+{
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const float lo = fminf(tv[j], v);
+        v = fmaxf(tv[j], v);
+        tv[j] = lo;
+    }
+}
+
+// Per-lane state of one 32-row column tile of the filter kernel: the k smallest u = d~ - |x|^2 seen so far, the limit in
+// accumulator scale, the row's constants and its candidate list.  Plain structs and force-inlined functions with explicit
+// references, not closures: hipcc leaves by-reference lambda captures that are reached through other lambdas in scratch
+// memory (a flat load plus a vmcnt wait in the middle of the scan).
+template <int TOPK>
+struct FilterRow {
+    float tv[TOPK];       // sorted ascending
+    float L;              // a value passes when acc >= L  (<=> u <= t + win)
+    float xn, win;        // |x|^2; 2 eps (-inf for padding rows: their limit stays +inf and nothing is ever appended)
+    int cnt;              // appended candidates (global list)
+    uint2 *list;          // this lane's candidate list of the row
+    unsigned lst;         // LDS byte address of the row's shared k-lists: [2 code-side waves][8 floats, 5 used]
+};
+constexpr int F_LST_ROWB = 64;        // bytes per row of the shared k-lists (two 32-byte halves: 16-byte aligned b128 reads)
+
+// LDS accesses of the epilogue go through asm.  hipcc orders ds_writes -- and, outside the main loop, ds_reads -- behind ALL
+// pending LDS-DMA ("s_waitcnt vmcnt(0)": a DMA is a pending LDS write that might alias), i.e. every one of them drained the
+// operand ring: for the waves that have just issued their DMA, a round trip to the L2 or beyond, several times per scan.
+// These bytes are never DMA targets.  (Same-wave LDS operations complete in order; the untracked lgkmcnt ticks only ever
+// make the compiler's own counted waits more conservative.)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_store_list(unsigned addr, const float (&c)[5])
+{
+    f32x4 q = {c[0], c[1], c[2], c[3]};
+    asm volatile("ds_write_b128 %0, %1\n\tds_write_b32 %0, %2 offset:16" ::"v"(addr), "v"(q), "v"(c[4]) : "memory");
+}
+// The other code-side wave's lists of both rows: four reads issued early (they may be a few stages stale anyway), waited for
+// where the values are needed.  Between the two statements the destination registers belong to the hardware: the wait
+// statement names them as read-write so that hipcc neither uses nor moves them before it.
+struct OtherLists { f32x4 q0, q1; float e0, e1; };
+__device__ __forceinline__ void lds_load_lists_issue(unsigned addr0, unsigned addr1, OtherLists &o)
+{
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b32 %1, %4 offset:16\n\tds_read_b128 %2, %5\n\tds_read_b32 %3, %5 offset:16"
+                 : "=&v"(o.q0), "=&v"(o.e0), "=&v"(o.q1), "=&v"(o.e1) : "v"(addr0), "v"(addr1) : "memory");
+}
+__device__ __forceinline__ void lds_load_lists_wait(OtherLists &o)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.q0), "+v"(o.e0), "+v"(o.q1), "+v"(o.e1)::"memory");
+}
+// value of the lane 32 away: v_permlane32_swap exchanges the upper half of one operand with the lower half of the other, so with
+// both operands = v the results hold v's lower half twice and its upper half twice (one VALU instruction; ds_bpermute is an
+// LDS round trip)
+__device__ __forceinline__ float other_half(float v, int lh)
+{
+    const unsigned b = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return __uint_as_float(lh ? r[0] : r[1]);
+}
+
+// The scan of one finished accumulator tile: four values per test (a 4-way max and ONE compare); only a quad that holds a
+// passing value in some lane is scanned value by value.  A hit is rare per lane but not per wave (64 lanes x 4 values at
+// p ~ 3e-3: half the quads): it is appended to the lane's candidate list and, unless the warm-up pass has counted it already,
+// folded into the lane's k-smallest list right there.  cb = the lane's first code of this 32-code group.
+// (Round 1 parked hits in LDS and flushed them once per 128 values, when a scan held many of them; with 16 values per scan
+// and row the parking only added LDS round trips -- each behind a drain of the DMA ring, see above.)
+template <int TOPK>
+__device__ __forceinline__ void filter_scan(FilterRow<TOPK> &r, const f32x16 &a, int cb, bool counted)
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float a0 = a[4 * g], a1 = a[4 * g + 1], a2 = a[4 * g + 2], a3 = a[4 * g + 3];
+        const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+        if (mx >= r.L) {
+            // Somewhere in the wave a value of this quad passes.  Each lane walks its own hits, lowest register first -- nearly
+            // always one lane with one hit, i.e. ONE pass of the body below instead of four exec-masked copies of it.
+            bool h0 = a0 >= r.L, h1 = a1 >= r.L, h2 = a2 >= r.L, h3 = a3 >= r.L;
+            while (h0 || h1 || h2 || h3) {
+                const float v = h0 ? a0 : h1 ? a1 : h2 ? a2 : a3;
+                const int j = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
+                h3 = h3 && (h0 || h1 || h2); h2 = h2 && (h0 || h1); h1 = h1 && h0; h0 = false;
+                const float u = v * -0x1p-15f;
+                if (r.cnt < F_CAP) r.list[r.cnt] = make_uint2(__float_as_uint(u + r.xn), (unsigned)(cb + j + 8 * g));
+                ++r.cnt;
+                if (!counted) thr_insert_bf<TOPK>(r.tv, u);
+            }
+        }
+    }
+}
+
+// acc >= L  <=>  u <= t + win.  t = +inf (fewer than k real codes seen): everything finite passes, but not the -inf of padded
+// codes.  win = -inf marks a padding row: its limit stays +inf whatever t is (inf - inf would be NaN -> everything passes).
+__device__ __forceinline__ float filter_limit(float t, float win)
+{
+    return win == -INFINITY ? INFINITY : fmaxf(-32768.0f * (t + win), -3.0e38f);
+}
+
+// After the scans: combine the four owners of each of the wave's two rows into one limit per row.
+// The row's k-th best over ALL codes seen so far, exactly: merge the sorted k-lists of the row's four owners.  (The minimum of
+// the owners' own k-th bests is only about the 4k-th best of the union: 2-3 x the candidates.)  Two sorted lists a, b:
+// {min(a_i, b_{k-1-i})} are the k smallest of their union.  The lh partner comes by shuffle; the other code-side wave
+// publishes its merged list in LDS -- possibly a few stages old, which is still a list of values of real codes, so T stays
+// valid.  (Extending the union across code splits through agent-scope global lists was measured 10 % SLOWER.)
+template <int TOPK>
+__device__ __forceinline__ void filter_merge_pair(FilterRow<TOPK> &r0, FilterRow<TOPK> &r1, int wm, int lh)
+{
+    constexpr int TL = TOPK < 5 ? TOPK : 5;       // list length shared per (row, code-side wave)
+    float t0, t1;
+    if (TOPK <= 5) {
+        OtherLists ot;
+        lds_load_lists_issue(r0.lst + (wm ^ 1) * 32, r1.lst + (wm ^ 1) * 32, ot);
+        float c0[5], c1[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { c0[i] = INFINITY; c1[i] = INFINITY; }
+#pragma unroll
+        for (int i = 0; i < TL; ++i) {
+            c0[i] = fminf(r0.tv[i], other_half(r0.tv[TL - 1 - i], lh));
+            c1[i] = fminf(r1.tv[i], other_half(r1.tv[TL - 1 - i], lh));
+        }
+#pragma unroll
+        for (int pass = 0; pass < TL; ++pass)              // odd-even transposition: ascending
+#pragma unroll
+            for (int i = pass & 1; i + 1 < TL; i += 2) {
+                const float lo0 = fminf(c0[i], c0[i + 1]), hi0 = fmaxf(c0[i], c0[i + 1]);
+                c0[i] = lo0; c0[i + 1] = hi0;
+                const float lo1 = fminf(c1[i], c1[i + 1]), hi1 = fmaxf(c1[i], c1[i + 1]);
+                c1[i] = lo1; c1[i + 1] = hi1;
+            }
+        if (lh == 0) {
+            lds_store_list(r0.lst + wm * 32, c0);
+            lds_store_list(r1.lst + wm * 32, c1);
+        }
+        lds_load_lists_wait(ot);
+        const float o0[5] = {ot.q0[0], ot.q0[1], ot.q0[2], ot.q0[3], ot.e0}, o1[5] = {ot.q1[0], ot.q1[1], ot.q1[2], ot.q1[3], ot.e1};
+        t0 = -INFINITY; t1 = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < TL; ++i) {
+            t0 = fmaxf(t0, fminf(c0[i], o0[TL - 1 - i]));
+            t1 = fmaxf(t1, fminf(c1[i], o1[TL - 1 - i]));
+        }
+    } else {                 // k = 8: the lists would not fit beside the ring; the pair's looser min rule
+        t0 = fminf(r0.tv[TOPK - 1], other_half(r0.tv[TOPK - 1], lh));
+        t1 = fminf(r1.tv[TOPK - 1], other_half(r1.tv[TOPK - 1], lh));
+    }
+    r0.L = filter_limit(t0, r0.win);
+    r1.L = filter_limit(t1, r1.win);
+}
+
+// accumulator start values of one 32-code group: -2^15 |e|^2 of this lane's 16 codes, both row tiles.  sp is wave-uniform ->
+// scalar loads (lgkmcnt, not vmcnt): the ring's DMA queue is not drained.
+__device__ __forceinline__ void filter_init_group(f32x16 &a0, f32x16 &a1, const float *__restrict__ sp, int lh)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int c = (r & 3) + 8 * (r >> 2);
+        const float lo = sp[c], hi = sp[c + 4];
+        const float v = lh ? hi : lo;
+        a0[r] = v; a1[r] = v;
+    }
+}
+
 // ---------------------------------------------------------------- the filter kernel
 // (Rejected variant, measured 14-24 % slower: 4-wave blocks of 256 codes x 128 rows, two per CU, hoping that co-resident
 // blocks drifting apart overlap one block's epilogue / DMA issue with the other's MFMAs -- it moves 1.5 x the L2 -> LDS
-// bytes per flop, and operand delivery is what binds this kernel.  The ring could also be 3 stages deep instead of 4:
-// the slot of stage s is free after the mid-iteration barrier of s.)
+// bytes per flop, and operand delivery is what binds this kernel.)
 // Block = 8 waves (2 code-side x 4 row-side), tile 256 codes x 256 rows, wave tile 128 x 64 = 4 x 2 MFMA
 // tiles of 32x32x16 (L2->LDS traffic per flop halves against a 128^2 tile; at fp16 rates that is what
-// binds).  Operands arrive by LDS-DMA (global_load_lds, 16 B/lane) into a double buffer; a tile row is
-// 128 B = 8 chunks, stored at chunk position c ^ ((row >> 1) & 7) so that the 16 rows a ds_read_b128
-// lane group touches land on 16 distinct 16-byte bank slots (the permutation is applied to the
-// per-lane SOURCE address; the LDS image itself is lane-linear as the DMA requires).
+// binds).  Operands arrive by LDS-DMA (buffer_load ... lds, 16 B/lane) into a 4-stage ring; a staged tile row is
+// 64 B = 4 chunks, stored at chunk position c ^ ((row >> 2) & 3) so that the rows a ds_read_b128 lane group
+// touches land on distinct 16-byte bank slots (the permutation is applied to the per-lane SOURCE address; the
+// LDS image itself is lane-linear as the DMA requires).
 // As in the fp32 kernel, codes are the A rows: a lane ends up with 16 codes of one input row per tile,
-// so thresholds and candidate appends are lane-local.  wsqp is a 16-byte aligned copy of wsq padded
-// with +inf to a multiple of 256, so the epilogue reads it as float4 with no bounds checks.
-template <int TOPK, bool DUMP>
+// so thresholds and candidate appends are lane-local.
+//
+// Scores in accumulator scale.  wsqs[c] = -2^15 |e_c|^2 (padded with -inf to a multiple of 256).  A code group's
+// accumulators START at that value instead of 0, so that after the k loop   acc = 2^16 s~ - 2^15 |e|^2 = -2^15 u,
+// u = |e|^2 - 2 s~ = d~ - |x|^2:  the epilogue tests  acc >= L  (L = -2^15 * limit, per lane) with no arithmetic per
+// value, and |e|^2 is read once per group and tile through the SCALAR cache (the 32 values are wave-uniform; a lane
+// picks by its half) -- a vector load here would wait for vmcnt(0), i.e. drain the whole LDS-DMA ring, every time.
+//
+// Staggered epilogue (STAG).  The scan of a finished code tile is VALU work; if both waves of a SIMD do it at the same
+// time the matrix pipe has nothing to issue (measured: 26 % of the kernel).  The order in which a dot product visits
+// its k16 half steps is free, and the x tile's k blocks recur with period nkb, so a 32-code group may switch to its next
+// code tile at ANY half step: group g' = 2 m + wm (m = group within the wave, wm = code-side wave) does so in the MIDDLE of
+// the stage that lies r = g' nkb / 8 + 1 stages into the cycle -- after the first half step's MFMAs and the barrier, before
+// the second half step's.  The eight groups of a SIMD's wave pair then finish one at a time, alternating between the two
+// waves, every nkb/8 stages, and while one wave scans (a quarter of its accumulators) its partner has the 16 MFMAs up to
+// the next barrier to issue.  For the DMA this means that the staged A rows of such a stage hold the OLD code tile in their
+// first two 16-byte chunks (k16 step 0) and the NEW one in the last two: one masked add on the per-lane source offset.
+// Cost: after the first code tile (scanned by all groups at once, which also teaches every list its threshold before
+// anything is appended) group g' idles r - 1/2 stages, and the block runs 7 nkb / 8 + 1 extra stages at the end -- about
+// 7/16 of a code tile per block, so staggering is used only when a block has >= 12 code tiles.
+__device__ __forceinline__ int filter_rot(int gp, int nkb) { return ((gp * nkb) >> 3) + 1; }
+constexpr int F_STAG_MIN_NKB = 16, F_STAG_MIN_TILES = 12;      // (a switch takes two stages: the SIMD partner's must not overlap it)
+
+template <int TOPK, bool DUMP, bool STAG>
 __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     const _Float16 *__restrict__ xh, const _Float16 *__restrict__ wh, const float *__restrict__ xsq,
-    const float *__restrict__ wsqp, const float *__restrict__ en_max_ptr, long n, int k_codes, int dp, int d,
+    const float *__restrict__ wsqs, const float *__restrict__ en_max_ptr, long n, int k_codes, int dp, int d,
     int codes_per_split, int own_total, uint2 *__restrict__ cand, int *__restrict__ cand_cnt,
     float *__restrict__ dump, int xcd_rows, int n_splits, int row_tile_base, int row_tile_end)
 {
+    static_assert(F_WM == 2 && F_MT == 4 && F_NT == 2, "the wave tile is 128 codes x 64 rows");
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / F_WN, wn = wave % F_WN;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);                   // provably wave-uniform copies
+    const int wm = wave / F_WN, wn = wave % F_WN, wm_s = wave_s / F_WN;
     const int li = lane & 31, lh = lane >> 5;
     // Block -> (row tile, code split).  Plain: grid (row tiles, splits).  XCD-aware (xcd_rows > 0): consecutive block ids
     // go round-robin to the 8 XCDs and each XCD runs 32 of its blocks at a time, so block j of XCD x is made
@@ -170,12 +360,12 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     const int code_hi = min(k_codes, code_lo + codes_per_split);
     const int nct = (code_hi - code_lo + F_BM - 1) / F_BM;
     const int nkb = dp / F_BK;
-    const int nstage = nct * nkb;
+    constexpr bool stag = STAG;              // (the host launches this instantiation only for blocks of >= F_STAG_MIN_TILES code tiles)
+    const int nstage = nct * nkb + (stag ? filter_rot(7, nkb) + 1 : 0);      // (+1: the second part of the last group's last scan)
 
-    // ---- staging: wave w DMA-copies tile rows [32w, 32w+32) of A and of B, 16 rows (of 64 B) per instruction.
-    // A tile row holds 4 chunks of 16 B, stored at chunk position c ^ ((row >> 2) & 3).  The per-lane part of
-    // the source address is a loop-invariant 32-bit offset; everything that moves (code tile, k block, the
-    // block's row base) is wave-uniform and stays in SGPRs, so a stage costs no per-lane address arithmetic.
+    // ---- staging: wave w DMA-copies tile rows [32w, 32w+32) of A (= code group w of the tile) and of B, 16 rows (of
+    // 64 B) per instruction.  The per-lane part of the source address is a loop-invariant 32-bit offset; everything that
+    // moves (code tile, k block, the block's row base) is wave-uniform and stays in SGPRs.
     const int s_r = lane >> 2, s_c = lane & 3;
     unsigned lane_off[2];
 #pragma unroll
@@ -186,8 +376,15 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     }
     const char *wbase = reinterpret_cast<const char *>(wh) + (long)code_lo * dp * 2;
     const char *xbase = reinterpret_cast<const char *>(xh) + row0 * dp * 2;
-    const int wave_lds = __builtin_amdgcn_readfirstlane(wave * 32 * F_ROWB);
-    int pct = 0, pkb = 0, pidx = 0;         // next stage to issue: (code tile, k block, linear index)
+    const int wave_lds = wave_s * 32 * F_ROWB;
+    // Source code tile of the group this wave stages (group w): tile 0 for the first nkb stages; tile 1 from there up to the
+    // group's first mid-stage switch B_2 = 2 nkb + r - 1, where chunks 0-1 still come from tile 1 and chunks 2-3 from tile 2; etc.
+    const int r_src = stag ? filter_rot(2 * (wave_s % F_MT) + wave_s / F_MT, nkb) : 0;
+    // all ones for lanes that feed chunks 2-3 (k16 step 1); the same for both instructions (rows 16 apart share the swizzle term)
+    const unsigned hi_half = ((s_c ^ ((s_r >> 2) & 3)) >> 1) ? 0xffffffffu : 0u;
+    const int tile_bytes = F_BM * dp * 2;
+    int pkb = 0, pidx = 0, ptile = 0;                   // next stage to issue: k block, linear index, source code tile (of chunks 0-1)
+    int ptleft = nkb;                                   // stages until the source tile changes
     // Issues stage `pidx` into ring slot pidx % 4 and advances -- except past the end, where it re-issues the
     // LAST stage into the slot that already holds it (same bytes, harmless) so the steady-state loop body has
     // no branch around its DMA and one instruction schedule fits every iteration.
@@ -195,62 +392,59 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // SGPR stage offset -- no per-lane 64-bit address arithmetic per instruction (+3 % over global_load_lds here)
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wbase, 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)xbase, 0, -1, 0x00020000);
-    auto stage = [&]() {
+    auto stage = [&]() __attribute__((always_inline)) {
         char *base = fsm + (pidx & (F_RING - 1)) * F_STAGEB + wave_lds;
         // readfirstlane: hipcc otherwise keeps the stage counters in VGPRs and wraps every buffer load in a waterfall loop
-        const int ua = __builtin_amdgcn_readfirstlane((pct * F_BM * dp + pkb * F_BK) * 2);    // a code split's fp16 image is < 2 GB
+        const int ua = __builtin_amdgcn_readfirstlane(ptile * tile_bytes + pkb * F_BK * 2);    // a code split's fp16 image is < 2 GB
         const int ub = __builtin_amdgcn_readfirstlane(pkb * F_BK * 2);
+        // a mid-stage switch (staggered groups, from their second real tile on): chunks 2-3 already come from the next tile
+        const bool split_stage = stag && ptile >= 1 && ptleft == 1 && ptile + 1 < nct;
+        const int bump = __builtin_amdgcn_readfirstlane(split_stage ? tile_bytes : 0);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+            const int va = STAG ? (int)(lane_off[q] + (hi_half & (unsigned)bump)) : (int)lane_off[q];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(base + q * 16 * F_ROWB), 16,
-                                                     (int)lane_off[q], ua, 0, 0);
+                                                     va, ua, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(base + F_TILEB + q * 16 * F_ROWB), 16,
                                                      (int)lane_off[q], ub, 0, 0);
         }
         const bool more = pidx + 1 < nstage;
         const bool wrap = pkb + 1 == nkb;
         pidx += more ? 1 : 0;
-        pct += (more && wrap) ? 1 : 0;
         pkb = more ? (wrap ? 0 : pkb + 1) : pkb;
+        // tile 0 lasts nkb stages; tile 1 (chunks 0-1) r_src + nkb: the idle window, then its real stages up to and including
+        // the split stage; every later tile nkb
+        const bool step = more && ptleft == 1;
+        ptleft = more ? (step ? (ptile == 0 ? nkb + r_src : nkb) : ptleft - 1) : ptleft;
+        ptile = step ? min(ptile + 1, nct - 1) : ptile;
     };
 
-    // ---- per-lane state: for each of the wave's two 32-row column tiles, the k smallest d~ so far
-    float tv[F_NT][TOPK], lim[F_NT], xn[F_NT], win[F_NT];
-    // Candidates found during a code tile are parked in a lane-private LDS slot pair (value, code) and written out
-    // once per tile: scattered global stores inside the value loop stall the wave, and registers are scarce here.
-    int np[F_NT] = {}, cnt[F_NT] = {};
-    float *thr_share = reinterpret_cast<float *>(fsm + F_LDS_BYTES);    // [F_BN][2 code-side waves][5]: sorted k-smallest lists
-    uint2 *park = reinterpret_cast<uint2 *>(fsm + F_LDS_BYTES + F_THR_BYTES) + tid * 4;   // [nn][slot]
-    auto xrow_of = [&](int nn) -> long { return row0 + wn * (32 * F_NT) + nn * 32 + li; };
+    // ---- per-lane state: one FilterRow for each of the wave's two 32-row column tiles
+    float *thr_share = reinterpret_cast<float *>(fsm + F_LDS_BYTES);    // [F_BN][2 code-side waves][8]: sorted k-smallest lists (5 used)
     const float en_max = en_max_ptr[0];
     const bool sane = en_max <= F_NORM_LIMIT;
+    const int owner = split * F_OWN_PER_SPLIT + wm * 2 + lh;
+    FilterRow<TOPK> row[F_NT];
 #pragma unroll
     for (int nn = 0; nn < F_NT; ++nn) {
+        const long xr = row0 + wn * (32 * F_NT) + nn * 32 + li;
 #pragma unroll
-        for (int j = 0; j < TOPK; ++j) tv[nn][j] = INFINITY;
-        lim[nn] = -INFINITY;                 // nothing is appended before the warm-up pass has set a finite limit
-        xn[nn] = xsq[min(xrow_of(nn), n - 1)];
-        win[nn] = 2.0f * filter_eps(xn[nn], en_max, d);
+        for (int j = 0; j < TOPK; ++j) row[nn].tv[j] = INFINITY;
+        row[nn].L = INFINITY;                // nothing is appended before the warm-up pass has set a finite limit
+        row[nn].xn = xsq[min(xr, n - 1)];
+        row[nn].win = xr < n ? 2.0f * filter_eps(row[nn].xn, en_max, d) : -INFINITY;
+        row[nn].cnt = 0;
+        row[nn].list = cand + (xr * own_total + owner) * F_CAP;
+        row[nn].lst = (unsigned)(size_t)(fsm + F_LDS_BYTES) + (unsigned)(wn * (32 * F_NT) + nn * 32 + li) * F_LST_ROWB;
     }
-    bool live[F_NT];                                         // padding rows never append (their limit stays -inf)
-#pragma unroll
-    for (int nn = 0; nn < F_NT; ++nn) live[nn] = xrow_of(nn) < n;
-    const int owner = split * F_OWN_PER_SPLIT + wm * 2 + lh;
-    auto put = [&](int nn, float u, int code) {       // append (d~, code) to this lane's candidate list (live rows only)
-        if (cnt[nn] < F_CAP)
-            cand[(xrow_of(nn) * own_total + owner) * F_CAP + cnt[nn]] = make_uint2(__float_as_uint(u + xn[nn]), (unsigned)code);
-        ++cnt[nn];
-    };
-    constexpr int TL = TOPK < 5 ? TOPK : 5;       // list length shared per (row, code-side wave)
-    for (int i = tid; i < F_BN * 2 * 5; i += F_THREADS) thr_share[i] = INFINITY;
+    for (int i = tid; i < (int)(F_THR_BYTES / 4); i += F_THREADS) thr_share[i] = INFINITY;
 
     f32x16 acc[F_MT][F_NT];
-#pragma unroll
-    for (int m = 0; m < F_MT; ++m)
-#pragma unroll
-        for (int nn = 0; nn < F_NT; ++nn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+    // start values of group M for code tile `tile` (wave-uniform address: see filter_init_group)
+#define F_INIT_GROUP(M, tile) \
+    filter_init_group(acc[M][0], acc[M][1], wsqs + __builtin_amdgcn_readfirstlane(code_lo + (tile) * F_BM + wm_s * (32 * F_MT) + (M) * 32), lh)
+    // the lane's first code of group M in code tile `tile`
+#define F_LANE_CB(M, tile) (code_lo + (tile) * F_BM + wm * (32 * F_MT) + (M) * 32 + 4 * lh)
 
     // fragment addresses within a stage: row i of the tile, chunk (2t + lh) ^ ((i >> 2) & 3).  Rows 32 apart
     // share the swizzle term, so one address per (operand, t) plus compile-time row offsets covers all tiles.
@@ -262,246 +456,263 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         b_adr[t] = F_TILEB + ib * F_ROWB + (((2 * t + lh) ^ ((ib >> 2) & 3)) << 4);
     }
 
-    // ---- software pipeline.  LDS ring of 4 stages; MFMA operands double-buffered in registers so the
-    // ds_reads of the NEXT k16-step are in flight while the MFMAs of the current one issue:
-    //   iteration s:  read frags(s, t1)  | MFMA(s, t0)
+    // ---- software pipeline.  LDS ring of 4 stages; the ds_reads of the NEXT k16-step are in flight while the MFMAs of the
+    // current one issue:
+    //   iteration s:  MFMA(s, t0)  | read frags(s, t1)
     //                 vmcnt (own part of stage s+1 landed) -> raw barrier (everyone's has; slot s-1 is free)
-    //                 LDS-DMA stage s+3  | read frags(s+1, t0) | MFMA(s, t1)
+    //                 LDS-DMA stage s+3  | MFMA(s, t1) | read frags(s+1, t0)
     // __syncthreads() would drain vmcnt(0) here (an LDS-DMA is a pending LDS write), hence the raw barrier.
-    auto load_frags = [&](half8 (&fa)[F_MT], half8 (&fb)[F_NT], int slot, int t) {
-#ifdef MEDTOK_FILTER_NOLDS        // dev experiment: operands stay whatever they were
-        if (slot >= 0) return;
-#endif
-        const char *pa = fsm + slot * F_STAGEB + a_adr[t];
-        const char *pb = fsm + slot * F_STAGEB + b_adr[t];
-#pragma unroll
-        for (int nn = 0; nn < F_NT; ++nn) fb[nn] = *reinterpret_cast<const half8 *>(pb + nn * 32 * F_ROWB);
-#pragma unroll
-        for (int m = 0; m < F_MT; ++m) fa[m] = *reinterpret_cast<const half8 *>(pa + m * 32 * F_ROWB);
+    // Registers: the code-side fragment of group m is dead once its two MFMAs are issued, so the next step's fragment is read
+    // into the SAME registers right behind them (6 MFMAs = 190+ cycles ahead of its first use); only the two row-side
+    // fragments, which every MFMA of the step reads, are double-buffered: 32 operand registers instead of 48.  (With 48
+    // the staggered scan below does not fit the 256-register budget: hipcc spills, and a scratch reload is a vmcnt wait.)
+    half8 fa[F_MT], fbA[F_NT], fbB[F_NT];
+    auto read_a = [&](int m, int slot, int t) __attribute__((always_inline)) {
+        fa[m] = *reinterpret_cast<const half8 *>(fsm + slot * F_STAGEB + a_adr[t] + m * 32 * F_ROWB);
     };
-    auto mfma_group = [&](const half8 (&fa)[F_MT], const half8 (&fb)[F_NT]) {
-#ifdef MEDTOK_FILTER_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
-#ifdef MEDTOK_FILTER_NOMFMA      // dev experiment: keep the operand reads alive, skip the matrix work
+    auto read_b = [&](half8 (&fb)[F_NT], int slot, int t) __attribute__((always_inline)) {
 #pragma unroll
-        for (int m = 0; m < F_MT; ++m) asm volatile("" ::"v"(fa[m]));
-#pragma unroll
-        for (int nn = 0; nn < F_NT; ++nn) asm volatile("" ::"v"(fb[nn]));
-        return;
+        for (int nn = 0; nn < F_NT; ++nn) fb[nn] = *reinterpret_cast<const half8 *>(fsm + slot * F_STAGEB + b_adr[t] + nn * 32 * F_ROWB);
+    };
+    // one k16 step on (fa, fb_cur); meanwhile the operands of step (slot, t) arrive in fa / fb_nxt
+    auto step = [&](const half8 (&fb_cur)[F_NT], half8 (&fb_nxt)[F_NT], int slot, int t) __attribute__((always_inline)) {
+#ifndef MEDTOK_FILTER_NOLDS
+        read_b(fb_nxt, slot, t);
 #endif
 #pragma unroll
-        for (int m = 0; m < F_MT; ++m)
+        for (int m = 0; m < F_MT; ++m) {
+#ifndef MEDTOK_FILTER_NOMFMA
 #pragma unroll
             for (int nn = 0; nn < F_NT; ++nn)
-                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb[nn], acc[m][nn], 0, 0, 0);
-#ifdef MEDTOK_FILTER_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb_cur[nn], acc[m][nn], 0, 0, 0);
+#else
+            asm volatile("" ::"v"(fa[m]), "v"(fb_cur[0]), "v"(fb_cur[1]));
 #endif
+#ifndef MEDTOK_FILTER_NOLDS
+            read_a(m, slot, t);
+#endif
+        }
     };
-    half8 fa0[F_MT], fb0[F_NT], fa1[F_MT], fb1[F_NT];
+
+    // A staggered group's mid-stage switch: scan both row tiles of the code tile it has finished (none at its first switch,
+    // which only ends the idle window), restart the accumulators on the next one (none after the last), update the limits.
+    // A staggered group's mid-stage switch, spread over TWO consecutive iterations so that each part fits into what the SIMD
+    // partner's MFMAs cover before the next barrier (~600 cycles): part A copies the second row tile's finished accumulators
+    // aside (16 registers, held for one iteration), scans the first row tile and restarts both on the next code tile; part B,
+    // one stage later, scans the copy.  (No scan at the group's first switch, which only ends its idle window; the start values
+    // after the last tile belong to the clamped last tile and are never scanned.)
+#ifndef MEDTOK_FILTER_NOEPI
+#define F_GROUP_SWITCH_A(M, next)                                                            \
+    do {                                                                                     \
+        held = acc[M][1];                                                                    \
+        if ((next) >= 2) filter_scan<TOPK>(row[0], acc[M][0], F_LANE_CB(M, (next) - 1), false); \
+        F_INIT_GROUP(M, min((next), nct - 1));                                               \
+    } while (0)
+    /* the four owners' lists are merged once per cycle (after the wave's last group), like once per code tile without
+       staggering; in between a lane's own hits do not move its limit (any T >= t~ is valid) */
+#define F_GROUP_SWITCH_B(M, next)                                                            \
+    do {                                                                                     \
+        if ((next) >= 2) {                                                                   \
+            filter_scan<TOPK>(row[1], held, F_LANE_CB(M, (next) - 1), false);                \
+            if ((M) == F_MT - 1) filter_merge_pair<TOPK>(row[0], row[1], wm, lh);            \
+        }                                                                                    \
+    } while (0)
+#else
+#define F_GROUP_SWITCH_A(M, next) do { asm volatile("" ::"v"(acc[M][0]), "v"(acc[M][1])); F_INIT_GROUP(M, min((next), nct - 1)); } while (0)
+#define F_GROUP_SWITCH_B(M, next) do { } while (0)
+#endif
+    // All four groups of the wave at once (the first code tile of every block; every tile without staggering).
+    auto tile_epilogue = [&](int tile, bool warm) __attribute__((always_inline)) {
+        if (DUMP) {
+#pragma unroll
+            for (int m = 0; m < F_MT; ++m)
+#pragma unroll
+                for (int nn = 0; nn < F_NT; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int code = F_LANE_CB(m, tile) + (r & 3) + 8 * (r >> 2);
+                        const long xr = row0 + wn * (32 * F_NT) + nn * 32 + li;
+                        // s~ as the search sees it: (|e|^2 - u) / 2 with u = -2^-15 acc  (includes the rounding of the non-zero start)
+                        if (code < code_hi && xr < n) dump[xr * k_codes + code] = fmaf(acc[m][nn][r], F_UNSCALE, wsqs[code] * -F_UNSCALE);
+                    }
+            if (tile + 1 < nct) { F_INIT_GROUP(0, tile + 1); F_INIT_GROUP(1, tile + 1); F_INIT_GROUP(2, tile + 1); F_INIT_GROUP(3, tile + 1); }
+            return;
+        }
+        if (warm) {
+            // First code tile: learn the thresholds from all 128 codes BEFORE appending anything, so the
+            // candidate lists do not fill up with the loose early threshold (appends only ever need T >= t~).
+#pragma unroll
+            for (int m = 0; m < F_MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int nn = 0; nn < F_NT; ++nn) {
+                        const float u = acc[m][nn][r] * -0x1p-15f;
+                        thr_insert_bf<TOPK>(row[nn].tv, u == u ? u : INFINITY);
+                    }
+#pragma unroll
+            for (int nn = 0; nn < F_NT; ++nn) row[nn].L = filter_limit(row[nn].tv[TOPK - 1], row[nn].win);
+        }
+#define F_ONE(M)                                                                                                   \
+        do {                                                                                                       \
+            const int cb_ = F_LANE_CB(M, tile);                                                                    \
+            _Pragma("unroll") for (int nn = 0; nn < F_NT; ++nn) filter_scan<TOPK>(row[nn], acc[M][nn], cb_, warm); \
+            if (tile + 1 < nct) F_INIT_GROUP(M, tile + 1);                                                         \
+        } while (0)
+        F_ONE(0); F_ONE(1); F_ONE(2); F_ONE(3);
+#undef F_ONE
+        filter_merge_pair<TOPK>(row[0], row[1], wm, lh);
+    };
+
     constexpr int LGKM0 = 0xC07F;           // s_waitcnt lgkmcnt(0) only (vmcnt / expcnt fields at their maxima)
+    {   // start values of the first code tile by vector loads (nothing is in flight yet, so the wait they need is harmless;
+        // four groups through the scalar cache at once would cost 128 SGPRs)
+#pragma unroll
+        for (int m = 0; m < F_MT; ++m) {
+            float4 e4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e4[g] = ld4(wsqs + F_LANE_CB(m, 0) + 8 * g);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float4 q4 = e4[r >> 2];
+                const float v = (r & 3) == 0 ? q4.x : (r & 3) == 1 ? q4.y : (r & 3) == 2 ? q4.z : q4.w;
+#pragma unroll
+                for (int nn = 0; nn < F_NT; ++nn) acc[m][nn][r] = v;
+            }
+        }
+    }
     stage(); stage(); stage();              // stages 0..2 (clamped when the block has fewer)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    load_frags(fa0, fb0, 0, 0);
-    int ct = 0, kb = 0;
+    read_b(fbA, 0, 0);
+#pragma unroll
+    for (int m = 0; m < F_MT; ++m) read_a(m, 0, 0);
     // The two waves of a SIMD (w and w + 4) issue their LDS-DMA at different points of the stage: an issuing wave is
     // held for ~100 cycles per instruction, and in lockstep both would leave the matrix pipe idle at the same time
     // (+2.5-3 % measured).  Either way a wave has issued all of stage s+3 between the waits of iterations s and s+1,
     // so the counted vmcnt below is the same for both halves.
-    const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+    const bool late = wave_s >= 4;
     // The second-dispatched half of the block loses issue arbitration to the older half at every segment start
     // (priority, then age): one static priority bump for it, no flips inside the loop (+2 %, levels 1 and 3 alike;
     // -1.5 % when given to the older half instead; flips around the MFMA groups measured -1 %).
     if (late) __builtin_amdgcn_s_setprio(3);
-    for (int s = 0; s < nstage; ++s) {
+
+    // first half of an iteration: MFMA(s, t0) with the operand reads of (s, t1) between them, then the stage barrier
+    auto first_half = [&](int s) __attribute__((always_inline)) {
         if (late && s > 0) stage();         // waves 4-7: stage s+2 (slot s-2, free since the barrier of iteration s-1)
-        constexpr int NRD = F_MT + F_NT;     // operand reads per k16-step (8 MFMAs)
-        load_frags(fa1, fb1, s & (F_RING - 1), 1);
-        mfma_group(fa0, fb0);
-        // interleave: the 6 operand reads of the next k16-step ride between the first MFMAs
+        step(fbA, fbB, s & (F_RING - 1), 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, F_NT, 0);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NRD - 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        // fa1/fb1 have landed (free: 8 MFMAs went by); own part of stage s+1 has landed; then everyone's has
+        for (int i = 0; i < F_MT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, F_NT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        // the next step's operands have landed; own part of stage s+1 has landed; then everyone's has
         __builtin_amdgcn_s_waitcnt(LGKM0);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #ifndef MEDTOK_FILTER_NOBAR       // dev experiment
         __builtin_amdgcn_s_barrier();
 #endif
         asm volatile("" ::: "memory");
-#ifndef MEDTOK_FILTER_NODMA       // dev experiment: without it the ring keeps its prologue contents
-        if (!late) stage();                 // waves 0-3: stage s+3 (slot s-1: everyone is past reading it)
-#endif
-        load_frags(fa0, fb0, (s + 1) & (F_RING - 1), 0);      // (past the last stage this reads stale LDS, never used)
-        mfma_group(fa1, fb1);
+    };
+    // second half: (DMA of stage s+3,) MFMA(s, t1) with the operand reads of (s+1, t0) between them
+    // (past the last stage the reads fetch stale LDS, never used)
+    auto second_half = [&](int s) __attribute__((always_inline)) {
+        step(fbB, fbA, (s + 1) & (F_RING - 1), 0);
         // after the barrier the matrix pipe restarts at once; DMA issue and operand reads ride between MFMAs
-        // (other interleave patterns for this half measured the same; two reads per MFMA in the first half: -5 %)
+        __builtin_amdgcn_sched_group_barrier(0x100, F_NT, 0);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NRD / 3, 0); }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#ifdef MEDTOK_FILTER_NOEPI      // dev experiment: main loop only (results are garbage)
-        if (++kb == nkb) {
-#pragma unroll
-            for (int m = 0; m < F_MT; ++m)
-#pragma unroll
-                for (int nn = 0; nn < F_NT; ++nn) {
-                    asm volatile("" ::"v"(acc[m][nn]));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
-                }
-            kb = 0; ++ct;
+        for (int i = 0; i < F_MT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, F_NT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
-        continue;
+    };
+
+    if constexpr (!STAG) {
+        // every group switches code tiles together: the scan of all four runs at the end of the tile's last stage
+        int ct = 0, kb = 0;
+        for (int s = 0; s < nstage; ++s) {
+            first_half(s);
+#ifndef MEDTOK_FILTER_NODMA       // dev experiment: without it the ring keeps its prologue contents
+            if (!late) stage();             // waves 0-3: stage s+3 (slot s-1: everyone is past reading it)
 #endif
-        if (++kb == nkb) {
-            // ---- epilogue.  Everything is kept relative to the lane's own |x|^2:  u = en - 2 s~ (one fmaf per
-            // value, shared by nothing else), thresholds and limits in the same u scale; d~ = u + xn is formed only
-            // for the few values that are stored.
-            const int cbase = code_lo + ct * F_BM + wm * (32 * F_MT) + 4 * lh;
-            const bool warm = (ct == 0);
-            if (!DUMP && warm) {
-                // First code tile: learn the thresholds from all 128 codes BEFORE appending anything, so the
-                // candidate lists do not fill up with the loose early threshold (appends only ever need T >= t~).
+            second_half(s);
+            if (++kb == nkb) {
+#ifndef MEDTOK_FILTER_NOEPI
+                tile_epilogue(ct, ct == 0);
+#else
 #pragma unroll
-                for (int m = 0; m < F_MT; ++m) {
-                    float4 wen[4];          // vector loads, one wait per 16 values (a load per value drains the DMA ring each time)
+                for (int m = 0; m < F_MT; ++m)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) wen[g] = ld4(wsqp + cbase + 32 * m + 8 * g);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float4 e4 = wen[r >> 2];
-                        const float en = (r & 3) == 0 ? e4.x : (r & 3) == 1 ? e4.y : (r & 3) == 2 ? e4.z : e4.w;
-#pragma unroll
-                        for (int nn = 0; nn < F_NT; ++nn) thr_insert<TOPK>(tv[nn], fmaf(acc[m][nn][r], -0x1p-15f, en));
-                    }
-                }
-#pragma unroll
-                for (int nn = 0; nn < F_NT; ++nn) lim[nn] = live[nn] ? fminf(tv[nn][TOPK - 1] + win[nn], 3.0e38f) : -INFINITY;
-            }
-#pragma unroll
-            for (int m = 0; m < F_MT; ++m) {
-                f32x16 env;                  // |e|^2 of this lane's 16 codes of the tile, in accumulator-register order
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 e4 = ld4(wsqp + cbase + 32 * m + 8 * g);
-                    env[4 * g] = e4.x; env[4 * g + 1] = e4.y; env[4 * g + 2] = e4.z; env[4 * g + 3] = e4.w;
-                }
-#pragma unroll
-                for (int nn = 0; nn < F_NT; ++nn) {
-#ifndef MEDTOK_FILTER_EPI_SCALAR
-                    // Four values per test: two packed fmas (bit-identical to fmaf per element), a 4-way min, ONE compare
-                    // and branch; only a quad that holds a passing value in some lane is scanned value by value.  A hit
-                    // is rare per lane but not per wave (64 lanes x 4 values at p ~ 2e-3: a third of the quads).  (+1 % over
-                    // the per-value form below; clearing the accumulators by a C = 0 first MFMA instead of 128 v_movs was
-                    // tried too: the per-stage branch it needs costs more than the moves.)
-                    if (!DUMP) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            typedef float f32x2 __attribute__((ext_vector_type(2)));
-                            const f32x2 cc = {-0x1p-15f, -0x1p-15f};
-                            const f32x2 a01 = {acc[m][nn][4 * g], acc[m][nn][4 * g + 1]}, a23 = {acc[m][nn][4 * g + 2], acc[m][nn][4 * g + 3]};
-                            const f32x2 e01 = {env[4 * g], env[4 * g + 1]}, e23 = {env[4 * g + 2], env[4 * g + 3]};
-                            const f32x2 u01 = __builtin_elementwise_fma(a01, cc, e01), u23 = __builtin_elementwise_fma(a23, cc, e23);
-                            const float uq[4] = {u01.x, u01.y, u23.x, u23.y};
-                            if (fminf(fminf(uq[0], uq[1]), fminf(uq[2], uq[3])) <= lim[nn]) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    if (uq[j] <= lim[nn]) {
-                                        const int code = cbase + 32 * m + j + 8 * g;
-                                        if (np[nn] < 2) { park[nn * 2 + np[nn]] = make_uint2(__float_as_uint(uq[j]), (unsigned)code); ++np[nn]; }
-                                        else put(nn, uq[j], code);
-                                    }
-                            }
-                        }
-                    } else
+                    for (int nn = 0; nn < F_NT; ++nn) { asm volatile("" ::"v"(acc[m][nn])); }
 #endif
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float u = fmaf(acc[m][nn][r], -0x1p-15f, env[r]);      // padded codes carry en = +inf
-                        if (DUMP) {
-                            const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2);
-                            if (code < code_hi && xrow_of(nn) < n) dump[xrow_of(nn) * k_codes + code] = acc[m][nn][r] * F_UNSCALE;
-                        } else if (u <= lim[nn]) {                                 // lim is finite, so +inf never passes
-                            // rare per lane (about 6/m after m codes) but not per wave: keep this body minimal -- park the
-                            // candidate in LDS; only a third hit within one code tile pays for a global store right here
-                            // (that one skips the k-smallest list: T stays valid, a touch looser).
-                            const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2);
-                            if (np[nn] < 2) { park[nn * 2 + np[nn]] = make_uint2(__float_as_uint(u), (unsigned)code); ++np[nn]; }
-                            else put(nn, u, code);
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
-                }
+                kb = 0;
+                ++ct;
             }
-            if (!DUMP) {
-                // per tile: flush, update the lane's k-smallest list, then combine the row's four owners into one threshold
-#pragma unroll
-                for (int nn = 0; nn < F_NT; ++nn) {
-                    // write out the parked candidates (at most two store instructions per tile) and fold them into the
-                    // k-smallest list; the warm-up pass already counted the first tile's values
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        if (q < np[nn]) {
-                            const uint2 e = park[nn * 2 + q];
-                            put(nn, __uint_as_float(e.x), (int)e.y);
-                            if (!warm) thr_insert<TOPK>(tv[nn], __uint_as_float(e.x));
-                        }
-                    }
-                    np[nn] = 0;
-                    // The row's k-th best over ALL codes seen so far, exactly: merge the sorted k-lists of the row's four
-                    // owners.  (The minimum of the owners' own k-th bests -- the old rule -- is only about the 4k-th best
-                    // of the union: 2-3 x the candidates.)  Two sorted lists a, b: {min(a_i, b_{k-1-i})} are the k smallest
-                    // of their union.  The lh partner comes by shuffle; the other code-side wave publishes its merged list
-                    // in LDS -- possibly one tile old, which is still a list of values of real codes, so T stays valid.
-                    // (Extending the union across code splits through agent-scope global lists was measured 10 % SLOWER:
-                    // the extra global loads/stores in the epilogue cost more than the candidates they save.)
-                    float t;
-                    if (TOPK <= 5) {
-                        float c[TL];
-#pragma unroll
-                        for (int i = 0; i < TL; ++i) c[i] = fminf(tv[nn][i], __shfl_xor(tv[nn][TL - 1 - i], 32, 64));
-#pragma unroll
-                        for (int pass = 0; pass < TL; ++pass)              // odd-even transposition: c ascending
-#pragma unroll
-                            for (int i = pass & 1; i + 1 < TL; i += 2) {
-                                const float lo = fminf(c[i], c[i + 1]), hi = fmaxf(c[i], c[i + 1]);
-                                c[i] = lo; c[i + 1] = hi;
-                            }
-                        float *lst = thr_share + (size_t)(wn * (32 * F_NT) + nn * 32 + li) * 10;
-                        if (lh == 0) {
-#pragma unroll
-                            for (int i = 0; i < TL; ++i) lst[wm * 5 + i] = c[i];
-                        }
-                        t = -INFINITY;
-#pragma unroll
-                        for (int i = 0; i < TL; ++i) t = fmaxf(t, fminf(c[i], lst[(wm ^ 1) * 5 + TL - 1 - i]));
-                    } else {                 // k = 8: the lists would not fit beside the ring; the pair's looser min rule
-                        t = tv[nn][TOPK - 1];
-                        t = fminf(t, __shfl_xor(t, 32, 64));
-                    }
-                    lim[nn] = live[nn] ? fminf(t + win[nn], 3.0e38f) : -INFINITY;
-                }
-            }
-            kb = 0;
-            ++ct;
         }
+    } else {
+        auto plain_iteration = [&](int s) __attribute__((always_inline)) {
+            first_half(s);
+#ifndef MEDTOK_FILTER_NODMA
+            if (!late) stage();             // waves 0-3: stage s+3 (slot s-1: everyone is past reading it)
+#endif
+            second_half(s);
+        };
+        // the first code tile: all groups together, then the scan that also teaches every list its threshold and restarts
+        // the groups on tile 1
+        int s = 0;
+        for (; s < nkb; ++s) plain_iteration(s);
+#if !defined(MEDTOK_FILTER_NOEPI) && !defined(EXP_NOWARM)
+        tile_epilogue(0, true);
+#endif
+        // From here on the wave's four groups switch code tiles one after the other, group M in the middle of stage
+        // nkb + rot(2 M + wm) - 1 + (cyc - 1) nkb of cycle cyc = 1 .. nct (cyc = the code tile it starts there; the scan is of
+        // tile cyc - 1, none in cycle 1, where the switch only ends the group's idle window; no restart after the last tile
+        // -- the start values it gets then belong to the clamped last tile and are never scanned).  The switches sit at FIXED
+        // places of the instruction stream (four stretches of plain iterations, each ended by an iteration with a switch in
+        // its middle), not behind a runtime group index: the eight 16-register accumulator tuples then never meet a join of
+        // several definitions, which hipcc answers with tuple copies and hundreds of spilled registers.
+        // While one wave scans (a quarter of its accumulators), its SIMD partner has the 8 + 8 MFMAs up to the next barrier to issue.
+#define F_SEGMENT(M)                                                                                                   \
+        do {                                                                                                           \
+            const int target = nkb + filter_rot(2 * (M) + wm_s, nkb) - 1 + (cyc - 1) * nkb;                             \
+            for (; s < target; ++s) plain_iteration(s);                                                               \
+            first_half(s);                                                                                             \
+            F_GROUP_SWITCH_A(M, cyc);                                                                                  \
+            F_STAGE_EARLY();                                                                                           \
+            second_half(s);                                                                                            \
+            ++s;                                                                                                       \
+            first_half(s);                                                                                             \
+            F_GROUP_SWITCH_B(M, cyc);                                                                                  \
+            F_STAGE_EARLY();                                                                                           \
+            second_half(s);                                                                                            \
+            ++s;                                                                                                       \
+        } while (0)
+#ifndef MEDTOK_FILTER_NODMA
+#define F_STAGE_EARLY() do { if (!late) stage(); } while (0)
+#else
+#define F_STAGE_EARLY() do { } while (0)
+#endif
+        f32x16 held;                         // the second row tile's finished accumulators between the two parts of a switch
+        for (int cyc = 1; cyc <= nct; ++cyc) {
+            F_SEGMENT(0); F_SEGMENT(1); F_SEGMENT(2); F_SEGMENT(3);
+        }
+#undef F_SEGMENT
+#undef F_STAGE_EARLY
+        for (; s < nstage; ++s) plain_iteration(s);      // (the other waves' last groups are still at work: same barrier count for all)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail re-issues may still be in flight
     if (!DUMP) {
 #pragma unroll
         for (int nn = 0; nn < F_NT; ++nn) {
             // rows outside the range the bound assumes are forced onto the exact path
-            const bool ok = sane && xn[nn] <= F_NORM_LIMIT;
-            if (live[nn]) cand_cnt[xrow_of(nn) * own_total + owner] = ok ? cnt[nn] : F_CAP + 1;
+            const long xr = row0 + wn * (32 * F_NT) + nn * 32 + li;
+            const bool ok = sane && row[nn].xn <= F_NORM_LIMIT;
+            if (xr < n) cand_cnt[xr * own_total + owner] = ok ? row[nn].cnt : F_CAP + 1;
         }
     }
+#undef F_GROUP_SWITCH_A
+#undef F_GROUP_SWITCH_B
+#undef F_INIT_GROUP
+#undef F_LANE_CB
 }
 
 // ---------------------------------------------------------------- exact re-score
@@ -685,9 +896,9 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     }
 }
 
-// padded, aligned copy of wsq: [k_pad] with +inf beyond k_codes
+// the accumulator start values: [k_pad] -2^15 |e|^2 (exact: a power-of-two scale), -inf beyond k_codes so that padded codes never pass
 __global__ __launch_bounds__(256) void pad_wsq_kernel(const float *__restrict__ wsq, int k, int k_pad, float *__restrict__ out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < k_pad) out[i] = i < k ? wsq[i] : INFINITY;
+    if (i < k_pad) out[i] = i < k ? wsq[i] * -32768.0f : -INFINITY;
 }
