@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg5", "full", "codeshard"], default="cfg3",
-                    help="cfg3: full soft VQ (headline); full: cfg3 plus the ragged cross-attention of get_shared_info in front of it; cfg2: argmin+EMA train step, 100k rows, K=8192; codeshard: one K=49152 soft top-5 search with the CODEBOOK sharded over the GPUs (every rank scores all rows "
+    ap.add_argument("--text-layers", type=int, default=12, help="cfg4: transformer layers of the BERT-shaped stand-in text encoder (12 = BERT-base)")
+    ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg4", "cfg5", "full", "codeshard"], default="cfg3",
+                    help="cfg3: full soft VQ (headline); full: cfg3 plus the ragged cross-attention of get_shared_info in front of it; cfg2: argmin+EMA train step, 100k rows, K=8192; cfg4: BASELINE config 4 -- one train step (stand-in BERT-shaped text encoder + 2-layer GAT -> soft VQ with aug view -> loss.py -> backward -> clip -> Adam) on 256 codes/GPU under bf16 autocast, L=512; codeshard: one K=49152 soft top-5 search with the CODEBOOK sharded over the GPUs (every rank scores all rows "
                          "against its slice; all-gather of the k-lists + exact merge); cfg5: the same step on 600k rows "
                          "TOTAL (split over the GPUs: strong scaling), K=16384, with the RCCL all-reduce of the EMA statistics")
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default 600000 for cfg3, 100000 for cfg2)")
@@ -312,6 +313,95 @@ class Cfg2:
         return cpu_protocol(run, sample_rows, 1, f"argmin + EMA train step, K={self.K}, D=768")
 
 
+class Cfg4:
+    """BASELINE config 4: the train step of train_MedTok.py:207-250 -- zero_grad, bf16 autocast forward of the tokenizer
+    (text + graph encoders, the aug view, VectorQuantizer.forward: cross-attention + 6 searches), the loss assembly of loss.py,
+    backward, gradient clipping, optimizer step -- on B = 256 synthetic PrimeKG-shaped codes per GPU, 512 text tokens.
+    The encoders are plain-torch stand-ins of the reference's shapes (BERT-base-shaped, frozen as in tokenizer.py:80-81; 2-layer
+    GAT): they are upstream of the path this package rebuilds, so their time is reported separately (`encoders_ms_per_step`)."""
+    name = "cfg4"
+    D, N_E, L, TOPK = 768, 49152, 512, 5
+
+    def __init__(self, rows, dev, seed, path, text_layers=12):
+        from medtok_amd.synthetic import StandInGAT, StandInTextEncoder, primekg_shaped_batch
+        from medtok_amd.tokenizer import MultimodalTokenizer
+        self.rows, self.dev = rows, dev
+        torch.manual_seed(1234)
+        self.model = MultimodalTokenizer(StandInTextEncoder(layers=text_layers), StandInGAT(dim=self.D), text_dim=768, graph_out_channels=self.D,
+                                         codebook_size=self.N_E, codebook_embed_dim=self.D).to(dev).train()
+        for p in self.model.text_model.parameters():
+            p.requires_grad = False                                     # tokenizer.py:80-81
+        self.model.quantize.search_path = path
+        self.opt = torch.optim.AdamW([p for p in self.model.parameters() if p.requires_grad], lr=1e-4)
+        self.inputs = primekg_shaped_batch(rows, dev, seed=seed, max_len=self.L)
+        self.enc_ms, self.enc_events = 0.0, []
+        self.description = (f"cfg4 train step: {rows} codes/GPU, {self.L} text tokens, PrimeKG-shaped subgraphs (median ~20 nodes), stand-in "
+                            f"BERT-shaped text encoder ({text_layers} layers, frozen) + 2-layer GAT -> soft VQ (n_e=49152, D=768, k=5, aug view, "
+                            f"cross-attention) -> loss.py -> backward -> clip -> AdamW; bf16 autocast")
+
+    def flops_per_code(self):
+        # the six searches of a train-mode forward (2 shared over n_e, 2 + 2 aug over a third)
+        return 2.0 * self.D * (2 * self.N_E + 4 * (self.N_E // 3))
+
+    def bytes_per_code(self):
+        return 6 * (8 * self.D) + 6 * self.TOPK * 12 + self.L * self.D * 4
+
+    def set_path(self, path):
+        self.model.quantize.search_path = path
+
+    def paths_agree(self):
+        return True          # (a train step mutates the weights: the two paths are compared at fixed weights by the tests)
+
+    def step(self):
+        from medtok_amd import loss as L
+        m = self.model
+        self.opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            r = m(self.inputs)
+            loss, _ = L.total_loss(r, 0.1, 0.1)
+        loss.float().backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        self.opt.step()
+        return (loss.detach(),)
+
+    def encoder_ms(self, steps=3):
+        """time of the stand-in encoders alone (both views, as forward() runs them), outside the timed region"""
+        m, x = self.model, self.inputs
+        def enc():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                for aug in (False, True):
+                    m.text_mapped(m.tokenize_text(x, aug=aug)); m.tokenize_graph(x, aug=aug)
+        enc(); torch.cuda.synchronize(self.dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            enc()
+        torch.cuda.synchronize(self.dev)
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    def cpu_baseline(self, sample_rows):
+        """the VQ + loss part of the step in CPU PyTorch on the reference's op sequence (dense N x K distances, autograd through
+        them), at the same B: the encoders are identical torch modules on either side and are left out"""
+        from oracle import torch_port as P
+        g = torch.Generator().manual_seed(0)
+        B, D = min(sample_rows, self.rows), self.D
+        W = torch.randn(self.N_E, D, generator=g, requires_grad=True)
+        xs = [torch.randn(B, D, generator=g, requires_grad=True) for _ in range(6)]
+        region = self.N_E // 3
+
+        def run(rows, threads):
+            torch.set_num_threads(threads)
+            tot = 0.0
+            for i, x in enumerate(xs):
+                Wr = W if i < 2 else (W[:region] if i % 2 == 0 else W[-region:])
+                xn = torch.nn.functional.normalize(x[:rows], dim=-1); wn = torch.nn.functional.normalize(Wr, dim=-1)
+                d = P.distance_matrix(xn, wn)
+                vals, idx = torch.topk(d, self.TOPK, largest=False)
+                zq = (torch.softmax(-vals, 1).unsqueeze(-1) * wn[idx]).sum(1)
+                tot = tot + ((zq - x[:rows].detach()) ** 2).mean() + 0.25 * ((zq.detach() - x[:rows]) ** 2).mean()
+            tot.backward()
+        return cpu_protocol(run, B, 1, "6 dense searches of a train-mode forward + their autograd backward, n_e=49152, D=768; encoders excluded")
+
+
 def pmc_traffic(workload, kernel, rows):
     """(bytes, source): fabric bytes per launch of `kernel`.  PMC counters cannot be read from inside this process (they need their
     own rocprofv3 --pmc passes, tools/pmc_traffic.sh), so the figure is the one RECORDED in profiles/pmc_traffic.json -- returned
@@ -379,6 +469,9 @@ def main():
     elif args.workload == "codeshard":
         rows = args.rows or 600000
         wl = CodeShard(rows, dev, seed=0, path=args.path, rank=rank, world=world)
+    elif args.workload == "cfg4":
+        rows = args.rows or 256
+        wl = Cfg4(rows, dev, seed=rank, path=args.path, text_layers=args.text_layers)
     else:
         rows = args.rows or {"cfg3": 600000, "full": 4096}.get(args.workload, 100000)
         wl = {"cfg3": Cfg3, "full": Full}.get(args.workload, Cfg2)(rows, dev, seed=rank, path=args.path)
@@ -400,7 +493,7 @@ def main():
 
     # the exact fp32-MFMA path on the same workload (1 step): the filter path returns the same bits, faster
     exact = None
-    if args.path == ops.PATH_AUTO and args.exact_steps > 0:
+    if args.path == ops.PATH_AUTO and args.exact_steps > 0 and args.workload != "cfg4":
         agree = wl.paths_agree()             # same state, same inputs, both paths: every output tensor must be bit-identical
         wl.set_path(ops.PATH_F32_MFMA)
         wl.step()
@@ -472,7 +565,14 @@ def main():
                                            for k, v in prof.items() if k != kname and v["launches"]}},
             "exact_fp32_path": exact,
         }
-        cpu_rows = args.cpu_rows if args.cpu_rows is not None else {"full": 512}.get(args.workload, 16384)
+        if args.workload == "cfg4":
+            enc = wl.encoder_ms()
+            line["dtype"] = "bf16 autocast (encoders, projections); the searches, their backward and the losses run in f32"
+            line["config"]["encoders_ms_per_step"] = enc
+            line["config"]["vq_path_ms_per_step"] = max(line["ms_per_step"] - enc, 0.0)
+            line["config"]["note"] = ("stand-in encoders (out of scope, upstream of the path); vq_path = cross-attention + 6 searches + "
+                                      "loss.py + backward + clip + AdamW = step - encoders")
+        cpu_rows = args.cpu_rows if args.cpu_rows is not None else {"full": 512, "cfg4": 256}.get(args.workload, 16384)
         if world == 1 and cpu_rows > 0:
             line["cpu_baseline"] = wl.cpu_baseline(cpu_rows)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -160,6 +160,24 @@ int medtok_info_nce_backward_f32(const float *q, const float *k, const float *pr
                                  const float *g_loss, int64_t b, int d, float temperature,
                                  float *gq, float *gk, const void *ws, size_t ws_bytes, void *stream);
 
+/* The two regularisers of loss.py next to InfoNCE, forward and backward.
+ *   alignment_loss(mu1, mu2) = mean_b <mu1[b], mu2[b]>  (loss.py:59-64): medtok_row_dot_f32 -> out[b], then
+ *     medtok_sum_scale_f32(out, B, 1/B); its gradients are mu2 * g / B and mu1 * g / B (medtok_scale_by_device_scalar_f32).
+ *   orthogonal_loss(z, z*) = || z^T z* ||_F  (loss.py:66-83): M = z^T z* by medtok_small_gemm_f32 (strides pick the
+ *     transposition), medtok_frobenius_f32(M); backward: G = M * g / ||M|| (scale_by_device_scalar with den = the norm),
+ *     dz = z* G^T and dz* = z G, two more small GEMMs.
+ * medtok_small_gemm_f32: C[m, n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn], C row-major [m, n]; every entry is one fp32 fmaf
+ * chain over k in increasing order (v_mfma_f32_32x32x2_f32), bit-reproducible.  Meant for the loss-sized operands
+ * (a few hundred rows): a correctness-first kernel, not a tuned GEMM.  d % 4 == 0 for the row kernels. */
+int medtok_row_dot_f32(const float *a, const float *b, int64_t n, int d, float *out, void *stream);
+int medtok_small_gemm_f32(const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn,
+                          int m, int n, int k, float *C, void *stream);
+size_t medtok_frobenius_workspace_bytes(int64_t rows);
+int medtok_frobenius_f32(const float *x, int64_t rows, int d, float *out, void *ws, size_t ws_bytes, void *stream);
+/* out[i] = x[i] * (c * num[0] / den[0]); num, den: device scalars (den may be NULL = 1; den[0] == 0 gives 0). */
+int medtok_scale_by_device_scalar_f32(const float *x, int64_t count, const float *num, const float *den, float c,
+                                      float *out, void *stream);
+
 /* Cross-attention core of get_shared_info (vector_quantization_soft_one_new.py:17-88,133-142) for ragged
  * batches.  With nn.MultiheadAttention's key/value projections folded into the queries on the host
  * (q_h.(Wk_h t + bk_h) = (Wk_h^T q_h).t + const;  sum_j p_j (Wv_h t_j + bv_h) = Wv_h (sum_j p_j t_j) + bv_h)
@@ -168,8 +186,9 @@ int medtok_info_nce_backward_f32(const float *q, const float *k, const float *pr
  * over the code's own query rows [q_start[b], +q_len[b]) of q and key rows [kv_start[b], +kv_len[b]) of kv
  * (raw rows of the other modality; every head is just another query row).  Nothing is padded and the
  * rows x keys matrix never reaches memory.  max_q_len >= max_b q_len[b] sizes the grid (rows beyond a
- * code's q_len cost nothing); d = 64 or d % 128 == 0, d <= 768.  A code with kv_len == 0 yields NaN rows, as
- * softmax over an empty set does in the reference.  q_start/q_len/kv_start/kv_len are DEVICE int64[n_codes]. */
+ * code's q_len cost nothing); d = 64 or d % 128 == 0, d <= 768.  A code with kv_len == 0 attends to nothing: its
+ * rows are zero (the reference's per-code loop would take a softmax over an empty set there).
+ * q_start/q_len/kv_start/kv_len are DEVICE int64[n_codes]; any number of codes per call. */
 int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const int64_t *q_len,
                                    const float *kv, const int64_t *kv_start, const int64_t *kv_len,
                                    int64_t n_codes, int64_t max_q_len, int d, float scale,

@@ -47,6 +47,11 @@ SIGNATURES = {
     "medtok_info_nce_workspace_bytes": (_sz, [_i64, _int]),
     "medtok_info_nce_forward_f32": (_int, [_vp, _vp, _i64, _int, _f, _vp, _vp, _vp, _sz, _vp]),
     "medtok_info_nce_backward_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _f, _vp, _vp, _vp, _sz, _vp]),
+    "medtok_row_dot_f32": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
+    "medtok_small_gemm_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp]),
+    "medtok_frobenius_workspace_bytes": (_sz, [_i64]),
+    "medtok_frobenius_f32": (_int, [_vp, _i64, _int, _vp, _vp, _sz, _vp]),
+    "medtok_scale_by_device_scalar_f32": (_int, [_vp, _i64, _vp, _vp, _f, _vp, _vp]),
     "medtok_shared_kv_attention_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f, _vp, _vp]),
     "medtok_ema_stats_workspace_bytes": (_sz, [_i64, _i64]),
     "medtok_ema_stats_f32": (_int, [_vp, _vp, _i64, _int, _i64, _vp, _vp, _vp, _sz, _vp]),

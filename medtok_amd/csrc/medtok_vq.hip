@@ -1084,6 +1084,53 @@ extern "C" int medtok_info_nce_backward_f32(const float *q, const float *k, cons
     return check_launch("info_nce_backward");
 }
 
+// ================================================================= alignment / orthogonality losses
+#include "loss_kernels.h"
+
+extern "C" int medtok_row_dot_f32(const float *a, const float *b, int64_t n, int d, float *out, void *stream)
+{
+    if (n < 0 || d <= 0 || (d & 3)) return fail("row_dot: bad shape n=%ld d=%d (d %% 4 == 0)", (long)n, d);
+    if (!a || !b || !out) return fail("row_dot: NULL argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, (long)n, d, out);
+    return check_launch("row_dot");
+}
+
+extern "C" int medtok_small_gemm_f32(const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, int m, int n, int k,
+                                     float *C, void *stream)
+{
+    if (m <= 0 || n <= 0 || k <= 0) return fail("small_gemm: bad shape m=%d n=%d k=%d", m, n, k);
+    if (!A || !B || !C) return fail("small_gemm: NULL argument");
+    const long tiles = (long)((m + 31) / 32) * ((n + 31) / 32);
+    hipLaunchKernelGGL(small_gemm_f32_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, A, (long)sam, (long)sak, B,
+                       (long)sbk, (long)sbn, m, n, k, C);
+    return check_launch("small_gemm");
+}
+
+extern "C" size_t medtok_frobenius_workspace_bytes(int64_t rows) { return rows > 0 ? align_up((size_t)rows * 4, 256) : 256; }
+
+extern "C" int medtok_frobenius_f32(const float *x, int64_t rows, int d, float *out, void *ws, size_t ws_bytes, void *stream)
+{
+    if (rows <= 0 || d <= 0 || (d & 3)) return fail("frobenius: bad shape rows=%ld d=%d (d %% 4 == 0)", (long)rows, d);
+    if (!x || !out || !ws || ws_bytes < (size_t)rows * 4) return fail("frobenius: NULL argument or workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float *sq = (float *)ws;
+    hipLaunchKernelGGL(rownorm_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, (long)rows, d, (float *)nullptr, sq, (_Float16 *)nullptr, 0);
+    hipLaunchKernelGGL(frobenius_kernel, dim3(1), dim3(1024), 0, s, sq, (long)rows, out);
+    return check_launch("frobenius");
+}
+
+extern "C" int medtok_scale_by_device_scalar_f32(const float *x, int64_t count, const float *num, const float *den, float c, float *out,
+                                                 void *stream)
+{
+    if (count < 0 || !x || !num || !out) return fail("scale_by_device_scalar: bad arguments");
+    if (count == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) return fail("scale_by_device_scalar: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(scale_by_device_scalar_kernel, dim3((unsigned)lmin(2048, (count + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream,
+                       x, (long)count, num, den, c, out);
+    return check_launch("scale_by_device_scalar");
+}
+
 // ================================================================= cross-attention core (ragged, shared key/value rows)
 #include "attention_kernels.h"
 

@@ -1,10 +1,10 @@
 """Cross-modal losses of MedTok (drop-in for the reference's MedTok/loss.py:40-110).
 
 Same function names, arguments and return structures (4-tuples of 0-dim fp32
-tensors, differentiable).  InfoNCE -- four calls per training step -- runs on the
-library's gfx950 kernels (forward and backward); the alignment and orthogonality
-terms are one reduction / one D x D product each and stay torch code.  The GAN
-losses of loss.py:5-37 have no caller in the reference and are out of scope.
+tensors, differentiable).  All of it -- InfoNCE, the alignment term and the
+orthogonality term, forward and backward -- runs on the library's gfx950 kernels
+through autograd.Functions.  The GAN losses of loss.py:5-37 have no caller in the
+reference and are out of scope.
 """
 from __future__ import annotations
 
@@ -50,21 +50,92 @@ def info_nce_loss(q, k, temperature=0.07):
     return _InfoNCEFunction.apply(q, k, float(temperature))
 
 
+def _pad4(*ts):
+    """kernels stride float4; zero columns change neither dot products nor norms"""
+    d = ts[0].shape[-1]
+    if d % 4 == 0:
+        return ts
+    return tuple(F.pad(t, (0, 4 - d % 4)) for t in ts)
+
+
+class _AlignmentFunction(torch.autograd.Function):
+    """mean_b <mu1[b], mu2[b]>: row dots (medtok_row_dot_f32) + the fixed-order fp64 mean; the gradients are the other
+    operand scaled by g / B on the device (medtok_scale_by_device_scalar_f32)."""
+
+    @staticmethod
+    def forward(ctx, mu1, mu2):
+        a, b = mu1.detach().float().contiguous(), mu2.detach().float().contiguous()
+        ctx.save_for_backward(a, b)
+        ctx.in_dtypes = (mu1.dtype, mu2.dtype)
+        return ops.sum_scale(ops.row_dot(a, b), 1.0 / a.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.float().contiguous()
+        c = 1.0 / a.shape[0]
+        return (ops.scale_by_device_scalar(b, g, None, c).to(ctx.in_dtypes[0]),
+                ops.scale_by_device_scalar(a, g, None, c).to(ctx.in_dtypes[1]))
+
+
+class _OrthogonalFunction(torch.autograd.Function):
+    """|| z^T z* ||_F on the exact fp32 MFMA GEMM (medtok_small_gemm_f32) and medtok_frobenius_f32; backward
+    G = g M / ||M||, dz = z* G^T, dz* = z G (two more small GEMMs)."""
+
+    @staticmethod
+    def forward(ctx, z, z_star):
+        a, b = z.detach().float().contiguous(), z_star.detach().float().contiguous()
+        m = ops.small_gemm(a, b, trans_a=True)                       # [d1, d2]
+        nrm = ops.frobenius(m)
+        ctx.save_for_backward(a, b, m, nrm)
+        ctx.in_dtypes = (z.dtype, z_star.dtype)
+        return nrm
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, m, nrm = ctx.saved_tensors
+        gm = ops.scale_by_device_scalar(m, g.float().contiguous(), nrm)         # dL/dM
+        dz = ops.small_gemm(b, gm, trans_b=True)                     # [B, d1] = z* G^T
+        dzs = ops.small_gemm(a, gm)                                  # [B, d2] = z G
+        return dz.to(ctx.in_dtypes[0]), dzs.to(ctx.in_dtypes[1])
+
+
 def alignment_loss(mu1, mu2):
     """Mean row-wise dot product (reference :59-64)."""
-    return (mu1 * mu2).sum(dim=1).mean()
+    mu1, mu2 = _pad4(mu1, mu2)
+    return _AlignmentFunction.apply(mu1, mu2)
 
 
 def orthogonal_loss(z, z_star):
     """Frobenius norm of z^T z* (reference :66-83)."""
-    return torch.linalg.matrix_norm(z.t() @ z_star, ord="fro")
+    if z_star.shape[-1] % 4:                              # (M's row length is z*'s width; z's width may be anything)
+        z_star = F.pad(z_star, (0, 4 - z_star.shape[-1] % 4))
+    return _OrthogonalFunction.apply(z, z_star)
+
+
+class _NormalizeFunction(torch.autograd.Function):
+    """F.normalize(x, p=2, dim=-1) on the rownorm kernel, backward on medtok_normalize_backward_f32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xf = x.detach().float().contiguous()
+        xhat, _ = ops.rownorm(xf)
+        ctx.save_for_backward(xf, xhat)
+        ctx.in_dtype = x.dtype
+        return xhat
+
+    @staticmethod
+    def backward(ctx, g):
+        xf, xhat = ctx.saved_tensors
+        return ops.normalize_backward(g.float().contiguous(), xhat, xf).to(ctx.in_dtype)
 
 
 def shared_loss(z1, z2, x1, x2, beta=0.1):
     """(nce(z1,z2), align(x1^,x2^), nce(z2,z1), align(x2^,x1^)) (reference :86-96);
     `beta` is applied by the caller (train_MedTok.py:221-224), as in the reference."""
-    x1n = F.normalize(x1, p=2, dim=-1)
-    x2n = F.normalize(x2, p=2, dim=-1)
+    x1, x2 = _pad4(x1, x2)
+    x1n = _NormalizeFunction.apply(x1)
+    x2n = _NormalizeFunction.apply(x2)
     return info_nce_loss(z1, z2), alignment_loss(x1n, x2n), info_nce_loss(z2, z1), alignment_loss(x2n, x1n)
 
 

@@ -231,6 +231,54 @@ def info_nce_backward(q, k, prob, ws, g_loss, temperature: float):
     return gq, gk
 
 
+def row_dot(a, b):
+    """out[r] = <a[r], b[r]> (fp32, the rownorm summation order)."""
+    a, b = _dev(a, "a"), _dev(b, "b")
+    n, d = a.shape
+    out = torch.empty(n, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().medtok_row_dot_f32(a.data_ptr(), b.data_ptr(), n, d, out.data_ptr(), _stream(a)), "medtok_row_dot_f32")
+    return out
+
+
+def small_gemm(A, B, trans_a: bool = False, trans_b: bool = False):
+    """op(A) @ op(B) in exact fp32 (one fmaf chain per entry, k ascending).  A, B: contiguous fp32 matrices; the transposes
+    are strides, nothing is copied."""
+    A, B = _dev(A, "A"), _dev(B, "B")
+    (m, k), (sam, sak) = ((A.shape[1], A.shape[0]), (1, A.shape[1])) if trans_a else ((A.shape[0], A.shape[1]), (A.shape[1], 1))
+    (k2, n), (sbk, sbn) = ((B.shape[1], B.shape[0]), (1, B.shape[1])) if trans_b else ((B.shape[0], B.shape[1]), (B.shape[1], 1))
+    if k != k2:
+        raise ValueError(f"small_gemm: inner dimensions differ ({k} vs {k2})")
+    C = torch.empty((m, n), dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        _lib.check(_lib.load().medtok_small_gemm_f32(A.data_ptr(), sam, sak, B.data_ptr(), sbk, sbn, m, n, k, C.data_ptr(), _stream(A)),
+                   "medtok_small_gemm_f32")
+    return C
+
+
+def frobenius(x):
+    """0-dim fp32 tensor ||x||_F of a contiguous [rows, d] matrix (d % 4 == 0)."""
+    x = _dev(x, "x")
+    rows, d = x.shape
+    lib = _lib.load()
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    ws = _ws(lib.medtok_frobenius_workspace_bytes(rows), x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.medtok_frobenius_f32(x.data_ptr(), rows, d, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x)), "medtok_frobenius_f32")
+    return out
+
+
+def scale_by_device_scalar(x, num, den=None, c: float = 1.0):
+    """x * (c * num / den) with num / den 0-dim device tensors (no host sync)."""
+    x, num = _dev(x, "x"), _dev(num, "num")
+    den = None if den is None else _dev(den, "den")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().medtok_scale_by_device_scalar_f32(x.data_ptr(), x.numel(), num.data_ptr(), _ptr(den), float(c), out.data_ptr(),
+                                                                 _stream(x)), "medtok_scale_by_device_scalar_f32")
+    return out
+
+
 def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, scale: float):
     """out[r] = softmax_j(scale * <q[r], kv[j]>) . kv over each code's own (ragged) query and key rows.
     q [Rq, d], kv [Rk, d] fp32; *_start / *_len int64 [n_codes] on the device; d % 128 == 0."""

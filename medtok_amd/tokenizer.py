@@ -36,6 +36,13 @@ def global_mean_pool(x: torch.Tensor, batch: torch.Tensor, size: Optional[int] =
 class MultimodalTokenizer(nn.Module):
     """text encoder + graph encoder -> soft VQ (reference tokenizer.py:47-277).
 
+    A STAND-IN for the reference class, not a signature-compatible replacement: the reference's constructor builds BERT and
+    the GCN itself (`text_model_name, graph_model_name, graph_in_channels, ...`, tokenizer.py:67-73) and owns an
+    `encoder_task_layer`; those are upstream of the VQ path and out of scope, so a reference checkpoint's `model` dict does
+    not load here with strict=True.  The drop-in for a MedTok checkout is INTEGRATION.md section A: keep the reference's
+    tokenizer.py and swap the import of its quantiser.  This class exists so that the quantise call sites (quant, the eval
+    assembly, tokenize) are exercised with pluggable encoders.
+
     text_encoder(input_ids, attention_mask) -> [B, L, text_dim] token features
     graph_encoder(x, edge_index, rel_index) -> [sum n_i, graph_dim] node features
     Either may be None; then `inputs.text_features` / `inputs.graph_node_features`
@@ -46,8 +53,14 @@ class MultimodalTokenizer(nn.Module):
                  text_dim: int = 768, graph_out_channels: int = 64, codebook_size: int = 21000,
                  codebook_embed_dim: int = 64, codebook_l2_norm: bool = True, codebook_show_usage: bool = True,
                  commit_loss_beta: float = 0.25, entropy_loss_ratio: float = 0.0, use_kmeans: bool = False,
-                 k: int = 5):
+                 k: int = 5, eval_aug_searches: bool = True):
         super().__init__()
+        # The reference's forward() encodes the augmented view and runs its two searches in eval mode too (tokenizer.py:211-225
+        # -> vector_quantization_soft_one_new.py:247-250): their results are discarded, but the 300k-id usage window
+        # (`codebook_used`, part of the state dict) slides two more times per batch.  True keeps that trajectory identical to
+        # the reference's; False skips the two searches (a third of an eval batch's search work) at the price of a different
+        # `codebook_used` buffer after an eval pass.  tokenize() never runs them (reference :265-269 passes None).
+        self.eval_aug_searches = eval_aug_searches
         self.text_model = text_encoder
         self.graph_encoder = graph_encoder
         self.text_code_dim = text_dim
@@ -78,8 +91,8 @@ class MultimodalTokenizer(nn.Module):
         if self.graph_encoder is None:
             return (inputs.graph_node_features_aug if aug and hasattr(inputs, "graph_node_features_aug")
                     else inputs.graph_node_features)
-        edge = inputs.edge_index_aug if aug else inputs.edge_index
-        rel = inputs.rel_index_aug if aug else inputs.rel_index
+        edge = getattr(inputs, "edge_index_aug", inputs.edge_index) if aug else inputs.edge_index
+        rel = getattr(inputs, "rel_index_aug", inputs.rel_index) if aug else inputs.rel_index
         out = self.graph_encoder(inputs.x, edge, rel)
         return out[-1] if isinstance(out, (list, tuple)) else out
 
@@ -107,7 +120,7 @@ class MultimodalTokenizer(nn.Module):
                                r["shared_text_embedding"], r["shared_graph_embedding"]), dim=-1)
         return embedding, tokens, weights
 
-    def forward(self, inputs):
+    def forward(self, inputs, _with_aug=None):
         batch = inputs.batch
         mask = inputs.attention_mask
         bsz = mask.shape[0]
@@ -115,7 +128,8 @@ class MultimodalTokenizer(nn.Module):
         nodes = self.tokenize_graph(inputs)
         pooled = global_mean_pool(nodes, batch, bsz)
         text_aug = nodes_aug = pooled_aug = None
-        if self.training:
+        with_aug = (self.training or self.eval_aug_searches) if _with_aug is None else _with_aug
+        if with_aug:
             text_aug = self.text_mapped(self.tokenize_text(inputs, aug=True))
             nodes_aug = self.tokenize_graph(inputs, aug=True)
             pooled_aug = global_mean_pool(nodes_aug, batch, bsz)
@@ -130,7 +144,7 @@ class MultimodalTokenizer(nn.Module):
         was_training = self.training
         self.eval()
         try:
-            embedding, _, _ = self.forward(inputs)
+            embedding, _, _ = self.forward(inputs, _with_aug=False)
         finally:
             self.train(was_training)
         return embedding

@@ -269,9 +269,55 @@ def fixture_ties(sq, name):
         build_rule_idx=np.array([[1, 3, 7], [4, 10, -1], [0, -1, -1]]))
 
 
+def fixture_eval_window(sq, name, B, L, max_nodes, D, n_e, seed):
+    """The usage window after ONE eval-mode forward WITH z_aug (what MultimodalTokenizer.forward does in eval,
+    tokenizer.py:211-225): the two aug searches slide it too (vector_quantization_soft_one_new.py:247-250,219-236).
+    Stored: the window's tail (everything this forward wrote) and the three usage floats."""
+    q = make_soft(sq, n_e, D, seed=seed, tag=name)
+    text, mask, nodes, batch = synth.ragged_batch(name + ".batch", B, L, max_nodes, D, seed)
+    z = synth.det_randn(name + ".z", (B, 2 * D), 1.0, seed)
+    z_aug = synth.det_randn(name + ".z_aug", (B, 2 * D), 1.0, seed)
+    q.eval()
+    with torch.no_grad():
+        r = q(z, text, nodes, mask, batch, z_aug)
+    wrote = 6 * B * q.k          # shared (2 B k) + text + graph + aug text + aug graph (B k each)
+    npz(name, n_e=n_e, e_dim=D, k=q.k, seed=seed, B=B, L=L, max_nodes=max_nodes, window_tail=q.codebook_used[-wrote:].detach().clone(),
+        head_untouched=q.codebook_used[: 16].detach().clone(),
+        usage=np.array([r["shared_codebook_usage"], r["text_specific_usage"], r["graph_specific_usage"]]))
+
+
+def fixture_kmeans(nq, name, N, D, K, seed):
+    """kmeans (norm_ema_quantizer.py:24-57) as EmbeddingEMA.init_embed_ calls it (:90: 10 iterations, cosine) on l2-normalised
+    samples.  Its only randomness is the choice of the initial means (sample_vectors -> torch.randperm, :14-22): patched to
+    return a recorded choice, after which the iteration is deterministic.  Samples come from the seeded recipe (not stored);
+    stored: the initial means' sample indices, every iteration's bucket assignment (captured at the reference's own
+    torch.bincount call), the final means and bins."""
+    samples = F.normalize(synth.det_randn(name + ".samples", (N, D), 1.0, seed), dim=-1)
+    g = torch.Generator().manual_seed(seed)
+    init_idx = torch.randperm(N, generator=g)[:K]
+    buckets = []
+    orig_bincount, orig_sample = torch.bincount, nq.sample_vectors
+
+    def capture(x, *a, **k):
+        buckets.append(x.clone())
+        return orig_bincount(x, *a, **k)
+    nq.sample_vectors = lambda smp, num: smp[init_idx]
+    torch.bincount = capture
+    try:
+        means, bins = nq.kmeans(samples, K, 10, use_cosine_sim=True)
+    finally:
+        torch.bincount, nq.sample_vectors = orig_bincount, orig_sample
+    npz(name, N=N, D=D, K=K, seed=seed, init_idx=init_idx, buckets=torch.stack(buckets).to(torch.int16), means=means, bins=bins)
+
+
 def main():
     torch.set_num_threads(8)
     sq, nq, ls = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "--round2-only":        # added in round 2: the rest are unchanged
+        fixture_kmeans(nq, "f12_kmeans_d64", N=4096, D=64, K=32, seed=21)
+        fixture_kmeans(nq, "f12_kmeans_d768", N=2048, D=768, K=256, seed=22)
+        fixture_eval_window(sq, "f13_eval_window", B=8, L=12, max_nodes=9, D=64, n_e=96, seed=23)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--info-nce-only":      # added after the first batch: the rest are unchanged
         fixture_info_nce(ls, "f11_info_nce", B=24, D=48, seed=12)
         fixture_info_nce(ls, "f11_info_nce_wide", B=40, D=256, seed=13, temperature=0.2, upstream=0.5)
@@ -288,6 +334,9 @@ def main():
     fixture_usage(sq, "f10_usage", seed=10)
     fixture_info_nce(ls, "f11_info_nce", B=24, D=48, seed=12)
     fixture_info_nce(ls, "f11_info_nce_wide", B=40, D=256, seed=13, temperature=0.2, upstream=0.5)
+    fixture_kmeans(nq, "f12_kmeans_d64", N=4096, D=64, K=32, seed=21)
+    fixture_kmeans(nq, "f12_kmeans_d768", N=2048, D=768, K=256, seed=22)
+    fixture_eval_window(sq, "f13_eval_window", B=8, L=12, max_nodes=9, D=64, n_e=96, seed=23)
     # BASELINE config 1: 1k codes, 768-d, K=8192 -- inputs regenerated from the seeded recipe
     fixture_forward(sq, "cfg1_inference_1k", B=1000, L=8, max_nodes=6, D=768, n_e=8192, seed=11,
                     train_too=False, store_inputs=False)

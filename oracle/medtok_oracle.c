@@ -479,4 +479,51 @@ int64_t oracle_usage_update(float *window, int64_t wlen, const int64_t *ids,
     return cnt;
 }
 
+/* ---- alignment / orthogonality losses (loss.py:59-83) -------------------------------------------------
+ * row dot: 64 strided fmaf chains joined by the xor butterfly (canon_sumsq with two operands). */
+int oracle_row_dot_f32(const float *a, const float *b, int64_t n, int d, float *out)
+{
+    for (int64_t r = 0; r < n; ++r) {
+        float p[64], q[64];
+        for (int l = 0; l < 64; ++l) p[l] = 0.0f;
+        for (int i = 0; i < d; ++i) {
+            int l = (i >> 2) & 63;
+            p[l] = fmaf(a[r * d + i], b[r * d + i], p[l]);
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ off];
+            memcpy(p, q, sizeof p);
+        }
+        out[r] = p[0];
+    }
+    return 0;
+}
+
+/* C[m, n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]: ONE fmaf chain over k = 0, 1, 2, ... from +0 per entry
+ * (torch.mm(z.T, z_star), loss.py:79, and the two products of its backward). */
+int oracle_small_gemm_f32(const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn,
+                          int m, int n, int k, float *C)
+{
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {
+            float acc = 0.0f;
+            for (int t = 0; t < k; ++t) acc = fmaf(A[i * sam + t * sak], B[t * sbk + j * sbn], acc);
+            C[(int64_t)i * n + j] = acc;
+        }
+    return 0;
+}
+
+/* ||x||_F (torch.norm(., p='fro'), loss.py:82): canonical per-row sums of squares, added in fp64 in row order
+ * by the kernel's fixed tree (1024 strided partial sums, pairwise), square root in fp64. */
+int oracle_frobenius_f32(const float *x, int64_t rows, int d, float *out)
+{
+    double part[1024];
+    for (int t = 0; t < 1024; ++t) part[t] = 0.0;
+    for (int64_t r = 0; r < rows; ++r) part[r % 1024] += (double)canon_sumsq(x + r * d, d);
+    for (int off = 512; off >= 1; off >>= 1)
+        for (int t = 0; t < off; ++t) part[t] += part[t + off];
+    out[0] = (float)sqrt(part[0]);
+    return 0;
+}
+
 int oracle_abi_version(void) { return 1; }

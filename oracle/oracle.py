@@ -173,6 +173,34 @@ def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, scale):
     return out
 
 
+def row_dot(a, b):
+    """<a[r], b[r]> per row (the summand of alignment_loss, loss.py:63)."""
+    a, ap = _f(a); b, bp = _f(b)
+    out = np.empty(a.shape[0], np.float32)
+    assert lib().oracle_row_dot_f32(ap, bp, C.c_int64(a.shape[0]), a.shape[1], out.ctypes.data_as(_f32p)) == 0
+    return out
+
+
+def small_gemm(A, B, trans_a=False, trans_b=False):
+    """op(A) @ op(B), one fp32 fmaf chain over k per entry (torch.mm of loss.py:79 and its backward)."""
+    A, Ap = _f(A); B, Bp = _f(B)
+    (m, k), (sam, sak) = ((A.shape[1], A.shape[0]), (1, A.shape[1])) if trans_a else ((A.shape[0], A.shape[1]), (A.shape[1], 1))
+    (k2, n), (sbk, sbn) = ((B.shape[1], B.shape[0]), (1, B.shape[1])) if trans_b else ((B.shape[0], B.shape[1]), (B.shape[1], 1))
+    assert k == k2
+    out = np.empty((m, n), np.float32)
+    assert lib().oracle_small_gemm_f32(Ap, C.c_int64(sam), C.c_int64(sak), Bp, C.c_int64(sbk), C.c_int64(sbn), m, n, k,
+                                       out.ctypes.data_as(_f32p)) == 0
+    return out
+
+
+def frobenius(x):
+    """||x||_F (torch.norm(p='fro'), loss.py:82)."""
+    x, xp = _f(x)
+    out = np.empty(1, np.float32)
+    assert lib().oracle_frobenius_f32(xp, C.c_int64(x.shape[0]), x.shape[1], out.ctypes.data_as(_f32p)) == 0
+    return out[0]
+
+
 def ema_stats(zhat, idx, k_codes):
     """bins and embed_sum ([K,D]) of norm_ema_quantizer.py:194,202."""
     zhat, zp = _f(zhat); idx, ip = _i(idx)

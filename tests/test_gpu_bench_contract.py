@@ -15,7 +15,8 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 @pytest.mark.parametrize("args", [["--rows", "20000", "--cpu-rows", "256"],
                                   ["--workload", "cfg2", "--rows", "20000", "--cpu-rows", "512"],
-                                  ["--workload", "full", "--rows", "256", "--cpu-rows", "8"]])
+                                  ["--workload", "full", "--rows", "256", "--cpu-rows", "8"],
+                                  ["--workload", "cfg4", "--rows", "32", "--text-layers", "1", "--cpu-rows", "16"]])
 def test_bench_prints_one_contract_line(dev, args):
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", *args],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)

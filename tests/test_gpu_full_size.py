@@ -1,0 +1,124 @@
+"""GPU: the BASELINE.json configurations at their REAL sizes (the plans the bench takes -- XCD-aware block order,
+two code splits, the tail launch -- are only reached there).  Same seeded inputs as bench.py's workloads."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_at_600k_rows_default_path_vs_exact_path_and_oracle(oracle, dev):
+    """cfg 3 exactly as bench.py runs it: N = 600 000 codes, n_e = 49 152, D = 768, k = 5, four searches.
+    (1) default path (fp16 shortlist + exact re-score) vs the exact fp32-MFMA path: embedding, tokens, weights bit-equal on all
+        600k rows;  (2) 320 sampled rows of every search vs the C oracle: ids and distances bit-equal, weights / embedding 1e-5."""
+    from medtok_amd import ops
+    from medtok_amd.inference import quantize_pooled
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    D, region, n = 768, 16384, 600000
+    torch.manual_seed(1234)
+    v = VectorQuantizer(3 * region, D, 0.25, 0.0, True, False, [D, D]).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(0)
+    h = torch.randn(n, 2 * D, device=dev, generator=g)
+    pt = torch.randn(n, D, device=dev, generator=g); pg = torch.randn(n, D, device=dev, generator=g)
+    emb, tok, w = quantize_pooled(v, h, pt, pg)
+    v.search_path = ops.PATH_F32_MFMA
+    emb2, tok2, w2 = quantize_pooled(v, h, pt, pg)
+    assert torch.equal(tok, tok2) and torch.equal(w, w2) and torch.equal(emb, emb2)
+    del emb2, tok2, w2
+    # sampled rows through the oracle (the last rows sit in the tail launch's row tiles)
+    sel = torch.cat([torch.arange(0, n, 2003, device=dev)[:300], torch.arange(n - 20, n, device=dev)])
+    W = v.codebook.weight.detach()
+    what_o, wsq_o = oracle.rownorm(W.cpu().numpy())
+    with torch.no_grad():
+        xs = [v.proj_text(h[sel, :D]), v.proj_graph(h[sel, D:]), pt[sel], pg[sel]]
+    regions = [(0, region), (2 * region, 3 * region), (0, 3 * region), (0, 3 * region)]
+    for s, (x, (lo, hi)) in enumerate(zip(xs, regions)):
+        xh_o, xs_o = oracle.rownorm(x.cpu().numpy())
+        idx_o, dist_o = oracle.topk_search(xh_o, xs_o, what_o[lo:hi], wsq_o[lo:hi], 5)
+        assert np.array_equal(tok[sel, s].cpu().numpy(), idx_o), s
+        w_o, zq_o, _ = oracle.soft_assign(x.cpu().numpy(), what_o[lo:hi], idx_o, dist_o)
+        assert np.abs(w[sel, s].cpu().numpy() - w_o).max() <= 1e-5
+        e = emb[sel, s * D:(s + 1) * D].cpu().numpy()
+        assert np.abs(e - zq_o).max() <= 1e-5 * np.abs(zq_o).max()
+
+
+def test_config2_module_train_step_at_100k_rows(oracle, dev):
+    """cfg 2 through the MODULE: NormEMAVectorQuantizer train step, N = 100 000, D = 768, K = 8192.  ids: default path ==
+    exact path == oracle on sampled rows; bins == an exact histogram of the ids; the updated codebook == oracle.ema_apply fed
+    the GPU's own statistics, on a 512-code subset; loss and z_q to 1e-5."""
+    from medtok_amd import ops
+    from medtok_amd.norm_ema_quantizer import NormEMAVectorQuantizer
+    N, D, K = 100000, 768, 8192
+    g = torch.Generator(device=dev).manual_seed(0)
+    z = torch.randn(N, D, 1, 1, device=dev, generator=g)
+    torch.manual_seed(1234)
+    q = NormEMAVectorQuantizer(K, D, 0.25).to(dev).train()
+    E0 = q.embedding.weight.data.clone(); cs0 = q.cluster_size.clone()
+    outs = {}
+    for path in (ops.PATH_AUTO, ops.PATH_F32_MFMA):
+        q.embedding.weight.data.copy_(E0); q.cluster_size.copy_(cs0)
+        q.search_path = path
+        with torch.no_grad():
+            zq, loss, idx = q(z)
+        outs[path] = (zq.clone(), loss.clone(), idx.clone(), q.embedding.weight.data.clone(), q.cluster_size.clone())
+    for a, b in zip(outs[ops.PATH_AUTO], outs[ops.PATH_F32_MFMA]):
+        assert torch.equal(a, b)
+    zq, loss, idx, E1, cs1 = outs[ops.PATH_AUTO]
+    assert idx.shape == (N,) and idx.dtype == torch.int64
+    # sampled rows vs the oracle's argmin
+    sel = torch.arange(0, N, 331, device=dev)[:300]
+    zh_o, zs_o = oracle.rownorm(z[sel, :, 0, 0].cpu().numpy())
+    _, es_o = oracle.rownorm(E0.cpu().numpy(), normalize=False)
+    idx_o, _ = oracle.topk_search(zh_o, zs_o, E0.cpu().numpy(), es_o, 1)
+    assert np.array_equal(idx[sel].cpu().numpy(), idx_o[:, 0])
+    # exact histogram, cluster_size EMA
+    bins = torch.bincount(idx, minlength=K).float()
+    assert torch.equal(cs1, cs0 * 0.99 + bins * (1 - 0.99)) or float((cs1 - (cs0 * 0.99 + bins * (1 - 0.99))).abs().max()) <= 1e-6
+    # codebook update on a code subset: oracle.ema_apply with the GPU's statistics
+    zh, _ = ops.rownorm(z[:, :, 0, 0].contiguous())
+    b_gpu, es_gpu = ops.ema_stats(zh, idx, K)
+    assert torch.equal(b_gpu, bins)
+    sub = torch.arange(0, K, 16, device=dev)
+    E_o = E0[sub].cpu().numpy().copy(); cs_o = cs0[sub].cpu().numpy().copy()
+    oracle.ema_apply(E_o, cs_o, b_gpu[sub].cpu().numpy(), es_gpu[sub].cpu().numpy(), 0.99)
+    assert np.array_equal(E1[sub].cpu().numpy(), E_o)
+    # loss = beta * mse(z_q, z^) and the straight-through value, dense fp64 check
+    zq_rows = zq[:, :, 0, 0]
+    ref_loss = 0.25 * ((E0[idx].double() - zh.double()) ** 2).mean()
+    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * float(ref_loss)
+    assert float((zq_rows.double() - (zh.double() + (E0[idx].double() - zh.double()))).abs().max()) <= 1e-6
+
+
+def test_config4_train_step_bf16_at_L512(dev):
+    """cfg 4 at its real shape: B = 256 codes, 512 BERT-shaped text tokens, PrimeKG-shaped subgraphs, train step under bf16
+    autocast (stand-in encoders: the reference's BERT / GAT are upstream of the path).  Against the SAME step in fp32:
+    token ids identical on >= 99 % of the (code, search, slot) entries (bf16 encoder outputs move a few near-ties), total loss
+    within 2e-2 relative, codebook gradient sparse and finite."""
+    from medtok_amd import loss as L
+    from medtok_amd.synthetic import StandInGAT, StandInTextEncoder, primekg_shaped_batch
+    from medtok_amd.tokenizer import MultimodalTokenizer
+    torch.manual_seed(0)
+    model = MultimodalTokenizer(StandInTextEncoder(layers=2), StandInGAT(dim=768), text_dim=768, graph_out_channels=768, codebook_size=49152,
+                                codebook_embed_dim=768).to(dev).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    inputs = primekg_shaped_batch(256, dev, seed=0, max_len=512)
+    res = {}
+    for name, ctx in (("fp32", torch.autocast("cuda", enabled=False)), ("bf16", torch.autocast("cuda", dtype=torch.bfloat16))):
+        model.zero_grad(set_to_none=True)
+        model.quantize.codebook_used.zero_()
+        with ctx:
+            r = model(inputs)
+            loss, parts = L.total_loss(r, 0.1, 0.1)
+        loss.float().backward()
+        gw = model.quantize.codebook.weight.grad
+        res[name] = (float(loss), torch.stack([r[k] for k in ("text_tokens", "graph_tokens", "shared_text_tokens", "shared_graph_tokens")]).clone(),
+                     gw.clone())
+        assert torch.isfinite(loss) and torch.isfinite(gw).all()
+        assert int((gw.abs().sum(1) > 0).sum()) <= 256 * 6 * 5            # sparse: only selected codes carry gradient
+    l32, t32, g32 = res["fp32"]; l16, t16, g16 = res["bf16"]
+    assert (t32 == t16).float().mean().item() >= 0.99
+    assert abs(l16 - l32) <= 2e-2 * abs(l32), (l16, l32)

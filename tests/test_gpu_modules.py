@@ -359,3 +359,65 @@ def test_packed_cross_attention_equals_projected_form_at_full_dims(dev, B, L, M,
         pt_p, pg_p = v.cross_attn.pooled(*a, fold=False)     # padded, projected keys
     for x, y in ((pt_k, pt_p), (pg_k, pg_p)):
         assert float((x - y).abs().max() / y.abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["f12_kmeans_d64", "f12_kmeans_d768"])
+def test_kmeans_matches_the_reference_run(golden, dev, name):
+    """k-means codebook init vs the reference's own kmeans() (norm_ema_quantizer.py:24-57) started from the same means (F12:
+    oracle/gen_golden.py patches sample_vectors; everything after it is deterministic).  Every iteration's bucket assignment is
+    the reference's wherever the fp64 best-vs-second margin (on the means that iteration used) exceeds 1e-5; final means within
+    1e-5, bins equal up to the rows inside that margin."""
+    from medtok_amd.kmeans import kmeans
+    from oracle import synth
+    g = golden(name)
+    N, D, K, seed = int(g["N"]), int(g["D"]), int(g["K"]), int(g["seed"])
+    samples = torch.nn.functional.normalize(synth.det_randn(name + ".samples", (N, D), 1.0, seed), dim=-1).to(dev)
+    init = samples[torch.from_numpy(g["init_idx"]).to(dev)]
+    trace = []
+    means, bins = kmeans(samples, K, 10, use_cosine_sim=True, init_means=init, trace=trace)
+    ref_buckets = torch.from_numpy(g["buckets"].astype(np.int64)).to(dev)
+    assert len(trace) == 10 and ref_buckets.shape == (10, N)
+    risky_total = 0
+    for it, (buckets, used) in enumerate(trace):
+        dots = samples.double() @ used.double().t()
+        top2 = torch.topk(dots, 2, dim=1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-5
+        risky_total += int((~safe).sum())
+        assert torch.equal(buckets[safe], ref_buckets[it][safe]), it
+    assert risky_total <= 10 * N // 200                   # the margin rule must not be what makes the test pass
+    assert float((means.cpu() - torch.from_numpy(g["means"])).abs().max()) <= 1e-5
+    assert float((bins.cpu() - torch.from_numpy(g["bins"]).float()).abs().max()) <= max(1, risky_total)
+    assert float(bins.sum()) == N
+
+
+def test_eval_forward_slides_the_usage_window_like_the_reference(golden, dev):
+    """Eval-mode forward WITH the augmented view (what the reference's MultimodalTokenizer.forward does, tokenizer.py:211-225):
+    the two aug searches slide the 300k-id window too.  The `codebook_used` buffer -- part of the state dict -- must end up
+    exactly as the reference's (F13), and the tokenizer's eval forward must take that route unless told not to."""
+    from medtok_amd.tokenizer import MultimodalTokenizer, make_inputs
+    g = golden("f13_eval_window")
+    name, B, D, k = "f13_eval_window", int(g["B"]), int(g["e_dim"]), int(g["k"])
+    v = make_vq(name, dict(g, beta=0.25), dev).eval()
+    text, mask, nodes, batch = synth.ragged_batch(name + ".batch", B, int(g["L"]), int(g["max_nodes"]), D, int(g["seed"]))
+    z = synth.det_randn(name + ".z", (B, 2 * D), 1.0, int(g["seed"])).to(dev)
+    z_aug = synth.det_randn(name + ".z_aug", (B, 2 * D), 1.0, int(g["seed"])).to(dev)
+    with torch.no_grad():
+        r = v(z, text.to(dev), nodes.to(dev), mask.to(dev), batch.to(dev), z_aug)
+    tail = g["window_tail"]
+    assert np.array_equal(v.codebook_used[-tail.size:].cpu().numpy(), tail)
+    assert np.array_equal(v.codebook_used[:16].cpu().numpy(), g["head_untouched"])
+    assert np.allclose([r["shared_codebook_usage"], r["text_specific_usage"], r["graph_specific_usage"]], g["usage"], rtol=0, atol=1e-12)
+
+    # tokenizer level: eval forward with / without the aug searches, tokenize() never
+    def run(flag, call):
+        tok = MultimodalTokenizer(text_dim=D, graph_out_channels=D, codebook_size=int(g["n_e"]), codebook_embed_dim=D, k=k,
+                                  eval_aug_searches=flag).to(dev).eval()
+        inputs = make_inputs(text_features=text.to(dev), graph_node_features=nodes.to(dev), attention_mask=mask.to(dev), batch=batch.to(dev))
+        with torch.no_grad():
+            call(tok)(inputs)
+        return int((tok.quantize.codebook_used != 0).sum().item()), tok.quantize.codebook_used
+    wrote_aug, _ = run(True, lambda t: t.forward)
+    wrote_plain, _ = run(False, lambda t: t.forward)
+    wrote_tokenize, _ = run(True, lambda t: t.tokenize)
+    # ids are >= 0 and a few are 0, so count by the upper bound of what each route can have written
+    assert wrote_aug <= 6 * B * k and wrote_plain <= 4 * B * k and wrote_tokenize <= 4 * B * k and wrote_aug > wrote_plain

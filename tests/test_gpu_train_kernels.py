@@ -12,6 +12,9 @@ from oracle import synth
 pytestmark = pytest.mark.gpu
 
 
+RTOL = 1e-5        # north_star: embeddings / losses within 1e-5 relative fp32
+
+
 def rel(a, b):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
@@ -128,3 +131,46 @@ def test_total_loss_assembly_on_device(golden, dev):
     loss, parts = L.total_loss(r)
     assert abs(float(loss) - float(g["total"])) <= 1e-5 * abs(float(g["total"]))
     assert set(parts) >= {"codebook_loss", "shared_loss", "specific_loss"}
+
+
+@pytest.mark.parametrize("b,d1,d2", [(16, 64, 64), (256, 768, 768), (37, 100, 36), (5, 4, 8)])
+def test_alignment_and_orthogonal_kernels_match_oracle(oracle, dev, b, d1, d2):
+    """alignment_loss / orthogonal_loss (loss.py:59-83) on the gfx950 kernels vs the C oracle: row dots and every entry of
+    z^T z* bit-identical (one fmaf chain per entry), the Frobenius norm to fp32 round-off; all three GEMM orientations the
+    backward uses."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(b + d1)
+    z = rng.standard_normal((b, d1), dtype=np.float32); zs = rng.standard_normal((b, d2), dtype=np.float32)
+    T = lambda a: torch.from_numpy(a).to(dev)
+    if d1 == d2:
+        assert np.array_equal(ops.row_dot(T(z), T(zs)).cpu().numpy(), oracle.row_dot(z, zs))
+    m = ops.small_gemm(T(z), T(zs), trans_a=True)
+    m_o = oracle.small_gemm(z, zs, trans_a=True)
+    assert np.array_equal(m.cpu().numpy(), m_o)
+    assert np.array_equal(ops.small_gemm(T(zs), m, trans_b=True).cpu().numpy(), oracle.small_gemm(zs, m_o, trans_b=True))
+    assert np.array_equal(ops.small_gemm(T(z), m).cpu().numpy(), oracle.small_gemm(z, m_o))
+    if d2 % 4 == 0:
+        f, f_o = float(ops.frobenius(m)), float(oracle.frobenius(m_o))
+        assert abs(f - f_o) <= 1e-6 * f_o
+        assert abs(f_o - np.linalg.norm(z.astype(np.float64).T @ zs.astype(np.float64))) <= 1e-5 * f_o
+
+
+def test_alignment_and_orthogonal_losses_match_reference_fixture(golden, dev):
+    """Values and autograd gradients of the two regularisers alone, against the reference's (F7)."""
+    from medtok_amd import loss as L
+    g = golden("f7_losses")
+    T = lambda k: torch.from_numpy(g[k]).to(dev).requires_grad_(True)
+    x1, x2 = T("x1"), T("x2")
+    al = L.alignment_loss(x1, x2)
+    assert abs(float(al) - float(g["align"])) <= RTOL * abs(float(g["align"]))
+    (al * 3.0).backward()
+    assert float((x1.grad - 3.0 * x2.detach() / x1.shape[0]).abs().max()) <= 1e-6
+    assert float((x2.grad - 3.0 * x1.detach() / x1.shape[0]).abs().max()) <= 1e-6
+    z, zc = T("z1"), T("z1_c")
+    orth = L.orthogonal_loss(z, zc)
+    assert abs(float(orth) - float(g["orth"])) <= RTOL * float(g["orth"])
+    orth.backward()
+    zr, zcr = torch.from_numpy(g["z1"]).double().requires_grad_(True), torch.from_numpy(g["z1_c"]).double().requires_grad_(True)
+    torch.linalg.matrix_norm(zr.t() @ zcr).backward()
+    assert float((z.grad.cpu().double() - zr.grad).abs().max()) <= RTOL * float(zr.grad.abs().max())
+    assert float((zc.grad.cpu().double() - zcr.grad).abs().max()) <= RTOL * float(zcr.grad.abs().max())

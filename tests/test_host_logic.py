@@ -45,17 +45,21 @@ def test_constructor_signatures_match_reference():
         "z", "text_features", "graph_node_features", "text_attention_mask", "batch", "z_aug"]
 
 
-def test_torch_side_losses_match_reference_fixture(golden):
-    """alignment / orthogonality terms (torch code) against the reference's values; InfoNCE is a HIP kernel and is
-    checked on the GPU (tests/test_gpu_train_kernels.py) -- on CPU tensors it must refuse loudly."""
+def test_losses_refuse_cpu_tensors_and_oracle_matches_reference_fixture(golden, oracle):
+    """Every term of loss.py runs on HIP kernels (checked on the GPU, tests/test_gpu_train_kernels.py): on CPU tensors they must
+    refuse loudly.  The oracle's restatements of the alignment / orthogonality terms are pinned to the reference's values here."""
     from medtok_amd import loss as L
     from medtok_amd._lib import MedTokLibraryError
     g = golden("f7_losses")
     t = {k: torch.from_numpy(g[k]) for k in ("z1", "z2", "x1", "x2", "z1_c")}
-    assert abs(float(L.alignment_loss(t["x1"], t["x2"])) - float(g["align"])) <= 1e-5 * abs(float(g["align"]))
-    assert abs(float(L.orthogonal_loss(t["z1"], t["z1_c"])) - float(g["orth"])) <= 1e-5 * float(g["orth"])
-    with pytest.raises(MedTokLibraryError):
-        L.info_nce_loss(t["z1"], t["z2"])
+    for fn, args in ((L.alignment_loss, ("x1", "x2")), (L.orthogonal_loss, ("z1", "z1_c")), (L.info_nce_loss, ("z1", "z2"))):
+        with pytest.raises(MedTokLibraryError):
+            fn(*[t[a] for a in args])
+    align = float(oracle.row_dot(g["x1"], g["x2"]).astype(np.float64).mean())
+    assert abs(align - float(g["align"])) <= 1e-5 * abs(float(g["align"]))
+    m = oracle.small_gemm(g["z1"], g["z1_c"], trans_a=True)
+    assert np.abs(m - g["z1"].astype(np.float64).T @ g["z1_c"].astype(np.float64)).max() <= 1e-5 * np.abs(m).max()
+    assert abs(float(oracle.frobenius(m)) - float(g["orth"])) <= 1e-5 * float(g["orth"])
 
 
 @pytest.mark.parametrize("name", ["f3_forward_d64", "f4_forward_d128"])
