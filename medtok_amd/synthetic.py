@@ -13,6 +13,28 @@ import torch.nn as nn
 from .tokenizer import make_inputs
 
 
+class _EncoderLayer(nn.Module):
+    """post-LN transformer layer written out in plain ops: every GEMM is a 2-D [B*L, d] x [d, *] product and the attention is
+    F.scaled_dot_product_attention without a mask.  (nn.TransformerEncoderLayer's inference fast path packs the unpadded tokens
+    into a nested tensor; the odd row counts it produces hit a memory fault in this image's hipBLASLt bf16 stream-K kernels.
+    The stand-in therefore lets padded positions attend like any other token -- its outputs there are never read: the VQ path
+    masks them as keys and only uses the CLS row as a query.)"""
+
+    def __init__(self, dim, heads, ffn):
+        super().__init__()
+        self.heads = heads
+        self.qkv, self.proj = nn.Linear(dim, 3 * dim), nn.Linear(dim, dim)
+        self.ff1, self.ff2 = nn.Linear(dim, ffn), nn.Linear(ffn, dim)
+        self.ln1, self.ln2 = nn.LayerNorm(dim), nn.LayerNorm(dim)
+
+    def forward(self, x):
+        b, l, d = x.shape
+        qkv = self.qkv(x.reshape(b * l, d)).view(b, l, 3, self.heads, d // self.heads).permute(2, 0, 3, 1, 4)
+        att = torch.nn.functional.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+        x = self.ln1(x + self.proj(att.transpose(1, 2).reshape(b * l, d)).view(b, l, d))
+        return self.ln2(x + self.ff2(torch.nn.functional.gelu(self.ff1(x.reshape(b * l, d)))).view(b, l, d))
+
+
 class StandInTextEncoder(nn.Module):
     """BERT-base-shaped encoder (hidden 768, 12 heads, FFN 3072; `layers` of them, 12 = BERT-base): token + position
     embeddings, post-LN transformer layers, returns [B, L, 768] token features like `last_hidden_state`."""
@@ -22,14 +44,12 @@ class StandInTextEncoder(nn.Module):
         self.tok = nn.Embedding(vocab, dim)
         self.pos = nn.Embedding(max_len, dim)
         self.norm = nn.LayerNorm(dim)
-        self.layers = nn.ModuleList([nn.TransformerEncoderLayer(dim, heads, ffn, dropout=0.1, activation="gelu", batch_first=True)
-                                     for _ in range(layers)])
+        self.layers = nn.ModuleList([_EncoderLayer(dim, heads, ffn) for _ in range(layers)])
 
     def forward(self, input_ids, attention_mask):
         x = self.norm(self.tok(input_ids) + self.pos(torch.arange(input_ids.shape[1], device=input_ids.device))[None])
-        pad = ~attention_mask.bool()
         for layer in self.layers:
-            x = layer(x, src_key_padding_mask=pad)
+            x = layer(x)
         return x
 
 

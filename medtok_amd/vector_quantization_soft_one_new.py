@@ -94,13 +94,18 @@ class CrossAttention(nn.Module):
         bq, _, bv = mha.in_proj_bias.chunk(3)
         q = torch.nn.functional.linear(query, wq, bq).view(bsz, rows, heads, hd)
         qf = torch.einsum("brhd,hdk->brhk", q, wk.view(heads, hd, dim)).reshape(bsz, rows * heads, dim)
-        scores = torch.bmm(qf, kv.transpose(1, 2)) * (hd ** -0.5)
-        scores = scores.masked_fill(~key_valid[:, None, :], float("-inf"))
-        prob = torch.softmax(scores, dim=-1)
-        prob = prob.masked_fill(~key_valid.any(-1)[:, None, None], 0.0)     # no valid key at all: attend to nothing (not NaN)
-        if layer.training and mha.dropout > 0.0:
-            prob = torch.nn.functional.dropout(prob, mha.dropout)
-        ctx = torch.bmm(prob.to(kv.dtype), kv).view(bsz, rows, heads, dim)
+        # The attention core runs in fp32 also under autocast: PyTorch 2.10 / hipBLASLt on gfx950 takes a memory fault in bf16
+        # strided-batched GEMMs at the training shape ([256, 800, 768] x [256, 512, 768]^T and the transposed forms autograd
+        # derives from it; fp32 is fine), and fp32 scores are what the inference kernel computes anyway.
+        with torch.autocast(device_type=query.device.type, enabled=False):
+            qf32, kv32 = qf.float(), kv.float()
+            scores = torch.bmm(qf32, kv32.transpose(1, 2)) * (hd ** -0.5)
+            scores = scores.masked_fill(~key_valid[:, None, :], float("-inf"))
+            prob = torch.softmax(scores, dim=-1)
+            prob = prob.masked_fill(~key_valid.any(-1)[:, None, None], 0.0)     # no valid key at all: attend to nothing (not NaN)
+            if layer.training and mha.dropout > 0.0:
+                prob = torch.nn.functional.dropout(prob, mha.dropout)
+            ctx = torch.bmm(prob, kv32).view(bsz, rows, heads, dim)
         attended = torch.einsum("brhk,hdk->brhd", ctx, wv.view(heads, hd, dim)).reshape(bsz, rows, dim) + bv
         attended = mha.out_proj(attended)
         return layer.layer_norm(query + layer.dropout(attended))
