@@ -280,8 +280,9 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    long row0 = (long)blockIdx.x * S_BN;
-    const long part_rows = INDIRECT ? (long)(list_end - list_begin) : n;     // row extent of the partial-result buffers
+    // direct form: this launch covers rows from list_begin on; its partial-result buffers span list_end rows (0 = all n)
+    long row0 = (long)blockIdx.x * S_BN + (INDIRECT ? 0 : list_begin);
+    const long part_rows = INDIRECT ? (long)(list_end - list_begin) : (list_end > 0 ? (long)list_end : n);     // row extent of the partial-result buffers
     if (INDIRECT) {
         // this launch covers list positions [list_begin, min(*row_count, list_end)); uniform for the whole grid
         n = min((long)*row_count, (long)list_end);
@@ -392,13 +393,35 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
         if (++kb == nkb) {
             // ---- epilogue: d = (|x|^2 + |e|^2) - 2 x.e for this lane's 64 codes, fold into the list
             const int cbase = code_lo + ct * S_BM;
+#ifdef MEDTOK_SEARCH_NOEPI        // dev experiment: main loop only (results are garbage)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
+                asm volatile("" ::"v"(acc[m]));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            }
+#else
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                // |e|^2 of this lane's 16 codes of the tile: four consecutive codes per register group, so four 16-byte loads
+                // (+2.3 % at K = 16384, k = 5); a group that straddles K or sits on an unaligned slice takes the scalar form
+                float en[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = cbase + 32 * m + 8 * g + 4 * lh;
+                    // (argmin, TOPK = 1: the 16 scalar loads measured 4 % faster than the vector form -- its epilogue is nothing else)
+                    if (TOPK > 1 && c0 + 3 < k_codes && ((reinterpret_cast<uintptr_t>(wsq + c0) & 15) == 0)) {
+                        const float4 e4 = ld4(wsq + c0);
+                        en[4 * g] = e4.x; en[4 * g + 1] = e4.y; en[4 * g + 2] = e4.z; en[4 * g + 3] = e4.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) en[4 * g + j] = wsq[min(c0 + j, k_codes - 1)];
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float en = wsq[min(code, k_codes - 1)];
-                    const float sum = xn + en;
+                    const float sum = xn + en[r];
                     const float two = 2.0f * acc[m][r];
                     float dv = sum - two;
                     if (code >= code_hi) dv = INFINITY;
@@ -406,6 +429,7 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
                     acc[m][r] = 0.f;
                 }
             }
+#endif
             kb = 0;
             ++ct;
         }
@@ -425,7 +449,7 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
             for (int j = 0; j < TOPK; ++j)
                 if (j < topk_out) { out_idx[myrow * topk_out + j] = bi[j]; out_dist[myrow * topk_out + j] = bv[j]; }
         } else {
-            const long base = ((long)split * part_rows + (INDIRECT ? mypos - list_begin : myrow)) * TOPK;
+            const long base = ((long)split * part_rows + (INDIRECT ? mypos - list_begin : myrow - list_begin)) * TOPK;
 #pragma unroll
             for (int j = 0; j < TOPK; ++j) { pval[base + j] = bv[j]; pidx[base + j] = bi[j]; }
         }
@@ -494,6 +518,10 @@ struct SearchPlan {
     int splits;          // code-range splits (grid.y)
     int codes_per_split; // multiple of 128
     long row_tiles;
+    // large searches: the first main_tiles row tiles (whole rounds of 512 resident blocks) walk ALL codes in one block; the
+    // row tiles of the last, partly filled round form a second launch with tail_splits code splits (0 = no tail launch)
+    long main_tiles;
+    int tail_splits, tail_codes_per_split;
 };
 
 static SearchPlan plan_search(int64_t n, int64_t k_codes, int topk)
@@ -515,6 +543,25 @@ static SearchPlan plan_search(int64_t n, int64_t k_codes, int topk)
     const long tiles_per_split = (code_tiles + want - 1) / want;
     p.codes_per_split = (int)(tiles_per_split * S_BM);
     p.splits = (int)((code_tiles + tiles_per_split - 1) / tiles_per_split);
+    p.main_tiles = p.row_tiles; p.tail_splits = 0; p.tail_codes_per_split = 0;
+    // From two full rounds of blocks up (2 blocks per CU resident: 512 per round) the code range is NOT split: every split
+    // restarts the lane-local top-k lists, and a young list sends the whole wave through the insertion code for most values
+    // (measured at N = 600k, K = 16384: the epilogue is 10 % of the kernel with 4 splits).  What splitting bought -- a short
+    // last round -- comes from a second launch instead: the row tiles of the partly filled last round, with enough splits to be
+    // one round of short blocks.
+    if (p.row_tiles >= 1024 && n < (1ll << 31) && g_plan_override.search_max_splits <= 0) {
+        const long round = 512;
+        const long main_tiles = p.row_tiles / round * round, tail_tiles = p.row_tiles - main_tiles;
+        p.splits = 1;
+        p.codes_per_split = (int)(code_tiles * S_BM);
+        long ts = tail_tiles > 0 ? lmin(lmin(64, code_tiles), round / tail_tiles) : 0;
+        if (ts >= 2) {
+            const long tps = (code_tiles + ts - 1) / ts;
+            p.main_tiles = main_tiles;
+            p.tail_codes_per_split = (int)(tps * S_BM);
+            p.tail_splits = (int)((code_tiles + tps - 1) / tps);
+        }
+    }
     return p;
 }
 
@@ -659,6 +706,11 @@ extern "C" size_t medtok_search_workspace_bytes(int64_t n, int64_t k_codes, int 
     if (resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER)
         return filter_ws_layout(nullptr, n, plan_filter(n, k_codes, d, topk)).total;
     SearchPlan p = plan_search(n, k_codes, topk);
+    if (p.tail_splits > 0) {
+        const size_t tail_rows = (size_t)(n - p.main_tiles * S_BN);
+        return align_up((size_t)p.tail_splits * tail_rows * p.tslots * sizeof(float), 256) +
+               align_up((size_t)p.tail_splits * tail_rows * p.tslots * sizeof(int), 256);
+    }
     if (p.splits == 1) return 256;
     return align_up((size_t)p.splits * n * p.tslots * sizeof(float), 256) +
            align_up((size_t)p.splits * n * p.tslots * sizeof(int), 256);
@@ -672,6 +724,29 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
     dim3 grid((unsigned)p.row_tiles, (unsigned)p.splits), block(256);
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
     const double pflops = 2.0 * (double)n * (double)k_codes * (double)d;
+    if (p.tail_splits > 0) {
+        // whole rounds of unsplit blocks, then the last round's row tiles with their own code splits + merge
+        const long tail_start = p.main_tiles * S_BN, tail_rows = n - tail_start;
+        const size_t vb = align_up((size_t)p.tail_splits * tail_rows * T * sizeof(float), 256);
+        const size_t ib = align_up((size_t)p.tail_splits * tail_rows * T * sizeof(int), 256);
+        if (!ws || ws_bytes < vb + ib) return fail("search: workspace too small (%zu < %zu)", ws_bytes, vb + ib);
+        float *pval = (float *)ws;
+        int *pidx = (int *)((char *)ws + vb);
+        (void)set_lds_once<search_f32_kernel<T, true, KTAIL, false>>(S_LDS_BYTES);
+        (void)set_lds_once<search_f32_kernel<T, false, KTAIL, false>>(S_LDS_BYTES);
+        hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, false>), dim3((unsigned)p.main_tiles, 1), block, S_LDS_BYTES, s, xhat, xsq, what, wsq,
+                           (long)n, (int)k_codes, d, p.codes_per_split, topk, (float *)nullptr, (int *)nullptr, idx, dist,
+                           (const int *)nullptr, (const int *)nullptr, 0, 0);
+        hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL, false>), dim3((unsigned)(p.row_tiles - p.main_tiles), (unsigned)p.tail_splits), block,
+                           S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n, (int)k_codes, d, p.tail_codes_per_split, topk, pval, pidx,
+                           (int64_t *)nullptr, (float *)nullptr, (const int *)nullptr, (const int *)nullptr, (int)tail_start, (int)tail_rows);
+        if (pa) g_prof.push_back({pa, prof_mark(s), pflops, 1});
+        if (check_launch("search_f32(main + tail)")) return 1;
+        hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((tail_rows + 31) / 32)), dim3(256), 0, s, pval, pidx, tail_rows,
+                           p.tail_splits, topk, idx + tail_start * topk, dist + tail_start * topk, (const int *)nullptr, (const int *)nullptr,
+                           (int)k_codes);
+        return check_launch("merge_topk(tail)");
+    }
     if (p.splits == 1) {
         (void)set_lds_once<search_f32_kernel<T, true, KTAIL, false>>(S_LDS_BYTES);
         hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,

@@ -38,6 +38,7 @@ def test_rownorm_bit_exact(oracle, dev, n, d):
     (64, 8192, 768, 8),      # 8-slot list
     (1, 16, 4, 3),           # minimum sizes
     (70000, 300, 32, 5),     # single split (FINAL kernel), ragged everything
+    (140001, 700, 32, 5),    # >= 1024 row tiles: unsplit main rounds + the last round's row tiles as a split tail launch
 ])
 def test_search_bit_exact(oracle, dev, n, k, d, topk):
     from medtok_amd import ops
@@ -51,6 +52,13 @@ def test_search_bit_exact(oracle, dev, n, k, d, topk):
     torch.cuda.synchronize()
     assert np.array_equal(dist.cpu().numpy(), dist_o), "distances must be bit-identical to the fmaf-chain oracle"
     assert np.array_equal(idx.cpu().numpy(), idx_o)
+    if n > 100000:           # the plan override takes the split-everything plan: same bits
+        ops.debug_plan_override(search_max_splits=64)
+        try:
+            idx2, dist2 = ops.topk_search(_t(xh, dev), _t(xs, dev), _t(wh, dev), _t(ws, dev), topk)
+        finally:
+            ops.debug_plan_override()
+        assert torch.equal(idx2, idx) and torch.equal(dist2, dist)
 
 
 def test_search_ties_lowest_index(oracle, dev, golden):

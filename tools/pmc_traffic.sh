@@ -30,6 +30,10 @@ for w in sys.argv[1:]:
         for k, n in seen.items(): agg[k]["n"] = max(agg[k]["n"], n)
     out[w] = {k: {"launches": v["n"], "fetch_bytes_x2": 2 * v["FETCH_SIZE"] / max(v["n"], 1), "write_bytes": v["WRITE_SIZE"] / max(v["n"], 1),
                   "total_bytes": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) / max(v["n"], 1)} for k, v in agg.items() if v["n"]}
+rows = {"cfg3": 600000, "cfg2": 100000, "full": 4096, "cfg5": 600000}
+flat = {"_meta": {"taken": "round 2 (tools/pmc_traffic.sh)", "rows": {w: rows.get(w) for w in out}}}
+for w, d in out.items(): flat[w] = {k: v["total_bytes"] for k, v in d.items()}
+json.dump(flat, open("gpurun_out/pmc/pmc_traffic.json", "w"), indent=1)
 json.dump(out, open("gpurun_out/pmc/summary.json", "w"), indent=1)
 for w, d in out.items():
     for k, v in sorted(d.items(), key=lambda kv: -kv[1]["total_bytes"] * kv[1]["launches"])[:12]:
