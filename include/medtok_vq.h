@@ -98,6 +98,10 @@ int medtok_debug_filter_scores_f32(const float *xhat, const float *xsq, int64_t 
                                    const float *what, const float *wsq, int64_t k_codes, int d,
                                    float *scores, void *ws, size_t ws_bytes, void *stream);
 
+/* Test hook: where, inside the workspace of a filter-path search, the int32 count of rows that were handed to the exact kernel
+ * lives (candidate-list overflow, out-of-range norms, NaN); (size_t)-1 when the shape does not take the filter path. */
+size_t medtok_debug_filter_fallback_count_offset(int64_t n, int64_t k_codes, int d, int topk, int path);
+
 /* Test hook: force plan branches the default heuristics only take at very large shapes (code-range splits, the XCD-aware
  * block order, the tail launch, the staggered epilogue of the filter kernel; the split cap of the exact kernel), so that
  * small parity tests cover them.  Process-wide; -1 restores the default for that field.  The product path never reads

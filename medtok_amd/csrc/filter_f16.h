@@ -39,7 +39,15 @@ constexpr size_t F_LDS_BYTES = (size_t)F_RING * F_STAGEB;     // 128 KB -> 1 blo
 constexpr size_t F_THR_BYTES = 256 * 64;                      // per row: the k <= 5 smallest d~ of each code-side wave pair (2 x 32 B)
 constexpr size_t F_SMEM_BYTES = F_LDS_BYTES + F_THR_BYTES;    // 144 KB
 constexpr int F_GLDS_PER_STAGE = 4;                           // LDS-DMA instructions each wave issues per stage
-constexpr int F_CAP = 96;                                     // candidate slots per (row, owner): ~25-30 used on random data
+#ifndef MEDTOK_FILTER_CAP
+#define MEDTOK_FILTER_CAP 48
+#endif
+// Candidate slots per (row, owner); a list that overflows sends its row to the exact kernel.  Measured at N = 600k, D = 768
+// (tools/cap_experiment.py, random rows): 32 slots overflow for 49 (K = 16384) / 506 (K = 49152) rows and cost 5-8 % through the
+// fallback; 48 and 96 overflow for none and time the same -- 48 halves the candidate region (1.8 GB instead of 3.7 GB per
+// 600k-row search).  Inputs that defeat the filter (thousands of near-identical codes) overflow any capacity and are simply
+// searched exactly.
+constexpr int F_CAP = MEDTOK_FILTER_CAP;
 #ifndef MEDTOK_FILTER_WM
 #define MEDTOK_FILTER_WM 2
 #endif

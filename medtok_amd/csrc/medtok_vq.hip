@@ -405,17 +405,21 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
             for (int m = 0; m < 4; ++m) {
                 // |e|^2 of this lane's 16 codes of the tile: four consecutive codes per register group, so four 16-byte loads
                 // (+2.3 % at K = 16384, k = 5); a group that straddles K or sits on an unaligned slice takes the scalar form
+                // codes at or beyond the split's end get |e|^2 = +inf, i.e. d = +inf: never inserted, and no range test per value
                 float en[16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c0 = cbase + 32 * m + 8 * g + 4 * lh;
                     // (argmin, TOPK = 1: the 16 scalar loads measured 4 % faster than the vector form -- its epilogue is nothing else)
-                    if (TOPK > 1 && c0 + 3 < k_codes && ((reinterpret_cast<uintptr_t>(wsq + c0) & 15) == 0)) {
+                    if (TOPK > 1 && c0 + 3 < code_hi && ((reinterpret_cast<uintptr_t>(wsq + c0) & 15) == 0)) {
                         const float4 e4 = ld4(wsq + c0);
                         en[4 * g] = e4.x; en[4 * g + 1] = e4.y; en[4 * g + 2] = e4.z; en[4 * g + 3] = e4.w;
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) en[4 * g + j] = wsq[min(c0 + j, k_codes - 1)];
+                        for (int j = 0; j < 4; ++j) {
+                            const float e = wsq[min(c0 + j, k_codes - 1)];        // (unconditional load: a branch around it drains vmcnt)
+                            en[4 * g + j] = c0 + j < code_hi ? e : INFINITY;
+                        }
                     }
                 }
 #pragma unroll
@@ -423,8 +427,7 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
                     const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     const float sum = xn + en[r];
                     const float two = 2.0f * acc[m][r];
-                    float dv = sum - two;
-                    if (code >= code_hi) dv = INFINITY;
+                    const float dv = sum - two;
                     topk_insert<TOPK>(bv, bi, dv, code);
                     acc[m][r] = 0.f;
                 }
@@ -891,6 +894,16 @@ extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64
                                       void *ws, size_t ws_bytes, int path, void *stream)
 {
     return search_impl(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, path, stream, nullptr);
+}
+
+// Test hook: byte offset, inside a filter-path search workspace, of the int32 count of rows the filter handed to the exact kernel
+// (candidate list overflow, norms outside the bound's range, NaN) -- tests and tools read it after a search; (size_t)-1 if the shape
+// does not take the filter path.
+extern "C" size_t medtok_debug_filter_fallback_count_offset(int64_t n, int64_t k_codes, int d, int topk, int path)
+{
+    if (n <= 0 || k_codes <= 0 || resolve_path(path, n, k_codes, d, topk) != MEDTOK_PATH_F16_FILTER) return (size_t)-1;
+    const FilterWs w = filter_ws_layout((void *)256, n, plan_filter(n, k_codes, d, topk));
+    return (size_t)((char *)w.fb_count - (char *)256);
 }
 
 // Test hook: the filter's approximate scores s~ [n, k_codes] (same MFMA sequence as the search uses),

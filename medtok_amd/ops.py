@@ -81,6 +81,11 @@ def rownorm(x: torch.Tensor, normalize: bool = True, want_xhat: bool = True):
     return xhat, sqn
 
 
+# Test hook: when set to a dict, topk_search records how many rows the fp16 filter handed to the exact kernel ("fallback_rows";
+# one host sync per search -- never set in product code).
+SEARCH_STATS = None
+
+
 def topk_search(xhat, xsq, what, wsq, topk: int, path: int = PATH_AUTO):
     """idx [n, topk] int64, dist [n, topk] fp32: the topk nearest codes per row."""
     xhat, xsq = _dev(xhat, "xhat"), _dev(xsq, "xsq")
@@ -105,6 +110,11 @@ def topk_search(xhat, xsq, what, wsq, topk: int, path: int = PATH_AUTO):
         if timer is not None:
             e1.record()
             timer.append((e0, e1, 2.0 * n * k * d))
+        if SEARCH_STATS is not None:
+            off = lib.medtok_debug_filter_fallback_count_offset(n, k, d, topk, path)
+            if off != 2 ** 64 - 1:
+                SEARCH_STATS["fallback_rows"] = int(ws[off: off + 4].view(torch.int32).item())
+                SEARCH_STATS["rows"] = n
     return idx, dist
 
 

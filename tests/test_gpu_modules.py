@@ -361,6 +361,28 @@ def test_packed_cross_attention_equals_projected_form_at_full_dims(dev, B, L, M,
         assert float((x - y).abs().max() / y.abs().max()) <= 1e-5
 
 
+def test_pooled_outputs_at_full_dims_vs_the_reference_loop(dev):
+    """The pooled cross-attention outputs at BASELINE dimensions (D = 768, L = 512 tokens, up to 40 nodes) against the
+    reference's own evaluation order -- its per-code loop over nn.MultiheadAttention layers (vector_quantization_soft_one_new.py:
+    133-142: CLS row of the attended text, mean of the attended nodes), run on the CPU in fp32 with the same weights.  (The loop is
+    the module's `forward`, pinned to the reference's outputs by fixtures F3/F4 in tests/test_host_logic.py.)"""
+    import copy
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    D, B, L, M = 768, 24, 512, 40
+    torch.manual_seed(0)
+    v = VectorQuantizer(96, D, 0.25, 0.0, True, False, [D, D]).eval()
+    text, mask, nodes, batch = synth.ragged_batch("pooled.full", B, L, M, D, 0)
+    ca = copy.deepcopy(v.cross_attn).eval()
+    with torch.no_grad():
+        ref_t, ref_g = [], []
+        for i in range(B):
+            a, b = ca(text[i, : int(mask[i].sum())], nodes[batch == i])
+            ref_t.append(a[0]); ref_g.append(b.mean(0))
+        ref_t, ref_g = torch.stack(ref_t), torch.stack(ref_g)
+        pt, pg = v.to(dev).cross_attn.pooled(text.to(dev), mask.to(dev), nodes.to(dev), batch.to(dev))
+    assert rel(pt, ref_t) <= 1e-5 and rel(pg, ref_g) <= 1e-5
+
+
 @pytest.mark.parametrize("name", ["f12_kmeans_d64", "f12_kmeans_d768"])
 def test_kmeans_matches_the_reference_run(golden, dev, name):
     """k-means codebook init vs the reference's own kmeans() (norm_ema_quantizer.py:24-57) started from the same means (F12:
