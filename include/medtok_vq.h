@@ -198,6 +198,25 @@ int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const
                                    int64_t n_codes, int64_t max_q_len, int d, float scale,
                                    float *out, void *stream);
 
+/* The same core for TRAINING, and its backward: dropout on the attention probabilities (nn.MultiheadAttention(dropout=0.1),
+ * reference :21,30) by a stateless hash mask of (seed, packed query row, key) -- P(keep) = 1 - dropout_p, kept probabilities
+ * scaled by 1 / (1 - dropout_p); the forward also returns lse[r] = log sum_j exp(scale <q_r, kv_j>) (-inf for an empty key
+ * set) from which the backward rebuilds the probabilities.  Backward (autograd of :45 through the folded form):
+ *   dq [q_rows, d]  = scale * dS . kv            dkv [kv_rows, d] = (P o M)^T . d_out + scale * dS^T . q
+ * with dS = P o ((d_out . kv^T) o M - <d_out, out>).  Rows of dq / dkv that belong to no code (or to no key of a code's slot)
+ * are zeroed.  max_kv_len >= max_b kv_len[b]; ws from medtok_shared_kv_attention_backward_workspace_bytes(q_rows). */
+int medtok_shared_kv_attention_train_f32(const float *q, const int64_t *q_start, const int64_t *q_len,
+                                         const float *kv, const int64_t *kv_start, const int64_t *kv_len,
+                                         int64_t n_codes, int64_t max_q_len, int d, float scale, float dropout_p,
+                                         uint32_t seed, float *out, float *lse, void *stream);
+size_t medtok_shared_kv_attention_backward_workspace_bytes(int64_t q_rows);
+int medtok_shared_kv_attention_backward_f32(const float *q, const int64_t *q_start, const int64_t *q_len,
+                                            const float *kv, const int64_t *kv_start, const int64_t *kv_len,
+                                            int64_t n_codes, int64_t max_q_len, int64_t max_kv_len, int64_t q_rows,
+                                            int64_t kv_rows, int d, float scale, float dropout_p, uint32_t seed,
+                                            const float *out, const float *lse, const float *d_out, float *dq, float *dkv,
+                                            void *ws, size_t ws_bytes, void *stream);
+
 /* EMA statistics of norm_ema_quantizer.py:183,194,202 without the one-hot:
  * bins[c] = #rows with idx == c (exact), embed_sum[c][:] = sum of those rows of
  * zhat added in increasing row order (deterministic).  embed_sum is [K, D]

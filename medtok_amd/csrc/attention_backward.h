@@ -1,0 +1,305 @@
+// attention_backward.h -- backward of the ragged shared-key/value attention core (attention_kernels.h), so that training
+// runs get_shared_info's cross-attention (vector_quantization_soft_one_new.py:17-88,133-142) on the same packed, unpadded
+// representation as inference.  Included by medtok_vq.hip; gfx950 only.
+//
+// Per code, with S = scale Q KV^T, P = softmax_rows(S), M the dropout mask scaled by 1/(1-p), O = (P o M) KV:
+//     dPm = dO KV^T          dP = dPm o M          delta_r = <dO_r, O_r>  (= sum_j P_rj dP_rj)
+//     dS  = P o (dP - delta)
+//     dQ  = scale dS KV                                              shared_kv_attention_dq_kernel   (block = 32 query rows)
+//     dKV = (P o M)^T dO + scale dS^T Q                              shared_kv_attention_dkv_kernel  (block = 32 key rows)
+// P is rebuilt from the log-sum-exp the forward stored (exp(S - lse)), the mask from the stateless hash (att_keep): nothing of
+// size rows x keys is ever stored.  Same tiling and exact fp32 MFMA as the forward: W waves each own D / W columns; a 32-row
+// chunk of the OTHER operand is parked in LDS (row stride D + 4), the W partial 32 x 32 products meet in LDS.
+#pragma once
+
+template <int W, int NT>
+struct AttShape {
+    static constexpr int D = 32 * W * NT, LD = D + 4, THREADS = 64 * W;
+    static constexpr int EPT = 1024 / THREADS, TPR = 32 / EPT;
+    static constexpr int FT = D / 4 < 32 ? D / 4 : 32, CI = D / 4 / FT, RP = THREADS / FT, RI = 32 / RP, NF = RI * CI;
+    // LDS floats: parked chunk + per-wave partial products + two 32 x 33 operand tiles + two 32-entry row-statistic arrays
+    static constexpr size_t LDS_FLOATS = (size_t)32 * LD + (size_t)W * 32 * 33 + 2 * 32 * 33 + 64;
+};
+
+// partial 32 x 32 product over this wave's D / W columns: A rows from registers (reg[g] = elements 8g + 4 lh .. + 3 of the slice of
+// row li), B rows = rows of the parked chunk.  Result r <-> [A row (r & 3) + 8 (r >> 2) + 4 lh][B row li].
+template <int W, int NT>
+__device__ __forceinline__ f32x16 att_partial(const float4 (&reg)[4 * NT], const float *kvs, int slice, int li, int lh)
+{
+    constexpr int LD = AttShape<W, NT>::LD;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const float *krow = kvs + li * LD + slice + 4 * lh;
+    float4 cur[4], nxt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cur[j] = *reinterpret_cast<const float4 *>(krow + 8 * j);
+#pragma unroll
+    for (int gb = 0; gb < NT; ++gb) {
+        if (gb + 1 < NT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nxt[j] = *reinterpret_cast<const float4 *>(krow + 8 * (4 * (gb + 1) + j));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = 4 * gb + j;
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(reg[g].x, cur[j].x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(reg[g].y, cur[j].y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(reg[g].z, cur[j].z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(reg[g].w, cur[j].w, s, 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+    }
+    return s;
+}
+
+// acc[t] += X^T-shaped product: A[i][k] = x[k][i] (a 32 x 33 LDS tile, contraction index first), B[k][col] = parked chunk row k
+template <int W, int NT>
+__device__ __forceinline__ void att_accumulate(f32x16 (&acc)[NT], const float (*x)[33], const float *kvs, int slice, int li, int lh)
+{
+    constexpr int LD = AttShape<W, NT>::LD;
+    const float *kcol = kvs + lh * LD + slice + li;
+    float pc = x[lh][li], pn = 0.f, kc[NT], kn[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { kc[t] = kcol[32 * t]; kn[t] = 0.f; }
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+        if (s2 + 1 < 16) {
+            pn = x[2 * (s2 + 1) + lh][li];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) kn[t] = kcol[2 * (s2 + 1) * LD + 32 * t];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pc, kc[t], acc[t], 0, 0, 0);
+        asm volatile("" ::: "memory");
+        pc = pn;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) kc[t] = kn[t];
+    }
+}
+
+#define ATT_LDS_BARRIER()                                                   \
+    do {                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  \
+        __builtin_amdgcn_s_barrier();                                       \
+        asm volatile("" ::: "memory");                                      \
+    } while (0)
+
+// ---------------------------------------------------------------- dQ
+template <int W, int NT>
+__global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
+    const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
+    const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
+    const float *__restrict__ d_out, const float *__restrict__ lse, const float *__restrict__ delta, float scale,
+    float *__restrict__ dq, int q_tiles, unsigned drop_thresh, unsigned seed, float keep_scale)
+{
+    using G = AttShape<W, NT>;
+    constexpr int D = G::D, LD = G::LD, EPT = G::EPT, TPR = G::TPR, FT = G::FT, CI = G::CI, RP = G::RP, RI = G::RI, NF = G::NF;
+    extern __shared__ __attribute__((aligned(16))) float att_sm[];
+    float *kvs = att_sm;
+    float (*part)[32][33] = reinterpret_cast<float (*)[32][33]>(kvs + 32 * LD);
+    float (*pt)[33] = reinterpret_cast<float (*)[33]>(kvs + 32 * LD + W * 32 * 33);
+    float *lse_s = kvs + 32 * LD + W * 32 * 33 + 2 * 32 * 33, *del_s = lse_s + 32;
+    const int b = (int)(blockIdx.x / (unsigned)q_tiles), qt = (int)(blockIdx.x % (unsigned)q_tiles);
+    const int ql = (int)q_len[b];
+    if (qt * 32 >= ql) return;
+    const long qs = q_start[b], ks = kv_start[b];
+    const int kl = (int)kv_len[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int slice = wave * 32 * NT;
+    const int f_r0 = tid / FT, f_c = (tid % FT) * 4;
+    float4 kf[NF];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri) {
+            const float *src = kv + (ks + min(k0 + f_r0 + RP * ri, kl - 1)) * (long)D + f_c;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) kf[ri * CI + ci] = ld4(src + 4 * FT * ci);
+        }
+    };
+    auto park = [&]() {
+        float *dst = kvs + f_r0 * LD + f_c;
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) *reinterpret_cast<float4 *>(dst + RP * ri * LD + 4 * FT * ci) = kf[ri * CI + ci];
+    };
+    if (kl > 0) fetch(0);
+    float4 qf[4 * NT], dof[4 * NT];
+    {
+        const long r = qs + min(qt * 32 + li, ql - 1);
+        const float *qrow = q + r * (long)D + slice + 4 * lh, *drow = d_out + r * (long)D + slice + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4 * NT; ++g) { qf[g] = ld4(qrow + 8 * g); dof[g] = ld4(drow + 8 * g); }
+    }
+    if (tid < 32) {
+        const long r = qs + min(qt * 32 + tid, ql - 1);
+        lse_s[tid] = lse[r];
+        del_s[tid] = delta[r];
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    __syncthreads();
+    const int row = tid / TPR, kq = (tid % TPR) * EPT;
+    for (int k0 = 0; k0 < kl; k0 += 32) {
+        park();
+        ATT_LDS_BARRIER();
+        f32x16 s = att_partial<W, NT>(qf, kvs, slice, li, lh);                    // S partial: [query row][key]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
+        ATT_LDS_BARRIER();
+        float sc[EPT];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < W; ++w2) a += part[w2][row][kq + j];
+            sc[j] = a * scale;
+        }
+        ATT_LDS_BARRIER();                                                         // everyone has read the S partials
+        s = att_partial<W, NT>(dof, kvs, slice, li, lh);                           // dPm partial = dO . KV^T
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
+        ATT_LDS_BARRIER();
+        if (k0 + 32 < kl) fetch(k0 + 32);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            float dp = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < W; ++w2) dp += part[w2][row][kq + j];
+            const int key = k0 + kq + j;
+            const float p = key < kl ? expf(sc[j] - lse_s[row]) : 0.f;
+            if (drop_thresh) dp = att_keep(seed, qs + qt * 32 + row, key, drop_thresh) ? dp * keep_scale : 0.f;
+            pt[kq + j][row] = p * (dp - del_s[row]) * scale;                       // scale dS, [key][row]
+        }
+        ATT_LDS_BARRIER();
+        att_accumulate<W, NT>(acc, pt, kvs, slice, li, lh);                        // dQ += (scale dS) . KV
+        ATT_LDS_BARRIER();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int orow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (qt * 32 + orow < ql) {
+            float *o = dq + (qs + qt * 32 + orow) * (long)D + slice + li;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o[32 * t] = acc[t][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- dKV
+template <int W, int NT>
+__global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
+    const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
+    const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
+    const float *__restrict__ d_out, const float *__restrict__ lse, const float *__restrict__ delta, float scale,
+    float *__restrict__ dkv, int kv_tiles, unsigned drop_thresh, unsigned seed, float keep_scale)
+{
+    using G = AttShape<W, NT>;
+    constexpr int D = G::D, LD = G::LD, EPT = G::EPT, TPR = G::TPR, FT = G::FT, CI = G::CI, RP = G::RP, RI = G::RI, NF = G::NF;
+    extern __shared__ __attribute__((aligned(16))) float att_sm[];
+    float *kvs = att_sm;                                                                // parked chunk: 32 query rows of Q or of dO
+    float (*part)[32][33] = reinterpret_cast<float (*)[32][33]>(kvs + 32 * LD);
+    float (*pm)[33] = reinterpret_cast<float (*)[33]>(kvs + 32 * LD + W * 32 * 33);     // (P o M)   [query][key]
+    float (*ds)[33] = pm + 32;                                                          // scale dS  [query][key]
+    float *lse_s = kvs + 32 * LD + W * 32 * 33 + 2 * 32 * 33, *del_s = lse_s + 32;
+    const int b = (int)(blockIdx.x / (unsigned)kv_tiles), kt = (int)(blockIdx.x % (unsigned)kv_tiles);
+    const int kl = (int)kv_len[b];
+    if (kt * 32 >= kl) return;
+    const long qs = q_start[b], ks = kv_start[b];
+    const int ql = (int)q_len[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int slice = wave * 32 * NT;
+    const int f_r0 = tid / FT, f_c = (tid % FT) * 4;
+    float4 kf[NF];
+    auto fetch = [&](const float *src_base, int c0) {
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri) {
+            const float *src = src_base + (qs + min(c0 + f_r0 + RP * ri, ql - 1)) * (long)D + f_c;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) kf[ri * CI + ci] = ld4(src + 4 * FT * ci);
+        }
+    };
+    auto park = [&]() {
+        float *dst = kvs + f_r0 * LD + f_c;
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) *reinterpret_cast<float4 *>(dst + RP * ri * LD + 4 * FT * ci) = kf[ri * CI + ci];
+    };
+    float4 kvf[4 * NT];                                   // this block's 32 key rows, the wave's column slice
+    {
+        const float *krow = kv + (ks + min(kt * 32 + li, kl - 1)) * (long)D + slice + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4 * NT; ++g) kvf[g] = ld4(krow + 8 * g);
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int krow_t = tid / TPR, qc = (tid % TPR) * EPT;        // elementwise steps: this thread's key row and query columns
+    for (int c0 = 0; c0 < ql; c0 += 32) {
+        __syncthreads();                                         // the previous chunk's readers of kvs / pm / ds / the statistics are done
+        if (tid < 32) {
+            const long r = qs + min(c0 + tid, ql - 1);
+            lse_s[tid] = lse[r];
+            del_s[tid] = delta[r];
+        }
+        fetch(q, c0);
+        park();
+        ATT_LDS_BARRIER();
+        f32x16 s = att_partial<W, NT>(kvf, kvs, slice, li, lh);                    // S^T partial: [key][query]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
+        ATT_LDS_BARRIER();
+        fetch(d_out, c0);                                                          // in flight under the elementwise step
+        float p[EPT];
+        bool keep[EPT];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < W; ++w2) a += part[w2][krow_t][qc + j];
+            const int key = kt * 32 + krow_t, qr = c0 + qc + j;
+            p[j] = (key < kl && qr < ql) ? expf(a * scale - lse_s[qc + j]) : 0.f;
+            keep[j] = !drop_thresh || att_keep(seed, qs + qr, key, drop_thresh);
+            pm[qc + j][krow_t] = keep[j] ? p[j] * keep_scale : 0.f;
+        }
+        ATT_LDS_BARRIER();                                                         // S partials and the Q chunk are consumed
+        park();                                                                    // dO chunk
+        ATT_LDS_BARRIER();
+        s = att_partial<W, NT>(kvf, kvs, slice, li, lh);                           // dPm^T partial = KV . dO^T
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
+        ATT_LDS_BARRIER();
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            float dp = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < W; ++w2) dp += part[w2][krow_t][qc + j];
+            dp = keep[j] ? dp * keep_scale : 0.f;
+            ds[qc + j][krow_t] = p[j] * (dp - del_s[qc + j]) * scale;
+        }
+        att_accumulate<W, NT>(acc, pm, kvs, slice, li, lh);                        // dKV += (P o M)^T . dO   (pm was complete two barriers ago)
+        fetch(q, c0);
+        ATT_LDS_BARRIER();                                                         // dO chunk consumed, ds complete
+        park();                                                                    // Q chunk again
+        ATT_LDS_BARRIER();
+        att_accumulate<W, NT>(acc, ds, kvs, slice, li, lh);                        // dKV += (scale dS)^T . Q
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int orow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (kt * 32 + orow < kl) {
+            float *o = dkv + (ks + kt * 32 + orow) * (long)D + slice + li;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o[32 * t] = acc[t][r];
+        }
+    }
+}

@@ -21,13 +21,24 @@
 //   output : each wave owns D / W output columns = NT tiles of 32, accumulators rescaled per chunk by exp(m_old - m_new).
 #pragma once
 
+// Dropout on the attention probabilities (nn.MultiheadAttention(dropout=0.1) in training, reference :21,30): element (query row r
+// of the packed query matrix, key j of its code) is kept when a 32-bit hash of (seed, r, j) clears the threshold -- stateless, so
+// the forward and both backward kernels regenerate the same mask; kept probabilities are scaled by 1 / (1 - p).
+__device__ __forceinline__ bool att_keep(unsigned seed, long qrow, int key, unsigned thresh)
+{
+    unsigned h = seed ^ ((unsigned)qrow * 0x9E3779B1u) ^ ((unsigned)(qrow >> 32) * 0x7F4A7C15u) ^ ((unsigned)key * 0x85EBCA77u);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h >= thresh;                         // thresh = p * 2^32: P(keep) = 1 - p
+}
+
 // Eight waves keep the per-lane state (query slice + output tiles + key fetch = 12 NT registers each) inside the 256
 // architectural VGPRs; with four waves at D = 768 hipcc parks the query slice in AGPRs and serialises the fetch.
 template <int W, int NT>      // waves per block, output column tiles per wave; D = 32 * W * NT
 __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
     const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
     const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
-    float scale, float *__restrict__ out, int q_tiles)
+    float scale, float *__restrict__ out, int q_tiles, float *__restrict__ lse = nullptr, unsigned drop_thresh = 0, unsigned seed = 0,
+    float keep_scale = 1.f)
 {
     constexpr int D = 32 * W * NT, LD = D + 4;     // LDS row stride in floats
     constexpr int THREADS = 64 * W;
@@ -151,7 +162,8 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
 #pragma unroll
             for (int j = 0; j < EPT; ++j) {
                 const float p = expf(v[j] - m_new);         // exp(-inf) = 0 for masked keys
-                pt[kq + j][row] = p;
+                // training: dropped probabilities do not reach the value product; the normaliser is that of the full softmax
+                pt[kq + j][row] = (drop_thresh && !att_keep(seed, qs + qt * 32 + row, k0 + kq + j, drop_thresh)) ? 0.f : p;
                 ps += p;
             }
 #pragma unroll
@@ -194,14 +206,18 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
         }
         lds_barrier();                             // all reads of this chunk's keys / probabilities are done
     }
-    if (tid % TPR == 0) l_s[tid / TPR] = l_run;
+    if (tid % TPR == 0) {
+        l_s[tid / TPR] = l_run;
+        // log-sum-exp of the scaled scores (the backward kernels rebuild the probabilities from it); -inf for an empty key set
+        if (lse && qt * 32 + tid / TPR < ql) lse[qs + qt * 32 + tid / TPR] = l_run > 0.f ? m_run + logf(l_run) : -INFINITY;
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (qt * 32 + row < ql) {
             const float lsum = l_s[row];
-            const float inv = lsum > 0.f ? 1.f / lsum : 0.f;     // a code with no key rows (empty graph / empty text) attends to nothing: context 0, not 0/0
+            const float inv = lsum > 0.f ? keep_scale / lsum : 0.f;     // a code with no key rows (empty graph / empty text) attends to nothing: context 0, not 0/0
             float *o = out + (qs + qt * 32 + row) * (long)D + slice + li;
 #pragma unroll
             for (int t = 0; t < NT; ++t) o[32 * t] = acc[t][r] * inv;

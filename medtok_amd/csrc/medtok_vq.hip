@@ -1222,26 +1222,29 @@ extern "C" int medtok_scale_by_device_scalar_f32(const float *x, int64_t count, 
 // ================================================================= cross-attention core (ragged, shared key/value rows)
 #include "attention_kernels.h"
 
-extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
-                                              const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
-                                              int d, float scale, float *out, void *stream)
+#include "attention_backward.h"
+
+static int attention_shape_ok(int d) { return d == 64 || (d > 0 && d % 128 == 0 && d <= 768); }
+
+// forward, shared by the inference and the training entry point
+static int attention_forward(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv, const int64_t *kv_start,
+                             const int64_t *kv_len, int64_t n_codes, int64_t max_q_len, int d, float scale, float *out, float *lse,
+                             float dropout_p, unsigned seed, hipStream_t s)
 {
-    if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
-    if (d != 64 && (d <= 0 || d % 128 || d > 768)) return fail("shared_kv_attention: d=%d must be 64 or a multiple of 128, at most 768", d);
-    if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out) return fail("shared_kv_attention: NULL argument");
-    if (n_codes == 0 || max_q_len == 0) return 0;
     const int64_t q_tiles = (max_q_len + 31) / 32;
     if (q_tiles * n_codes >= (1ll << 31)) return fail("shared_kv_attention: n_codes * ceil(max_q_len / 32) = %ld exceeds the grid limit", (long)(q_tiles * n_codes));
     const dim3 grid((unsigned)(q_tiles * n_codes));
-    hipStream_t s = (hipStream_t)stream;
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
     const int waves = d == 64 ? 2 : (d % 256 == 0 ? 8 : 4);
     const size_t lds = ((size_t)32 * (d + 4) + (waves + 1) * 32 * 33 + 64) * sizeof(float);   // key chunk + per-wave partial scores + probabilities + row state
+    const unsigned thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
+    const float keep_scale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
 #define MEDTOK_ATT(W, NT)                                                                                                        \
     do {                                                                                                                         \
         if (lds > 64 * 1024 && !set_lds_once<shared_kv_attention_kernel<W, NT>>(lds))                                            \
             return fail("shared_kv_attention: cannot reserve %zu bytes of LDS", lds);                                            \
-        hipLaunchKernelGGL((shared_kv_attention_kernel<W, NT>), grid, dim3(64 * W), lds, s, q, q_start, q_len, kv, kv_start, kv_len, scale, out, (int)q_tiles); \
+        hipLaunchKernelGGL((shared_kv_attention_kernel<W, NT>), grid, dim3(64 * W), lds, s, q, q_start, q_len, kv, kv_start, kv_len, scale, out, \
+                           (int)q_tiles, lse, thresh, seed, keep_scale);                                                        \
     } while (0)
     switch (d / 128) {
     case 0: MEDTOK_ATT(2, 1); break;      // d = 64, the reference's default e_dim
@@ -1255,6 +1258,78 @@ extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_s
 #undef MEDTOK_ATT
     if (pa) g_prof.push_back({pa, prof_mark(s), 0.0, 2});      // the row / key counts live on the device: the caller prices the launch
     return check_launch("shared_kv_attention");
+}
+
+extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
+                                              const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
+                                              int d, float scale, float *out, void *stream)
+{
+    if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
+    if (!attention_shape_ok(d)) return fail("shared_kv_attention: d=%d must be 64 or a multiple of 128, at most 768", d);
+    if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out) return fail("shared_kv_attention: NULL argument");
+    if (n_codes == 0 || max_q_len == 0) return 0;
+    return attention_forward(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, nullptr, 0.f, 0u, (hipStream_t)stream);
+}
+
+extern "C" int medtok_shared_kv_attention_train_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
+                                                    const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
+                                                    int d, float scale, float dropout_p, uint32_t seed, float *out, float *lse, void *stream)
+{
+    if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention_train: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
+    if (!attention_shape_ok(d)) return fail("shared_kv_attention_train: d=%d must be 64 or a multiple of 128, at most 768", d);
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail("shared_kv_attention_train: dropout_p=%g must be in [0, 1)", (double)dropout_p);
+    if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out || !lse) return fail("shared_kv_attention_train: NULL argument");
+    if (n_codes == 0 || max_q_len == 0) return 0;
+    return attention_forward(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, lse, dropout_p, seed, (hipStream_t)stream);
+}
+
+extern "C" size_t medtok_shared_kv_attention_backward_workspace_bytes(int64_t q_rows) { return q_rows > 0 ? align_up((size_t)q_rows * 4, 256) : 256; }
+
+extern "C" int medtok_shared_kv_attention_backward_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
+                                                       const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
+                                                       int64_t max_kv_len, int64_t q_rows, int64_t kv_rows, int d, float scale, float dropout_p,
+                                                       uint32_t seed, const float *out, const float *lse, const float *d_out, float *dq,
+                                                       float *dkv, void *ws, size_t ws_bytes, void *stream)
+{
+    if (n_codes < 0 || max_q_len < 0 || max_kv_len < 0 || q_rows < 0 || kv_rows < 0) return fail("shared_kv_attention_backward: bad sizes");
+    if (!attention_shape_ok(d)) return fail("shared_kv_attention_backward: d=%d must be 64 or a multiple of 128, at most 768", d);
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail("shared_kv_attention_backward: dropout_p=%g must be in [0, 1)", (double)dropout_p);
+    if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out || !lse || !d_out || !dq || !dkv) return fail("shared_kv_attention_backward: NULL argument");
+    if (!ws || ws_bytes < (size_t)q_rows * 4) return fail("shared_kv_attention_backward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    // rows no block owns (key rows past a code's kv_len inside its slot, query rows of no code) get a zero gradient
+    if (q_rows > 0 && hipMemsetAsync(dq, 0, (size_t)q_rows * d * 4, s) != hipSuccess) return fail("shared_kv_attention_backward: memset failed");
+    if (kv_rows > 0 && hipMemsetAsync(dkv, 0, (size_t)kv_rows * d * 4, s) != hipSuccess) return fail("shared_kv_attention_backward: memset failed");
+    if (n_codes == 0 || q_rows == 0) return 0;
+    float *delta = (float *)ws;
+    hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)((q_rows + 3) / 4)), dim3(256), 0, s, d_out, out, (long)q_rows, d, delta);
+    const int64_t q_tiles = (max_q_len + 31) / 32, kv_tiles = (max_kv_len + 31) / 32;
+    if (q_tiles * n_codes >= (1ll << 31) || kv_tiles * n_codes >= (1ll << 31)) return fail("shared_kv_attention_backward: grid limit exceeded");
+    const unsigned thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
+    const float keep_scale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+#define MEDTOK_ATT_BWD(W, NT)                                                                                                    \
+    do {                                                                                                                         \
+        const size_t lds = AttShape<W, NT>::LDS_FLOATS * sizeof(float);                                                          \
+        if (lds > 64 * 1024 && (!set_lds_once<shared_kv_attention_dq_kernel<W, NT>>(lds) || !set_lds_once<shared_kv_attention_dkv_kernel<W, NT>>(lds))) \
+            return fail("shared_kv_attention_backward: cannot reserve %zu bytes of LDS", lds);                                   \
+        if (q_tiles > 0)                                                                                                         \
+            hipLaunchKernelGGL((shared_kv_attention_dq_kernel<W, NT>), dim3((unsigned)(q_tiles * n_codes)), dim3(64 * W), lds, s, q, q_start, q_len, \
+                               kv, kv_start, kv_len, d_out, lse, delta, scale, dq, (int)q_tiles, thresh, seed, keep_scale);      \
+        if (kv_tiles > 0)                                                                                                        \
+            hipLaunchKernelGGL((shared_kv_attention_dkv_kernel<W, NT>), dim3((unsigned)(kv_tiles * n_codes)), dim3(64 * W), lds, s, q, q_start, q_len, \
+                               kv, kv_start, kv_len, d_out, lse, delta, scale, dkv, (int)kv_tiles, thresh, seed, keep_scale);    \
+    } while (0)
+    switch (d / 128) {
+    case 0: MEDTOK_ATT_BWD(2, 1); break;
+    case 1: MEDTOK_ATT_BWD(4, 1); break;
+    case 2: MEDTOK_ATT_BWD(8, 1); break;
+    case 3: MEDTOK_ATT_BWD(4, 3); break;
+    case 4: MEDTOK_ATT_BWD(8, 2); break;
+    case 5: MEDTOK_ATT_BWD(4, 5); break;
+    default: MEDTOK_ATT_BWD(8, 3); break;
+    }
+#undef MEDTOK_ATT_BWD
+    return check_launch("shared_kv_attention_backward");
 }
 
 // ================================================================= EMA statistics

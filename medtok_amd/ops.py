@@ -304,6 +304,39 @@ def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int,
     return out
 
 
+def shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, scale: float, dropout_p: float = 0.0, seed: int = 0):
+    """(out, lse): the attention core with dropout on the probabilities (stateless hash mask) and the log-sum-exp per query row."""
+    q, kv = _dev(q, "q"), _dev(kv, "kv")
+    qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
+    ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
+    out = torch.zeros_like(q)                 # rows that belong to no code stay zero
+    lse = torch.full((q.shape[0],), float("-inf"), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.load().medtok_shared_kv_attention_train_f32(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(),
+                                                                    kl.data_ptr(), qs.numel(), int(max_q_len), q.shape[1], float(scale),
+                                                                    float(dropout_p), int(seed) & 0xFFFFFFFF, out.data_ptr(), lse.data_ptr(),
+                                                                    _stream(q)), "medtok_shared_kv_attention_train_f32")
+    return out, lse
+
+
+def shared_kv_attention_backward(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, max_kv_len: int, scale: float, dropout_p: float,
+                                 seed: int, out, lse, d_out):
+    """(dq, dkv) of shared_kv_attention_train for the upstream gradient d_out."""
+    q, kv, out, lse, d_out = _dev(q, "q"), _dev(kv, "kv"), _dev(out, "out"), _dev(lse, "lse"), _dev(d_out, "d_out")
+    qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
+    ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    lib = _lib.load()
+    ws = _ws(lib.medtok_shared_kv_attention_backward_workspace_bytes(q.shape[0]), q)
+    with torch.cuda.device(q.device):
+        _lib.check(lib.medtok_shared_kv_attention_backward_f32(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(), kl.data_ptr(),
+                                                               qs.numel(), int(max_q_len), int(max_kv_len), q.shape[0], kv.shape[0], q.shape[1],
+                                                               float(scale), float(dropout_p), int(seed) & 0xFFFFFFFF, out.data_ptr(), lse.data_ptr(),
+                                                               d_out.data_ptr(), dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(), ws.numel(), _stream(q)),
+                   "medtok_shared_kv_attention_backward_f32")
+    return dq, dkv
+
+
 def sum_scale(vals: torch.Tensor, scale: float) -> torch.Tensor:
     """0-dim fp32 tensor = scale * sum(vals) (fp64 accumulation, fixed order)."""
     vals = _dev(vals, "vals")

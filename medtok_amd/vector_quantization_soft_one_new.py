@@ -39,6 +39,28 @@ from .norm_ema_quantizer import EmbeddingEMA
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
 
 
+class _RaggedAttentionFunction(torch.autograd.Function):
+    """The ragged attention core under autograd: forward = medtok_shared_kv_attention_train_f32 (dropout on the probabilities by
+    a stateless hash mask, log-sum-exp kept per row), backward = medtok_shared_kv_attention_backward_f32 (dQ and dKV kernels that
+    rebuild probabilities and mask; nothing of size rows x keys is stored).  fp32 whatever autocast says."""
+
+    @staticmethod
+    def forward(ctx, q, kv, q_start, q_len, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed):
+        qf, kvf = q.detach().float().contiguous(), kv.detach().float().contiguous()
+        out, lse = ops.shared_kv_attention_train(qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, scale, dropout_p, seed)
+        ctx.save_for_backward(qf, kvf, out, lse, q_start, q_len, kv_start, kv_len)
+        ctx.cfg = (max_q_len, max_kv_len, scale, dropout_p, seed, q.dtype, kv.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        qf, kvf, out, lse, q_start, q_len, kv_start, kv_len = ctx.saved_tensors
+        max_q_len, max_kv_len, scale, dropout_p, seed, qd, kd = ctx.cfg
+        dq, dkv = ops.shared_kv_attention_backward(qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed,
+                                                   out, lse, d_out.float().contiguous())
+        return dq.to(qd), dkv.to(kd), None, None, None, None, None, None, None, None, None
+
+
 class CrossAttentionLayer(nn.Module):
     """Multi-head attention + residual + LayerNorm (reference :17-51)."""
 
@@ -113,8 +135,8 @@ class CrossAttention(nn.Module):
     @staticmethod
     def _folded_rows(layer, rows, attend):
         """_folded_layer for PACKED query rows [R, D] (no batch axis, nothing padded): the attention core is
-        `attend(qf [R*heads, D]) -> ctx [R*heads, D]`, i.e. the ragged gfx950 kernel (ops.shared_kv_attention).
-        Inference form: dropout is the identity here (callers only take this path in eval mode)."""
+        `attend(qf [R*heads, D]) -> ctx [R*heads, D]`, i.e. the ragged gfx950 kernel (ops.shared_kv_attention in eval;
+        _RaggedAttentionFunction with the attention-probability dropout under autograd / in training)."""
         mha = layer.multihead_attn
         n_rows, dim = rows.shape
         heads, hd = mha.num_heads, mha.head_dim
@@ -123,16 +145,24 @@ class CrossAttention(nn.Module):
         q = torch.nn.functional.linear(rows, wq, bq).view(n_rows, heads, hd)
         qf = torch.einsum("rhd,hdk->rhk", q, wk.view(heads, hd, dim)).reshape(n_rows * heads, dim)
         ctx = attend(qf.contiguous()).view(n_rows, heads, dim)
-        attended = torch.einsum("rhk,hdk->rhd", ctx, wv.view(heads, hd, dim)).reshape(n_rows, dim) + bv
-        return layer.layer_norm(rows + mha.out_proj(attended))
+        attended = torch.einsum("rhk,hdk->rhd", ctx.to(wv.dtype) if torch.is_autocast_enabled() else ctx, wv.view(heads, hd, dim)).reshape(n_rows, dim) + bv
+        return layer.layer_norm(rows + layer.dropout(mha.out_proj(attended)))
 
-    def _pooled_packed(self, text, valid_len, nodes_sorted, batch_sorted, slot, counts, starts, max_nodes, core):
-        """Inference path of `pooled` with no padding anywhere: packed query rows, ragged attention core.
-        `core(q, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale)` is ops.shared_kv_attention."""
+    def _pooled_packed(self, text, valid_len, nodes_sorted, batch_sorted, slot, counts, starts, max_nodes, core, autograd=False):
+        """`pooled` with no padding anywhere: packed query rows, ragged attention core.
+        `core(q, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale)` is ops.shared_kv_attention at inference; with
+        `autograd` every call goes through _RaggedAttentionFunction instead (HIP forward with the layer's attention dropout in
+        training mode + HIP backward)."""
         bsz, seq_len, dim = text.shape
         mha = self.model[0].multihead_attn
         heads, scale = mha.num_heads, mha.head_dim ** -0.5
         dev = text.device
+        if autograd:
+            def core(q, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale, _max_kv={}):      # noqa: E306
+                p = float(mha.dropout) if self.training else 0.0
+                seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0.0 else 0      # host RNG: no device sync
+                max_kv = max_nodes if kv is nodes_sorted else seq_len
+                return _RaggedAttentionFunction.apply(q, kv, q_start, q_len, kv_start, kv_len, max_q_len, max_kv, scale, p, seed)
         code = torch.arange(bsz, device=dev, dtype=torch.long)
         text_flat = text.reshape(bsz * seq_len, dim)
         # text side: the CLS row of every code queries that code's nodes
@@ -183,9 +213,12 @@ class CrossAttention(nn.Module):
         heads = self.model[0].multihead_attn.num_heads
         needs_grad = torch.is_grad_enabled() and (text.requires_grad or nodes.requires_grad
                                                   or any(p.requires_grad for p in self.parameters()))
-        kernel_ok = (not self.training and not needs_grad and (dim == 64 or (dim % 128 == 0 and dim <= 768))
-                     and text.dtype == torch.float32 and not torch.is_autocast_enabled() and max_nodes > 0
-                     and (core is not None or text.is_cuda))
+        shape_ok = (dim == 64 or (dim % 128 == 0 and dim <= 768)) and max_nodes > 0
+        train_path = self.training or needs_grad
+        # inference: fp32 inputs, no autocast (the 1e-5 parity path).  Training / autograd: the kernels are fp32 whatever the
+        # inputs' dtype or autocast says, and replace the padded torch form entirely (no B x rows x keys tensors, HIP backward).
+        kernel_ok = shape_ok and ((core is not None and not train_path) or text.is_cuda) and \
+            (train_path or (text.dtype == torch.float32 and not torch.is_autocast_enabled()))
         if fold is None:
             # flops: 4 n D^2 + 4 n H T D folded  vs  4 T D^2 + 4 n T D projected; where the ragged kernel can run the folded,
             # packed form wins regardless (D = 64, B = 1024: 1.1 vs 2.4 ms -- no padding, a fraction of the launches)
@@ -193,7 +226,7 @@ class CrossAttention(nn.Module):
         packed = fold and kernel_ok
         if packed:
             return self._pooled_packed(text.contiguous(), valid.sum(1), nodes[order].contiguous(), batch[order], slot, counts, starts,
-                                       max_nodes, core or ops.shared_kv_attention)
+                                       max_nodes, core or ops.shared_kv_attention, autograd=train_path and core is None)
 
         padded = text.new_zeros(bsz, max_nodes, text.shape[-1])
         padded[batch[order], slot] = nodes[order]

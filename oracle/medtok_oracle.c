@@ -383,6 +383,80 @@ int oracle_shared_kv_attention_f32(const float *q, const int64_t *q_start, const
     return 0;
 }
 
+/* The dropout mask of the training-mode attention core: a stateless 32-bit hash of (seed, packed query row, key of the code).
+ * Bit for bit the device function att_keep() (attention_kernels.h) -- the mask is part of the function being checked. */
+static int att_keep(uint32_t seed, int64_t qrow, int key, uint32_t thresh)
+{
+    uint32_t h = seed ^ ((uint32_t)qrow * 0x9E3779B1u) ^ ((uint32_t)((uint64_t)qrow >> 32) * 0x7F4A7C15u) ^ ((uint32_t)key * 0x85EBCA77u);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h >= thresh;
+}
+
+/* Training-mode attention core and its backward (nn.MultiheadAttention with dropout on the attention weights, reference :21,30,45,
+ * after the projections are folded into the queries): per code
+ *   P = softmax(scale Q KV^T), M = keep / (1 - p), O = (P o M) KV, lse = log sum exp(scale Q KV^T);
+ *   dQ = scale dS KV, dKV = (P o M)^T dO + scale dS^T Q with dS = P o ((dO KV^T) o M - <dO, O>).
+ * Double accumulation (tolerance checker).  dq / dkv / lse may be NULL (forward only when d_out is NULL). */
+int oracle_shared_kv_attention_train_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
+                                         const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int d, float scale,
+                                         float dropout_p, uint32_t seed, float *out, float *lse, const float *d_out, float *dq, float *dkv,
+                                         int64_t kv_rows)
+{
+    double t = (double)dropout_p * 4294967296.0;
+    const uint32_t thresh = dropout_p > 0.f ? (uint32_t)(t > 4294967295.0 ? 4294967295.0 : t) : 0u;
+    const double ks = dropout_p > 0.f ? (double)(1.f / (1.f - dropout_p)) : 1.0;
+    if (d_out && dkv) memset(dkv, 0, sizeof(float) * (size_t)kv_rows * d);
+    for (int64_t b = 0; b < n_codes; ++b) {
+        const int64_t kl = kv_len[b], k0 = kv_start[b];
+        double *p = (double *)malloc(sizeof(double) * (kl > 0 ? kl : 1));
+        double *acc_kv = d_out && dkv ? (double *)calloc((size_t)(kl > 0 ? kl : 1) * d, sizeof(double)) : NULL;
+        for (int64_t r = q_start[b]; r < q_start[b] + q_len[b]; ++r) {
+            double m = -INFINITY, l = 0.0;
+            for (int64_t j = 0; j < kl; ++j) {
+                double a = 0.0;
+                for (int i = 0; i < d; ++i) a += (double)q[r * d + i] * kv[(k0 + j) * d + i];
+                p[j] = a * scale;
+                if (p[j] > m) m = p[j];
+            }
+            for (int64_t j = 0; j < kl; ++j) { p[j] = exp(p[j] - m); l += p[j]; }
+            for (int64_t j = 0; j < kl; ++j) p[j] /= l;
+            if (lse) lse[r] = kl > 0 ? (float)(m + log(l)) : -INFINITY;
+            for (int i = 0; i < d; ++i) {
+                double a = 0.0;
+                for (int64_t j = 0; j < kl; ++j)
+                    if (!thresh || att_keep(seed, r, (int)j, thresh)) a += p[j] * ks * kv[(k0 + j) * d + i];
+                out[r * d + i] = kl > 0 ? (float)a : 0.0f;
+            }
+            if (!d_out) continue;
+            double delta = 0.0;
+            for (int i = 0; i < d; ++i) delta += (double)d_out[r * d + i] * out[r * d + i];
+            for (int i = 0; i < d && dq; ++i) dq[r * d + i] = 0.0f;
+            double *dqa = (double *)calloc(d, sizeof(double));
+            for (int64_t j = 0; j < kl; ++j) {
+                const int keep = !thresh || att_keep(seed, r, (int)j, thresh);
+                double dp = 0.0;
+                for (int i = 0; i < d; ++i) dp += (double)d_out[r * d + i] * kv[(k0 + j) * d + i];
+                dp = keep ? dp * ks : 0.0;
+                const double ds = p[j] * (dp - delta) * scale;
+                const double pm = keep ? p[j] * ks : 0.0;
+                for (int i = 0; i < d; ++i) {
+                    dqa[i] += ds * kv[(k0 + j) * d + i];
+                    if (acc_kv) acc_kv[j * d + i] += pm * d_out[r * d + i] + ds * q[r * d + i];
+                }
+            }
+            if (dq) for (int i = 0; i < d; ++i) dq[r * d + i] = (float)dqa[i];
+            free(dqa);
+        }
+        if (acc_kv) {
+            for (int64_t j = 0; j < kl; ++j)
+                for (int i = 0; i < d; ++i) dkv[(k0 + j) * d + i] = (float)acc_kv[j * d + i];
+            free(acc_kv);
+        }
+        free(p);
+    }
+    return 0;
+}
+
 /* EMA statistics (norm_ema_quantizer.py:194,202): bins[c] = #rows assigned to
  * c; embed_sum[c][:] = sum of those rows of zhat, added in increasing row
  * order (layout [K,D]; the reference's [D,K] is its transpose). */

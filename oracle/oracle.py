@@ -173,6 +173,23 @@ def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, scale):
     return out
 
 
+def shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, scale, dropout_p=0.0, seed=0, d_out=None):
+    """Training-mode attention core: (out, lse) or, with d_out, (out, lse, dq, dkv) -- dropout by the stateless hash mask
+    (vector_quantization_soft_one_new.py:21,30,45 after folding the projections; autograd of the same)."""
+    q, qp = _f(q); kv, kp = _f(kv)
+    qs, qsp = _i(q_start); ql, qlp = _i(q_len); ks, ksp = _i(kv_start); kl, klp = _i(kv_len)
+    out = np.zeros_like(q); lse = np.full(q.shape[0], -np.inf, np.float32)
+    dq = np.zeros_like(q) if d_out is not None else None
+    dkv = np.zeros_like(kv) if d_out is not None else None
+    dop = _f(d_out)[1] if d_out is not None else None
+    rc = lib().oracle_shared_kv_attention_train_f32(qp, qsp, qlp, kp, ksp, klp, C.c_int64(len(qs)), q.shape[1], C.c_float(scale),
+                                                    C.c_float(dropout_p), C.c_uint32(seed), out.ctypes.data_as(_f32p), lse.ctypes.data_as(_f32p),
+                                                    dop, None if dq is None else dq.ctypes.data_as(_f32p),
+                                                    None if dkv is None else dkv.ctypes.data_as(_f32p), C.c_int64(kv.shape[0]))
+    assert rc == 0
+    return (out, lse) if d_out is None else (out, lse, dq, dkv)
+
+
 def row_dot(a, b):
     """<a[r], b[r]> per row (the summand of alignment_loss, loss.py:63)."""
     a, ap = _f(a); b, bp = _f(b)

@@ -251,3 +251,42 @@ def test_shared_kv_attention_rejects_bad_shapes(dev):
     z = torch.zeros(1, dtype=torch.int64, device=dev)
     with pytest.raises(MedTokLibraryError):
         ops.shared_kv_attention(torch.zeros(4, 96, device=dev), z, z + 4, torch.zeros(4, 96, device=dev), z, z + 4, 4, 1.0)
+
+
+@pytest.mark.parametrize("d,p", [(64, 0.0), (128, 0.1), (768, 0.1), (256, 0.5), (384, 0.0)])
+def test_attention_train_forward_and_backward_match_oracle(oracle, dev, d, p):
+    """Training-mode ragged attention core (dropout by the stateless hash mask, log-sum-exp) and its backward (dQ / dKV kernels)
+    vs the C oracle -- itself pinned to torch autograd (tests/test_oracle_golden.py).  Ragged codes incl. one without keys, one
+    without queries, lengths that are not multiples of the 32-row tiles; rows of dq / dkv that belong to no code must be zero."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(d + int(100 * p))
+    q_len = np.array([40, 7, 0, 64, 33, 5], np.int64); kv_len = np.array([50, 33, 12, 100, 0, 1], np.int64)
+    slot_kv = kv_len + np.array([0, 3, 0, 0, 4, 0])                      # some codes' key slots are longer than their valid keys
+    q_start, kv_start = np.cumsum(q_len) - q_len, np.cumsum(slot_kv) - slot_kv
+    nq, nk = int(q_len.sum()) + 2, int(slot_kv.sum())                    # + two query rows that belong to no code
+    q = (rng.standard_normal((nq, d)) * 0.3).astype(np.float32); kv = rng.standard_normal((nk, d)).astype(np.float32)
+    d_out = rng.standard_normal((nq, d)).astype(np.float32)
+    scale, seed = 0.2, 99
+    T = lambda a: torch.from_numpy(a).to(dev)
+    args = (T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len))
+    out, lse = ops.shared_kv_attention_train(*args, int(q_len.max()), scale, p, seed)
+    out_o, lse_o, dq_o, dkv_o = oracle.shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, scale, p, seed, d_out)
+    assert np.abs(out.cpu().numpy() - out_o).max() <= 1e-5 * np.abs(out_o).max()
+    own = np.zeros(nq, bool)
+    for b in range(len(q_len)):
+        own[q_start[b]: q_start[b] + q_len[b]] = True
+    fin = own & np.isfinite(lse_o)
+    assert np.allclose(lse.cpu().numpy()[fin], lse_o[fin], rtol=1e-5, atol=1e-5) and np.isinf(lse.cpu().numpy()[own & ~fin]).all()
+    if p == 0.0:                                                          # no dropout: the inference kernel's output
+        plain = ops.shared_kv_attention(*args, int(q_len.max()), scale)
+        assert torch.equal(plain[T(own)], out[T(own)])
+    dq, dkv = ops.shared_kv_attention_backward(*args, int(q_len.max()), int(kv_len.max()), scale, p, seed, out, lse, T(d_out))
+    assert np.abs(dq.cpu().numpy() - dq_o).max() <= 1e-5 * np.abs(dq_o).max()
+    assert np.abs(dkv.cpu().numpy() - dkv_o).max() <= 1e-5 * np.abs(dkv_o).max()
+    assert not dq.cpu().numpy()[~own].any()
+    # deterministic: same seed, same bits; another seed, another mask
+    out2, _ = ops.shared_kv_attention_train(*args, int(q_len.max()), scale, p, seed)
+    assert torch.equal(out2, out)
+    if p > 0:
+        out3, _ = ops.shared_kv_attention_train(*args, int(q_len.max()), scale, p, seed + 1)
+        assert not torch.equal(out3, out)

@@ -168,3 +168,42 @@ def test_info_nce_matches_reference(oracle, golden, name):
     assert abs(loss - float(g["loss"])) <= RTOL * abs(float(g["loss"]))
     assert rel(gq, g["grad_q"]) <= 2e-5
     assert rel(gk, g["grad_k"]) <= 2e-5
+
+
+def test_oracle_attention_backward_matches_torch_autograd(oracle):
+    import torch
+    """The oracle's training-mode attention core (dropout by the stateless hash mask) and its backward against torch autograd of the
+    dense formula.  The mask is data-independent, so it is read off the oracle itself with one-hot keys and zero queries
+    (uniform probabilities: out[r, j] = M[r, j] / ((1 - p) n_keys))."""
+    rng = np.random.default_rng(3)
+    d, p, seed, scale = 16, 0.25, 1234, 0.4
+    q_len = np.array([5, 0, 7], np.int64); kv_len = np.array([6, 3, 9], np.int64)
+    q_start, kv_start = np.cumsum(q_len) - q_len, np.cumsum(kv_len) - kv_len
+    nq, nk = int(q_len.sum()), int(kv_len.sum())
+    # the mask
+    kv_hot = np.zeros((nk, d), np.float32)
+    for b in range(3):
+        for j in range(kv_len[b]):
+            kv_hot[kv_start[b] + j, j] = 1.0
+    out_hot, _ = oracle.shared_kv_attention_train(np.zeros((nq, d), np.float32), q_start, q_len, kv_hot, kv_start, kv_len, scale, p, seed)
+    q = rng.standard_normal((nq, d)).astype(np.float32); kv = rng.standard_normal((nk, d)).astype(np.float32)
+    d_out = rng.standard_normal((nq, d)).astype(np.float32)
+    out, lse, dq, dkv = oracle.shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, scale, p, seed, d_out)
+    qt, kt = torch.from_numpy(q).double().requires_grad_(True), torch.from_numpy(kv).double().requires_grad_(True)
+    outs = []
+    kept = 0
+    for b in range(3):
+        if q_len[b] == 0:
+            continue
+        qs, ks, n = int(q_start[b]), int(kv_start[b]), int(kv_len[b])
+        mask = torch.from_numpy(out_hot[qs: qs + q_len[b], :n] > 0).double() / (1.0 - np.float32(p))
+        kept += int((mask > 0).sum())
+        s = scale * qt[qs: qs + q_len[b]] @ kt[ks: ks + n].t()
+        outs.append((torch.softmax(s, -1) * mask) @ kt[ks: ks + n])
+        assert np.allclose(lse[qs: qs + q_len[b]], torch.logsumexp(s, -1).detach().numpy(), rtol=1e-5, atol=1e-6)
+    ref = torch.cat(outs)
+    assert 0.6 < kept / float((q_len * kv_len).sum()) < 0.9            # P(keep) = 0.75
+    ref.backward(torch.from_numpy(d_out).double())
+    assert np.abs(out - ref.detach().numpy()).max() <= 1e-5
+    assert np.abs(dq - qt.grad.numpy()).max() <= 1e-5 * np.abs(qt.grad.numpy()).max()
+    assert np.abs(dkv - kt.grad.numpy()).max() <= 1e-5 * np.abs(kt.grad.numpy()).max()
