@@ -103,11 +103,11 @@ int medtok_debug_filter_scores_f32(const float *xhat, const float *xsq, int64_t 
 size_t medtok_debug_filter_fallback_count_offset(int64_t n, int64_t k_codes, int d, int topk, int path);
 
 /* Test hook: force plan branches the default heuristics only take at very large shapes (code-range splits, the XCD-aware
- * block order, the tail launch, the staggered epilogue of the filter kernel; the split cap of the exact kernel), so that
+ * block order, the tail launch; the split cap of the exact kernel), so that
  * small parity tests cover them.  Process-wide; -1 restores the default for that field.  The product path never reads
  * environment variables.  Results are bit-identical under every plan (tests/test_gpu_filter.py). */
 int medtok_debug_plan_override(int64_t filter_splits, int64_t filter_xcd, int64_t filter_tail_min_blocks,
-                               int64_t search_max_splits, int64_t filter_stagger);
+                               int64_t search_max_splits);
 
 /* Soft assignment: w = softmax(-dist), zq = sum_j w_j * what[idx_j],
  * zq_ste = xref + (zq - xref), row_sqerr[r] = sum_i (zq - xref)^2.

@@ -37,7 +37,8 @@ constexpr int F_STAGEB = 2 * F_TILEB;                         // A + B = 32 KB
 constexpr int F_RING = 4;                                     // stages in the LDS ring: 3 in flight while 1 is computed on
 constexpr size_t F_LDS_BYTES = (size_t)F_RING * F_STAGEB;     // 128 KB -> 1 block (8 waves) / CU
 constexpr size_t F_THR_BYTES = 256 * 64;                      // per row: the k <= 5 smallest d~ of each code-side wave pair (2 x 32 B)
-constexpr size_t F_SMEM_BYTES = F_LDS_BYTES + F_THR_BYTES;    // 144 KB
+constexpr size_t F_INIT_BYTES = 2 * 256 * 4;                  // the accumulator start values (-2^15 |e|^2) of two code tiles
+constexpr size_t F_SMEM_BYTES = F_LDS_BYTES + F_THR_BYTES + F_INIT_BYTES;    // 146 KB
 constexpr int F_GLDS_PER_STAGE = 4;                           // LDS-DMA instructions each wave issues per stage
 #ifndef MEDTOK_FILTER_CAP
 #define MEDTOK_FILTER_CAP 48
@@ -159,8 +160,10 @@ struct FilterRow {
     float tv[TOPK];       // sorted ascending
     float L;              // a value passes when acc >= L  (<=> u <= t + win)
     float xn, win;        // |x|^2; 2 eps (-inf for padding rows: their limit stays +inf and nothing is ever appended)
-    int cnt;              // appended candidates (global list)
-    uint2 *list;          // this lane's candidate list of the row
+    // The lane's candidate list of the row, as byte offsets from a wave-uniform base (SGPR base + 32-bit offset stores, no 64-bit
+    // address arithmetic per hit).  pos counts every hit; a hit beyond the capacity overwrites the LAST slot (store offset =
+    // min(pos, endm8)), which is harmless: a list with more than F_CAP hits sends its row to the exact kernel anyway.
+    unsigned pos, endm8;  // next slot; last slot
     unsigned lst;         // LDS byte address of the row's shared k-lists: [2 code-side waves][8 floats, 5 used]
 };
 constexpr int F_LST_ROWB = 64;        // bytes per row of the shared k-lists (two 32-byte halves: 16-byte aligned b128 reads)
@@ -199,31 +202,142 @@ __device__ __forceinline__ float other_half(float v, int lh)
     return __uint_as_float(lh ? r[0] : r[1]);
 }
 
-// The scan of one finished accumulator tile: four values per test (a 4-way max and ONE compare); only a quad that holds a
-// passing value in some lane is scanned value by value.  A hit is rare per lane but not per wave (64 lanes x 4 values at
-// p ~ 3e-3: half the quads): it is appended to the lane's candidate list and, unless the warm-up pass has counted it already,
-// folded into the lane's k-smallest list right there.  cb = the lane's first code of this 32-code group.
-// (Round 1 parked hits in LDS and flushed them once per 128 values, when a scan held many of them; with 16 values per scan
-// and row the parking only added LDS round trips -- each behind a drain of the DMA ring, see above.)
+// Single-instruction helpers for the scan: fmaxf / fminf on MFMA results make hipcc put a canonicalising v_max in front of each
+// of them, and plain -O3 packs neighbouring f32 operations into v_pk_* (slower beside MFMAs).
+__device__ __forceinline__ float v_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float v_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float v_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+__device__ __forceinline__ float v_med3(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// sorted insert without a dependent chain: t_j' = med3(t_{j-1}, t_j, v) (t_{j-1} <= t_j), t_0' = min(t_0, v); v must not be NaN
+template <int T>
+__device__ __forceinline__ void thr_insert_med3(float (&tv)[T], float v)
+{
+#pragma unroll
+    for (int j = T - 1; j >= 1; --j) tv[j] = v_med3(tv[j - 1], tv[j], v);
+    tv[0] = v_min(tv[0], v);
+}
+
+// One candidate: the score in ACCUMULATOR scale (acc = -2^15 u; the re-score kernel converts: d~ = fma(acc, -2^-15, |x|^2), the
+// same bits as rounding u + |x|^2) and the code.
+__device__ __forceinline__ void filter_append(unsigned &pos, unsigned endm8, const char *cbase, float v, unsigned code)
+{
+    *reinterpret_cast<uint2 *>(const_cast<char *>(cbase) + min(pos, endm8)) = make_uint2(__float_as_uint(v), code);
+    pos += 8;
+}
+
+// The hit path of the scan as ONE straight-line, exec-masked instruction sequence (about 28 instructions; the compiler's
+// version of the same logic is 60-70 with four nested branches, and every instruction of it is exposed: while a wave scans,
+// its SIMD has no matrix work).  For the lanes whose quad maximum passes: find its position (three compares), append
+// (acc, code) with two SGPR-base stores, fold u = -2^-15 acc into the sorted k-list with independent v_med3
+// (t_j' = med3(t_{j-1}, t_j, u): no dependent chain), and note in `multi` whether the quad's SECOND largest value passes as well
+// (p ~ 4e-5 per lane and quad on random data): the tile is then revisited by filter_scan_rest.  L is not moved here: the
+// merge at the end of the code tile recomputes it from the lists.
+#define F_HIT_HEAD                                                                       \
+    "v_cmp_ge_f32 vcc, %[mx], %[L]\n\t"                                                  \
+    "s_and_saveexec_b64 %[sv], vcc\n\t"                                                  \
+    "v_cmp_eq_f32 vcc, %[a2], %[mx]\n\t"                                                 \
+    "v_cndmask_b32_e64 %[j], 3, 2, vcc\n\t"                                              \
+    "v_cmp_eq_f32 vcc, %[a1], %[mx]\n\t"                                                 \
+    "v_cndmask_b32_e64 %[j], %[j], 1, vcc\n\t"                                           \
+    "v_cmp_eq_f32 vcc, %[a0], %[mx]\n\t"                                                 \
+    "v_cndmask_b32_e64 %[j], %[j], 0, vcc\n\t"                                           \
+    "v_max_f32 %[p], %[a0], %[a1]\n\t"                                                   \
+    "v_max_f32 %[q], %[a2], %[a3]\n\t"                                                   \
+    "v_min_f32 %[p], %[p], %[q]\n\t"                                                     \
+    "v_min_f32 %[q], %[a0], %[a1]\n\t"                                                   \
+    "v_min_f32 %[u], %[a2], %[a3]\n\t"                                                   \
+    "v_max3_f32 %[p], %[p], %[q], %[u]\n\t"                                              \
+    "v_cmp_ge_f32 vcc, %[p], %[L]\n\t"                                                   \
+    "s_or_b64 %[multi], %[multi], vcc\n\t"                                               \
+    "v_mul_f32 %[u], 0xb8000000, %[mx]\n\t"                                              \
+    "v_add_u32 %[j], %[j], %[cbg]\n\t"                                                   \
+    "v_min_u32 %[q], %[pos], %[endm8]\n\t"                                               \
+    "global_store_dword %[q], %[mx], %[base]\n\t"                                        \
+    "global_store_dword %[q], %[j], %[base] offset:4\n\t"                                \
+    "v_add_u32 %[pos], 8, %[pos]\n\t"
+#define F_HIT_TAIL "s_mov_b64 exec, %[sv]"
+#define F_HIT_OUT(r) [pos] "+v"(r.pos), [multi] "+s"(multi), [sv] "=&s"(sv), [j] "=&v"(j), [p] "=&v"(p), [q] "=&v"(q), [u] "=&v"(u)
+#define F_HIT_IN(r) [mx] "v"(mx), [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [L] "v"(r.L), [cbg] "v"(cbg), [endm8] "v"(r.endm8), [base] "s"(cbase)
 template <int TOPK>
-__device__ __forceinline__ void filter_scan(FilterRow<TOPK> &r, const f32x16 &a, int cb, bool counted)
+__device__ __forceinline__ void filter_hit(FilterRow<TOPK> &r, float a0, float a1, float a2, float a3, float mx, int cbg, const char *cbase,
+                                           unsigned long &multi)
+{
+    unsigned long sv;
+    unsigned j;
+    float p, q, u;
+    if constexpr (TOPK == 1) {
+        asm volatile(F_HIT_HEAD "v_min_f32 %[t0], %[t0], %[u]\n\t" F_HIT_TAIL
+                     : F_HIT_OUT(r), [t0] "+v"(r.tv[0]) : F_HIT_IN(r) : "vcc");
+    } else if constexpr (TOPK == 5) {
+        asm volatile(F_HIT_HEAD
+                     "v_med3_f32 %[t4], %[t3], %[t4], %[u]\n\t"
+                     "v_med3_f32 %[t3], %[t2], %[t3], %[u]\n\t"
+                     "v_med3_f32 %[t2], %[t1], %[t2], %[u]\n\t"
+                     "v_med3_f32 %[t1], %[t0], %[t1], %[u]\n\t"
+                     "v_min_f32 %[t0], %[t0], %[u]\n\t" F_HIT_TAIL
+                     : F_HIT_OUT(r), [t0] "+v"(r.tv[0]), [t1] "+v"(r.tv[1]), [t2] "+v"(r.tv[2]), [t3] "+v"(r.tv[3]), [t4] "+v"(r.tv[4])
+                     : F_HIT_IN(r) : "vcc");
+    } else {
+        static_assert(TOPK == 8, "k-lists of 1, 5 or 8");
+        asm volatile(F_HIT_HEAD
+                     "v_med3_f32 %[t7], %[t6], %[t7], %[u]\n\t"
+                     "v_med3_f32 %[t6], %[t5], %[t6], %[u]\n\t"
+                     "v_med3_f32 %[t5], %[t4], %[t5], %[u]\n\t"
+                     "v_med3_f32 %[t4], %[t3], %[t4], %[u]\n\t"
+                     "v_med3_f32 %[t3], %[t2], %[t3], %[u]\n\t"
+                     "v_med3_f32 %[t2], %[t1], %[t2], %[u]\n\t"
+                     "v_med3_f32 %[t1], %[t0], %[t1], %[u]\n\t"
+                     "v_min_f32 %[t0], %[t0], %[u]\n\t" F_HIT_TAIL
+                     : F_HIT_OUT(r), [t0] "+v"(r.tv[0]), [t1] "+v"(r.tv[1]), [t2] "+v"(r.tv[2]), [t3] "+v"(r.tv[3]), [t4] "+v"(r.tv[4]),
+                       [t5] "+v"(r.tv[5]), [t6] "+v"(r.tv[6]), [t7] "+v"(r.tv[7])
+                     : F_HIT_IN(r) : "vcc");
+    }
+}
+#undef F_HIT_HEAD
+#undef F_HIT_TAIL
+#undef F_HIT_OUT
+#undef F_HIT_IN
+
+// The scan of one finished accumulator tile: four values per test (a 4-way max and ONE compare, wave-uniform branch); only a
+// quad that holds a passing value in some lane -- rare per lane, but 64 lanes x 4 values at p ~ 3e-3 is half the quads --
+// runs the hit sequence above.  cb = the lane's first code of this 32-code group.
+// (Round 1 parked hits in LDS and flushed them once per 128 values; with 16 values per scan and row the parking only added
+// LDS round trips -- each behind a drain of the DMA ring, see above.)
+template <int TOPK>
+__device__ __forceinline__ void filter_scan(FilterRow<TOPK> &r, const f32x16 &a, int cb, const char *cbase, unsigned long &multi)
 {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const float a0 = a[4 * g], a1 = a[4 * g + 1], a2 = a[4 * g + 2], a3 = a[4 * g + 3];
-        const float mx = fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+        const float mx = v_max(v_max3(a0, a1, a2), a3);
+#ifndef MEDTOK_FILTER_NOHIT       // dev experiment: the tests alone
+        if (__builtin_amdgcn_ballot_w64(mx >= r.L)) filter_hit<TOPK>(r, a0, a1, a2, a3, mx, cb + 8 * g, cbase, multi);
+#else
+        if (__builtin_amdgcn_ballot_w64(mx >= r.L)) asm volatile("s_nop 0");
+#endif
+    }
+}
+
+// Everything of a tile that passes and is NOT its quad's maximum (first position holding it) -- the revisit after `multi`.
+// With INSERT = false: ALL passing values, appended but not folded into the k-list -- the warm-up tile, whose values the
+// lists have seen already.  Plain divergent code: rare (multi) or once per block (warm-up).
+template <int TOPK, bool INSERT>
+__device__ __forceinline__ void filter_scan_rest(FilterRow<TOPK> &r, const f32x16 &a, int cb, const char *cbase)
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float a0 = a[4 * g], a1 = a[4 * g + 1], a2 = a[4 * g + 2], a3 = a[4 * g + 3];
+        const float mx = v_max(v_max3(a0, a1, a2), a3);
         if (mx >= r.L) {
-            // Somewhere in the wave a value of this quad passes.  Each lane walks its own hits, lowest register first -- nearly
-            // always one lane with one hit, i.e. ONE pass of the body below instead of four exec-masked copies of it.
-            bool h0 = a0 >= r.L, h1 = a1 >= r.L, h2 = a2 >= r.L, h3 = a3 >= r.L;
-            while (h0 || h1 || h2 || h3) {
-                const float v = h0 ? a0 : h1 ? a1 : h2 ? a2 : a3;
-                const int j = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
-                h3 = h3 && (h0 || h1 || h2); h2 = h2 && (h0 || h1); h1 = h1 && h0; h0 = false;
-                const float u = v * -0x1p-15f;
-                if (r.cnt < F_CAP) r.list[r.cnt] = make_uint2(__float_as_uint(u + r.xn), (unsigned)(cb + j + 8 * g));
-                ++r.cnt;
-                if (!counted) thr_insert_bf<TOPK>(r.tv, u);
+            const int jm = !INSERT ? -1 : (a0 == mx ? 0 : a1 == mx ? 1 : a2 == mx ? 2 : 3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = j == 0 ? a0 : j == 1 ? a1 : j == 2 ? a2 : a3;
+                if (j != jm && v >= r.L) {
+                    filter_append(r.pos, r.endm8, cbase, v, (unsigned)(cb + j + 8 * g));
+                    if (INSERT) thr_insert_bf<TOPK>(r.tv, v * -0x1p-15f);
+                }
             }
         }
     }
@@ -300,6 +414,22 @@ __device__ __forceinline__ void filter_init_group(f32x16 &a0, f32x16 &a1, const 
     }
 }
 
+// The same from LDS (the block keeps the start values of the next code tile there, see the kernel): four ds_read_b128 straight
+// into the accumulator registers, no VALU.  asm for the reason given above lds_store_list; the caller waits (lds_init_wait).
+__device__ __forceinline__ f32x16 lds_init_issue(unsigned addr)
+{
+    f32x4 q0, q1, q2, q3;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(addr));
+    const auto lo = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+}
+// (only the first row tile's registers are loaded: see `step` in the kernel)
+__device__ __forceinline__ void lds_init_wait(f32x16 (&a)[4][2])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(a[2][0]), "+v"(a[3][0]));
+}
+
 // ---------------------------------------------------------------- the filter kernel
 // (Rejected variant, measured 14-24 % slower: 4-wave blocks of 256 codes x 128 rows, two per CU, hoping that co-resident
 // blocks drifting apart overlap one block's epilogue / DMA issue with the other's MFMAs -- it moves 1.5 x the L2 -> LDS
@@ -316,25 +446,24 @@ __device__ __forceinline__ void filter_init_group(f32x16 &a0, f32x16 &a1, const 
 // Scores in accumulator scale.  wsqs[c] = -2^15 |e_c|^2 (padded with -inf to a multiple of 256).  A code group's
 // accumulators START at that value instead of 0, so that after the k loop   acc = 2^16 s~ - 2^15 |e|^2 = -2^15 u,
 // u = |e|^2 - 2 s~ = d~ - |x|^2:  the epilogue tests  acc >= L  (L = -2^15 * limit, per lane) with no arithmetic per
-// value, and |e|^2 is read once per group and tile through the SCALAR cache (the 32 values are wave-uniform; a lane
-// picks by its half) -- a vector load here would wait for vmcnt(0), i.e. drain the whole LDS-DMA ring, every time.
+// value.  The start values reach the lanes through LDS: wave 0 DMA-copies the 256 values of code tile t+2 (1 KB, one
+// instruction) into one of two 1 KB buffers during the scan of tile t, and a group restarts with eight ds_read_b128 straight
+// into its accumulator registers.  (A vector load here would wait for vmcnt(0), i.e. drain the whole LDS-DMA ring, every
+// time; round 2's first form read them through the scalar cache and selected per half-wave -- 2 scalar loads with their
+// latency plus 56 VALU instructions per group, measured 1.1 ms of a 15 ms launch, 40 % of the whole scan phase.)
 //
-// Staggered epilogue (STAG).  The scan of a finished code tile is VALU work; if both waves of a SIMD do it at the same
-// time the matrix pipe has nothing to issue (measured: 26 % of the kernel).  The order in which a dot product visits
-// its k16 half steps is free, and the x tile's k blocks recur with period nkb, so a 32-code group may switch to its next
-// code tile at ANY half step: group g' = 2 m + wm (m = group within the wave, wm = code-side wave) does so in the MIDDLE of
-// the stage that lies r = g' nkb / 8 + 1 stages into the cycle -- after the first half step's MFMAs and the barrier, before
-// the second half step's.  The eight groups of a SIMD's wave pair then finish one at a time, alternating between the two
-// waves, every nkb/8 stages, and while one wave scans (a quarter of its accumulators) its partner has the 16 MFMAs up to
-// the next barrier to issue.  For the DMA this means that the staged A rows of such a stage hold the OLD code tile in their
-// first two 16-byte chunks (k16 step 0) and the NEW one in the last two: one masked add on the per-lane source offset.
-// Cost: after the first code tile (scanned by all groups at once, which also teaches every list its threshold before
-// anything is appended) group g' idles r - 1/2 stages, and the block runs 7 nkb / 8 + 1 extra stages at the end -- about
-// 7/16 of a code tile per block, so staggering is used only when a block has >= 12 code tiles.
-__device__ __forceinline__ int filter_rot(int gp, int nkb) { return ((gp * nkb) >> 3) + 1; }
-constexpr int F_STAG_MIN_NKB = 16, F_STAG_MIN_TILES = 12;      // (a switch takes two stages: the SIMD partner's must not overlap it)
-
-template <int TOPK, bool DUMP, bool STAG>
+// Staggered epilogues -- built twice, measured, removed.  The scan of a finished code tile is VALU work, and while both waves
+// of a SIMD scan the matrix pipe idles (about 20 % of the kernel).  Because the k16 half steps of a dot product may be visited
+// in any order and the x tile's k blocks recur, each 32-code group can switch code tiles in the middle of a different stage
+// (the DMA then feeds the two halves of that stage's code rows from two code tiles), so that a SIMD's two waves never scan at
+// the same time.  (a) Round 2, first form: the group's scan (the branchy one) in the middle of its switch stage: bit-identical,
+// 11-13 % SLOWER (K = 16384: 17.5 vs 15.5 ms).  (b) Second form: the hand-off through the MFMA destination (last MFMAs of the
+// tile write D != C, first MFMAs of the next read the start values as C: no copies) and a fully branch-free, exec-masked scan
+// of 8 quads woven between the next two stages' MFMAs (vmcnt(12) for the stage wait): 17.95 ms.  Both for the same reason: the
+// ring has ONE block-wide barrier per stage, so whatever one wave does beyond its MFMAs in a stage is added to that stage for
+// all eight -- about +990 cycles per scanning stage for ~140 extra instructions, in 16 of 24 stages, against one exposed scan
+// per tile.  What pays instead is making that one scan short (filter_hit above).
+template <int TOPK, bool DUMP>
 __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     const _Float16 *__restrict__ xh, const _Float16 *__restrict__ wh, const float *__restrict__ xsq,
     const float *__restrict__ wsqs, const float *__restrict__ en_max_ptr, long n, int k_codes, int dp, int d,
@@ -368,8 +497,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     const int code_hi = min(k_codes, code_lo + codes_per_split);
     const int nct = (code_hi - code_lo + F_BM - 1) / F_BM;
     const int nkb = dp / F_BK;
-    constexpr bool stag = STAG;              // (the host launches this instantiation only for blocks of >= F_STAG_MIN_TILES code tiles)
-    const int nstage = nct * nkb + (stag ? filter_rot(7, nkb) + 1 : 0);      // (+1: the second part of the last group's last scan)
+    const int nstage = nct * nkb;
 
     // ---- staging: wave w DMA-copies tile rows [32w, 32w+32) of A (= code group w of the tile) and of B, 16 rows (of
     // 64 B) per instruction.  The per-lane part of the source address is a loop-invariant 32-bit offset; everything that
@@ -385,14 +513,8 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     const char *wbase = reinterpret_cast<const char *>(wh) + (long)code_lo * dp * 2;
     const char *xbase = reinterpret_cast<const char *>(xh) + row0 * dp * 2;
     const int wave_lds = wave_s * 32 * F_ROWB;
-    // Source code tile of the group this wave stages (group w): tile 0 for the first nkb stages; tile 1 from there up to the
-    // group's first mid-stage switch B_2 = 2 nkb + r - 1, where chunks 0-1 still come from tile 1 and chunks 2-3 from tile 2; etc.
-    const int r_src = stag ? filter_rot(2 * (wave_s % F_MT) + wave_s / F_MT, nkb) : 0;
-    // all ones for lanes that feed chunks 2-3 (k16 step 1); the same for both instructions (rows 16 apart share the swizzle term)
-    const unsigned hi_half = ((s_c ^ ((s_r >> 2) & 3)) >> 1) ? 0xffffffffu : 0u;
     const int tile_bytes = F_BM * dp * 2;
-    int pkb = 0, pidx = 0, ptile = 0;                   // next stage to issue: k block, linear index, source code tile (of chunks 0-1)
-    int ptleft = nkb;                                   // stages until the source tile changes
+    int pkb = 0, pidx = 0, ptile = 0;                   // next stage to issue: k block, linear index, code tile
     // Issues stage `pidx` into ring slot pidx % 4 and advances -- except past the end, where it re-issues the
     // LAST stage into the slot that already holds it (same bytes, harmless) so the steady-state loop body has
     // no branch around its DMA and one instruction schedule fits every iteration.
@@ -405,14 +527,10 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         // readfirstlane: hipcc otherwise keeps the stage counters in VGPRs and wraps every buffer load in a waterfall loop
         const int ua = __builtin_amdgcn_readfirstlane(ptile * tile_bytes + pkb * F_BK * 2);    // a code split's fp16 image is < 2 GB
         const int ub = __builtin_amdgcn_readfirstlane(pkb * F_BK * 2);
-        // a mid-stage switch (staggered groups, from their second real tile on): chunks 2-3 already come from the next tile
-        const bool split_stage = stag && ptile >= 1 && ptleft == 1 && ptile + 1 < nct;
-        const int bump = __builtin_amdgcn_readfirstlane(split_stage ? tile_bytes : 0);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int va = STAG ? (int)(lane_off[q] + (hi_half & (unsigned)bump)) : (int)lane_off[q];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(base + q * 16 * F_ROWB), 16,
-                                                     va, ua, 0, 0);
+                                                     (int)lane_off[q], ua, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(base + F_TILEB + q * 16 * F_ROWB), 16,
                                                      (int)lane_off[q], ub, 0, 0);
         }
@@ -420,30 +538,43 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         const bool wrap = pkb + 1 == nkb;
         pidx += more ? 1 : 0;
         pkb = more ? (wrap ? 0 : pkb + 1) : pkb;
-        // tile 0 lasts nkb stages; tile 1 (chunks 0-1) r_src + nkb: the idle window, then its real stages up to and including
-        // the split stage; every later tile nkb
-        const bool step = more && ptleft == 1;
-        ptleft = more ? (step ? (ptile == 0 ? nkb + r_src : nkb) : ptleft - 1) : ptleft;
-        ptile = step ? min(ptile + 1, nct - 1) : ptile;
+        ptile += (more && wrap) ? 1 : 0;
     };
+
+    // start values of code tile `tile` -> LDS buffer tile & 1 (wave 0; an ordinary member of its in-order DMA stream)
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(wsqs + code_lo), 0, -1, 0x00020000);
+    auto stage_init = [&](int tile) __attribute__((always_inline)) {
+        if (wave_s == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (__attribute__((address_space(3))) void *)(fsm + F_LDS_BYTES + F_THR_BYTES + (tile & 1) * (F_BM * 4)),
+                                                     16, lane * 16, __builtin_amdgcn_readfirstlane(min(tile, nct - 1) * (F_BM * 4)), 0, 0);
+    };
+    // the lane's 16 start values of group M: codes wm 128 + M 32 + 8 g + 4 lh + {0..3}, g = 0..3
+    const unsigned init_adr = (unsigned)(size_t)(fsm + F_LDS_BYTES + F_THR_BYTES) + (unsigned)(wm * (32 * F_MT) + 4 * lh) * 4u;
+#define F_INIT_LDS(M, tile) \
+    do { acc[M][0] = lds_init_issue(init_adr + (unsigned)(((tile) & 1) * (F_BM * 4) + (M) * 128)); } while (0)
 
     // ---- per-lane state: one FilterRow for each of the wave's two 32-row column tiles
     float *thr_share = reinterpret_cast<float *>(fsm + F_LDS_BYTES);    // [F_BN][2 code-side waves][8]: sorted k-smallest lists (5 used)
     const float en_max = en_max_ptr[0];
     const bool sane = en_max <= F_NORM_LIMIT;
     const int owner = split * F_OWN_PER_SPLIT + wm * 2 + lh;
+    // the block's candidate lists: wave-uniform base + per-lane 32-bit byte offsets (256 rows x own_total lists of F_CAP slots)
+    const char *cbase = reinterpret_cast<const char *>(cand + row0 * own_total * F_CAP);
     FilterRow<TOPK> row[F_NT];
+    unsigned list_start[F_NT];
 #pragma unroll
     for (int nn = 0; nn < F_NT; ++nn) {
-        const long xr = row0 + wn * (32 * F_NT) + nn * 32 + li;
+        const int rl = wn * (32 * F_NT) + nn * 32 + li;
+        const long xr = row0 + rl;
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) row[nn].tv[j] = INFINITY;
         row[nn].L = INFINITY;                // nothing is appended before the warm-up pass has set a finite limit
         row[nn].xn = xsq[min(xr, n - 1)];
         row[nn].win = xr < n ? 2.0f * filter_eps(row[nn].xn, en_max, d) : -INFINITY;
-        row[nn].cnt = 0;
-        row[nn].list = cand + (xr * own_total + owner) * F_CAP;
-        row[nn].lst = (unsigned)(size_t)(fsm + F_LDS_BYTES) + (unsigned)(wn * (32 * F_NT) + nn * 32 + li) * F_LST_ROWB;
+        list_start[nn] = (unsigned)((rl * own_total + owner) * F_CAP) * 8u;
+        row[nn].pos = list_start[nn];
+        row[nn].endm8 = list_start[nn] + (F_CAP - 1) * 8u;
+        row[nn].lst = (unsigned)(size_t)(fsm + F_LDS_BYTES) + (unsigned)rl * F_LST_ROWB;
     }
     for (int i = tid; i < (int)(F_THR_BYTES / 4); i += F_THREADS) thr_share[i] = INFINITY;
 
@@ -472,8 +603,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // __syncthreads() would drain vmcnt(0) here (an LDS-DMA is a pending LDS write), hence the raw barrier.
     // Registers: the code-side fragment of group m is dead once its two MFMAs are issued, so the next step's fragment is read
     // into the SAME registers right behind them (6 MFMAs = 190+ cycles ahead of its first use); only the two row-side
-    // fragments, which every MFMA of the step reads, are double-buffered: 32 operand registers instead of 48.  (With 48
-    // the staggered scan below does not fit the 256-register budget: hipcc spills, and a scratch reload is a vmcnt wait.)
+    // fragments, which every MFMA of the step reads, are double-buffered: 32 operand registers instead of 48.
     half8 fa[F_MT], fbA[F_NT], fbB[F_NT];
     auto read_a = [&](int m, int slot, int t) __attribute__((always_inline)) {
         fa[m] = *reinterpret_cast<const half8 *>(fsm + slot * F_STAGEB + a_adr[t] + m * 32 * F_ROWB);
@@ -482,17 +612,26 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 #pragma unroll
         for (int nn = 0; nn < F_NT; ++nn) fb[nn] = *reinterpret_cast<const half8 *>(fsm + slot * F_STAGEB + b_adr[t] + nn * 32 * F_ROWB);
     };
-    // one k16 step on (fa, fb_cur); meanwhile the operands of step (slot, t) arrive in fa / fb_nxt
-    auto step = [&](const half8 (&fb_cur)[F_NT], half8 (&fb_nxt)[F_NT], int slot, int t) __attribute__((always_inline)) {
+    // one k16 step on (fa, fb_cur); meanwhile the operands of step (slot, t) arrive in fa / fb_nxt.
+    // FIRST = the first k16 step of a code tile: only the FIRST row tile's accumulators hold the start values; the second row
+    // tile's MFMA reads them from there as its C operand (D != C), then the first row tile's MFMA runs in place.  A restart
+    // therefore loads 16 registers per group, not 32, and copies nothing.
+    auto step = [&](const half8 (&fb_cur)[F_NT], half8 (&fb_nxt)[F_NT], int slot, int t, auto first) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first)::value;
 #ifndef MEDTOK_FILTER_NOLDS
         read_b(fb_nxt, slot, t);
 #endif
 #pragma unroll
         for (int m = 0; m < F_MT; ++m) {
 #ifndef MEDTOK_FILTER_NOMFMA
+            if (FIRST) {
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb_cur[1], acc[m][0], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb_cur[0], acc[m][0], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int nn = 0; nn < F_NT; ++nn)
-                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb_cur[nn], acc[m][nn], 0, 0, 0);
+                for (int nn = 0; nn < F_NT; ++nn)
+                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb_cur[nn], acc[m][nn], 0, 0, 0);
+            }
 #else
             asm volatile("" ::"v"(fa[m]), "v"(fb_cur[0]), "v"(fb_cur[1]));
 #endif
@@ -502,34 +641,8 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         }
     };
 
-    // A staggered group's mid-stage switch: scan both row tiles of the code tile it has finished (none at its first switch,
-    // which only ends the idle window), restart the accumulators on the next one (none after the last), update the limits.
-    // A staggered group's mid-stage switch, spread over TWO consecutive iterations so that each part fits into what the SIMD
-    // partner's MFMAs cover before the next barrier (~600 cycles): part A copies the second row tile's finished accumulators
-    // aside (16 registers, held for one iteration), scans the first row tile and restarts both on the next code tile; part B,
-    // one stage later, scans the copy.  (No scan at the group's first switch, which only ends its idle window; the start values
-    // after the last tile belong to the clamped last tile and are never scanned.)
-#ifndef MEDTOK_FILTER_NOEPI
-#define F_GROUP_SWITCH_A(M, next)                                                            \
-    do {                                                                                     \
-        held = acc[M][1];                                                                    \
-        if ((next) >= 2) filter_scan<TOPK>(row[0], acc[M][0], F_LANE_CB(M, (next) - 1), false); \
-        F_INIT_GROUP(M, min((next), nct - 1));                                               \
-    } while (0)
-    /* the four owners' lists are merged once per cycle (after the wave's last group), like once per code tile without
-       staggering; in between a lane's own hits do not move its limit (any T >= t~ is valid) */
-#define F_GROUP_SWITCH_B(M, next)                                                            \
-    do {                                                                                     \
-        if ((next) >= 2) {                                                                   \
-            filter_scan<TOPK>(row[1], held, F_LANE_CB(M, (next) - 1), false);                \
-            if ((M) == F_MT - 1) filter_merge_pair<TOPK>(row[0], row[1], wm, lh);            \
-        }                                                                                    \
-    } while (0)
-#else
-#define F_GROUP_SWITCH_A(M, next) do { asm volatile("" ::"v"(acc[M][0]), "v"(acc[M][1])); F_INIT_GROUP(M, min((next), nct - 1)); } while (0)
-#define F_GROUP_SWITCH_B(M, next) do { } while (0)
-#endif
-    // All four groups of the wave at once (the first code tile of every block; every tile without staggering).
+    // The scan of a finished code tile: all four groups of the wave.
+    unsigned long multi = 0;             // wave-uniform: some lane had a second passing value in one quad (filter_hit)
     auto tile_epilogue = [&](int tile, bool warm) __attribute__((always_inline)) {
         if (DUMP) {
 #pragma unroll
@@ -556,7 +669,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 #pragma unroll
                     for (int nn = 0; nn < F_NT; ++nn) {
                         const float u = acc[m][nn][r] * -0x1p-15f;
-                        thr_insert_bf<TOPK>(row[nn].tv, u == u ? u : INFINITY);
+                        thr_insert_med3<TOPK>(row[nn].tv, u == u ? u : INFINITY);
                     }
 #pragma unroll
             for (int nn = 0; nn < F_NT; ++nn) row[nn].L = filter_limit(row[nn].tv[TOPK - 1], row[nn].win);
@@ -564,12 +677,34 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 #define F_ONE(M)                                                                                                   \
         do {                                                                                                       \
             const int cb_ = F_LANE_CB(M, tile);                                                                    \
-            _Pragma("unroll") for (int nn = 0; nn < F_NT; ++nn) filter_scan<TOPK>(row[nn], acc[M][nn], cb_, warm); \
-            if (tile + 1 < nct) F_INIT_GROUP(M, tile + 1);                                                         \
+            _Pragma("unroll") for (int nn = 0; nn < F_NT; ++nn) {                                                  \
+                if (warm) filter_scan_rest<TOPK, false>(row[nn], acc[M][nn], cb_, cbase);                          \
+                else {                                                                                             \
+                    F_DEV_SCAN(filter_scan<TOPK>(row[nn], acc[M][nn], cb_, cbase, multi));                         \
+                    if (multi) { filter_scan_rest<TOPK, true>(row[nn], acc[M][nn], cb_, cbase); multi = 0; }       \
+                }                                                                                                  \
+            }                                                                                                      \
+            F_DEV_INIT(M, tile + 1);        /* (past the last tile: values of a clamped tile, never scanned) */     \
         } while (0)
+#ifdef MEDTOK_FILTER_SGPRINIT     /* dev experiment: round 2's first form of the restart */
+#define F_DEV_INIT(M, t) do { if ((t) < nct) F_INIT_GROUP(M, t); } while (0)
+#else
+#define F_DEV_INIT(M, t) F_INIT_LDS(M, t)
+#endif
+#ifdef MEDTOK_FILTER_NOSCAN       /* dev experiments: the epilogue without its scans / without the merge of the owners' lists */
+#define F_DEV_SCAN(x) do { } while (0)
+#else
+#define F_DEV_SCAN(x) x
+#endif
         F_ONE(0); F_ONE(1); F_ONE(2); F_ONE(3);
 #undef F_ONE
+#undef F_DEV_SCAN
+#undef F_DEV_INIT
+        stage_init(tile + 2);               // into the buffer this tile's start values came from (last read a whole tile ago)
+#ifndef MEDTOK_FILTER_NOMERGE
         filter_merge_pair<TOPK>(row[0], row[1], wm, lh);
+#endif
+        lds_init_wait(acc);
     };
 
     constexpr int LGKM0 = 0xC07F;           // s_waitcnt lgkmcnt(0) only (vmcnt / expcnt fields at their maxima)
@@ -584,11 +719,11 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
             for (int r = 0; r < 16; ++r) {
                 const float4 q4 = e4[r >> 2];
                 const float v = (r & 3) == 0 ? q4.x : (r & 3) == 1 ? q4.y : (r & 3) == 2 ? q4.z : q4.w;
-#pragma unroll
-                for (int nn = 0; nn < F_NT; ++nn) acc[m][nn][r] = v;
+                acc[m][0][r] = v;
             }
         }
     }
+    stage_init(1);                          // (older than everything the wait below leaves in flight)
     stage(); stage(); stage();              // stages 0..2 (clamped when the block has fewer)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -607,9 +742,9 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     if (late) __builtin_amdgcn_s_setprio(3);
 
     // first half of an iteration: MFMA(s, t0) with the operand reads of (s, t1) between them, then the stage barrier
-    auto first_half = [&](int s) __attribute__((always_inline)) {
+    auto first_half = [&](int s, auto first) __attribute__((always_inline)) {
         if (late && s > 0) stage();         // waves 4-7: stage s+2 (slot s-2, free since the barrier of iteration s-1)
-        step(fbA, fbB, s & (F_RING - 1), 1);
+        step(fbA, fbB, s & (F_RING - 1), 1, first);
         __builtin_amdgcn_sched_group_barrier(0x100, F_NT, 0);
 #pragma unroll
         for (int i = 0; i < F_MT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, F_NT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
@@ -624,7 +759,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // second half: (DMA of stage s+3,) MFMA(s, t1) with the operand reads of (s+1, t0) between them
     // (past the last stage the reads fetch stale LDS, never used)
     auto second_half = [&](int s) __attribute__((always_inline)) {
-        step(fbB, fbA, (s + 1) & (F_RING - 1), 0);
+        step(fbB, fbA, (s + 1) & (F_RING - 1), 0, std::false_type{});
         // after the barrier the matrix pipe restarts at once; DMA issue and operand reads ride between MFMAs
         __builtin_amdgcn_sched_group_barrier(0x100, F_NT, 0);
 #pragma unroll
@@ -634,78 +769,27 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         }
     };
 
-    if constexpr (!STAG) {
-        // every group switches code tiles together: the scan of all four runs at the end of the tile's last stage
-        int ct = 0, kb = 0;
-        for (int s = 0; s < nstage; ++s) {
-            first_half(s);
+    // every group switches code tiles together: the scan of all four runs at the end of the tile's last stage
+    auto iteration = [&](int s, auto first) __attribute__((always_inline)) {
+        first_half(s, first);
 #ifndef MEDTOK_FILTER_NODMA       // dev experiment: without it the ring keeps its prologue contents
-            if (!late) stage();             // waves 0-3: stage s+3 (slot s-1: everyone is past reading it)
+        if (!late) stage();             // waves 0-3: stage s+3 (slot s-1: everyone is past reading it)
 #endif
-            second_half(s);
-            if (++kb == nkb) {
+        second_half(s);
+    };
+    int s = 0;
+    for (int ct = 0; ct < nct; ++ct) {
+        iteration(s, std::true_type{});
+        ++s;
+        for (int kb = 1; kb < nkb; ++kb, ++s) iteration(s, std::false_type{});
 #ifndef MEDTOK_FILTER_NOEPI
-                tile_epilogue(ct, ct == 0);
+        tile_epilogue(ct, ct == 0);
 #else
 #pragma unroll
-                for (int m = 0; m < F_MT; ++m)
+        for (int m = 0; m < F_MT; ++m)
 #pragma unroll
-                    for (int nn = 0; nn < F_NT; ++nn) { asm volatile("" ::"v"(acc[m][nn])); }
+            for (int nn = 0; nn < F_NT; ++nn) { asm volatile("" ::"v"(acc[m][nn])); }
 #endif
-                kb = 0;
-                ++ct;
-            }
-        }
-    } else {
-        auto plain_iteration = [&](int s) __attribute__((always_inline)) {
-            first_half(s);
-#ifndef MEDTOK_FILTER_NODMA
-            if (!late) stage();             // waves 0-3: stage s+3 (slot s-1: everyone is past reading it)
-#endif
-            second_half(s);
-        };
-        // the first code tile: all groups together, then the scan that also teaches every list its threshold and restarts
-        // the groups on tile 1
-        int s = 0;
-        for (; s < nkb; ++s) plain_iteration(s);
-#if !defined(MEDTOK_FILTER_NOEPI) && !defined(EXP_NOWARM)
-        tile_epilogue(0, true);
-#endif
-        // From here on the wave's four groups switch code tiles one after the other, group M in the middle of stage
-        // nkb + rot(2 M + wm) - 1 + (cyc - 1) nkb of cycle cyc = 1 .. nct (cyc = the code tile it starts there; the scan is of
-        // tile cyc - 1, none in cycle 1, where the switch only ends the group's idle window; no restart after the last tile
-        // -- the start values it gets then belong to the clamped last tile and are never scanned).  The switches sit at FIXED
-        // places of the instruction stream (four stretches of plain iterations, each ended by an iteration with a switch in
-        // its middle), not behind a runtime group index: the eight 16-register accumulator tuples then never meet a join of
-        // several definitions, which hipcc answers with tuple copies and hundreds of spilled registers.
-        // While one wave scans (a quarter of its accumulators), its SIMD partner has the 8 + 8 MFMAs up to the next barrier to issue.
-#define F_SEGMENT(M)                                                                                                   \
-        do {                                                                                                           \
-            const int target = nkb + filter_rot(2 * (M) + wm_s, nkb) - 1 + (cyc - 1) * nkb;                             \
-            for (; s < target; ++s) plain_iteration(s);                                                               \
-            first_half(s);                                                                                             \
-            F_GROUP_SWITCH_A(M, cyc);                                                                                  \
-            F_STAGE_EARLY();                                                                                           \
-            second_half(s);                                                                                            \
-            ++s;                                                                                                       \
-            first_half(s);                                                                                             \
-            F_GROUP_SWITCH_B(M, cyc);                                                                                  \
-            F_STAGE_EARLY();                                                                                           \
-            second_half(s);                                                                                            \
-            ++s;                                                                                                       \
-        } while (0)
-#ifndef MEDTOK_FILTER_NODMA
-#define F_STAGE_EARLY() do { if (!late) stage(); } while (0)
-#else
-#define F_STAGE_EARLY() do { } while (0)
-#endif
-        f32x16 held;                         // the second row tile's finished accumulators between the two parts of a switch
-        for (int cyc = 1; cyc <= nct; ++cyc) {
-            F_SEGMENT(0); F_SEGMENT(1); F_SEGMENT(2); F_SEGMENT(3);
-        }
-#undef F_SEGMENT
-#undef F_STAGE_EARLY
-        for (; s < nstage; ++s) plain_iteration(s);      // (the other waves' last groups are still at work: same barrier count for all)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail re-issues may still be in flight
     if (!DUMP) {
@@ -714,12 +798,11 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
             // rows outside the range the bound assumes are forced onto the exact path
             const long xr = row0 + wn * (32 * F_NT) + nn * 32 + li;
             const bool ok = sane && row[nn].xn <= F_NORM_LIMIT;
-            if (xr < n) cand_cnt[xr * own_total + owner] = ok ? row[nn].cnt : F_CAP + 1;
+            if (xr < n) cand_cnt[xr * own_total + owner] = ok ? (int)((row[nn].pos - list_start[nn]) >> 3) : F_CAP + 1;
         }
     }
-#undef F_GROUP_SWITCH_A
-#undef F_GROUP_SWITCH_B
 #undef F_INIT_GROUP
+#undef F_INIT_LDS
 #undef F_LANE_CB
 }
 
@@ -764,7 +847,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(
         for (int j = 0; j < TOPK; ++j) tv[j] = INFINITY;
         for (int o = 0; o < own_total; ++o) {
             const int m = cc[o];
-            for (int sidx = l8; sidx < m; sidx += 8) thr_insert<TOPK>(tv, __uint_as_float(rc[o * F_CAP + sidx].x));
+            for (int sidx = l8; sidx < m; sidx += 8) thr_insert<TOPK>(tv, fmaf(__uint_as_float(rc[o * F_CAP + sidx].x), -0x1p-15f, xn));
         }
 #pragma unroll
         for (int off = 4; off >= 1; off >>= 1) {
@@ -782,7 +865,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(
             const int m = cc[o];
             for (int sidx = l8; sidx < m; sidx += 8) {
                 const uint2 e = rc[o * F_CAP + sidx];
-                if (__uint_as_float(e.x) <= lim && e.y < (unsigned)k_codes) {
+                if (fmaf(__uint_as_float(e.x), -0x1p-15f, xn) <= lim && e.y < (unsigned)k_codes) {
                     const int p = atomicAdd(&s_cnt[g], 1);
                     if (p < R_SURV) s_code[g * R_SURV + p] = (int)e.y;
                 }

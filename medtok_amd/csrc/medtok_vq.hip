@@ -502,17 +502,15 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict
 
 // Test / dev hook (medtok_debug_plan_override): force plan branches that the default heuristics only take at very large
 // shapes, so small tests can cover them.  Process-wide, -1 = default; the product path never reads the environment.
-struct PlanOverride { long filter_splits = -1, filter_xcd = -1, filter_tail_min_blocks = -1, search_max_splits = -1, filter_stagger = -1; };
+struct PlanOverride { long filter_splits = -1, filter_xcd = -1, filter_tail_min_blocks = -1, search_max_splits = -1; };
 static PlanOverride g_plan_override;
 
-extern "C" int medtok_debug_plan_override(int64_t filter_splits, int64_t filter_xcd, int64_t filter_tail_min_blocks, int64_t search_max_splits,
-                                          int64_t filter_stagger)
+extern "C" int medtok_debug_plan_override(int64_t filter_splits, int64_t filter_xcd, int64_t filter_tail_min_blocks, int64_t search_max_splits)
 {
     g_plan_override.filter_splits = (long)filter_splits;
     g_plan_override.filter_xcd = (long)filter_xcd;
     g_plan_override.filter_tail_min_blocks = (long)filter_tail_min_blocks;
     g_plan_override.search_max_splits = (long)search_max_splits;
-    g_plan_override.filter_stagger = (long)filter_stagger;
     return 0;
 }
 
@@ -576,7 +574,6 @@ struct FilterPlan {
     // tail launch: the last main_tiles..row_tiles row tiles with more, shorter splits (0 tiles = none)
     long main_tiles;
     int tail_splits, tail_codes_per_split, own_tail;
-    bool stagger;      // main launch: staggered per-group epilogue (filter_f16.h); the tail's short splits never use it
 };
 
 static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
@@ -605,13 +602,6 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
     f.codes_per_split = (int)(tiles_per_split * F_BM);
     f.splits = (int)((code_tiles + tiles_per_split - 1) / tiles_per_split);
     f.own_total = f.splits * F_OWN_PER_SPLIT;
-    // The staggered epilogue (filter_f16.h) is OFF by default: measured on MI355X at N = 600k, D = 768 it is 11-13 % slower than
-    // scanning all groups together (K = 16384: 17.5 vs 15.5 ms; K = 49152: 48.2 vs 43.1 ms) -- with one block-wide barrier per
-    // stage a scanning wave's latency-bound instruction stream is exposed whether or not its SIMD partner has MFMAs to issue.
-    // It stays selectable (same bits; tests/test_gpu_filter.py) as the starting point for a ring with split barriers.
-    f.stagger = false;
-    if (g_plan_override.filter_stagger >= 0)
-        f.stagger = g_plan_override.filter_stagger != 0 && f.dp / F_BK >= F_STAG_MIN_NKB && tiles_per_split >= 2;
     f.xcd_rows = (xcd && f.splits >= 2 && 32 % f.splits == 0) ? 32 / f.splits : 0;
     // One 8-wave block per CU and equal-cost blocks: B blocks take ceil(B / 256) rounds, the last one however few blocks it
     // holds (N = 600k: 4688 blocks = 18.3 rounds -> 19).  The row tiles of that last round go into a second launch
@@ -801,23 +791,17 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, w.en_max);
     hipLaunchKernelGGL(pad_wsq_kernel, dim3((unsigned)((f.k_pad + 255) / 256)), dim3(256), 0, s, wsq, (int)k_codes, (int)f.k_pad, w.wsqp);
     if (hipMemsetAsync(w.fb_count, 0, 4, s) != hipSuccess) return fail("search(filter): memset failed");
-    (void)set_lds_once<filter_f16_kernel<T, false, false>>(F_SMEM_BYTES);
-    (void)set_lds_once<filter_f16_kernel<T, false, true>>(F_SMEM_BYTES);
+    (void)set_lds_once<filter_f16_kernel<T, false>>(F_SMEM_BYTES);
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
     dim3 fgrid((unsigned)f.main_tiles, (unsigned)f.splits);
     if (f.xcd_rows) fgrid = dim3((unsigned)(((f.main_tiles + 8 * f.xcd_rows - 1) / (8 * f.xcd_rows)) * 256), 1);
-    if (f.stagger)
-        hipLaunchKernelGGL((filter_f16_kernel<T, false, true>), fgrid, dim3(F_THREADS), F_SMEM_BYTES, s,
-                           w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
-                           w.cand, w.cand_cnt, (float *)nullptr, f.xcd_rows, f.splits, 0, (int)f.main_tiles);
-    else
-        hipLaunchKernelGGL((filter_f16_kernel<T, false, false>), fgrid, dim3(F_THREADS), F_SMEM_BYTES, s,
-                           w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
-                           w.cand, w.cand_cnt, (float *)nullptr, f.xcd_rows, f.splits, 0, (int)f.main_tiles);
+    hipLaunchKernelGGL((filter_f16_kernel<T, false>), fgrid, dim3(F_THREADS), F_SMEM_BYTES, s,
+                       w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
+                       w.cand, w.cand_cnt, (float *)nullptr, f.xcd_rows, f.splits, 0, (int)f.main_tiles);
     const long tail_start = f.main_tiles * F_BN;
     if (f.main_tiles < f.row_tiles) {
         // the kernel indexes its lists by absolute row: bias the tail region's base pointers accordingly
-        hipLaunchKernelGGL((filter_f16_kernel<T, false, false>), dim3((unsigned)(f.row_tiles - f.main_tiles), (unsigned)f.tail_splits), dim3(F_THREADS),
+        hipLaunchKernelGGL((filter_f16_kernel<T, false>), dim3((unsigned)(f.row_tiles - f.main_tiles), (unsigned)f.tail_splits), dim3(F_THREADS),
                            F_SMEM_BYTES, s, w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.tail_codes_per_split, f.own_tail,
                            w.cand_tail - tail_start * f.own_tail * F_CAP, w.cnt_tail - tail_start * f.own_tail, (float *)nullptr, 0, f.tail_splits,
                            (int)f.main_tiles, (int)f.row_tiles);
@@ -930,8 +914,8 @@ extern "C" int medtok_debug_filter_scores_f32(const float *xhat, const float *xs
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.n_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, xhat, (long)n, d, f.n_pad, f.dp, xh);
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, wh);
     hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, en_max);
-    (void)set_lds_once<filter_f16_kernel<5, true, false>>(F_SMEM_BYTES);
-    hipLaunchKernelGGL((filter_f16_kernel<5, true, false>), dim3((unsigned)f.row_tiles, 1), dim3(F_THREADS), F_SMEM_BYTES, s, xh, wh, xsq, wsqp, en_max,
+    (void)set_lds_once<filter_f16_kernel<5, true>>(F_SMEM_BYTES);
+    hipLaunchKernelGGL((filter_f16_kernel<5, true>), dim3((unsigned)f.row_tiles, 1), dim3(F_THREADS), F_SMEM_BYTES, s, xh, wh, xsq, wsqp, en_max,
                        (long)n, (int)k_codes, f.dp, d, (int)f.k_pad, F_OWN_PER_SPLIT, (uint2 *)nullptr, (int *)nullptr, scores, 0, 1,
                        0, (int)f.row_tiles);
     return check_launch("filter_f16(dump)");

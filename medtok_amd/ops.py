@@ -32,10 +32,9 @@ def profile_end() -> dict:
 
 
 def debug_plan_override(filter_splits: int = -1, filter_xcd: int = -1, filter_tail_min_blocks: int = -1,
-                        search_max_splits: int = -1, filter_stagger: int = -1) -> None:
+                        search_max_splits: int = -1) -> None:
     """Test hook (medtok_debug_plan_override): force plan branches of the search kernels; call with no arguments to reset."""
-    _lib.check(_lib.load().medtok_debug_plan_override(filter_splits, filter_xcd, filter_tail_min_blocks, search_max_splits,
-                                                      filter_stagger), "medtok_debug_plan_override")
+    _lib.check(_lib.load().medtok_debug_plan_override(filter_splits, filter_xcd, filter_tail_min_blocks, search_max_splits), "medtok_debug_plan_override")
 
 
 def _stream(t: torch.Tensor) -> int:

@@ -224,19 +224,30 @@ def test_tail_launch_gives_the_same_bits(dev, splits, tiles, plan):
 
 @pytest.mark.parametrize("n,K,D,topk,splits", [(256 * 5 + 3, 256 * 7, 512, 5, 1), (256 * 9 + 100, 256 * 26 - 5, 768, 5, 2),
                                                (256 * 3, 256 * 4, 512, 1, 1), (256 * 4 + 17, 256 * 6, 1024, 8, 1), (256 * 2 + 1, 256 * 3 - 200, 640, 3, 1)])
-def test_staggered_epilogue_gives_the_same_bits(oracle, dev, plan, n, K, D, topk, splits):
-    """The staggered epilogue (default from 12 code tiles per block up, D >= 512) forced at small sizes: every 32-code group
-    switches code tiles in the middle of a different stage, the DMA splits those stages' code rows between two tiles, blocks run
-    extra stages for the late groups.  ids and distances must equal the exact path (and the oracle), with and without it."""
+def test_scan_hit_path_with_several_passing_values_per_quad(oracle, dev, plan, n, K, D, topk, splits):
+    """The scan's hit path is one exec-masked instruction sequence that appends a quad's MAXIMUM; a second passing value in the
+    same quad (4 consecutive codes of a lane) raises a flag and the tile is revisited (filter_scan_rest).  Random codebooks almost
+    never take that branch, so here every code comes in a run of near-copies: whole quads pass together, including exact ties
+    (the revisit must skip exactly the position the hit path took).  Many code tiles per block and every k-list length (1, 5, 8
+    slots).  ids and distances must equal the exact path (and the oracle)."""
     from medtok_amd import ops
     g = torch.Generator(device=dev).manual_seed(n + K)
     xh, xs = ops.rownorm(torch.randn(n, D, device=dev, generator=g))
-    wh, ws = ops.rownorm(torch.randn(K, D, device=dev, generator=g))
+    base = torch.randn((K + 5) // 6, D, device=dev, generator=g)
+    W = base.repeat_interleave(6, 0)[:K].clone()                       # runs of 6: a run straddles quads and 32-code groups
+    W[1::6] += 1e-3 * torch.randn(W[1::6].shape, device=dev, generator=g)
+    W[2::6] += 1e-4 * torch.randn(W[2::6].shape, device=dev, generator=g)
+    W[4::6] += 1e-2 * torch.randn(W[4::6].shape, device=dev, generator=g)      # 0, 3, 5: exact copies
+    wh, ws = ops.rownorm(W)
     i_ref, d_ref = ops.topk_search(xh, xs, wh, ws, topk, ops.PATH_F32_MFMA)
-    for stagger in (1, 0):
-        plan(filter_splits=splits, filter_stagger=stagger)
+    plan(filter_splits=splits)
+    ops.SEARCH_STATS = {}
+    try:
         i_s, d_s = ops.topk_search(xh, xs, wh, ws, topk, ops.PATH_F16_FILTER)
-        assert torch.equal(i_s, i_ref) and torch.equal(d_s, d_ref), stagger
+        assert ops.SEARCH_STATS["fallback_rows"] < n // 4        # the filter path decided these rows, not the exact redo
+    finally:
+        ops.SEARCH_STATS = None
+    assert torch.equal(i_s, i_ref) and torch.equal(d_s, d_ref)
     sub = slice(0, 300)
     io, do = oracle.topk_search(xh[sub].cpu().numpy(), xs[sub].cpu().numpy(), wh.cpu().numpy(), ws.cpu().numpy(), topk)
     assert np.array_equal(i_s[sub].cpu().numpy(), io) and np.array_equal(d_s[sub].cpu().numpy(), do)

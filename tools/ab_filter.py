@@ -1,4 +1,4 @@
-"""Dev tool: filter kernel time at the cfg-3 shapes, staggered epilogue on / off (ops.debug_plan_override), same bits as the exact path.
+"""Dev tool: filter kernel time at the cfg-3 shapes, same bits as the exact path.
 MEDTOK_TOOL_LIB=<path> binds an alternative build of the same ABI."""
 import sys, time
 sys.path.insert(0, ".")
@@ -16,14 +16,13 @@ for N, K in shapes:
     xh, xs = ops.rownorm(x); wh, ws = ops.rownorm(W)
     ir, dr = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F32_MFMA)
     for rnd in range(2):
-        for stag in (0, 1):
-            ops.debug_plan_override(filter_stagger=stag)
-            for _ in range(2): idx, dist = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
-            torch.cuda.synchronize(); ops.profile_begin(); t0 = time.perf_counter()
-            for _ in range(3): idx, dist = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
-            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
-            p = ops.profile_end()["filter_f16_kernel"]
-            print(f"N={N} K={K} stagger={stag}: filter kernel {p['ms']/p['launches']:.2f} ms ({p['flops']/p['ms']/1e9:.0f} TF), whole search {dt*1e3:.2f} ms, "
-                  f"same bits as exact: {torch.equal(idx, ir) and torch.equal(dist, dr)}", flush=True)
-    ops.debug_plan_override()
+        ops.SEARCH_STATS = {}
+        for _ in range(2): idx, dist = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
+        fb = ops.SEARCH_STATS.get("fallback_rows"); ops.SEARCH_STATS = None
+        torch.cuda.synchronize(); ops.profile_begin(); t0 = time.perf_counter()
+        for _ in range(3): idx, dist = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+        p = ops.profile_end()["filter_f16_kernel"]
+        print(f"N={N} K={K}: filter kernel {p['ms']/p['launches']:.2f} ms ({p['flops']/p['ms']/1e9:.0f} TF), whole search {dt*1e3:.2f} ms, "
+              f"fallback rows {fb}, same bits as exact: {torch.equal(idx, ir) and torch.equal(dist, dr)}", flush=True)
     del x, W, xh, wh

@@ -1,5 +1,4 @@
-"""Dev tool: filter kernel time only (results are garbage under the ablation macros) for the build in MEDTOK_TOOL_LIB,
-staggered epilogue off / on."""
+"""Dev tool: filter kernel time only (results are garbage under the ablation macros) for the build in MEDTOK_TOOL_LIB."""
 import sys, time
 sys.path.insert(0, ".")
 import os as _os
@@ -12,11 +11,10 @@ N, K, D = 600000, int(sys.argv[1]) if len(sys.argv) > 1 else 16384, 768
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.randn(N, D, device=dev, generator=g); W = torch.randn(K, D, device=dev, generator=g)
 xh, xs = ops.rownorm(x); wh, ws = ops.rownorm(W)
-for stag in (0, 1, 0, 1):
-    ops.debug_plan_override(filter_stagger=stag)
+for rnd in range(2):
     for _ in range(2): ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
     torch.cuda.synchronize(); ops.profile_begin()
     for _ in range(3): ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
     torch.cuda.synchronize()
     p = ops.profile_end()["filter_f16_kernel"]
-    print(f"stagger={stag}: filter kernel {p['ms']/p['launches']:.2f} ms ({p['flops']/p['ms']/1e9:.0f} TF)", flush=True)
+    print(f"filter kernel {p['ms']/p['launches']:.2f} ms ({p['flops']/p['ms']/1e9:.0f} TF)", flush=True)

@@ -25,7 +25,7 @@ for c in range(cases):
     norm = kind != 3
     xh, xs = ops.rownorm(x); wh, ws = ops.rownorm(W, normalize=norm) if not norm else ops.rownorm(W)
     if not norm: wh = W.contiguous()
-    for env in ({}, dict(filter_splits=int(rng.choice([1, 2, 4, 8])), filter_xcd=1), dict(filter_stagger=1), dict(filter_stagger=0)):
+    for env in ({}, dict(filter_splits=int(rng.choice([1, 2, 4, 8])), filter_xcd=1)):
         ops.debug_plan_override(**env)
         i0, d0 = ops.topk_search(xh, xs, wh, ws, k, ops.PATH_F32_MFMA)
         i1, d1 = ops.topk_search(xh, xs, wh, ws, k, ops.PATH_F16_FILTER)
