@@ -193,6 +193,10 @@ extern "C" int medtok_rownorm_f32(const float *x, int64_t n, int d, int normaliz
     return check_launch("rownorm");
 }
 
+// single VALU instructions (fminf on MFMA results makes hipcc put a canonicalising v_max in front of each operand)
+__device__ __forceinline__ float vs_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vs_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 // ================================================================= top-k list helpers
 // Sorted ascending by (value, index).  A lane meets its codes in increasing index order,
 // so a strict '<' on the value alone implements "ties -> lowest index" during the scan.
@@ -422,14 +426,28 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
                         }
                     }
                 }
+                // four codes per test: the smallest of their distances against the list's last entry, ONE wave-uniform branch; a
+                // quad in which some lane has a better code is then folded in value by value, in code order as before
+                // (ties -> lowest index).  (+0.6 % at k = 5; the argmin kernel keeps the per-value form: -0.5 % there.)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int code = cbase + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float sum = xn + en[r];
-                    const float two = 2.0f * acc[m][r];
-                    const float dv = sum - two;
-                    topk_insert<TOPK>(bv, bi, dv, code);
-                    acc[m][r] = 0.f;
+                for (int g = 0; g < 4; ++g) {
+                    float dv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float sum = xn + en[4 * g + j];
+                        const float two = 2.0f * acc[m][4 * g + j];
+                        dv[j] = sum - two;
+                        acc[m][4 * g + j] = 0.f;
+                    }
+                    bool any = true;
+                    if (TOPK > 1) {
+                        const float mn = vs_min(vs_min3(dv[0], dv[1], dv[2]), dv[3]);      // (NaN never wins a v_min: a NaN distance is never inserted)
+                        any = __builtin_amdgcn_ballot_w64(mn < bv[TOPK - 1]) != 0;
+                    }
+                    if (any) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) topk_insert<TOPK>(bv, bi, dv[j], cbase + 32 * m + j + 8 * g + 4 * lh);
+                    }
                 }
             }
 #endif
