@@ -142,10 +142,23 @@ class CrossAttention(nn.Module):
         heads, hd = mha.num_heads, mha.head_dim
         wq, wk, wv = mha.in_proj_weight.chunk(3)
         bq, _, bv = mha.in_proj_bias.chunk(3)
-        q = torch.nn.functional.linear(rows, wq, bq).view(n_rows, heads, hd)
-        qf = torch.einsum("rhd,hdk->rhk", q, wk.view(heads, hd, dim)).reshape(n_rows * heads, dim)
-        ctx = attend(qf.contiguous()).view(n_rows, heads, dim)
-        attended = torch.einsum("rhk,hdk->rhd", ctx.to(wv.dtype) if torch.is_autocast_enabled() else ctx, wv.view(heads, hd, dim)).reshape(n_rows, dim) + bv
+        q = torch.nn.functional.linear(rows, wq, bq)
+        plain = not torch.is_grad_enabled() and not torch.is_autocast_enabled() and rows.dtype == wk.dtype
+        if plain:
+            # one GEMM per head straight into / out of the [R, heads, D] layout the kernel works on (strided operands and
+            # outputs, leading dimension heads*D or D): einsum's permute-and-copy of these R*heads*D tensors was ~5 % of the
+            # forward.  `out=` has no autograd, so only where none is recorded.
+            qf3 = rows.new_empty(n_rows, heads, dim)
+            for h in range(heads):
+                torch.mm(q[:, h * hd:(h + 1) * hd], wk[h * hd:(h + 1) * hd], out=qf3[:, h])
+            ctx = attend(qf3.view(n_rows * heads, dim)).view(n_rows, heads, dim)
+            attended = rows.new_empty(n_rows, dim)
+            for h in range(heads):
+                torch.addmm(bv[h * hd:(h + 1) * hd], ctx[:, h], wv[h * hd:(h + 1) * hd].t(), out=attended[:, h * hd:(h + 1) * hd])
+        else:
+            qf = torch.einsum("rhd,hdk->rhk", q.view(n_rows, heads, hd), wk.view(heads, hd, dim)).reshape(n_rows * heads, dim)
+            ctx = attend(qf.contiguous()).view(n_rows, heads, dim)
+            attended = torch.einsum("rhk,hdk->rhd", ctx.to(wv.dtype) if torch.is_autocast_enabled() else ctx, wv.view(heads, hd, dim)).reshape(n_rows, dim) + bv
         return layer.layer_norm(rows + layer.dropout(mha.out_proj(attended)))
 
     def _pooled_packed(self, text, valid_len, nodes_sorted, batch_sorted, slot, counts, starts, max_nodes, core, autograd=False):
