@@ -516,7 +516,9 @@ def main():
     # dominant kernel = the matrix-pipe kernel with the most time in the timed region
     if hasattr(wl, "attention_flops"):       # the ragged counts live on the device; the workload knows them
         prof["shared_kv_attention_kernel"]["flops"] = wl.attention_flops * args.steps
-    kname = max(prof, key=lambda k: prof[k]["ms"])
+    # (a kernel whose flops the library cannot know -- the ragged attention launches of the train step -- cannot carry a roofline)
+    known = {k: v for k, v in prof.items() if v["flops"] > 0} or prof
+    kname = max(known, key=lambda k: known[k]["ms"])
     kp = prof[kname]
     peak = F16_MFMA_PEAK_TFLOPS if kname == "filter_f16_kernel" else FP32_MFMA_PEAK_TFLOPS
     achieved = kp["flops"] / (kp["ms"] * 1e-3) / 1e12 if kp["ms"] > 0 else 0.0
