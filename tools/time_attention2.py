@@ -1,6 +1,9 @@
 """Dev tool: per-chunk latency / throughput regimes of ops.shared_kv_attention (uniform shapes)."""
 import sys, time
 sys.path.insert(0, ".")
+import os as _os
+if _os.environ.get("MEDTOK_TOOL_LIB"):
+    from medtok_amd import _lib as _l; _l.use_library(_os.environ["MEDTOK_TOOL_LIB"])
 import torch
 from medtok_amd import ops
 dev = torch.device("cuda:0")
@@ -17,4 +20,6 @@ def run(B, rows, T, reps=20):
     fl = B * rows * T * D * 4.0
     tiles = B * ((rows + 31) // 32); chunks = (T + 31) // 32
     print(f"B={B:5d} rows={rows:4d} T={T:4d}: {dt*1e6:8.1f} us  {fl/dt/1e12:6.1f} TF  | blocks {tiles:6d} x {chunks:3d} chunks -> {dt*1e6/chunks/max(1, tiles/256):.2f} us per chunk-round", flush=True)
-run(256, 32, 512); run(256, 32, 32); run(256, 32, 64); run(256, 32, 128); run(512, 32, 512); run(2048, 32, 512); run(256, 160, 512); run(2048, 96, 256)
+shapes = [(256, 32, 512), (256, 32, 32), (256, 32, 64), (256, 32, 128), (512, 32, 512), (2048, 32, 512), (256, 160, 512), (2048, 96, 256)]
+if len(sys.argv) > 2: shapes = [(2048, 96, 256), (2048, 32, 512)]
+for sh in shapes: run(*sh)
