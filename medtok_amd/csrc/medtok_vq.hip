@@ -370,6 +370,163 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
+    // ---- epilogue of one code tile: d = (|x|^2 + |e|^2) - 2 x.e for this lane's 64 codes, fold into the list
+    auto tile_epilogue = [&](int ct) __attribute__((always_inline)) {
+        // ---- epilogue: d = (|x|^2 + |e|^2) - 2 x.e for this lane's 64 codes, fold into the list
+        const int cbase = code_lo + ct * S_BM;
+#ifdef MEDTOK_SEARCH_NOEPI        // dev experiment: main loop only (results are garbage)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            asm volatile("" ::"v"(acc[m]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        }
+#else
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            // |e|^2 of this lane's 16 codes of the tile: four consecutive codes per register group, so four 16-byte loads
+            // (+2.3 % at K = 16384, k = 5); a group that straddles K or sits on an unaligned slice takes the scalar form
+            // codes at or beyond the split's end get |e|^2 = +inf, i.e. d = +inf: never inserted, and no range test per value
+            float en[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = cbase + 32 * m + 8 * g + 4 * lh;
+                // (argmin, TOPK = 1: the 16 scalar loads measured 4 % faster than the vector form -- its epilogue is nothing else)
+                if (TOPK > 1 && c0 + 3 < code_hi && ((reinterpret_cast<uintptr_t>(wsq + c0) & 15) == 0)) {
+                    const float4 e4 = ld4(wsq + c0);
+                    en[4 * g] = e4.x; en[4 * g + 1] = e4.y; en[4 * g + 2] = e4.z; en[4 * g + 3] = e4.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float e = wsq[min(c0 + j, k_codes - 1)];        // (unconditional load: a branch around it drains vmcnt)
+                        en[4 * g + j] = c0 + j < code_hi ? e : INFINITY;
+                    }
+                }
+            }
+            // four codes per test: the smallest of their distances against the list's last entry, ONE wave-uniform branch; a
+            // quad in which some lane has a better code is then folded in value by value, in code order as before
+            // (ties -> lowest index).  (+0.6 % at k = 5; the argmin kernel keeps the per-value form: -0.5 % there.)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float dv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sum = xn + en[4 * g + j];
+                    const float two = 2.0f * acc[m][4 * g + j];
+                    dv[j] = sum - two;
+                    acc[m][4 * g + j] = 0.f;
+                }
+                bool any = true;
+                if (TOPK > 1) {
+                    const float mn = vs_min(vs_min3(dv[0], dv[1], dv[2]), dv[3]);      // (NaN never wins a v_min: a NaN distance is never inserted)
+                    any = __builtin_amdgcn_ballot_w64(mn < bv[TOPK - 1]) != 0;
+                }
+                if (any) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) topk_insert<TOPK>(bv, bi, dv[j], cbase + 32 * m + j + 8 * g + 4 * lh);
+                }
+            }
+        }
+#endif
+    };
+
+    if constexpr (!KTAIL && !INDIRECT) {
+        // ---- operand staging by LDS-DMA (D % 32 == 0, rows addressed directly).  A stage = 32 floats of 128 code rows and 128 input rows, each row 128 B =
+        // eight 16-byte chunks; wave w copies rows [32w, 32w+32) of both tiles, eight rows per global_load_lds_dwordx4 (lane l:
+        // row l >> 3, chunk slot l & 7), straight from L2 into one of TWO 32 KB buffers -- no staging registers, no ds_write pass,
+        // nothing to wait for before the MFMAs of a stage but the barrier.  The rows are unpadded (the DMA's LDS image is
+        // lane-linear), so chunk c of row r is stored in slot c ^ ((r >> 1) & 7): the 16 lanes a ds_read_b128 services together
+        // then hit 16 distinct 16-byte bank groups (rows of equal parity in such a group differ in bits 1..3 of r).  The swizzle is
+        // applied to the per-lane SOURCE address.  Staging through registers + ds_write (the KTAIL form below, which needs it to
+        // zero the columns past D) measured 130.8 TFLOP/s in the main loop against 152 with the staging removed; this form 143.7
+        // (N = 600k, K = 16 384, D = 768; whole kernel 123.2 -> 137.4 TFLOP/s at k = 5, 126.8 -> 134.9 for the argmin at 100k x 8192).
+        constexpr int ROWB = S_BK * 4, TILEB = S_BM * ROWB;            // 128 B per staged row, 16 KB per tile
+        char *lds = reinterpret_cast<char *>(smem);                      // [2 buffers][A tile | B tile]
+        const int d_r = lane >> 3, d_p = lane & 7;                       // row within the instruction, chunk slot
+        // buffer-addressed DMA (SGPR descriptor + loop-invariant 32-bit lane offset + SGPR stage offset; hipcc drains
+        // vmcnt(0) before every ds_read that follows a global_load_lds, but not after the raw-buffer form).  The descriptors
+        // carry the valid byte range: rows past K or past n read as zeros instead of touching memory (such codes get
+        // |e|^2 = +inf in the epilogue, such rows are never written back).
+        const float *abase_p = what + (long)code_lo * d, *bbase_p = xhat + row0 * d;
+        const long rows_left = n - row0;
+        const int a_bytes = (k_codes - code_lo) * d * 4;                                  // < 2 GB: a code split's fp32 rows
+        const int b_bytes = (int)(rows_left < S_BN ? rows_left : S_BN) * d * 4;
+        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)abase_p, 0, a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)bbase_p, 0, b_bytes, 0x00020000);
+        unsigned lane_off[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wave * 32 + 8 * i + d_r;
+            lane_off[i] = (unsigned)(r * d + 4 * (d_p ^ ((r >> 1) & 7))) * 4u;
+        }
+        const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+        int pct = 0, pkb = 0;
+        auto dma = [&](int buf) __attribute__((always_inline)) {
+            char *abase = lds + buf * 2 * TILEB + (wave_s * 32) * ROWB, *bbase = abase + TILEB;
+            const int ub = __builtin_amdgcn_readfirstlane(pkb * S_BK * 4);
+            const int ua = __builtin_amdgcn_readfirstlane(pct * S_BM * d * 4 + pkb * S_BK * 4);       // a code split is < 2 GB
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void *)(abase + 8 * i * ROWB), 16, (int)lane_off[i], ua, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void *)(bbase + 8 * i * ROWB), 16, (int)lane_off[i], ub, 0, 0);
+            }
+            if (++pkb == nkb) { pkb = 0; ++pct; }
+        };
+        // fragment addresses: lane (li, lh) reads chunk 2 kk + lh of row li (+ 32 m) -- slot (2 kk + lh) ^ ((li >> 1) & 7).
+        // The fragment reads are asm: hipcc orders a C++ ds_read behind ALL pending LDS-DMA ("s_waitcnt vmcnt(0)": a DMA is a pending
+        // LDS write that might alias), i.e. it drained the stage just issued -- a round trip to the L2 per stage in front of the
+        // MFMAs.  The reads of step kk + 1 are issued before the MFMAs of step kk (two register sets); lgkmcnt is waited by hand.
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const unsigned lds0 = (unsigned)(size_t)lds;
+        unsigned fragA[S_BK / 8], fragB[S_BK / 8];
+#pragma unroll
+        for (int kk = 0; kk < S_BK / 8; ++kk) {
+            fragA[kk] = lds0 + li * ROWB + ((2 * kk + lh) ^ ((li >> 1) & 7)) * 16;
+            fragB[kk] = fragA[kk] + TILEB + wave * 32 * ROWB;
+        }
+        f32x4 af[2][4], bf[2];
+        auto frag_read = [&](int set, int kk, unsigned bufofs) __attribute__((always_inline)) {
+            asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %6\n\tds_read_b128 %2, %6 offset:4096\n\t"
+                         "ds_read_b128 %3, %6 offset:8192\n\tds_read_b128 %4, %6 offset:12288"
+                         : "=&v"(bf[set]), "=&v"(af[set][0]), "=&v"(af[set][1]), "=&v"(af[set][2]), "=&v"(af[set][3])
+                         : "v"(fragB[kk] + bufofs), "v"(fragA[kk] + bufofs));
+        };
+        auto frag_wait = [&](int set) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[set]), "+v"(af[set][0]), "+v"(af[set][1]), "+v"(af[set][2]), "+v"(af[set][3]));
+        };
+        static_assert(32 * ROWB == 4096, "fragment offsets above are written for 128-byte staged rows");
+        dma(0);
+        int ct = 0, kb = 0;
+        for (int s = 0; s < nstage; ++s) {
+            const unsigned bufofs = (unsigned)(s & 1) * (2 * TILEB);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // own part of stage s has landed
+            __builtin_amdgcn_s_barrier();                               // everyone's has; everyone is done with the other buffer
+            asm volatile("" ::: "memory");
+            frag_read(0, 0, bufofs);
+            if (s + 1 < nstage) dma((s & 1) ^ 1);
+            frag_wait(0);
+#pragma unroll
+            for (int kk = 0; kk < S_BK / 8; ++kk) {
+                const int cur = kk & 1;
+                if (kk + 1 < S_BK / 8) frag_read(cur ^ 1, kk + 1, bufofs);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][m].x, bf[cur].x, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][m].y, bf[cur].y, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][m].z, bf[cur].z, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][m].w, bf[cur].w, acc[m], 0, 0, 0);
+                if (kk + 1 < S_BK / 8) frag_wait(cur ^ 1);
+            }
+            if (++kb == nkb) {
+                tile_epilogue(ct);
+                kb = 0;
+                ++ct;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
     gload();
     int ct = 0, kb = 0;
     for (int s = 0; s < nstage; ++s) {
@@ -395,65 +552,11 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
             for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf.w, acc[m], 0, 0, 0);
         }
         if (++kb == nkb) {
-            // ---- epilogue: d = (|x|^2 + |e|^2) - 2 x.e for this lane's 64 codes, fold into the list
-            const int cbase = code_lo + ct * S_BM;
-#ifdef MEDTOK_SEARCH_NOEPI        // dev experiment: main loop only (results are garbage)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                asm volatile("" ::"v"(acc[m]));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-            }
-#else
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                // |e|^2 of this lane's 16 codes of the tile: four consecutive codes per register group, so four 16-byte loads
-                // (+2.3 % at K = 16384, k = 5); a group that straddles K or sits on an unaligned slice takes the scalar form
-                // codes at or beyond the split's end get |e|^2 = +inf, i.e. d = +inf: never inserted, and no range test per value
-                float en[16];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c0 = cbase + 32 * m + 8 * g + 4 * lh;
-                    // (argmin, TOPK = 1: the 16 scalar loads measured 4 % faster than the vector form -- its epilogue is nothing else)
-                    if (TOPK > 1 && c0 + 3 < code_hi && ((reinterpret_cast<uintptr_t>(wsq + c0) & 15) == 0)) {
-                        const float4 e4 = ld4(wsq + c0);
-                        en[4 * g] = e4.x; en[4 * g + 1] = e4.y; en[4 * g + 2] = e4.z; en[4 * g + 3] = e4.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float e = wsq[min(c0 + j, k_codes - 1)];        // (unconditional load: a branch around it drains vmcnt)
-                            en[4 * g + j] = c0 + j < code_hi ? e : INFINITY;
-                        }
-                    }
-                }
-                // four codes per test: the smallest of their distances against the list's last entry, ONE wave-uniform branch; a
-                // quad in which some lane has a better code is then folded in value by value, in code order as before
-                // (ties -> lowest index).  (+0.6 % at k = 5; the argmin kernel keeps the per-value form: -0.5 % there.)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float dv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float sum = xn + en[4 * g + j];
-                        const float two = 2.0f * acc[m][4 * g + j];
-                        dv[j] = sum - two;
-                        acc[m][4 * g + j] = 0.f;
-                    }
-                    bool any = true;
-                    if (TOPK > 1) {
-                        const float mn = vs_min(vs_min3(dv[0], dv[1], dv[2]), dv[3]);      // (NaN never wins a v_min: a NaN distance is never inserted)
-                        any = __builtin_amdgcn_ballot_w64(mn < bv[TOPK - 1]) != 0;
-                    }
-                    if (any) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) topk_insert<TOPK>(bv, bi, dv[j], cbase + 32 * m + j + 8 * g + 4 * lh);
-                    }
-                }
-            }
-#endif
+            tile_epilogue(ct);
             kb = 0;
             ++ct;
         }
+    }
     }
 
     // ---- join the two half-waves that share an input row (disjoint code sets)
