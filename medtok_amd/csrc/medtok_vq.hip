@@ -447,11 +447,11 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
         // vmcnt(0) before every ds_read that follows a global_load_lds, but not after the raw-buffer form).  The descriptors
         // carry the valid byte range: rows past K or past n read as zeros instead of touching memory (such codes get
         // |e|^2 = +inf in the epilogue, such rows are never written back).
+        // The code-side descriptor is rebuilt per stage for the stage's code tile (base = the tile's first row, range = its rows
+        // inside K: a handful of SALU operations), so every offset stays far below 2^31 whatever K * D is.
         const float *abase_p = what + (long)code_lo * d, *bbase_p = xhat + row0 * d;
         const long rows_left = n - row0;
-        const int a_bytes = (k_codes - code_lo) * d * 4;                                  // < 2 GB: a code split's fp32 rows
         const int b_bytes = (int)(rows_left < S_BN ? rows_left : S_BN) * d * 4;
-        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)abase_p, 0, a_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)bbase_p, 0, b_bytes, 0x00020000);
         unsigned lane_off[4];
 #pragma unroll
@@ -464,10 +464,12 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
         auto dma = [&](int buf) __attribute__((always_inline)) {
             char *abase = lds + buf * 2 * TILEB + (wave_s * 32) * ROWB, *bbase = abase + TILEB;
             const int ub = __builtin_amdgcn_readfirstlane(pkb * S_BK * 4);
-            const int ua = __builtin_amdgcn_readfirstlane(pct * S_BM * d * 4 + pkb * S_BK * 4);       // a code split is < 2 GB
+            const int tile_codes = __builtin_amdgcn_readfirstlane(min(S_BM, k_codes - code_lo - pct * S_BM));
+            const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)(abase_p + (long)__builtin_amdgcn_readfirstlane(pct) * S_BM * d), 0,
+                                                                                 tile_codes * d * 4, 0x00020000);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void *)(abase + 8 * i * ROWB), 16, (int)lane_off[i], ua, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void *)(abase + 8 * i * ROWB), 16, (int)lane_off[i], ub, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void *)(bbase + 8 * i * ROWB), 16, (int)lane_off[i], ub, 0, 0);
             }
             if (++pkb == nkb) { pkb = 0; ++pct; }
