@@ -198,6 +198,18 @@ int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const
                                    int64_t n_codes, int64_t max_q_len, int d, float scale,
                                    float *out, void *stream);
 
+/* Around the core, for packed rows (no batch axis):
+ *   medtok_residual_layernorm_f32: the tail of CrossAttentionLayer.forward (vector_quantization_soft_one_new.py:47-50),
+ *     y[r] = LayerNorm(a[r] + b[r]) * gamma + beta  with nn.LayerNorm's biased variance and eps inside the square root
+ *     (a = the layer's input rows, b = out_proj(attended); dropout is the identity in eval).  d % 4 == 0, d <= 4096.
+ *   medtok_segment_mean_f32: `.mean(dim=0)` of each code's attended graph nodes (:140-141),
+ *     out[b] = sum of rows [seg_start[b], seg_start[b] + seg_len[b]) of x, added in row order, / max(seg_len[b], 1).
+ *     seg_start / seg_len are DEVICE int64[n_seg]; d % 4 == 0.  An empty segment gives a zero row. */
+int medtok_residual_layernorm_f32(const float *a, const float *b, const float *gamma, const float *beta,
+                                  int64_t n, int d, float eps, float *y, void *stream);
+int medtok_segment_mean_f32(const float *x, const int64_t *seg_start, const int64_t *seg_len, int64_t n_seg, int d,
+                            float *out, void *stream);
+
 /* The same core for TRAINING, and its backward: dropout on the attention probabilities (nn.MultiheadAttention(dropout=0.1),
  * reference :21,30) by a stateless hash mask of (seed, packed query row, key) -- P(keep) = 1 - dropout_p, kept probabilities
  * scaled by 1 / (1 - dropout_p); the forward also returns lse[r] = log sum_j exp(scale <q_r, kv_j>) (-inf for an empty key

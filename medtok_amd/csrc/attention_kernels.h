@@ -251,3 +251,71 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
         }
     }
 }
+
+// ---------------------------------------------------------------- around the core: residual + LayerNorm, node mean
+// CrossAttentionLayer's tail (vector_quantization_soft_one_new.py:47-50):  y[r] = LayerNorm(a[r] + b[r]) * gamma + beta  (biased
+// variance, eps inside the square root).  One wavefront per row; the row a + b stays in registers between the three passes
+// (mean, centred sum of squares, output), so HBM sees each operand once: 12 D bytes per row instead of the 20 D of an add kernel
+// followed by a LayerNorm kernel.  Lane l owns float4 #(l + 64 t): the per-lane sums run in increasing element order and meet in
+// the xor butterfly -- the order oracle_residual_layernorm_f32 restates.  d % 4 == 0, d <= 4096.
+constexpr int LN_MAXV = 16;
+__global__ __launch_bounds__(256) void residual_layernorm_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                 long n, int d, float eps, float *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int cpr = d >> 2;                                  // float4 chunks per row
+    const float *pa = a + row * d, *pb = b + row * d;
+    float4 v[LN_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+        const int c = lane + 64 * t;
+        if (c < cpr) {
+            const float4 x = ld4(pa + 4 * c), z = ld4(pb + 4 * c);
+            v[t] = make_float4(x.x + z.x, x.y + z.y, x.z + z.z, x.w + z.w);
+            sum += v[t].x; sum += v[t].y; sum += v[t].z; sum += v[t].w;
+        }
+    }
+    const float mean = wave_butterfly_sum(sum) / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+        if (lane + 64 * t < cpr) {
+            v[t].x -= mean; v[t].y -= mean; v[t].z -= mean; v[t].w -= mean;
+            sq = fmaf(v[t].x, v[t].x, sq); sq = fmaf(v[t].y, v[t].y, sq); sq = fmaf(v[t].z, v[t].z, sq); sq = fmaf(v[t].w, v[t].w, sq);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_butterfly_sum(sq) / (float)d + eps);
+    float *py = y + row * d;
+#pragma unroll
+    for (int t = 0; t < LN_MAXV; ++t) {
+        const int c = lane + 64 * t;
+        if (c < cpr) {
+            const float4 g = ld4(gamma + 4 * c), h = ld4(beta + 4 * c);
+            st4(py + 4 * c, make_float4(fmaf(v[t].x * rstd, g.x, h.x), fmaf(v[t].y * rstd, g.y, h.y), fmaf(v[t].z * rstd, g.z, h.z),
+                                        fmaf(v[t].w * rstd, g.w, h.w)));
+        }
+    }
+}
+
+// Mean of each code's attended graph nodes (:140-141): out[b] = (sum of rows [start[b], start[b] + len[b]) of x) / max(len[b], 1),
+// rows added in order (one fp32 chain per column: deterministic, no atomics, nothing padded).  Thread = one float4 column.
+__global__ __launch_bounds__(256) void segment_mean_kernel(const float *__restrict__ x, const int64_t *__restrict__ seg_start,
+                                                           const int64_t *__restrict__ seg_len, int d, float *__restrict__ out)
+{
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (4 * c >= d) return;
+    const long b = blockIdx.x, r0 = seg_start[b];
+    const int len = (int)seg_len[b];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *p = x + r0 * d + 4 * c;
+    for (int r = 0; r < len; ++r) {
+        const float4 v = ld4(p + (long)r * d);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float den = (float)(len > 1 ? len : 1);
+    st4(out + b * d + 4 * c, make_float4(acc.x / den, acc.y / den, acc.z / den, acc.w / den));
+}

@@ -1378,6 +1378,32 @@ extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_s
     return attention_forward(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, nullptr, 0.f, 0u, (hipStream_t)stream);
 }
 
+// the layer tail and the node mean around the attention core (attention_kernels.h)
+extern "C" int medtok_residual_layernorm_f32(const float *a, const float *b, const float *gamma, const float *beta, int64_t n, int d,
+                                             float eps, float *y, void *stream)
+{
+    if (n < 0 || d <= 0 || d % 4 != 0 || d > 4 * 64 * LN_MAXV) return fail("residual_layernorm: bad shape n=%ld d=%d (d %% 4 == 0, d <= %d)", (long)n, d, 4 * 64 * LN_MAXV);
+    if (!(eps >= 0.f)) return fail("residual_layernorm: eps=%g must be >= 0", (double)eps);
+    if (n == 0) return 0;
+    if (!a || !b || !gamma || !beta || !y) return fail("residual_layernorm: NULL argument");
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15) return fail("residual_layernorm: pointers must be 16-byte aligned");
+    if ((n + 3) / 4 >= (1ll << 31)) return fail("residual_layernorm: too many rows");
+    hipLaunchKernelGGL(residual_layernorm_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, gamma, beta, (long)n, d, eps, y);
+    return check_launch("residual_layernorm");
+}
+
+extern "C" int medtok_segment_mean_f32(const float *x, const int64_t *seg_start, const int64_t *seg_len, int64_t n_seg, int d, float *out,
+                                       void *stream)
+{
+    if (n_seg < 0 || d <= 0 || d % 4 != 0 || n_seg >= (1ll << 31)) return fail("segment_mean: bad shape n_seg=%ld d=%d (d %% 4 == 0)", (long)n_seg, d);
+    if (n_seg == 0) return 0;
+    if (!x || !seg_start || !seg_len || !out) return fail("segment_mean: NULL argument");
+    if (((uintptr_t)x | (uintptr_t)out) & 15) return fail("segment_mean: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(segment_mean_kernel, dim3((unsigned)n_seg, (unsigned)((d / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, seg_start,
+                       seg_len, d, out);
+    return check_launch("segment_mean");
+}
+
 extern "C" int medtok_shared_kv_attention_train_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
                                                     const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
                                                     int d, float scale, float dropout_p, uint32_t seed, float *out, float *lse, void *stream)

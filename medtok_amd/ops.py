@@ -277,6 +277,35 @@ def frobenius(x):
     return out
 
 
+def residual_layernorm(a, b, gamma, beta, eps: float):
+    """LayerNorm(a + b) * gamma + beta per row of the contiguous fp32 matrices a, b [n, d] (the tail of CrossAttentionLayer,
+    vector_quantization_soft_one_new.py:47-50); d % 4 == 0, d <= 4096."""
+    a, b, gamma, beta = _dev(a, "a"), _dev(b, "b"), _dev(gamma, "gamma"), _dev(beta, "beta")
+    if a.shape != b.shape or a.dim() != 2 or gamma.shape != (a.shape[1],) or beta.shape != (a.shape[1],):
+        raise ValueError(f"residual_layernorm: shapes a={tuple(a.shape)} b={tuple(b.shape)} gamma={tuple(gamma.shape)} beta={tuple(beta.shape)}")
+    n, d = a.shape
+    y = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().medtok_residual_layernorm_f32(a.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, d, float(eps),
+                                                             y.data_ptr(), _stream(a)), "medtok_residual_layernorm_f32")
+    return y
+
+
+def segment_mean(x, seg_start, seg_len):
+    """out[b] = mean of rows [seg_start[b], seg_start[b] + seg_len[b]) of the contiguous fp32 matrix x [rows, d] (rows added in
+    order; an empty segment gives zeros) -- the `.mean(dim=0)` over a code's graph nodes (:140-141).  seg_* int64 device vectors."""
+    x = _dev(x, "x")
+    seg_start, seg_len = _dev(seg_start, "seg_start", torch.int64), _dev(seg_len, "seg_len", torch.int64)
+    n_seg, d = seg_start.numel(), x.shape[1]
+    if seg_len.numel() != n_seg:
+        raise ValueError("segment_mean: seg_start and seg_len differ in length")
+    out = torch.empty((n_seg, d), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().medtok_segment_mean_f32(x.data_ptr(), seg_start.data_ptr(), seg_len.data_ptr(), n_seg, d, out.data_ptr(), _stream(x)),
+                   "medtok_segment_mean_f32")
+    return out
+
+
 def scale_by_device_scalar(x, num, den=None, c: float = 1.0):
     """x * (c * num / den) with num / den 0-dim device tensors (no host sync)."""
     x, num = _dev(x, "x"), _dev(num, "num")

@@ -159,7 +159,11 @@ class CrossAttention(nn.Module):
             qf = torch.einsum("rhd,hdk->rhk", q.view(n_rows, heads, hd), wk.view(heads, hd, dim)).reshape(n_rows * heads, dim)
             ctx = attend(qf.contiguous()).view(n_rows, heads, dim)
             attended = torch.einsum("rhk,hdk->rhd", ctx.to(wv.dtype) if torch.is_autocast_enabled() else ctx, wv.view(heads, hd, dim)).reshape(n_rows, dim) + bv
-        return layer.layer_norm(rows + layer.dropout(mha.out_proj(attended)))
+        ln = layer.layer_norm
+        if plain and not layer.training and rows.is_cuda and dim % 4 == 0 and dim <= 4096 and ln.elementwise_affine and ln.bias is not None:
+            # residual + LayerNorm in one pass over the rows (dropout is the identity in eval)
+            return ops.residual_layernorm(rows, mha.out_proj(attended), ln.weight, ln.bias, ln.eps)
+        return ln(rows + layer.dropout(mha.out_proj(attended)))
 
     def _pooled_packed(self, text, valid_len, nodes_sorted, batch_sorted, slot, counts, starts, max_nodes, core, autograd=False):
         """`pooled` with no padding anywhere: packed query rows, ragged attention core.
@@ -189,6 +193,8 @@ class CrossAttention(nn.Module):
         for layer in self.model:
             g = self._folded_rows(layer, g, lambda qf: core(qf, g_start, g_len, text_flat, tok_start, valid_len,
                                                             max_nodes * heads, scale))
+        if not autograd and not torch.is_grad_enabled() and g.is_cuda and g.dtype == torch.float32 and dim % 4 == 0:
+            return cur, ops.segment_mean(g, starts, counts)        # rows of a code are adjacent: one ordered chain per column
         padded = g.new_zeros(bsz, max_nodes, dim)
         padded[batch_sorted, slot] = g                     # deterministic mean (no atomics): pad, sum, divide
         return cur, padded.sum(1) / counts.clamp(min=1).unsqueeze(-1).to(g.dtype)

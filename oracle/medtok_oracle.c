@@ -601,3 +601,46 @@ int oracle_frobenius_f32(const float *x, int64_t rows, int d, float *out)
 }
 
 int oracle_abi_version(void) { return 1; }
+
+/* ---- around the attention core -----------------------------------------------------------------------
+ * CrossAttentionLayer's tail (vector_quantization_soft_one_new.py:47-50): y = LayerNorm(a + b) * gamma + beta, nn.LayerNorm's
+ * biased variance and eps inside the square root.  Summation order of the kernel: element i belongs to chain (i / 4) % 64,
+ * chains run in increasing i and meet in the xor butterfly (as canon_sumsq); the variance is that of the centred values. */
+int oracle_residual_layernorm_f32(const float *a, const float *b, const float *gamma, const float *beta, int64_t n, int d,
+                                  float eps, float *y)
+{
+    float *v = (float *)malloc(sizeof(float) * (size_t)d);
+    if (!v) return -2;
+    for (int64_t r = 0; r < n; ++r) {
+        float p[64], q[64];
+        for (int l = 0; l < 64; ++l) p[l] = 0.0f;
+        for (int i = 0; i < d; ++i) {
+            v[i] = a[r * d + i] + b[r * d + i];
+            p[(i >> 2) & 63] += v[i];
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ off];
+            memcpy(p, q, sizeof p);
+        }
+        const float mean = p[0] / (float)d;
+        for (int i = 0; i < d; ++i) v[i] -= mean;
+        const float rstd = 1.0f / sqrtf(canon_sumsq(v, d) / (float)d + eps);
+        for (int i = 0; i < d; ++i) y[r * d + i] = fmaf(v[i] * rstd, gamma[i], beta[i]);
+    }
+    free(v);
+    return 0;
+}
+
+/* `.mean(dim=0)` over each code's attended graph nodes (:140-141): rows added in order, one fp32 chain per column. */
+int oracle_segment_mean_f32(const float *x, const int64_t *seg_start, const int64_t *seg_len, int64_t n_seg, int d, float *out)
+{
+    for (int64_t b = 0; b < n_seg; ++b) {
+        const float den = (float)(seg_len[b] > 1 ? seg_len[b] : 1);
+        for (int c = 0; c < d; ++c) {
+            float acc = 0.0f;
+            for (int64_t r = 0; r < seg_len[b]; ++r) acc += x[(seg_start[b] + r) * d + c];
+            out[b * d + c] = acc / den;
+        }
+    }
+    return 0;
+}

@@ -218,6 +218,25 @@ def frobenius(x):
     return out[0]
 
 
+def residual_layernorm(a, b, gamma, beta, eps):
+    """LayerNorm(a + b) * gamma + beta per row (the tail of CrossAttentionLayer, vector_quantization_soft_one_new.py:47-50)."""
+    a, ap = _f(a); b, bp = _f(b); gamma, gp = _f(gamma); beta, bep = _f(beta)
+    y = np.empty_like(a)
+    assert lib().oracle_residual_layernorm_f32(ap, bp, gp, bep, C.c_int64(a.shape[0]), a.shape[1], C.c_float(eps), y.ctypes.data_as(_f32p)) == 0
+    return y
+
+
+def segment_mean(x, seg_start, seg_len):
+    """Mean of rows [seg_start[b], +seg_len[b]) of x per segment (`.mean(dim=0)` over a code's nodes, :140-141)."""
+    x, xp = _f(x)
+    ss = np.ascontiguousarray(seg_start, np.int64); sl = np.ascontiguousarray(seg_len, np.int64)
+    out = np.empty((len(ss), x.shape[1]), np.float32)
+    i64p = C.POINTER(C.c_int64)
+    assert lib().oracle_segment_mean_f32(xp, ss.ctypes.data_as(i64p), sl.ctypes.data_as(i64p), C.c_int64(len(ss)), x.shape[1],
+                                         out.ctypes.data_as(_f32p)) == 0
+    return out
+
+
 def ema_stats(zhat, idx, k_codes):
     """bins and embed_sum ([K,D]) of norm_ema_quantizer.py:194,202."""
     zhat, zp = _f(zhat); idx, ip = _i(idx)

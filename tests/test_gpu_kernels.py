@@ -290,3 +290,36 @@ def test_attention_train_forward_and_backward_match_oracle(oracle, dev, d, p):
     if p > 0:
         out3, _ = ops.shared_kv_attention_train(*args, int(q_len.max()), scale, p, seed + 1)
         assert not torch.equal(out3, out)
+
+
+@pytest.mark.parametrize("n,d", [(1, 4), (130, 768), (1000, 64), (7, 4096), (33, 132)])
+def test_residual_layernorm_bit_exact(oracle, dev, n, d):
+    """The tail of CrossAttentionLayer (residual + LayerNorm) in one kernel: the oracle restates its summation order."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(n + d)
+    a = rng.standard_normal((n, d), dtype=np.float32) * 3
+    b = rng.standard_normal((n, d), dtype=np.float32)
+    if n > 2:
+        a[1] = 0.0; b[1] = 0.0              # constant row: variance 0, eps alone under the root
+    g, h = rng.standard_normal(d, dtype=np.float32), rng.standard_normal(d, dtype=np.float32)
+    y = ops.residual_layernorm(_t(a, dev), _t(b, dev), _t(g, dev), _t(h, dev), 1e-5).cpu().numpy()
+    y_o = oracle.residual_layernorm(a, b, g, h, 1e-5)
+    assert np.array_equal(y, y_o)
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(a + b), (d,), torch.from_numpy(g), torch.from_numpy(h), 1e-5).numpy()
+    assert np.abs(y - ref).max() <= 4e-6 * max(np.abs(ref).max(), 1.0)
+    with pytest.raises(Exception):
+        ops.residual_layernorm(_t(a[:, :d - 1].copy(), dev), _t(b[:, :d - 1].copy(), dev), _t(g[:d - 1].copy(), dev), _t(h[:d - 1].copy(), dev), 1e-5)
+
+
+def test_segment_mean_bit_exact(oracle, dev):
+    from medtok_amd import ops
+    rng = np.random.default_rng(5)
+    length = np.array([3, 0, 200, 1, 17, 0], np.int64)
+    start = np.cumsum(length) - length
+    for d in (64, 768, 1028):
+        x = rng.standard_normal((int(length.sum()), d), dtype=np.float32)
+        out = ops.segment_mean(_t(x, dev), _t(start, dev), _t(length, dev)).cpu().numpy()
+        assert np.array_equal(out, oracle.segment_mean(x, start, length))
+        assert not out[1].any() and not out[5].any()            # empty segments: zero rows
+        assert np.abs(out[2] - x[start[2]:start[2] + 200].astype(np.float64).mean(0)).max() <= 1e-6
+    assert ops.segment_mean(_t(x, dev), _t(start[:0], dev), _t(length[:0], dev)).shape == (0, 1028)

@@ -207,3 +207,26 @@ def test_oracle_attention_backward_matches_torch_autograd(oracle):
     assert np.abs(out - ref.detach().numpy()).max() <= 1e-5
     assert np.abs(dq - qt.grad.numpy()).max() <= 1e-5 * np.abs(qt.grad.numpy()).max()
     assert np.abs(dkv - kt.grad.numpy()).max() <= 1e-5 * np.abs(kt.grad.numpy()).max()
+
+
+def test_oracle_layer_tail_and_node_mean_match_torch(oracle):
+    """The restatements of CrossAttentionLayer's residual + LayerNorm (vector_quantization_soft_one_new.py:47-50) and of the
+    node mean (:140-141) against torch's own ops on the CPU (summation orders differ: 1e-6)."""
+    import torch
+    rng = np.random.default_rng(11)
+    for n, d in ((37, 768), (5, 64), (3, 12)):
+        a = rng.standard_normal((n, d), dtype=np.float32) * 2
+        b = rng.standard_normal((n, d), dtype=np.float32)
+        ln = torch.nn.LayerNorm(d)
+        with torch.no_grad():
+            ln.weight.copy_(torch.from_numpy(rng.standard_normal(d, dtype=np.float32)))
+            ln.bias.copy_(torch.from_numpy(rng.standard_normal(d, dtype=np.float32)))
+            ref = ln(torch.from_numpy(a) + torch.from_numpy(b)).numpy()
+        got = oracle.residual_layernorm(a, b, ln.weight.detach().numpy(), ln.bias.detach().numpy(), ln.eps)
+        assert np.abs(got - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1.0) * 4
+    x = rng.standard_normal((50, 64), dtype=np.float32)
+    start, length = np.array([0, 7, 7, 30], np.int64), np.array([7, 0, 23, 20], np.int64)
+    got = oracle.segment_mean(x, start, length)
+    for b in range(4):
+        ref = x[start[b]:start[b] + length[b]].astype(np.float64).mean(0) if length[b] else np.zeros(64)
+        assert np.abs(got[b] - ref).max() <= 1e-6
