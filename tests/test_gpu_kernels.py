@@ -323,3 +323,25 @@ def test_segment_mean_bit_exact(oracle, dev):
         assert not out[1].any() and not out[5].any()            # empty segments: zero rows
         assert np.abs(out[2] - x[start[2]:start[2] + 200].astype(np.float64).mean(0)).max() <= 1e-6
     assert ops.segment_mean(_t(x, dev), _t(start[:0], dev), _t(length[:0], dev)).shape == (0, 1028)
+
+
+@pytest.mark.parametrize("topk", [1, 5])
+def test_exact_search_on_pointers_that_are_only_4_byte_aligned(oracle, dev, topk):
+    """The C ABI promises nothing beyond float alignment for the row matrices: views at an odd element offset (the LDS-DMA staging
+    and the 16-byte |e|^2 loads of the exact kernel must cope)."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(3)
+    n, k, d = 300, 700, 64
+    xh, xs = oracle.rownorm(rng.standard_normal((n, d), dtype=np.float32))
+    wh, ws = oracle.rownorm(rng.standard_normal((k, d), dtype=np.float32))
+    idx_o, dist_o = oracle.topk_search(xh, xs, wh, ws, topk)
+
+    def odd(a):                      # the same values behind a pointer that is 4 bytes past a 16-byte boundary
+        buf = torch.empty(a.size + 1, dtype=torch.float32, device=dev)
+        view = buf[1:].view(a.shape)
+        view.copy_(torch.from_numpy(a))
+        assert view.data_ptr() % 16 == 4
+        return view
+
+    idx, dist = ops.topk_search(odd(xh), odd(xs), odd(wh), odd(ws), topk, ops.PATH_F32_MFMA)
+    assert np.array_equal(dist.cpu().numpy(), dist_o) and np.array_equal(idx.cpu().numpy(), idx_o)
