@@ -13,7 +13,7 @@
 //   keys   : a chunk of 32 key rows is fetched with fully coalesced 16-byte loads (a thread's MFMA operands would be
 //            16 B out of every 128-byte line, re-fetching each line four times through a thrashing L1) and parked in
 //            LDS (row stride D + 4 floats: conflict-free for both operand shapes below) where both products read it.
-//            The next chunk's fetch is issued before the softmax step and stays in flight under the second product
+//            The next chunk's fetch is issued as soon as this one is parked and stays in flight under the whole iteration
 //            (barriers inside the loop are LDS-only: s_waitcnt lgkmcnt(0) + s_barrier, never a vmcnt drain);
 //   scores : each wave owns D / W columns, keeps its slice of the 32 query rows in registers for the block's lifetime
 //            and accumulates a partial 32 x 32 score tile per chunk; the W partials meet in LDS;
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
     float m_run = -INFINITY, l_run = 0.f;          // online-softmax state of row tid / TPR, replicated in its TPR threads
     for (int k0 = 0; k0 < kl; k0 += 32) {
         park();                                    // this chunk: registers -> LDS (the previous chunk's readers are past the loop-end barrier)
+        if (k0 + 32 < kl) fetch(k0 + 32);          // next chunk: in flight under the whole iteration
         lds_barrier();
 
         // ---- partial scores over this wave's D / W columns
@@ -168,7 +169,6 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
         lds_barrier();
-        if (k0 + 32 < kl) fetch(k0 + 32);          // next chunk: in flight under the softmax step and the second product
 
         // ---- join the W partials, online softmax: thread -> row tid / TPR, keys EPT (tid % TPR) .. + EPT - 1
         {
