@@ -461,18 +461,25 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
         }
         const int wave_s = __builtin_amdgcn_readfirstlane(wave);
         int pct = 0, pkb = 0;
-        auto dma = [&](int buf) __attribute__((always_inline)) {
-            char *abase = lds + buf * 2 * TILEB + (wave_s * 32) * ROWB, *bbase = abase + TILEB;
-            const int ub = __builtin_amdgcn_readfirstlane(pkb * S_BK * 4);
+        // One stage = eight DMA instructions per wave.  Issued as a burst they hold the wave (and, through the CU's one address
+        // path, its neighbours) at the head of the stage; instead the descriptor is prepared once per stage and the eight pieces
+        // go out one per group of four MFMAs of the stage's first two k steps.  Past the last stage the same stage is issued
+        // again into the buffer nobody reads (same bytes, harmless): no branch around a DMA.
+        __amdgpu_buffer_rsrc_t ars = brs;
+        int ub = 0;
+        char *abase = lds, *bbase = lds;
+        auto dma_prepare = [&](int buf) __attribute__((always_inline)) {
+            abase = lds + buf * 2 * TILEB + (wave_s * 32) * ROWB; bbase = abase + TILEB;
+            ub = __builtin_amdgcn_readfirstlane(pkb * S_BK * 4);
             const int tile_codes = __builtin_amdgcn_readfirstlane(min(S_BM, k_codes - code_lo - pct * S_BM));
-            const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)(abase_p + (long)__builtin_amdgcn_readfirstlane(pct) * S_BM * d), 0,
-                                                                                 tile_codes * d * 4, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void *)(abase + 8 * i * ROWB), 16, (int)lane_off[i], ub, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void *)(bbase + 8 * i * ROWB), 16, (int)lane_off[i], ub, 0, 0);
-            }
-            if (++pkb == nkb) { pkb = 0; ++pct; }
+            ars = __builtin_amdgcn_make_buffer_rsrc((void *)(abase_p + (long)__builtin_amdgcn_readfirstlane(pct) * S_BM * d), 0, tile_codes * d * 4, 0x00020000);
+            const bool wrap = pkb + 1 == nkb, more = !(wrap && pct + 1 == nct);
+            pkb = more ? (wrap ? 0 : pkb + 1) : pkb;
+            pct += (more && wrap) ? 1 : 0;
+        };
+        auto dma_piece = [&](int i) __attribute__((always_inline)) {          // i = 0..7: A rows 8 (i/2) .. of the wave's 32, then B rows
+            if (i & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void *)(bbase + 8 * (i >> 1) * ROWB), 16, (int)lane_off[i >> 1], ub, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void *)(abase + 8 * (i >> 1) * ROWB), 16, (int)lane_off[i >> 1], ub, 0, 0);
         };
         // fragment addresses: lane (li, lh) reads chunk 2 kk + lh of row li (+ 32 m) -- slot (2 kk + lh) ^ ((li >> 1) & 7).
         // The fragment reads are asm: hipcc orders a C++ ds_read behind ALL pending LDS-DMA ("s_waitcnt vmcnt(0)": a DMA is a pending
@@ -497,7 +504,9 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[set]), "+v"(af[set][0]), "+v"(af[set][1]), "+v"(af[set][2]), "+v"(af[set][3]));
         };
         static_assert(32 * ROWB == 4096, "fragment offsets above are written for 128-byte staged rows");
-        dma(0);
+        dma_prepare(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma_piece(i);
         int ct = 0, kb = 0;
         for (int s = 0; s < nstage; ++s) {
             const unsigned bufofs = (unsigned)(s & 1) * (2 * TILEB);
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
             __builtin_amdgcn_s_barrier();                               // everyone's has; everyone is done with the other buffer
             asm volatile("" ::: "memory");
             frag_read(0, 0, bufofs);
-            if (s + 1 < nstage) dma((s & 1) ^ 1);
+            dma_prepare((s & 1) ^ 1);
             frag_wait(0);
 #pragma unroll
             for (int kk = 0; kk < S_BK / 8; ++kk) {
@@ -513,12 +522,20 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
                 if (kk + 1 < S_BK / 8) frag_read(cur ^ 1, kk + 1, bufofs);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][m].x, bf[cur].x, acc[m], 0, 0, 0);
+                if (kk < 2) { dma_piece(4 * kk); asm volatile("" ::: "memory"); }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][m].y, bf[cur].y, acc[m], 0, 0, 0);
+                if (kk < 2) { dma_piece(4 * kk + 1); asm volatile("" ::: "memory"); }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][m].z, bf[cur].z, acc[m], 0, 0, 0);
+                if (kk < 2) { dma_piece(4 * kk + 2); asm volatile("" ::: "memory"); }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][m].w, bf[cur].w, acc[m], 0, 0, 0);
+                if (kk < 2) { dma_piece(4 * kk + 3); asm volatile("" ::: "memory"); }
+                if (kk < 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+                }
                 if (kk + 1 < S_BK / 8) frag_wait(cur ^ 1);
             }
             if (++kb == nkb) {
