@@ -10,12 +10,14 @@
 //
 // Block = (32 query rows of one code) x all of its keys, W = 8 waves (D % 256 == 0), 4 waves (other multiples of 128) or 2 waves (D = 64).  Both products run on the exact
 // fp32 matrix pipe (v_mfma_f32_32x32x2_f32, 157 TF peak) -- fp16/bf16 inputs would break the 1e-5 parity bar:
-//   keys   : a chunk of 32 key rows is fetched with fully coalesced 16-byte loads (a thread's MFMA operands would be
-//            16 B out of every 128-byte line, re-fetching each line four times through a thrashing L1) and parked in
-//            LDS (row stride D + 4 floats: conflict-free for both operand shapes below) where both products read it.
+//   keys   : each wave owns D / W columns of everything -- queries, keys, outputs -- so it fetches, parks and reads only its
+//            own column slice of a chunk of 32 key rows: full 128-byte lines per load (a thread's MFMA operands would be
+//            16 B out of every line, re-fetching each line four times through a thrashing L1), parked in the wave's own LDS
+//            slice (row stride 32 NT + 4 floats: conflict-free for both operand shapes below) where both products read it.
+//            No barrier guards the chunk buffer (a wave's LDS operations complete in order); the two barriers per chunk are
+//            those around the softmax step (LDS-only: s_waitcnt lgkmcnt(0) + s_barrier, never a vmcnt drain).
 //            The next chunk's fetch is woven into the score MFMAs of this one (one load per four MFMAs) and stays in flight
-//            under the softmax step and the second product
-//            (barriers inside the loop are LDS-only: s_waitcnt lgkmcnt(0) + s_barrier, never a vmcnt drain);
+//            under the softmax step and the second product;
 //   scores : each wave owns D / W columns, keeps its slice of the 32 query rows in registers for the block's lifetime
 //            and accumulates a partial 32 x 32 score tile per chunk; the W partials meet in LDS;
 //   softmax: online (running max / sum per row), 8 threads per row, exact expf;
@@ -69,15 +71,17 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
     float scale, float *__restrict__ out, int q_tiles, float *__restrict__ lse = nullptr, unsigned drop_thresh = 0, unsigned seed = 0,
     float keep_scale = 1.f)
 {
-    constexpr int D = 32 * W * NT, LD = D + 4;     // LDS row stride in floats
+    constexpr int D = 32 * W * NT;
+    constexpr int SL = 32 * NT + 4;                // LDS row stride of a wave's key slice in floats (conflict-free for both operand shapes)
+    constexpr int KV_FLOATS = W * 32 * SL;         // W private slices of 32 key rows
     constexpr int THREADS = 64 * W;
     constexpr int EPT = 1024 / THREADS;            // score elements per thread in the softmax step (4 or 2)
     constexpr int TPR = 32 / EPT;                  // threads per score row (8 or 16)
     extern __shared__ __attribute__((aligned(16))) float att_sm[];
-    float *kvs = att_sm;                                                              // [32][LD] current key chunk
-    float (*part)[32][33] = reinterpret_cast<float (*)[32][33]>(kvs + 32 * LD);       // [W][32][33] per-wave partial scores [row][key]
-    float (*pt)[33] = reinterpret_cast<float (*)[33]>(kvs + 32 * LD + W * 32 * 33);   // [32][33] probabilities, transposed [key][row]
-    float *alpha_s = kvs + 32 * LD + (W + 1) * 32 * 33, *l_s = alpha_s + 32;
+    float *kvs = att_sm;                                                              // [W][32][SL] current key chunk, one column slice per wave
+    float (*part)[32][33] = reinterpret_cast<float (*)[32][33]>(kvs + KV_FLOATS);       // [W][32][33] per-wave partial scores [row][key]
+    float (*pt)[33] = reinterpret_cast<float (*)[33]>(kvs + KV_FLOATS + W * 32 * 33);   // [32][33] probabilities, transposed [key][row]
+    float *alpha_s = kvs + KV_FLOATS + (W + 1) * 32 * 33, *l_s = alpha_s + 32;
     // 1-D grid: block id = code * q_tiles + query tile (the tiles of one code stay adjacent: they share its keys in the L2;
     // grid.y would cap a call at 65535 codes)
     const int b = (int)(blockIdx.x / (unsigned)q_tiles), qt = (int)(blockIdx.x % (unsigned)q_tiles);
@@ -88,26 +92,30 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int slice = wave * 32 * NT;      // this wave's D columns [slice, slice + 32 NT)
 
-    // key chunk fetch: FT = min(32, D/4) consecutive threads read one row's 16-byte columns (512 contiguous bytes at
-    // D >= 128), thread t owns columns (t % FT) + FT ci of rows (t / FT) + RP ri; every LDS / global offset below is a
-    // compile-time constant off one per-thread base; rows past the code's last key are clamped (their probabilities are zero)
-    constexpr int FT = D / 4 < 32 ? D / 4 : 32, CI = D / 4 / FT, RP = THREADS / FT, RI = 32 / RP, NF = RI * CI;
-    const int f_r0 = tid / FT, f_c = (tid % FT) * 4;
+    // Key chunk: every wave fetches, parks and reads ONLY its own column slice of the 32 key rows -- both products need nothing
+    // else -- so the chunk buffer carries no dependency between waves: no barrier after the park, none before the next one,
+    // and a wave that is done with a chunk parks the next while the others still multiply.  Lane (lr, lc) = (lane / 8, lane % 8)
+    // loads float4 #(8 ic + lc) of slice row 8 ir + lr for load i = (ir, ic) = (i / NT, i % NT): eight full 128-byte lines per
+    // wave instruction (the slice starts on a line: 128 NT bytes per wave).  Rows past the code's last key are clamped (their
+    // probabilities are zero); every LDS / global offset is a compile-time constant off a per-lane base.
+    constexpr int NF = 4 * NT;
+    const int lr = lane >> 3, lc = lane & 7;
+    float *kw = kvs + wave * 32 * SL;              // this wave's slice [32][SL]
     float4 kf[NF];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int ri = 0; ri < RI; ++ri) {
-            const float *src = kv + (ks + min(k0 + f_r0 + RP * ri, kl - 1)) * (long)D + f_c;
+        for (int ir = 0; ir < 4; ++ir) {
+            const float *src = kv + (ks + min(k0 + 8 * ir + lr, kl - 1)) * (long)D + slice + 4 * lc;
 #pragma unroll
-            for (int ci = 0; ci < CI; ++ci) kf[ri * CI + ci] = ld4(src + 4 * FT * ci);
+            for (int ic = 0; ic < NT; ++ic) kf[ir * NT + ic] = ld4(src + 32 * ic);
         }
     };
     auto park = [&]() {
-        float *dst = kvs + f_r0 * LD + f_c;
+        float *dst = kw + lr * SL + 4 * lc;
 #pragma unroll
-        for (int ri = 0; ri < RI; ++ri)
+        for (int ir = 0; ir < 4; ++ir)
 #pragma unroll
-            for (int ci = 0; ci < CI; ++ci) *reinterpret_cast<float4 *>(dst + RP * ri * LD + 4 * FT * ci) = kf[ri * CI + ci];
+            for (int ic = 0; ic < NT; ++ic) *reinterpret_cast<float4 *>(dst + 8 * ir * SL + 32 * ic) = kf[ir * NT + ic];
     };
     // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the key fetch that is meant to stay in
     // flight under the second product
@@ -133,15 +141,14 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
 
     float m_run = -INFINITY, l_run = 0.f;          // online-softmax state of row tid / TPR, replicated in its TPR threads
     for (int k0 = 0; k0 < kl; k0 += 32) {
-        park();                                    // this chunk: registers -> LDS (the previous chunk's readers are past the loop-end barrier)
+        park();                                    // this chunk: registers -> the wave's own slice (its own reads of the previous chunk are ahead in the same LDS queue)
         // next chunk: one 16-byte load per group of four score MFMAs below (NF = 4 NT loads, 4 NT groups), so that their issue
         // rides in the matrix pipe's shadow -- issued as one burst (12 wave-instructions x 8 waves through the CU's one address
-        // path) they held every wave for ~1 us per chunk: 9.36 -> 8.30 us per chunk at D = 768.  Rows past the last key are
-        // clamped (the loads stay unconditional; the last chunk re-reads one row).
-        const float *fsrc[RI];
+        // path) they held every wave for ~1 us per chunk: 9.36 -> 8.30 us per chunk at D = 768.  (The loads stay unconditional;
+        // past the last key they re-read one row.)
+        const float *fsrc[4];
 #pragma unroll
-        for (int ri = 0; ri < RI; ++ri) fsrc[ri] = kv + (ks + min(k0 + 32 + f_r0 + RP * ri, kl - 1)) * (long)D + f_c;
-        lds_barrier();
+        for (int ir = 0; ir < 4; ++ir) fsrc[ir] = kv + (ks + min(k0 + 32 + 8 * ir + lr, kl - 1)) * (long)D + slice + 4 * lc;
 
         // ---- partial scores over this wave's D / W columns
         f32x16 s;
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
         {
             // operands four groups (16 MFMAs ~ 1000 cycles of pipe) ahead of their use; the empty asm keeps hipcc from
             // hoisting every ds_read of the fully unrolled loop to the top
-            const float *krow = kvs + li * LD + slice + 4 * lh;
+            const float *krow = kw + li * SL + 4 * lh;
             float4 cur[4], nxt[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) cur[j] = *reinterpret_cast<const float4 *>(krow + 8 * j);
@@ -167,8 +174,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
                     s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g].y, cur[j].y, s, 0, 0, 0);
                     s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g].z, cur[j].z, s, 0, 0, 0);
                     s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[g].w, cur[j].w, s, 0, 0, 0);
-                    static_assert(NF == 4 * NT, "one load per MFMA group");
-                    kf[g] = ld4(fsrc[g / CI] + 4 * FT * (g % CI));
+                    kf[g] = ld4(fsrc[g / NT] + 32 * (g % NT));
                 }
                 asm volatile("" ::: "memory");
 #pragma unroll
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] *= a16[r];
-            const float *kcol = kvs + lh * LD + slice + li;
+            const float *kcol = kw + lh * SL + li;
             float pc, pn = 0.f, kc[NT], kn[NT];
             pc = pt[lh][li];
 #pragma unroll
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
                 if (s2 + 1 < 16) {
                     pn = pt[2 * (s2 + 1) + lh][li];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) kn[t] = kcol[2 * (s2 + 1) * LD + 32 * t];
+                    for (int t = 0; t < NT; ++t) kn[t] = kcol[2 * (s2 + 1) * SL + 32 * t];
                 }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pc, kc[t], acc[t], 0, 0, 0);
@@ -240,7 +246,8 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
                 for (int t = 0; t < NT; ++t) kc[t] = kn[t];
             }
         }
-        lds_barrier();                             // all reads of this chunk's keys / probabilities are done
+        // (no barrier here: the key slice is this wave's own, and the score / probability tiles are next written behind the
+        // two barriers of the next chunk)
     }
     if (tid % TPR == 0) {
         l_s[tid / TPR] = l_run;

@@ -1360,7 +1360,7 @@ static int attention_forward(const float *q, const int64_t *q_start, const int64
     const dim3 grid((unsigned)(q_tiles * n_codes));
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
     const int waves = d == 64 ? 2 : (d % 256 == 0 ? 8 : 4);
-    const size_t lds = ((size_t)32 * (d + 4) + (waves + 1) * 32 * 33 + 64) * sizeof(float);   // key chunk + per-wave partial scores + probabilities + row state
+    const size_t lds = ((size_t)32 * (d + 4 * waves) + (waves + 1) * 32 * 33 + 64) * sizeof(float);   // key chunk (one padded column slice per wave) + per-wave partial scores + probabilities + row state
     const unsigned thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
     const float keep_scale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
 #define MEDTOK_ATT(W, NT)                                                                                                        \
