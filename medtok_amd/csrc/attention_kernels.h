@@ -110,12 +110,11 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
             for (int ic = 0; ic < NT; ++ic) kf[ir * NT + ic] = ld4(src + 32 * ic);
         }
     };
-    auto park = [&]() {
-        float *dst = kw + lr * SL + 4 * lc;
+    // rows 8 ir .. 8 ir + 7 of the fetched chunk: registers -> the wave's slice
+    auto park_rows = [&](int ir) __attribute__((always_inline)) {
+        float *dst = kw + (8 * ir + lr) * SL + 4 * lc;
 #pragma unroll
-        for (int ir = 0; ir < 4; ++ir)
-#pragma unroll
-            for (int ic = 0; ic < NT; ++ic) *reinterpret_cast<float4 *>(dst + 8 * ir * SL + 32 * ic) = kf[ir * NT + ic];
+        for (int ic = 0; ic < NT; ++ic) *reinterpret_cast<float4 *>(dst + 32 * ic) = kf[ir * NT + ic];
     };
     // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the key fetch that is meant to stay in
     // flight under the second product
@@ -125,6 +124,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
         asm volatile("" ::: "memory");
     };
     if (kl > 0) fetch(0);
+    bool parked0 = false;
 
     // query slice of row (qt*32 + li): element 8g + 4 lh + j feeds MFMA step 4g + j (k index lh); keys use the same map
     float4 qf[4 * NT];
@@ -141,7 +141,12 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
 
     float m_run = -INFINITY, l_run = 0.f;          // online-softmax state of row tid / TPR, replicated in its TPR threads
     for (int k0 = 0; k0 < kl; k0 += 32) {
-        park();                                    // this chunk: registers -> the wave's own slice (its own reads of the previous chunk are ahead in the same LDS queue)
+        // The first chunk is parked here; every later one was parked during the second product of the chunk before it (below).
+        if (!parked0) {
+#pragma unroll
+            for (int ir = 0; ir < 4; ++ir) park_rows(ir);
+            parked0 = true;
+        }
         // next chunk: one 16-byte load per group of four score MFMAs below (NF = 4 NT loads, 4 NT groups), so that their issue
         // rides in the matrix pipe's shadow -- issued as one burst (12 wave-instructions x 8 waves through the CU's one address
         // path) they held every wave for ~1 us per chunk: 9.36 -> 8.30 us per chunk at D = 768.  (The loads stay unconditional;
@@ -241,10 +246,15 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pc, kc[t], acc[t], 0, 0, 0);
                 asm volatile("" ::: "memory");
+                // Step s2 was the last reader of key rows 2 s2, 2 s2 + 1 (the operands of step s2 + 1 are already in registers):
+                // once eight rows are dead the NEXT chunk's rows go into their place -- the park rides between the MFMAs instead
+                // of standing in front of the next chunk's (a wave's LDS operations complete in order; nobody else reads this slice).
+                if (s2 % 4 == 3 && s2 < 15) park_rows(s2 / 4);
                 pc = pn;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) kc[t] = kn[t];
             }
+            park_rows(3);
         }
         // (no barrier here: the key slice is this wave's own, and the score / probability tiles are next written behind the
         // two barriers of the next chunk)
