@@ -1500,36 +1500,82 @@ __global__ __launch_bounds__(256) void hist_kernel(const int64_t *__restrict__ i
         atomicAdd(&counts[clamp_code(idx[i], k_codes)], 1);
 }
 
-// exclusive scan of counts[0..k) -> offsets[0..k] (single block, fixed order).  Each thread owns a contiguous
-// chunk (a multiple of 4 entries, read as int4) so the two passes over the table are wide loads.
+// exclusive scan of counts[0..k) -> offsets[0..k] (single block, fixed order).  A thread owns 16 consecutive entries of each of
+// up to four 16384-entry slabs per pass (a wave's loads cover 4 KB of consecutive memory): per-thread sums, a shuffle scan inside
+// the wave, one scan of the 64 (slab, wave) totals by wave 0, then the entries are written with their running offsets.  (The first
+// form gave every thread one long contiguous chunk -- 64 lanes 256 bytes apart -- and took 30-40 us for the 65536-entry digit
+// table of a radix pass.)
 __global__ __launch_bounds__(1024) void scan_kernel(const int *__restrict__ counts, int k, int *__restrict__ offsets)
 {
-    __shared__ int part[1024];
-    const int per = ((k + 1023) / 1024 + 3) & ~3;
-    const int lo = min(k, (int)threadIdx.x * per), hi = min(k, lo + per);
+    constexpr int PER = 16, SLABS = 4;
+    __shared__ int wave_tot[SLABS * 16], wave_pre[SLABS * 16], carry_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool vec = ((reinterpret_cast<uintptr_t>(counts) | reinterpret_cast<uintptr_t>(offsets)) & 15) == 0;
-    int s = 0;
-    int i = lo;
-    if (vec) for (; i + 4 <= hi; i += 4) { const int4 v = *reinterpret_cast<const int4 *>(counts + i); s += v.x + v.y + v.z + v.w; }
-    for (; i < hi; ++i) s += counts[i];
-    part[threadIdx.x] = s;
+    if (t == 0) carry_s = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = ((int)threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+    for (int base = 0; base < k; base += SLABS * 1024 * PER) {
+        int v[SLABS][PER], incl[SLABS], sum[SLABS];
+#pragma unroll
+        for (int j = 0; j < SLABS; ++j) {
+            const int start = base + (j * 1024 + t) * PER;
+            if (vec && start + PER <= k) {
+#pragma unroll
+                for (int c = 0; c < PER / 4; ++c) {
+                    const int4 q = *reinterpret_cast<const int4 *>(counts + start + 4 * c);
+                    v[j][4 * c] = q.x; v[j][4 * c + 1] = q.y; v[j][4 * c + 2] = q.z; v[j][4 * c + 3] = q.w;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < PER; ++c) v[j][c] = start + c < k ? counts[start + c] : 0;
+            }
+            int sm = 0;
+#pragma unroll
+            for (int c = 0; c < PER; ++c) sm += v[j][c];
+            sum[j] = sm;
+            int in = sm;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(in, off, 64);
+                if (lane >= off) in += o;
+            }
+            incl[j] = in;
+            if (lane == 63) wave_tot[j * 16 + wave] = in;
+        }
         __syncthreads();
-        part[threadIdx.x] += v;
+        if (t < 64) {                                   // the 64 (slab, wave) totals in order
+            const int carry = carry_s;                  // (only this wave touches carry_s inside the loop: read, then written below, in program order)
+            const int x = wave_tot[t];
+            int in = x;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(in, off, 64);
+                if (lane >= off) in += o;
+            }
+            wave_pre[t] = carry + in - x;
+            if (t == 63) carry_s = carry + in;
+        }
         __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SLABS; ++j) {
+            const int start = base + (j * 1024 + t) * PER;
+            int run = wave_pre[j * 16 + wave] + incl[j] - sum[j];
+            if (vec && start + PER <= k) {
+#pragma unroll
+                for (int c = 0; c < PER / 4; ++c) {
+                    int4 o;
+                    o.x = run; o.y = o.x + v[j][4 * c]; o.z = o.y + v[j][4 * c + 1]; o.w = o.z + v[j][4 * c + 2];
+                    run = o.w + v[j][4 * c + 3];
+                    *reinterpret_cast<int4 *>(offsets + start + 4 * c) = o;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < PER; ++c)
+                    if (start + c < k) { offsets[start + c] = run; run += v[j][c]; }
+            }
+        }
+        __syncthreads();                                // wave_tot / wave_pre are reused by the next pass
     }
-    int run = part[threadIdx.x] - s;
-    i = lo;
-    if (vec) for (; i + 4 <= hi; i += 4) {
-        const int4 v = *reinterpret_cast<const int4 *>(counts + i);
-        int4 o; o.x = run; o.y = run + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
-        run = o.w + v.w;
-        *reinterpret_cast<int4 *>(offsets + i) = o;
-    }
-    for (; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
-    if (threadIdx.x == 1023) offsets[k] = part[1023];
+    if (t == 0) offsets[k] = carry_s;
 }
 
 __device__ __forceinline__ void wave_chunk(long n, int gw, long &lo, long &hi)
