@@ -1192,7 +1192,16 @@ __global__ __launch_bounds__(1024) void sum_scale_kernel(const float *__restrict
 {
     __shared__ double sh[1024];
     double a = 0.0;
-    for (long i = threadIdx.x; i < n; i += 1024) a += (double)v[i];
+    long i = threadIdx.x;
+    // same order of additions as the plain loop; eight loads in flight per thread instead of one (one block: latency-bound)
+    for (; i + 7 * 1024 < n; i += 8 * 1024) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = v[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += (double)x[u];
+    }
+    for (; i < n; i += 1024) a += (double)v[i];
     sh[threadIdx.x] = a;
     __syncthreads();
     for (int off = 512; off >= 1; off >>= 1) {
