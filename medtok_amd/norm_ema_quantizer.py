@@ -27,12 +27,13 @@ class _L2NormFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t):
         flat = t.detach().reshape(-1, t.shape[-1]).float()
-        that, _ = ops.rownorm(flat)
+        that, sq = ops.rownorm(flat)          # sq = |that|^2 per row, in the kernel's summation order: what the search consumes
         ctx.save_for_backward(t, that)
-        return that.view(t.shape)
+        ctx.mark_non_differentiable(sq)
+        return that.view(t.shape), sq
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_sq=None):
         t, that = ctx.saved_tensors
         that = that.view(t.shape)
         nrm = t.norm(dim=-1, keepdim=True).clamp_min(1e-12)
@@ -41,6 +42,11 @@ class _L2NormFunction(torch.autograd.Function):
 
 def l2norm(t):
     """x / max(||x||, 1e-12) along the last dim (reference :8-9)."""
+    return _L2NormFunction.apply(t)[0]
+
+
+def l2norm_with_sq(t):
+    """(l2norm(t), the squared norms of its rows [numel / D]) from ONE pass of the rownorm kernel."""
     return _L2NormFunction.apply(t)
 
 
@@ -134,7 +140,7 @@ class NormEMAVectorQuantizer(nn.Module):
         b, c, h, w = z.shape
         # 'b c h w -> b h w c' (reference :169); for the usual [N, D, 1, 1] input this is a view
         z = z.permute(0, 2, 3, 1)
-        z = l2norm(z)
+        z, zsq = l2norm_with_sq(z)                          # the rows' |z|^2 come out of the same pass (no second read of z)
         z_flat = z.reshape(-1, self.codebook_dim)
         zd = z_flat.detach()
         n = zd.shape[0]
@@ -142,7 +148,6 @@ class NormEMAVectorQuantizer(nn.Module):
         self.embedding.init_embed_(zd)
         E = self.embedding.weight.data                      # stored normalised, NOT re-normalised (:175-177)
         _, esq = ops.rownorm(E, normalize=False, want_xhat=False)
-        _, zsq = ops.rownorm(zd, normalize=False, want_xhat=False)
         idx2, _ = ops.topk_search(zd, zsq, E, esq, 1, self.search_path)
         encoding_indices = idx2.view(-1)
         # gather BEFORE the EMA update (:181)
