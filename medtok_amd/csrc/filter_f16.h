@@ -430,19 +430,6 @@ __device__ __forceinline__ void lds_init_wait(f32x16 (&a)[4][2])
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(a[2][0]), "+v"(a[3][0]));
 }
 
-// Fragment reads of the main loop as asm (MEDTOK_FILTER_ASMREAD): hipcc never sees an LDS read that a pending LDS-DMA could alias,
-// so the loop's control flow can be arranged freely without `s_waitcnt vmcnt(0)` appearing between the DMA issues; the price is
-// that the lgkmcnt waits are placed by hand (frag_wait below: at every MFMA pair exactly five younger reads are outstanding).
-template <int OFF>
-__device__ __forceinline__ void frag_read128(half8 &dst, unsigned addr)
-{
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-__device__ __forceinline__ void frag_wait5(half8 &a, half8 &b0, half8 &b1)
-{
-    asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a), "+v"(b0), "+v"(b1));
-}
-
 // ---------------------------------------------------------------- the filter kernel
 // (Rejected variant, measured 14-24 % slower: 4-wave blocks of 256 codes x 128 rows, two per CU, hoping that co-resident
 // blocks drifting apart overlap one block's epilogue / DMA issue with the other's MFMAs -- it moves 1.5 x the L2 -> LDS
@@ -554,27 +541,6 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         ptile += (more && wrap) ? 1 : 0;
     };
 
-    // The same in five parts (MEDTOK_FILTER_ASMREAD): the stage's offsets are fixed first, then its four instructions go out one
-    // per pair of MFMAs of a k16 step.
-    char *sp_base = fsm;
-    int sp_ua = 0, sp_ub = 0;
-    auto stage_prepare = [&]() __attribute__((always_inline)) {
-        sp_base = fsm + (pidx & (F_RING - 1)) * F_STAGEB + wave_lds;
-        sp_ua = __builtin_amdgcn_readfirstlane(ptile * tile_bytes + pkb * F_BK * 2);
-        sp_ub = __builtin_amdgcn_readfirstlane(pkb * F_BK * 2);
-        const bool more = pidx + 1 < nstage;
-        const bool wrap = pkb + 1 == nkb;
-        pidx += more ? 1 : 0;
-        pkb = more ? (wrap ? 0 : pkb + 1) : pkb;
-        ptile += (more && wrap) ? 1 : 0;
-    };
-    auto stage_piece = [&](int i) __attribute__((always_inline)) {      // i = 0..3: code rows 0-15, x rows 0-15, code rows 16-31, x rows 16-31 of the wave's 32
-        const int q = i >> 1;
-        if (i & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(sp_base + F_TILEB + q * 16 * F_ROWB), 16, (int)lane_off[q], sp_ub, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(sp_base + q * 16 * F_ROWB), 16, (int)lane_off[q], sp_ua, 0, 0);
-        asm volatile("" ::: "memory");
-    };
-
     // start values of code tile `tile` -> LDS buffer tile & 1 (wave 0; an ordinary member of its in-order DMA stream)
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(wsqs + code_lo), 0, -1, 0x00020000);
     auto stage_init = [&](int tile) __attribute__((always_inline)) {
@@ -650,30 +616,6 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // FIRST = the first k16 step of a code tile: only the FIRST row tile's accumulators hold the start values; the second row
     // tile's MFMA reads them from there as its C operand (D != C), then the first row tile's MFMA runs in place.  A restart
     // therefore loads 16 registers per group, not 32, and copies nothing.
-#ifdef MEDTOK_FILTER_ASMREAD
-    static_assert(F_MT == 4 && F_NT == 2, "the asm step is written out for four code groups and two row tiles");
-    const unsigned fsm0 = (unsigned)(size_t)fsm;
-    auto step = [&](half8 (&fb_cur)[F_NT], half8 (&fb_nxt)[F_NT], int slot, int t, auto first, auto piece_base) __attribute__((always_inline)) {
-        constexpr bool FIRST = decltype(first)::value;
-        constexpr int PB = decltype(piece_base)::value;       // DMA pieces PB, PB + 1 go out behind groups 1 and 3
-        const unsigned sa = fsm0 + (unsigned)(slot * F_STAGEB + a_adr[t]), sb = fsm0 + (unsigned)(slot * F_STAGEB + b_adr[t]);
-        frag_read128<0>(fb_nxt[0], sb);
-        frag_read128<32 * F_ROWB>(fb_nxt[1], sb);
-#define F_STEP_GROUP(M)                                                                                              \
-        frag_wait5(fa[M], fb_cur[0], fb_cur[1]);                                                                     \
-        if (FIRST) {                                                                                                 \
-            acc[M][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[M], fb_cur[1], acc[M][0], 0, 0, 0);               \
-            acc[M][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[M], fb_cur[0], acc[M][0], 0, 0, 0);               \
-        } else {                                                                                                     \
-            acc[M][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[M], fb_cur[0], acc[M][0], 0, 0, 0);               \
-            acc[M][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[M], fb_cur[1], acc[M][1], 0, 0, 0);               \
-        }                                                                                                            \
-        if ((M) & 1) stage_piece(PB + ((M) >> 1));                                                                   \
-        frag_read128<(M) * 32 * F_ROWB>(fa[M], sa);
-        F_STEP_GROUP(0) F_STEP_GROUP(1) F_STEP_GROUP(2) F_STEP_GROUP(3)
-#undef F_STEP_GROUP
-    };
-#else
     auto step = [&](const half8 (&fb_cur)[F_NT], half8 (&fb_nxt)[F_NT], int slot, int t, auto first) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first)::value;
 #ifndef MEDTOK_FILTER_NOLDS
@@ -698,7 +640,6 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 #endif
         }
     };
-#endif
 
     // The scan of a finished code tile: all four groups of the wave.
     unsigned long multi = 0;             // wave-uniform: some lane had a second passing value in one quad (filter_hit)
@@ -787,18 +728,9 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#ifdef MEDTOK_FILTER_ASMREAD
-    frag_read128<0>(fbA[0], fsm0 + (unsigned)b_adr[0]);
-    frag_read128<32 * F_ROWB>(fbA[1], fsm0 + (unsigned)b_adr[0]);
-    frag_read128<0>(fa[0], fsm0 + (unsigned)a_adr[0]);
-    frag_read128<32 * F_ROWB>(fa[1], fsm0 + (unsigned)a_adr[0]);
-    frag_read128<64 * F_ROWB>(fa[2], fsm0 + (unsigned)a_adr[0]);
-    frag_read128<96 * F_ROWB>(fa[3], fsm0 + (unsigned)a_adr[0]);
-#else
     read_b(fbA, 0, 0);
 #pragma unroll
     for (int m = 0; m < F_MT; ++m) read_a(m, 0, 0);
-#endif
     // The two waves of a SIMD (w and w + 4) issue their LDS-DMA at different points of the stage: an issuing wave is
     // held for ~100 cycles per instruction, and in lockstep both would leave the matrix pipe idle at the same time
     // (+2.5-3 % measured).  Either way a wave has issued all of stage s+3 between the waits of iterations s and s+1,
@@ -809,31 +741,13 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // -1.5 % when given to the older half instead; flips around the MFMA groups measured -1 %).
     if (late) __builtin_amdgcn_s_setprio(3);
 
-#ifdef MEDTOK_FILTER_ASMREAD
-    // One iteration = the two k16 steps of stage s with the stage barrier between them.  Slot s-1 is free for EVERY wave from the
-    // start of iteration s (its last readers ran before the barrier of iteration s-1), so all waves run one program: the four DMA
-    // instructions of stage s+3 go out one behind every second MFMA pair of the whole iteration -- two before the barrier, two
-    // after it -- and nobody issues a burst (an issuing wave is held for ~100 cycles per instruction).  At the stage wait a wave
-    // has stage s+1, stage s+2 and half of stage s+3 in flight: vmcnt(6).
-    auto iteration = [&](int s, auto first) __attribute__((always_inline)) {
-        stage_prepare();
-        step(fbA, fbB, s & (F_RING - 1), 1, first, std::integral_constant<int, 0>{});
-        __builtin_amdgcn_s_waitcnt(LGKM0);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        step(fbB, fbA, (s + 1) & (F_RING - 1), 0, std::false_type{}, std::integral_constant<int, 2>{});
-    };
-#else
     // first half of an iteration: MFMA(s, t0) with the operand reads of (s, t1) between them, then the stage barrier
     auto first_half = [&](int s, auto first) __attribute__((always_inline)) {
         if (late && s > 0) stage();         // waves 4-7: stage s+2 (slot s-2, free since the barrier of iteration s-1)
         step(fbA, fbB, s & (F_RING - 1), 1, first);
-#ifndef MEDTOK_FILTER_ASMREAD
         __builtin_amdgcn_sched_group_barrier(0x100, F_NT, 0);
 #pragma unroll
         for (int i = 0; i < F_MT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, F_NT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-#endif
         // the next step's operands have landed; own part of stage s+1 has landed; then everyone's has
         __builtin_amdgcn_s_waitcnt(LGKM0);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -847,17 +761,12 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     auto second_half = [&](int s) __attribute__((always_inline)) {
         step(fbB, fbA, (s + 1) & (F_RING - 1), 0, std::false_type{});
         // after the barrier the matrix pipe restarts at once; DMA issue and operand reads ride between MFMAs
-#ifndef MEDTOK_FILTER_ASMREAD
         __builtin_amdgcn_sched_group_barrier(0x100, F_NT, 0);
 #pragma unroll
         for (int i = 0; i < F_MT; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, F_NT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
-#else
-#pragma unroll
-        for (int i = 0; i < F_MT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, F_NT, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-#endif
     };
 
     // every group switches code tiles together: the scan of all four runs at the end of the tile's last stage
@@ -868,7 +777,6 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 #endif
         second_half(s);
     };
-#endif
     int s = 0;
     for (int ct = 0; ct < nct; ++ct) {
         iteration(s, std::true_type{});
