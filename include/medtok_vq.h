@@ -262,6 +262,15 @@ int medtok_usage_update(float *window, int64_t window_len, const int64_t *ids, i
                         int64_t n_codes, int32_t *count_out, void *ws, size_t ws_bytes,
                         void *stream);
 
+/* The head of NormEMAVectorQuantizer.forward (norm_ema_quantizer.py:169-179) in one call: zhat = F.normalize(z) [n, d], its squared
+ * norms zsq [n], and the topk nearest rows of the codebook (what, wsq as for medtok_topk_search_f32; topk = 1 is the reference's
+ * argmin).  Same bits as medtok_rownorm_f32 followed by medtok_topk_search_f32; on the fp16-shortlist path the normalising pass
+ * also writes the fp16 image the shortlist streams (one pass over z less). */
+size_t medtok_normalized_search_workspace_bytes(int64_t n, int64_t k_codes, int d, int topk, int path);
+int medtok_normalized_search_f32(const float *z, int64_t n, int d, const float *what, const float *wsq,
+                                 int64_t k_codes, int topk, int path, float *zhat, float *zsq, int64_t *idx,
+                                 float *dist, void *ws, size_t ws_bytes, void *stream);
+
 /* One-call forward of VectorQuantizer.specific_embedding / the search half of
  * get_shared_info (vector_quantization_soft_one_new.py:147-182,194-214) for
  * rows x [n, d] against an already normalised codebook slice:

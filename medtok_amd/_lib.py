@@ -68,6 +68,8 @@ SIGNATURES = {
     "medtok_ema_cluster_size_f32": (_int, [_vp, _vp, _i64, _f, _f, _vp]),
     "medtok_usage_workspace_bytes": (_sz, [_i64, _i64]),
     "medtok_usage_update": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "medtok_normalized_search_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int]),
+    "medtok_normalized_search_f32": (_int, [_vp, _i64, _int, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "medtok_soft_vq_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int]),
     "medtok_soft_vq_forward_f32": (_int, [_vp, _i64, _int, _vp, _vp, _i64, _int, _int,
                                           _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),

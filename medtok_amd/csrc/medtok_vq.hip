@@ -1907,6 +1907,39 @@ extern "C" int medtok_usage_update(float *window, int64_t window_len, const int6
 }
 
 // ================================================================= one-call soft VQ forward
+// l2norm + nearest codes in one call (the head of NormEMAVectorQuantizer.forward): on the filter path the fp16 image of the
+// normalised rows that the shortlist pass streams comes out of the pass that normalises them (one read of z less).
+extern "C" size_t medtok_normalized_search_workspace_bytes(int64_t n, int64_t k_codes, int d, int topk, int path)
+{
+    return medtok_search_workspace_bytes(n, k_codes, d, topk, path);
+}
+
+extern "C" int medtok_normalized_search_f32(const float *z, int64_t n, int d, const float *what, const float *wsq, int64_t k_codes, int topk,
+                                            int path, float *zhat, float *zsq, int64_t *idx, float *dist, void *ws, size_t ws_bytes,
+                                            void *stream)
+{
+    if (n < 0 || k_codes <= 0 || d <= 0 || (d & 3)) return fail("normalized_search: bad shape n=%ld K=%ld d=%d (d %% 4 == 0)", (long)n, (long)k_codes, d);
+    if (n == 0) return 0;
+    if (!z || !zhat || !zsq || !what || !wsq || !idx || !dist) return fail("normalized_search: NULL argument");
+    FuseAssign fuse = {nullptr, nullptr, nullptr, 0L, false, nullptr, nullptr, false};
+    const bool filter_path = topk >= 1 && topk <= MEDTOK_MAX_TOPK && k_codes < (1ll << 31) && n < (1ll << 31) &&
+                             resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER;
+    if (filter_path) {
+        const FilterPlan f = plan_filter(n, k_codes, d, topk);
+        const FilterWs fw = filter_ws_layout(ws, n, f);
+        if (!ws || ws_bytes < fw.total) return fail("normalized_search: workspace too small (%zu < %zu)", ws_bytes, fw.total);
+        hipStream_t s = (hipStream_t)stream;
+        hipLaunchKernelGGL(rownorm_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, z, (long)n, d, zhat, zsq, fw.xh, f.dp);
+        if (f.n_pad > n && hipMemsetAsync(fw.xh + (size_t)n * f.dp, 0, (size_t)(f.n_pad - n) * f.dp * 2, s) != hipSuccess)
+            return fail("normalized_search: memset failed");
+        if (check_launch("rownorm(+fp16)")) return 1;
+        fuse.xh_done = true;
+    } else if (medtok_rownorm_f32(z, n, d, 1, zhat, zsq, stream)) {
+        return 1;
+    }
+    return search_impl(zhat, zsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, path, stream, filter_path ? &fuse : nullptr);
+}
+
 extern "C" size_t medtok_soft_vq_workspace_bytes(int64_t n, int64_t k_codes, int d, int topk, int path)
 {
     if (n <= 0) return 256;

@@ -126,6 +126,7 @@ class NormEMAVectorQuantizer(nn.Module):
         if statistic_code_usage:
             self.register_buffer("cluster_size", torch.zeros(n_embed))
         # like the reference (:155-159) the choice is made once, at construction time
+        self.fused_head = True           # l2norm + search in one library call where no autograd graph is needed (forward)
         if distributed.is_available() and distributed.is_initialized():
             self.all_reduce_fn = distributed.all_reduce
         else:
@@ -140,18 +141,29 @@ class NormEMAVectorQuantizer(nn.Module):
         b, c, h, w = z.shape
         # 'b c h w -> b h w c' (reference :169); for the usual [N, D, 1, 1] input this is a view
         z = z.permute(0, 2, 3, 1)
-        z, zsq = l2norm_with_sq(z)                          # the rows' |z|^2 come out of the same pass (no second read of z)
-        z_flat = z.reshape(-1, self.codebook_dim)
-        zd = z_flat.detach()
-        n = zd.shape[0]
-
-        self.embedding.init_embed_(zd)
-        E = self.embedding.weight.data                      # stored normalised, NOT re-normalised (:175-177)
-        _, esq = ops.rownorm(E, normalize=False, want_xhat=False)
-        idx2, _ = ops.topk_search(zd, zsq, E, esq, 1, self.search_path)
+        need_grad = torch.is_grad_enabled() and z.requires_grad
+        # (`if self.initted` in init_embed_ is a host read in the reference too: done once here)
+        initted = bool(self.embedding.initted)
+        if self.fused_head and not need_grad and initted and z.is_cuda and z.dtype == torch.float32:
+            # l2norm and the nearest-code search in ONE library call: on the fp16-shortlist path the normalising pass also writes
+            # the fp16 image the shortlist streams (same bits as the two calls of the other branch)
+            E = self.embedding.weight.data                  # stored normalised, NOT re-normalised (:175-177)
+            _, esq = ops.rownorm(E, normalize=False, want_xhat=False)
+            zd, zsq, idx2, _ = ops.normalized_search(z.reshape(-1, self.codebook_dim), E, esq, 1, self.search_path)
+            z_flat = zd
+            n = zd.shape[0]
+        else:
+            z, zsq = l2norm_with_sq(z)                      # the rows' |z|^2 come out of the same pass (no second read of z)
+            z_flat = z.reshape(-1, self.codebook_dim)
+            zd = z_flat.detach()
+            n = zd.shape[0]
+            if not initted:
+                self.embedding.init_embed_(zd)
+            E = self.embedding.weight.data
+            _, esq = ops.rownorm(E, normalize=False, want_xhat=False)
+            idx2, _ = ops.topk_search(zd, zsq, E, esq, 1, self.search_path)
         encoding_indices = idx2.view(-1)
         # gather BEFORE the EMA update (:181)
-        need_grad = torch.is_grad_enabled() and z_flat.requires_grad
         if need_grad:
             _, zq, _ = ops.soft_assign(zd, E, encoding_indices, None, hard=True, want_w=False, want_sqerr=False, raw=True)
         else:   # straight-through value and squared error in the same pass

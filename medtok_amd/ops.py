@@ -447,6 +447,26 @@ def usage_update_(window: torch.Tensor, ids: torch.Tensor, n_codes: int) -> torc
     return count
 
 
+def normalized_search(z, what, wsq, topk: int = 1, path: int = PATH_AUTO):
+    """(zhat, |zhat|^2, idx [n, topk], dist [n, topk]): F.normalize(z) and its nearest codes in one C call -- the head of
+    NormEMAVectorQuantizer.forward (norm_ema_quantizer.py:169-179).  Same bits as rownorm() + topk_search()."""
+    z, what, wsq = _dev(z, "z"), _dev(what, "what"), _dev(wsq, "wsq")
+    n, d = z.shape
+    k = what.shape[0]
+    lib = _lib.load()
+    dev = z.device
+    zhat = torch.empty_like(z)
+    zsq = torch.empty(n, dtype=torch.float32, device=dev)
+    idx = torch.empty((n, topk), dtype=torch.int64, device=dev)
+    dist = torch.empty((n, topk), dtype=torch.float32, device=dev)
+    ws = _ws(lib.medtok_normalized_search_workspace_bytes(n, k, d, topk, path), z)
+    with torch.cuda.device(dev):
+        _lib.check(lib.medtok_normalized_search_f32(z.data_ptr(), n, d, what.data_ptr(), wsq.data_ptr(), k, topk, path, zhat.data_ptr(),
+                                                    zsq.data_ptr(), idx.data_ptr(), dist.data_ptr(), ws.data_ptr(), ws.numel(), _stream(z)),
+                   "medtok_normalized_search_f32")
+    return zhat, zsq, idx, dist
+
+
 def soft_vq_forward(x, what, wsq, topk: int, path: int = PATH_AUTO, want_sqerr: bool = True, out=None):
     """rownorm -> search -> soft assign in one C call.
     Returns dict(xhat, idx, dist, w, zq, row_sqerr); `out` as in soft_assign."""

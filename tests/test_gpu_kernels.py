@@ -345,3 +345,20 @@ def test_exact_search_on_pointers_that_are_only_4_byte_aligned(oracle, dev, topk
 
     idx, dist = ops.topk_search(odd(xh), odd(xs), odd(wh), odd(ws), topk, ops.PATH_F32_MFMA)
     assert np.array_equal(dist.cpu().numpy(), dist_o) and np.array_equal(idx.cpu().numpy(), idx_o)
+
+
+@pytest.mark.parametrize("n,k,d,topk,path_name", [(3000, 2048, 768, 1, "PATH_F16_FILTER"), (3000, 2048, 768, 5, "PATH_F16_FILTER"),
+                                                  (257, 300, 64, 1, "PATH_F32_MFMA"), (70000, 4096, 256, 1, "PATH_AUTO")])
+def test_normalized_search_equals_rownorm_plus_search(dev, n, k, d, topk, path_name):
+    """The one-call head of NormEMAVectorQuantizer.forward (l2norm + nearest codes): same bits as the two calls it replaces."""
+    from medtok_amd import ops
+    path = getattr(ops, path_name)
+    g = torch.Generator(device=dev).manual_seed(n + k)
+    z = torch.randn(n, d, device=dev, generator=g) * 2
+    z[1] = 0.0
+    E, esq = ops.rownorm(torch.randn(k, d, device=dev, generator=g))
+    zhat, zsq = ops.rownorm(z)
+    idx, dist = ops.topk_search(zhat, zsq, E, esq, topk, path)
+    zhat2, zsq2, idx2, dist2 = ops.normalized_search(z, E, esq, topk, path)
+    assert torch.equal(zhat, zhat2) and torch.equal(zsq, zsq2)
+    assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
