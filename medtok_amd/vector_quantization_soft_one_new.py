@@ -34,6 +34,11 @@ import torch
 import torch.nn as nn
 
 from . import ops
+
+# The cross-attention layers run on combined weight products (one GEMM per side instead of in_proj -> per-head fold and per-head
+# Wv -> out_proj) while the extra flops of that form, 4 R D^2 (heads - 2) per layer, stay below this: launch-bound sizes (eight
+# launches of ~8 us saved per layer against ~70 us of fp32 GEMM at the bound).  Negative: never.
+COMBINE_MAX_EXTRA_FLOPS = 8e9
 from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
@@ -133,6 +138,33 @@ class CrossAttention(nn.Module):
         return layer.layer_norm(query + layer.dropout(attended))
 
     @staticmethod
+    def _combined_weights(layer):
+        """(Mq [D, heads*D], cq [heads*D], Mo [heads*D, D], co [D]) with
+            qf[r, h, :]  = rows[r] @ Mq[:, hD:(h+1)D] + cq[hD:(h+1)D]      (= Wk_h^T (Wq_h x + bq_h))
+            out_proj(concat_h(Wv_h ctx_h + bv_h)) = sum_h ctx[r, h, :] @ Mo[hD:(h+1)D, :] + co
+        products formed in fp64, cached on the layer per (storage, version) of its four tensors.  A `.data` write that autograd's
+        version counter does not see needs VectorQuantizer.invalidate_codebook_cache() (which drops this cache too)."""
+        mha = layer.multihead_attn
+        params = (mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias)
+        key = tuple((t.data_ptr(), t._version, t.device) for t in params)
+        cache = getattr(layer, "_medtok_fold_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        heads, hd = mha.num_heads, mha.head_dim
+        dim = heads * hd
+        wq, wk, wv = (t.double() for t in mha.in_proj_weight.detach().chunk(3))
+        bq, _, bv = (t.double() for t in mha.in_proj_bias.detach().chunk(3))
+        wo, bo = mha.out_proj.weight.detach().double(), mha.out_proj.bias.detach().double()
+        sl = [slice(h * hd, (h + 1) * hd) for h in range(heads)]
+        mq = torch.cat([wq[s].t() @ wk[s] for s in sl], dim=1)                   # [D, heads * D]
+        cq = torch.cat([bq[s] @ wk[s] for s in sl])                              # [heads * D]
+        mo = torch.cat([wv[s].t() @ wo[:, s].t() for s in sl], dim=0)            # [heads * D, D]
+        co = bv @ wo.t() + bo
+        out = tuple(t.float().contiguous() for t in (mq, cq, mo, co))
+        layer._medtok_fold_cache = (key, out)
+        return out
+
+    @staticmethod
     def _folded_rows(layer, rows, attend):
         """_folded_layer for PACKED query rows [R, D] (no batch axis, nothing padded): the attention core is
         `attend(qf [R*heads, D]) -> ctx [R*heads, D]`, i.e. the ragged gfx950 kernel (ops.shared_kv_attention in eval;
@@ -142,8 +174,21 @@ class CrossAttention(nn.Module):
         heads, hd = mha.num_heads, mha.head_dim
         wq, wk, wv = mha.in_proj_weight.chunk(3)
         bq, _, bv = mha.in_proj_bias.chunk(3)
-        q = torch.nn.functional.linear(rows, wq, bq)
         plain = not torch.is_grad_enabled() and not torch.is_autocast_enabled() and rows.dtype == wk.dtype
+        if plain and not layer.training and rows.is_cuda and 4.0 * n_rows * dim * dim * max(heads - 2, 0) <= COMBINE_MAX_EXTRA_FLOPS:
+            # small widths (the reference's default e_dim = 64) are launch-bound: the query-side chain (in_proj -> fold) and the
+            # value-side chain (Wv -> out_proj) each collapse into ONE GEMM against products of the layer's weights, formed once
+            # per weight version in eval mode (12 launches per layer -> 4; twice the flops of the two-step form, which is why the
+            # wide case keeps that)
+            mq, cq, mo, co = CrossAttention._combined_weights(layer)
+            qf = torch.addmm(cq, rows, mq)                                       # [R, heads * D] = the kernel's [R * heads, D]
+            ctx = attend(qf.view(n_rows * heads, dim))
+            out = torch.addmm(co, ctx.view(n_rows, heads * dim), mo)
+            ln = layer.layer_norm
+            if dim % 4 == 0 and ln.elementwise_affine and ln.bias is not None:
+                return ops.residual_layernorm(rows, out, ln.weight, ln.bias, ln.eps)
+            return ln(rows + out)
+        q = torch.nn.functional.linear(rows, wq, bq)
         if plain:
             # one GEMM per head straight into / out of the [R, heads, D] layout the kernel works on (strided operands and
             # outputs, leading dimension heads*D or D): einsum's permute-and-copy of these R*heads*D tensors was ~5 % of the
@@ -360,6 +405,8 @@ class VectorQuantizer(nn.Module):
         does not see (`codebook.weight.data.copy_()/.uniform_()`, a master-weight copy-back): such writes leave
         `_version` unchanged, so an eval-mode cache cannot notice them by itself."""
         self._norm_cache = None
+        for layer in self.cross_attn.model:           # the folded-weight products of the cross-attention layers
+            layer._medtok_fold_cache = None
 
     def train(self, mode: bool = True):
         self._norm_cache = None              # a mode switch is where weights typically change hands

@@ -443,3 +443,40 @@ def test_eval_forward_slides_the_usage_window_like_the_reference(golden, dev):
     wrote_tokenize, _ = run(True, lambda t: t.tokenize)
     # ids are >= 0 and a few are 0, so count by the upper bound of what each route can have written
     assert wrote_aug <= 6 * B * k and wrote_plain <= 4 * B * k and wrote_tokenize <= 4 * B * k and wrote_aug > wrote_plain
+
+
+def test_cross_attention_combined_weights_match_two_step_form(dev):
+    """Small widths run the layers on products of their weights (one GEMM per side): same function as the two-step form, the
+    cache follows weight versions, and invalidate_codebook_cache() covers writes the version counter does not see."""
+    import medtok_amd.vector_quantization_soft_one_new as M
+    from oracle import synth
+    torch.manual_seed(3)
+    D, B = 64, 40
+    v = M.VectorQuantizer(300, D, 0.25, 0.0, True, True, [D, D]).to(dev).eval()
+    text, mask, nodes, batch = (t.to(dev) for t in synth.ragged_batch("tf", B, 48, 12, D, 5))
+
+    def both():
+        with torch.no_grad():
+            a = v.cross_attn.pooled(text, mask, nodes, batch)
+            keep, M.COMBINE_MAX_EXTRA_FLOPS = M.COMBINE_MAX_EXTRA_FLOPS, -1.0
+            try:
+                b = v.cross_attn.pooled(text, mask, nodes, batch)
+            finally:
+                M.COMBINE_MAX_EXTRA_FLOPS = keep
+        return a, b
+
+    (a_t, a_g), (b_t, b_g) = both()
+    assert v.cross_attn.model[0]._medtok_fold_cache is not None          # the combined path ran
+    for x, y in ((a_t, b_t), (a_g, b_g)):
+        assert float((x - y).abs().max()) <= 2e-6 * max(float(y.abs().max()), 1.0)
+    # an optimizer-style in-place update bumps the version: the products are rebuilt
+    with torch.no_grad():
+        v.cross_attn.model[0].multihead_attn.in_proj_weight.mul_(1.5)
+    (a_t2, a_g2), (b_t2, b_g2) = both()
+    assert float((a_g2 - b_g2).abs().max()) <= 2e-6 * max(float(b_g2.abs().max()), 1.0)
+    assert float((a_g2 - a_g).abs().max()) > 1e-4
+    # a .data write is invisible to the version counter: explicit invalidation
+    v.cross_attn.model[1].multihead_attn.out_proj.weight.data.mul_(0.5)
+    v.invalidate_codebook_cache()
+    (a_t3, a_g3), (b_t3, b_g3) = both()
+    assert float((a_g3 - b_g3).abs().max()) <= 2e-6 * max(float(b_g3.abs().max()), 1.0)
