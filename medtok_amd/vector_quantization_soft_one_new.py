@@ -264,14 +264,30 @@ class CrossAttention(nn.Module):
             nodes, text = nodes.to(common), text.to(common)
         valid = text_mask.to(torch.bool)
         batch = batch.reshape(-1).to(torch.long)
-        counts = torch.bincount(batch, minlength=bsz) if batch.numel() else torch.zeros(bsz, dtype=torch.long, device=text.device)
-        if counts.numel() != bsz:           # bincount grows past minlength when an id is >= B (and raises on negative ids)
-            raise ValueError(f"pooled(): `batch` must hold code ids in [0, {bsz}); largest id seen: {counts.numel() - 1}")
-        max_nodes = int(counts.max()) if counts.numel() else 0          # the one host sync of this call
+        n_nodes = batch.numel()
+        if n_nodes:
+            # node counts per code without torch.bincount (which reads the id range back to the host, twice): ids are clamped
+            # for the scatter and validated by the ONE host read of this call, which also brings the largest count (it sizes
+            # the launch) and whether `batch` is already sorted (PyG batch vectors are: then there is nothing to rank)
+            counts = torch.zeros(bsz, dtype=torch.long, device=batch.device).scatter_add_(
+                0, batch.clamp(0, max(bsz - 1, 0)), torch.ones_like(batch))
+            unsorted = (batch[1:] < batch[:-1]).any() if n_nodes > 1 else torch.zeros((), dtype=torch.bool, device=batch.device)
+            max_nodes, id_lo, id_hi, unsorted = torch.stack([counts.max(), batch.min(), batch.max(), unsorted.to(torch.long)]).tolist()
+            if id_lo < 0 or id_hi >= bsz:
+                raise ValueError(f"pooled(): `batch` must hold code ids in [0, {bsz}); range seen: [{id_lo}, {id_hi}]")
+        else:
+            counts = torch.zeros(bsz, dtype=torch.long, device=text.device)
+            max_nodes, unsorted = 0, 0
         starts = torch.cumsum(counts, 0) - counts
-        # nodes of one code need not be contiguous in `batch`: rank them with a stable sort
-        order = torch.argsort(batch, stable=True)
-        slot = torch.arange(batch.numel(), device=batch.device) - starts[batch[order]]
+        position = torch.arange(n_nodes, device=batch.device)
+        if unsorted:                        # nodes of one code need not be contiguous in `batch`: rank them with a stable sort
+            order = torch.argsort(batch, stable=True)
+            slot = position - starts[batch[order]]
+        else:
+            order = None
+            slot = position - starts[batch]
+        nodes_in_order = nodes if order is None else nodes[order]
+        batch_in_order = batch if order is None else batch[order]
 
         seq_len, dim = text.shape[1], text.shape[2]
         heads = self.model[0].multihead_attn.num_heads
@@ -289,11 +305,11 @@ class CrossAttention(nn.Module):
             fold = kernel_ok or max_nodes * (dim + (heads - 1) * seq_len) < seq_len * dim
         packed = fold and kernel_ok
         if packed:
-            return self._pooled_packed(text.contiguous(), valid.sum(1), nodes[order].contiguous(), batch[order], slot, counts, starts,
+            return self._pooled_packed(text.contiguous(), valid.sum(1), nodes_in_order.contiguous(), batch_in_order, slot, counts, starts,
                                        max_nodes, core or ops.shared_kv_attention, autograd=train_path and core is None)
 
         padded = text.new_zeros(bsz, max_nodes, text.shape[-1])
-        padded[batch[order], slot] = nodes[order]
+        padded[batch_in_order, slot] = nodes_in_order
         node_valid = torch.arange(max_nodes, device=batch.device)[None, :] < counts[:, None]
 
         # text side: one CLS query per code against that code's nodes -- always cheaper folded
