@@ -602,32 +602,34 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
 // Joins the per-split candidate lists of one row: 8 lanes per row, each folds every 8th split, then three shuffle rounds.
 // (d, index) is a total order, so the result does not depend on who inserts what when.  (A thread per row walked
 // up to 64 splits x k entries serially: 90 us for a 256-row batch.)
-template <int TOPK>
+// LPR lanes per row: 8, or a whole wave (64) for small batches with many splits (256 rows x 128 splits: 28 -> ~12 us).
+template <int TOPK, int LPR = 8>
 __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict__ pval, const int *__restrict__ pidx,
                                                          long n, int splits, int topk_out,
                                                          int64_t *__restrict__ out_idx, float *__restrict__ out_dist,
                                                          const int *__restrict__ row_list, const int *__restrict__ row_count, int k_codes)
 {
     // with a row list: partial lists are indexed by list position (extent n), results go to row_list[position]
-    const int l8 = threadIdx.x & 7;
-    const long pos = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    constexpr int RPB = 256 / LPR;                       // rows per block
+    const int l8 = threadIdx.x & (LPR - 1);
+    const long pos = (long)blockIdx.x * RPB + (threadIdx.x / LPR);
     const long limit = row_list ? min(n, (long)*row_count) : n;
     const long row = min(pos, n - 1);                    // lanes past the end keep shuffling with their group, write nothing
     float bv[TOPK];
     int bi[TOPK];
 #pragma unroll
     for (int j = 0; j < TOPK; ++j) { bv[j] = INFINITY; bi[j] = 0x7fffffff; }
-    for (int s = l8; s < splits; s += 8) {
+    for (int s = l8; s < splits; s += LPR) {
         const long base = ((long)s * n + row) * TOPK;
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) topk_insert_lex<TOPK>(bv, bi, pval[base + j], pidx[base + j]);
     }
 #pragma unroll
-    for (int off = 4; off >= 1; off >>= 1) {
+    for (int off = LPR / 2; off >= 1; off >>= 1) {
         float pv[TOPK];
         int pi[TOPK];
 #pragma unroll
-        for (int j = 0; j < TOPK; ++j) { pv[j] = __shfl_xor(bv[j], off, 8); pi[j] = __shfl_xor(bi[j], off, 8); }
+        for (int j = 0; j < TOPK; ++j) { pv[j] = __shfl_xor(bv[j], off, LPR); pi[j] = __shfl_xor(bi[j], off, LPR); }
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) topk_insert_lex<TOPK>(bv, bi, pv[j], pi[j]);
     }
@@ -899,8 +901,12 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
                        (const int *)nullptr, (const int *)nullptr, 0, 0);
     if (pa) g_prof.push_back({pa, prof_mark(s), pflops, 1});
     if (check_launch("search_f32(split)")) return 1;
-    hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, pval, pidx, (long)n,
-                       p.splits, topk, idx, dist, (const int *)nullptr, (const int *)nullptr, (int)k_codes);
+    if (p.splits >= 64 && n <= 8192)     // few rows, many lists each: a wave per row
+        hipLaunchKernelGGL((merge_topk_kernel<T, 64>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, pval, pidx, (long)n,
+                           p.splits, topk, idx, dist, (const int *)nullptr, (const int *)nullptr, (int)k_codes);
+    else
+        hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, pval, pidx, (long)n,
+                           p.splits, topk, idx, dist, (const int *)nullptr, (const int *)nullptr, (int)k_codes);
     return check_launch("merge_topk");
 }
 
