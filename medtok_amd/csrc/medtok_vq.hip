@@ -184,8 +184,8 @@ extern "C" int medtok_rownorm_f32(const float *x, int64_t n, int d, int normaliz
                                   float *sqn, void *stream)
 {
     if (n < 0 || d <= 0 || (d & 3)) return fail("rownorm: need n >= 0, d > 0, d %% 4 == 0 (n=%ld d=%d)", (long)n, d);
+    if (n == 0) return 0;                      // (an empty torch tensor has a null data pointer: sizes first, pointers after)
     if (normalize && !xhat) return fail("rownorm: xhat required when normalize != 0");
-    if (n == 0) return 0;
     dim3 grid((unsigned)((n + 3) / 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (normalize) hipLaunchKernelGGL(rownorm_kernel<true>, grid, block, 0, s, x, (long)n, d, xhat, sqn);
@@ -1185,8 +1185,8 @@ extern "C" int medtok_soft_assign_f32(const float *xref, const float *what, cons
     if (topk < 1 || topk > MEDTOK_MAX_TOPK) return fail("soft_assign: topk=%d unsupported", topk);
     if (hard && topk != 1) return fail("soft_assign: hard assignment needs topk == 1");
     if (!hard && !dist) return fail("soft_assign: dist required");
-    if (!zq_ste) return fail("soft_assign: zq_ste required");
     if (n == 0) return 0;
+    if (!zq_ste) return fail("soft_assign: zq_ste required");
     hipLaunchKernelGGL((soft_assign_kernel<MEDTOK_MAX_TOPK>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        xref, what, idx, dist, (long)n, d, topk, flags, w, zq_ste, (long)zq_stride, row_sqerr,
                        (const int *)nullptr, (const int *)nullptr);
@@ -1234,9 +1234,9 @@ extern "C" int medtok_soft_vq_backward_f32(const float *x, const float *xhat, co
 {
     if (n < 0 || d <= 0 || (d & 3)) return fail("soft_vq_backward: bad shape n=%ld d=%d", (long)n, d);
     if (topk < 1 || topk > MEDTOK_MAX_TOPK) return fail("soft_vq_backward: topk=%d unsupported", topk);
+    if (n == 0) return 0;
     if (!x || !xhat || !what || !idx || !w) return fail("soft_vq_backward: x, xhat, what, idx and w are required");
     if (!gx && !g_code) return fail("soft_vq_backward: nothing to compute (gx and g_code are both NULL)");
-    if (n == 0) return 0;
     hipLaunchKernelGGL((soft_vq_backward_kernel<MEDTOK_MAX_TOPK>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        x, xhat, what, idx, w, (long)n, d, topk, g_zq, g_xhat, g_out, g_vq, g_commit, vq_scale, commit_scale, gx, g_code);
     return check_launch("soft_vq_backward");
@@ -1245,8 +1245,8 @@ extern "C" int medtok_soft_vq_backward_f32(const float *x, const float *xhat, co
 extern "C" int medtok_normalize_backward_f32(const float *g, const float *vhat, const float *v, int64_t n, int d, float *out, void *stream)
 {
     if (n < 0 || d <= 0 || (d & 3)) return fail("normalize_backward: bad shape n=%ld d=%d", (long)n, d);
-    if (!g || !vhat || !v || !out) return fail("normalize_backward: NULL argument");
     if (n == 0) return 0;
+    if (!g || !vhat || !v || !out) return fail("normalize_backward: NULL argument");
     hipLaunchKernelGGL(normalize_backward_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, vhat, v, (long)n, d, out);
     return check_launch("normalize_backward");
 }
@@ -1317,8 +1317,8 @@ extern "C" int medtok_info_nce_backward_f32(const float *q, const float *k, cons
 extern "C" int medtok_row_dot_f32(const float *a, const float *b, int64_t n, int d, float *out, void *stream)
 {
     if (n < 0 || d <= 0 || (d & 3)) return fail("row_dot: bad shape n=%ld d=%d (d %% 4 == 0)", (long)n, d);
-    if (!a || !b || !out) return fail("row_dot: NULL argument");
     if (n == 0) return 0;
+    if (!a || !b || !out) return fail("row_dot: NULL argument");
     hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, (long)n, d, out);
     return check_launch("row_dot");
 }
@@ -1405,8 +1405,8 @@ extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_s
 {
     if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
     if (!attention_shape_ok(d)) return fail("shared_kv_attention: d=%d must be 64 or a multiple of 128, at most 768", d);
-    if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out) return fail("shared_kv_attention: NULL argument");
     if (n_codes == 0 || max_q_len == 0) return 0;
+    if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out) return fail("shared_kv_attention: NULL argument");
     return attention_forward(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, nullptr, 0.f, 0u, (hipStream_t)stream);
 }
 
@@ -1443,8 +1443,8 @@ extern "C" int medtok_shared_kv_attention_train_f32(const float *q, const int64_
     if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention_train: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
     if (!attention_shape_ok(d)) return fail("shared_kv_attention_train: d=%d must be 64 or a multiple of 128, at most 768", d);
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail("shared_kv_attention_train: dropout_p=%g must be in [0, 1)", (double)dropout_p);
-    if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out || !lse) return fail("shared_kv_attention_train: NULL argument");
     if (n_codes == 0 || max_q_len == 0) return 0;
+    if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out || !lse) return fail("shared_kv_attention_train: NULL argument");
     return attention_forward(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, lse, dropout_p, seed, (hipStream_t)stream);
 }
 
@@ -1459,7 +1459,9 @@ extern "C" int medtok_shared_kv_attention_backward_f32(const float *q, const int
     if (n_codes < 0 || max_q_len < 0 || max_kv_len < 0 || q_rows < 0 || kv_rows < 0) return fail("shared_kv_attention_backward: bad sizes");
     if (!attention_shape_ok(d)) return fail("shared_kv_attention_backward: d=%d must be 64 or a multiple of 128, at most 768", d);
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail("shared_kv_attention_backward: dropout_p=%g must be in [0, 1)", (double)dropout_p);
-    if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out || !lse || !d_out || !dq || !dkv) return fail("shared_kv_attention_backward: NULL argument");
+    if (q_rows == 0 && kv_rows == 0) return 0;                 // nothing to write
+    if (!q_start || !q_len || !kv_start || !kv_len || (q_rows > 0 && (!q || !out || !lse || !d_out || !dq)) || (kv_rows > 0 && (!kv || !dkv)))
+        return fail("shared_kv_attention_backward: NULL argument");
     if (!ws || ws_bytes < (size_t)q_rows * 4) return fail("shared_kv_attention_backward: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     // rows no block owns (key rows past a code's kv_len inside its slot, query rows of no code) get a zero gradient

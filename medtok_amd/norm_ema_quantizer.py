@@ -184,7 +184,7 @@ class NormEMAVectorQuantizer(nn.Module):
             loss = self.beta * torch.mean((zq - z_flat) ** 2)          # F.mse_loss(z_q.detach(), z)
             z_q = z_flat + (zq - z_flat).detach()
         else:
-            loss = self.beta * ops.sum_scale(row_sqerr, 1.0 / (n * d))
+            loss = self.beta * ops.sum_scale(row_sqerr, (1.0 / (n * d)) if n else float("nan"))      # mean of nothing: nan, like F.mse_loss
             z_q = zq_ste
         z_q = z_q.view(b, h, w, c).permute(0, 3, 1, 2)
         return z_q, loss, encoding_indices

@@ -350,7 +350,7 @@ class _SoftVQFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         r = ops.soft_vq_forward(x.detach(), what, wsq, topk, path, want_sqerr=True)
         n, d = x.shape
-        vq = ops.sum_scale(r["row_sqerr"], 1.0 / (n * d))
+        vq = ops.sum_scale(r["row_sqerr"], (1.0 / (n * d)) if n else float("nan"))      # mean of nothing: nan, like F.mse_loss
         commit = ops.sum_scale(r["row_sqerr"], beta / (n * d))
         ctx.save_for_backward(x, weight, r["xhat"], what, r["idx"], r["w"])
         ctx.beta = beta
@@ -465,7 +465,7 @@ class VectorQuantizer(nn.Module):
         r = ops.soft_vq_forward(x.detach().float(), what[lo:hi], wsq[lo:hi].contiguous(), self.k, self.search_path,
                                 want_sqerr=training, out=out)
         if training:
-            vq = ops.sum_scale(r["row_sqerr"], 1.0 / (n * x.shape[1]))
+            vq = ops.sum_scale(r["row_sqerr"], (1.0 / (n * x.shape[1])) if n else float("nan"))
             commit = self.beta * vq
         else:
             vq = torch.tensor(0.0)

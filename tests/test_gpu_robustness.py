@@ -100,3 +100,44 @@ def test_attention_kernel_with_empty_key_sets_and_many_codes(oracle, dev):
     assert np.abs(out - ref).max() <= 1e-5 * np.abs(ref).max()
     empty_rows = np.concatenate([np.arange(q_start[b], q_start[b] + q_len[b]) for b in np.nonzero(kv_len == 0)[0]])
     assert not out[empty_rows].any()
+
+
+def test_empty_inputs_through_every_row_op(dev):
+    """Zero rows / zero segments / zero codes: every row-wise entry point returns empty results instead of launching anything."""
+    from medtok_amd import ops
+    d, k = 64, 96
+    g = torch.Generator(device=dev).manual_seed(0)
+    W, wsq = ops.rownorm(torch.randn(k, d, device=dev, generator=g))
+    x0 = torch.empty(0, d, device=dev)
+    xh, xs = ops.rownorm(x0)
+    assert xh.shape == (0, d) and xs.shape == (0,)
+    for path in (ops.PATH_AUTO, ops.PATH_F32_MFMA, ops.PATH_F16_FILTER):
+        idx, dist = ops.topk_search(xh, xs, W, wsq, 5, path)
+        assert idx.shape == (0, 5) and dist.shape == (0, 5)
+        zh, zs, idx, dist = ops.normalized_search(x0, W, wsq, 1, path)
+        assert zh.shape == (0, d) and idx.shape == (0, 1)
+    r = ops.soft_vq_forward(x0, W, wsq, 5)
+    assert r["zq"].shape == (0, d) and r["idx"].shape == (0, 5)
+    y = ops.residual_layernorm(x0, x0, torch.ones(d, device=dev), torch.zeros(d, device=dev), 1e-5)
+    assert y.shape == (0, d)
+    z64 = torch.zeros(0, dtype=torch.int64, device=dev)
+    assert ops.segment_mean(torch.randn(3, d, device=dev, generator=g), z64, z64).shape == (0, d)
+    out = ops.shared_kv_attention(x0, z64, z64, torch.randn(3, d, device=dev, generator=g), z64, z64, 0, 0.125)
+    assert out.shape == (0, d)
+    torch.cuda.synchronize()
+
+
+def test_empty_batch_through_the_modules(dev):
+    """B = 0 (an empty shard of a ragged last batch): the drop-in modules return empty results of the right shapes."""
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    from medtok_amd.norm_ema_quantizer import NormEMAVectorQuantizer
+    D = 64
+    v = VectorQuantizer(96, D, 0.25, 0.0, True, True, [D, D]).to(dev).eval()
+    with torch.no_grad():
+        r = v(torch.empty(0, 2 * D, device=dev), torch.empty(0, 8, D, device=dev), torch.empty(0, D, device=dev),
+              torch.empty(0, 8, dtype=torch.long, device=dev), torch.empty(0, dtype=torch.long, device=dev))
+    assert r["text_tokens"].shape == (0, 5) and r["shared_text_tokens"].shape == (0, 5)
+    q = NormEMAVectorQuantizer(32, D, 0.25).to(dev).eval()
+    with torch.no_grad():
+        zq, loss, idx = q(torch.empty(0, D, 1, 1, device=dev))
+    assert zq.shape == (0, D, 1, 1) and idx.shape == (0,)
