@@ -385,6 +385,9 @@ class VectorQuantizer(nn.Module):
         self.l2_norm = l2_norm
         self.show_usage = show_usage
         self.split = split
+        if not 1 <= int(k) <= ops.MAX_TOPK or int(k) > n_e // 3:
+            raise ValueError(f"VectorQuantizer: k={k} unsupported -- the search kernels keep lists of up to {ops.MAX_TOPK} codes per row "
+                             f"(reference default 5), and a modality region holds n_e // 3 = {n_e // 3} codes")
         self.k = k
         self.kmeans_init = kmeans
         self.initted = False

@@ -217,3 +217,14 @@ def test_bench_parent_spawns_ranks_without_touching_the_gpu(monkeypatch):
     monkeypatch.delenv("MEDTOK_DIST_BACKEND")
     if torch.cuda.device_count() < 2:
         assert bench.spawn_ranks(bench.parse()) == 2          # RCCL: one GPU per rank, checked before anything is started
+
+
+def test_unsupported_k_fails_at_construction():
+    """k beyond the kernels' list length (or beyond a region's size) is refused when the module is built, not at the first search."""
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    for bad in (0, 9, 64):
+        with pytest.raises(ValueError, match="k="):
+            VectorQuantizer(96, 16, 0.25, 0.0, True, True, [16, 16], k=bad)
+    with pytest.raises(ValueError, match="k="):
+        VectorQuantizer(12, 16, 0.25, 0.0, True, True, [16, 16], k=5)          # regions of 4 codes
+    VectorQuantizer(96, 16, 0.25, 0.0, True, True, [16, 16], k=8)
