@@ -23,8 +23,11 @@ struct AttShape {
 
 // partial 32 x 32 product over this wave's D / W columns: A rows from registers (reg[g] = elements 8g + 4 lh .. + 3 of the slice of
 // row li), B rows = rows of the parked chunk.  Result r <-> [A row (r & 3) + 8 (r >> 2) + 4 lh][B row li].
-template <int W, int NT>
-__device__ __forceinline__ f32x16 att_partial(const float4 (&reg)[4 * NT], const float *kvs, int slice, int li, int lh)
+struct AttNoHook { __device__ __forceinline__ void operator()(int) const {} };
+// `hook(g)` runs behind the four MFMAs of group g (g = 0 .. 4 NT - 1): the callers weave the NF = 4 NT loads of their next chunk
+// there, one per group, instead of issuing them as a burst (see shared_kv_attention_kernel).
+template <int W, int NT, typename Hook = AttNoHook>
+__device__ __forceinline__ f32x16 att_partial(const float4 (&reg)[4 * NT], const float *kvs, int slice, int li, int lh, Hook hook = Hook())
 {
     constexpr int LD = AttShape<W, NT>::LD;
     f32x16 s;
@@ -47,6 +50,7 @@ __device__ __forceinline__ f32x16 att_partial(const float4 (&reg)[4 * NT], const
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(reg[g].y, cur[j].y, s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(reg[g].z, cur[j].z, s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(reg[g].w, cur[j].w, s, 0, 0, 0);
+            hook(g);
         }
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -56,8 +60,9 @@ __device__ __forceinline__ f32x16 att_partial(const float4 (&reg)[4 * NT], const
 }
 
 // acc[t] += X^T-shaped product: A[i][k] = x[k][i] (a 32 x 33 LDS tile, contraction index first), B[k][col] = parked chunk row k
-template <int W, int NT>
-__device__ __forceinline__ void att_accumulate(f32x16 (&acc)[NT], const float (*x)[33], const float *kvs, int slice, int li, int lh)
+// `hook(s2)` runs behind the MFMAs of step s2 (0 .. 15).
+template <int W, int NT, typename Hook = AttNoHook>
+__device__ __forceinline__ void att_accumulate(f32x16 (&acc)[NT], const float (*x)[33], const float *kvs, int slice, int li, int lh, Hook hook = Hook())
 {
     constexpr int LD = AttShape<W, NT>::LD;
     const float *kcol = kvs + lh * LD + slice + li;
@@ -73,6 +78,7 @@ __device__ __forceinline__ void att_accumulate(f32x16 (&acc)[NT], const float (*
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pc, kc[t], acc[t], 0, 0, 0);
+        hook(s2);
         asm volatile("" ::: "memory");
         pc = pn;
 #pragma unroll
@@ -148,8 +154,12 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
     const int row = tid / TPR, kq = (tid % TPR) * EPT;
     for (int k0 = 0; k0 < kl; k0 += 32) {
         park();
+        // the next chunk's rows: one 16-byte load behind every four MFMAs of the first product (rows past the last key clamped)
+        const float *fsrc[RI];
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri) fsrc[ri] = kv + (ks + min(k0 + 32 + f_r0 + RP * ri, kl - 1)) * (long)D + f_c;
         ATT_LDS_BARRIER();
-        f32x16 s = att_partial<W, NT>(qf, kvs, slice, li, lh);                    // S partial: [query row][key]
+        f32x16 s = att_partial<W, NT>(qf, kvs, slice, li, lh, [&](int g) { kf[g] = ld4(fsrc[g / CI] + 4 * FT * (g % CI)); });   // S partial: [query row][key]
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
         ATT_LDS_BARRIER();
@@ -166,7 +176,6 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
         ATT_LDS_BARRIER();
-        if (k0 + 32 < kl) fetch(k0 + 32);
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             float dp = 0.f;
@@ -244,6 +253,19 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int krow_t = tid / TPR, qc = (tid % TPR) * EPT;        // elementwise steps: this thread's key row and query columns
+    // The three chunk fetches of an iteration (Q, dO, Q again) ride between MFMAs, one 16-byte load per group / step, instead of
+    // going out as bursts: dO behind the groups of the first product, Q-again behind the steps of the first accumulation, and the
+    // NEXT iteration's Q behind the steps of the last accumulation (the first one is fetched here).  Rows past the code's last
+    // query are clamped.
+    auto woven = [&](const float *src_base, int c0) __attribute__((always_inline)) {
+        return [=, &kf](int g) __attribute__((always_inline)) {
+            if (g < NF) {
+                const int ri = g / CI, ci = g % CI;
+                kf[g] = ld4(src_base + (qs + min(c0 + f_r0 + RP * ri, ql - 1)) * (long)D + f_c + 4 * FT * ci);
+            }
+        };
+    };
+    if (ql > 0) fetch(q, 0);
     for (int c0 = 0; c0 < ql; c0 += 32) {
         __syncthreads();                                         // the previous chunk's readers of kvs / pm / ds / the statistics are done
         if (tid < 32) {
@@ -251,14 +273,12 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
             lse_s[tid] = lse[r];
             del_s[tid] = delta[r];
         }
-        fetch(q, c0);
-        park();
+        park();                                                                    // Q chunk (fetched during the previous iteration)
         ATT_LDS_BARRIER();
-        f32x16 s = att_partial<W, NT>(kvf, kvs, slice, li, lh);                    // S^T partial: [key][query]
+        f32x16 s = att_partial<W, NT>(kvf, kvs, slice, li, lh, woven(d_out, c0));  // S^T partial: [key][query]; dO chunk on its way
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
         ATT_LDS_BARRIER();
-        fetch(d_out, c0);                                                          // in flight under the elementwise step
         float p[EPT];
         bool keep[EPT];
 #pragma unroll
@@ -286,12 +306,11 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
             dp = keep[j] ? dp * keep_scale : 0.f;
             ds[qc + j][krow_t] = p[j] * (dp - del_s[qc + j]) * scale;
         }
-        att_accumulate<W, NT>(acc, pm, kvs, slice, li, lh);                        // dKV += (P o M)^T . dO   (pm was complete two barriers ago)
-        fetch(q, c0);
+        att_accumulate<W, NT>(acc, pm, kvs, slice, li, lh, woven(q, c0));          // dKV += (P o M)^T . dO   (pm was complete two barriers ago); Q again on its way
         ATT_LDS_BARRIER();                                                         // dO chunk consumed, ds complete
         park();                                                                    // Q chunk again
         ATT_LDS_BARRIER();
-        att_accumulate<W, NT>(acc, ds, kvs, slice, li, lh);                        // dKV += (scale dS)^T . Q
+        att_accumulate<W, NT>(acc, ds, kvs, slice, li, lh, woven(q, c0 + 32));     // dKV += (scale dS)^T . Q; the next iteration's Q on its way
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
