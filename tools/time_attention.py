@@ -2,10 +2,13 @@
 import sys, time
 sys.path.insert(0, ".")
 import torch
+import os as _os
+if _os.environ.get("MEDTOK_TOOL_LIB"):
+    from medtok_amd import _lib as _l; _l.use_library(_os.environ["MEDTOK_TOOL_LIB"])
 from medtok_amd import ops
 from oracle import synth
 dev = torch.device("cuda:0")
-B, L, M, D, H = 256, 512, 40, 768, 4
+B, L, M, D, H = (int(sys.argv[1]) if len(sys.argv) > 1 else 256), 512, 40, (int(sys.argv[2]) if len(sys.argv) > 2 else 768), 4
 text, mask, nodes, batch = synth.ragged_batch("tf", B, L, M, D, 0)
 counts = torch.bincount(batch, minlength=B); starts = torch.cumsum(counts, 0) - counts
 valid = mask.sum(1)

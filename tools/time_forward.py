@@ -5,7 +5,9 @@ import torch
 from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
 from oracle import synth
 dev = torch.device("cuda:0")
-for B, L, M, D, n_e in ((256, 512, 40, 64, 21000), (1024, 512, 40, 64, 21000), (256, 64, 20, 768, 24576)):
+import sys as _s
+SHAPES = ((256, 512, 40, 64, 21000), (1024, 512, 40, 64, 21000), (256, 64, 20, 768, 24576)) if len(_s.argv) < 2 else ((4096, 512, 40, 64, 21000), (16384, 512, 40, 64, 21000))
+for B, L, M, D, n_e in SHAPES:
     torch.manual_seed(0)
     v = VectorQuantizer(n_e, D, 0.25, 0.0, True, True, [D, D]).to(dev).eval()
     text, mask, nodes, batch = synth.ragged_batch("tf", B, L, M, D, 0)
