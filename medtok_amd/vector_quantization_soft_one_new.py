@@ -39,6 +39,7 @@ from . import ops
 # Wv -> out_proj) while the extra flops of that form, 4 R D^2 (heads - 2) per layer, stay below this: launch-bound sizes (eight
 # launches of ~8 us saved per layer against ~70 us of fp32 GEMM at the bound).  Negative: never.
 COMBINE_MAX_EXTRA_FLOPS = 8e9
+LPT_ORDER = True
 from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
@@ -234,9 +235,15 @@ class CrossAttention(nn.Module):
             cur = self._folded_rows(layer, cur, lambda qf: core(qf, t_start, t_len, nodes_sorted, starts, counts, heads, scale))
         # graph side: every node queries the valid text tokens of its code
         g_start, g_len, tok_start = starts * heads, counts * heads, code * seq_len
+        g_kv_len = valid_len
+        if LPT_ORDER and not autograd and bsz > 1:
+            # longest blocks first: the kernel takes (code, tile) blocks in list order, and a block's time is its key count -- the
+            # lists are permuted (the rows they point at are not), so results are the same and the launch has a short tail
+            order = torch.argsort(valid_len, descending=True)
+            g_start, g_len, tok_start, g_kv_len = g_start[order], g_len[order], tok_start[order], valid_len[order]
         g = nodes_sorted
         for layer in self.model:
-            g = self._folded_rows(layer, g, lambda qf: core(qf, g_start, g_len, text_flat, tok_start, valid_len,
+            g = self._folded_rows(layer, g, lambda qf: core(qf, g_start, g_len, text_flat, tok_start, g_kv_len,
                                                             max_nodes * heads, scale))
         if not autograd and not torch.is_grad_enabled() and g.is_cuda and g.dtype == torch.float32 and dim % 4 == 0:
             return cur, ops.segment_mean(g, starts, counts)        # rows of a code are adjacent: one ordered chain per column
