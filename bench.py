@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default 600000 for cfg3, 100000 for cfg2)")
     ap.add_argument("--path", type=int, default=ops.PATH_AUTO)
     ap.add_argument("--cpu-rows", type=int, default=None, help="row sample for the CPU baseline (0 disables)")
+    ap.add_argument("--no-collectives", action="store_true", help="N > 1, headline workload: skip the extra cfg5 / codeshard strong-scaling block")
     ap.add_argument("--exact-steps", type=int, default=1, help="extra steps on the exact fp32-MFMA path for comparison (0 disables)")
     return ap.parse_args()
 
@@ -421,6 +422,50 @@ def pmc_traffic(workload, kernel, rows):
         return None, None
 
 
+def collective_block(args, rank, world, dev):
+    """N > 1 only: the two partitionings of BASELINE config 5 that DO exchange data, so that the driver's unchanged command line
+    (`bench.py --gpus N`, whose headline workload shards rows with no data-path collective) also measures RCCL over xGMI.
+      cfg5_ema_step     600k rows in total row-sharded over the ranks, K = 16384: argmin + EMA statistics + ONE all-reduce of
+                        [embed_sum | bins] (50.4 MB) + the fused codebook update -- strong scaling;
+      codeshard_search  one K = 49152 top-5 search of 600k replicated rows with the CODEBOOK sharded over the ranks: ONE packed
+                        all-gather of the k-lists (n * k * 8 B per rank) + the exact merge -- strong scaling.
+    Each is timed like the headline (warm-up, barrier + synchronize on both sides, max over ranks); the collectives are
+    bracketed by HIP events on the stream they are enqueued on (medtok_amd.distributed.COLLECTIVE_TIMER)."""
+    out = {}
+    total_rows = 600000
+
+    def timed(wl, units):
+        for _ in range(max(args.warmup, 1)):
+            wl.step()
+        torch.cuda.synchronize(dev); mdist.barrier(); torch.cuda.synchronize(dev)
+        mdist.COLLECTIVE_TIMER = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.step()
+        torch.cuda.synchronize(dev); mdist.barrier(); torch.cuda.synchronize(dev)
+        dt = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+        recs, mdist.COLLECTIVE_TIMER = mdist.COLLECTIVE_TIMER, None
+        ms = [e0.elapsed_time(e1) for _, e0, e1, _ in recs]
+        coll_ms = mdist.max_over_ranks(sum(ms) / max(args.steps, 1), dev)
+        nbytes = sum(b for _, _, _, b in recs) / max(args.steps, 1)
+        return dict(value=units * args.steps / dt, unit="rows/s (whole job)", ms_per_step=dt / args.steps * 1e3, collective=recs[0][0] if recs else None,
+                    collective_ms_per_step=coll_ms, collective_bytes_per_step=nbytes, collectives_per_step=len(recs) / max(args.steps, 1),
+                    # ring-equivalent bus bandwidth: all-reduce moves 2 (N-1)/N of the buffer per rank, all-gather (N-1)/N of the result
+                    busbw_gbs=((2.0 if recs and recs[0][0] == "all_reduce" else 1.0) * (world - 1) / world * nbytes / (coll_ms * 1e-3) / 1e9
+                               if coll_ms > 0 else None))
+    lo, hi = mdist.row_shard(total_rows, rank, world)
+    wl = Cfg2(hi - lo, dev, seed=rank, path=args.path, k_codes=16384)
+    out["cfg5_ema_step"] = dict(timed(wl, total_rows), workload=f"{total_rows} rows row-sharded x{world}, D=768, K=16384, train step")
+    del wl
+    torch.cuda.empty_cache()
+    wl = CodeShard(total_rows, dev, seed=0, path=args.path, rank=rank, world=world)
+    out["codeshard_search"] = dict(timed(wl, total_rows), workload=f"{total_rows} rows replicated, K=49152 sharded x{world}, top-5 + soft assignment")
+    del wl
+    torch.cuda.empty_cache()
+    out["backend"] = torch.distributed.get_backend()
+    return out
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N fresh rank processes (one per GPU, env://
     rendezvous on 127.0.0.1 -- the launch contract of MedTok/utils/distributed.py:20-58), relay rank 0's JSON line and
@@ -429,10 +474,17 @@ def spawn_ranks(args) -> int:
     import socket
     import subprocess
     backend = os.environ.get("MEDTOK_DIST_BACKEND") or "nccl"
-    have = torch.cuda.device_count()              # counting devices does not initialise the runtime
-    if backend == "nccl" and have < args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible (RCCL needs one GPU per rank)", file=sys.stderr)
-        return 2
+    if backend == "nccl":
+        # RCCL needs one GPU per rank: refuse up front.  The count is read in a short-lived CHILD -- even counting devices can
+        # open the driver, and this parent must stay a process that has never touched the GPU.
+        try:
+            have = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                                      capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1])
+        except Exception:
+            have = None         # could not tell: let the ranks report it (init_distributed() fails cleanly when LOCAL_RANK has no GPU)
+        if have is not None and have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible (RCCL needs one GPU per rank)", file=sys.stderr)
+            return 2
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -526,6 +578,13 @@ def main():
     alg_bytes_step = float(wl.bytes_per_code()) * rows                # SURVEY 8d per-code figure x the codes one step processes (per GPU)
     hbm_gbs = alg_bytes_step * args.steps / elapsed / 1e9
 
+    # N > 1 under the headline workload: also time the two partitionings that exchange data (RCCL all-reduce / all-gather)
+    strong = None
+    if world > 1 and args.workload == "cfg3" and not args.no_collectives:
+        del wl.h, wl.pooled_text, wl.pooled_graph
+        torch.cuda.empty_cache()
+        strong = collective_block(args, rank, world, dev)
+
     if rank == 0:
         total_codes = (float(args.rows or 600000) if args.workload in ("cfg5", "codeshard") else float(rows) * world) * args.steps
         value = total_codes / elapsed
@@ -567,6 +626,8 @@ def main():
                                            for k, v in prof.items() if k != kname and v["launches"]}},
             "exact_fp32_path": exact,
         }
+        if strong is not None:
+            line["extra"] = {"strong_scaling": strong}
         if args.workload == "cfg4":
             enc = wl.encoder_ms()
             line["dtype"] = "bf16 autocast (encoders, projections); the searches, their backward and the losses run in f32"

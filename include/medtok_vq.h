@@ -42,6 +42,15 @@ extern "C" {
 #define MEDTOK_PATH_AUTO 0          /* library picks the fastest exact path          */
 #define MEDTOK_PATH_F32_MFMA 1      /* brute force on v_mfma_f32_32x32x2_f32          */
 #define MEDTOK_PATH_F16_FILTER 2    /* fp16-MFMA shortlist + exact fp32 re-score: same bits, ~16x the matrix rate */
+#define MEDTOK_PATH_MASK 0xF        /* the selector proper; the bits above it are the test hooks below */
+/* Test hooks, OR-ed into any `path` argument: force launch-plan branches the default heuristics only take at very large shapes
+ * (code-range splits, the XCD-aware block order, the tail launch; the split cap of the exact kernel) so that small parity tests
+ * cover them.  Per call -- the library keeps no plan state; the *_workspace_bytes query must be given the same `path`.
+ * Results are bit-identical under every plan (tests/test_gpu_filter.py). */
+#define MEDTOK_PLAN_FILTER_SPLITS(s) (((s) & 0xFF) << 8)            /* 0 = default */
+#define MEDTOK_PLAN_FILTER_XCD(on) (((on) ? 2 : 1) << 16)           /* XCD-aware block order on / off (full 256-CU device only) */
+#define MEDTOK_PLAN_FILTER_TAIL(on) (((on) ? 2 : 1) << 18)          /* tail launch from 256 blocks up / never */
+#define MEDTOK_PLAN_SEARCH_MAX_SPLITS(s) (((s) & 0xFF) << 20)       /* 0 = default */
 
 /* flags for medtok_soft_assign_f32 */
 #define MEDTOK_ASSIGN_HARD 1        /* NormEMA form: topk == 1, zq = what[idx]        */
@@ -101,13 +110,6 @@ int medtok_debug_filter_scores_f32(const float *xhat, const float *xsq, int64_t 
 /* Test hook: where, inside the workspace of a filter-path search, the int32 count of rows that were handed to the exact kernel
  * lives (candidate-list overflow, out-of-range norms, NaN); (size_t)-1 when the shape does not take the filter path. */
 size_t medtok_debug_filter_fallback_count_offset(int64_t n, int64_t k_codes, int d, int topk, int path);
-
-/* Test hook: force plan branches the default heuristics only take at very large shapes (code-range splits, the XCD-aware
- * block order, the tail launch; the split cap of the exact kernel), so that
- * small parity tests cover them.  Process-wide; -1 restores the default for that field.  The product path never reads
- * environment variables.  Results are bit-identical under every plan (tests/test_gpu_filter.py). */
-int medtok_debug_plan_override(int64_t filter_splits, int64_t filter_xcd, int64_t filter_tail_min_blocks,
-                               int64_t search_max_splits);
 
 /* Soft assignment: w = softmax(-dist), zq = sum_j w_j * what[idx_j],
  * zq_ste = xref + (zq - xref), row_sqerr[r] = sum_i (zq - xref)^2.

@@ -25,6 +25,20 @@ ABI_VERSION = 1
 MAX_TOPK = 8
 PATH_AUTO, PATH_F32_MFMA, PATH_F16_FILTER = 0, 1, 2
 
+
+def plan_path(path: int = PATH_AUTO, filter_splits: int = 0, filter_xcd=None, filter_tail=None, search_max_splits: int = 0) -> int:
+    """Test hook (MEDTOK_PLAN_* in include/medtok_vq.h): a `path` argument that also forces launch-plan branches -- code-range
+    splits, XCD-aware block order on/off, tail launch on/off, the exact kernel's split cap -- for THIS call only (the library
+    keeps no plan state).  Results are bit-identical under every plan."""
+    p = path & 0xF
+    p |= (filter_splits & 0xFF) << 8
+    if filter_xcd is not None:
+        p |= (2 if filter_xcd else 1) << 16
+    if filter_tail is not None:
+        p |= (2 if filter_tail else 1) << 18
+    p |= (search_max_splits & 0xFF) << 20
+    return p
+
 _vp, _i64, _int, _sz, _f, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float, C.c_double
 
 # name -> (restype, argtypes); mirrors include/medtok_vq.h one to one
@@ -40,7 +54,6 @@ SIGNATURES = {
     "medtok_debug_filter_scores_workspace_bytes": (_sz, [_i64, _i64, _int]),
     "medtok_debug_filter_scores_f32": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "medtok_debug_filter_fallback_count_offset": (_sz, [_i64, _i64, _int, _int, _int]),
-    "medtok_debug_plan_override": (_int, [_i64, _i64, _i64, _i64]),
     "medtok_soft_assign_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _i64, _vp, _vp]),
     "medtok_sum_scale_f32": (_int, [_vp, _i64, _dbl, _vp, _vp]),
     "medtok_soft_vq_backward_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),

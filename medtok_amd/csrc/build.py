@@ -39,8 +39,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     newest = max(p.stat().st_mtime for p in deps)
     if not force and OUT.exists() and OUT.stat().st_mtime >= newest:
         return OUT
-    extra = os.environ.get("MEDTOK_HIPCC_EXTRA", "").split()     # dev knob, e.g. -DMEDTOK_SEARCH_BK=16
-    cmd = [hipcc(), *FLAGS, *extra, str(SRC), "-o", str(OUT)]
+    cmd = [hipcc(), *FLAGS, str(SRC), "-o", str(OUT)]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

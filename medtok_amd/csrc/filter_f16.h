@@ -40,19 +40,13 @@ constexpr size_t F_THR_BYTES = 256 * 64;                      // per row: the k 
 constexpr size_t F_INIT_BYTES = 2 * 256 * 4;                  // the accumulator start values (-2^15 |e|^2) of two code tiles
 constexpr size_t F_SMEM_BYTES = F_LDS_BYTES + F_THR_BYTES + F_INIT_BYTES;    // 146 KB
 constexpr int F_GLDS_PER_STAGE = 4;                           // LDS-DMA instructions each wave issues per stage
-#ifndef MEDTOK_FILTER_CAP
-#define MEDTOK_FILTER_CAP 48
-#endif
 // Candidate slots per (row, owner); a list that overflows sends its row to the exact kernel.  Measured at N = 600k, D = 768
 // (tools/cap_experiment.py, random rows): 32 slots overflow for 49 (K = 16384) / 506 (K = 49152) rows and cost 5-8 % through the
 // fallback; 48 and 96 overflow for none and time the same -- 48 halves the candidate region (1.8 GB instead of 3.7 GB per
 // 600k-row search).  Inputs that defeat the filter (thousands of near-identical codes) overflow any capacity and are simply
 // searched exactly.
-constexpr int F_CAP = MEDTOK_FILTER_CAP;
-#ifndef MEDTOK_FILTER_WM
-#define MEDTOK_FILTER_WM 2
-#endif
-constexpr int F_WM = MEDTOK_FILTER_WM;                        // code-side waves (2: wave tile 128 x 64; 1: wave tile 256 x 32)
+constexpr int F_CAP = 48;
+constexpr int F_WM = 2;                                       // code-side waves (wave tile 128 x 64)
 constexpr int F_WN = 8 / F_WM;                                // row-side waves
 constexpr int F_MT = 8 / F_WM;                                // 32-code MFMA tiles per wave
 constexpr int F_NT = 8 / F_WN;                                // 32-row MFMA tiles per wave
@@ -311,11 +305,7 @@ __device__ __forceinline__ void filter_scan(FilterRow<TOPK> &r, const f32x16 &a,
     for (int g = 0; g < 4; ++g) {
         const float a0 = a[4 * g], a1 = a[4 * g + 1], a2 = a[4 * g + 2], a3 = a[4 * g + 3];
         const float mx = v_max(v_max3(a0, a1, a2), a3);
-#ifndef MEDTOK_FILTER_NOHIT       // dev experiment: the tests alone
         if (__builtin_amdgcn_ballot_w64(mx >= r.L)) filter_hit<TOPK>(r, a0, a1, a2, a3, mx, cb + 8 * g, cbase, multi);
-#else
-        if (__builtin_amdgcn_ballot_w64(mx >= r.L)) asm volatile("s_nop 0");
-#endif
     }
 }
 
@@ -618,12 +608,9 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // therefore loads 16 registers per group, not 32, and copies nothing.
     auto step = [&](const half8 (&fb_cur)[F_NT], half8 (&fb_nxt)[F_NT], int slot, int t, auto first) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first)::value;
-#ifndef MEDTOK_FILTER_NOLDS
         read_b(fb_nxt, slot, t);
-#endif
 #pragma unroll
         for (int m = 0; m < F_MT; ++m) {
-#ifndef MEDTOK_FILTER_NOMFMA
             if (FIRST) {
                 acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb_cur[1], acc[m][0], 0, 0, 0);
                 acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb_cur[0], acc[m][0], 0, 0, 0);
@@ -632,12 +619,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
                 for (int nn = 0; nn < F_NT; ++nn)
                     acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb_cur[nn], acc[m][nn], 0, 0, 0);
             }
-#else
-            asm volatile("" ::"v"(fa[m]), "v"(fb_cur[0]), "v"(fb_cur[1]));
-#endif
-#ifndef MEDTOK_FILTER_NOLDS
             read_a(m, slot, t);
-#endif
         }
     };
 
@@ -680,30 +662,16 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
             _Pragma("unroll") for (int nn = 0; nn < F_NT; ++nn) {                                                  \
                 if (warm) filter_scan_rest<TOPK, false>(row[nn], acc[M][nn], cb_, cbase);                          \
                 else {                                                                                             \
-                    F_DEV_SCAN(filter_scan<TOPK>(row[nn], acc[M][nn], cb_, cbase, multi));                         \
+                    filter_scan<TOPK>(row[nn], acc[M][nn], cb_, cbase, multi);                                     \
                     if (multi) { filter_scan_rest<TOPK, true>(row[nn], acc[M][nn], cb_, cbase); multi = 0; }       \
                 }                                                                                                  \
             }                                                                                                      \
-            F_DEV_INIT(M, tile + 1);        /* (past the last tile: values of a clamped tile, never scanned) */     \
+            F_INIT_LDS(M, tile + 1);        /* (past the last tile: values of a clamped tile, never scanned) */     \
         } while (0)
-#ifdef MEDTOK_FILTER_SGPRINIT     /* dev experiment: round 2's first form of the restart */
-#define F_DEV_INIT(M, t) do { if ((t) < nct) F_INIT_GROUP(M, t); } while (0)
-#else
-#define F_DEV_INIT(M, t) F_INIT_LDS(M, t)
-#endif
-#ifdef MEDTOK_FILTER_NOSCAN       /* dev experiments: the epilogue without its scans / without the merge of the owners' lists */
-#define F_DEV_SCAN(x) do { } while (0)
-#else
-#define F_DEV_SCAN(x) x
-#endif
         F_ONE(0); F_ONE(1); F_ONE(2); F_ONE(3);
 #undef F_ONE
-#undef F_DEV_SCAN
-#undef F_DEV_INIT
         stage_init(tile + 2);               // into the buffer this tile's start values came from (last read a whole tile ago)
-#ifndef MEDTOK_FILTER_NOMERGE
         filter_merge_pair<TOPK>(row[0], row[1], wm, lh);
-#endif
         lds_init_wait(acc);
     };
 
@@ -751,9 +719,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         // the next step's operands have landed; own part of stage s+1 has landed; then everyone's has
         __builtin_amdgcn_s_waitcnt(LGKM0);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#ifndef MEDTOK_FILTER_NOBAR       // dev experiment
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
     };
     // second half: (DMA of stage s+3,) MFMA(s, t1) with the operand reads of (s+1, t0) between them
@@ -772,9 +738,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // every group switches code tiles together: the scan of all four runs at the end of the tile's last stage
     auto iteration = [&](int s, auto first) __attribute__((always_inline)) {
         first_half(s, first);
-#ifndef MEDTOK_FILTER_NODMA       // dev experiment: without it the ring keeps its prologue contents
         if (!late) stage();             // waves 0-3: stage s+3 (slot s-1: everyone is past reading it)
-#endif
         second_half(s);
     };
     int s = 0;
@@ -782,14 +746,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         iteration(s, std::true_type{});
         ++s;
         for (int kb = 1; kb < nkb; ++kb, ++s) iteration(s, std::false_type{});
-#ifndef MEDTOK_FILTER_NOEPI
         tile_epilogue(ct, ct == 0);
-#else
-#pragma unroll
-        for (int m = 0; m < F_MT; ++m)
-#pragma unroll
-            for (int nn = 0; nn < F_NT; ++nn) { asm volatile("" ::"v"(acc[m][nn])); }
-#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail re-issues may still be in flight
     if (!DUMP) {

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <type_traits>
 #include <vector>
 
@@ -259,10 +260,7 @@ __device__ __forceinline__ void topk_insert_lex(float (&bv)[T], int (&bi)[T], fl
 // permutation anywhere.  Rows are padded to 36 floats: conflict-free ds_read_b128 (16 lanes x
 // stride 36 dwords hit 16 distinct 4-bank slots) and ds_write_b128.
 constexpr int S_BM = 128, S_BN = 128;
-#ifndef MEDTOK_SEARCH_BK
-#define MEDTOK_SEARCH_BK 32
-#endif
-constexpr int S_BK = MEDTOK_SEARCH_BK;                    // 32: 2 blocks/CU (74 KB LDS); 16: 3 blocks/CU (41 KB)
+constexpr int S_BK = 32;                                  // 2 blocks/CU (74 KB LDS); 16 with 3 blocks/CU measured the same
 constexpr int S_LD = S_BK + 4;                            // row stride in floats (36 and 20 are both conflict-free)
 constexpr int S_TILE = S_BM * S_LD;                       // floats per staged operand tile
 constexpr size_t S_LDS_BYTES = (size_t)4 * S_TILE * sizeof(float);   // A[2] + B[2]
@@ -374,14 +372,6 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
     auto tile_epilogue = [&](int ct) __attribute__((always_inline)) {
         // ---- epilogue: d = (|x|^2 + |e|^2) - 2 x.e for this lane's 64 codes, fold into the list
         const int cbase = code_lo + ct * S_BM;
-#ifdef MEDTOK_SEARCH_NOEPI        // dev experiment: main loop only (results are garbage)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            asm volatile("" ::"v"(acc[m]));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-        }
-#else
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             // |e|^2 of this lane's 16 codes of the tile: four consecutive codes per register group, so four 16-byte loads
@@ -427,7 +417,6 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
                 }
             }
         }
-#endif
     };
 
     if constexpr (!KTAIL && !INDIRECT) {
@@ -642,18 +631,38 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict
 
 #include "filter_f16.h"
 
-// Test / dev hook (medtok_debug_plan_override): force plan branches that the default heuristics only take at very large
-// shapes, so small tests can cover them.  Process-wide, -1 = default; the product path never reads the environment.
+// Test hook: plan branches that the default heuristics only take at very large shapes can be forced PER CALL through the upper
+// bits of the `path` argument (MEDTOK_PLAN_* in medtok_vq.h), so small parity tests cover them.  No process state: the
+// workspace query and the launch decode the same argument.  The product path never reads the environment.
 struct PlanOverride { long filter_splits = -1, filter_xcd = -1, filter_tail_min_blocks = -1, search_max_splits = -1; };
-static PlanOverride g_plan_override;
-
-extern "C" int medtok_debug_plan_override(int64_t filter_splits, int64_t filter_xcd, int64_t filter_tail_min_blocks, int64_t search_max_splits)
+static PlanOverride decode_plan(int path)
 {
-    g_plan_override.filter_splits = (long)filter_splits;
-    g_plan_override.filter_xcd = (long)filter_xcd;
-    g_plan_override.filter_tail_min_blocks = (long)filter_tail_min_blocks;
-    g_plan_override.search_max_splits = (long)search_max_splits;
-    return 0;
+    PlanOverride o;
+    const int fs = (path >> 8) & 0xFF, xcd = (path >> 16) & 3, tail = (path >> 18) & 3, ss = (path >> 20) & 0xFF;
+    if (fs) o.filter_splits = fs;
+    if (xcd) o.filter_xcd = xcd - 1;
+    if (tail) o.filter_tail_min_blocks = tail == 1 ? 0 : 256;
+    if (ss) o.search_max_splits = ss;
+    return o;
+}
+static inline int path_id(int path) { return path & MEDTOK_PATH_MASK; }
+
+// Device geometry the launch plans are sized for, queried once per device (hipDeviceGetAttribute); without a device (a
+// workspace query on a CPU-only box) the full MI355X is assumed.  `full` = the unpartitioned chip (256 CUs in 8 XCDs of 32):
+// the XCD-aware block order is only used there; on a partitioned device (CPX / a CU mask) the round arithmetic follows the
+// CU count that is actually visible.
+struct DevInfo { int cus; bool full; };
+static DevInfo dev_info()
+{
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return {256, true}; }
+    int cus = cached[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+        cached[dev].store(cus, std::memory_order_relaxed);
+    }
+    return {cus, cus == 256};
 }
 
 struct SearchPlan {
@@ -667,21 +676,22 @@ struct SearchPlan {
     int tail_splits, tail_codes_per_split;
 };
 
-static SearchPlan plan_search(int64_t n, int64_t k_codes, int topk)
+static SearchPlan plan_search(int64_t n, int64_t k_codes, int topk, const PlanOverride &ov)
 {
     SearchPlan p;
+    const DevInfo di = dev_info();
     p.tslots = topk == 1 ? 1 : (topk <= 5 ? 5 : 8);
     p.row_tiles = (n + S_BN - 1) / S_BN;
     const long code_tiles = (k_codes + S_BM - 1) / S_BM;
-    // Blocks all cost the same and run 2-3 per CU on 256 CUs, so a launch of B blocks wastes up to
-    // one "round" of ~600; ask for >= 16384 blocks (tail <= ~4%) by splitting the code range.
-    long want = (16384 + p.row_tiles - 1) / p.row_tiles;
+    // Blocks all cost the same and run 2-3 per CU, so a launch of B blocks wastes up to one "round" of ~2.3 blocks per CU
+    // (600 on the full chip); ask for >= 64 blocks per CU (16384: tail <= ~4%) by splitting the code range.
+    long want = (64L * di.cus + p.row_tiles - 1) / p.row_tiles;
     if (want < 1) want = 1;
     if (want > code_tiles) want = code_tiles;
     // at most 64 splits -- except for one or two row tiles (batches of <= 256 rows), where 64 splits would leave half
     // the CUs without a block: n = 256, K = 49152: 463 -> 276 us with 128 splits; n = 64: 459 -> 202 us with 256
-    long cap = p.row_tiles <= 2 ? 256 / p.row_tiles : 64;
-    if (g_plan_override.search_max_splits > 0) cap = g_plan_override.search_max_splits;
+    long cap = p.row_tiles <= 2 ? lmin(256, di.cus) / p.row_tiles : 64;
+    if (ov.search_max_splits > 0) cap = ov.search_max_splits;
     if (want > cap) want = cap;
     const long tiles_per_split = (code_tiles + want - 1) / want;
     p.codes_per_split = (int)(tiles_per_split * S_BM);
@@ -692,8 +702,8 @@ static SearchPlan plan_search(int64_t n, int64_t k_codes, int topk)
     // (measured at N = 600k, K = 16384: the epilogue is 10 % of the kernel with 4 splits).  What splitting bought -- a short
     // last round -- comes from a second launch instead: the row tiles of the partly filled last round, with enough splits to be
     // one round of short blocks.
-    if (p.row_tiles >= 1024 && n < (1ll << 31) && g_plan_override.search_max_splits <= 0) {
-        const long round = 512;
+    if (p.row_tiles >= 4L * di.cus && n < (1ll << 31) && ov.search_max_splits <= 0) {
+        const long round = 2L * di.cus;      // two blocks per CU resident
         const long main_tiles = p.row_tiles / round * round, tail_tiles = p.row_tiles - main_tiles;
         p.splits = 1;
         p.codes_per_split = (int)(code_tiles * S_BM);
@@ -718,9 +728,10 @@ struct FilterPlan {
     int tail_splits, tail_codes_per_split, own_tail;
 };
 
-static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
+static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk, const PlanOverride &ov)
 {
     FilterPlan f;
+    const DevInfo di = dev_info();
     f.tslots = topk == 1 ? 1 : (topk <= 5 ? 5 : 8);
     f.n_pad = (n + F_BN - 1) / F_BN * F_BN;
     f.k_pad = (k_codes + F_BM - 1) / F_BM * F_BM;
@@ -729,14 +740,14 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
     const long code_tiles = f.k_pad / F_BM;
     // every split adds 4 candidate lists per row, so split only as far as filling the chip needs
     // one 8-wave block per CU: a launch of B equal blocks wastes up to one round of 256
-    long want = f.row_tiles >= 1024 ? 2 : (1024 + f.row_tiles - 1) / f.row_tiles;
+    long want = f.row_tiles >= 4L * di.cus ? 2 : (4L * di.cus + f.row_tiles - 1) / f.row_tiles;
     // With >= 1024 row tiles the blocks are ordered XCD-aware (see filter_f16_kernel): the 32 CUs of an XCD share
     // 32/splits x tiles, which then stay in its 4 MB L2 (393 KB each at D = 768) instead of being re-streamed from
     // the Infinity Cache once per code tile (measured at N = 600k, K = 49152: 6-8 % on the kernel).  Two splits: more
     // would keep more of the x tiles resident but loosen the per-split thresholds (4: +3.6 %, 8: +7.7 % kernel time).
-    bool xcd = f.row_tiles >= 1024;
-    if (g_plan_override.filter_splits > 0) want = g_plan_override.filter_splits;
-    if (g_plan_override.filter_xcd >= 0) xcd = g_plan_override.filter_xcd != 0;
+    bool xcd = di.full && f.row_tiles >= 1024;      // (the block order below is written for 8 XCDs of 32 CUs)
+    if (ov.filter_splits > 0) want = ov.filter_splits;
+    if (ov.filter_xcd >= 0) xcd = di.full && ov.filter_xcd != 0;
     if (want > code_tiles) want = code_tiles;
     if (want > 16) want = 16;      // (more splits for small batches were measured: slower from 32 up)
     if (want < 1) want = 1;
@@ -750,16 +761,17 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk)
     // with enough splits to be ONE round of short blocks (N = 600k: 40 row tiles x 6 splits, a third of a round).
     f.main_tiles = f.row_tiles; f.tail_splits = 0; f.tail_codes_per_split = 0; f.own_tail = 0;
     const long blocks = f.row_tiles * f.splits;
-    long tail_min_blocks = 8 * 256;
-    if (g_plan_override.filter_tail_min_blocks >= 0)
-        tail_min_blocks = g_plan_override.filter_tail_min_blocks > 0 ? g_plan_override.filter_tail_min_blocks : (1L << 60);   // 0 = off
+    long tail_min_blocks = 8L * di.cus;
+    if (ov.filter_tail_min_blocks >= 0)
+        tail_min_blocks = ov.filter_tail_min_blocks > 0 ? ov.filter_tail_min_blocks : (1L << 60);   // 0 = off
     const bool tail = blocks >= tail_min_blocks && f.splits <= 4 && code_tiles >= 4L * f.splits;
     if (tail) {
-        const long main_blocks = blocks / 256 * 256;
-        const long main_tiles = main_blocks / f.splits;             // 256 % splits == 0
+        const long round = (long)di.cus / f.splits * f.splits;     // one block per CU, whole row tiles (splits <= 4)
+        const long main_blocks = blocks / round * round;
+        const long main_tiles = main_blocks / f.splits;
         // as many splits as make the tail ONE round of short blocks (at most 16: every split costs candidates)
         const long tail_tiles = f.row_tiles - main_tiles;
-        const long ts = tail_tiles > 0 ? lmin(lmin(16, code_tiles), 256 / tail_tiles) : 0;
+        const long ts = tail_tiles > 0 ? lmin(lmin(16, code_tiles), round / tail_tiles) : 0;
         if (ts >= 2L * f.splits) {
             const long tps = (code_tiles + ts - 1) / ts;
             f.main_tiles = main_tiles;
@@ -830,6 +842,7 @@ static bool filter_eligible(int64_t n, int64_t k_codes, int d, int topk)
 
 static int resolve_path(int path, int64_t n, int64_t k_codes, int d, int topk)
 {
+    path = path_id(path);
     if (path == MEDTOK_PATH_AUTO) return filter_eligible(n, k_codes, d, topk) ? MEDTOK_PATH_F16_FILTER : MEDTOK_PATH_F32_MFMA;
     if (path == MEDTOK_PATH_F16_FILTER && (double)k_codes * (double)(d + 64) >= 536870912.0) return MEDTOK_PATH_F32_MFMA;
     return path;
@@ -838,9 +851,10 @@ static int resolve_path(int path, int64_t n, int64_t k_codes, int d, int topk)
 extern "C" size_t medtok_search_workspace_bytes(int64_t n, int64_t k_codes, int d, int topk, int path)
 {
     if (n <= 0 || k_codes <= 0 || topk < 1 || topk > MEDTOK_MAX_TOPK) return 0;
+    const PlanOverride ov = decode_plan(path);
     if (resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER)
-        return filter_ws_layout(nullptr, n, plan_filter(n, k_codes, d, topk)).total;
-    SearchPlan p = plan_search(n, k_codes, topk);
+        return filter_ws_layout(nullptr, n, plan_filter(n, k_codes, d, topk, ov)).total;
+    SearchPlan p = plan_search(n, k_codes, topk, ov);
     if (p.tail_splits > 0) {
         const size_t tail_rows = (size_t)(n - p.main_tiles * S_BN);
         return align_up((size_t)p.tail_splits * tail_rows * p.tslots * sizeof(float), 256) +
@@ -926,9 +940,9 @@ struct FuseAssign { const float *xref; float *w; float *zq; long zq_stride; bool
 template <int T, bool KTAIL>
 static int launch_filter(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
                          int64_t k_codes, int d, int topk, int64_t *idx, float *dist, void *ws, size_t ws_bytes,
-                         hipStream_t s, FuseAssign *fuse)
+                         hipStream_t s, FuseAssign *fuse, const PlanOverride &ov)
 {
-    const FilterPlan f = plan_filter(n, k_codes, d, topk);
+    const FilterPlan f = plan_filter(n, k_codes, d, topk, ov);
     const FilterWs w = filter_ws_layout(ws, n, f);
     if (!ws || ws_bytes < w.total) return fail("search(filter): workspace too small (%zu < %zu)", ws_bytes, w.total);
     if (!(fuse && fuse->xh_done))      // (the one-call forward's rownorm has already written the fp16 image of x)
@@ -985,10 +999,10 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
 template <int T>
 static int launch_filter_t(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
                            int64_t k_codes, int d, int topk, int64_t *idx, float *dist, void *ws, size_t ws_bytes, hipStream_t s,
-                           FuseAssign *fuse)
+                           FuseAssign *fuse, const PlanOverride &ov)
 {
-    if (d % S_BK) return launch_filter<T, true>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse);
-    return launch_filter<T, false>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse);
+    if (d % S_BK) return launch_filter<T, true>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse, ov);
+    return launch_filter<T, false>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse, ov);
 }
 
 // `fuse` (internal callers only): when the filter path runs, its re-score kernel also does the soft assignment described there
@@ -999,19 +1013,20 @@ static int search_impl(const float *xhat, const float *xsq, int64_t n, const flo
     if (n < 0 || k_codes <= 0 || d <= 0 || (d & 3)) return fail("search: bad shape n=%ld K=%ld d=%d (d %% 4 == 0)", (long)n, (long)k_codes, d);
     if (topk < 1 || topk > MEDTOK_MAX_TOPK || topk > k_codes) return fail("search: topk=%d unsupported (1..%d, <= K)", topk, MEDTOK_MAX_TOPK);
     if (k_codes >= (1ll << 31)) return fail("search: K too large");
-    if (path != MEDTOK_PATH_AUTO && path != MEDTOK_PATH_F32_MFMA && path != MEDTOK_PATH_F16_FILTER) return fail("search: unknown path %d", path);
+    if (path_id(path) != MEDTOK_PATH_AUTO && path_id(path) != MEDTOK_PATH_F32_MFMA && path_id(path) != MEDTOK_PATH_F16_FILTER) return fail("search: unknown path %d", path_id(path));
+    const PlanOverride ov = decode_plan(path);
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int tslots = topk == 1 ? 1 : (topk <= 5 ? 5 : 8);
     if (resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER) {
         if (n >= (1ll << 31)) return fail("search(filter): n too large");
         switch (tslots) {
-        case 1: return launch_filter_t<1>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse);
-        case 5: return launch_filter_t<5>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse);
-        default: return launch_filter_t<8>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse);
+        case 1: return launch_filter_t<1>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse, ov);
+        case 5: return launch_filter_t<5>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse, ov);
+        default: return launch_filter_t<8>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, s, fuse, ov);
         }
     }
-    const SearchPlan p = plan_search(n, k_codes, topk);
+    const SearchPlan p = plan_search(n, k_codes, topk, ov);
     switch (tslots) {
     case 1: return launch_search_t<1>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
     case 5: return launch_search_t<5>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
@@ -1032,7 +1047,7 @@ extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64
 extern "C" size_t medtok_debug_filter_fallback_count_offset(int64_t n, int64_t k_codes, int d, int topk, int path)
 {
     if (n <= 0 || k_codes <= 0 || resolve_path(path, n, k_codes, d, topk) != MEDTOK_PATH_F16_FILTER) return (size_t)-1;
-    const FilterWs w = filter_ws_layout((void *)256, n, plan_filter(n, k_codes, d, topk));
+    const FilterWs w = filter_ws_layout((void *)256, n, plan_filter(n, k_codes, d, topk, decode_plan(path)));
     return (size_t)((char *)w.fb_count - (char *)256);
 }
 
@@ -1041,7 +1056,7 @@ extern "C" size_t medtok_debug_filter_fallback_count_offset(int64_t n, int64_t k
 extern "C" size_t medtok_debug_filter_scores_workspace_bytes(int64_t n, int64_t k_codes, int d)
 {
     if (n <= 0 || k_codes <= 0 || d <= 0) return 0;
-    FilterPlan f = plan_filter(n, k_codes, d, 5);
+    FilterPlan f = plan_filter(n, k_codes, d, 5, PlanOverride());
     return align_up((size_t)f.n_pad * f.dp * 2, 256) + align_up((size_t)f.k_pad * f.dp * 2, 256) + 512 + align_up((size_t)f.k_pad * 4, 256);
 }
 
@@ -1049,7 +1064,7 @@ extern "C" int medtok_debug_filter_scores_f32(const float *xhat, const float *xs
                                               int64_t k_codes, int d, float *scores, void *ws, size_t ws_bytes, void *stream)
 {
     if (n <= 0 || k_codes <= 0 || d <= 0 || (d & 3)) return fail("debug_filter_scores: bad shape");
-    FilterPlan f = plan_filter(n, k_codes, d, 5);
+    FilterPlan f = plan_filter(n, k_codes, d, 5, PlanOverride());
     const size_t xb = align_up((size_t)f.n_pad * f.dp * 2, 256), wb = align_up((size_t)f.k_pad * f.dp * 2, 256);
     if (!ws || ws_bytes < xb + wb + 512 + (size_t)f.k_pad * 4) return fail("debug_filter_scores: workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -1933,7 +1948,7 @@ extern "C" int medtok_normalized_search_f32(const float *z, int64_t n, int d, co
     const bool filter_path = topk >= 1 && topk <= MEDTOK_MAX_TOPK && k_codes < (1ll << 31) && n < (1ll << 31) &&
                              resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER;
     if (filter_path) {
-        const FilterPlan f = plan_filter(n, k_codes, d, topk);
+        const FilterPlan f = plan_filter(n, k_codes, d, topk, decode_plan(path));
         const FilterWs fw = filter_ws_layout(ws, n, f);
         if (!ws || ws_bytes < fw.total) return fail("normalized_search: workspace too small (%zu < %zu)", ws_bytes, fw.total);
         hipStream_t s = (hipStream_t)stream;
@@ -1971,7 +1986,7 @@ extern "C" int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d, cons
     const bool filter_path = topk >= 1 && topk <= MEDTOK_MAX_TOPK && resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER;
     if (try_fuse && filter_path && xhat && !(d & 3)) {
         // the filter's fp16 image of the normalised rows comes out of the same pass that normalises them
-        const FilterPlan f = plan_filter(n, k_codes, d, topk);
+        const FilterPlan f = plan_filter(n, k_codes, d, topk, decode_plan(path));
         const FilterWs fw = filter_ws_layout(sws, n, f);
         hipStream_t s = (hipStream_t)stream;
         hipLaunchKernelGGL(rownorm_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, (long)n, d, xhat, xsq, fw.xh, f.dp);

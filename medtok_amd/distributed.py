@@ -56,10 +56,35 @@ def row_shard(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# Measurement hook (bench.py): when set to a list, every data-path collective below is bracketed by HIP events on the current
+# stream -- torch's synchronous collectives make the current stream wait for the communicator's stream, so the pair encloses the
+# collective -- and (name, start, stop, payload_bytes) is appended.  None = no overhead.
+COLLECTIVE_TIMER = None
+
+
+def _timed(name: str, nbytes: int, fn):
+    timer = COLLECTIVE_TIMER
+    if timer is None or not torch.cuda.is_available():
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    timer.append((name, e0, e1, int(nbytes)))
+    return out
+
+
+def all_reduce_sum(t: torch.Tensor) -> None:
+    """torch.distributed.all_reduce(t) (SUM, in place, default group) -- what NormEMAVectorQuantizer binds at construction time
+    (norm_ema_quantizer.py:155-159), visible to the measurement hook above."""
+    _timed("all_reduce", t.numel() * t.element_size(), lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+
+
 def all_reduce_stats(stats: torch.Tensor, group=None) -> torch.Tensor:
     """In-place SUM of the fused EMA statistics buffer across ranks (no-op single-process)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        _timed("all_reduce", stats.numel() * stats.element_size(),
+               lambda: dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group))
     return stats
 
 
@@ -94,6 +119,24 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
 
 
+def gather_ragged(local: torch.Tensor, group=None) -> torch.Tensor:
+    """Concatenate per-rank tensors whose FIRST dimension differs (rank order) on every rank: one all-gather of the lengths,
+    one of the rows padded to the longest shard.  Single-process: returns `local`."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    lens = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(lens, n_local, group=group)
+    lens = [int(x.item()) for x in lens]
+    longest = max(lens)
+    pad = local.new_zeros((longest,) + tuple(local.shape[1:]))
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    _timed("all_gather", pad.numel() * pad.element_size() * world, lambda: dist.all_gather(parts, pad, group=group))
+    return torch.cat([p[:m] for p, m in zip(parts, lens)], dim=0)
+
+
 def code_shard(k_codes: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [lo, hi) slice of the codebook for `rank` (same balancing rule as row_shard)."""
     return row_shard(k_codes, rank, world)
@@ -102,8 +145,8 @@ def code_shard(k_codes: int, rank: int, world: int) -> Tuple[int, int]:
 def code_sharded_search(xhat: torch.Tensor, xsq: torch.Tensor, what_local: torch.Tensor, wsq_local: torch.Tensor,
                         code_lo: int, topk: int, group=None, search_fn=None, merge_fn=None):
     """The variant north_star names: every rank holds a slice [code_lo, code_lo + K_local) of the codebook and ALL rows.
-    Local top-k over the slice -> all-gather of the (distance, global id) lists (n * k * 12 bytes per rank over xGMI)
-    -> exact (d, index) merge.  Identical bits to a single-GPU search because the contract's dot-product order does
+    Local top-k over the slice -> ONE all-gather of the packed (distance, global id) lists (n * k * 8 bytes per rank over
+    xGMI) -> exact (d, index) merge.  Identical bits to a single-GPU search because the contract's dot-product order does
     not depend on where a code lives.  `search_fn` / `merge_fn` default to the HIP ops; the CPU gloo test passes the
     oracle's so the exchange logic runs without a GPU."""
     if search_fn is None or merge_fn is None:
@@ -115,8 +158,13 @@ def code_sharded_search(xhat: torch.Tensor, xsq: torch.Tensor, what_local: torch
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return idx, d_local
     world = dist.get_world_size(group)
-    d_parts = [torch.empty_like(d_local) for _ in range(world)]
-    i_parts = [torch.empty_like(idx) for _ in range(world)]
-    dist.all_gather(d_parts, d_local.contiguous(), group=group)
-    dist.all_gather(i_parts, idx.contiguous(), group=group)
-    return merge_fn(torch.stack(d_parts), torch.stack(i_parts))
+    n, k = idx.shape
+    # ONE collective: a (distance, id) pair travels as one int64 -- the fp32 bits of the distance in the high word, the global
+    # code id (< 2^32) in the low word: n * k * 8 bytes per rank instead of two gathers of 4 + 8
+    packed = (d_local.contiguous().view(torch.int32).to(torch.int64) << 32) | (idx & 0xFFFFFFFF)
+    gathered = torch.empty((world * n, k), dtype=torch.int64, device=packed.device)
+    _timed("all_gather", gathered.numel() * 8, lambda: dist.all_gather_into_tensor(gathered, packed, group=group))
+    gathered = gathered.view(world, n, k)
+    d_parts = (gathered >> 32).to(torch.int32).view(torch.float32)
+    i_parts = gathered & 0xFFFFFFFF
+    return merge_fn(d_parts, i_parts)

@@ -54,20 +54,44 @@ def save_outputs(out_dir, embeddings: np.ndarray, tokens: np.ndarray, weights: n
 @torch.no_grad()
 def run_inference(model: MultimodalTokenizer, batches: Iterable, out_dir: Optional[str] = None, device=None):
     """Loop of inference.py:105-115 over `batches` (objects with the fields MultimodalTokenizer.forward
-    reads plus `code_indices`), then order by code index and optionally write the three arrays."""
+    reads plus `code_indices`), then order by code index and optionally write the three arrays.
+
+    Multi-rank (reference inference.py:66-93: DistributedSampler + DDP, one process per GPU): every rank passes ITS batches; the
+    per-rank results are gathered over the process group (RCCL on GPUs), ordered by code index -- a sampler that pads the last
+    round by repeating codes leaves duplicates: the first copy is kept -- and rank 0 writes the files.  Every rank returns the
+    full, ordered arrays.  (The reference lets every rank write its own shard over the same three files; the evident intent is
+    one table of all codes, which is what the downstream readers of embeddings_all.npy expect.)"""
+    from . import distributed as mdist
     model.eval()
     embs, toks, wts, order = [], [], [], []
     for x in batches:
         if device is not None and hasattr(x, "to"):
             x = x.to(device)
         e, t, w = model(x)
-        embs.append(e.cpu()); toks.append(t.cpu()); wts.append(w.cpu())
-        order.append(torch.as_tensor(x.code_indices).reshape(-1).cpu())
-    order = torch.cat(order)
+        embs.append(e); toks.append(t); wts.append(w)
+        order.append(torch.as_tensor(x.code_indices).reshape(-1).to(e.device, torch.int64))
+    multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    if not embs:
+        if not multi:
+            raise ValueError("run_inference: no batches")
+        k, e_dim = model.quantize.k, model.quantize.e_dim
+        dev = device if device is not None else next(model.parameters()).device
+        embs, toks = [torch.zeros(0, 4 * e_dim, device=dev)], [torch.zeros(0, 4, k, dtype=torch.int64, device=dev)]
+        wts, order = [torch.zeros(0, 4, k, device=dev)], [torch.zeros(0, dtype=torch.int64, device=dev)]
+    emb, tok, wt, order = torch.cat(embs), torch.cat(toks), torch.cat(wts), torch.cat(order)
+    rank = 0
+    if multi:
+        rank = torch.distributed.get_rank()
+        emb, tok, wt, order = (mdist.gather_ragged(t.contiguous()) for t in (emb, tok, wt, order))
     perm = torch.argsort(order, stable=True)
-    embeddings = torch.cat(embs)[perm].numpy()
-    tokens = torch.cat(toks)[perm].numpy()
-    weights = torch.cat(wts)[perm].numpy()
-    if out_dir is not None:
+    sorted_ids = order[perm]
+    if sorted_ids.numel() > 1:                       # drop repeated codes (a padding sampler's wrap-around): keep the first copy
+        keep = torch.ones_like(sorted_ids, dtype=torch.bool)
+        keep[1:] = sorted_ids[1:] != sorted_ids[:-1]
+        perm = perm[keep]
+    embeddings = emb[perm].cpu().numpy()
+    tokens = tok[perm].cpu().numpy()
+    weights = wt[perm].cpu().numpy()
+    if out_dir is not None and rank == 0:
         save_outputs(out_dir, embeddings, tokens, weights)
     return embeddings, tokens, weights

@@ -51,7 +51,8 @@ def info_nce_loss(q, k, temperature=0.07):
 
 
 def _pad4(*ts):
-    """kernels stride float4; zero columns change neither dot products nor norms"""
+    """kernels stride float4; zero columns change neither dot products nor norms.  A width that is not a multiple of 4 costs one
+    padded COPY of each operand per call (F.pad); widths that are (every configuration of the reference: e_dim 64 / 768) cost nothing."""
     d = ts[0].shape[-1]
     if d % 4 == 0:
         return ts
@@ -67,13 +68,13 @@ class _AlignmentFunction(torch.autograd.Function):
         a, b = mu1.detach().float().contiguous(), mu2.detach().float().contiguous()
         ctx.save_for_backward(a, b)
         ctx.in_dtypes = (mu1.dtype, mu2.dtype)
-        return ops.sum_scale(ops.row_dot(a, b), 1.0 / a.shape[0])
+        return ops.sum_scale(ops.row_dot(a, b), (1.0 / a.shape[0]) if a.shape[0] else float("nan"))     # mean of nothing: nan, like torch.mean
 
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         g = g.float().contiguous()
-        c = 1.0 / a.shape[0]
+        c = (1.0 / a.shape[0]) if a.shape[0] else float("nan")
         return (ops.scale_by_device_scalar(b, g, None, c).to(ctx.in_dtypes[0]),
                 ops.scale_by_device_scalar(a, g, None, c).to(ctx.in_dtypes[1]))
 

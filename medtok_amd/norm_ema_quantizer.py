@@ -18,6 +18,7 @@ import torch
 import torch.distributed as distributed
 import torch.nn as nn
 
+from . import distributed as mdist
 from . import ops
 
 
@@ -128,7 +129,7 @@ class NormEMAVectorQuantizer(nn.Module):
         # like the reference (:155-159) the choice is made once, at construction time
         self.fused_head = True           # l2norm + search in one library call where no autograd graph is needed (forward)
         if distributed.is_available() and distributed.is_initialized():
-            self.all_reduce_fn = distributed.all_reduce
+            self.all_reduce_fn = mdist.all_reduce_sum        # torch.distributed.all_reduce (RCCL on GPUs), SUM, in place
         else:
             self.all_reduce_fn = nn.Identity()
 

@@ -9,7 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import PATH_AUTO, PATH_F16_FILTER, PATH_F32_MFMA, MAX_TOPK  # noqa: F401
+from ._lib import PATH_AUTO, PATH_F16_FILTER, PATH_F32_MFMA, MAX_TOPK, plan_path  # noqa: F401
 
 
 # Profiling hook (bench.py): when set to a list, every search CALL (all of its kernels) is bracketed
@@ -31,10 +31,19 @@ def profile_end() -> dict:
     return {names[i]: dict(ms=ms[i], flops=fl[i], launches=ln[i]) for i in range(3)}
 
 
-def debug_plan_override(filter_splits: int = -1, filter_xcd: int = -1, filter_tail_min_blocks: int = -1,
-                        search_max_splits: int = -1) -> None:
-    """Test hook (medtok_debug_plan_override): force plan branches of the search kernels; call with no arguments to reset."""
-    _lib.check(_lib.load().medtok_debug_plan_override(filter_splits, filter_xcd, filter_tail_min_blocks, search_max_splits), "medtok_debug_plan_override")
+MedTokLibraryError = _lib.MedTokLibraryError
+
+
+def attention_width(d: int) -> int:
+    """Width the ragged attention kernels run a D-wide problem at: D itself for 64 and multiples of 128 up to 768, else the next
+    such width (the caller appends zero columns).  Wider than 768 is refused: a 32-key chunk of fp32 rows would not fit the LDS."""
+    if d <= 64:
+        return 64
+    w = (d + 127) // 128 * 128
+    if w > 768:
+        raise _lib.MedTokLibraryError(f"cross-attention width D = {d} is not supported by the gfx950 attention kernels: they take D <= 768 "
+                                      f"(64 or a multiple of 128 natively, anything else zero-padded to the next such width)")
+    return w
 
 
 def _stream(t: torch.Tensor) -> int:

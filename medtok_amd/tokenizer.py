@@ -130,7 +130,10 @@ class MultimodalTokenizer(nn.Module):
         text_aug = nodes_aug = pooled_aug = None
         with_aug = (self.training or self.eval_aug_searches) if _with_aug is None else _with_aug
         if with_aug:
-            text_aug = self.text_mapped(self.tokenize_text(inputs, aug=True))
+            # the reference encodes the text a second time for the aug view with the same frozen model and the same inputs
+            # (tokenizer.py:211-212: if_aug is never set); outside training that pass is bit-identical to the first, so the eval
+            # forward reuses it (same values, same usage-window trajectory) and only the aug GRAPH view is encoded
+            text_aug = self.text_mapped(self.tokenize_text(inputs, aug=True)) if self.training or hasattr(inputs, "text_features_aug") else text
             nodes_aug = self.tokenize_graph(inputs, aug=True)
             pooled_aug = global_mean_pool(nodes_aug, batch, bsz)
         result = self.quant(text, nodes, pooled, text_aug, nodes_aug, pooled_aug, mask, batch)

@@ -103,7 +103,8 @@ class CrossAttention(nn.Module):
 
     @staticmethod
     def _folded_layer(layer, query, kv, key_valid):
-        """One CrossAttentionLayer with the key/value projections folded into the query side.
+        """(Comparator form, used by pooled_reference only.)  One CrossAttentionLayer with the key/value projections folded into
+        the query side, on PADDED batches in plain torch ops.
 
         nn.MultiheadAttention projects every key row: 4*T*D^2 flops per layer for T key rows.  With few
         queries against many keys (graph nodes attending to <= 512 text tokens, or the single CLS query
@@ -128,9 +129,11 @@ class CrossAttention(nn.Module):
         with torch.autocast(device_type=query.device.type, enabled=False):
             qf32, kv32 = qf.float(), kv.float()
             scores = torch.bmm(qf32, kv32.transpose(1, 2)) * (hd ** -0.5)
-            scores = scores.masked_fill(~key_valid[:, None, :], float("-inf"))
-            prob = torch.softmax(scores, dim=-1)
-            prob = prob.masked_fill(~key_valid.any(-1)[:, None, None], 0.0)     # no valid key at all: attend to nothing (not NaN)
+            any_valid = key_valid.any(-1)[:, None, None]
+            # a code with no valid key: its scores stay finite (0) through the softmax and its probabilities are zeroed after it --
+            # a row of -inf would make softmax (and, in training, its gradient) NaN for the whole batch
+            scores = torch.where(any_valid, scores.masked_fill(~key_valid[:, None, :], float("-inf")), torch.zeros_like(scores))
+            prob = torch.softmax(scores, dim=-1) * any_valid.to(scores.dtype)
             if layer.training and mha.dropout > 0.0:
                 prob = torch.nn.functional.dropout(prob, mha.dropout)
             ctx = torch.bmm(prob, kv32).view(bsz, rows, heads, dim)
@@ -212,27 +215,42 @@ class CrossAttention(nn.Module):
         return ln(rows + layer.dropout(mha.out_proj(attended)))
 
     def _pooled_packed(self, text, valid_len, nodes_sorted, batch_sorted, slot, counts, starts, max_nodes, core, autograd=False):
-        """`pooled` with no padding anywhere: packed query rows, ragged attention core.
-        `core(q, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale)` is ops.shared_kv_attention at inference; with
-        `autograd` every call goes through _RaggedAttentionFunction instead (HIP forward with the layer's attention dropout in
-        training mode + HIP backward)."""
+        """`pooled` with no padding of rows anywhere: packed query rows, ragged attention core.
+        `core(q, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale)` is ops.shared_kv_attention at inference (or, from
+        pooled_reference, the oracle's restatement); with `autograd` every call goes through _RaggedAttentionFunction instead
+        (HIP forward with the layer's attention dropout in training mode + HIP backward).
+        The gfx950 kernels take D = 64 or a multiple of 128 up to 768: any other width D <= 768 runs on the same kernels with
+        zero COLUMNS appended to queries and keys (they change neither the scores nor the first D output columns)."""
         bsz, seq_len, dim = text.shape
         mha = self.model[0].multihead_attn
         heads, scale = mha.num_heads, mha.head_dim ** -0.5
         dev = text.device
-        if autograd:
-            def core(q, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale, _max_kv={}):      # noqa: E306
+        pad = (ops.attention_width(dim) - dim) if (text.is_cuda or autograd) else 0
+        widen = (lambda t: torch.nn.functional.pad(t, (0, pad))) if pad else (lambda t: t)
+        text_flat = text.reshape(bsz * seq_len, dim)
+        if nodes_sorted.shape[0] == 0:                     # no graph node anywhere: one zero row no code points at stands in for the key set
+            nodes_sorted = text.new_zeros(1, dim)
+        kv_nodes, kv_text = widen(nodes_sorted), widen(text_flat)
+        if not autograd and text.is_cuda:                  # the inference kernel is fp32 whatever autocast hands over
+            kv_nodes, kv_text = kv_nodes.float(), kv_text.float()
+
+        def attend(qf, q_start, q_len, kv, kv_start, kv_len, max_q_len, max_kv_len):
+            if autograd:
                 p = float(mha.dropout) if self.training else 0.0
                 seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0.0 else 0      # host RNG: no device sync
-                max_kv = max_nodes if kv is nodes_sorted else seq_len
-                return _RaggedAttentionFunction.apply(q, kv, q_start, q_len, kv_start, kv_len, max_q_len, max_kv, scale, p, seed)
+                out = _RaggedAttentionFunction.apply(widen(qf), kv, q_start, q_len, kv_start, kv_len, max_q_len, max_kv_len, scale, p, seed)
+            else:
+                q_in = widen(qf)
+                out = core(q_in.float() if q_in.is_cuda else q_in, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale)
+            return out[:, :dim] if pad else out
         code = torch.arange(bsz, device=dev, dtype=torch.long)
-        text_flat = text.reshape(bsz * seq_len, dim)
         # text side: the CLS row of every code queries that code's nodes
         t_start, t_len = code * heads, torch.full((bsz,), heads, device=dev, dtype=torch.long)
         cur = text[:, 0].contiguous()
         for layer in self.model:
-            cur = self._folded_rows(layer, cur, lambda qf: core(qf, t_start, t_len, nodes_sorted, starts, counts, heads, scale))
+            cur = self._folded_rows(layer, cur, lambda qf: attend(qf, t_start, t_len, kv_nodes, starts, counts, heads, max_nodes))
+        if max_nodes == 0:                                 # nothing to attend from: the node mean of every code is zero
+            return cur, cur.new_zeros(bsz, dim)
         # graph side: every node queries the valid text tokens of its code
         g_start, g_len, tok_start = starts * heads, counts * heads, code * seq_len
         g_kv_len = valid_len
@@ -243,28 +261,17 @@ class CrossAttention(nn.Module):
             g_start, g_len, tok_start, g_kv_len = g_start[order], g_len[order], tok_start[order], valid_len[order]
         g = nodes_sorted
         for layer in self.model:
-            g = self._folded_rows(layer, g, lambda qf: core(qf, g_start, g_len, text_flat, tok_start, g_kv_len,
-                                                            max_nodes * heads, scale))
+            g = self._folded_rows(layer, g, lambda qf: attend(qf, g_start, g_len, kv_text, tok_start, g_kv_len, max_nodes * heads, seq_len))
         if not autograd and not torch.is_grad_enabled() and g.is_cuda and g.dtype == torch.float32 and dim % 4 == 0:
             return cur, ops.segment_mean(g, starts, counts)        # rows of a code are adjacent: one ordered chain per column
         padded = g.new_zeros(bsz, max_nodes, dim)
         padded[batch_sorted, slot] = g                     # deterministic mean (no atomics): pad, sum, divide
         return cur, padded.sum(1) / counts.clamp(min=1).unsqueeze(-1).to(g.dtype)
 
-    def pooled(self, text, text_mask, nodes, batch, fold=None, core=None):
-        """Batched equivalent of the reference's per-code loop (:133-142).
-
-        text [B, L, D] with a left-aligned mask [B, L]; nodes [sum n_i, D] with a
-        PyG-style `batch` vector.  Returns (CLS row of the attended text [B, D],
-        mean of the attended graph nodes [B, D]).  Queries never interact, so the
-        text side only evaluates its CLS query.  `fold` forces (True) or forbids (False)
-        the folded-projection form for the graph side; None picks the cheaper one from
-        the padded shapes.  One host sync per call (the largest node count sizes the padded / packed launch; the same
-        read validates `batch`).  A code with no nodes, or no valid token, attends to nothing: its context is zero
-        (the reference's per-code loop would take a softmax over an empty row there).  In eval mode without autograd, fp32, D % 128 == 0
-        and folding on, everything runs packed on the ragged gfx950 attention kernel
-        (`core`, default ops.shared_kv_attention; tests inject the oracle's restatement).
-        """
+    @staticmethod
+    def _pack(text, text_mask, nodes, batch):
+        """Shared prologue of pooled / pooled_reference: dtype alignment, the codes' node counts and offsets, nodes in code order.
+        One host read (the largest node count sizes the launches; the same read validates `batch` and tells whether it is sorted)."""
         bsz = text.shape[0]
         if nodes.dtype != text.dtype:                      # autocast hands over bf16 text features and fp32 node features
             common = torch.promote_types(nodes.dtype, text.dtype)
@@ -295,29 +302,48 @@ class CrossAttention(nn.Module):
             slot = position - starts[batch]
         nodes_in_order = nodes if order is None else nodes[order]
         batch_in_order = batch if order is None else batch[order]
+        return text, valid, nodes_in_order, batch_in_order, slot, counts, starts, max_nodes
 
-        seq_len, dim = text.shape[1], text.shape[2]
-        heads = self.model[0].multihead_attn.num_heads
+    def pooled(self, text, text_mask, nodes, batch):
+        """Batched equivalent of the reference's per-code loop (:133-142) -- the PRODUCT path: gfx950 kernels only.
+
+        text [B, L, D] with a left-aligned mask [B, L]; nodes [sum n_i, D] with a PyG-style `batch` vector, all on an MI355X.
+        Returns (CLS row of the attended text [B, D], mean of the attended graph nodes [B, D]).  Queries never interact, so the
+        text side only evaluates its CLS query.  Everything runs packed (nothing padded to [B, max, D]) on the ragged attention
+        kernels with the key/value projections folded into the queries: ops.shared_kv_attention at inference (fp32 whatever
+        autocast says), _RaggedAttentionFunction (HIP forward with dropout + HIP backward) in training / under autograd.  Widths
+        the kernels do not take natively (not 64 / a multiple of 128) get zero columns appended; D > 768 raises
+        MedTokLibraryError -- there is no eager-PyTorch fallback (pooled_reference below is the test-side comparator).
+        One host sync per call.  A code with no nodes, or no valid token, attends to nothing: its context is zero (the
+        reference's per-code loop would take a softmax over an empty row there)."""
+        if not (text.is_cuda and nodes.is_cuda):
+            raise ops.MedTokLibraryError(f"CrossAttention.pooled: expected tensors on an MI355X (cuda/HIP) device, got {text.device} / "
+                                         f"{nodes.device}; medtok_amd has no CPU path")
+        ops.attention_width(text.shape[-1])                # raises for widths the kernels cannot take
+        text, valid, nodes_in_order, batch_in_order, slot, counts, starts, max_nodes = self._pack(text, text_mask, nodes, batch)
         needs_grad = torch.is_grad_enabled() and (text.requires_grad or nodes.requires_grad
                                                   or any(p.requires_grad for p in self.parameters()))
-        shape_ok = (dim == 64 or (dim % 128 == 0 and dim <= 768)) and max_nodes > 0
-        train_path = self.training or needs_grad
-        # inference: fp32 inputs, no autocast (the 1e-5 parity path).  Training / autograd: the kernels are fp32 whatever the
-        # inputs' dtype or autocast says, and replace the padded torch form entirely (no B x rows x keys tensors, HIP backward).
-        kernel_ok = shape_ok and ((core is not None and not train_path) or text.is_cuda) and \
-            (train_path or (text.dtype == torch.float32 and not torch.is_autocast_enabled()))
-        if fold is None:
-            # flops: 4 n D^2 + 4 n H T D folded  vs  4 T D^2 + 4 n T D projected; where the ragged kernel can run the folded,
-            # packed form wins regardless (D = 64, B = 1024: 1.1 vs 2.4 ms -- no padding, a fraction of the launches)
-            fold = kernel_ok or max_nodes * (dim + (heads - 1) * seq_len) < seq_len * dim
-        packed = fold and kernel_ok
-        if packed:
+        return self._pooled_packed(text.contiguous(), valid.sum(1), nodes_in_order.contiguous(), batch_in_order, slot, counts, starts,
+                                   max_nodes, ops.shared_kv_attention, autograd=self.training or needs_grad)
+
+    def pooled_reference(self, text, text_mask, nodes, batch, fold=None, core=None):
+        """TEST-SIDE COMPARATOR, never called by the product path: the same function as pooled() in plain torch ops on any device
+        -- padded [B, max_nodes, D] batches with nn.MultiheadAttention (`fold=False`: projected keys) or the folded-projection
+        algebra (`fold=True`), or the packed form around an injected attention core (`core`: the oracle's restatement of the
+        ragged kernel; pins the packing logic on CPU).  `fold=None` picks the cheaper padded form from the shapes."""
+        text, valid, nodes_in_order, batch_in_order, slot, counts, starts, max_nodes = self._pack(text, text_mask, nodes, batch)
+        bsz, seq_len, dim = text.shape
+        heads = self.model[0].multihead_attn.num_heads
+        if core is not None:
             return self._pooled_packed(text.contiguous(), valid.sum(1), nodes_in_order.contiguous(), batch_in_order, slot, counts, starts,
-                                       max_nodes, core or ops.shared_kv_attention, autograd=train_path and core is None)
+                                       max_nodes, core, autograd=False)
+        if fold is None:
+            # flops: 4 n D^2 + 4 n H T D folded  vs  4 T D^2 + 4 n T D projected
+            fold = max_nodes * (dim + (heads - 1) * seq_len) < seq_len * dim
 
         padded = text.new_zeros(bsz, max_nodes, text.shape[-1])
         padded[batch_in_order, slot] = nodes_in_order
-        node_valid = torch.arange(max_nodes, device=batch.device)[None, :] < counts[:, None]
+        node_valid = torch.arange(max_nodes, device=batch_in_order.device)[None, :] < counts[:, None]
 
         # text side: one CLS query per code against that code's nodes -- always cheaper folded
         q_text = text[:, :1]
@@ -435,8 +461,9 @@ class VectorQuantizer(nn.Module):
             layer._medtok_fold_cache = None
 
     def train(self, mode: bool = True):
-        self._norm_cache = None              # a mode switch is where weights typically change hands
-        return super().train(mode)
+        if mode != self.training:
+            self._norm_cache = None          # a mode switch is where weights typically change hands (an eval()/train(False) that
+        return super().train(mode)           # changes nothing keeps the eval-mode cache: quantize_pooled / tokenize call it per batch)
 
     def _load_from_state_dict(self, *args, **kwargs):
         self._norm_cache = None

@@ -80,3 +80,10 @@ def test_bench_gpus_2_starts_its_own_ranks(dev):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["rows_per_gpu"] == 20000
+    # the unchanged driver command also times the two partitionings that exchange data (cfg 5): collective timings are in the line
+    ss = d["extra"]["strong_scaling"]
+    e, c = ss["cfg5_ema_step"], ss["codeshard_search"]
+    assert e["collective"] == "all_reduce" and e["collectives_per_step"] == 1 and e["collective_bytes_per_step"] == 16384 * 769 * 4
+    assert c["collective"] == "all_gather" and c["collectives_per_step"] == 1 and c["collective_bytes_per_step"] == 2 * 600000 * 5 * 8
+    for r in (e, c):
+        assert r["value"] > 0 and r["collective_ms_per_step"] > 0 and r["busbw_gbs"] > 0

@@ -1,0 +1,117 @@
+"""GPU, two ranks sharing this box's one MI355X over gloo: the N > 1 PRODUCT paths (HIP kernels + torch.distributed) against the
+single-rank run of the same seeded problem.  RCCL itself needs one GPU per rank, so the collective layer here is gloo
+(MEDTOK_DIST_BACKEND); everything around it -- shard arithmetic, the fused statistics buffer, the packed k-list exchange, DDP's
+gradient averaging, the gathered inference tables -- is what runs on an 8-GPU node.
+
+  BASELINE config 5: the EMA train step row-sharded (norm_ema_quantizer.py:194-210) and the code-sharded search of north_star;
+  train_MedTok.py:185: DDP(find_unused_parameters=True);  inference.py:66-138: the sharded inference driver."""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def run_ranks(mode, out_dir, *sizes, world=2, timeout=900):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MEDTOK_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "dist_worker.py"), mode, str(out_dir),
+                          *[str(v) for v in sizes]], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-4000:]
+
+
+def test_two_rank_hip_ema_step_equals_one_rank(dev, tmp_path):
+    """cfg 5, EMA variant: 120 000 rows x 768 row-sharded over two ranks, K = 16 384, two consecutive train steps of the HIP
+    NormEMAVectorQuantizer with ONE all-reduce of [embed_sum | bins] per step.  Against the same module run on all rows by one
+    rank: gathered ids bit-equal (both steps: the second runs on the updated codebook), cluster_size exactly equal (integer
+    counts), codebook <= 1e-6 (fp32 partial sums are associated differently across the shard boundary)."""
+    import dist_worker as W
+    n, k, d = 120000, 16384, 768
+    run_ranks("ema", tmp_path, n, k, d)
+    z, e0 = W.ema_problem(n, k, d, dev)
+    q, ids, losses = W.ema_step(z, e0)
+    r0, r1 = np.load(tmp_path / "ema_r0.npz"), np.load(tmp_path / "ema_r1.npz")
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, n // 2, n // 2, n)
+    for r in (r0, r1):
+        assert np.array_equal(r["ids0"], ids[0].cpu().numpy()), "step-1 ids differ from the single-rank run"
+        assert np.array_equal(r["ids1"], ids[1].cpu().numpy()), "step-2 ids (searched on the all-reduced codebook) differ"
+        assert np.array_equal(r["cluster_size"], q.cluster_size.cpu().numpy())
+        w1 = q.embedding.weight.data.cpu().numpy()
+        assert np.abs(r["weight"] - w1).max() <= 1e-6, np.abs(r["weight"] - w1).max()
+    assert np.array_equal(r0["weight"], r1["weight"]) and np.array_equal(r0["cluster_size"], r1["cluster_size"])     # ranks agree exactly
+    # the commitment loss is a mean over the rank's own rows (as in the reference): the shard means average to the global mean
+    g = np.array([float(x) for x in losses])
+    assert np.abs((r0["loss"] + r1["loss"]) / 2 - g).max() <= 1e-6 * np.abs(g).max()
+    used = int((q.cluster_size > 0).sum())
+    assert 0 < used <= k
+
+
+def test_two_rank_hip_code_sharded_search_is_bit_exact(dev, tmp_path):
+    """north_star's partitioning: every rank holds half the codebook and all rows; HIP search over the slice, one packed
+    all-gather of the k-lists, HIP merge kernel.  Equal to one search over the whole codebook bit for bit, including a duplicated
+    code on either side of the shard boundary (tie -> lowest global id)."""
+    import dist_worker as W
+    from medtok_amd import ops
+    n, k, d = 100000, 16384, 768
+    run_ranks("codeshard", tmp_path, n, k, d)
+    xh, xs, wh, ws = W.codeshard_problem(n, k, d, dev)
+    idx, dist_ = ops.topk_search(xh, xs, wh, ws, 5)
+    for r in range(2):
+        got = np.load(tmp_path / f"codeshard_r{r}.npz")
+        assert np.array_equal(got["idx"], idx.cpu().numpy()) and np.array_equal(got["dist"], dist_.cpu().numpy()), r
+    dup = (idx == 5).any(1) | (idx == k // 2 + 3).any(1)
+    assert int(dup.sum()) > 0          # rows that see the duplicated pair exist, so the cross-rank tie rule was exercised
+
+
+def test_ddp_train_step_equals_the_mean_of_single_rank_steps(dev, tmp_path):
+    """train_MedTok.py:185: the model wrapped in DDP(find_unused_parameters=True), two ranks, each on its own batch.  DDP averages
+    the ranks' gradients, so they must equal the mean of two single-process steps on those batches -- codebook, projections,
+    cross-attention and the text mapping, all of which receive their gradients from the HIP backward kernels."""
+    import dist_worker as W
+    bsz = 24
+    run_ranks("ddp", tmp_path, bsz)
+    grads, losses = [], []
+    for rank in range(2):
+        m = W.ddp_model(dev)
+        losses.append(float(W.ddp_step(m, W.ddp_batch(bsz, dev, seed=100 + rank))))
+        q = m.quantize
+        grads.append([t.grad.clone() for t in (q.codebook.weight, q.proj_text.weight, q.cross_attn.model[0].multihead_attn.in_proj_weight,
+                                               m.text_mapped.weight)])
+    mean = [(a + b) / 2 for a, b in zip(*grads)]
+    r0, r1 = np.load(tmp_path / "ddp_r0.npz"), np.load(tmp_path / "ddp_r1.npz")
+    assert abs(float(r0["loss"]) - losses[0]) <= 1e-5 * abs(losses[0]) and abs(float(r1["loss"]) - losses[1]) <= 1e-5 * abs(losses[1])
+    for name, want in zip(("g_codebook", "g_proj", "g_inproj", "g_text_mapped"), mean):
+        assert np.array_equal(r0[name], r1[name]), name                      # every rank ends with the same averaged gradient
+        w = want.cpu().numpy()
+        assert np.abs(r0[name] - w).max() <= 1e-5 * np.abs(w).max(), (name, np.abs(r0[name] - w).max(), np.abs(w).max())
+    assert np.abs(r0["g_codebook"]).max() > 0 and np.abs(r0["g_inproj"]).max() > 0
+
+
+def test_sharded_inference_writes_the_single_rank_files(dev, tmp_path):
+    """inference.py:93-138 with two ranks: each runs its share of the batches, the tables are gathered, ordered by code index and
+    written by rank 0 -- identical files to a one-rank pass over all batches."""
+    import dist_worker as W
+    from medtok_amd.inference import run_inference
+    n_codes, bsz = 150, 16
+    run_ranks("inference", tmp_path, n_codes, bsz)
+    m = W.inference_model(dev)
+    emb, tok, wt = run_inference(m, W.inference_batches(n_codes, bsz, dev), out_dir=tmp_path / "single", device=dev)
+    assert emb.shape == (n_codes, 4 * 64) and tok.shape == (n_codes, 4, 5) and tok.dtype == np.int64
+    for name in ("embeddings_all.npy", "tokens_all.npy", "weights_all.npy"):
+        a, b = np.load(tmp_path / "single" / name), np.load(tmp_path / "sharded" / name)
+        assert a.shape == b.shape and a.dtype == b.dtype, name
+        if name == "tokens_all.npy":
+            assert np.array_equal(a, b)
+        else:
+            assert np.abs(a - b).max() <= 1e-6 * max(np.abs(a).max(), 1.0), name

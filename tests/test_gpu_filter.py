@@ -149,16 +149,14 @@ def test_filter_race_screen(dev):
             assert torch.equal(i1, i2) and torch.equal(d1, d2), (rep, n, k, d)
 
 
-@pytest.fixture
-def plan():
-    """ops.debug_plan_override with a guaranteed reset (the override is process-wide)."""
+def _filter_path(**plan):
+    """PATH_F16_FILTER with launch-plan branches forced for that one call (MEDTOK_PLAN_* bits of `path`; no process state)."""
     from medtok_amd import ops
-    yield ops.debug_plan_override
-    ops.debug_plan_override()
+    return ops.plan_path(ops.PATH_F16_FILTER, **plan)
 
 
 @pytest.mark.parametrize("splits", [2, 4, 8])
-def test_xcd_block_order_gives_the_same_bits(dev, splits, plan):
+def test_xcd_block_order_gives_the_same_bits(dev, splits):
     """The XCD-aware block order (default from 1024 row tiles up) forced at a small size: every (row tile, split) pair must be
     visited exactly once -- ids and distances equal the exact path, including a row count that leaves XCD chunks partly empty."""
     from medtok_amd import ops
@@ -167,8 +165,7 @@ def test_xcd_block_order_gives_the_same_bits(dev, splits, plan):
     xh, xs = ops.rownorm(torch.randn(n, D, device=dev, generator=g))
     wh, ws = ops.rownorm(torch.randn(K, D, device=dev, generator=g))
     i_ref, d_ref = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F32_MFMA)
-    plan(filter_splits=splits, filter_xcd=1)
-    i_x, d_x = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
+    i_x, d_x = ops.topk_search(xh, xs, wh, ws, 5, _filter_path(filter_splits=splits, filter_xcd=True))
     assert torch.equal(i_x, i_ref) and torch.equal(d_x, d_ref)
 
 
@@ -204,7 +201,7 @@ def test_fused_assignment_equals_separate_kernels(dev, case):
 
 
 @pytest.mark.parametrize("splits,tiles", [(2, 131), (4, 70), (1, 260)])
-def test_tail_launch_gives_the_same_bits(dev, splits, tiles, plan):
+def test_tail_launch_gives_the_same_bits(dev, splits, tiles):
     """Large searches launch the row tiles of the last, partly filled round of blocks separately with more code splits (their own
     candidate lists, a second region the re-score kernel reads by row range).  Forced here at a small size."""
     from medtok_amd import ops
@@ -213,18 +210,18 @@ def test_tail_launch_gives_the_same_bits(dev, splits, tiles, plan):
     xh, xs = ops.rownorm(torch.randn(n, D, device=dev, generator=g))
     wh, ws = ops.rownorm(torch.randn(K, D, device=dev, generator=g))
     i_ref, d_ref = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F32_MFMA)
-    for xcd in (0, 1):
-        plan(filter_splits=splits, filter_tail_min_blocks=256, filter_xcd=xcd)
-        i_t, d_t = ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
+    for xcd in (False, True):
+        path = _filter_path(filter_splits=splits, filter_tail=True, filter_xcd=xcd)
+        i_t, d_t = ops.topk_search(xh, xs, wh, ws, 5, path)
         assert torch.equal(i_t, i_ref) and torch.equal(d_t, d_ref), xcd
-    r = ops.soft_vq_forward(xh, wh, ws, 5, ops.PATH_F16_FILTER, want_sqerr=False)      # fused assignment over both regions
+    r = ops.soft_vq_forward(xh, wh, ws, 5, path, want_sqerr=False)      # fused assignment over both regions
     r0 = ops.soft_vq_forward(xh, wh, ws, 5, ops.PATH_F32_MFMA, want_sqerr=False)
     assert all(torch.equal(r[k], r0[k]) for k in ("idx", "dist", "w", "zq"))
 
 
 @pytest.mark.parametrize("n,K,D,topk,splits", [(256 * 5 + 3, 256 * 7, 512, 5, 1), (256 * 9 + 100, 256 * 26 - 5, 768, 5, 2),
                                                (256 * 3, 256 * 4, 512, 1, 1), (256 * 4 + 17, 256 * 6, 1024, 8, 1), (256 * 2 + 1, 256 * 3 - 200, 640, 3, 1)])
-def test_scan_hit_path_with_several_passing_values_per_quad(oracle, dev, plan, n, K, D, topk, splits):
+def test_scan_hit_path_with_several_passing_values_per_quad(oracle, dev, n, K, D, topk, splits):
     """The scan's hit path is one exec-masked instruction sequence that appends a quad's MAXIMUM; a second passing value in the
     same quad (4 consecutive codes of a lane) raises a flag and the tile is revisited (filter_scan_rest).  Random codebooks almost
     never take that branch, so here every code comes in a run of near-copies: whole quads pass together, including exact ties
@@ -240,10 +237,9 @@ def test_scan_hit_path_with_several_passing_values_per_quad(oracle, dev, plan, n
     W[4::6] += 1e-2 * torch.randn(W[4::6].shape, device=dev, generator=g)      # 0, 3, 5: exact copies
     wh, ws = ops.rownorm(W)
     i_ref, d_ref = ops.topk_search(xh, xs, wh, ws, topk, ops.PATH_F32_MFMA)
-    plan(filter_splits=splits)
     ops.SEARCH_STATS = {}
     try:
-        i_s, d_s = ops.topk_search(xh, xs, wh, ws, topk, ops.PATH_F16_FILTER)
+        i_s, d_s = ops.topk_search(xh, xs, wh, ws, topk, _filter_path(filter_splits=splits))
         assert ops.SEARCH_STATS["fallback_rows"] < n // 4        # the filter path decided these rows, not the exact redo
     finally:
         ops.SEARCH_STATS = None

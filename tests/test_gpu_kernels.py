@@ -52,12 +52,8 @@ def test_search_bit_exact(oracle, dev, n, k, d, topk):
     torch.cuda.synchronize()
     assert np.array_equal(dist.cpu().numpy(), dist_o), "distances must be bit-identical to the fmaf-chain oracle"
     assert np.array_equal(idx.cpu().numpy(), idx_o)
-    if n > 100000:           # the plan override takes the split-everything plan: same bits
-        ops.debug_plan_override(search_max_splits=64)
-        try:
-            idx2, dist2 = ops.topk_search(_t(xh, dev), _t(xs, dev), _t(wh, dev), _t(ws, dev), topk)
-        finally:
-            ops.debug_plan_override()
+    if n > 100000:           # the per-call plan hook takes the split-everything plan: same bits
+        idx2, dist2 = ops.topk_search(_t(xh, dev), _t(xs, dev), _t(wh, dev), _t(ws, dev), topk, ops.plan_path(search_max_splits=64))
         assert torch.equal(idx2, idx) and torch.equal(dist2, dist)
 
 

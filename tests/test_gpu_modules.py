@@ -343,10 +343,12 @@ def test_kmeans_init_path(dev):
     assert torch.equal(q.embedding.weight.data, w_before)
 
 
-@pytest.mark.parametrize("B,L,M,D", [(48, 512, 40, 768), (64, 512, 40, 64), (32, 100, 200, 256)])
+@pytest.mark.parametrize("B,L,M,D", [(48, 512, 40, 768), (64, 512, 40, 64), (32, 100, 200, 256), (24, 60, 17, 96), (16, 80, 30, 192), (16, 128, 9, 320), (8, 40, 12, 20)])
 def test_packed_cross_attention_equals_projected_form_at_full_dims(dev, B, L, M, D):
     """BASELINE-sized ragged batch: the packed path (folded projections + ragged gfx950 attention kernel) against the padded
-    nn.MultiheadAttention form with projected keys -- two different evaluation orders of the reference's layers."""
+    nn.MultiheadAttention form with projected keys (pooled_reference, the torch comparator) -- two different evaluation orders of
+    the reference's layers.  Widths the kernels do not take natively (96, 192, 320, 20) run on them with zero columns appended:
+    there is no eager fallback behind pooled()."""
     from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
     from oracle import synth
     torch.manual_seed(0)
@@ -356,9 +358,35 @@ def test_packed_cross_attention_equals_projected_form_at_full_dims(dev, B, L, M,
     a = [t.to(dev) for t in (text, mask, nodes[perm], batch[perm])]
     with torch.no_grad():
         pt_k, pg_k = v.cross_attn.pooled(*a)                 # packed + HIP kernel (eval, no grad, fp32)
-        pt_p, pg_p = v.cross_attn.pooled(*a, fold=False)     # padded, projected keys
+        pt_p, pg_p = v.cross_attn.pooled_reference(*a, fold=False)     # padded, projected keys (torch comparator)
     for x, y in ((pt_k, pt_p), (pg_k, pg_p)):
         assert float((x - y).abs().max() / y.abs().max()) <= 1e-5
+
+
+def test_pooled_refuses_what_the_kernels_cannot_take(dev):
+    """No silent eager-PyTorch path behind pooled(): CPU tensors and widths beyond the kernels' LDS budget raise."""
+    from medtok_amd import ops
+    from medtok_amd.vector_quantization_soft_one_new import CrossAttention
+    from oracle import synth
+    ca = CrossAttention(1024, 4).to(dev).eval()
+    text, mask, nodes, batch = synth.ragged_batch("wide", 4, 16, 5, 1024, 0)
+    with torch.no_grad():
+        with pytest.raises(ops.MedTokLibraryError, match="768"):
+            ca.pooled(text.to(dev), mask.to(dev), nodes.to(dev), batch.to(dev))
+        ca64 = CrossAttention(64, 4).eval()
+        t2, m2, n2, b2 = synth.ragged_batch("cpu", 4, 16, 5, 64, 0)
+        with pytest.raises(ops.MedTokLibraryError, match="no CPU path"):
+            ca64.pooled(t2, m2, n2, b2)
+        # eval under autocast runs the fp32 kernels too (it used to drop to the padded torch form)
+        ca64 = ca64.to(dev)
+        ref = ca64.pooled(t2.to(dev), m2.to(dev), n2.to(dev), b2.to(dev))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got = ca64.pooled(t2.to(dev), m2.to(dev), n2.to(dev), b2.to(dev))
+        for x, y in zip(got, ref):
+            assert float((x.float() - y).abs().max() / y.abs().max()) <= 3e-2      # bf16 projections around an fp32 core
+        # no graph node at all: the text side attends to nothing, the node means are zero
+        pt, pg = ca64.pooled(t2.to(dev), m2.to(dev), n2[:0].to(dev), b2[:0].to(dev))
+        assert torch.isfinite(pt).all() and float(pg.abs().max()) == 0.0
 
 
 def test_pooled_outputs_at_full_dims_vs_the_reference_loop(dev):

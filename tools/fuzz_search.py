@@ -25,10 +25,9 @@ for c in range(cases):
     norm = kind != 3
     xh, xs = ops.rownorm(x); wh, ws = ops.rownorm(W, normalize=norm) if not norm else ops.rownorm(W)
     if not norm: wh = W.contiguous()
-    for env in ({}, dict(filter_splits=int(rng.choice([1, 2, 4, 8])), filter_xcd=1)):
-        ops.debug_plan_override(**env)
+    for env in ({}, dict(filter_splits=int(rng.choice([1, 2, 4, 8])), filter_xcd=True)):
         i0, d0 = ops.topk_search(xh, xs, wh, ws, k, ops.PATH_F32_MFMA)
-        i1, d1 = ops.topk_search(xh, xs, wh, ws, k, ops.PATH_F16_FILTER)
+        i1, d1 = ops.topk_search(xh, xs, wh, ws, k, ops.plan_path(ops.PATH_F16_FILTER, **env))
         ok = torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32))
         if not ok:
             bad += 1

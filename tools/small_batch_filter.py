@@ -1,4 +1,4 @@
-"""Dev tool: fp16-filter path at small / medium batch vs the number of code splits (ops.debug_plan_override), against the exact path."""
+"""Dev tool: fp16-filter path at small / medium batch vs the number of code splits (ops.plan_path: per-call plan hook), against the exact path."""
 import os, sys, time
 sys.path.insert(0, ".")
 import torch
@@ -14,9 +14,7 @@ for n, K in ((1024, 49152), (2048, 49152), (4096, 49152), (1024, 8192), (2048, 8
     g = torch.Generator(device=dev).manual_seed(0)
     x = torch.randn(n, D, device=dev, generator=g); W = torch.randn(K, D, device=dev, generator=g)
     xh, xs = ops.rownorm(x); wh, ws = ops.rownorm(W)
-    ops.debug_plan_override()
     line = f"n={n} K={K}: exact {t(lambda: ops.topk_search(xh, xs, wh, ws, 5, 1)):.0f} us | filter auto {t(lambda: ops.topk_search(xh, xs, wh, ws, 5, 2)):.0f}"
     for sp in (16, 32, 64, 128):
-        ops.debug_plan_override(filter_splits=sp)
-        line += f" | S={sp}: {t(lambda: ops.topk_search(xh, xs, wh, ws, 5, 2)):.0f}"
+        line += f" | S={sp}: {t(lambda: ops.topk_search(xh, xs, wh, ws, 5, ops.plan_path(2, filter_splits=sp))):.0f}"
     print(line, flush=True)
