@@ -310,9 +310,93 @@ def fixture_kmeans(nq, name, N, D, K, seed):
     npz(name, N=N, D=D, K=K, seed=seed, init_idx=init_idx, buckets=torch.stack(buckets).to(torch.int16), means=means, bins=bins)
 
 
+def _near_rows(g64, tau):
+    """rows whose smallest gap between consecutive fp64 top-(k+1) distances is <= tau: (row ids int32, their fp64 lists)"""
+    gapmin = (g64[:, 1:] - g64[:, :-1]).min(1).values
+    rows = torch.nonzero(gapmin <= tau).reshape(-1)
+    return gapmin.float(), rows.to(torch.int32), g64[rows]
+
+
+def fixture_cfg3_slice(sq, name, N, D, n_e, seed, chunk=2048, tau_store=1e-4):
+    """F14 -- BASELINE config 3 at its REAL codebook size, pinned to the reference itself: the reference's VectorQuantizer
+    (n_e = 49152, D = 768, k = 5) on a seeded N-row slice, all four searches of a forward with the cross-attention bypassed as
+    bench.py's cfg3 does (text / graph through proj_* over their codebook thirds :187-205, the two shared searches over all
+    n_e :147-165).  Nothing of size N x n_e is stored: per search the ids (uint16), the smallest fp64 gap among the row's
+    top-6 distances, the fp64 top-6 lists of the rows whose gap is <= 1e-4 (the near-tie census material), the
+    softmax weights of the first 1024 rows; plus the first rows of the embedding as the reference's own methods return it."""
+    q = make_soft(sq, n_e, D, seed=seed, tag=name)
+    q.eval()
+    h = synth.det_randn(name + ".h", (N, 2 * D), 1.0, seed)
+    pooled = {"shared_text": synth.det_randn(name + ".pt", (N, D), 1.0, seed), "shared_graph": synth.det_randn(name + ".pg", (N, D), 1.0, seed)}
+    out = {"n_e": n_e, "e_dim": D, "k": q.k, "seed": seed, "N": N, "tau_store": tau_store}
+    with torch.no_grad():
+        inputs = {"text": q.proj_text(h[:, :D]), "graph": q.proj_graph(h[:, D:]), **pooled}
+        for key, x in inputs.items():
+            region = key if key in ("text", "graph") else "shared"
+            idx, w, g64 = [], [], []
+            for r0 in range(0, N, chunk):
+                i, ww, _, g = ref_tokens(q, x[r0: r0 + chunk], region)
+                idx.append(i); w.append(ww); g64.append(g)
+            idx, w, g64 = torch.cat(idx), torch.cat(w), torch.cat(g64)
+            gapmin, rows, lists = _near_rows(g64, tau_store)
+            assert int(idx.max()) < 65536
+            out.update({f"{key}.idx": idx.to(torch.int32).numpy().astype(np.uint16), f"{key}.gapmin": gapmin, f"{key}.near_rows": rows,
+                        f"{key}.near_d64": lists, f"{key}.w_head": w[:1024]})
+            print(f"  {name} {key}: {int((gapmin <= 1e-5).sum())} rows with a gap <= 1e-5, {rows.numel()} <= {tau_store}", flush=True)
+        # the embedding as the reference's own methods return it (first rows): specific_embedding for the two modality searches;
+        # the shared half follows get_shared_info's lines :164-165,181-182 on the reference's ops
+        head = 64
+        zt, _, _ = q.specific_embedding(h[:head, :D], types="text")
+        zg, _, _ = q.specific_embedding(h[:head, D:], types="graph")
+        wn = F.normalize(q.codebook.weight, p=2, dim=-1)
+        sh = []
+        for key in ("shared_text", "shared_graph"):
+            x = pooled[key][:head]
+            i, ww, _, _ = ref_tokens(q, x, "shared")
+            zq = torch.sum(ww.unsqueeze(-1) * wn[i], dim=1)
+            sh.append(x + (zq - x).detach())
+        out["emb_head"] = torch.cat([zt, zg, sh[0], sh[1]], dim=-1)
+    npz(name, **out)
+
+
+def fixture_cfg2_slice(nq, name, N, D, K, seed, beta=0.25, decay=0.99, tau_store=1e-4):
+    """F15 -- BASELINE config 2's module at its real codebook size, pinned to the reference itself: ONE train-mode forward of the
+    reference's NormEMAVectorQuantizer (K = 8192, D = 768) on a seeded N-row slice: ids (uint16), the smallest fp64 top-2 gap per
+    row and the near-tie lists, the exact cluster sizes, the loss, 256 rows of the EMA-updated codebook (every 32nd code)."""
+    torch.manual_seed(seed)
+    q = nq.NormEMAVectorQuantizer(K, D, beta, decay)
+    E0 = F.normalize(synth.det_randn(name + ".E", (K, D), 1.0, seed), dim=-1)
+    q.embedding.weight.data.copy_(E0)
+    q.train()
+    z = synth.det_randn(name + ".z", (N, D), 1.0, seed)
+    zn = F.normalize(z, dim=-1)
+    g64 = torch.cat([gaps64(zn[r0: r0 + 2048], E0, 1) for r0 in range(0, N, 2048)])
+    gapmin, rows, lists = _near_rows(g64, tau_store)
+    with torch.no_grad():
+        zq, loss, idx = q(z[:, :, None, None])
+    print(f"  {name}: {int((gapmin <= 1e-5).sum())} rows with a top-2 gap <= 1e-5, {rows.numel()} <= {tau_store}", flush=True)
+    npz(name, K=K, D=D, N=N, seed=seed, beta=beta, decay=decay, idx=idx.to(torch.int32).numpy().astype(np.uint16), gapmin=gapmin,
+        near_rows=rows, near_d64=lists, cluster_size=q.cluster_size.clone(), loss=loss, weight_slice=q.embedding.weight.data[::32].clone(),
+        zq_head=zq[:16, :, 0, 0].clone(), tau_store=tau_store)
+
+
+def fixture_state_dict_keys(sq, name):
+    """State-dict keys and shapes of the reference's soft VectorQuantizer (the checkpoint contract), read off
+    the reference's own module instead of a hand-typed list."""
+    q = sq.VectorQuantizer(96, 16, 0.25, 0.0, True, True, [16, 16])
+    sd = q.state_dict()
+    npz(name, keys=np.array(list(sd.keys())), shapes=np.array([",".join(str(int(v)) for v in t.shape) for t in sd.values()]),
+        n_e=96, e_dim=16)
+
+
 def main():
     torch.set_num_threads(8)
     sq, nq, ls = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "--round3-only":        # added in round 3: the rest are unchanged
+        fixture_state_dict_keys(sq, "f16_soft_state_dict")
+        fixture_cfg2_slice(nq, "f15_cfg2_slice", N=16384, D=768, K=8192, seed=15)
+        fixture_cfg3_slice(sq, "f14_cfg3_slice", N=16384, D=768, n_e=49152, seed=14)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--round2-only":        # added in round 2: the rest are unchanged
         fixture_kmeans(nq, "f12_kmeans_d64", N=4096, D=64, K=32, seed=21)
         fixture_kmeans(nq, "f12_kmeans_d768", N=2048, D=768, K=256, seed=22)
@@ -337,6 +421,9 @@ def main():
     fixture_kmeans(nq, "f12_kmeans_d64", N=4096, D=64, K=32, seed=21)
     fixture_kmeans(nq, "f12_kmeans_d768", N=2048, D=768, K=256, seed=22)
     fixture_eval_window(sq, "f13_eval_window", B=8, L=12, max_nodes=9, D=64, n_e=96, seed=23)
+    fixture_state_dict_keys(sq, "f16_soft_state_dict")
+    fixture_cfg2_slice(nq, "f15_cfg2_slice", N=16384, D=768, K=8192, seed=15)
+    fixture_cfg3_slice(sq, "f14_cfg3_slice", N=16384, D=768, n_e=49152, seed=14)
     # BASELINE config 1: 1k codes, 768-d, K=8192 -- inputs regenerated from the seeded recipe
     fixture_forward(sq, "cfg1_inference_1k", B=1000, L=8, max_nodes=6, D=768, n_e=8192, seed=11,
                     train_too=False, store_inputs=False)

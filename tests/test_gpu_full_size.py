@@ -125,3 +125,106 @@ def test_config4_train_step_bf16_at_L512(dev):
     assert (t32[..., 0] == t16[..., 0]).float().mean().item() >= 0.98
     assert (t32 == t16).float().mean().item() >= 0.95
     assert abs(l16 - l32) <= 2e-2 * abs(l32), (l16, l32)
+
+
+TAU = 1e-5
+
+
+def _census(idx_got, dist_got, idx_ref, gapmin, near_rows, near_d64, what):
+    """SURVEY H1 protocol over ALL rows: ids identical to the reference's wherever the fp64 gap between neighbouring top-(k+1)
+    distances exceeds tau; inside tau the chosen distances must still be the reference's near-ties.  Returns the census."""
+    n, k = idx_got.shape
+    same = (idx_got == idx_ref).all(1)
+    inside = gapmin <= TAU
+    bad = np.nonzero(~same & ~inside)[0]
+    assert bad.size == 0, f"{what}: ids differ from the reference OUTSIDE tau on {bad.size} rows, e.g. {bad[:8].tolist()}"
+    where = np.full(n, -1, np.int64); where[near_rows] = np.arange(near_rows.size)
+    rows = np.nonzero(inside)[0]
+    if rows.size:
+        d64 = near_d64[where[rows]][:, :k]
+        assert np.abs(dist_got[rows].astype(np.float64) - d64).max() <= TAU, f"{what}: a row inside tau picked a code that is not a near-tie"
+    return dict(rows=n, inside_tau=int(inside.sum()), ids_differ_inside_tau=int((~same & inside).sum()), mismatches_outside_tau=0)
+
+
+def test_cfg3_ids_pinned_to_the_reference_at_full_codebook_size(dev, golden, capsys):
+    """F14: 16 384 rows x the four searches of BASELINE config 3 (n_e = 49 152, D = 768, k = 5), ids generated by the REFERENCE's own
+    VectorQuantizer on CPU (oracle/gen_golden.py: fixture_cfg3_slice).  The product path (quantize_pooled: proj Linear -> rownorm
+    -> fp16 shortlist + exact re-score -> soft assignment) must give the same ids on every row whose fp64 top-6 gaps exceed
+    tau = 1e-5 and reference near-ties inside it; the census is printed and bounded (<= 1 % of the rows inside tau: 5 gaps per row at K up to 49 152)."""
+    import torch
+    from medtok_amd.inference import quantize_pooled
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    from oracle import synth
+    name = "f14_cfg3_slice"
+    g = golden(name)
+    n_e, D, k, seed, N = int(g["n_e"]), int(g["e_dim"]), int(g["k"]), int(g["seed"]), int(g["N"])
+    v = VectorQuantizer(n_e, D, 0.25, 0.0, True, True, [D, D], k=k)
+    v.load_state_dict(synth.det_state_dict(v, name, seed), strict=True)
+    v = v.to(dev).eval()
+    h = synth.det_randn(name + ".h", (N, 2 * D), 1.0, seed).to(dev)
+    pt = synth.det_randn(name + ".pt", (N, D), 1.0, seed).to(dev)
+    pg = synth.det_randn(name + ".pg", (N, D), 1.0, seed).to(dev)
+    emb, tok, wts = quantize_pooled(v, h, pt, pg)
+    # the searches' distances (not part of the module's return): same call sequence on the ops level
+    dists = []
+    what, wsq = v._normalised_codebook()
+    region = n_e // 3
+    with torch.no_grad():
+        for x, (lo, hi) in ((v.proj_text(h[:, :D]), (0, region)), (v.proj_graph(h[:, D:]), (n_e - region, n_e)), (pt, (0, n_e)), (pg, (0, n_e))):
+            from medtok_amd import ops
+            r = ops.soft_vq_forward(x.float().contiguous(), what[lo:hi], wsq[lo:hi].contiguous(), k)
+            dists.append(r["dist"].cpu().numpy())
+    tok = tok.cpu().numpy()
+    total = dict(rows=0, inside_tau=0, ids_differ_inside_tau=0)
+    for s_, key in enumerate(("text", "graph", "shared_text", "shared_graph")):
+        c = _census(tok[:, s_], dists[s_], g[f"{key}.idx"].astype(np.int64), g[f"{key}.gapmin"], g[f"{key}.near_rows"].astype(np.int64),
+                    g[f"{key}.near_d64"], key)
+        for f in total:
+            total[f] += c[f]
+        w_ref = g[f"{key}.w_head"]
+        ok = (tok[: w_ref.shape[0], s_] == g[f"{key}.idx"][: w_ref.shape[0]].astype(np.int64)).all(1)
+        assert np.abs(wts[: w_ref.shape[0], s_].cpu().numpy()[ok] - w_ref[ok]).max() <= 1e-5 * max(w_ref.max(), 1e-30) * 10   # weights: e^-d, d to ~1e-6
+    with capsys.disabled():
+        print(f"\n[F14 census] {N} rows x 4 searches vs the reference: 0 mismatches outside tau = {TAU:g}; {total['inside_tau']} of "
+              f"{total['rows']} rows inside tau, of which {total['ids_differ_inside_tau']} resolve the near-tie differently")
+    assert total["inside_tau"] <= 0.01 * total["rows"]          # (the reference run itself counted 508 of 65 536: oracle/gen_golden.py)
+    head = g["emb_head"]
+    got = emb[: head.shape[0]].cpu().numpy()
+    same_rows = (tok[: head.shape[0]] == np.stack([g[f"{key}.idx"][: head.shape[0]].astype(np.int64) for key in ("text", "graph", "shared_text", "shared_graph")], 1)).all((1, 2))
+    assert same_rows.sum() >= head.shape[0] - 2
+    assert np.abs(got[same_rows] - head[same_rows]).max() <= 1e-5 * np.abs(head).max()
+
+
+def test_cfg2_train_step_pinned_to_the_reference_at_full_codebook_size(dev, golden, capsys):
+    """F15: one train-mode forward of the reference's NormEMAVectorQuantizer (K = 8192, D = 768) on 16 384 rows.  ids under the tau
+    protocol; then -- the ids being the reference's -- the cluster sizes exactly and the EMA-updated codebook rows to 1e-5."""
+    import torch
+    from medtok_amd.norm_ema_quantizer import NormEMAVectorQuantizer
+    from oracle import synth
+    name = "f15_cfg2_slice"
+    g = golden(name)
+    K, D, N, seed = int(g["K"]), int(g["D"]), int(g["N"]), int(g["seed"])
+    q = NormEMAVectorQuantizer(K, D, float(g["beta"]), float(g["decay"])).to(dev).train()
+    E0 = torch.nn.functional.normalize(synth.det_randn(name + ".E", (K, D), 1.0, seed), dim=-1)
+    q.embedding.weight.data.copy_(E0.to(dev))
+    z = synth.det_randn(name + ".z", (N, D), 1.0, seed).to(dev)
+    from medtok_amd import ops
+    zh, zs = ops.rownorm(z)
+    _, es = ops.rownorm(q.embedding.weight.data, normalize=False, want_xhat=False)
+    _, dist = ops.topk_search(zh, zs, q.embedding.weight.data.clone(), es, 1)
+    with torch.no_grad():
+        zq, loss, idx = q(z[:, :, None, None])
+    c = _census(idx.cpu().numpy()[:, None], dist.cpu().numpy(), g["idx"].astype(np.int64)[:, None], g["gapmin"], g["near_rows"].astype(np.int64),
+                g["near_d64"], "cfg2")
+    with capsys.disabled():
+        print(f"\n[F15 census] {N} rows, K = {K}: 0 mismatches outside tau = {TAU:g}; {c['inside_tau']} rows inside tau, "
+              f"{c['ids_differ_inside_tau']} resolved differently")
+    assert c["inside_tau"] <= 0.005 * N
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    assert np.abs(zq[:16, :, 0, 0].cpu().numpy() - g["zq_head"]).max() <= 1e-5 * np.abs(g["zq_head"]).max()
+    if c["ids_differ_inside_tau"] == 0:
+        assert np.array_equal(q.cluster_size.cpu().numpy(), g["cluster_size"]), "same ids: the counts are integers and must be equal"
+        w = q.embedding.weight.data[::32].cpu().numpy()
+        assert np.abs(w - g["weight_slice"]).max() <= 1e-5 * np.abs(g["weight_slice"]).max()
+    else:       # a near-tie resolved the other way moves one count by one and two codebook rows slightly
+        assert np.abs(q.cluster_size.cpu().numpy() - g["cluster_size"]).max() <= 0.01 * c["ids_differ_inside_tau"] + 1e-6

@@ -230,3 +230,60 @@ def test_oracle_layer_tail_and_node_mean_match_torch(oracle):
     for b in range(4):
         ref = x[start[b]:start[b] + length[b]].astype(np.float64).mean(0) if length[b] else np.zeros(64)
         assert np.abs(got[b] - ref).max() <= 1e-6
+
+
+TAU = 1e-5      # ids must be identical wherever the fp64 gap between neighbouring top-(k+1) distances exceeds this
+
+
+def census_check(idx_got, dist_got, idx_ref, gapmin, near_rows, near_d64, rows, what):
+    """The tau protocol on the rows `rows` (array of row numbers): ids identical outside tau; inside tau the distances must
+    still be the reference's (each of the k sorted distances within tau of the fp64 list).  Returns (rows inside tau, of which
+    ids differ)."""
+    inside = gapmin[rows] <= TAU
+    bad = [int(r) for r, got, ref, ins in zip(rows, idx_got, idx_ref[rows], inside) if not ins and not np.array_equal(got, ref)]
+    assert not bad, f"{what}: ids differ from the reference OUTSIDE tau on rows {bad[:10]}"
+    where = {int(r): i for i, r in enumerate(near_rows)}
+    differ = 0
+    for j, r in enumerate(rows):
+        if inside[j]:
+            d64 = near_d64[where[int(r)]][: idx_got.shape[1]]
+            assert np.abs(dist_got[j].astype(np.float64) - d64).max() <= TAU, f"{what}: row {int(r)} inside tau picked a code that is not a near-tie"
+            differ += int(not np.array_equal(idx_got[j], idx_ref[int(r)]))
+    return int(inside.sum()), differ
+
+
+def test_cfg3_slice_oracle_vs_reference(oracle, golden):
+    """F14: the reference's VectorQuantizer at n_e = 49152, D = 768, k = 5 (BASELINE config 3's codebook).  The C oracle on the
+    first rows of each of the four searches; the GPU test runs all 16 384."""
+    g = golden("f14_cfg3_slice")
+    n_e, D, k, seed, N = int(g["n_e"]), int(g["e_dim"]), int(g["k"]), int(g["seed"]), int(g["N"])
+    name = "f14_cfg3_slice"
+    W = synth.det_randn(f"{name}.codebook.weight", (n_e, D), 1.0, seed).numpy()
+    region = n_e // 3
+    h = synth.det_randn(name + ".h", (N, 2 * D), 1.0, seed)[:48]
+    import torch
+    lin = {t: (synth.det_randn(f"{name}.proj_{t}.weight", (D, D), 1.0 / D ** 0.5, seed), synth.det_randn(f"{name}.proj_{t}.bias", (D,), 0.02, seed))
+           for t in ("text", "graph")}
+    xs = {"text": torch.nn.functional.linear(h[:, :D], *lin["text"]).numpy(), "graph": torch.nn.functional.linear(h[:, D:], *lin["graph"]).numpy(),
+          "shared_text": synth.det_randn(name + ".pt", (N, D), 1.0, seed)[:24].numpy(),
+          "shared_graph": synth.det_randn(name + ".pg", (N, D), 1.0, seed)[:24].numpy()}
+    for key, x in xs.items():
+        Wr = W[:region] if key == "text" else (W[-region:] if key == "graph" else W)
+        r = oracle.specific_search(np.ascontiguousarray(x), Wr, k)
+        rows = np.arange(x.shape[0])
+        census_check(r["idx"], r["dist"], g[f"{key}.idx"].astype(np.int64), g[f"{key}.gapmin"], g[f"{key}.near_rows"], g[f"{key}.near_d64"], rows, key)
+        assert rel(r["w"], g[f"{key}.w_head"][: x.shape[0]]) <= 1e-4       # softmax weights move by the distances' round-off (a few 1e-7 of d ~ 2)
+
+
+def test_cfg2_slice_oracle_vs_reference(oracle, golden):
+    """F15: one train step of the reference's NormEMAVectorQuantizer at K = 8192, D = 768 on 16 384 rows.  The oracle's ids on
+    the first rows; the whole step (ids -> exact counts -> EMA codebook) is checked on the GPU."""
+    g = golden("f15_cfg2_slice")
+    K, D, N, seed = int(g["K"]), int(g["D"]), int(g["N"]), int(g["seed"])
+    name = "f15_cfg2_slice"
+    E0 = oracle.rownorm(synth.det_randn(name + ".E", (K, D), 1.0, seed).numpy())[0]
+    z = synth.det_randn(name + ".z", (N, D), 1.0, seed)[:128].numpy()
+    zh, zs = oracle.rownorm(z)
+    _, es = oracle.rownorm(E0, False)
+    idx, dist = oracle.topk_search(zh, zs, E0, es, 1)
+    census_check(idx, dist, g["idx"].astype(np.int64)[:, None], g["gapmin"], g["near_rows"], g["near_d64"], np.arange(128), "cfg2")
