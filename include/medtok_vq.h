@@ -130,6 +130,27 @@ int medtok_soft_assign_f32(const float *xref, const float *what, const int64_t *
  * norm_ema_quantizer.py:212). */
 int medtok_sum_scale_f32(const float *vals, int64_t n, double scale, float *out, void *stream);
 
+/* ---- fp32-accurate dense products on the fp16 matrix pipe (the projections around the cross-attention core:
+ * nn.MultiheadAttention's in_proj / out_proj and the folded W_k / W_v products, vector_quantization_soft_one_new.py:17-51).
+ * Every operand is a PAIR of fp16 images (hi, lo) with x = hi + lo; a product runs as three fp16 MFMA passes
+ * (hi hi + hi lo + lo hi, fp32 accumulation): ~2^-22 relative, the order of a plain fp32 GEMM's own round-off.
+ *
+ * medtok_split_half_f32: src [n, d] fp32 (row stride src_stride floats) -> hi, lo [n, dp] fp16, dp >= d a multiple of 8, columns
+ * past d zero; `scale` (an exact power of two) is applied first -- 1 for activations, the per-matrix prescale for weights. */
+int medtok_split_half_f32(const float *src, int64_t n, int d, int64_t src_stride, int dp, float scale,
+                          void *hi, void *lo, void *stream);
+
+/* C = unscale * (A . B^T) + bias for `groups` independent problems that share the row range [0, m):
+ *   group g:  A_g = columns [g * a_group_cols, + k_g) of A [m, lda],  B_g = rows [g * b_group_rows, + n_g) of B [b_rows, ldb]
+ *             (depth k_g, k contiguous in both),  C_g = columns [g * n_g, + n_g) of C.
+ * Outputs: c (fp32 [m, ldc]) and/or the (hi, lo) images c_hi / c_lo ([m, ldch] fp16) that a following product reads directly.
+ * k_g % 32 == 0, n_g % 4 == 0, lda / ldb / a_group_cols % 8 == 0, ldc / ldch % 4 == 0; bias [groups * n_g] or NULL.
+ * groups = 1: a plain GEMM.  The per-head products of the folded attention form are groups = heads. */
+int medtok_split_gemm_f16(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols,
+                          const void *b_hi, const void *b_lo, int64_t b_rows, int ldb, int b_group_rows,
+                          int n_g, int k_g, int groups, const float *bias, float unscale,
+                          float *c, int ldc, void *c_hi, void *c_lo, int ldch, void *stream);
+
 /* ---- training half ------------------------------------------------------------------------------
  * Sparse backward of the soft top-k assignment (the reference back-propagates through a dense
  * N x K distance matrix built at vector_quantization_soft_one_new.py:120-125,157-182,203-214; only

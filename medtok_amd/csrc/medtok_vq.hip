@@ -1451,6 +1451,55 @@ extern "C" int medtok_segment_mean_f32(const float *x, const int64_t *seg_start,
     return check_launch("segment_mean");
 }
 
+// ================================================================= split-fp16 dense products (split_gemm.h)
+#include "split_gemm.h"
+
+extern "C" int medtok_split_half_f32(const float *src, int64_t n, int d, int64_t src_stride, int dp, float scale, void *hi, void *lo, void *stream)
+{
+    if (n < 0 || d <= 0 || (d & 3) || dp < d || (dp & 7) || src_stride < d || (src_stride & 3))
+        return fail("split_half: bad shape n=%ld d=%d stride=%ld dp=%d (d %% 4 == 0, dp %% 8 == 0, dp >= d)", (long)n, d, (long)src_stride, dp);
+    if (n == 0) return 0;
+    if (!src || !hi || !lo) return fail("split_half: NULL argument");
+    if (((uintptr_t)src | (uintptr_t)hi | (uintptr_t)lo) & 15) return fail("split_half: pointers must be 16-byte aligned");
+    const long total = n * (dp / 8);
+    hipLaunchKernelGGL(split_half_kernel, dim3((unsigned)lmin(8192, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (long)n, d,
+                       (long)src_stride, dp, scale, (_Float16 *)hi, (_Float16 *)lo);
+    return check_launch("split_half");
+}
+
+extern "C" int medtok_split_gemm_f16(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols,
+                                     const void *b_hi, const void *b_lo, int64_t b_rows, int ldb, int b_group_rows,
+                                     int n_g, int k_g, int groups, const float *bias, float unscale,
+                                     float *c, int ldc, void *c_hi, void *c_lo, int ldch, void *stream)
+{
+    if (m < 0 || groups < 1 || n_g <= 0 || k_g <= 0 || (n_g & 3) || (k_g % G_BK) || (lda & 7) || (ldb & 7) || (a_group_cols & 7) || lda < k_g || ldb < k_g)
+        return fail("split_gemm: bad shape m=%ld groups=%d n_g=%d k_g=%d lda=%d ldb=%d a_group_cols=%d (n_g %% 4 == 0, k_g %% 32 == 0, strides %% 8 == 0)",
+                    (long)m, groups, n_g, k_g, lda, ldb, a_group_cols);
+    if ((long)(groups - 1) * a_group_cols + k_g > lda || (long)(groups - 1) * b_group_rows + n_g > b_rows)
+        return fail("split_gemm: the last group reads past its operand (A columns %ld > lda %d or B rows %ld > %ld)",
+                    (long)(groups - 1) * a_group_cols + k_g, lda, (long)(groups - 1) * b_group_rows + n_g, (long)b_rows);
+    if (m == 0) return 0;
+    if (!a_hi || !a_lo || !b_hi || !b_lo || (!c && !c_hi)) return fail("split_gemm: NULL argument");
+    if ((c_hi == nullptr) != (c_lo == nullptr)) return fail("split_gemm: c_hi and c_lo go together");
+    if (c && ((ldc & 3) || ldc < groups * n_g)) return fail("split_gemm: ldc=%d must be a multiple of 4 and >= groups * n_g", ldc);
+    if (c_hi && ((ldch & 3) || ldch < groups * n_g)) return fail("split_gemm: ldch=%d must be a multiple of 4 and >= groups * n_g", ldch);
+    if (((uintptr_t)a_hi | (uintptr_t)a_lo | (uintptr_t)b_hi | (uintptr_t)b_lo | (uintptr_t)c | (uintptr_t)c_hi | (uintptr_t)c_lo | (uintptr_t)bias) & 15)
+        return fail("split_gemm: pointers must be 16-byte aligned");
+    if ((double)m * lda * 2 >= 2147483647.0 * 256 || (double)b_rows * ldb * 2 >= 2147483647.0) return fail("split_gemm: operand too large");
+    SplitGemmArgs p;
+    p.ah = (const _Float16 *)a_hi; p.al = (const _Float16 *)a_lo; p.bh = (const _Float16 *)b_hi; p.bl = (const _Float16 *)b_lo;
+    p.bias = bias; p.c = c; p.ch = (_Float16 *)c_hi; p.cl = (_Float16 *)c_lo;
+    p.M = (long)m; p.a_bytes = (long)m * lda * 2; p.b_bytes = (long)b_rows * ldb * 2;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldch = ldch; p.n_g = n_g; p.k_g = k_g; p.groups = groups;
+    p.a_group_cols = a_group_cols; p.b_group_rows = b_group_rows; p.unscale = unscale;
+    p.row_tiles = (int)((m + G_BN - 1) / G_BN); p.ftiles = (n_g + G_BM - 1) / G_BM;
+    const long blocks = (long)((p.row_tiles + 7) / 8) * 8 * p.ftiles * groups;
+    if (blocks >= (1ll << 31)) return fail("split_gemm: grid too large");
+    if (!set_lds_once<split_gemm_kernel>(G_LDS_BYTES)) return fail("split_gemm: cannot reserve %zu bytes of LDS", G_LDS_BYTES);
+    hipLaunchKernelGGL(split_gemm_kernel, dim3((unsigned)blocks), dim3(G_THREADS), G_LDS_BYTES, (hipStream_t)stream, p);
+    return check_launch("split_gemm");
+}
+
 extern "C" int medtok_shared_kv_attention_train_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
                                                     const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
                                                     int d, float scale, float dropout_p, uint32_t seed, float *out, float *lse, void *stream)

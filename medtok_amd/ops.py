@@ -286,6 +286,45 @@ def frobenius(x):
     return out
 
 
+def split_half(x, dp: int = None, scale: float = 1.0):
+    """(hi, lo) fp16 images [n, dp] of the fp32 matrix x [n, d] (last dim contiguous; a row-strided view is fine): x * scale =
+    hi + lo to ~2^-22 relative.  dp (default: d rounded up to 8) pads with zero columns."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise _lib.MedTokLibraryError("split_half: expected an fp32 [n, d] matrix with contiguous rows on an MI355X device")
+    n, d = x.shape
+    dp = (d + 7) // 8 * 8 if dp is None else int(dp)
+    hi = torch.empty((n, dp), dtype=torch.float16, device=x.device)
+    lo = torch.empty((n, dp), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().medtok_split_half_f32(x.data_ptr(), n, d, x.stride(0) if n > 1 else d, dp, float(scale), hi.data_ptr(), lo.data_ptr(),
+                                                     _stream(x)), "medtok_split_half_f32")
+    return hi, lo
+
+
+def split_gemm(a, b, n_g: int, k_g: int, groups: int = 1, a_group_cols: int = 0, b_group_rows: int = 0, bias=None, unscale: float = 1.0,
+               want_f32: bool = True, want_split: bool = False):
+    """unscale * (A . B^T) + bias on three fp16 MFMA passes (medtok_split_gemm_f16).  a = (hi, lo) [m, lda], b = (hi, lo)
+    [b_rows, ldb] fp16 images; see include/medtok_vq.h for the grouped form.  Returns (c fp32 [m, groups * n_g] or None,
+    (c_hi, c_lo) or None)."""
+    a_hi, a_lo = a
+    b_hi, b_lo = b
+    for t in (a_hi, a_lo, b_hi, b_lo):
+        if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.dim() == 2):
+            raise _lib.MedTokLibraryError("split_gemm: operands must be contiguous fp16 matrices on an MI355X device")
+    m, lda = a_hi.shape
+    b_rows, ldb = b_hi.shape
+    n_out = groups * n_g
+    bias = None if bias is None else _dev(bias, "bias")
+    c = torch.empty((m, n_out), dtype=torch.float32, device=a_hi.device) if want_f32 else None
+    ch = torch.empty((m, n_out), dtype=torch.float16, device=a_hi.device) if want_split else None
+    cl = torch.empty((m, n_out), dtype=torch.float16, device=a_hi.device) if want_split else None
+    with torch.cuda.device(a_hi.device):
+        _lib.check(_lib.load().medtok_split_gemm_f16(a_hi.data_ptr(), a_lo.data_ptr(), m, lda, int(a_group_cols), b_hi.data_ptr(), b_lo.data_ptr(),
+                                                     b_rows, ldb, int(b_group_rows), int(n_g), int(k_g), int(groups), _ptr(bias), float(unscale),
+                                                     _ptr(c), n_out, _ptr(ch), _ptr(cl), n_out, _stream(a_hi)), "medtok_split_gemm_f16")
+    return c, ((ch, cl) if want_split else None)
+
+
 def residual_layernorm(a, b, gamma, beta, eps: float):
     """LayerNorm(a + b) * gamma + beta per row of the contiguous fp32 matrices a, b [n, d] (the tail of CrossAttentionLayer,
     vector_quantization_soft_one_new.py:47-50); d % 4 == 0, d <= 4096."""

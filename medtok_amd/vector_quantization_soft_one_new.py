@@ -40,6 +40,10 @@ from . import ops
 # launches of ~8 us saved per layer against ~70 us of fp32 GEMM at the bound).  Negative: never.
 COMBINE_MAX_EXTRA_FLOPS = 8e9
 LPT_ORDER = True
+# Inference: the layers' dense products run on the library's split-fp16 MFMA GEMMs (CrossAttention._folded_rows_split) from this many
+# packed query rows up; below it the launch-bound forms further down (combined weights / library GEMMs) are kept.
+SPLIT_PRODUCTS = True
+SPLIT_MIN_ROWS = 1024
 from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
@@ -169,6 +173,73 @@ class CrossAttention(nn.Module):
         return out
 
     @staticmethod
+    def _split_weights(layer):
+        """The layer's four weight matrices as (hi, lo) fp16 image pairs in the layouts medtok_split_gemm_f16 reads (k contiguous,
+        depths padded to 32, the head slices padded to hd' = 32 ceil(hd / 32), the model width to Dw = ops.attention_width(D)), each
+        prescaled by an exact power of two that brings its largest entry into [2^11, 2^12) -- cached on the layer per (storage,
+        version) of its tensors like _combined_weights (a `.data` write needs VectorQuantizer.invalidate_codebook_cache()):
+            wq [H hd', Dw]   rows h hd' + j = W_q[h hd + j]            q'  = rows . wq^T + bq'
+            wk [H Dw, hd']   row h Dw + c, column j = W_k[h hd + j, c]   qf_h = q'_h . wk_h^T        (group h)
+            wv [H hd', Dw]   rows as wq, from W_v                      att_h = ctx_h . wv_h^T + bv' (group h)
+            wo [D, H hd']    column h hd' + j = W_o[:, h hd + j]        out = att . wo^T + bo"""
+        import math
+        mha = layer.multihead_attn
+        params = (mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias)
+        key = tuple((t.data_ptr(), t._version, t.device) for t in params)
+        cache = getattr(layer, "_medtok_split_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        heads, hd = mha.num_heads, mha.head_dim
+        dim = heads * hd
+        dw, hp = ops.attention_width(dim), (hd + 31) // 32 * 32
+        dev = mha.in_proj_weight.device
+        wq, wk, wv = (t.detach().float() for t in mha.in_proj_weight.chunk(3))
+        bq, _, bv = (t.detach().float() for t in mha.in_proj_bias.chunk(3))
+        wo, bo = mha.out_proj.weight.detach().float(), mha.out_proj.bias.detach().float().contiguous()
+
+        def head_rows(w, b):                    # [D, D] -> [H hd', Dw] and its bias [H hd']
+            out = torch.zeros(heads, hp, dw, device=dev)
+            out[:, :hd, :dim] = w.view(heads, hd, dim)
+            bias = torch.zeros(heads, hp, device=dev)
+            bias[:, :hd] = b.view(heads, hd)
+            return out.view(heads * hp, dw), bias.view(-1).contiguous()
+        m_q, b_q = head_rows(wq, bq)
+        m_v, b_v = head_rows(wv, bv)
+        m_k = torch.zeros(heads, dw, hp, device=dev)
+        m_k[:, :dim, :hd] = wk.view(heads, hd, dim).transpose(1, 2)
+        m_o = torch.zeros(dim, heads, hp, device=dev)
+        m_o[:, :, :hd] = wo.view(dim, heads, hd)
+
+        def split(w):
+            amax = float(w.abs().max())
+            scale = 2.0 ** (11 - math.floor(math.log2(amax))) if amax > 0.0 and math.isfinite(amax) else 1.0
+            return ops.split_half(w.contiguous(), dp=w.shape[1], scale=scale), 1.0 / scale
+        out = dict(heads=heads, hd=hd, hp=hp, dim=dim, dw=dw, wq=split(m_q), bq=b_q, wk=split(m_k.view(heads * dw, hp)),
+                   wv=split(m_v), bv=b_v, wo=split(m_o.view(dim, heads * hp)), bo=bo)
+        layer._medtok_split_cache = (key, out)
+        return out
+
+    @staticmethod
+    def _folded_rows_split(layer, rows, attend):
+        """_folded_rows at inference on the library's own dense products: the four projections of the layer run as split-fp16 MFMA
+        GEMMs (medtok_split_gemm_f16: fp32-accurate, ~5x the fp32 matrix rate; the per-head fold and the per-head W_v product are
+        one grouped launch each), every product hands its result to the next as (hi, lo) fp16 images, the tail is the fused
+        residual + LayerNorm kernel.  No library GEMM, nothing padded.  `attend` maps qf [R heads, Dw] to the context [R heads, Dw]."""
+        w = CrossAttention._split_weights(layer)
+        heads, hp, dim, dw = w["heads"], w["hp"], w["dim"], w["dw"]
+        n_rows = rows.shape[0]
+        x = ops.split_half(rows, dp=dw)
+        _, q = ops.split_gemm(x, w["wq"][0], n_g=heads * hp, k_g=dw, bias=w["bq"], unscale=w["wq"][1], want_f32=False, want_split=True)
+        qf, _ = ops.split_gemm(q, w["wk"][0], n_g=dw, k_g=hp, groups=heads, a_group_cols=hp, b_group_rows=dw, unscale=w["wk"][1])
+        ctx = attend(qf.view(n_rows * heads, dw))
+        c = ops.split_half(ctx.view(n_rows, heads * dw))
+        _, att = ops.split_gemm(c, w["wv"][0], n_g=hp, k_g=dw, groups=heads, a_group_cols=dw, b_group_rows=hp, bias=w["bv"], unscale=w["wv"][1],
+                                want_f32=False, want_split=True)
+        out, _ = ops.split_gemm(att, w["wo"][0], n_g=dim, k_g=heads * hp, bias=w["bo"], unscale=w["wo"][1])
+        ln = layer.layer_norm
+        return ops.residual_layernorm(rows, out, ln.weight, ln.bias, ln.eps)
+
+    @staticmethod
     def _folded_rows(layer, rows, attend):
         """_folded_layer for PACKED query rows [R, D] (no batch axis, nothing padded): the attention core is
         `attend(qf [R*heads, D]) -> ctx [R*heads, D]`, i.e. the ragged gfx950 kernel (ops.shared_kv_attention in eval;
@@ -179,6 +250,10 @@ class CrossAttention(nn.Module):
         wq, wk, wv = mha.in_proj_weight.chunk(3)
         bq, _, bv = mha.in_proj_bias.chunk(3)
         plain = not torch.is_grad_enabled() and not torch.is_autocast_enabled() and rows.dtype == wk.dtype
+        ln = layer.layer_norm
+        if (plain and not layer.training and rows.is_cuda and rows.dtype == torch.float32 and SPLIT_PRODUCTS and dim % 4 == 0
+                and ln.elementwise_affine and ln.bias is not None and mha.in_proj_bias is not None and n_rows >= SPLIT_MIN_ROWS):
+            return CrossAttention._folded_rows_split(layer, rows, attend)
         if plain and not layer.training and rows.is_cuda and 4.0 * n_rows * dim * dim * max(heads - 2, 0) <= COMBINE_MAX_EXTRA_FLOPS:
             # small widths (the reference's default e_dim = 64) are launch-bound: the query-side chain (in_proj -> fold) and the
             # value-side chain (Wv -> out_proj) each collapse into ONE GEMM against products of the layer's weights, formed once
@@ -235,14 +310,15 @@ class CrossAttention(nn.Module):
             kv_nodes, kv_text = kv_nodes.float(), kv_text.float()
 
         def attend(qf, q_start, q_len, kv, kv_start, kv_len, max_q_len, max_kv_len):
+            wide_in = qf.shape[1] != dim                   # _folded_rows_split hands over (and takes back) rows at the kernel width
+            q_in = qf if wide_in else widen(qf)
             if autograd:
                 p = float(mha.dropout) if self.training else 0.0
                 seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0.0 else 0      # host RNG: no device sync
-                out = _RaggedAttentionFunction.apply(widen(qf), kv, q_start, q_len, kv_start, kv_len, max_q_len, max_kv_len, scale, p, seed)
+                out = _RaggedAttentionFunction.apply(q_in, kv, q_start, q_len, kv_start, kv_len, max_q_len, max_kv_len, scale, p, seed)
             else:
-                q_in = widen(qf)
                 out = core(q_in.float() if q_in.is_cuda else q_in, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale)
-            return out[:, :dim] if pad else out
+            return out[:, :dim].contiguous() if (pad and not wide_in) else out
         code = torch.arange(bsz, device=dev, dtype=torch.long)
         # text side: the CLS row of every code queries that code's nodes
         t_start, t_len = code * heads, torch.full((bsz,), heads, device=dev, dtype=torch.long)
@@ -459,6 +535,7 @@ class VectorQuantizer(nn.Module):
         self._norm_cache = None
         for layer in self.cross_attn.model:           # the folded-weight products of the cross-attention layers
             layer._medtok_fold_cache = None
+            layer._medtok_split_cache = None
 
     def train(self, mode: bool = True):
         if mode != self.training:

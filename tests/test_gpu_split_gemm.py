@@ -1,0 +1,73 @@
+"""GPU: the split-fp16 dense products (medtok_split_gemm_f16, split_gemm.h) against fp64 -- the projections around the
+cross-attention core.  These are tolerance items (north_star: embeddings within 1e-5 relative fp32); the bar written here is
+3e-6 of the output scale, i.e. the split form must be as good as an fp32 GEMM, not merely inside 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _split_weights(w, ops):
+    """power-of-two prescale so that max |w| lands in [2^11, 2^12) + the (hi, lo) images"""
+    import math
+    amax = float(w.abs().max())
+    scale = 2.0 ** (11 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+    return ops.split_half(w.contiguous(), dp=w.shape[1], scale=scale), 1.0 / scale
+
+
+@pytest.mark.parametrize("m,n,k", [(1000, 768, 768), (256, 256, 32), (4097, 3072, 192), (37, 100, 64), (3000, 64, 3072)])
+def test_plain_product_matches_fp64(dev, m, n, k):
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(m + n + k)
+    a = torch.randn(m, k, device=dev, generator=g) * 1.7
+    w = torch.randn(n, k, device=dev, generator=g) / k ** 0.5
+    bias = torch.randn(n, device=dev, generator=g) * 0.1
+    (wh, wl), unscale = _split_weights(w, ops)
+    c, split = ops.split_gemm(ops.split_half(a), (wh, wl), n_g=n, k_g=k, bias=bias, unscale=unscale, want_f32=True, want_split=True)
+    ref = a.double() @ w.double().t() + bias.double()
+    scale = float(ref.abs().max())
+    err = float((c.double() - ref).abs().max()) / scale
+    ref32 = float((torch.nn.functional.linear(a, w, bias).double() - ref).abs().max()) / scale
+    assert err <= 3e-6, (err, ref32)
+    # the (hi, lo) images of the result are the result
+    ch, cl = split
+    assert float((ch.double() + cl.double() - ref).abs().max()) / scale <= 3e-6
+    assert err <= max(4 * ref32, 1e-6), f"split product {err:.2e} vs the library's fp32 GEMM {ref32:.2e}"
+
+
+def test_grouped_products_are_the_per_head_products(dev):
+    """The two per-head products of the folded attention form, as one launch each: group g reads its own column block of A and
+    row block of B and writes its own column block of C."""
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    R, H, hd, D = 777, 4, 192, 768
+    q = torch.randn(R, H * hd, device=dev, generator=g)
+    wk = torch.randn(H * D, hd, device=dev, generator=g) / hd ** 0.5          # B of group h: rows [h D, (h+1) D), depth hd
+    (bh, bl), un = _split_weights(wk, ops)
+    qf, _ = ops.split_gemm(ops.split_half(q), (bh, bl), n_g=D, k_g=hd, groups=H, a_group_cols=hd, b_group_rows=D, unscale=un)
+    ref = torch.stack([q[:, h * hd:(h + 1) * hd].double() @ wk[h * D:(h + 1) * D].double().t() for h in range(H)], 1).reshape(R, H * D)
+    assert float((qf.double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    # value side: depth D per head, hd output features per head (not a multiple of the 256-feature tile: masked stores)
+    ctx = torch.randn(R, H * D, device=dev, generator=g)
+    wv = torch.randn(H * hd, D, device=dev, generator=g) / D ** 0.5
+    bv = torch.randn(H * hd, device=dev, generator=g) * 0.05
+    (vh, vl), un = _split_weights(wv, ops)
+    out, _ = ops.split_gemm(ops.split_half(ctx), (vh, vl), n_g=hd, k_g=D, groups=H, a_group_cols=D, b_group_rows=hd, bias=bv, unscale=un)
+    ref = torch.cat([ctx[:, h * D:(h + 1) * D].double() @ wv[h * hd:(h + 1) * hd].double().t() for h in range(H)], 1) + bv.double()
+    assert float((out.double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+
+
+def test_split_half_is_exact_to_22_bits_and_pads_with_zeros(dev):
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn(513, 100, device=dev, generator=g) * torch.logspace(-3, 2, 100, device=dev)
+    hi, lo = ops.split_half(x, dp=128)
+    assert hi.shape == (513, 128) and not hi[:, 100:].any() and not lo[:, 100:].any()
+    back = hi[:, :100].double() + lo[:, :100].double()
+    err = (back - x.double()).abs()
+    assert bool((err <= x.abs().double() * 2.0 ** -21 + 2.0 ** -24).all())       # 2^-22 relative, or the fp16 subnormal step
+    # a strided view (a column block of a wider matrix) is taken as it is
+    wide = torch.randn(64, 300, device=dev, generator=g)
+    h2, l2 = ops.split_half(wide[:, 100:164])
+    assert float((h2.double() + l2.double() - wide[:, 100:164].double()).abs().max()) <= 2.0 ** -20
