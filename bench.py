@@ -163,6 +163,7 @@ class Full(Cfg3):
         # algorithmic flops of the attention core per step: 2 products x 2 flops x D per (query row, key) pair
         pairs = float((self.n_nodes * heads * self.tok).sum()) + float((heads * self.n_nodes).sum())
         self.attention_flops = 4.0 * D * pairs * layers
+        self.attention_f16x3 = True          # inference: medtok_shared_kv_attention_f32(exact_f32 = 0)
         self.description = (f"full VectorQuantizer.forward: {rows} codes/GPU/step, ragged cross-attention (<= {self.L} tokens x <= "
                             f"{self.MAX_NODES} nodes per code, 4 heads, 2 layers per direction, D=768) + the 4 searches of cfg3 "
                             f"(n_e = 49152, k=5), eval, fp32")
@@ -335,6 +336,14 @@ class Cfg4:
         self.model.quantize.search_path = path
         self.opt = torch.optim.AdamW([p for p in self.model.parameters() if p.requires_grad], lr=1e-4)
         self.inputs = primekg_shaped_batch(rows, dev, seed=seed, max_len=self.L)
+        # (query row, key) pairs of the cross-attention per layer: every node x head against its code's valid tokens, and the
+        # CLS row x head against the code's nodes; forward 2 products (4 D flop per pair), backward 10 D per pair and kernel
+        heads, layers = 4, 2
+        tok = self.inputs.attention_mask.sum(1).to(torch.float64)
+        n_nodes = torch.bincount(self.inputs.batch, minlength=rows).to(torch.float64)
+        pairs = float((n_nodes * heads * tok).sum()) + float((heads * n_nodes).sum())
+        self.attention_flops = 4.0 * self.D * pairs * layers
+        self._attention_bwd_flops = 20.0 * self.D * pairs * layers
         self.enc_ms, self.enc_events = 0.0, []
         self.description = (f"cfg4 train step: {rows} codes/GPU, {self.L} text tokens, PrimeKG-shaped subgraphs (median ~20 nodes), stand-in "
                             f"BERT-shaped text encoder ({text_layers} layers, frozen) + 2-layer GAT -> soft VQ (n_e=49152, D=768, k=5, aug view, "
@@ -364,6 +373,9 @@ class Cfg4:
         torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
         self.opt.step()
         return (loss.detach(),)
+
+    def attention_backward_flops(self):
+        return self._attention_bwd_flops
 
     def encoder_ms(self, steps=3):
         """time of the stand-in encoders alone (both views, as forward() runs them), outside the timed region"""
@@ -565,15 +577,20 @@ def main():
                               "avg_launch_ms": e_prof["ms"] / max(e_prof["launches"], 1)}}
         wl.set_path(args.path)
 
-    # dominant kernel = the matrix-pipe kernel with the most time in the timed region
-    if hasattr(wl, "attention_flops"):       # the ragged counts live on the device; the workload knows them
+    # dominant kernel = the library kernel with the most TIME in the timed region (HIP events recorded by the library around its
+    # matrix-pipe launches); its flops come from the library where the launch knows them, from the workload where the ragged
+    # counts live on the device, and are null (no roofline fraction) where neither does
+    if hasattr(wl, "attention_flops"):
         prof["shared_kv_attention_kernel"]["flops"] = wl.attention_flops * args.steps
-    # (a kernel whose flops the library cannot know -- the ragged attention launches of the train step -- cannot carry a roofline)
-    known = {k: v for k, v in prof.items() if v["flops"] > 0} or prof
-    kname = max(known, key=lambda k: known[k]["ms"])
+    if hasattr(wl, "attention_backward_flops"):
+        prof["shared_kv_attention_backward_kernels"]["flops"] = wl.attention_backward_flops() * args.steps
+    kname = max(prof, key=lambda k: prof[k]["ms"])
     kp = prof[kname]
-    peak = F16_MFMA_PEAK_TFLOPS if kname == "filter_f16_kernel" else FP32_MFMA_PEAK_TFLOPS
-    achieved = kp["flops"] / (kp["ms"] * 1e-3) / 1e12 if kp["ms"] > 0 else 0.0
+    # the split kernels run a product as three fp16 MFMA passes: their algorithmic (fp32-equivalent) flops are priced against a
+    # third of the dense fp16 peak
+    f16x3 = kname == "split_gemm_kernel" or (kname == "shared_kv_attention_kernel" and getattr(wl, "attention_f16x3", False))
+    peak = F16_MFMA_PEAK_TFLOPS if kname == "filter_f16_kernel" else (F16_MFMA_PEAK_TFLOPS / 3.0 if f16x3 else FP32_MFMA_PEAK_TFLOPS)
+    achieved = (kp["flops"] / (kp["ms"] * 1e-3) / 1e12) if (kp["ms"] > 0 and kp["flops"] > 0) else None
     traffic, traffic_source = pmc_traffic(wl.name, kname, rows)
     alg_bytes_step = float(wl.bytes_per_code()) * rows                # SURVEY 8d per-code figure x the codes one step processes (per GPU)
     hbm_gbs = alg_bytes_step * args.steps / elapsed / 1e9
@@ -600,7 +617,8 @@ def main():
             "scaling": "strong" if args.workload in ("cfg5", "codeshard") else "weak",
             "vs_baseline": None,
             "dtype": ("f32 results (bit-identical to the fp32-MFMA path); f16-MFMA shortlist + exact f32 re-score"
-                      if kname == "filter_f16_kernel" else "f32"),
+                      if kname == "filter_f16_kernel" else
+                      "f32 in / f32 out; products as three f16 MFMA passes over (hi, lo) pairs (~2^-22 relative), f32 softmax and accumulation" if f16x3 else "f32"),
             "data": "synthetic",
             "n_ranks_seen": (torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
             "config": {"workload": wl.description, "rows_per_gpu": rows, "D": wl.D, "search_path": args.path,
@@ -610,16 +628,17 @@ def main():
                        "parallelism": (f"code-shard x{world}: all-gather of the per-rank k-lists (n*k*12 B per rank) + exact merge"
                                        if args.workload == "codeshard" else
                                        f"row-shard x{world}, codebook replicated, no data-path collective")},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved is not None else None,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": kname,
                          "hbm_frac": hbm_gbs / HBM_PEAK_GBS, "hbm_achieved_gbs": hbm_gbs, "hbm_peak_gbs": HBM_PEAK_GBS,
                          "algorithmic_bytes_per_step": alg_bytes_step,
                          "binding_roof": "mfma (arithmetic intensity K/4 flop/B >> ridge; the HBM fraction is reported because BASELINE.json asks for it)",
-                         "peak_note": ("dense f16 MFMA" if kname == "filter_f16_kernel" else "dense f32-input MFMA") + " (MI355X_MICROARCH.md)",
+                         "peak_note": ("dense f16 MFMA" if kname == "filter_f16_kernel" else
+                                       "dense f16 MFMA / 3: every product is three fp16 passes over (hi, lo) pairs" if f16x3 else "dense f32-input MFMA") + " (MI355X_MICROARCH.md)",
                          "launches_timed": kp["launches"], "avg_launch_ms": kp["ms"] / max(kp["launches"], 1),
-                         "algorithmic_flops_per_launch": kp["flops"] / max(kp["launches"], 1),
+                         "algorithmic_flops_per_launch": (kp["flops"] / max(kp["launches"], 1)) if kp["flops"] > 0 else None,
                          "kernel_share_of_step": kp["ms"] / (elapsed * 1e3),
-                         "achieved_over_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "achieved_over_fp32_mfma_peak": (achieved / FP32_MFMA_PEAK_TFLOPS) if achieved is not None else None,
                          "whole_step_tflops": wl.flops_per_code() * rows * args.steps / elapsed / 1e12,
                          "other_kernels": {k: {"ms_per_step": v["ms"] / args.steps, "launches": v["launches"],
                                                "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)}

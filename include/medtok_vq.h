@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MEDTOK_VQ_ABI_VERSION 1
+#define MEDTOK_VQ_ABI_VERSION 2
 #define MEDTOK_MAX_TOPK 8
 
 /* search path selector for medtok_topk_search_f32 */
@@ -61,10 +61,11 @@ const char *medtok_last_error(void);
 
 /* Optional self-profiling for bench.py: between _begin and _end every launch of the three matrix-pipe
  * kernels is bracketed by HIP events on its launch stream (no host sync until _end).  _end fills, for
- * kind 0 = filter_f16_kernel, 1 = search_f32_kernel, 2 = shared_kv_attention_kernel: total
- * milliseconds, total algorithmic flops (2*n*K*D per search launch; 0 for kind 2, whose ragged
- * row/key counts live on the device -- the caller prices it) and the number of launches.  Thread-local. */
-#define MEDTOK_PROFILE_KINDS 3
+ * kind 0 = filter_f16_kernel, 1 = search_f32_kernel, 2 = the attention forward kernels, 3 = the attention backward
+ * pair (dQ + dKV), 4 = split_gemm_kernel: total milliseconds, total algorithmic flops (2*n*K*D per search launch,
+ * 2*m*n*k per dense product -- its fp32-equivalent work, computed as three fp16 passes; 0 for kinds 2 and 3, whose ragged
+ * row/key counts live on the device -- the caller prices them) and the number of launches.  Thread-local. */
+#define MEDTOK_PROFILE_KINDS 5
 int medtok_profile_begin(void);
 int medtok_profile_end(double ms[MEDTOK_PROFILE_KINDS], double flops[MEDTOK_PROFILE_KINDS],
                        int launches[MEDTOK_PROFILE_KINDS]);
@@ -215,11 +216,15 @@ int medtok_scale_by_device_scalar_f32(const float *x, int64_t count, const float
  * rows x keys matrix never reaches memory.  max_q_len >= max_b q_len[b] sizes the grid (rows beyond a
  * code's q_len cost nothing); d = 64 or d % 128 == 0, d <= 768.  A code with kv_len == 0 attends to nothing: its
  * rows are zero (the reference's per-code loop would take a softmax over an empty set there).
- * q_start/q_len/kv_start/kv_len are DEVICE int64[n_codes]; any number of codes per call. */
+ * q_start/q_len/kv_start/kv_len are DEVICE int64[n_codes]; any number of codes per call.
+ * exact_f32 = 0 (what the modules use at inference): both products on the fp16 matrix pipe as three MFMAs over (hi, lo) fp16
+ * pairs -- fp32 inputs, fp32 softmax, ~2^-22-relative products, 16/3 of the fp32 pipe's rate; |q|, |kv| entries must stay
+ * below 65504 (beyond it the result is NaN, not a silently wrong number).  exact_f32 = 1: both products on
+ * v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains), the kernel the training forward shares. */
 int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const int64_t *q_len,
                                    const float *kv, const int64_t *kv_start, const int64_t *kv_len,
                                    int64_t n_codes, int64_t max_q_len, int d, float scale,
-                                   float *out, void *stream);
+                                   float *out, int exact_f32, void *stream);
 
 /* Around the core, for packed rows (no batch axis):
  *   medtok_residual_layernorm_f32: the tail of CrossAttentionLayer.forward (vector_quantization_soft_one_new.py:47-50),

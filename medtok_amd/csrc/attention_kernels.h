@@ -278,6 +278,219 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
     }
 }
 
+// ---------------------------------------------------------------- the same attention core on the fp16 matrix pipe (inference)
+// out[r] = softmax_j(scale <q[r], kv[j]>) . kv with both products as THREE v_mfma_f32_32x32x16_f16 each on (hi, lo) fp16 pairs
+// (x = hi + lo, hi = fp16(x), lo = fp16(x - hi): hi hi + hi lo + lo hi reproduces the fp32 product to ~2^-22 relative, see
+// split_gemm.h) -- 16/3 of the fp32 pipe's rate, with the fp32 softmax between them unchanged.  Attention outputs are tolerance
+// items (1e-5), checked against the oracle like the fp32 kernel above, which stays the training forward (dropout, log-sum-exp).
+//
+// Same decomposition as the fp32 kernel: block = 32 query rows of one code x all its keys, W waves that each own D / W columns
+// of queries, keys and outputs, 32-key chunks, wave-private key slices in LDS (no barrier guards them), two LDS-only barriers
+// per chunk around the softmax.  What differs:
+//   keys    : a wave converts the fp32 rows it fetched to (hi, lo) on the way into LDS -- two fp16 planes per slice, row stride
+//             32 NT + 8 halves (conflict-free ds_read_b128 of 8 consecutive columns of 32 different keys);
+//   scores  : the query slice lives in registers as (hi, lo) MFMA A operands; per 16 columns one b128 read of each plane and
+//             three MFMAs; the next chunk's global loads ride between them, two per k step;
+//   values  : the second product contracts over KEYS, so its B operand is 8 consecutive keys of one column: sixteen 16-bit LDS
+//             reads per operand pair straight into register halves (ds_read_u16_d16 / _d16_hi) -- the probabilities are
+//             written by the softmax step as (hi, lo) rows [query][key] and read with one b128 per plane and k step.
+template <int W, int NT>
+__global__ __launch_bounds__(64 * W) void shared_kv_attention_f16s_kernel(
+    const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
+    const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
+    float scale, float *__restrict__ out, int q_tiles)
+{
+    constexpr int D = 32 * W * NT;
+    constexpr int SLH = 32 * NT + 8;               // halves per key row of a wave's plane
+    constexpr int PLANE = 32 * SLH;                // halves per plane (32 keys)
+    constexpr int KV_HALVES = W * 2 * PLANE;       // W slices x (hi, lo)
+    constexpr int THREADS = 64 * W;
+    constexpr int EPT = 1024 / THREADS;            // score elements per thread in the softmax step (2, 4 or 8)
+    constexpr int TPR = 32 / EPT;                  // threads per score row
+    constexpr int PSL = 40;                        // halves per probability row: 32 keys + 8 (conflict-free b128 reads)
+    typedef _Float16 halfE __attribute__((ext_vector_type(EPT)));
+    extern __shared__ __attribute__((aligned(16))) float att_sm[];
+    _Float16 *kvs = reinterpret_cast<_Float16 *>(att_sm);                                     // [W][2][32][SLH]
+    float (*part)[32][33] = reinterpret_cast<float (*)[32][33]>(kvs + KV_HALVES);               // [W][32][33] partial scores [row][key]
+    _Float16 *ph = reinterpret_cast<_Float16 *>(&part[W][0][0]), *pl = ph + 32 * PSL;          // probabilities [row][key], hi and lo
+    float *alpha_s = reinterpret_cast<float *>(pl + 32 * PSL), *l_s = alpha_s + 32;
+    const int b = (int)(blockIdx.x / (unsigned)q_tiles), qt = (int)(blockIdx.x % (unsigned)q_tiles);
+    const int nq = (int)q_len[b];
+    if (qt * 32 >= nq) return;
+    const long qs = q_start[b], ks = kv_start[b];
+    const int kl = (int)kv_len[b];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int slice = wave * 32 * NT;
+    _Float16 *kw_h = kvs + wave * 2 * PLANE, *kw_l = kw_h + PLANE;
+
+    constexpr int NF = 4 * NT;
+    const int lr = lane >> 3, lc = lane & 7;
+    float4 kf[NF];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int ir = 0; ir < 4; ++ir) {
+            const float *src = kv + (ks + min(k0 + 8 * ir + lr, kl - 1)) * (long)D + slice + 4 * lc;
+#pragma unroll
+            for (int ic = 0; ic < NT; ++ic) kf[ir * NT + ic] = ld4(src + 32 * ic);
+        }
+    };
+    // rows 8 ir .. 8 ir + 7 of the fetched chunk: fp32 registers -> (hi, lo) planes of the wave's slice
+    auto park_rows = [&](int ir) __attribute__((always_inline)) {
+        _Float16 *dh = kw_h + (8 * ir + lr) * SLH + 4 * lc, *dl = kw_l + (8 * ir + lr) * SLH + 4 * lc;
+#pragma unroll
+        for (int ic = 0; ic < NT; ++ic) {
+            const float4 x = kf[ir * NT + ic];
+            half4v h, l;
+            h[0] = (_Float16)x.x; h[1] = (_Float16)x.y; h[2] = (_Float16)x.z; h[3] = (_Float16)x.w;
+            l[0] = (_Float16)(x.x - (float)h[0]); l[1] = (_Float16)(x.y - (float)h[1]);
+            l[2] = (_Float16)(x.z - (float)h[2]); l[3] = (_Float16)(x.w - (float)h[3]);
+            *reinterpret_cast<half4v *>(dh + 32 * ic) = h;
+            *reinterpret_cast<half4v *>(dl + 32 * ic) = l;
+        }
+    };
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    if (kl > 0) fetch(0);
+    bool parked0 = false;
+
+    // query slice as MFMA A operands: k step s covers columns slice + 16 s .. + 15; lane (li, lh) holds row li, columns + 8 lh .. + 7
+    half8 qh[2 * NT], qlo[2 * NT];
+    {
+        const float *qrow = q + (qs + min(qt * 32 + li, nq - 1)) * (long)D + slice + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < 2 * NT; ++s) {
+            const float4 a = ld4(qrow + 16 * s), c = ld4(qrow + 16 * s + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                qh[s][e] = (_Float16)v[e];
+                qlo[s][e] = (_Float16)(v[e] - (float)qh[s][e]);
+            }
+        }
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int k0 = 0; k0 < kl; k0 += 32) {
+        if (!parked0) {
+#pragma unroll
+            for (int ir = 0; ir < 4; ++ir) park_rows(ir);
+            parked0 = true;
+        }
+        const float *fsrc[4];
+#pragma unroll
+        for (int ir = 0; ir < 4; ++ir) fsrc[ir] = kv + (ks + min(k0 + 32 + 8 * ir + lr, kl - 1)) * (long)D + slice + 4 * lc;
+
+        // ---- partial scores over this wave's D / W columns: hi hi into one accumulator, the two cross terms into another
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        {
+            const _Float16 *krow_h = kw_h + li * SLH + 8 * lh, *krow_l = kw_l + li * SLH + 8 * lh;
+#pragma unroll
+            for (int s = 0; s < 2 * NT; ++s) {
+                const half8 kh = *reinterpret_cast<const half8 *>(krow_h + 16 * s);
+                const half8 kq = *reinterpret_cast<const half8 *>(krow_l + 16 * s);
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[s], kh, s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[s], kq, s1, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(qlo[s], kh, s1, 0, 0, 0);
+                // next chunk: two of its 4 NT loads per k step (unconditional; past the last key they re-read one row)
+                kf[2 * s] = ld4(fsrc[(2 * s) / NT] + 32 * ((2 * s) % NT));
+                kf[2 * s + 1] = ld4(fsrc[(2 * s + 1) / NT] + 32 * ((2 * s + 1) % NT));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s0[r] + s1[r];
+        lds_barrier();
+
+        // ---- join the W partials, online softmax: thread -> row tid / TPR, keys EPT (tid % TPR) .. + EPT - 1
+        {
+            const int row = tid / TPR, kq0 = (tid % TPR) * EPT;
+            float v[EPT], mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                float sc = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < W; ++w2) sc += part[w2][row][kq0 + j];
+                sc *= scale;
+                v[j] = (k0 + kq0 + j < kl) ? sc : -INFINITY;
+                mx = fmaxf(mx, v[j]);
+            }
+            static_assert(TPR == 4 || TPR == 8 || TPR == 16, "score-row groups of 4, 8 or 16 lanes");
+            mx = att_group_max<TPR>(mx);
+            const float m_new = fmaxf(m_run, mx);
+            float psum = 0.f;
+            halfE hv, lv;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const float pr = expf(v[j] - m_new);
+                hv[j] = (_Float16)pr;
+                lv[j] = (_Float16)(pr - (float)hv[j]);
+                psum += pr;
+            }
+            *reinterpret_cast<halfE *>(ph + row * PSL + kq0) = hv;
+            *reinterpret_cast<halfE *>(pl + row * PSL + kq0) = lv;
+            psum = att_group_sum<TPR>(psum);
+            const float a = expf(m_run - m_new);
+            l_run = fmaf(l_run, a, psum);
+            m_run = m_new;
+            if (tid % TPR == 0) alpha_s[row] = a;
+        }
+        lds_barrier();
+
+        // ---- out = alpha * out + P . KV on this wave's NT column tiles; the contraction runs over the chunk's 32 keys (2 k steps)
+        {
+            float a16[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a16[r] = alpha_s[(r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] *= a16[r];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const half8 pa_h = *reinterpret_cast<const half8 *>(ph + li * PSL + 16 * s + 8 * lh);
+                const half8 pa_l = *reinterpret_cast<const half8 *>(pl + li * PSL + 16 * s + 8 * lh);
+                const _Float16 *vcol_h = kw_h + (16 * s + 8 * lh) * SLH + li, *vcol_l = kw_l + (16 * s + 8 * lh) * SLH + li;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    half8 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { vh[e] = vcol_h[e * SLH + 32 * t]; vl[e] = vcol_l[e * SLH + 32 * t]; }
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_h, vh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_h, vl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_l, vh, acc[t], 0, 0, 0);
+                }
+                asm volatile("" ::: "memory");
+                // keys 16 s .. 16 s + 15 have had their last reader (a wave's LDS operations complete in order; nobody else reads
+                // this slice): the next chunk's rows take their place
+                park_rows(2 * s);
+                park_rows(2 * s + 1);
+            }
+        }
+    }
+    if (tid % TPR == 0) l_s[tid / TPR] = l_run;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (qt * 32 + row < nq) {
+            const float lsum = l_s[row];
+            const float inv = lsum > 0.f ? 1.f / lsum : 0.f;        // a code with no key rows attends to nothing: context 0, not 0/0
+            float *o = out + (qs + qt * 32 + row) * (long)D + slice + li;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o[32 * t] = acc[t][r] * inv;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- around the core: residual + LayerNorm, node mean
 // CrossAttentionLayer's tail (vector_quantization_soft_one_new.py:47-50):  y[r] = LayerNorm(a[r] + b[r]) * gamma + beta  (biased
 // variance, eps inside the square root).  One wavefront per row; the row a + b stays in registers between the three passes

@@ -55,7 +55,7 @@ extern "C" const char *medtok_last_error(void) { return g_err; }
 // ---------------------------------------------------------------- optional self-profiling (bench.py)
 // Between medtok_profile_begin() and medtok_profile_end() every launch of a search kernel is
 // bracketed by HIP events recorded on its own launch stream; nothing synchronises until _end().
-struct ProfRec { hipEvent_t a, b; double flops; int kind; };   // kind 0 = filter_f16_kernel, 1 = search_f32_kernel, 2 = shared_kv_attention_kernel
+struct ProfRec { hipEvent_t a, b; double flops; int kind; };   // kind 0 = filter_f16_kernel, 1 = search_f32_kernel, 2 = attention forward (either kernel), 3 = attention backward (dQ + dKV), 4 = split_gemm_kernel
 static thread_local bool g_prof_on = false;
 static thread_local std::vector<ProfRec> g_prof;
 
@@ -1414,14 +1414,46 @@ static int attention_forward(const float *q, const int64_t *q_start, const int64
     return check_launch("shared_kv_attention");
 }
 
+static int attention_forward_f16s(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv, const int64_t *kv_start,
+                                  const int64_t *kv_len, int64_t n_codes, int64_t max_q_len, int d, float scale, float *out, hipStream_t s)
+{
+    const int64_t q_tiles = (max_q_len + 31) / 32;
+    if (q_tiles * n_codes >= (1ll << 31)) return fail("shared_kv_attention: n_codes * ceil(max_q_len / 32) = %ld exceeds the grid limit", (long)(q_tiles * n_codes));
+    const dim3 grid((unsigned)(q_tiles * n_codes));
+    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+    const int waves = d == 64 ? 2 : (d % 256 == 0 ? 8 : 4);
+    // (hi, lo) key planes of W slices, 32 keys x (d / W + 8) halves each; per-wave partial scores; probabilities (hi, lo); row state
+    const size_t lds = (size_t)waves * 2 * 32 * (d / waves + 8) * 2 + (size_t)waves * 32 * 33 * 4 + 2 * 32 * 40 * 2 + 64 * 4;
+#define MEDTOK_ATT16(W, NT)                                                                                                      \
+    do {                                                                                                                         \
+        if (lds > 64 * 1024 && !set_lds_once<shared_kv_attention_f16s_kernel<W, NT>>(lds))                                       \
+            return fail("shared_kv_attention: cannot reserve %zu bytes of LDS", lds);                                            \
+        hipLaunchKernelGGL((shared_kv_attention_f16s_kernel<W, NT>), grid, dim3(64 * W), lds, s, q, q_start, q_len, kv, kv_start, kv_len, scale, \
+                           out, (int)q_tiles);                                                                                   \
+    } while (0)
+    switch (d / 128) {
+    case 0: MEDTOK_ATT16(2, 1); break;
+    case 1: MEDTOK_ATT16(4, 1); break;
+    case 2: MEDTOK_ATT16(8, 1); break;
+    case 3: MEDTOK_ATT16(4, 3); break;
+    case 4: MEDTOK_ATT16(8, 2); break;
+    case 5: MEDTOK_ATT16(4, 5); break;
+    default: MEDTOK_ATT16(8, 3); break;
+    }
+#undef MEDTOK_ATT16
+    if (pa) g_prof.push_back({pa, prof_mark(s), 0.0, 2});
+    return check_launch("shared_kv_attention(f16 x 3)");
+}
+
 extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
                                               const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
-                                              int d, float scale, float *out, void *stream)
+                                              int d, float scale, float *out, int exact_f32, void *stream)
 {
     if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
     if (!attention_shape_ok(d)) return fail("shared_kv_attention: d=%d must be 64 or a multiple of 128, at most 768", d);
     if (n_codes == 0 || max_q_len == 0) return 0;
     if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out) return fail("shared_kv_attention: NULL argument");
+    if (!exact_f32) return attention_forward_f16s(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, (hipStream_t)stream);
     return attention_forward(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, nullptr, 0.f, 0u, (hipStream_t)stream);
 }
 
@@ -1496,7 +1528,9 @@ extern "C" int medtok_split_gemm_f16(const void *a_hi, const void *a_lo, int64_t
     const long blocks = (long)((p.row_tiles + 7) / 8) * 8 * p.ftiles * groups;
     if (blocks >= (1ll << 31)) return fail("split_gemm: grid too large");
     if (!set_lds_once<split_gemm_kernel>(G_LDS_BYTES)) return fail("split_gemm: cannot reserve %zu bytes of LDS", G_LDS_BYTES);
+    hipEvent_t pa = g_prof_on ? prof_mark((hipStream_t)stream) : nullptr;
     hipLaunchKernelGGL(split_gemm_kernel, dim3((unsigned)blocks), dim3(G_THREADS), G_LDS_BYTES, (hipStream_t)stream, p);
+    if (pa) g_prof.push_back({pa, prof_mark((hipStream_t)stream), 2.0 * (double)m * (double)n_g * (double)k_g * (double)groups, 4});     // fp32-equivalent flops (x3 on the fp16 pipe)
     return check_launch("split_gemm");
 }
 
@@ -1538,6 +1572,7 @@ extern "C" int medtok_shared_kv_attention_backward_f32(const float *q, const int
     if (q_tiles * n_codes >= (1ll << 31) || kv_tiles * n_codes >= (1ll << 31)) return fail("shared_kv_attention_backward: grid limit exceeded");
     const unsigned thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
     const float keep_scale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    hipEvent_t pa_bwd = g_prof_on ? prof_mark(s) : nullptr;
 #define MEDTOK_ATT_BWD(W, NT)                                                                                                    \
     do {                                                                                                                         \
         const size_t lds = AttShape<W, NT>::LDS_FLOATS * sizeof(float);                                                          \
@@ -1560,6 +1595,7 @@ extern "C" int medtok_shared_kv_attention_backward_f32(const float *q, const int
     default: MEDTOK_ATT_BWD(8, 3); break;
     }
 #undef MEDTOK_ATT_BWD
+    if (pa_bwd) g_prof.push_back({pa_bwd, prof_mark(s), 0.0, 3});     // dQ + dKV; the caller prices the pair (ragged counts live on the device)
     return check_launch("shared_kv_attention_backward");
 }
 

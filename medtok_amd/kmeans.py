@@ -1,8 +1,9 @@
 """k-means codebook initialisation (reference norm_ema_quantizer.py:14-57,85-93).
 
-Cosine k-means on l2-normalised samples: assignment is the same nearest-code
-search kernel (argmax of the dot product == argmin of the distance for unit
-vectors), the per-cluster sums are the EMA statistics kernel.  The reference's
+Both branches of the reference run on the same two kernels: the assignment is the nearest-code search (Euclidean branch :36-39:
+argmax of -|s - m|^2 is the search's argmin of |s|^2 + |m|^2 - 2 s.m as it stands; cosine branch :34 on l2-normalised samples
+and means: argmax of the dot product == argmin of that distance for unit vectors), the per-cluster sums are the EMA statistics
+kernel; the cosine branch re-normalises the means (:50-51).  The reference's
 only randomness is the choice of the initial means (torch.randperm); with the
 same `init_means` the iteration is deterministic and is checked against the
 reference's own run (fixture F12, tests/test_gpu_modules.py): bucket assignments
@@ -28,8 +29,6 @@ def sample_vectors(samples, num):
 def kmeans(samples, num_clusters, num_iters=10, use_cosine_sim=False, init_means=None, trace=None):
     """(means [K, D], bins [K]) like the reference's kmeans (:24-57).  `init_means` replaces the random choice of the
     initial means; `trace` (a list) receives (buckets, means_used) of every iteration (tests)."""
-    if not use_cosine_sim:
-        raise NotImplementedError("the reference only ever calls kmeans(..., use_cosine_sim=True) (:90)")
     samples = samples.detach().float().contiguous()
     means = (sample_vectors(samples, num_clusters) if init_means is None else init_means.detach().float()).contiguous()
     _, ssq = ops.rownorm(samples, normalize=False, want_xhat=False)
@@ -42,6 +41,7 @@ def kmeans(samples, num_clusters, num_iters=10, use_cosine_sim=False, init_means
         bins, sums = ops.ema_stats(samples, idx.view(-1), num_clusters)
         zero = bins == 0
         new_means = sums / bins.masked_fill(zero, 1.0).unsqueeze(-1)
-        new_means, _ = ops.rownorm(new_means.contiguous())
+        if use_cosine_sim:
+            new_means, _ = ops.rownorm(new_means.contiguous())
         means = torch.where(zero.unsqueeze(-1), means, new_means).contiguous()
     return means, bins

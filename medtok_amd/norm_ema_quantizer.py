@@ -96,6 +96,23 @@ class EmbeddingEMA(nn.Module):
         self.cluster_size.data.copy_(cluster_size)
         self.initted.data.copy_(torch.Tensor([True]))
 
+    @torch.jit.ignore
+    def init_embed_split(self, data, split):
+        """Two independent k-means runs over the column halves of `data`, means concatenated (reference :96-107; no caller there)."""
+        if self.initted:
+            return
+        from .kmeans import kmeans
+        embed1, cluster_size1 = kmeans(data[:, :split[0]].contiguous(), self.num_tokens, 10, use_cosine_sim=True)
+        embed2, cluster_size2 = kmeans(data[:, split[0]:].contiguous(), self.num_tokens, 10, use_cosine_sim=True)
+        self.weight.data.copy_(torch.cat([embed1, embed2], dim=-1))
+        self.cluster_size.data.copy_((cluster_size1 + cluster_size2) / 2.)
+        self.initted.data.copy_(torch.Tensor([True]))
+
+    @torch.jit.ignore
+    def init_embed_with_ind(self, data, inds):
+        """(reference :109-116: `inds` is accepted and unused there too)"""
+        self.init_embed_(data)
+
     def forward(self, embed_id):
         return torch.nn.functional.embedding(embed_id, self.weight)
 

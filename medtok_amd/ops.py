@@ -25,10 +25,11 @@ def profile_begin() -> None:
 def profile_end() -> dict:
     """Stop it; returns {kernel: dict(ms, flops, launches)} (synchronises on the recorded events)."""
     import ctypes as C
-    ms, fl, ln = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int * 3)()
+    names = ("filter_f16_kernel", "search_f32_kernel", "shared_kv_attention_kernel", "shared_kv_attention_backward_kernels", "split_gemm_kernel")
+    n = len(names)
+    ms, fl, ln = (C.c_double * n)(), (C.c_double * n)(), (C.c_int * n)()
     _lib.check(_lib.load().medtok_profile_end(ms, fl, ln), "medtok_profile_end")
-    names = ("filter_f16_kernel", "search_f32_kernel", "shared_kv_attention_kernel")
-    return {names[i]: dict(ms=ms[i], flops=fl[i], launches=ln[i]) for i in range(3)}
+    return {names[i]: dict(ms=ms[i], flops=fl[i], launches=ln[i]) for i in range(n)}
 
 
 MedTokLibraryError = _lib.MedTokLibraryError
@@ -365,9 +366,11 @@ def scale_by_device_scalar(x, num, den=None, c: float = 1.0):
     return out
 
 
-def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, scale: float):
+def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, scale: float, exact_f32: bool = False):
     """out[r] = softmax_j(scale * <q[r], kv[j]>) . kv over each code's own (ragged) query and key rows.
-    q [Rq, d], kv [Rk, d] fp32; *_start / *_len int64 [n_codes] on the device; d % 128 == 0."""
+    q [Rq, d], kv [Rk, d] fp32; *_start / *_len int64 [n_codes] on the device; d = 64 or a multiple of 128 up to 768.
+    Default: both products as three fp16 MFMAs over (hi, lo) pairs (fp32-accurate, 16/3 the fp32 pipe's rate); exact_f32: the
+    fp32-MFMA kernel the training forward uses."""
     q, kv = _dev(q, "q"), _dev(kv, "kv")
     qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
     ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
@@ -376,7 +379,7 @@ def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int,
     with torch.cuda.device(q.device):
         _lib.check(lib.medtok_shared_kv_attention_f32(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(),
                                                       kl.data_ptr(), qs.numel(), int(max_q_len), q.shape[1], float(scale),
-                                                      out.data_ptr(), _stream(q)), "medtok_shared_kv_attention_f32")
+                                                      out.data_ptr(), int(bool(exact_f32)), _stream(q)), "medtok_shared_kv_attention_f32")
     return out
 
 

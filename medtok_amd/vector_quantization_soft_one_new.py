@@ -674,3 +674,19 @@ class VectorQuantizer(nn.Module):
         """Map region-local ids (what the searches return) to rows of codebook.weight."""
         lo, _ = self._region(types)
         return local_ids + lo
+
+
+def compute_entropy_loss(affinity, loss_type="softmax", temperature=0.01):
+    """Entropy regulariser over a dense [N, K] affinity matrix (reference :273-287).  Kept for API parity only: nothing in the
+    reference calls it (entropy_loss_ratio is stored and never read, :96), and the search kernels never materialise the N x K
+    matrix it wants -- a caller must bring its own (e.g. -VectorQuantizer.get_distance(x, y)).  Plain torch ops, not in place
+    (the reference divides its argument in place)."""
+    flat_affinity = affinity.reshape(-1, affinity.shape[-1]) / temperature
+    probs = torch.softmax(flat_affinity, dim=-1)
+    log_probs = torch.log_softmax(flat_affinity + 1e-5, dim=-1)
+    if loss_type != "softmax":
+        raise ValueError("Entropy loss {} not supported".format(loss_type))
+    avg_probs = torch.mean(probs, dim=0)
+    avg_entropy = -torch.sum(avg_probs * torch.log(avg_probs + 1e-5))
+    sample_entropy = -torch.mean(torch.sum(probs * log_probs, dim=-1))
+    return sample_entropy - avg_entropy

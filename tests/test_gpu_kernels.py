@@ -212,10 +212,12 @@ def test_code_sharded_merge_is_bit_exact(oracle, dev):
     assert torch.equal(idx_m, idx) and torch.equal(dist_m, dist)
 
 
+@pytest.mark.parametrize("exact_f32", [False, True])
 @pytest.mark.parametrize("d,heads,seed", [(128, 4, 0), (768, 4, 1), (512, 2, 2), (384, 1, 3), (640, 4, 4), (256, 4, 5), (64, 4, 6)])
-def test_shared_kv_attention_matches_oracle(oracle, dev, d, heads, seed):
+def test_shared_kv_attention_matches_oracle(oracle, dev, d, heads, seed, exact_f32):
     """Ragged attention core vs the oracle's restatement (double accumulation): ragged query/key counts that are not
-    multiples of the 32-row tiles, empty query sets, single keys, a key spike that forces the online-softmax rescale."""
+    multiples of the 32-row tiles, empty query sets, single keys, a key spike that forces the online-softmax rescale.
+    Both kernels: the inference default (three fp16 MFMAs per product over (hi, lo) pairs) and the exact fp32-MFMA one."""
     from medtok_amd import ops
     rng = np.random.default_rng(seed)
     q_len = np.array([0, 1, 31, 32, 33, 80, 4, 200 * heads % 97 + 1, 64], np.int64) * 1
@@ -231,13 +233,13 @@ def test_shared_kv_attention_matches_oracle(oracle, dev, d, heads, seed):
     scale = (d // heads) ** -0.5
     want = oracle.shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, scale)
     T = lambda a: torch.from_numpy(a).to(dev)
-    got = ops.shared_kv_attention(T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len), int(q_len.max()), scale).cpu().numpy()
+    got = ops.shared_kv_attention(T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len), int(q_len.max()), scale, exact_f32).cpu().numpy()
     touched = ~np.isnan(want).all(1)
     assert touched.sum() == q_len.sum()
     err = np.abs(got[touched].astype(np.float64) - want[touched]).max() / np.abs(want[touched]).max()
     assert err <= 1e-5, err
     # deterministic
-    again = ops.shared_kv_attention(T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len), int(q_len.max()), scale).cpu().numpy()
+    again = ops.shared_kv_attention(T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len), int(q_len.max()), scale, exact_f32).cpu().numpy()
     assert np.array_equal(got[touched], again[touched])
 
 
@@ -274,7 +276,7 @@ def test_attention_train_forward_and_backward_match_oracle(oracle, dev, d, p):
     fin = own & np.isfinite(lse_o)
     assert np.allclose(lse.cpu().numpy()[fin], lse_o[fin], rtol=1e-5, atol=1e-5) and np.isinf(lse.cpu().numpy()[own & ~fin]).all()
     if p == 0.0:                                                          # no dropout: the inference kernel's output
-        plain = ops.shared_kv_attention(*args, int(q_len.max()), scale)
+        plain = ops.shared_kv_attention(*args, int(q_len.max()), scale, exact_f32=True)
         assert torch.equal(plain[T(own)], out[T(own)])
     dq, dkv = ops.shared_kv_attention_backward(*args, int(q_len.max()), int(kv_len.max()), scale, p, seed, out, lse, T(d_out))
     assert np.abs(dq.cpu().numpy() - dq_o).max() <= 1e-5 * np.abs(dq_o).max()

@@ -508,3 +508,66 @@ def test_cross_attention_combined_weights_match_two_step_form(dev):
     v.invalidate_codebook_cache()
     (a_t3, a_g3), (b_t3, b_g3) = both()
     assert float((a_g3 - b_g3).abs().max()) <= 2e-6 * max(float(b_g3.abs().max()), 1.0)
+
+
+def test_euclidean_kmeans_and_split_init(dev):
+    """kmeans(use_cosine_sim=False) (reference norm_ema_quantizer.py:36-39,46-48) against the reference's formula in fp64 on the
+    same initial means: bucket assignments identical wherever the fp64 best-vs-second squared-distance margin exceeds 1e-5, final
+    means within 1e-5; EmbeddingEMA.init_embed_split (:96-107) = two runs over the column halves, concatenated."""
+    from medtok_amd.kmeans import kmeans
+    from medtok_amd.norm_ema_quantizer import EmbeddingEMA
+    g = torch.Generator(device=dev).manual_seed(3)
+    N, D, K = 3000, 48, 24
+    centers = torch.randn(K, D, device=dev, generator=g) * 2.0
+    samples = centers[torch.randint(0, K, (N,), device=dev, generator=g)] + torch.randn(N, D, device=dev, generator=g)
+    init = samples[torch.randperm(N, device=dev, generator=g)[:K]].clone()
+    trace = []
+    means, bins = kmeans(samples, K, 6, use_cosine_sim=False, init_means=init, trace=trace)
+    ref = init.double()
+    risky = 0
+    for it, (buckets, used) in enumerate(trace):
+        assert float((used.double() - ref).abs().max()) <= 1e-5, it
+        d2 = ((samples.double()[:, None, :] - ref[None]) ** 2).sum(-1)
+        two = torch.topk(d2, 2, dim=1, largest=False).values
+        safe = (two[:, 1] - two[:, 0]) > 1e-5
+        risky += int((~safe).sum())
+        assert torch.equal(buckets[safe], d2.argmin(1)[safe]), it
+        bk = buckets                                    # follow the kernel's own assignment (ties inside the margin may differ)
+        cnt = torch.bincount(bk, minlength=K)
+        new = torch.zeros(K, D, dtype=torch.float64, device=dev).index_add_(0, bk, samples.double()) / cnt.clamp(min=1)[:, None]
+        ref = torch.where((cnt == 0)[:, None], ref, new)
+    assert risky <= N // 100
+    assert float((means.double() - ref).abs().max()) <= 1e-5 and float(bins.sum()) == N
+    # split init: each half clustered on its own
+    e = EmbeddingEMA(K, D, kmeans_init=True).to(dev)
+    data = torch.nn.functional.normalize(samples[:, : D // 2], dim=-1), torch.nn.functional.normalize(samples[:, D // 2:], dim=-1)
+    torch.manual_seed(11)
+    e.init_embed_split(torch.cat(data, dim=-1), [D // 2, D // 2])
+    assert float(e.initted) == 1.0 and e.weight.shape == (K, D)
+    assert float((e.weight[:, : D // 2].norm(dim=-1) - 1).abs().max()) <= 1e-5 and float((e.weight[:, D // 2:].norm(dim=-1) - 1).abs().max()) <= 1e-5
+    assert float(e.cluster_size.sum()) == N             # (cluster_size1 + cluster_size2) / 2
+    w = e.weight.clone()
+    e.init_embed_split(torch.cat(data, dim=-1), [D // 2, D // 2])       # initted: a second call is a no-op
+    assert torch.equal(e.weight, w)
+
+
+def test_soft_quantizer_with_ema_codebook_holder(golden, dev):
+    """VectorQuantizer(kmeans=True) keeps its codebook in an EmbeddingEMA (reference :109-112; nothing there ever initialises or
+    updates it).  A forward through it must be the forward of the nn.Embedding variant with the same weight."""
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    name = "f3_forward_d64"
+    g = golden(name)
+    D, n_e = int(g["e_dim"]), int(g["n_e"])
+    ref = make_vq(name, g, dev).eval()
+    v = VectorQuantizer(n_e, D, float(g["beta"]), 0.0, True, True, [D, D], kmeans=True, k=int(g["k"])).to(dev).eval()
+    sd = {k_: t for k_, t in ref.state_dict().items() if not k_.startswith("codebook.")}
+    missing = v.load_state_dict(sd, strict=False)
+    assert set(missing.missing_keys) == {"codebook.weight", "codebook.cluster_size", "codebook.embed_avg", "codebook.initted"}
+    v.codebook.weight.data.copy_(ref.codebook.weight.data)
+    v.invalidate_codebook_cache()
+    args = [torch.from_numpy(g[k_]).to(dev) for k_ in ("z", "text", "nodes", "mask", "batch", "z_aug")]
+    with torch.no_grad():
+        a, b = v(*args), ref(*args)
+    for key in ("shared_text_embedding", "specific_embedding_text", "specific_embedding_graph_aug", "text_tokens", "shared_graph_tokens_weights"):
+        assert torch.equal(a[key], b[key]), key
+    assert same_ids(a["shared_text_tokens"], g["shared_text.idx"])

@@ -22,9 +22,11 @@ for c in range(cases):
     kv = rng.standard_normal((max(int(kv_len.sum()), 1), d)).astype(np.float32)
     scale = float(rng.choice([0.07, 0.125, 0.25]))
     T = lambda a: torch.from_numpy(a).to(dev)
-    out = ops.shared_kv_attention(T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len), int(q_len.max()), scale).cpu().numpy()
     ref = O.shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, scale)
-    err = np.abs(out - ref).max() / max(np.abs(ref).max(), 1e-30)
+    err = 0.0
+    for exact in (False, True):
+        out = ops.shared_kv_attention(T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len), int(q_len.max()), scale, exact).cpu().numpy()
+        err = max(err, np.abs(out - ref).max() / max(np.abs(ref).max(), 1e-30))
     if not (err <= 1e-5):
         bad += 1
         print(f"MISMATCH case {c}: d={d} codes={n_codes} q_len={q_len.tolist()} kv_len={kv_len.tolist()} rel err {err:.3g}", flush=True)

@@ -8,11 +8,12 @@ import torch
 from medtok_amd import ops
 dev = torch.device("cuda:0")
 D, H = int(sys.argv[1]) if len(sys.argv) > 1 else 768, 4
+EXACT = bool(int(_os.environ.get("ATT_EXACT", "0")))
 def run(B, rows, T, reps=20):
     q = torch.randn(B * rows, D, device=dev) * 0.05
     kv = torch.randn(B * T, D, device=dev)
     code = torch.arange(B, device=dev)
-    a = (q, code * rows, torch.full((B,), rows, device=dev), kv, code * T, torch.full((B,), T, device=dev), rows, 192 ** -0.5)
+    a = (q, code * rows, torch.full((B,), rows, device=dev), kv, code * T, torch.full((B,), T, device=dev), rows, 192 ** -0.5, EXACT)
     for _ in range(3): ops.shared_kv_attention(*a)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): ops.shared_kv_attention(*a)
