@@ -139,7 +139,9 @@ int medtok_sum_scale_f32(const float *vals, int64_t n, double scale, float *out,
  * medtok_split_half_f32: src [n, d] fp32 (row stride src_stride floats) -> hi, lo [n, dp] fp16, dp >= d a multiple of 8, columns
  * past d zero; `scale` (an exact power of two) is applied first -- 1 for activations, the per-matrix prescale for weights. */
 int medtok_split_half_f32(const float *src, int64_t n, int d, int64_t src_stride, int dp, float scale,
-                          void *hi, void *lo, void *stream);
+                          void *hi, void *lo, const int64_t *seg_len, int seg_rows, void *stream);
+/* (seg_len != NULL: the rows are segments of seg_rows rows -- a [B, L, d] batch -- and only the first seg_len[b] rows of segment b
+ * are converted: padding tokens, which are never read as keys, are skipped.) */
 
 /* C = unscale * (A . B^T) + bias for `groups` independent problems that share the row range [0, m):
  *   group g:  A_g = columns [g * a_group_cols, + k_g) of A [m, lda],  B_g = rows [g * b_group_rows, + n_g) of B [b_rows, ldb]
@@ -224,7 +226,21 @@ int medtok_scale_by_device_scalar_f32(const float *x, int64_t count, const float
 int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const int64_t *q_len,
                                    const float *kv, const int64_t *kv_start, const int64_t *kv_len,
                                    int64_t n_codes, int64_t max_q_len, int d, float scale,
-                                   float *out, int exact_f32, void *stream);
+                                   float *out, void *out_hi, void *out_lo, int exact_f32, void *stream);
+/* (out_hi / out_lo, exact_f32 = 0 only: the (hi, lo) fp16 images [Rq, d] of the result, written by the kernel itself for the
+ * dense product that follows (medtok_split_gemm_f16); out may then be NULL.) */
+
+/* The same core for wide inference batches: 64 query rows per block and the keys given as the (hi, lo) fp16 images of
+ * medtok_split_half_f32 (kv_hi / kv_lo [Rk, d], made once per forward: a key row serves every query tile of its code and both
+ * layers), copied into LDS by DMA -- no per-block conversion, half the key traffic per query row.  Same arithmetic as
+ * medtok_shared_kv_attention_f32 with exact_f32 = 0 (three fp16 MFMA passes per product, fp32 softmax); d = 128, 256, 384, 512 or
+ * 768.  Rows of the images that no (kv_start, kv_len) range covers are never read. */
+int medtok_shared_kv_attention_split_f32(const float *q, const int64_t *q_start, const int64_t *q_len,
+                                         const void *kv_hi, const void *kv_lo, const int64_t *kv_start, const int64_t *kv_len,
+                                         int64_t n_codes, int64_t max_q_len, int d, float scale, float *out,
+                                         void *out_hi, void *out_lo, int variant, void *stream);
+/* (variant, d = 768 only: 0 = 32 query rows per block and two blocks per CU -- one block's softmax and copy waits overlap the
+ * other's matrix work; 1 = 64 rows per block, one block per CU, double-buffered key ring.  Same results.) */
 
 /* Around the core, for packed rows (no batch axis):
  *   medtok_residual_layernorm_f32: the tail of CrossAttentionLayer.forward (vector_quantization_soft_one_new.py:47-50),

@@ -66,8 +66,9 @@ SIGNATURES = {
     "medtok_frobenius_workspace_bytes": (_sz, [_i64]),
     "medtok_frobenius_f32": (_int, [_vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "medtok_scale_by_device_scalar_f32": (_int, [_vp, _i64, _vp, _vp, _f, _vp, _vp]),
-    "medtok_shared_kv_attention_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f, _vp, _int, _vp]),
-    "medtok_split_half_f32": (_int, [_vp, _i64, _int, _i64, _int, _f, _vp, _vp, _vp]),
+    "medtok_shared_kv_attention_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f, _vp, _vp, _vp, _int, _vp]),
+    "medtok_split_half_f32": (_int, [_vp, _i64, _int, _i64, _int, _f, _vp, _vp, _vp, _int, _vp]),
+    "medtok_shared_kv_attention_split_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f, _vp, _vp, _vp, _int, _vp]),
     "medtok_split_gemm_f16": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _i64, _int, _int, _int, _int, _int, _vp, _f, _vp, _int, _vp, _vp, _int, _vp]),
     "medtok_residual_layernorm_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _f, _vp, _vp]),
     "medtok_segment_mean_f32": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp]),

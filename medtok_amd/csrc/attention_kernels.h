@@ -278,6 +278,49 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_kernel(
     }
 }
 
+// Output of one 32-row tile for the inference kernels: the accumulators (one column slice per wave, MFMA C layout) go through LDS
+// so that every row leaves as full 16-byte pieces -- fp32 (out) and/or the (hi, lo) fp16 images (oh, ol) that the next dense
+// product reads directly (split_gemm.h): no conversion pass over the [rows x heads, D] context in between.  `stage` = LDS the
+// main loop no longer needs, 32 x (D / HALVES + 4) floats: the tile goes out in HALVES column passes (the waves whose slices
+// lie in the pass write, everybody stores).  All threads of the block call it (two barriers per pass).
+template <int W, int NT, int HALVES = 1>
+__device__ __forceinline__ void att_store_tile(float *stage, const f32x16 (&acc)[NT], const float (&l16)[16], int rows_valid, long row0,
+                                               float *__restrict__ out, _Float16 *__restrict__ oh, _Float16 *__restrict__ ol,
+                                               int slice, int li, int lh, int tid)
+{
+    constexpr int D = 32 * W * NT, DH = D / HALVES, SD = DH + 4, THREADS = 64 * W;
+    static_assert(W % HALVES == 0, "a wave's slice lies in one pass");
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) {
+        if (slice / DH == h) {                                          // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;        // l16[r] = the softmax denominator of that row
+                const float inv = l16[r] > 0.f ? 1.f / l16[r] : 0.f;    // a code with no key rows attends to nothing: context 0, not 0/0
+#pragma unroll
+                for (int t = 0; t < NT; ++t) stage[row * SD + slice - h * DH + li + 32 * t] = acc[t][r] * inv;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 32 * (DH / 8); i += THREADS) {
+            const int row = i / (DH / 8), c8 = (i % (DH / 8)) * 8;
+            if (row >= rows_valid) continue;
+            const float4 a = *reinterpret_cast<const float4 *>(stage + row * SD + c8), b = *reinterpret_cast<const float4 *>(stage + row * SD + c8 + 4);
+            const long o = (row0 + row) * (long)D + h * DH + c8;
+            if (out) { st4(out + o, a); st4(out + o + 4, b); }
+            if (oh) {
+                const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                half8 hh, ll;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { hh[e] = (_Float16)v[e]; ll[e] = (_Float16)(v[e] - (float)hh[e]); }
+                *reinterpret_cast<half8 *>(oh + o) = hh;
+                *reinterpret_cast<half8 *>(ol + o) = ll;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- the same attention core on the fp16 matrix pipe (inference)
 // out[r] = softmax_j(scale <q[r], kv[j]>) . kv with both products as THREE v_mfma_f32_32x32x16_f16 each on (hi, lo) fp16 pairs
 // (x = hi + lo, hi = fp16(x), lo = fp16(x - hi): hi hi + hi lo + lo hi reproduces the fp32 product to ~2^-22 relative, see
@@ -298,7 +341,7 @@ template <int W, int NT>
 __global__ __launch_bounds__(64 * W) void shared_kv_attention_f16s_kernel(
     const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
     const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
-    float scale, float *__restrict__ out, int q_tiles)
+    float scale, float *__restrict__ out, _Float16 *__restrict__ out_h, _Float16 *__restrict__ out_l, int q_tiles)
 {
     constexpr int D = 32 * W * NT;
     constexpr int SLH = 32 * NT + 8;               // halves per key row of a wave's plane
@@ -476,19 +519,15 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_f16s_kernel(
             }
         }
     }
+    // the row sums move to registers first: the staging tile overwrites the LDS they live in
+    __syncthreads();
     if (tid % TPR == 0) l_s[tid / TPR] = l_run;
     __syncthreads();
+    float l16[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (qt * 32 + row < nq) {
-            const float lsum = l_s[row];
-            const float inv = lsum > 0.f ? 1.f / lsum : 0.f;        // a code with no key rows attends to nothing: context 0, not 0/0
-            float *o = out + (qs + qt * 32 + row) * (long)D + slice + li;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) o[32 * t] = acc[t][r] * inv;
-        }
-    }
+    for (int r = 0; r < 16; ++r) l16[r] = l_s[(r & 3) + 8 * (r >> 2) + 4 * lh];
+    __syncthreads();
+    att_store_tile<W, NT>(att_sm, acc, l16, nq - qt * 32, qs + qt * 32, out, out_h, out_l, slice, li, lh, tid);
 }
 
 // ---------------------------------------------------------------- around the core: residual + LayerNorm, node mean

@@ -1377,6 +1377,7 @@ extern "C" int medtok_scale_by_device_scalar_f32(const float *x, int64_t count, 
 #include "attention_kernels.h"
 
 #include "attention_backward.h"
+#include "attention_dma.h"
 
 static int attention_shape_ok(int d) { return d == 64 || (d > 0 && d % 128 == 0 && d <= 768); }
 
@@ -1415,7 +1416,8 @@ static int attention_forward(const float *q, const int64_t *q_start, const int64
 }
 
 static int attention_forward_f16s(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv, const int64_t *kv_start,
-                                  const int64_t *kv_len, int64_t n_codes, int64_t max_q_len, int d, float scale, float *out, hipStream_t s)
+                                  const int64_t *kv_len, int64_t n_codes, int64_t max_q_len, int d, float scale, float *out, _Float16 *out_h,
+                                  _Float16 *out_l, hipStream_t s)
 {
     const int64_t q_tiles = (max_q_len + 31) / 32;
     if (q_tiles * n_codes >= (1ll << 31)) return fail("shared_kv_attention: n_codes * ceil(max_q_len / 32) = %ld exceeds the grid limit", (long)(q_tiles * n_codes));
@@ -1429,7 +1431,7 @@ static int attention_forward_f16s(const float *q, const int64_t *q_start, const 
         if (lds > 64 * 1024 && !set_lds_once<shared_kv_attention_f16s_kernel<W, NT>>(lds))                                       \
             return fail("shared_kv_attention: cannot reserve %zu bytes of LDS", lds);                                            \
         hipLaunchKernelGGL((shared_kv_attention_f16s_kernel<W, NT>), grid, dim3(64 * W), lds, s, q, q_start, q_len, kv, kv_start, kv_len, scale, \
-                           out, (int)q_tiles);                                                                                   \
+                           out, out_h, out_l, (int)q_tiles);                                                                     \
     } while (0)
     switch (d / 128) {
     case 0: MEDTOK_ATT16(2, 1); break;
@@ -1445,15 +1447,59 @@ static int attention_forward_f16s(const float *q, const int64_t *q_start, const 
     return check_launch("shared_kv_attention(f16 x 3)");
 }
 
+// 64-row blocks, keys from (hi, lo) fp16 images by LDS-DMA (attention_dma.h)
+static bool attention_dma_shape_ok(int d) { return d == 128 || d == 256 || d == 384 || d == 512 || d == 768; }
+
+extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const void *kv_hi, const void *kv_lo,
+                                                    const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
+                                                    int d, float scale, float *out, void *out_hi, void *out_lo, int variant, void *stream)
+{
+    if ((out_hi == nullptr) != (out_lo == nullptr)) return fail("shared_kv_attention_split: out_hi and out_lo go together");
+    if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention_split: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
+    if (!attention_dma_shape_ok(d)) return fail("shared_kv_attention_split: d=%d must be 128, 256, 384, 512 or 768", d);
+    if (n_codes == 0 || max_q_len == 0) return 0;
+    if (!q || !q_start || !q_len || !kv_hi || !kv_lo || !kv_start || !kv_len || (!out && !out_hi)) return fail("shared_kv_attention_split: NULL argument");
+    if (((uintptr_t)q | (uintptr_t)kv_hi | (uintptr_t)kv_lo | (uintptr_t)out) & 15) return fail("shared_kv_attention_split: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+#define MEDTOK_ATT_DMA(W, NT, MT, RING)                                                                                          \
+    do {                                                                                                                         \
+        const size_t lds = AttDma<W, NT, MT, RING>::LDS_BYTES;                                                                   \
+        const int64_t q_tiles = (max_q_len + 32 * MT - 1) / (32 * MT);                                                           \
+        if (q_tiles * (n_codes + 8) >= (1ll << 31)) return fail("shared_kv_attention_split: grid limit exceeded");                \
+        if (lds > 64 * 1024 && !set_lds_once<shared_kv_attention_dma_kernel<W, NT, MT, RING>>(lds))                              \
+            return fail("shared_kv_attention_split: cannot reserve %zu bytes of LDS", lds);                                      \
+        hipLaunchKernelGGL((shared_kv_attention_dma_kernel<W, NT, MT, RING>), dim3((unsigned)(q_tiles * ((n_codes + 7) / 8 * 8))), dim3(64 * W), \
+                           lds, s, q, q_start, q_len, (const _Float16 *)kv_hi, (const _Float16 *)kv_lo, kv_start, kv_len, scale, out, \
+                           (_Float16 *)out_hi, (_Float16 *)out_lo, (int)q_tiles, (int)n_codes);                                  \
+    } while (0)
+    switch (d) {
+    case 128: MEDTOK_ATT_DMA(4, 1, 2, 2); break;
+    case 256: MEDTOK_ATT_DMA(8, 1, 2, 2); break;
+    case 384: MEDTOK_ATT_DMA(4, 3, 2, 2); break;
+    case 512: MEDTOK_ATT_DMA(8, 2, 2, 2); break;
+    default:                               // 768: variant 0 = 32 rows per block, two blocks per CU; 1 = 64 rows per block, one per CU
+        if (variant == 1) MEDTOK_ATT_DMA(8, 3, 2, 2); else MEDTOK_ATT_DMA(4, 6, 1, 1);
+        break;
+    }
+#undef MEDTOK_ATT_DMA
+    if (pa) g_prof.push_back({pa, prof_mark(s), 0.0, 2});
+    return check_launch("shared_kv_attention_split");
+}
+
 extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
                                               const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
-                                              int d, float scale, float *out, int exact_f32, void *stream)
+                                              int d, float scale, float *out, void *out_hi, void *out_lo, int exact_f32, void *stream)
 {
+    if ((out_hi == nullptr) != (out_lo == nullptr)) return fail("shared_kv_attention: out_hi and out_lo go together");
+    if (exact_f32 && out_hi) return fail("shared_kv_attention: the (hi, lo) output images come from the inference kernels (exact_f32 = 0)");
+    if (!out && !out_hi && n_codes > 0 && max_q_len > 0) return fail("shared_kv_attention: no output buffer");
     if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
     if (!attention_shape_ok(d)) return fail("shared_kv_attention: d=%d must be 64 or a multiple of 128, at most 768", d);
     if (n_codes == 0 || max_q_len == 0) return 0;
-    if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out) return fail("shared_kv_attention: NULL argument");
-    if (!exact_f32) return attention_forward_f16s(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, (hipStream_t)stream);
+    if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len) return fail("shared_kv_attention: NULL argument");
+    if (!exact_f32) return attention_forward_f16s(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, (_Float16 *)out_hi,
+                                                  (_Float16 *)out_lo, (hipStream_t)stream);
     return attention_forward(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, nullptr, 0.f, 0u, (hipStream_t)stream);
 }
 
@@ -1486,8 +1532,10 @@ extern "C" int medtok_segment_mean_f32(const float *x, const int64_t *seg_start,
 // ================================================================= split-fp16 dense products (split_gemm.h)
 #include "split_gemm.h"
 
-extern "C" int medtok_split_half_f32(const float *src, int64_t n, int d, int64_t src_stride, int dp, float scale, void *hi, void *lo, void *stream)
+extern "C" int medtok_split_half_f32(const float *src, int64_t n, int d, int64_t src_stride, int dp, float scale, void *hi, void *lo,
+                                     const int64_t *seg_len, int seg_rows, void *stream)
 {
+    if (seg_len && (seg_rows <= 0 || n % seg_rows)) return fail("split_half: n=%ld is not a whole number of segments of %d rows", (long)n, seg_rows);
     if (n < 0 || d <= 0 || (d & 3) || dp < d || (dp & 7) || src_stride < d || (src_stride & 3))
         return fail("split_half: bad shape n=%ld d=%d stride=%ld dp=%d (d %% 4 == 0, dp %% 8 == 0, dp >= d)", (long)n, d, (long)src_stride, dp);
     if (n == 0) return 0;
@@ -1495,7 +1543,7 @@ extern "C" int medtok_split_half_f32(const float *src, int64_t n, int d, int64_t
     if (((uintptr_t)src | (uintptr_t)hi | (uintptr_t)lo) & 15) return fail("split_half: pointers must be 16-byte aligned");
     const long total = n * (dp / 8);
     hipLaunchKernelGGL(split_half_kernel, dim3((unsigned)lmin(8192, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (long)n, d,
-                       (long)src_stride, dp, scale, (_Float16 *)hi, (_Float16 *)lo);
+                       (long)src_stride, dp, scale, (_Float16 *)hi, (_Float16 *)lo, seg_len, seg_rows > 0 ? seg_rows : 1);
     return check_launch("split_half");
 }
 

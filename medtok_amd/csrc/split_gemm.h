@@ -210,15 +210,18 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
 }
 
 // fp32 rows [n, d] -> (hi, lo) fp16 images [n, dp] (dp >= d, multiple of 8; columns past d are zero), scaled by `scale` first
-// (an exact power of two; 1 for activations).  One thread per 8 elements.
+// (an exact power of two; 1 for activations).  One thread per 8 elements.  With seg_len: the rows come in segments of seg_rows
+// (a [B, L, d] batch) of which only the first seg_len[b] are converted -- padding tokens are never read as keys.
 __global__ __launch_bounds__(256) void split_half_kernel(const float *__restrict__ src, long n, int d, long src_stride, int dp, float scale,
-                                                         _Float16 *__restrict__ hi, _Float16 *__restrict__ lo)
+                                                         _Float16 *__restrict__ hi, _Float16 *__restrict__ lo,
+                                                         const int64_t *__restrict__ seg_len, int seg_rows)
 {
     const int cpr = dp / 8;
     const long total = n * cpr;
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
         const long r = t / cpr;
         const int c = (int)(t - r * cpr) * 8;
+        if (seg_len && (r % seg_rows) >= seg_len[r / seg_rows]) continue;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = 0.f;

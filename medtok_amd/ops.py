@@ -287,9 +287,10 @@ def frobenius(x):
     return out
 
 
-def split_half(x, dp: int = None, scale: float = 1.0):
+def split_half(x, dp: int = None, scale: float = 1.0, seg_len=None, seg_rows: int = 0):
     """(hi, lo) fp16 images [n, dp] of the fp32 matrix x [n, d] (last dim contiguous; a row-strided view is fine): x * scale =
-    hi + lo to ~2^-22 relative.  dp (default: d rounded up to 8) pads with zero columns."""
+    hi + lo to ~2^-22 relative.  dp (default: d rounded up to 8) pads with zero columns.  seg_len (int64 [n / seg_rows] on the
+    device): only the first seg_len[b] rows of every segment of seg_rows rows are converted (the rest stay uninitialised)."""
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
         raise _lib.MedTokLibraryError("split_half: expected an fp32 [n, d] matrix with contiguous rows on an MI355X device")
     n, d = x.shape
@@ -298,7 +299,8 @@ def split_half(x, dp: int = None, scale: float = 1.0):
     lo = torch.empty((n, dp), dtype=torch.float16, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().medtok_split_half_f32(x.data_ptr(), n, d, x.stride(0) if n > 1 else d, dp, float(scale), hi.data_ptr(), lo.data_ptr(),
-                                                     _stream(x)), "medtok_split_half_f32")
+                                                     _ptr(None if seg_len is None else _dev(seg_len, "seg_len", torch.int64)), int(seg_rows), _stream(x)),
+                   "medtok_split_half_f32")
     return hi, lo
 
 
@@ -366,21 +368,50 @@ def scale_by_device_scalar(x, num, den=None, c: float = 1.0):
     return out
 
 
-def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, scale: float, exact_f32: bool = False):
+def _attention_outputs(q, split_out):
+    """fp32 result, or its (hi, lo) fp16 images (rows that belong to no code stay uninitialised either way)"""
+    if not split_out:
+        return torch.empty_like(q), None, None
+    return None, torch.empty(q.shape, dtype=torch.float16, device=q.device), torch.empty(q.shape, dtype=torch.float16, device=q.device)
+
+
+def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, scale: float, exact_f32: bool = False, split_out: bool = False):
     """out[r] = softmax_j(scale * <q[r], kv[j]>) . kv over each code's own (ragged) query and key rows.
     q [Rq, d], kv [Rk, d] fp32; *_start / *_len int64 [n_codes] on the device; d = 64 or a multiple of 128 up to 768.
     Default: both products as three fp16 MFMAs over (hi, lo) pairs (fp32-accurate, 16/3 the fp32 pipe's rate); exact_f32: the
-    fp32-MFMA kernel the training forward uses."""
+    fp32-MFMA kernel the training forward uses.  split_out: return the (hi, lo) fp16 images of the result instead (written by the
+    kernel for the dense product that follows)."""
     q, kv = _dev(q, "q"), _dev(kv, "kv")
     qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
     ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
-    out = torch.empty_like(q)
+    out, oh, ol = _attention_outputs(q, split_out)
     lib = _lib.load()
     with torch.cuda.device(q.device):
         _lib.check(lib.medtok_shared_kv_attention_f32(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(),
                                                       kl.data_ptr(), qs.numel(), int(max_q_len), q.shape[1], float(scale),
-                                                      out.data_ptr(), int(bool(exact_f32)), _stream(q)), "medtok_shared_kv_attention_f32")
-    return out
+                                                      _ptr(out), _ptr(oh), _ptr(ol), int(bool(exact_f32)), _stream(q)), "medtok_shared_kv_attention_f32")
+    return (oh, ol) if split_out else out
+
+
+ATTENTION_SPLIT_WIDTHS = (128, 256, 384, 512, 768)
+
+
+def shared_kv_attention_split(q, q_start, q_len, kv_split, kv_start, kv_len, max_q_len: int, scale: float, split_out: bool = False, variant: int = 0):
+    """shared_kv_attention for wide batches: the keys as the (hi, lo) fp16 images of split_half (made once per forward), 64 query
+    rows per block, keys copied into LDS by DMA.  d in ATTENTION_SPLIT_WIDTHS."""
+    q = _dev(q, "q")
+    kh, kl_ = kv_split
+    for t in (kh, kl_):
+        if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == q.shape[1]):
+            raise _lib.MedTokLibraryError("shared_kv_attention_split: the key images must be contiguous fp16 [Rk, d] device tensors")
+    qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
+    ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
+    out, oh, ol = _attention_outputs(q, split_out)
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.load().medtok_shared_kv_attention_split_f32(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kh.data_ptr(), kl_.data_ptr(),
+                                                                    ks.data_ptr(), kl.data_ptr(), qs.numel(), int(max_q_len), q.shape[1], float(scale),
+                                                                    _ptr(out), _ptr(oh), _ptr(ol), int(variant), _stream(q)), "medtok_shared_kv_attention_split_f32")
+    return (oh, ol) if split_out else out
 
 
 def shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, scale: float, dropout_p: float = 0.0, seed: int = 0):

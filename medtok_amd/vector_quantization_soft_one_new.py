@@ -43,6 +43,7 @@ LPT_ORDER = True
 # Inference: the layers' dense products run on the library's split-fp16 MFMA GEMMs (CrossAttention._folded_rows_split) from this many
 # packed query rows up; below it the launch-bound forms further down (combined weights / library GEMMs) are kept.
 SPLIT_PRODUCTS = True
+SPLIT_ATTENTION = True       # the graph side's attention on ops.shared_kv_attention_split (64-row blocks, keys from fp16 images)
 SPLIT_MIN_ROWS = 1024
 from .norm_ema_quantizer import EmbeddingEMA
 
@@ -231,8 +232,8 @@ class CrossAttention(nn.Module):
         x = ops.split_half(rows, dp=dw)
         _, q = ops.split_gemm(x, w["wq"][0], n_g=heads * hp, k_g=dw, bias=w["bq"], unscale=w["wq"][1], want_f32=False, want_split=True)
         qf, _ = ops.split_gemm(q, w["wk"][0], n_g=dw, k_g=hp, groups=heads, a_group_cols=hp, b_group_rows=dw, unscale=w["wk"][1])
-        ctx = attend(qf.view(n_rows * heads, dw))
-        c = ops.split_half(ctx.view(n_rows, heads * dw))
+        c_hi, c_lo = attend(qf.view(n_rows * heads, dw), split_out=True)       # the kernel writes the (hi, lo) images of the context itself
+        c = (c_hi.view(n_rows, heads * dw), c_lo.view(n_rows, heads * dw))
         _, att = ops.split_gemm(c, w["wv"][0], n_g=hp, k_g=dw, groups=heads, a_group_cols=dw, b_group_rows=hp, bias=w["bv"], unscale=w["wv"][1],
                                 want_f32=False, want_split=True)
         out, _ = ops.split_gemm(att, w["wo"][0], n_g=dim, k_g=heads * hp, bias=w["bo"], unscale=w["wo"][1])
@@ -252,7 +253,8 @@ class CrossAttention(nn.Module):
         plain = not torch.is_grad_enabled() and not torch.is_autocast_enabled() and rows.dtype == wk.dtype
         ln = layer.layer_norm
         if (plain and not layer.training and rows.is_cuda and rows.dtype == torch.float32 and SPLIT_PRODUCTS and dim % 4 == 0
-                and ln.elementwise_affine and ln.bias is not None and mha.in_proj_bias is not None and n_rows >= SPLIT_MIN_ROWS):
+                and ln.elementwise_affine and ln.bias is not None and mha.in_proj_bias is not None and n_rows >= SPLIT_MIN_ROWS
+                and getattr(attend, "library_core", False)):
             return CrossAttention._folded_rows_split(layer, rows, attend)
         if plain and not layer.training and rows.is_cuda and 4.0 * n_rows * dim * dim * max(heads - 2, 0) <= COMBINE_MAX_EXTRA_FLOPS:
             # small widths (the reference's default e_dim = 64) are launch-bound: the query-side chain (in_proj -> fold) and the
@@ -309,10 +311,17 @@ class CrossAttention(nn.Module):
         if not autograd and text.is_cuda:                  # the inference kernel is fp32 whatever autocast hands over
             kv_nodes, kv_text = kv_nodes.float(), kv_text.float()
 
-        def attend(qf, q_start, q_len, kv, kv_start, kv_len, max_q_len, max_kv_len):
+        def attend(qf, q_start, q_len, kv, kv_start, kv_len, max_q_len, max_kv_len, kv_split=None, split_out=False):
             wide_in = qf.shape[1] != dim                   # _folded_rows_split hands over (and takes back) rows at the kernel width
             q_in = qf if wide_in else widen(qf)
-            if autograd:
+            if split_out:                                  # (inference on the library's core only: the kernel writes the (hi, lo) images itself)
+                assert qf.shape[1] == dim + pad and not autograd and core is ops.shared_kv_attention
+                if kv_split is not None:
+                    return ops.shared_kv_attention_split(q_in, q_start, q_len, kv_split, kv_start, kv_len, max_q_len, scale, split_out=True)
+                return ops.shared_kv_attention(q_in, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale, split_out=True)
+            if kv_split is not None:                       # wide inference batches: 64-row blocks, keys by LDS-DMA from their fp16 images
+                out = ops.shared_kv_attention_split(q_in.float(), q_start, q_len, kv_split, kv_start, kv_len, max_q_len, scale)
+            elif autograd:
                 p = float(mha.dropout) if self.training else 0.0
                 seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0.0 else 0      # host RNG: no device sync
                 out = _RaggedAttentionFunction.apply(q_in, kv, q_start, q_len, kv_start, kv_len, max_q_len, max_kv_len, scale, p, seed)
@@ -323,8 +332,13 @@ class CrossAttention(nn.Module):
         # text side: the CLS row of every code queries that code's nodes
         t_start, t_len = code * heads, torch.full((bsz,), heads, device=dev, dtype=torch.long)
         cur = text[:, 0].contiguous()
+        lib_core = (not autograd) and core is ops.shared_kv_attention and text.is_cuda     # the split-product layer form needs the library's own core
+
+        def text_attend(qf, **kw):
+            return attend(qf, t_start, t_len, kv_nodes, starts, counts, heads, max_nodes, **kw)
+        text_attend.library_core = lib_core
         for layer in self.model:
-            cur = self._folded_rows(layer, cur, lambda qf: attend(qf, t_start, t_len, kv_nodes, starts, counts, heads, max_nodes))
+            cur = self._folded_rows(layer, cur, text_attend)
         if max_nodes == 0:                                 # nothing to attend from: the node mean of every code is zero
             return cur, cur.new_zeros(bsz, dim)
         # graph side: every node queries the valid text tokens of its code
@@ -336,8 +350,18 @@ class CrossAttention(nn.Module):
             order = torch.argsort(valid_len, descending=True)
             g_start, g_len, tok_start, g_kv_len = g_start[order], g_len[order], tok_start[order], valid_len[order]
         g = nodes_sorted
+        # inference on the library's own core: the text rows become (hi, lo) fp16 images ONCE per forward (valid tokens only) -- every
+        # query tile of a code and both layers read them
+        text_split = None
+        if (not autograd and core is ops.shared_kv_attention and text.is_cuda and kv_text.shape[1] in ops.ATTENTION_SPLIT_WIDTHS
+                and SPLIT_ATTENTION and g.shape[0] * heads >= SPLIT_MIN_ROWS):
+            text_split = ops.split_half(kv_text, seg_len=valid_len, seg_rows=seq_len)
+
+        def graph_attend(qf, **kw):
+            return attend(qf, g_start, g_len, kv_text, tok_start, g_kv_len, max_nodes * heads, seq_len, kv_split=text_split, **kw)
+        graph_attend.library_core = lib_core
         for layer in self.model:
-            g = self._folded_rows(layer, g, lambda qf: attend(qf, g_start, g_len, kv_text, tok_start, g_kv_len, max_nodes * heads, seq_len))
+            g = self._folded_rows(layer, g, graph_attend)
         if not autograd and not torch.is_grad_enabled() and g.is_cuda and g.dtype == torch.float32 and dim % 4 == 0:
             return cur, ops.segment_mean(g, starts, counts)        # rows of a code are adjacent: one ordered chain per column
         padded = g.new_zeros(bsz, max_nodes, dim)

@@ -360,3 +360,64 @@ def test_normalized_search_equals_rownorm_plus_search(dev, n, k, d, topk, path_n
     zhat2, zsq2, idx2, dist2 = ops.normalized_search(z, E, esq, topk, path)
     assert torch.equal(zhat, zhat2) and torch.equal(zsq, zsq2)
     assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
+
+
+@pytest.mark.parametrize("d,heads,seed,variant", [(128, 4, 0, 0), (768, 4, 1, 0), (768, 4, 1, 1), (512, 2, 2, 0), (384, 1, 3, 0), (256, 4, 5, 0)])
+def test_shared_kv_attention_split_matches_oracle(oracle, dev, d, heads, seed, variant):
+    """The wide-batch attention core (64 query rows per block, keys copied into LDS by DMA from their (hi, lo) fp16 images, value
+    operands by transposed LDS reads) vs the oracle: same ragged cases as above -- query counts around the 64-row tile, key counts
+    around the 16-key chunk, empty query sets, single keys, the late key spike that forces the online-softmax rescale, key rows
+    that belong to no code left UNINITIALISED in the images (the masked split skips them)."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(seed)
+    q_len = np.array([0, 1, 63, 64, 65, 130, 4, 200 * heads % 97 + 1, 16], np.int64)
+    kv_len = np.array([5, 1, 33, 512, 15, 260, 16, 17, 96], np.int64)
+    slot = 520                                                    # every code owns a slot of 520 key rows; only kv_len of them are valid
+    q_start = np.cumsum(q_len) - q_len + 3
+    kv_start = np.arange(len(kv_len), dtype=np.int64) * slot
+    nq, nk = int(q_start[-1] + q_len[-1]) + 2, int(len(kv_len) * slot)
+    q = (rng.standard_normal((nq, d)) * 0.3).astype(np.float32)
+    kv = rng.standard_normal((nk, d)).astype(np.float32)
+    kv[kv_start[3] + 300] = q[q_start[3] + 5] * 40.0
+    scale = (d // heads) ** -0.5
+    want = oracle.shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, scale)
+    T = lambda a: torch.from_numpy(a).to(dev)
+    images = ops.split_half(T(kv), seg_len=T(kv_len), seg_rows=slot)
+    # poison what the masked conversion skipped: nothing may read it
+    hi, lo = images
+    valid = (torch.arange(slot, device=dev)[None, :] < T(kv_len)[:, None]).reshape(-1)
+    hi[~valid] = float("nan"); lo[~valid] = float("nan")
+    got = ops.shared_kv_attention_split(T(q), T(q_start), T(q_len), images, T(kv_start), T(kv_len), int(q_len.max()), scale, variant=variant).cpu().numpy()
+    touched = ~np.isnan(want).all(1)
+    assert touched.sum() == q_len.sum()
+    err = np.abs(got[touched].astype(np.float64) - want[touched]).max() / np.abs(want[touched]).max()
+    assert err <= 1e-5, err
+    again = ops.shared_kv_attention_split(T(q), T(q_start), T(q_len), images, T(kv_start), T(kv_len), int(q_len.max()), scale, variant=variant).cpu().numpy()
+    assert np.array_equal(got[touched], again[touched])
+    # and the 32-row kernel on the same problem: same function
+    other = ops.shared_kv_attention(T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len), int(q_len.max()), scale).cpu().numpy()
+    assert np.abs(other[touched] - got[touched]).max() <= 2e-6 * np.abs(want[touched]).max()
+
+
+@pytest.mark.parametrize("d", [64, 128, 768, 384])
+def test_attention_split_output_images_equal_the_fp32_output(dev, d):
+    """split_out: the inference kernels write the (hi, lo) fp16 images of the context themselves (through LDS, 16-byte pieces per row)
+    for the dense product that follows; hi + lo must be the kernel's own fp32 output to the split's 2^-22."""
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(d)
+    q_len = torch.tensor([70, 5, 0, 64, 33], device=dev); kv_len = torch.tensor([40, 17, 9, 100, 1], device=dev)
+    q_start = torch.cumsum(q_len, 0) - q_len; kv_start = torch.cumsum(kv_len, 0) - kv_len
+    q = torch.randn(int(q_len.sum()), d, device=dev, generator=g) * 0.3
+    kv = torch.randn(int(kv_len.sum()), d, device=dev, generator=g)
+    a = (q, q_start, q_len, kv, kv_start, kv_len, 70, 0.2)
+    ref = ops.shared_kv_attention(*a)
+    hi, lo = ops.shared_kv_attention(*a, split_out=True)
+    assert float((hi.double() + lo.double() - ref.double()).abs().max()) <= 2.0 ** -21 * float(ref.abs().max()) + 2.0 ** -24
+    if d in ops.ATTENTION_SPLIT_WIDTHS:
+        img = ops.split_half(kv)
+        b = (q, q_start, q_len, img, kv_start, kv_len, 70, 0.2)
+        for variant in ((0, 1) if d == 768 else (0,)):
+            ref2 = ops.shared_kv_attention_split(*b, variant=variant)
+            hi2, lo2 = ops.shared_kv_attention_split(*b, split_out=True, variant=variant)
+            assert float((hi2.double() + lo2.double() - ref2.double()).abs().max()) <= 2.0 ** -21 * float(ref2.abs().max()) + 2.0 ** -24
+            assert float((ref2 - ref).abs().max()) <= 2e-6 * float(ref.abs().max())

@@ -91,7 +91,9 @@ def test_train_step_fp16_autocast_with_grad_scaler(dev):
     # (a) the reference's loop
     model = build()
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
-    scaler = torch.amp.GradScaler("cuda", enabled=True)
+    # (a moderate initial scale: at the default 2^16 the stand-in encoders' fp16 backward overflows in the first iterations, which
+    # the scaler answers by skipping those steps -- part (c) below runs that protocol)
+    scaler = torch.amp.GradScaler("cuda", enabled=True, init_scale=2.0 ** 10)
     w0 = model.quantize.codebook.weight.detach().clone()
     opt.zero_grad()
     with torch.autocast("cuda", dtype=torch.float16):
@@ -121,3 +123,24 @@ def test_train_step_fp16_autocast_with_grad_scaler(dev):
         assert torch.isfinite(got).all()
         assert float((got - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-8, float((got - ref).abs().max()) / float(ref.abs().max())
     assert (grads_scaled[0].abs().sum(1) > 0).sum() <= 128 * 6 * 5                  # the codebook gradient stays sparse
+    # (c) the reference's default scaler (init 2^16, train_MedTok.py:99): overflowing iterations are skipped and halve the scale;
+    # within a few iterations steps are taken and the codebook moves
+    model3 = build()
+    opt3 = torch.optim.Adam([p for p in model3.parameters() if p.requires_grad], lr=1e-4)
+    scaler3 = torch.amp.GradScaler("cuda", enabled=True)
+    w3 = model3.quantize.codebook.weight.detach().clone()
+    taken = 0
+    for _ in range(10):
+        opt3.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            l3, _ = L.total_loss(model3(inputs), 0.1, 0.1)
+        assert torch.isfinite(l3)
+        scaler3.scale(l3).backward()
+        scaler3.unscale_(opt3)
+        torch.nn.utils.clip_grad_norm_(model3.parameters(), 1.0)
+        before = scaler3.get_scale()
+        scaler3.step(opt3)
+        scaler3.update()
+        taken += int(scaler3.get_scale() >= before)
+    assert taken >= 3 and not torch.equal(model3.quantize.codebook.weight.detach(), w3)
+    assert torch.isfinite(model3.quantize.codebook.weight).all()
