@@ -64,7 +64,8 @@ const char *medtok_last_error(void);
  * kind 0 = filter_f16_kernel, 1 = search_f32_kernel, 2 = the attention forward kernels, 3 = the attention backward
  * pair (dQ + dKV), 4 = split_gemm_kernel: total milliseconds, total algorithmic flops (2*n*K*D per search launch,
  * 2*m*n*k per dense product -- its fp32-equivalent work, computed as three fp16 passes; 0 for kinds 2 and 3, whose ragged
- * row/key counts live on the device -- the caller prices them) and the number of launches.  Thread-local. */
+ * row/key counts live on the device -- the caller prices them) and the number of launches.  Process-wide (autograd launches the
+ * backward kernels from its own thread); meant for one profiling client at a time. */
 #define MEDTOK_PROFILE_KINDS 5
 int medtok_profile_begin(void);
 int medtok_profile_end(double ms[MEDTOK_PROFILE_KINDS], double flops[MEDTOK_PROFILE_KINDS],

@@ -764,14 +764,15 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 }
 
 // ---------------------------------------------------------------- exact re-score
-// Block = 32 rows x 8 lanes.  Phase 1 (per row, 8 lanes): the row's true t~ = k-th smallest d~ over all
+// Block = RR rows x 8 lanes (RR = 32; 8 for searches of a few thousand rows, where 32-row blocks would leave most CUs without one
+// and each block would crawl through its ~220 chains alone: 4096 rows: 0.24 -> see DESIGN).  Phase 1 (per row, 8 lanes): the row's true t~ = k-th smallest d~ over all
 // owners' candidates.  Phase 2a: candidates with d~ <= t~ + 2 eps are compacted into an LDS list.
 // Phase 2b: the block's survivors (about 7 per row, so ~220 for 256 threads) are spread densely over the
 // threads and each is re-scored with the canonical fp32 chain; x and code rows stream from L1/L2 (the
 // survivors of a row run side by side, so its x row is fetched once).  Phase 3 (per row): exact
 // (d, index) top-k of the row's survivors.
-template <int TOPK>
-__global__ __launch_bounds__(256) void rescore_kernel(
+template <int TOPK, int RR = R_ROWS>
+__global__ __launch_bounds__(8 * RR) void rescore_kernel(
     const uint2 *__restrict__ cand, const int *__restrict__ cand_cnt, int own_total,
     const uint2 *__restrict__ cand_tail, const int *__restrict__ cnt_tail, int own_tail, long tail_start,
     const float *__restrict__ xhat, const float *__restrict__ xsq, const float *__restrict__ what,
@@ -779,13 +780,13 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     int64_t *__restrict__ out_idx, float *__restrict__ out_dist, int *__restrict__ fb_count, int *__restrict__ fb_rows,
     const float *__restrict__ xref, float *__restrict__ w_out, float *zq_out, long zq_stride)
 {
-    __shared__ int s_code[R_ROWS * R_SURV];
-    __shared__ float s_d[R_ROWS * R_SURV];
-    __shared__ int s_cnt[2 * R_ROWS + 1];                 // [R_ROWS] survivors, [R_ROWS] offsets, total
+    __shared__ int s_code[RR * R_SURV];
+    __shared__ float s_d[RR * R_SURV];
+    __shared__ int s_cnt[2 * RR + 1];                 // [RR] survivors, [RR] offsets, total
     const int g = threadIdx.x >> 3, l8 = threadIdx.x & 7;
-    const long pos = (long)blockIdx.x * R_ROWS + g;
+    const long pos = (long)blockIdx.x * RR + g;
     const long row = min(pos, n - 1);
-    if (threadIdx.x < R_ROWS) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < RR) s_cnt[threadIdx.x] = 0;
     const float xn = xsq[row];
     const float win = 2.0f * filter_eps(xn, en_max_ptr[0], d);
     // rows from tail_start on were filtered by the tail launch: its own lists, own_tail of them per row
@@ -831,23 +832,23 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     }
     __syncthreads();
     // rows with more survivors than the list holds also go to the exact path
-    if (threadIdx.x < R_ROWS && s_cnt[threadIdx.x] > R_SURV) s_cnt[threadIdx.x] = -1;
+    if (threadIdx.x < RR && s_cnt[threadIdx.x] > R_SURV) s_cnt[threadIdx.x] = -1;
     __syncthreads();
     if (threadIdx.x == 0) {
         int run = 0;
-        for (int r = 0; r < R_ROWS; ++r) { s_cnt[R_ROWS + r] = run; run += max(s_cnt[r], 0); }
-        s_cnt[2 * R_ROWS] = run;
+        for (int r = 0; r < RR; ++r) { s_cnt[RR + r] = run; run += max(s_cnt[r], 0); }
+        s_cnt[2 * RR] = run;
     }
     __syncthreads();
     // ---- phase 2b: dense exact chains
-    const int total = s_cnt[2 * R_ROWS];
-    for (int wi = threadIdx.x; wi < total; wi += 256) {
+    const int total = s_cnt[2 * RR];
+    for (int wi = threadIdx.x; wi < total; wi += 8 * RR) {
         int rr = 0;
 #pragma unroll
-        for (int r = 1; r < R_ROWS; ++r) rr += (wi >= s_cnt[R_ROWS + r]) ? 1 : 0;
-        const int j = wi - s_cnt[R_ROWS + rr];
+        for (int r = 1; r < RR; ++r) rr += (wi >= s_cnt[RR + r]) ? 1 : 0;
+        const int j = wi - s_cnt[RR + rr];
         const int code = s_code[rr * R_SURV + j];
-        const long arow = min((long)blockIdx.x * R_ROWS + rr, n - 1);
+        const long arow = min((long)blockIdx.x * RR + rr, n - 1);
         const float *xr = xhat + arow * d;
         const float *wr = what + (long)code * d;
         float accv = 0.f;

@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -55,25 +56,37 @@ extern "C" const char *medtok_last_error(void) { return g_err; }
 // ---------------------------------------------------------------- optional self-profiling (bench.py)
 // Between medtok_profile_begin() and medtok_profile_end() every launch of a search kernel is
 // bracketed by HIP events recorded on its own launch stream; nothing synchronises until _end().
-struct ProfRec { hipEvent_t a, b; double flops; int kind; };   // kind 0 = filter_f16_kernel, 1 = search_f32_kernel, 2 = attention forward (either kernel), 3 = attention backward (dQ + dKV), 4 = split_gemm_kernel
-static thread_local bool g_prof_on = false;
-static thread_local std::vector<ProfRec> g_prof;
+struct ProfRec { hipEvent_t a, b; double flops; int kind; };   // kind 0 = filter_f16_kernel, 1 = search_f32_kernel, 2 = attention forward (any kernel), 3 = attention backward (dQ + dKV), 4 = split_gemm_kernel
+// Process-wide (the backward kernels are launched from autograd's own thread): a flag read on every launch, the records and the
+// event pool behind one mutex that is only ever taken while profiling is on.
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof;
 
 // Events come from a pool that medtok_profile_begin() fills BEFORE the timed region: recording is all a launch pays.
-static thread_local std::vector<hipEvent_t> g_event_pool;
-constexpr size_t PROF_POOL = 2048;
+static std::vector<hipEvent_t> g_event_pool;
+constexpr size_t PROF_POOL = 4096;
 
 static hipEvent_t prof_mark(hipStream_t s)
 {
     hipEvent_t e = nullptr;
-    if (!g_event_pool.empty()) { e = g_event_pool.back(); g_event_pool.pop_back(); }
-    else if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_event_pool.empty()) { e = g_event_pool.back(); g_event_pool.pop_back(); }
+    }
+    if (!e && hipEventCreate(&e) != hipSuccess) return nullptr;
     (void)hipEventRecord(e, s);
     return e;
+}
+static void prof_push(hipEvent_t a, hipEvent_t b, double flops, int kind)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back({a, b, flops, kind});
 }
 
 extern "C" int medtok_profile_begin(void)
 {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &r : g_prof) { if (r.a) g_event_pool.push_back(r.a); if (r.b) g_event_pool.push_back(r.b); }
     g_prof.clear();
     while (g_event_pool.size() < PROF_POOL) {
@@ -88,6 +101,7 @@ extern "C" int medtok_profile_begin(void)
 extern "C" int medtok_profile_end(double *ms, double *flops, int *launches)
 {
     g_prof_on = false;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (int k = 0; k < MEDTOK_PROFILE_KINDS; ++k) { ms[k] = 0.0; flops[k] = 0.0; launches[k] = 0; }
     for (auto &r : g_prof) {
         float t = 0.f;
@@ -889,7 +903,7 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
         hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL, false>), dim3((unsigned)(p.row_tiles - p.main_tiles), (unsigned)p.tail_splits), block,
                            S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n, (int)k_codes, d, p.tail_codes_per_split, topk, pval, pidx,
                            (int64_t *)nullptr, (float *)nullptr, (const int *)nullptr, (const int *)nullptr, (int)tail_start, (int)tail_rows);
-        if (pa) g_prof.push_back({pa, prof_mark(s), pflops, 1});
+        if (pa) prof_push(pa, prof_mark(s), pflops, 1);
         if (check_launch("search_f32(main + tail)")) return 1;
         hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((tail_rows + 31) / 32)), dim3(256), 0, s, pval, pidx, tail_rows,
                            p.tail_splits, topk, idx + tail_start * topk, dist + tail_start * topk, (const int *)nullptr, (const int *)nullptr,
@@ -901,7 +915,7 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
         hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
                            (int)k_codes, d, p.codes_per_split, topk, (float *)nullptr, (int *)nullptr, idx, dist,
                            (const int *)nullptr, (const int *)nullptr, 0, 0);
-        if (pa) g_prof.push_back({pa, prof_mark(s), pflops, 1});
+        if (pa) prof_push(pa, prof_mark(s), pflops, 1);
         return check_launch("search_f32");
     }
     const size_t vbytes = align_up((size_t)p.splits * n * T * sizeof(float), 256);
@@ -913,7 +927,7 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
     hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
                        (int)k_codes, d, p.codes_per_split, topk, pval, pidx, (int64_t *)nullptr, (float *)nullptr,
                        (const int *)nullptr, (const int *)nullptr, 0, 0);
-    if (pa) g_prof.push_back({pa, prof_mark(s), pflops, 1});
+    if (pa) prof_push(pa, prof_mark(s), pflops, 1);
     if (check_launch("search_f32(split)")) return 1;
     if (p.splits >= 64 && n <= 8192)     // few rows, many lists each: a wave per row
         hipLaunchKernelGGL((merge_topk_kernel<T, 64>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, pval, pidx, (long)n,
@@ -966,13 +980,17 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
                            w.cand_tail - tail_start * f.own_tail * F_CAP, w.cnt_tail - tail_start * f.own_tail, (float *)nullptr, 0, f.tail_splits,
                            (int)f.main_tiles, (int)f.row_tiles);
     }
-    if (pa) g_prof.push_back({pa, prof_mark(s), 2.0 * (double)n * (double)k_codes * (double)d, 0});
+    if (pa) prof_push(pa, prof_mark(s), 2.0 * (double)n * (double)k_codes * (double)d, 0);
     if (check_launch("filter_f16")) return 1;
-    hipLaunchKernelGGL((rescore_kernel<T>), dim3((unsigned)((n + R_ROWS - 1) / R_ROWS)), dim3(256), 0, s, w.cand, w.cand_cnt, f.own_total,
-                       w.cand_tail, w.cnt_tail, f.own_tail, f.main_tiles < f.row_tiles ? tail_start : (long)n,
-                       xhat, xsq, what, wsq, w.en_max, (long)n, (int)k_codes, d, topk, idx, dist, w.fb_count, w.fb_rows,
-                       fuse ? fuse->xref : (const float *)nullptr, fuse ? fuse->w : (float *)nullptr,
-                       fuse ? fuse->zq : (float *)nullptr, fuse ? fuse->zq_stride : 0L);
+    // few rows: 8-row blocks (one wavefront) so that every CU gets several; many rows: 32-row blocks
+#define MEDTOK_RESCORE(RR)                                                                                                       \
+    hipLaunchKernelGGL((rescore_kernel<T, RR>), dim3((unsigned)((n + RR - 1) / RR)), dim3(8 * RR), 0, s, w.cand, w.cand_cnt, f.own_total,   \
+                       w.cand_tail, w.cnt_tail, f.own_tail, f.main_tiles < f.row_tiles ? tail_start : (long)n,                   \
+                       xhat, xsq, what, wsq, w.en_max, (long)n, (int)k_codes, d, topk, idx, dist, w.fb_count, w.fb_rows,         \
+                       fuse ? fuse->xref : (const float *)nullptr, fuse ? fuse->w : (float *)nullptr,                            \
+                       fuse ? fuse->zq : (float *)nullptr, fuse ? fuse->zq_stride : 0L)
+    if (n < 32L * 4 * dev_info().cus) MEDTOK_RESCORE(8); else MEDTOK_RESCORE(32);
+#undef MEDTOK_RESCORE
     if (check_launch("rescore")) return 1;
     // exact redo of the rows the filter gave up on (normally none: every block exits on *fb_count)
     const long code_tiles = (k_codes + S_BM - 1) / S_BM;
@@ -1411,7 +1429,7 @@ static int attention_forward(const float *q, const int64_t *q_start, const int64
     default: MEDTOK_ATT(8, 3); break;
     }
 #undef MEDTOK_ATT
-    if (pa) g_prof.push_back({pa, prof_mark(s), 0.0, 2});      // the row / key counts live on the device: the caller prices the launch
+    if (pa) prof_push(pa, prof_mark(s), 0.0, 2);      // the row / key counts live on the device: the caller prices the launch
     return check_launch("shared_kv_attention");
 }
 
@@ -1443,7 +1461,7 @@ static int attention_forward_f16s(const float *q, const int64_t *q_start, const 
     default: MEDTOK_ATT16(8, 3); break;
     }
 #undef MEDTOK_ATT16
-    if (pa) g_prof.push_back({pa, prof_mark(s), 0.0, 2});
+    if (pa) prof_push(pa, prof_mark(s), 0.0, 2);
     return check_launch("shared_kv_attention(f16 x 3)");
 }
 
@@ -1483,7 +1501,7 @@ extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_
         break;
     }
 #undef MEDTOK_ATT_DMA
-    if (pa) g_prof.push_back({pa, prof_mark(s), 0.0, 2});
+    if (pa) prof_push(pa, prof_mark(s), 0.0, 2);
     return check_launch("shared_kv_attention_split");
 }
 
@@ -1573,12 +1591,13 @@ extern "C" int medtok_split_gemm_f16(const void *a_hi, const void *a_lo, int64_t
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldch = ldch; p.n_g = n_g; p.k_g = k_g; p.groups = groups;
     p.a_group_cols = a_group_cols; p.b_group_rows = b_group_rows; p.unscale = unscale;
     p.row_tiles = (int)((m + G_BN - 1) / G_BN); p.ftiles = (n_g + G_BM - 1) / G_BM;
-    const long blocks = (long)((p.row_tiles + 7) / 8) * 8 * p.ftiles * groups;
-    if (blocks >= (1ll << 31)) return fail("split_gemm: grid too large");
+    const long ids = (long)((p.row_tiles + 7) / 8) * 8 * p.ftiles * groups;
+    if (ids >= (1ll << 31)) return fail("split_gemm: grid too large");
+    const long blocks = lmin(ids, (long)(dev_info().cus / 8) * 8);         // persistent: one block per CU (a multiple of 8: the XCD round-robin)
     if (!set_lds_once<split_gemm_kernel>(G_LDS_BYTES)) return fail("split_gemm: cannot reserve %zu bytes of LDS", G_LDS_BYTES);
     hipEvent_t pa = g_prof_on ? prof_mark((hipStream_t)stream) : nullptr;
     hipLaunchKernelGGL(split_gemm_kernel, dim3((unsigned)blocks), dim3(G_THREADS), G_LDS_BYTES, (hipStream_t)stream, p);
-    if (pa) g_prof.push_back({pa, prof_mark((hipStream_t)stream), 2.0 * (double)m * (double)n_g * (double)k_g * (double)groups, 4});     // fp32-equivalent flops (x3 on the fp16 pipe)
+    if (pa) prof_push(pa, prof_mark((hipStream_t)stream), 2.0 * (double)m * (double)n_g * (double)k_g * (double)groups, 4);     // fp32-equivalent flops (x3 on the fp16 pipe)
     return check_launch("split_gemm");
 }
 
@@ -1643,7 +1662,7 @@ extern "C" int medtok_shared_kv_attention_backward_f32(const float *q, const int
     default: MEDTOK_ATT_BWD(8, 3); break;
     }
 #undef MEDTOK_ATT_BWD
-    if (pa_bwd) g_prof.push_back({pa_bwd, prof_mark(s), 0.0, 3});     // dQ + dKV; the caller prices the pair (ragged counts live on the device)
+    if (pa_bwd) prof_push(pa_bwd, prof_mark(s), 0.0, 3);     // dQ + dKV; the caller prices the pair (ragged counts live on the device)
     return check_launch("shared_kv_attention_backward");
 }
 

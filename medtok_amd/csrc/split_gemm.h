@@ -57,17 +57,25 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave / G_WN, wn = wave % G_WN;
     const int li = lane & 31, lh = lane >> 5;
-    // block -> (row tile, group, feature tile): consecutive ids go round-robin to the 8 XCDs; the blocks that share one row tile
-    // (all feature tiles of all groups) are made consecutive WITHIN an XCD, so the activation tile is fetched into that L2 once
+    // PERSISTENT blocks: block b works through the tile ids b, b + gridDim.x, ... (gridDim.x a multiple of 8, so all of them run on
+    // XCD b % 8).  id -> (row tile, group, feature tile): the ids that share one row tile (all feature tiles of all groups) are
+    // consecutive WITHIN an XCD, so the activation tile is fetched into that L2 once.  The operand ring never drains between
+    // tiles: while one tile's accumulators are stored, the first stages of the block's next tile are already in flight -- a tile
+    // costs neither a pipeline fill nor an exposed epilogue (K = 192 per-head products: 18 stages per tile, where fill + epilogue
+    // were 40 % of a block's life).
     const int per_row = p.ftiles * p.groups;
-    const int bid = blockIdx.x, xcd = bid & 7, t = bid >> 3;
-    const long row_tile = (long)(t / per_row) * 8 + xcd;
-    if (row_tile >= p.row_tiles) return;
-    const int gf = t % per_row, grp = gf / p.ftiles, ft = gf % p.ftiles;
-    const long row0 = row_tile * G_BN;
-    const int f0 = ft * G_BM;                                  // first feature of this tile within the group
+    const int n_ids = (p.row_tiles + 7) / 8 * 8 * per_row;
+    const int stride = (int)gridDim.x;
     const int nkb = p.k_g / G_BK;
     const int nstage = 3 * nkb;
+    auto row_tile_of = [&](int id) { return (long)((id >> 3) / per_row) * 8 + (id & 7); };
+    auto next_tile = [&](int id) {                       // the block's next id with a real row tile (ids of the padded last 8 are skipped)
+        for (id += stride; id < n_ids && row_tile_of(id) >= p.row_tiles; id += stride) {}
+        return id;
+    };
+    int first = (int)blockIdx.x;
+    if (row_tile_of(first) >= p.row_tiles) first = next_tile(first);
+    if (first >= n_ids) return;
 
     // ---- staging (as filter_f16_kernel): wave w copies tile rows [32w, 32w+32) of both operands, 16 rows per instruction
     const int s_r = lane >> 2, s_c = lane & 3;
@@ -80,25 +88,32 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
         b_off[q] = (unsigned)(r * p.ldb + c * 8) * 2u;
     }
     // descriptors start at the tile's first row / the group's first column; num_records = what is left of the image from there
-    const long a_base = (row0 * p.lda + (long)grp * p.a_group_cols) * 2;
-    const long b_base = ((long)(grp * p.b_group_rows + f0) * p.ldb) * 2;
     auto rsrc = [](const _Float16 *img, long base, long bytes) {
         const long left = bytes - base;
         return __builtin_amdgcn_make_buffer_rsrc((void *)(reinterpret_cast<const char *>(img) + base), 0,
                                                  (int)(left < 0 ? 0 : (left > 0x7fffffffL ? 0x7fffffffL : left)), 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t ah_rs = rsrc(p.ah, a_base, p.a_bytes), al_rs = rsrc(p.al, a_base, p.a_bytes);
-    const __amdgpu_buffer_rsrc_t bh_rs = rsrc(p.bh, b_base, p.b_bytes), bl_rs = rsrc(p.bl, b_base, p.b_bytes);
+    __amdgpu_buffer_rsrc_t ah_rs, al_rs, bh_rs, bl_rs;
+    auto bind_tile = [&](int id) __attribute__((always_inline)) {
+        const int gf = (id >> 3) % per_row, grp = gf / p.ftiles, ft = gf % p.ftiles;
+        const long a_base = (row_tile_of(id) * G_BN * p.lda + (long)grp * p.a_group_cols) * 2;
+        const long b_base = ((long)(grp * p.b_group_rows + ft * G_BM) * p.ldb) * 2;
+        ah_rs = rsrc(p.ah, a_base, p.a_bytes); al_rs = rsrc(p.al, a_base, p.a_bytes);
+        bh_rs = rsrc(p.bh, b_base, p.b_bytes); bl_rs = rsrc(p.bl, b_base, p.b_bytes);
+    };
+    bind_tile(first);
     const int wave_lds = wave_s * 32 * G_ROWB;
-    int pkb = 0, pidx = 0, ppass = 0;                   // next stage to issue: k block, linear index, pass
-    // Issues stage `pidx` into ring slot pidx % 4 and advances; past the end it re-issues the LAST stage into the slot that
-    // already holds it (same bytes) so the steady-state loop has no branch around its DMA.
+    int iid = first, ikb = 0, ipass = 0, islot = 0;      // the stage to issue next: tile id, k block, pass; ring position
+    bool idone = false;
+    // Issues the next stage into ring slot islot % 4 and advances -- across tile boundaries.  Past the block's last stage it
+    // re-issues that stage into the slot that already holds it (same bytes) so the loop has no branch around its DMA and the
+    // counted vmcnt waits see the same number of instructions in every iteration.
     auto stage = [&]() __attribute__((always_inline)) {
-        char *base = gsm + (pidx & (G_RING - 1)) * G_STAGEB + wave_lds;
-        const int uk = __builtin_amdgcn_readfirstlane(pkb * G_BK * 2);
+        char *base = gsm + (islot & (G_RING - 1)) * G_STAGEB + wave_lds;
+        const int uk = __builtin_amdgcn_readfirstlane(ikb * G_BK * 2);
         // pass 0: (B_hi, A_hi), 1: (B_lo, A_hi), 2: (B_hi, A_lo) -- wave-uniform selects of SGPR descriptors
-        const __amdgpu_buffer_rsrc_t wrs = ppass == 1 ? bl_rs : bh_rs;
-        const __amdgpu_buffer_rsrc_t xrs = ppass == 2 ? al_rs : ah_rs;
+        const __amdgpu_buffer_rsrc_t wrs = ipass == 1 ? bl_rs : bh_rs;
+        const __amdgpu_buffer_rsrc_t xrs = ipass == 2 ? al_rs : ah_rs;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(base + q * 16 * G_ROWB), 16,
@@ -106,21 +121,16 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(base + G_TILEB + q * 16 * G_ROWB), 16,
                                                      (int)a_off[q], uk, 0, 0);
         }
-        const bool more = pidx + 1 < nstage;
-        const bool wrap = pkb + 1 == nkb;
-        pidx += more ? 1 : 0;
-        pkb = more ? (wrap ? 0 : pkb + 1) : pkb;
-        ppass += (more && wrap) ? 1 : 0;
+        if (idone) return;
+        if (ikb + 1 < nkb) { ++ikb; ++islot; return; }
+        if (ipass < 2) { ikb = 0; ++ipass; ++islot; return; }
+        const int nid = next_tile(iid);                  // this was the tile's last stage
+        if (nid >= n_ids) { idone = true; return; }      // (cursor and slot stay on the block's last stage)
+        iid = nid; ikb = 0; ipass = 0; ++islot;
+        bind_tile(iid);
     };
 
     f32x16 acc[G_MT][G_NT];
-#pragma unroll
-    for (int m = 0; m < G_MT; ++m)
-#pragma unroll
-        for (int nn = 0; nn < G_NT; ++nn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
-
     int a_adr[2], b_adr[2];                 // fragment addresses within a stage (a = weights / MFMA A operand, b = activations)
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
     };
 
     constexpr int LGKM0 = 0xC07F;           // s_waitcnt lgkmcnt(0) only
-    stage(); stage(); stage();              // stages 0..2 (clamped when the block has fewer)
+    stage(); stage(); stage();              // the first three stages (re-issues when the block has fewer)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -157,56 +167,68 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
     for (int m = 0; m < G_MT; ++m) read_a(m, 0, 0);
     const bool late = wave_s >= 4;          // the two waves of a SIMD issue their DMA at different points of the stage (filter_f16.h)
     if (late) __builtin_amdgcn_s_setprio(3);
-    for (int s = 0; s < nstage; ++s) {
-        if (late && s > 0) stage();         // waves 4-7: stage s+2 (slot s-2, free since the barrier of iteration s-1)
-        step(fbA, fbB, s & (G_RING - 1), 1);
-        __builtin_amdgcn_sched_group_barrier(0x100, G_NT, 0);
-#pragma unroll
-        for (int i = 0; i < G_MT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, G_NT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-        __builtin_amdgcn_s_waitcnt(LGKM0);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (!late) stage();                 // waves 0-3: stage s+3 (slot s-1: everyone is past reading it)
-        step(fbB, fbA, (s + 1) & (G_RING - 1), 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, G_NT, 0);
-#pragma unroll
-        for (int i = 0; i < G_MT; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, G_NT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail re-issues may still be in flight
-
-    // ---- epilogue: lane (li, lh) holds, for row wn*64 + nn*32 + li, the features wm*128 + m*32 + 8 g + 4 lh + {0..3}, g = 0..3
-    const int cbase = grp * p.n_g;
-#pragma unroll
-    for (int nn = 0; nn < G_NT; ++nn) {
-        const long row = row0 + wn * (32 * G_NT) + nn * 32 + li;
-        if (row >= p.M) continue;
+    int gs = 0;                             // stages computed so far = ring position of the stage in the registers
+    for (int cid = first; cid < n_ids; cid = next_tile(cid)) {
 #pragma unroll
         for (int m = 0; m < G_MT; ++m)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f = f0 + wm * (32 * G_MT) + m * 32 + 8 * g + 4 * lh;
-                if (f >= p.n_g) continue;
-                float4 v = make_float4(acc[m][nn][4 * g] * p.unscale, acc[m][nn][4 * g + 1] * p.unscale, acc[m][nn][4 * g + 2] * p.unscale,
-                                       acc[m][nn][4 * g + 3] * p.unscale);
-                if (p.bias) {
-                    const float4 b4 = ld4(p.bias + cbase + f);
-                    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-                }
-                if (p.c) st4(p.c + row * p.ldc + cbase + f, v);
-                if (p.ch) {
-                    half4v hi, lo;
-                    hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-                    lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
-                    lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
-                    *reinterpret_cast<half4v *>(p.ch + row * p.ldch + cbase + f) = hi;
-                    *reinterpret_cast<half4v *>(p.cl + row * p.ldch + cbase + f) = lo;
-                }
+            for (int nn = 0; nn < G_NT; ++nn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+        for (int s = 0; s < nstage; ++s, ++gs) {
+            if (late && gs > 0) stage();        // waves 4-7: stage gs+2 (slot gs-2, free since the barrier of iteration gs-1)
+            step(fbA, fbB, gs & (G_RING - 1), 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, G_NT, 0);
+#pragma unroll
+            for (int i = 0; i < G_MT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, G_NT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_s_waitcnt(LGKM0);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (!late) stage();                 // waves 0-3: stage gs+3 (slot gs-1: everyone is past reading it)
+            step(fbB, fbA, (gs + 1) & (G_RING - 1), 0);     // (past a tile's last stage these are the NEXT tile's first operands)
+            __builtin_amdgcn_sched_group_barrier(0x100, G_NT, 0);
+#pragma unroll
+            for (int i = 0; i < G_MT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, G_NT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
+        }
+
+        // ---- epilogue of tile cid (the next tile's first stages are in flight meanwhile; stores only make the counted vmcnt waits
+        // more conservative): lane (li, lh) holds, for row wn*64 + nn*32 + li, the features wm*128 + m*32 + 8 g + 4 lh + {0..3}
+        const int gf = (cid >> 3) % per_row, grp = gf / p.ftiles, f0 = (gf % p.ftiles) * G_BM;
+        const long row0 = row_tile_of(cid) * G_BN;
+        const int cbase = grp * p.n_g;
+#pragma unroll
+        for (int nn = 0; nn < G_NT; ++nn) {
+            const long row = row0 + wn * (32 * G_NT) + nn * 32 + li;
+            if (row >= p.M) continue;
+#pragma unroll
+            for (int m = 0; m < G_MT; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f = f0 + wm * (32 * G_MT) + m * 32 + 8 * g + 4 * lh;
+                    if (f >= p.n_g) continue;
+                    float4 v = make_float4(acc[m][nn][4 * g] * p.unscale, acc[m][nn][4 * g + 1] * p.unscale, acc[m][nn][4 * g + 2] * p.unscale,
+                                           acc[m][nn][4 * g + 3] * p.unscale);
+                    if (p.bias) {
+                        const float4 b4 = ld4(p.bias + cbase + f);
+                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                    }
+                    if (p.c) st4(p.c + row * p.ldc + cbase + f, v);
+                    if (p.ch) {
+                        half4v hi, lo;
+                        hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+                        lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+                        lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+                        *reinterpret_cast<half4v *>(p.ch + row * p.ldch + cbase + f) = hi;
+                        *reinterpret_cast<half4v *>(p.cl + row * p.ldch + cbase + f) = lo;
+                    }
+                }
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the re-issues of the last stage may still be in flight
 }
 
 // fp32 rows [n, d] -> (hi, lo) fp16 images [n, dp] (dp >= d, multiple of 8; columns past d are zero), scaled by `scale` first
