@@ -421,3 +421,37 @@ def test_attention_split_output_images_equal_the_fp32_output(dev, d):
             hi2, lo2 = ops.shared_kv_attention_split(*b, split_out=True, variant=variant)
             assert float((hi2.double() + lo2.double() - ref2.double()).abs().max()) <= 2.0 ** -21 * float(ref2.abs().max()) + 2.0 ** -24
             assert float((ref2 - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+def test_attention_dropout_mask_rate_and_independence(dev):
+    """nn.MultiheadAttention's dropout on the attention probabilities is a stateless hash mask of (seed, query row, key) here, not
+    torch's RNG stream: same distribution, not the same bits.  With zero queries (uniform probabilities) and one-hot
+    keys the output IS the mask (out[r, j] = keep[r, j] / (T (1 - p))), so its statistics can be checked directly: keep rate
+    1 - p within 4 sigma, rows / keys / seeds mutually independent (agreement of two masks = (1-p)^2 + p^2, lag-1 correlations ~ 0),
+    and no mask at p = 0."""
+    from medtok_amd import ops
+    T, R, D, p = 128, 4096, 128, 0.1
+    q = torch.zeros(R, D, device=dev)
+    kv = torch.eye(T, D, device=dev)
+    z = torch.zeros(1, dtype=torch.int64, device=dev)
+    a = (q, z, z + R, kv, z, z + T, R, 1.0)
+
+    def mask(seed, prob=p):
+        out, _ = ops.shared_kv_attention_train(*a, prob, seed)
+        m = out * (T * (1.0 - prob))
+        assert bool(((m - m.round()).abs() < 1e-4).all()) and bool(((m.round() == 0) | (m.round() == 1)).all())
+        return m.round()
+    m1, m2 = mask(11), mask(12)
+    n = R * T
+    sigma = (p * (1 - p) / n) ** 0.5
+    for m in (m1, m2):
+        assert abs(float(m.mean()) - (1 - p)) <= 4 * sigma
+        assert float(m.mean(1).min()) > 0.7 and float(m.mean(0).min()) > 0.85          # no dead row, no dead key
+    agree = float((m1 == m2).float().mean())
+    assert abs(agree - ((1 - p) ** 2 + p ** 2)) <= 6 * (0.18 * 0.82 / n) ** 0.5       # two seeds: independent masks
+    c = m1 - m1.mean()
+    var = float((c * c).mean())
+    assert abs(float((c[:, 1:] * c[:, :-1]).mean()) / var) < 0.01                      # neighbouring keys
+    assert abs(float((c[1:] * c[:-1]).mean()) / var) < 0.01                            # neighbouring rows
+    assert torch.equal(mask(11), m1)                                                   # stateless: same seed, same mask
+    assert bool((mask(5, 0.0) == 1).all())

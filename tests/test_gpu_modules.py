@@ -65,11 +65,11 @@ def test_specific_embedding_eval_and_train(golden, dev, name):
         assert abs(float(cm) - float(g[f"{t}.train.commit"])) <= RTOL * float(g[f"{t}.train.commit"])
         (vq + cm + (zq * probe).sum() / N).backward()
         proj = v.proj_text if t == "text" else v.proj_graph
-        assert rel(xg.grad, g[f"{t}.train.grad_x"]) <= 1e-4
-        assert rel(v.codebook.weight.grad, g[f"{t}.train.grad_codebook"]) <= 1e-4
-        assert rel(proj.bias.grad, g[f"{t}.train.grad_proj_b"]) <= 1e-4
-        assert rel(proj.weight.grad[:8], g[f"{t}.train.grad_proj_w_head"]) <= 1e-4
-        assert rel(proj.weight.grad.double().sum(0), g[f"{t}.train.grad_proj_w_colsum"]) <= 1e-4
+        assert rel(xg.grad, g[f"{t}.train.grad_x"]) <= RTOL
+        assert rel(v.codebook.weight.grad, g[f"{t}.train.grad_codebook"]) <= RTOL
+        assert rel(proj.bias.grad, g[f"{t}.train.grad_proj_b"]) <= RTOL
+        assert rel(proj.weight.grad[:8], g[f"{t}.train.grad_proj_w_head"]) <= RTOL
+        assert rel(proj.weight.grad.double().sum(0), g[f"{t}.train.grad_proj_w_colsum"]) <= RTOL
         # train-mode forward without autograd takes the fused kernel path: same numbers
         with torch.no_grad():
             zq_f, (vq_f, cm_f, _, _), _ = v.specific_embedding(x, types=t)
@@ -129,12 +129,12 @@ def test_full_forward_dict(golden, dev, name):
     total = total + ((r["shared_text_embedding"] + r["shared_graph_embedding"] + r["specific_embedding_text"]
                       + r["specific_embedding_graph"] + r["specific_embedding_text_aug"]) * probe).sum() / z.shape[0]
     total.backward()
-    assert rel(zr.grad, g["train.grad_z"]) <= 1e-4
-    assert rel(tr.grad, g["train.grad_text"]) <= 1e-4
-    assert rel(nr.grad, g["train.grad_nodes"]) <= 1e-4
-    assert rel(v.codebook.weight.grad, g["train.grad_codebook"]) <= 1e-4
-    assert rel(v.cross_attn.model[0].multihead_attn.in_proj_weight.grad, g["train.grad_in_proj0"]) <= 1e-4
-    assert rel(v.proj_text.weight.grad, g["train.grad_proj_text_w"]) <= 1e-4
+    assert rel(zr.grad, g["train.grad_z"]) <= RTOL
+    assert rel(tr.grad, g["train.grad_text"]) <= RTOL
+    assert rel(nr.grad, g["train.grad_nodes"]) <= RTOL
+    assert rel(v.codebook.weight.grad, g["train.grad_codebook"]) <= RTOL
+    assert rel(v.cross_attn.model[0].multihead_attn.in_proj_weight.grad, g["train.grad_in_proj0"]) <= RTOL
+    assert rel(v.proj_text.weight.grad, g["train.grad_proj_text_w"]) <= RTOL
 
 
 @pytest.mark.parametrize("name", ["f5_normema_d32", "f5_normema_d768", "f6_normema_zero_usage"])
@@ -157,7 +157,7 @@ def test_norm_ema_quantizer(golden, dev, name):
         assert rel(q.embedding.weight, g[f"s{s}.E"]) <= RTOL
         assert rel(q.cluster_size, g[f"s{s}.cluster_size"]) <= RTOL
         (loss + zq.square().sum() * 0.5).backward()
-        assert rel(zr.grad, g[f"s{s}.grad_z"]) <= 1e-4
+        assert rel(zr.grad, g[f"s{s}.grad_z"]) <= RTOL
     # the EmbeddingEMA side state is never touched by forward
     assert float(q.embedding.cluster_size.abs().sum()) == 0.0
     q.eval()

@@ -151,12 +151,12 @@ def test_soft_backward_matches_reference_gradients(oracle, golden, name):
         what, _ = oracle.rownorm(Wr)
         gx, gc = oracle.soft_vq_backward(xp, xhat, what, g[f"{t}.idx"], g[f"{t}.w"], g_out=probe / N, g_vq=1.0, g_commit=1.0,
                                          vq_scale=2.0 / (N * D), commit_scale=2.0 * beta / (N * D))
-        assert rel(gx.astype(np.float64).sum(0), g[f"{t}.train.grad_proj_b"]) <= 1e-4
-        assert rel(gx.astype(np.float64) @ Wp.astype(np.float64), g[f"{t}.train.grad_x"]) <= 1e-4
+        assert rel(gx.astype(np.float64).sum(0), g[f"{t}.train.grad_proj_b"]) <= RTOL
+        assert rel(gx.astype(np.float64) @ Wp.astype(np.float64), g[f"{t}.train.grad_x"]) <= RTOL
         _, g_what = oracle.ema_stats(gc, g[f"{t}.idx"].reshape(-1), region)
         gW = oracle.normalize_backward(g_what, what, Wr)
         ref = g[f"{t}.train.grad_codebook"]
-        assert rel(gW, ref[lo:lo + region]) <= 1e-4
+        assert rel(gW, ref[lo:lo + region]) <= RTOL          # (measured 2e-7 .. 7e-7 on F1 / F2)
         outside = np.ones(n_e, bool); outside[lo:lo + region] = False
         assert not ref[outside].any()            # codes outside the searched region get no gradient
 
