@@ -49,6 +49,35 @@ from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
 
+# Inference forward: the work that does not depend on the graph side of the cross-attention -- the two (four with an aug view)
+# modality-specific searches and the text side's attention chain, about an eighth of a forward, all launches of a few hundred
+# blocks -- is enqueued on a second HIP stream and runs in the shadow of the graph side's chip-filling kernels; the streams join
+# before the shared searches.  From this many codes per call (below it a forward is launch-bound and a second stream only adds
+# host work); 0 turns it off.
+SIDE_STREAM_MIN_CODES = 512
+_side_streams = {}
+
+
+def _side_stream(device, which=0):
+    """(side, current): a per-device extra stream (`which`: 0 = the cross-attention's text side, 1 = the modality-specific searches)
+    that has just been made to wait for everything enqueued on the current one"""
+    cur = torch.cuda.current_stream(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(device=device)
+    side.wait_stream(cur)
+    return side, cur
+
+
+def _join_side(side, cur, tensors):
+    """the current stream waits for the side stream; tensors born on the side stream are marked as used on the current one, so that
+    the caching allocator does not hand their memory to later side-stream work while current-stream readers are still pending"""
+    cur.wait_stream(side)
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(cur)
+
 
 class _RaggedAttentionFunction(torch.autograd.Function):
     """The ragged attention core under autograd: forward = medtok_shared_kv_attention_train_f32 (dropout on the probabilities by
@@ -291,7 +320,7 @@ class CrossAttention(nn.Module):
             return ops.residual_layernorm(rows, mha.out_proj(attended), ln.weight, ln.bias, ln.eps)
         return ln(rows + layer.dropout(mha.out_proj(attended)))
 
-    def _pooled_packed(self, text, valid_len, nodes_sorted, batch_sorted, slot, counts, starts, max_nodes, core, autograd=False):
+    def _pooled_packed(self, text, valid_len, nodes_sorted, batch_sorted, slot, counts, starts, max_nodes, core, autograd=False, join=True):
         """`pooled` with no padding of rows anywhere: packed query rows, ragged attention core.
         `core(q, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale)` is ops.shared_kv_attention at inference (or, from
         pooled_reference, the oracle's restatement); with `autograd` every call goes through _RaggedAttentionFunction instead
@@ -337,10 +366,27 @@ class CrossAttention(nn.Module):
         def text_attend(qf, **kw):
             return attend(qf, t_start, t_len, kv_nodes, starts, counts, heads, max_nodes, **kw)
         text_attend.library_core = lib_core
-        for layer in self.model:
-            cur = self._folded_rows(layer, cur, text_attend)
+        side = None
+        text_split = images_ready = None
+        want_images = (not autograd and core is ops.shared_kv_attention and text.is_cuda and kv_text.shape[1] in ops.ATTENTION_SPLIT_WIDTHS
+                       and SPLIT_ATTENTION and nodes_sorted.shape[0] * heads >= SPLIT_MIN_ROWS and max_nodes > 0)
+        if lib_core and max_nodes > 0 and 0 < SIDE_STREAM_MIN_CODES <= bsz and not torch.is_grad_enabled():
+            # the text side (one query row per code and head) is independent of the graph side until the shared searches: second
+            # stream.  The fp16 images of the text rows -- an HBM-bound pass the graph side needs only at its first attention, two
+            # dense products in -- go first on that stream, beside those products.
+            side, main = _side_stream(text.device)
+            with torch.cuda.stream(side):
+                if want_images:
+                    text_split = ops.split_half(kv_text, seg_len=valid_len, seg_rows=seq_len)
+                    images_ready = torch.cuda.Event()
+                    images_ready.record(side)
+                for layer in self.model:
+                    cur = self._folded_rows(layer, cur, text_attend)
+        else:
+            for layer in self.model:
+                cur = self._folded_rows(layer, cur, text_attend)
         if max_nodes == 0:                                 # nothing to attend from: the node mean of every code is zero
-            return cur, cur.new_zeros(bsz, dim)
+            return (cur, cur.new_zeros(bsz, dim)) if join else (cur, cur.new_zeros(bsz, dim), None)
         # graph side: every node queries the valid text tokens of its code
         g_start, g_len, tok_start = starts * heads, counts * heads, code * seq_len
         g_kv_len = valid_len
@@ -352,21 +398,33 @@ class CrossAttention(nn.Module):
         g = nodes_sorted
         # inference on the library's own core: the text rows become (hi, lo) fp16 images ONCE per forward (valid tokens only) -- every
         # query tile of a code and both layers read them
-        text_split = None
-        if (not autograd and core is ops.shared_kv_attention and text.is_cuda and kv_text.shape[1] in ops.ATTENTION_SPLIT_WIDTHS
-                and SPLIT_ATTENTION and g.shape[0] * heads >= SPLIT_MIN_ROWS):
+        if want_images and text_split is None:
             text_split = ops.split_half(kv_text, seg_len=valid_len, seg_rows=seq_len)
 
         def graph_attend(qf, **kw):
+            nonlocal images_ready
+            if images_ready is not None:                   # first use of the images made on the other stream
+                torch.cuda.current_stream(text.device).wait_event(images_ready)
+                for t in text_split:
+                    t.record_stream(torch.cuda.current_stream(text.device))
+                images_ready = None
             return attend(qf, g_start, g_len, kv_text, tok_start, g_kv_len, max_nodes * heads, seq_len, kv_split=text_split, **kw)
         graph_attend.library_core = lib_core
         for layer in self.model:
             g = self._folded_rows(layer, g, graph_attend)
+        pending = None
+        if side is not None:
+            if join:
+                _join_side(side, main, (cur,))
+            else:
+                pending = (side, main)                     # the caller keeps using the side stream (get_shared_info: the shared-text search)
         if not autograd and not torch.is_grad_enabled() and g.is_cuda and g.dtype == torch.float32 and dim % 4 == 0:
-            return cur, ops.segment_mean(g, starts, counts)        # rows of a code are adjacent: one ordered chain per column
+            gm = ops.segment_mean(g, starts, counts)               # rows of a code are adjacent: one ordered chain per column
+            return (cur, gm) if join else (cur, gm, pending)
         padded = g.new_zeros(bsz, max_nodes, dim)
         padded[batch_sorted, slot] = g                     # deterministic mean (no atomics): pad, sum, divide
-        return cur, padded.sum(1) / counts.clamp(min=1).unsqueeze(-1).to(g.dtype)
+        gm = padded.sum(1) / counts.clamp(min=1).unsqueeze(-1).to(g.dtype)
+        return (cur, gm) if join else (cur, gm, pending)
 
     @staticmethod
     def _pack(text, text_mask, nodes, batch):
@@ -404,7 +462,7 @@ class CrossAttention(nn.Module):
         batch_in_order = batch if order is None else batch[order]
         return text, valid, nodes_in_order, batch_in_order, slot, counts, starts, max_nodes
 
-    def pooled(self, text, text_mask, nodes, batch):
+    def pooled(self, text, text_mask, nodes, batch, join=True):
         """Batched equivalent of the reference's per-code loop (:133-142) -- the PRODUCT path: gfx950 kernels only.
 
         text [B, L, D] with a left-aligned mask [B, L]; nodes [sum n_i, D] with a PyG-style `batch` vector, all on an MI355X.
@@ -415,7 +473,9 @@ class CrossAttention(nn.Module):
         the kernels do not take natively (not 64 / a multiple of 128) get zero columns appended; D > 768 raises
         MedTokLibraryError -- there is no eager-PyTorch fallback (pooled_reference below is the test-side comparator).
         One host sync per call.  A code with no nodes, or no valid token, attends to nothing: its context is zero (the
-        reference's per-code loop would take a softmax over an empty row there)."""
+        reference's per-code loop would take a softmax over an empty row there).
+        join=False (get_shared_info): returns a third value, (side stream, main stream) or None -- when the text side ran on the
+        second stream, it is NOT joined yet: the pooled text rows may only be used on that stream until _join_side()."""
         if not (text.is_cuda and nodes.is_cuda):
             raise ops.MedTokLibraryError(f"CrossAttention.pooled: expected tensors on an MI355X (cuda/HIP) device, got {text.device} / "
                                          f"{nodes.device}; medtok_amd has no CPU path")
@@ -424,7 +484,7 @@ class CrossAttention(nn.Module):
         needs_grad = torch.is_grad_enabled() and (text.requires_grad or nodes.requires_grad
                                                   or any(p.requires_grad for p in self.parameters()))
         return self._pooled_packed(text.contiguous(), valid.sum(1), nodes_in_order.contiguous(), batch_in_order, slot, counts, starts,
-                                   max_nodes, ops.shared_kv_attention, autograd=self.training or needs_grad)
+                                   max_nodes, ops.shared_kv_attention, autograd=self.training or needs_grad, join=join)
 
     def pooled_reference(self, text, text_mask, nodes, batch, fold=None, core=None):
         """TEST-SIDE COMPARATOR, never called by the product path: the same function as pooled() in plain torch ops on any device
@@ -615,9 +675,19 @@ class VectorQuantizer(nn.Module):
 
     # ------------------------------------------------------------------ reference API
     def get_shared_info(self, z_text, z_graph, text_mask, batch):
-        pooled_text, pooled_graph = self.cross_attn.pooled(z_text, text_mask, z_graph, batch)
-        zq_t, vq_t, cm_t, xhat_t, idx_t, w_t = self._search(pooled_text, "shared", self.training)
-        zq_g, vq_g, cm_g, xhat_g, idx_g, w_g = self._search(pooled_graph, "shared", self.training)
+        pooled_text, pooled_graph, pending = self.cross_attn.pooled(z_text, text_mask, z_graph, batch, join=False)
+        if pending is not None:
+            # the text side ran on the second stream: its shared search follows it there, beside the graph side's tail and search
+            side, main = pending
+            with torch.cuda.stream(side):
+                r_t = self._search(pooled_text, "shared", self.training)
+            r_g = self._search(pooled_graph, "shared", self.training)
+            _join_side(side, main, (pooled_text, *r_t))
+            zq_t, vq_t, cm_t, xhat_t, idx_t, w_t = r_t
+            zq_g, vq_g, cm_g, xhat_g, idx_g, w_g = r_g
+        else:
+            zq_t, vq_t, cm_t, xhat_t, idx_t, w_t = self._search(pooled_text, "shared", self.training)
+            zq_g, vq_g, cm_g, xhat_g, idx_g, w_g = self._search(pooled_graph, "shared", self.training)
         usage = self.codebook_usage(torch.cat([idx_t, idx_g], dim=-1), types="shared")
         self._last_tokens = {"shared_text_tokens": idx_t, "shared_text_tokens_weights": w_t,
                              "shared_graph_tokens": idx_g, "shared_graph_tokens_weights": w_g}
@@ -652,23 +722,44 @@ class VectorQuantizer(nn.Module):
             self._norm_cache = None     # training: re-normalise once per forward (the 4-6 searches of one forward share it)
         self._in_forward = True
         try:
+            z_text_embedding, z_graph_embedding = torch.split(z, self.split, dim=-1)
+            aug = (None, None) if z_aug is None else torch.split(z_aug, self.split, dim=-1)
+            early = None
+            if (not self.training and not torch.is_grad_enabled() and z.is_cuda and not torch.is_autocast_enabled()
+                    and 0 < SIDE_STREAM_MIN_CODES <= z.shape[0]):
+                # inference: the modality-specific searches depend on nothing the cross-attention produces: second stream, joined
+                # below; their usage-window updates stay in the reference's order (shared, text, graph, aug text, aug graph: :241-250)
+                side, main = _side_stream(z.device, 1)
+                with torch.cuda.stream(side):
+                    early = [self._search(proj(x), types, False) for proj, x, types in
+                             ((self.proj_text, z_text_embedding, "text"), (self.proj_graph, z_graph_embedding, "graph"),
+                              (self.proj_text, aug[0], "text"), (self.proj_graph, aug[1], "graph")) if x is not None]
             shared_embedding, shared_embed_loss, u_shared = self.get_shared_info(
                 text_features, graph_node_features, text_attention_mask, batch)
             tokens = dict(self._last_tokens)
             shared_text_embedding, shared_graph_embedding = torch.split(shared_embedding, self.split, dim=-1)
-            z_text_embedding, z_graph_embedding = torch.split(z, self.split, dim=-1)
-            spec_text, text_specific_loss, u_text = self.specific_embedding(z_text_embedding, types="text")
-            tokens["text_tokens"], tokens["text_tokens_weights"] = self._last_specific
-            spec_graph, graph_specific_loss, u_graph = self.specific_embedding(z_graph_embedding, types="graph")
-            tokens["graph_tokens"], tokens["graph_tokens_weights"] = self._last_specific
-            if z_aug is not None:
-                # the reference discards these two usage values but its window still slides (:249-250)
-                z_aug_text, z_aug_graph = torch.split(z_aug, self.split, dim=-1)
-                spec_text_aug, _, _ = self.specific_embedding(z_aug_text, types="text")
-                spec_graph_aug, _, _ = self.specific_embedding(z_aug_graph, types="graph")
+            if early is not None:
+                _join_side(side, main, [t for r in early for t in r])
+                results = []
+                for (zq, vq, commit, xhat, idx, w), types in zip(early, ("text", "graph", "text", "graph")):
+                    usage = self.codebook_usage(idx, types=types + "-specific")
+                    results.append((zq, (vq, commit, xhat, zq), usage, idx, w))
+                spec_text, text_specific_loss, u_text, tokens["text_tokens"], tokens["text_tokens_weights"] = results[0]
+                spec_graph, graph_specific_loss, u_graph, tokens["graph_tokens"], tokens["graph_tokens_weights"] = results[1]
+                spec_text_aug = results[2][0] if z_aug is not None else None
+                spec_graph_aug = results[3][0] if z_aug is not None else None
             else:
-                spec_text_aug = None
-                spec_graph_aug = None
+                spec_text, text_specific_loss, u_text = self.specific_embedding(z_text_embedding, types="text")
+                tokens["text_tokens"], tokens["text_tokens_weights"] = self._last_specific
+                spec_graph, graph_specific_loss, u_graph = self.specific_embedding(z_graph_embedding, types="graph")
+                tokens["graph_tokens"], tokens["graph_tokens_weights"] = self._last_specific
+                if z_aug is not None:
+                    # the reference discards these two usage values but its window still slides (:249-250)
+                    spec_text_aug, _, _ = self.specific_embedding(aug[0], types="text")
+                    spec_graph_aug, _, _ = self.specific_embedding(aug[1], types="graph")
+                else:
+                    spec_text_aug = None
+                    spec_graph_aug = None
             deferred = self._defer_usage[:3]
         finally:
             self._defer_usage = None

@@ -571,3 +571,38 @@ def test_soft_quantizer_with_ema_codebook_holder(golden, dev):
     for key in ("shared_text_embedding", "specific_embedding_text", "specific_embedding_graph_aug", "text_tokens", "shared_graph_tokens_weights"):
         assert torch.equal(a[key], b[key]), key
     assert same_ids(a["shared_text_tokens"], g["shared_text.idx"])
+
+
+def test_side_stream_forward_equals_single_stream(dev):
+    """Inference forwards of >= 512 codes enqueue the modality-specific searches and the text side of the cross-attention on a second
+    HIP stream (they do not depend on the graph side) and join before the shared searches.  Every output and the usage window
+    (whose updates must stay in the reference's order) must equal the single-stream forward bit for bit -- run several times:
+    a missing wait or an allocator hand-over between the streams shows up as a difference."""
+    import medtok_amd.vector_quantization_soft_one_new as M
+    torch.manual_seed(5)
+    D, B = 128, 700
+    v = M.VectorQuantizer(3 * 1024, D, 0.25, 0.0, True, True, [D, D]).to(dev).eval()
+    text, mask, nodes, batch = (t.to(dev) for t in synth.ragged_batch("side", B, 40, 9, D, 3))
+    z = synth.det_randn("side.z", (B, 2 * D), 1.0, 3).to(dev)
+    z_aug = synth.det_randn("side.za", (B, 2 * D), 1.0, 3).to(dev)
+
+    def run(min_codes):
+        keep, M.SIDE_STREAM_MIN_CODES = M.SIDE_STREAM_MIN_CODES, min_codes
+        try:
+            v.codebook_used.zero_()
+            with torch.no_grad():
+                r = v(z, text, nodes, mask, batch, z_aug)
+            torch.cuda.synchronize()
+            return {k: (t.clone() if isinstance(t, torch.Tensor) else t) for k, t in r.items()}, v.codebook_used.clone()
+        finally:
+            M.SIDE_STREAM_MIN_CODES = keep
+    ref, used_ref = run(0)
+    for _ in range(4):
+        got, used = run(512)
+        torch.empty(64 << 20, device=dev).fill_(float("nan"))          # churn the allocator between the runs
+        assert torch.equal(used, used_ref)
+        for k, t in ref.items():
+            if isinstance(t, torch.Tensor):
+                assert torch.equal(got[k], t), k
+            elif isinstance(t, float):
+                assert got[k] == t, k
