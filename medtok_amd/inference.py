@@ -32,8 +32,8 @@ def quantize_pooled(vq: VectorQuantizer, h: torch.Tensor, pooled_text: torch.Ten
         e = vq.e_dim
         # the four searches write straight into their column block of the result (the reference's torch.cat, :246)
         embedding = torch.empty((h.shape[0], 4 * e), dtype=torch.float32, device=h.device)
-        _, _, _, _, idx_t, w_t = vq._search(vq.proj_text(h_text), "text", False, out=embedding[:, 0:e])
-        _, _, _, _, idx_g, w_g = vq._search(vq.proj_graph(h_graph), "graph", False, out=embedding[:, e:2 * e])
+        _, _, _, _, idx_t, w_t = vq._search(vq.project(h_text, "text"), "text", False, out=embedding[:, 0:e])
+        _, _, _, _, idx_g, w_g = vq._search(vq.project(h_graph, "graph"), "graph", False, out=embedding[:, e:2 * e])
         _, _, _, _, idx_st, w_st = vq._search(pooled_text, "shared", False, out=embedding[:, 2 * e:3 * e])
         _, _, _, _, idx_sg, w_sg = vq._search(pooled_graph, "shared", False, out=embedding[:, 3 * e:4 * e])
     finally:

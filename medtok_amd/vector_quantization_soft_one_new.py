@@ -620,6 +620,8 @@ class VectorQuantizer(nn.Module):
         for layer in self.cross_attn.model:           # the folded-weight products of the cross-attention layers
             layer._medtok_fold_cache = None
             layer._medtok_split_cache = None
+        self.proj_text._medtok_split_cache = None
+        self.proj_graph._medtok_split_cache = None
 
     def train(self, mode: bool = True):
         if mode != self.training:
@@ -644,6 +646,28 @@ class VectorQuantizer(nn.Module):
             what, wsq = ops.rownorm(wt.detach())
             self._norm_cache = (key, what, wsq)
         return self._norm_cache[1], self._norm_cache[2]
+
+    def project(self, x, types):
+        """proj_text / proj_graph (reference :190,192: nn.Linear(split[i], e_dim)).  Inference on wide batches: the library's own
+        split-fp16 product (medtok_split_gemm_f16: fp32-accurate, ~2.5x the library fp32 GEMM; weights split once per weight
+        version) -- anything else (training, autograd, autocast, small batches, CPU): the nn.Linear as it stands."""
+        lin = self.proj_text if types == "text" else self.proj_graph
+        if (not SPLIT_PRODUCTS or self.training or torch.is_grad_enabled() or torch.is_autocast_enabled() or not x.is_cuda
+                or x.dtype != torch.float32 or x.dim() != 2 or x.shape[0] < SPLIT_MIN_ROWS or lin.bias is None
+                or lin.in_features % 32 or lin.out_features % 4 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16):
+            return lin(x)
+        key = (lin.weight.data_ptr(), lin.weight._version, lin.bias.data_ptr(), lin.bias._version, lin.weight.device)
+        cache = getattr(lin, "_medtok_split_cache", None)
+        if cache is None or cache[0] != key:
+            import math
+            w = lin.weight.detach().float().contiguous()
+            amax = float(w.abs().max())
+            scale = 2.0 ** (11 - math.floor(math.log2(amax))) if amax > 0.0 and math.isfinite(amax) else 1.0
+            cache = (key, ops.split_half(w, dp=w.shape[1], scale=scale), 1.0 / scale, lin.bias.detach().float().contiguous())
+            lin._medtok_split_cache = cache
+        _, w_split, unscale, bias = cache
+        out, _ = ops.split_gemm(ops.split_half(x), w_split, n_g=lin.out_features, k_g=lin.in_features, bias=bias, unscale=unscale)
+        return out
 
     def get_distance(self, x, y):
         """Dense distance matrix (reference :120-125); for inspection only -- the
@@ -695,10 +719,8 @@ class VectorQuantizer(nn.Module):
                 (vq_t + vq_g, cm_t + cm_g, xhat_t, xhat_g, zq_t, zq_g), usage)
 
     def specific_embedding(self, original_embedding, types="text"):
-        if types == "text":
-            original_embedding = self.proj_text(original_embedding)
-        if types == "graph":
-            original_embedding = self.proj_graph(original_embedding)
+        if types in ("text", "graph"):
+            original_embedding = self.project(original_embedding, types)
         zq, vq, commit, xhat, idx, w = self._search(original_embedding, types, self.training)
         usage = self.codebook_usage(idx, types=types + "-specific")
         self._last_specific = (idx, w)
@@ -731,9 +753,8 @@ class VectorQuantizer(nn.Module):
                 # below; their usage-window updates stay in the reference's order (shared, text, graph, aug text, aug graph: :241-250)
                 side, main = _side_stream(z.device, 1)
                 with torch.cuda.stream(side):
-                    early = [self._search(proj(x), types, False) for proj, x, types in
-                             ((self.proj_text, z_text_embedding, "text"), (self.proj_graph, z_graph_embedding, "graph"),
-                              (self.proj_text, aug[0], "text"), (self.proj_graph, aug[1], "graph")) if x is not None]
+                    early = [self._search(self.project(x, types), types, False) for x, types in
+                             ((z_text_embedding, "text"), (z_graph_embedding, "graph"), (aug[0], "text"), (aug[1], "graph")) if x is not None]
             shared_embedding, shared_embed_loss, u_shared = self.get_shared_info(
                 text_features, graph_node_features, text_attention_mask, batch)
             tokens = dict(self._last_tokens)

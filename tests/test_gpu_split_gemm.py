@@ -71,3 +71,33 @@ def test_split_half_is_exact_to_22_bits_and_pads_with_zeros(dev):
     wide = torch.randn(64, 300, device=dev, generator=g)
     h2, l2 = ops.split_half(wide[:, 100:164])
     assert float((h2.double() + l2.double() - wide[:, 100:164].double()).abs().max()) <= 2.0 ** -20
+
+
+def test_projection_of_the_specific_searches_matches_nn_linear(dev):
+    """VectorQuantizer.project: proj_text / proj_graph (reference :190,192) on the split-fp16 product at inference from 1024 rows up
+    (a column block of a wider [N, 2D] tensor, as forward() hands it over), nn.Linear otherwise; the cached weight images follow
+    weight versions."""
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    torch.manual_seed(1)
+    D = 768
+    v = VectorQuantizer(3 * 512, D, 0.25, 0.0, True, False, [D, D]).to(dev).eval()
+    z = torch.randn(5000, 2 * D, device=dev)
+    zt, zg = torch.split(z, [D, D], dim=-1)
+    with torch.no_grad():
+        for x, types, lin in ((zt, "text", v.proj_text), (zg, "graph", v.proj_graph)):
+            got = v.project(x, types)
+            ref = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double())
+            lib = lin(x)
+            scale = float(ref.abs().max())
+            assert float((got.double() - ref).abs().max()) <= 3e-6 * scale
+            assert float((got.double() - ref).abs().max()) <= max(4 * float((lib.double() - ref).abs().max()), 1e-6 * scale)
+            assert getattr(lin, "_medtok_split_cache", None) is not None
+        small = v.project(zt[:100], "text")                      # below the row threshold: the nn.Linear itself
+        assert torch.equal(small, v.proj_text(zt[:100]))
+        v.proj_text.weight.mul_(2.0)                             # version bump: the images are rebuilt
+        got2 = v.project(zt, "text")
+        ref2 = torch.nn.functional.linear(zt.double(), v.proj_text.weight.double(), v.proj_text.bias.double())
+        assert float((got2.double() - ref2).abs().max()) <= 3e-6 * float(ref2.abs().max())
+    x = zt.clone().requires_grad_(True)                           # under autograd: the nn.Linear (its backward is torch's)
+    v.project(x, "text").sum().backward()
+    assert x.grad is not None
