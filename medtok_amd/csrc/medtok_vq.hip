@@ -1590,13 +1590,19 @@ extern "C" int medtok_split_gemm_f16(const void *a_hi, const void *a_lo, int64_t
     p.M = (long)m; p.a_bytes = (long)m * lda * 2; p.b_bytes = (long)b_rows * ldb * 2;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldch = ldch; p.n_g = n_g; p.k_g = k_g; p.groups = groups;
     p.a_group_cols = a_group_cols; p.b_group_rows = b_group_rows; p.unscale = unscale;
-    p.row_tiles = (int)((m + G_BN - 1) / G_BN); p.ftiles = (n_g + G_BM - 1) / G_BM;
+    // tile height: 256 features, or 192 where that pads the group's features by > 10 % less (n_g = 192: the per-head W_v product)
+    const long pad4 = (long)((n_g + 255) / 256) * 256, pad3 = (long)((n_g + 191) / 192) * 192;
+    const bool mt3 = pad3 * 10 < pad4 * 9;
+    const int bm = mt3 ? 192 : 256;
+    p.row_tiles = (int)((m + G_BN - 1) / G_BN); p.ftiles = (n_g + bm - 1) / bm;
     const long ids = (long)((p.row_tiles + 7) / 8) * 8 * p.ftiles * groups;
     if (ids >= (1ll << 31)) return fail("split_gemm: grid too large");
     const long blocks = lmin(ids, (long)(dev_info().cus / 8) * 8);         // persistent: one block per CU (a multiple of 8: the XCD round-robin)
-    if (!set_lds_once<split_gemm_kernel>(G_LDS_BYTES)) return fail("split_gemm: cannot reserve %zu bytes of LDS", G_LDS_BYTES);
+    const size_t lds = mt3 ? GemmShape<3>::LDS_BYTES : GemmShape<4>::LDS_BYTES;
+    if (!(mt3 ? set_lds_once<split_gemm_kernel<3>>(lds) : set_lds_once<split_gemm_kernel<4>>(lds))) return fail("split_gemm: cannot reserve %zu bytes of LDS", lds);
     hipEvent_t pa = g_prof_on ? prof_mark((hipStream_t)stream) : nullptr;
-    hipLaunchKernelGGL(split_gemm_kernel, dim3((unsigned)blocks), dim3(G_THREADS), G_LDS_BYTES, (hipStream_t)stream, p);
+    if (mt3) hipLaunchKernelGGL(split_gemm_kernel<3>, dim3((unsigned)blocks), dim3(G_THREADS), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(split_gemm_kernel<4>, dim3((unsigned)blocks), dim3(G_THREADS), lds, (hipStream_t)stream, p);
     if (pa) prof_push(pa, prof_mark((hipStream_t)stream), 2.0 * (double)m * (double)n_g * (double)k_g * (double)groups, 4);     // fp32-equivalent flops (x3 on the fp16 pipe)
     return check_launch("split_gemm");
 }

@@ -3,8 +3,9 @@
 //
 // Where it is used.  The cross-attention layers of get_shared_info (vector_quantization_soft_one_new.py:17-88,133-142) are, around
 // their attention core, four dense D x D products per packed query row and layer (in_proj of the queries, the fold of W_k into
-// them, W_v on the attended rows, out_proj).  On the fp32 matrix pipe (157 TFLOP/s) they were 39 % of a forward at BASELINE
-// sizes; v_mfma_f32_32x32x16_f16 runs 16x faster, and three of them reproduce an fp32 product to ~2^-22 relative:
+// them, W_v on the attended rows, out_proj); proj_text / proj_graph of the specific searches (:190,192) are two more.  On the fp32
+// matrix pipe (157 TFLOP/s) they were 39 % of a forward at BASELINE sizes; v_mfma_f32_32x32x16_f16 runs 16x faster, and three of
+// them reproduce an fp32 product to ~2^-22 relative:
 //     a b  ~  a_hi b_hi + a_hi b_lo + a_lo b_hi          (a_lo b_lo ~ 2^-22 |a b| is dropped)
 // with a_hi = fp16(a), a_lo = fp16(a - a_hi): products of two fp16 are exact in the fp32 accumulator, so the only errors are the
 // dropped term, the 2^-22-relative (or 2^-25 absolute: fp16 subnormal step) residual of the split, and the fp32 accumulation
@@ -13,26 +14,42 @@
 // weights use the fp16 normal range; undone in the epilogue); activations are taken as they are: |x| must stay below 65504,
 // beyond that the hi part is inf and the outputs are NaN -- loud, not silently wrong.
 //
-// Kernel.  The operand pipeline is the fp16 filter's (filter_f16.h): block = 8 waves, tile 256 output features x 256 rows, wave
-// tile 128 x 64 = 4 x 2 MFMA tiles; operands by buffer-addressed LDS-DMA into a 4-stage ring of 32-deep k blocks, XOR-swizzled
-// through the SOURCE address, counted vmcnt + raw s_barrier.  The k loop runs three passes over K -- (B_hi, A_hi), (B_lo, A_hi),
-// (B_hi, A_lo) -- i.e. it is one fp16 GEMM over 3 K whose stage picks its two source images by pass (four buffer descriptors,
-// exact sizes: rows past M and features past the last group read as zeros).  Weights are the MFMA A operand, so a lane ends up
-// with runs of four consecutive output features of ONE row: the epilogue adds the bias and stores fp32 (float4) and/or the
-// (hi, lo) fp16 images of the result (8 bytes each) that the next product reads -- no separate conversion pass between the
-// products of a layer.
+// Kernel.  Block = 8 waves (2 x 4), tile = 64 MT output features x 256 rows (MT = 4, or 3 where that wastes less: the per-head
+// W_v product has 192 features per head), wave tile 32 MT x 64 = MT x 2 MFMA tiles; operands by buffer-addressed LDS-DMA,
+// XOR-swizzled through the SOURCE address (filter_f16.h), raw s_barrier.  A stage is one 32-deep k block of all FOUR images
+// (W_hi | W_lo | X_hi | X_lo, 64 KB at MT = 4; two stages), and the wave forms the three products from it:
+//     per 16-deep k step:   W_hi . X_hi   |   W_hi . X_lo   |   W_lo . X_hi        (2 MT MFMAs each)
+// with the weight fragments rolling through one register set (W_hi stays for two groups, W_lo replaces it fragment by fragment
+// behind its last use, the next step's W_hi replaces that) and the activation fragments in three (X_hi of this step, X_lo, X_hi
+// of the next).  Round 3's first form ran the three products as three passes over K -- an fp16 GEMM over 3 K that copied six
+// 16 KB tiles and read 36 fragments per 48 MFMAs; as in the fp16 filter the copies through the CU's L1 path then take
+// as long as the MFMAs they feed.  The six tiles are four different ones: this form copies 64 KB and reads 24 fragments per 48
+// MFMAs -- two thirds of the L1 and LDS traffic -- with ONE block-wide barrier per 48 MFMAs instead of three.  The barrier sits in
+// front of a stage's last group, whose operands are in registers by then: behind it the other slot is known to hold the next
+// stage (every wave waited for its own copies) and this stage's slot is free for the stage after next.  Alone on a CU the main
+// loop keeps the matrix pipe 87 % busy (35.4 us per 256 x 256 x 768 tile); with all 256 CUs at the sagged clock 58 us.
+// Weights are the MFMA A operand, so a lane ends up with runs of four consecutive output features of ONE row; the epilogue
+// transposes every 32 x 32 tile through the wave's own 4 KB of LDS and stores whole rows: fp32 and/or the (hi, lo) fp16 images of
+// the result that the next product reads -- no separate conversion pass between the products of a layer.
 // Grouped form: G independent problems (the heads) that differ by a column offset into A, a row offset into B and a column
 // offset into C -- the per-head fold and the per-head W_v product are one launch each.
 #pragma once
+#include <type_traits>
 
-constexpr int G_BM = 256, G_BN = 256, G_BK = 32;              // output features x rows x k (fp16 elements) per stage
+constexpr int G_BN = 256, G_BK = 32;                          // rows x k (fp16 elements) per stage; features per tile: 64 MT
 constexpr int G_THREADS = 512;
 constexpr int G_ROWB = G_BK * 2;                              // bytes per staged tile row (64)
-constexpr int G_TILEB = G_BM * G_ROWB;                        // 16 KB per operand tile
-constexpr int G_STAGEB = 2 * G_TILEB;                         // weights + activations = 32 KB
-constexpr int G_RING = 4;
-constexpr size_t G_LDS_BYTES = (size_t)G_RING * G_STAGEB;     // 128 KB -> 1 block (8 waves) / CU
-constexpr int G_WN = 4, G_MT = 4, G_NT = 2;                   // row-side waves; 32-feature / 32-row MFMA tiles per wave
+constexpr int G_XTILEB = G_BN * G_ROWB;                       // 16 KB per activation tile
+constexpr int G_WN = 4, G_NT = 2;                             // row-side waves; 32-row MFMA tiles per wave
+typedef float g_f4 __attribute__((ext_vector_type(4)));
+
+template <int MT>
+struct GemmShape {
+    static constexpr int BM = 64 * MT;                        // 2 feature-side waves x MT x 32
+    static constexpr int WTILEB = BM * G_ROWB;
+    static constexpr int STG = 2 * WTILEB + 2 * G_XTILEB;     // W_hi | W_lo | X_hi | X_lo
+    static constexpr size_t LDS_BYTES = (size_t)2 * STG + 8 * 4096;      // two stages + 4 KB of epilogue staging per wave (MT = 4: all 160 KB)
+};
 
 struct SplitGemmArgs {
     const _Float16 *ah, *al;        // activations [M, lda]: hi and lo images
@@ -47,11 +64,27 @@ struct SplitGemmArgs {
     int a_group_cols;               // group g reads A columns [g * a_group_cols, + k_g)
     int b_group_rows;               // ... B rows [g * b_group_rows, + n_g) and writes C columns [g * n_g, + n_g)
     float unscale;                  // applied to the accumulators (undoes the weights' power-of-two prescale)
-    int row_tiles, ftiles;          // M / 256 rounded up; feature tiles per group
+    int row_tiles, ftiles;          // M / 256 rounded up; feature tiles (of 64 MT) per group
 };
 
+template <int MT, int FRONT, bool PER_M, int VMEM>
+__device__ __forceinline__ void gemm_weave()            // scheduling hints for one group of MT x G_NT MFMAs
+{
+    if constexpr (FRONT > 0) __builtin_amdgcn_sched_group_barrier(0x100, FRONT, 0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, G_NT, 0);
+        if constexpr (PER_M) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if constexpr (VMEM > 0) __builtin_amdgcn_sched_group_barrier(0x020, VMEM, 0);
+    }
+}
+
+template <int MT>
 __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGemmArgs p)
 {
+    using S = GemmShape<MT>;
+    constexpr int BM = S::BM, WTILEB = S::WTILEB, STG = S::STG;
+    constexpr int XOFF = 2 * WTILEB;                     // activation images within a stage
     extern __shared__ __attribute__((aligned(16))) char gsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
@@ -60,14 +93,12 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
     // PERSISTENT blocks: block b works through the tile ids b, b + gridDim.x, ... (gridDim.x a multiple of 8, so all of them run on
     // XCD b % 8).  id -> (row tile, group, feature tile): the ids that share one row tile (all feature tiles of all groups) are
     // consecutive WITHIN an XCD, so the activation tile is fetched into that L2 once.  The operand ring never drains between
-    // tiles: while one tile's accumulators are stored, the first stages of the block's next tile are already in flight -- a tile
-    // costs neither a pipeline fill nor an exposed epilogue (K = 192 per-head products: 18 stages per tile, where fill + epilogue
-    // were 40 % of a block's life).
+    // tiles: while one tile's accumulators are stored, the first stage of the block's next tile is already in LDS and the second
+    // in flight.
     const int per_row = p.ftiles * p.groups;
     const int n_ids = (p.row_tiles + 7) / 8 * 8 * per_row;
     const int stride = (int)gridDim.x;
     const int nkb = p.k_g / G_BK;
-    const int nstage = 3 * nkb;
     auto row_tile_of = [&](int id) { return (long)((id >> 3) / per_row) * 8 + (id & 7); };
     auto next_tile = [&](int id) {                       // the block's next id with a real row tile (ids of the padded last 8 are skipped)
         for (id += stride; id < n_ids && row_tile_of(id) >= p.row_tiles; id += stride) {}
@@ -77,16 +108,18 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
     if (row_tile_of(first) >= p.row_tiles) first = next_tile(first);
     if (first >= n_ids) return;
 
-    // ---- staging (as filter_f16_kernel): wave w copies tile rows [32w, 32w+32) of both operands, 16 rows per instruction
+    // ---- staging: one LDS-DMA instruction copies 16 tile rows x 64 B; wave w copies row blocks w and w + 8 of every tile (the
+    // weight tile of MT = 3 has 12: its second block exists for waves 0-3 only)
     const int s_r = lane >> 2, s_c = lane & 3;
     unsigned a_off[2], b_off[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int r = wave * 32 + q * 16 + s_r;
+        const int r = (wave + 8 * q) * 16 + s_r;
         const int c = s_c ^ ((r >> 2) & 3);
         a_off[q] = (unsigned)(r * p.lda + c * 8) * 2u;
         b_off[q] = (unsigned)(r * p.ldb + c * 8) * 2u;
     }
+    const bool w_second = wave_s + 8 < BM / 16;
     // descriptors start at the tile's first row / the group's first column; num_records = what is left of the image from there
     auto rsrc = [](const _Float16 *img, long base, long bytes) {
         const long left = bytes - base;
@@ -97,138 +130,216 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
     auto bind_tile = [&](int id) __attribute__((always_inline)) {
         const int gf = (id >> 3) % per_row, grp = gf / p.ftiles, ft = gf % p.ftiles;
         const long a_base = (row_tile_of(id) * G_BN * p.lda + (long)grp * p.a_group_cols) * 2;
-        const long b_base = ((long)(grp * p.b_group_rows + ft * G_BM) * p.ldb) * 2;
+        const long b_base = ((long)(grp * p.b_group_rows + ft * BM) * p.ldb) * 2;
         ah_rs = rsrc(p.ah, a_base, p.a_bytes); al_rs = rsrc(p.al, a_base, p.a_bytes);
         bh_rs = rsrc(p.bh, b_base, p.b_bytes); bl_rs = rsrc(p.bl, b_base, p.b_bytes);
     };
     bind_tile(first);
-    const int wave_lds = wave_s * 32 * G_ROWB;
-    int iid = first, ikb = 0, ipass = 0, islot = 0;      // the stage to issue next: tile id, k block, pass; ring position
-    bool idone = false;
-    // Issues the next stage into ring slot islot % 4 and advances -- across tile boundaries.  Past the block's last stage it
-    // re-issues that stage into the slot that already holds it (same bytes) so the loop has no branch around its DMA and the
-    // counted vmcnt waits see the same number of instructions in every iteration.
+    const int wave_lds = wave_s * 16 * G_ROWB;
+    int iid = first, ikb = 0, islot = 0;                 // the stage to issue next: tile id, k block; slot parity
+    bool more = true;                                    // false once the block's last stage has been issued
     auto stage = [&]() __attribute__((always_inline)) {
-        char *base = gsm + (islot & (G_RING - 1)) * G_STAGEB + wave_lds;
+        char *base = gsm + (islot & 1) * STG + wave_lds;
         const int uk = __builtin_amdgcn_readfirstlane(ikb * G_BK * 2);
-        // pass 0: (B_hi, A_hi), 1: (B_lo, A_hi), 2: (B_hi, A_lo) -- wave-uniform selects of SGPR descriptors
-        const __amdgpu_buffer_rsrc_t wrs = ipass == 1 ? bl_rs : bh_rs;
-        const __amdgpu_buffer_rsrc_t xrs = ipass == 2 ? al_rs : ah_rs;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(base + q * 16 * G_ROWB), 16,
-                                                     (int)b_off[q], uk, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(base + G_TILEB + q * 16 * G_ROWB), 16,
-                                                     (int)a_off[q], uk, 0, 0);
+            char *dst = base + q * 8 * 16 * G_ROWB;
+            if (q == 0 || w_second) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(bh_rs, (__attribute__((address_space(3))) void *)dst, 16, (int)b_off[q], uk, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(bl_rs, (__attribute__((address_space(3))) void *)(dst + WTILEB), 16, (int)b_off[q], uk, 0, 0);
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ah_rs, (__attribute__((address_space(3))) void *)(dst + XOFF), 16, (int)a_off[q], uk, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(al_rs, (__attribute__((address_space(3))) void *)(dst + XOFF + G_XTILEB), 16, (int)a_off[q], uk, 0, 0);
         }
-        if (idone) return;
-        if (ikb + 1 < nkb) { ++ikb; ++islot; return; }
-        if (ipass < 2) { ikb = 0; ++ipass; ++islot; return; }
+        ++islot;
+        if (ikb + 1 < nkb) { ++ikb; return; }
         const int nid = next_tile(iid);                  // this was the tile's last stage
-        if (nid >= n_ids) { idone = true; return; }      // (cursor and slot stay on the block's last stage)
-        iid = nid; ikb = 0; ipass = 0; ++islot;
+        if (nid >= n_ids) { more = false; return; }
+        iid = nid; ikb = 0;
         bind_tile(iid);
     };
 
-    f32x16 acc[G_MT][G_NT];
-    int a_adr[2], b_adr[2];                 // fragment addresses within a stage (a = weights / MFMA A operand, b = activations)
+    const unsigned stg_a = (unsigned)(size_t)(gsm + 2 * STG) + (unsigned)(wave * 4096);      // this wave's 4 KB of epilogue staging
+    // what the epilogue needs of the arguments, in registers from here on: a kernel argument re-read inside the epilogue is a scalar
+    // load, and its s_waitcnt lgkmcnt(0) would also wait for the LDS read-backs in flight
+    float e_unscale = p.unscale;
+    long e_M = p.M;
+    int e_ldc = p.ldc, e_ldch = p.ldch, e_ng = p.n_g;
+    unsigned long e_c = (unsigned long)p.c, e_ch = (unsigned long)p.ch, e_cl = (unsigned long)p.cl, e_bias = (unsigned long)p.bias;   // (as integers:
+    // a pointer that went through an asm operand would come back as a generic one, i.e. flat_store)
+    asm volatile("" : "+v"(e_unscale), "+s"(e_M), "+s"(e_ldc), "+s"(e_ldch), "+s"(e_ng), "+s"(e_c), "+s"(e_ch), "+s"(e_cl), "+s"(e_bias));
+    typedef __attribute__((address_space(1))) g_f4 gl_f4;
+    typedef __attribute__((address_space(1))) half4v gl_h4;
+    f32x16 acc[MT][G_NT];
+    int w_adr[2], x_adr[2];                 // fragment addresses of the hi images within a stage, per k step (lo: + the tile size)
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-        const int ia = wm * (32 * G_MT) + li, ib = wn * (32 * G_NT) + li;
-        a_adr[tt] = ia * G_ROWB + (((2 * tt + lh) ^ ((ia >> 2) & 3)) << 4);
-        b_adr[tt] = G_TILEB + ib * G_ROWB + (((2 * tt + lh) ^ ((ib >> 2) & 3)) << 4);
+        const int ia = wm * (32 * MT) + li, ib = wn * (32 * G_NT) + li;
+        w_adr[tt] = ia * G_ROWB + (((2 * tt + lh) ^ ((ia >> 2) & 3)) << 4);
+        x_adr[tt] = XOFF + ib * G_ROWB + (((2 * tt + lh) ^ ((ib >> 2) & 3)) << 4);
     }
-    half8 fa[G_MT], fbA[G_NT], fbB[G_NT];
-    auto read_a = [&](int m, int slot, int tt) __attribute__((always_inline)) {
-        fa[m] = *reinterpret_cast<const half8 *>(gsm + slot * G_STAGEB + a_adr[tt] + m * 32 * G_ROWB);
+    half8 fw[MT], xa[G_NT], xb[G_NT], xl[G_NT];
+    auto read_w = [&](int m, int slot, int tt, int lo) __attribute__((always_inline)) {
+        fw[m] = *reinterpret_cast<const half8 *>(gsm + slot * STG + lo * WTILEB + w_adr[tt] + m * 32 * G_ROWB);
     };
-    auto read_b = [&](half8 (&fb)[G_NT], int slot, int tt) __attribute__((always_inline)) {
+    auto read_x = [&](half8 (&fx)[G_NT], int slot, int tt, int lo) __attribute__((always_inline)) {
 #pragma unroll
-        for (int nn = 0; nn < G_NT; ++nn) fb[nn] = *reinterpret_cast<const half8 *>(gsm + slot * G_STAGEB + b_adr[tt] + nn * 32 * G_ROWB);
+        for (int nn = 0; nn < G_NT; ++nn) fx[nn] = *reinterpret_cast<const half8 *>(gsm + slot * STG + lo * G_XTILEB + x_adr[tt] + nn * 32 * G_ROWB);
     };
-    auto step = [&](const half8 (&fb_cur)[G_NT], half8 (&fb_nxt)[G_NT], int slot, int tt) __attribute__((always_inline)) {
-        read_b(fb_nxt, slot, tt);
+    // one group of MT x G_NT MFMAs: fw x fx; behind the MFMAs of a weight fragment that fragment is reloaded (w_next: 0 = keep)
+    auto group = [&](const half8 (&fx)[G_NT], int w_next, int slot, int tt, int lo) __attribute__((always_inline)) {
 #pragma unroll
-        for (int m = 0; m < G_MT; ++m) {
+        for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int nn = 0; nn < G_NT; ++nn)
-                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[m], fb_cur[nn], acc[m][nn], 0, 0, 0);
-            read_a(m, slot, tt);
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[m], fx[nn], acc[m][nn], 0, 0, 0);
+            if (w_next) read_w(m, slot, tt, lo);
         }
     };
 
     constexpr int LGKM0 = 0xC07F;           // s_waitcnt lgkmcnt(0) only
-    stage(); stage(); stage();              // the first three stages (re-issues when the block has fewer)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    stage();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    read_b(fbA, 0, 0);
+    if (more) stage();
+    read_x(xa, 0, 0, 0);
 #pragma unroll
-    for (int m = 0; m < G_MT; ++m) read_a(m, 0, 0);
-    const bool late = wave_s >= 4;          // the two waves of a SIMD issue their DMA at different points of the stage (filter_f16.h)
+    for (int m = 0; m < MT; ++m) read_w(m, 0, 0, 0);
+    // the two waves of a SIMD issue their copies at different points of the stage (filter_f16.h): waves 0-3 right behind the barrier,
+    // waves 4-7 two groups later
+    const bool late = wave_s >= 4;
     if (late) __builtin_amdgcn_s_setprio(3);
-    int gs = 0;                             // stages computed so far = ring position of the stage in the registers
+    int gs = 0;                             // stages computed so far: its parity is the slot of the stage in the registers
+    bool owe = false;                       // a late wave's copy of the stage after next is due
     for (int cid = first; cid < n_ids; cid = next_tile(cid)) {
+        const int gf = (cid >> 3) % per_row, grp = gf / p.ftiles, f0 = (gf % p.ftiles) * BM;
+        const int cbase = grp * p.n_g;
+        const int ec = lane & 7, er = lane >> 3;         // epilogue, after the transposition: 4-feature chunk and row % 8 of the lane
 #pragma unroll
-        for (int m = 0; m < G_MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int nn = 0; nn < G_NT; ++nn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
-        for (int s = 0; s < nstage; ++s, ++gs) {
-            if (late && gs > 0) stage();        // waves 4-7: stage gs+2 (slot gs-2, free since the barrier of iteration gs-1)
-            step(fbA, fbB, gs & (G_RING - 1), 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, G_NT, 0);
+        g_f4 bzs[MT];
+        // One stage.  The tile's LAST stage is a second copy of the code: it also fetches the lane's bias quads -- at its top, waited
+        // for behind its barrier, where vmcnt is 0 anyway.  Loads and stores share the counter and return out of order with each
+        // other, so a load waited for inside the epilogue costs s_waitcnt vmcnt(0): the copies in flight, and between the stores
+        // every store before it.  (Quads past the group's features: the last one is read instead -- no select on a loaded value,
+        // which would be a wait; their stores are masked.)
+        auto body = [&](auto last_tag) __attribute__((always_inline)) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            const int sl = gs & 1, nx = sl ^ 1;
+            if constexpr (LAST) {
+                if (e_bias) {
 #pragma unroll
-            for (int i = 0; i < G_MT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, G_NT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                    for (int m = 0; m < MT; ++m) {
+                        const int f = f0 + wm * (32 * MT) + m * 32 + 4 * ec;
+                        bzs[m] = *(const gl_f4 *)(e_bias + (unsigned long)(cbase + (f < e_ng ? f : e_ng - 4)) * 4);
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) bzs[m] = (g_f4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            // k step 0
+            read_x(xl, sl, 0, 1);
+            group(xa, 0, 0, 0, 0);                  gemm_weave<MT, G_NT, false, 0>();
+            group(xl, 1, sl, 0, 1);                 gemm_weave<MT, 0, true, 0>();                   // fw <- W_lo(step 0)
+            if (owe) { stage(); owe = false; }
+            read_x(xb, sl, 1, 0);
+            group(xa, 1, sl, 1, 0);                 gemm_weave<MT, G_NT, true, 2>();                // fw <- W_hi(step 1)
+            // k step 1
+            read_x(xl, sl, 1, 1);
+            group(xb, 0, 0, 0, 0);                  gemm_weave<MT, G_NT, false, 0>();
+            group(xl, 1, sl, 1, 1);                 gemm_weave<MT, 0, true, 0>();                   // fw <- W_lo(step 1)
             __builtin_amdgcn_s_waitcnt(LGKM0);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (!late) stage();                 // waves 0-3: stage gs+3 (slot gs-1: everyone is past reading it)
-            step(fbB, fbA, (gs + 1) & (G_RING - 1), 0);     // (past a tile's last stage these are the NEXT tile's first operands)
-            __builtin_amdgcn_sched_group_barrier(0x100, G_NT, 0);
+            if constexpr (LAST) {
 #pragma unroll
-            for (int i = 0; i < G_MT; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, G_NT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(bzs[m]));                       // (the bias quads have arrived)
+            }
+            if (more) { if (late) owe = true; else stage(); }
+            read_x(xa, nx, 0, 0);
+            group(xb, 1, nx, 0, 0);                 gemm_weave<MT, G_NT, true, 2>();                // fw <- W_hi(next stage, step 0)
+            ++gs;
+        };
+        for (int s = 0; s + 1 < nkb; ++s) body(std::false_type{});
+        body(std::true_type{});
+
+        // ---- epilogue of tile cid.  A lane holds runs of four features of ONE row per MFMA tile: stored from there, a wave's store
+        // instruction is 32 rows x 32 bytes (16 for the fp16 images), every piece its own request to the L2.  Each 32 x 32 tile
+        // goes through the wave's own 4 KB of LDS behind the ring instead ([row][8 x 16 B], the pieces XOR-swizzled by the row) and
+        // leaves as whole rows: 8 lanes x 16 B = one 128-byte line (fp32), 8 lanes x 8 B = 64 B per image.  Tile i + 1 is written
+        // while the read-back of tile i is in flight (a wave's LDS instructions execute in order).  asm LDS instructions: hipcc
+        // would put s_waitcnt vmcnt(0) -- the stores just issued -- in front of its own ds_write.
+        const long row0 = row_tile_of(cid) * G_BN + wn * (32 * G_NT);
+        const unsigned e_wr = stg_a + (unsigned)(li * 128), e_rd = stg_a + (unsigned)(er * 128 + ((ec ^ (er & 7)) << 4));
+        int mv = (e_ng - f0 - wm * (32 * MT) + 31) / 32;                                  // this wave's MFMA tiles that hold features of the group
+        mv = mv < 0 ? 0 : (mv > MT ? MT : mv);
+        const int n_it = __builtin_amdgcn_readfirstlane(mv * G_NT);
+        // (the multiplications are compiler-visible VALU work between the MFMA and the asm stores: hazard wait states.  The four
+        // stores of a tile are ONE statement from sixteen different registers with two idle cycles behind them: a VALU write to the
+        // data registers of a 128-bit LDS store needs two wait states on gfx950, which hipcc inserts for its own stores only.  The
+        // read-back, the next tile's stores and the wait are one statement too: hipcc may copy an asm output anywhere behind the
+        // statement that produces it -- with the wait in a later statement it copied the registers before the data had arrived.)
+        auto scaled = [&](int i, g_f4 (&v)[4]) __attribute__((always_inline)) {
+            const int m = i / G_NT, nn = i % G_NT;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                v[g] = (g_f4){acc[m][nn][4 * g] * e_unscale, acc[m][nn][4 * g + 1] * e_unscale, acc[m][nn][4 * g + 2] * e_unscale,
+                              acc[m][nn][4 * g + 3] * e_unscale};
+        };
+        const unsigned sw = (unsigned)(li & 7);
+        const unsigned wa0 = e_wr + (((0 + lh) ^ sw) << 4), wa1 = e_wr + (((2 + lh) ^ sw) << 4), wa2 = e_wr + (((4 + lh) ^ sw) << 4),
+                       wa3 = e_wr + (((6 + lh) ^ sw) << 4);
+        if (n_it > 0) {
+            g_f4 v[4];
+            scaled(0, v);
+            asm volatile("ds_write_b128 %0, %4\n\tds_write_b128 %1, %5\n\tds_write_b128 %2, %6\n\tds_write_b128 %3, %7\n\ts_nop 1"
+                         ::"v"(wa0), "v"(wa1), "v"(wa2), "v"(wa3), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < MT * G_NT; ++i) {
+            if (i >= n_it) break;
+            const int m = i / G_NT, nn = i % G_NT;
+            g_f4 r0, r1, r2, r3;
+            if (i + 1 < MT * G_NT && i + 1 < n_it) {
+                g_f4 v[4];
+                scaled(i + 1 < MT * G_NT ? i + 1 : i, v);
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                             "ds_read_b128 %3, %4 offset:3072\n\t"
+                             "ds_write_b128 %5, %9\n\tds_write_b128 %6, %10\n\tds_write_b128 %7, %11\n\tds_write_b128 %8, %12\n\t"
+                             "s_waitcnt lgkmcnt(4)"
+                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                             : "v"(e_rd), "v"(wa0), "v"(wa1), "v"(wa2), "v"(wa3), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory");
+            } else {
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                             "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(e_rd) : "memory");
+            }
+            const int f = f0 + wm * (32 * MT) + m * 32 + 4 * ec;
+            if (f >= e_ng) continue;
+            const g_f4 rr[4] = {r0 + bzs[m], r1 + bzs[m], r2 + bzs[m], r3 + bzs[m]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long row = row0 + nn * 32 + 8 * j + er;
+                if (row >= e_M) continue;
+                if (e_c) *(gl_f4 *)(e_c + (unsigned long)(row * e_ldc + cbase + f) * 4) = rr[j];
+                if (e_ch) {
+                    half4v hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)rr[j][e]; lo[e] = (_Float16)(rr[j][e] - (float)hi[e]); }
+                    *(gl_h4 *)(e_ch + (unsigned long)(row * e_ldch + cbase + f) * 2) = hi;
+                    *(gl_h4 *)(e_cl + (unsigned long)(row * e_ldch + cbase + f) * 2) = lo;
+                }
             }
         }
-
-        // ---- epilogue of tile cid (the next tile's first stages are in flight meanwhile; stores only make the counted vmcnt waits
-        // more conservative): lane (li, lh) holds, for row wn*64 + nn*32 + li, the features wm*128 + m*32 + 8 g + 4 lh + {0..3}
-        const int gf = (cid >> 3) % per_row, grp = gf / p.ftiles, f0 = (gf % p.ftiles) * G_BM;
-        const long row0 = row_tile_of(cid) * G_BN;
-        const int cbase = grp * p.n_g;
-#pragma unroll
-        for (int nn = 0; nn < G_NT; ++nn) {
-            const long row = row0 + wn * (32 * G_NT) + nn * 32 + li;
-            if (row >= p.M) continue;
-#pragma unroll
-            for (int m = 0; m < G_MT; ++m)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int f = f0 + wm * (32 * G_MT) + m * 32 + 8 * g + 4 * lh;
-                    if (f >= p.n_g) continue;
-                    float4 v = make_float4(acc[m][nn][4 * g] * p.unscale, acc[m][nn][4 * g + 1] * p.unscale, acc[m][nn][4 * g + 2] * p.unscale,
-                                           acc[m][nn][4 * g + 3] * p.unscale);
-                    if (p.bias) {
-                        const float4 b4 = ld4(p.bias + cbase + f);
-                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-                    }
-                    if (p.c) st4(p.c + row * p.ldc + cbase + f, v);
-                    if (p.ch) {
-                        half4v hi, lo;
-                        hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-                        lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
-                        lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
-                        *reinterpret_cast<half4v *>(p.ch + row * p.ldch + cbase + f) = hi;
-                        *reinterpret_cast<half4v *>(p.cl + row * p.ldch + cbase + f) = lo;
-                    }
-                }
-        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the re-issues of the last stage may still be in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // fp32 rows [n, d] -> (hi, lo) fp16 images [n, dp] (dp >= d, multiple of 8; columns past d are zero), scaled by `scale` first
