@@ -343,31 +343,48 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
 }
 
 // fp32 rows [n, d] -> (hi, lo) fp16 images [n, dp] (dp >= d, multiple of 8; columns past d are zero), scaled by `scale` first
-// (an exact power of two; 1 for activations).  One thread per 8 elements.  With seg_len: the rows come in segments of seg_rows
-// (a [B, L, d] batch) of which only the first seg_len[b] are converted -- padding tokens are never read as keys.
+// (an exact power of two; 1 for activations).  One thread per 8 elements, U of them in flight per thread (all loads of an
+// iteration are issued before the first conversion).  With seg_len: the rows come in segments of seg_rows (a [B, L, d] batch) of
+// which only the first seg_len[b] are converted -- padding tokens are never read as keys.  (Its 62 registers let one of its waves
+// per SIMD run beside a resident split_gemm_kernel block: issued behind a dense product, the pass starts under it.)
+template <int U>
 __global__ __launch_bounds__(256) void split_half_kernel(const float *__restrict__ src, long n, int d, long src_stride, int dp, float scale,
                                                          _Float16 *__restrict__ hi, _Float16 *__restrict__ lo,
                                                          const int64_t *__restrict__ seg_len, int seg_rows)
 {
     const int cpr = dp / 8;
-    const long total = n * cpr;
-    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-        const long r = t / cpr;
-        const int c = (int)(t - r * cpr) * 8;
-        if (seg_len && (r % seg_rows) >= seg_len[r / seg_rows]) continue;
-        float v[8];
+    const long total = n * cpr, step = (long)gridDim.x * 256;
+    for (long t0 = (long)blockIdx.x * 256 + threadIdx.x; t0 < total; t0 += step * U) {
+        g_f4 va[U], vb[U];
+        long r[U];
+        int c[U];
+        bool ok[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        if (c < d) { const float4 a = ld4(src + r * src_stride + c); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
-        if (c + 4 < d) { const float4 b = ld4(src + r * src_stride + c + 4); v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
-        half8 h, l;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = v[j] * scale;
-            h[j] = (_Float16)x;
-            l[j] = (_Float16)(x - (float)h[j]);
+        for (int u = 0; u < U; ++u) {
+            const long t = t0 + u * step;
+            ok[u] = t < total;
+            r[u] = ok[u] ? t / cpr : 0;
+            c[u] = (int)(t - r[u] * cpr) * 8;
+            if (seg_len && ok[u]) ok[u] = (r[u] % seg_rows) < seg_len[r[u] / seg_rows];
         }
-        *reinterpret_cast<half8 *>(hi + r * dp + c) = h;
-        *reinterpret_cast<half8 *>(lo + r * dp + c) = l;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            va[u] = vb[u] = (g_f4){0.f, 0.f, 0.f, 0.f};
+            if (ok[u] && c[u] < d) va[u] = *reinterpret_cast<const g_f4 *>(src + r[u] * src_stride + c[u]);
+            if (ok[u] && c[u] + 4 < d) vb[u] = *reinterpret_cast<const g_f4 *>(src + r[u] * src_stride + c[u] + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            half8 h, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = (j < 4 ? va[u][j] : vb[u][j - 4]) * scale;
+                h[j] = (_Float16)x;
+                l[j] = (_Float16)(x - (float)h[j]);
+            }
+            *reinterpret_cast<half8 *>(hi + r[u] * dp + c[u]) = h;
+            *reinterpret_cast<half8 *>(lo + r[u] * dp + c[u]) = l;
+        }
     }
 }

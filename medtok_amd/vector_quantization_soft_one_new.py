@@ -59,13 +59,16 @@ _side_streams = {}
 
 
 def _side_stream(device, which=0):
-    """(side, current): a per-device extra stream (`which`: 0 = the cross-attention's text side, 1 = the modality-specific searches)
+    """(side, current): a per-device extra stream (`which`: 0 = the cross-attention's text side, 1 = the modality-specific searches,
+    2 = the fp16 images of the text)
     that has just been made to wait for everything enqueued on the current one"""
     cur = torch.cuda.current_stream(device)
     key = (device.index if device.index is not None else torch.cuda.current_device(), which)
     side = _side_streams.get(key)
     if side is None:
-        side = _side_streams[key] = torch.cuda.Stream(device=device)
+        # (the text side's stream has the higher priority: its kernels are small -- one query row per code and head -- and, at equal
+        # priority, wait for slots behind the graph side's chip-filling launches until they END the forward instead of hiding in it)
+        side = _side_streams[key] = torch.cuda.Stream(device=device, priority=-1 if which == 0 else 0)
     side.wait_stream(cur)
     return side, cur
 
@@ -320,7 +323,8 @@ class CrossAttention(nn.Module):
             return ops.residual_layernorm(rows, mha.out_proj(attended), ln.weight, ln.bias, ln.eps)
         return ln(rows + layer.dropout(mha.out_proj(attended)))
 
-    def _pooled_packed(self, text, valid_len, nodes_sorted, batch_sorted, slot, counts, starts, max_nodes, core, autograd=False, join=True):
+    def _pooled_packed(self, text, valid_len, nodes_sorted, batch_sorted, slot, counts, starts, max_nodes, core, autograd=False, join=True,
+                       lists=None, images=None):
         """`pooled` with no padding of rows anywhere: packed query rows, ragged attention core.
         `core(q, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale)` is ops.shared_kv_attention at inference (or, from
         pooled_reference, the oracle's restatement); with `autograd` every call goes through _RaggedAttentionFunction instead
@@ -357,9 +361,16 @@ class CrossAttention(nn.Module):
             else:
                 out = core(q_in.float() if q_in.is_cuda else q_in, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale)
             return out[:, :dim].contiguous() if (pad and not wide_in) else out
-        code = torch.arange(bsz, device=dev, dtype=torch.long)
+        if lists is None:                                  # (pooled_reference with an injected core; pooled() brings them from _pack)
+            code = torch.arange(bsz, device=dev, dtype=torch.long)
+            lists = dict(t_start=code * heads, t_len=torch.full((bsz,), heads, device=dev, dtype=torch.long),
+                         g_start=starts * heads, g_len=counts * heads, tok_start=code * seq_len, g_kv_len=valid_len)
+            if LPT_ORDER and not autograd and bsz > 1:
+                order = torch.argsort(valid_len, descending=True)
+                for key in ("g_start", "g_len", "tok_start", "g_kv_len"):
+                    lists[key] = lists[key][order]
         # text side: the CLS row of every code queries that code's nodes
-        t_start, t_len = code * heads, torch.full((bsz,), heads, device=dev, dtype=torch.long)
+        t_start, t_len = lists["t_start"], lists["t_len"]
         cur = text[:, 0].contiguous()
         lib_core = (not autograd) and core is ops.shared_kv_attention and text.is_cuda     # the split-product layer form needs the library's own core
 
@@ -370,39 +381,37 @@ class CrossAttention(nn.Module):
         text_split = images_ready = None
         want_images = (not autograd and core is ops.shared_kv_attention and text.is_cuda and kv_text.shape[1] in ops.ATTENTION_SPLIT_WIDTHS
                        and SPLIT_ATTENTION and nodes_sorted.shape[0] * heads >= SPLIT_MIN_ROWS and max_nodes > 0)
-        if lib_core and max_nodes > 0 and 0 < SIDE_STREAM_MIN_CODES <= bsz and not torch.is_grad_enabled():
-            # the text side (one query row per code and head) is independent of the graph side until the shared searches: second
-            # stream.  The fp16 images of the text rows -- an HBM-bound pass the graph side needs only at its first attention, two
-            # dense products in -- go first on that stream, beside those products.
-            side, main = _side_stream(text.device)
-            with torch.cuda.stream(side):
-                if want_images:
-                    text_split = ops.split_half(kv_text, seg_len=valid_len, seg_rows=seq_len)
-                    images_ready = torch.cuda.Event()
-                    images_ready.record(side)
-                for layer in self.model:
-                    cur = self._folded_rows(layer, cur, text_attend)
-        else:
+        def text_chain(cur):
             for layer in self.model:
                 cur = self._folded_rows(layer, cur, text_attend)
+            return cur
+        use_side = lib_core and max_nodes > 0 and 0 < SIDE_STREAM_MIN_CODES <= bsz and not torch.is_grad_enabled()
+        if use_side:
+            # the text side (one query row per code and head) is independent of the graph side until the shared searches: second
+            # stream.  Its launches are issued behind the graph side's first layer (by then the device has a layer of work queued
+            # and the host is ahead of it).
+            side, main = _side_stream(text.device)
+        else:
+            cur = text_chain(cur)
         if max_nodes == 0:                                 # nothing to attend from: the node mean of every code is zero
             return (cur, cur.new_zeros(bsz, dim)) if join else (cur, cur.new_zeros(bsz, dim), None)
         # graph side: every node queries the valid text tokens of its code
-        g_start, g_len, tok_start = starts * heads, counts * heads, code * seq_len
-        g_kv_len = valid_len
-        if LPT_ORDER and not autograd and bsz > 1:
-            # longest blocks first: the kernel takes (code, tile) blocks in list order, and a block's time is its key count -- the
-            # lists are permuted (the rows they point at are not), so results are the same and the launch has a short tail
-            order = torch.argsort(valid_len, descending=True)
-            g_start, g_len, tok_start, g_kv_len = g_start[order], g_len[order], tok_start[order], valid_len[order]
+        g_start, g_len, tok_start, g_kv_len = lists["g_start"], lists["g_len"], lists["tok_start"], lists["g_kv_len"]
         g = nodes_sorted
         # inference on the library's own core: the text rows become (hi, lo) fp16 images ONCE per forward (valid tokens only) -- every
         # query tile of a code and both layers read them
-        if want_images and text_split is None:
-            text_split = ops.split_half(kv_text, seg_len=valid_len, seg_rows=seq_len)
+        def make_images():
+            nonlocal text_split, images_ready
+            if not want_images or text_split is not None:
+                return
+            if images is not None:                         # (pooled() issued them before anything else)
+                text_split, images_ready = images
+            else:
+                text_split = ops.split_half(kv_text, seg_len=valid_len, seg_rows=seq_len)
 
         def graph_attend(qf, **kw):
             nonlocal images_ready
+            make_images()
             if images_ready is not None:                   # first use of the images made on the other stream
                 torch.cuda.current_stream(text.device).wait_event(images_ready)
                 for t in text_split:
@@ -410,8 +419,11 @@ class CrossAttention(nn.Module):
                 images_ready = None
             return attend(qf, g_start, g_len, kv_text, tok_start, g_kv_len, max_nodes * heads, seq_len, kv_split=text_split, **kw)
         graph_attend.library_core = lib_core
-        for layer in self.model:
+        for i, layer in enumerate(self.model):
             g = self._folded_rows(layer, g, graph_attend)
+            if use_side and i == 0:
+                with torch.cuda.stream(side):
+                    cur = text_chain(cur)
         pending = None
         if side is not None:
             if join:
@@ -427,40 +439,62 @@ class CrossAttention(nn.Module):
         return (cur, gm) if join else (cur, gm, pending)
 
     @staticmethod
-    def _pack(text, text_mask, nodes, batch):
+    def _pack(text, text_mask, nodes, batch, heads=None, lpt=False):
         """Shared prologue of pooled / pooled_reference: dtype alignment, the codes' node counts and offsets, nodes in code order.
-        One host read (the largest node count sizes the launches; the same read validates `batch` and tells whether it is sorted)."""
-        bsz = text.shape[0]
+        One host read (the largest node count sizes the launches; the same read validates `batch` and tells whether it is sorted).
+        Every small device op that needs no host value is issued IN FRONT of that read -- behind it the device queue is empty and
+        each launch would be exposed to the host's dispatch latency (measured at BASELINE sizes: 2 ms of mostly idle device between
+        the read and the first dense product).  With `heads`, the (start, length) lists of both attention sides are part of that:
+        returned as a dict (`lpt`: the graph side's lists longest key set first)."""
+        bsz, seq_len = text.shape[0], text.shape[1]
         if nodes.dtype != text.dtype:                      # autocast hands over bf16 text features and fp32 node features
             common = torch.promote_types(nodes.dtype, text.dtype)
             nodes, text = nodes.to(common), text.to(common)
         valid = text_mask.to(torch.bool)
+        valid_len = valid.sum(1)
         batch = batch.reshape(-1).to(torch.long)
         n_nodes = batch.numel()
+        dev = batch.device if n_nodes else text.device
+        position = torch.arange(n_nodes, device=dev)
         if n_nodes:
             # node counts per code without torch.bincount (which reads the id range back to the host, twice): ids are clamped
             # for the scatter and validated by the ONE host read of this call, which also brings the largest count (it sizes
             # the launch) and whether `batch` is already sorted (PyG batch vectors are: then there is nothing to rank)
-            counts = torch.zeros(bsz, dtype=torch.long, device=batch.device).scatter_add_(
-                0, batch.clamp(0, max(bsz - 1, 0)), torch.ones_like(batch))
-            unsorted = (batch[1:] < batch[:-1]).any() if n_nodes > 1 else torch.zeros((), dtype=torch.bool, device=batch.device)
-            max_nodes, id_lo, id_hi, unsorted = torch.stack([counts.max(), batch.min(), batch.max(), unsorted.to(torch.long)]).tolist()
+            clamped = batch.clamp(0, max(bsz - 1, 0))
+            counts = torch.zeros(bsz, dtype=torch.long, device=dev).scatter_add_(0, clamped, torch.ones_like(batch))
+            unsorted = (batch[1:] < batch[:-1]).any() if n_nodes > 1 else torch.zeros((), dtype=torch.bool, device=dev)
+            stats = torch.stack([counts.max(), batch.min(), batch.max(), unsorted.to(torch.long)])
+            starts = torch.cumsum(counts, 0) - counts
+            slot = position - starts[clamped]              # (the sorted case, speculatively)
+        else:
+            counts = torch.zeros(bsz, dtype=torch.long, device=dev)
+            starts = torch.zeros(bsz, dtype=torch.long, device=dev)
+            slot = position
+            stats = None
+        lists = None
+        if heads is not None:
+            code = torch.arange(bsz, device=dev, dtype=torch.long)
+            lists = dict(t_start=code * heads, t_len=torch.full((bsz,), heads, device=dev, dtype=torch.long),
+                         g_start=starts * heads, g_len=counts * heads, tok_start=code * seq_len, g_kv_len=valid_len)
+            if lpt and bsz > 1:
+                # longest blocks first: the kernel takes (code, tile) blocks in list order, and a block's time is its key count -- the
+                # lists are permuted (the rows they point at are not), so results are the same and the launch has a short tail
+                order_k = torch.argsort(valid_len, descending=True)
+                for key in ("g_start", "g_len", "tok_start", "g_kv_len"):
+                    lists[key] = lists[key][order_k]
+        if stats is not None:
+            max_nodes, id_lo, id_hi, unsorted = stats.tolist()       # <- the host read
             if id_lo < 0 or id_hi >= bsz:
                 raise ValueError(f"pooled(): `batch` must hold code ids in [0, {bsz}); range seen: [{id_lo}, {id_hi}]")
         else:
-            counts = torch.zeros(bsz, dtype=torch.long, device=text.device)
             max_nodes, unsorted = 0, 0
-        starts = torch.cumsum(counts, 0) - counts
-        position = torch.arange(n_nodes, device=batch.device)
         if unsorted:                        # nodes of one code need not be contiguous in `batch`: rank them with a stable sort
             order = torch.argsort(batch, stable=True)
             slot = position - starts[batch[order]]
-        else:
-            order = None
-            slot = position - starts[batch]
-        nodes_in_order = nodes if order is None else nodes[order]
-        batch_in_order = batch if order is None else batch[order]
-        return text, valid, nodes_in_order, batch_in_order, slot, counts, starts, max_nodes
+            nodes, batch = nodes[order], batch[order]
+        if heads is None:
+            return text, valid, nodes, batch, slot, counts, starts, max_nodes
+        return text, valid, valid_len, nodes, batch, slot, counts, starts, max_nodes, lists
 
     def pooled(self, text, text_mask, nodes, batch, join=True):
         """Batched equivalent of the reference's per-code loop (:133-142) -- the PRODUCT path: gfx950 kernels only.
@@ -480,11 +514,29 @@ class CrossAttention(nn.Module):
             raise ops.MedTokLibraryError(f"CrossAttention.pooled: expected tensors on an MI355X (cuda/HIP) device, got {text.device} / "
                                          f"{nodes.device}; medtok_amd has no CPU path")
         ops.attention_width(text.shape[-1])                # raises for widths the kernels cannot take
-        text, valid, nodes_in_order, batch_in_order, slot, counts, starts, max_nodes = self._pack(text, text_mask, nodes, batch)
         needs_grad = torch.is_grad_enabled() and (text.requires_grad or nodes.requires_grad
                                                   or any(p.requires_grad for p in self.parameters()))
-        return self._pooled_packed(text.contiguous(), valid.sum(1), nodes_in_order.contiguous(), batch_in_order, slot, counts, starts,
-                                   max_nodes, ops.shared_kv_attention, autograd=self.training or needs_grad, join=join)
+        autograd = self.training or needs_grad
+        heads = self.model[0].multihead_attn.num_heads
+        bsz, seq_len, dim = text.shape
+        images = None
+        if (not autograd and not torch.is_grad_enabled() and SPLIT_ATTENTION and 0 < SIDE_STREAM_MIN_CODES <= bsz
+                and text.dtype == torch.float32 and nodes.dtype == torch.float32 and text.is_contiguous()
+                and dim in ops.ATTENTION_SPLIT_WIDTHS and nodes.shape[0] * heads >= SPLIT_MIN_ROWS and nodes.shape[0] > 0):
+            # The (hi, lo) fp16 images of the valid text rows -- the keys of the graph side, an HBM-bound pass over the whole text
+            # batch (1.3 ms at BASELINE sizes) that needs nothing but the mask: FIRST thing of the call, on a stream of its own,
+            # under the packing prologue and its host read (the kernel's grid leaves wave slots for those small launches).
+            lens = text_mask.to(torch.bool).sum(1)
+            image_stream, _ = _side_stream(text.device, 2)
+            with torch.cuda.stream(image_stream):
+                text_split = ops.split_half(text.view(bsz * seq_len, dim), seg_len=lens, seg_rows=seq_len)
+                ready = torch.cuda.Event()
+                ready.record(image_stream)
+            images = (text_split, ready)
+        text, valid, valid_len, nodes_in_order, batch_in_order, slot, counts, starts, max_nodes, lists = self._pack(
+            text, text_mask, nodes, batch, heads=heads, lpt=LPT_ORDER and not autograd)
+        return self._pooled_packed(text.contiguous(), valid_len, nodes_in_order.contiguous(), batch_in_order, slot, counts, starts,
+                                   max_nodes, ops.shared_kv_attention, autograd=autograd, join=join, lists=lists, images=images)
 
     def pooled_reference(self, text, text_mask, nodes, batch, fold=None, core=None):
         """TEST-SIDE COMPARATOR, never called by the product path: the same function as pooled() in plain torch ops on any device
