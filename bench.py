@@ -554,6 +554,26 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dev)
     prof = ops.profile_end()
+    prof_note = None
+    if args.workload == "full":
+        # The forward enqueues on several HIP streams: an event pair around a launch then also covers the other streams' kernels that
+        # share the device with it (a 0.05 ms text-side product is "1.3 ms" beside the graph side's attention).  Kernel durations for
+        # the roofline object come from a second pass of the same steps on ONE stream; `value` is the multi-stream timed region above.
+        import medtok_amd.vector_quantization_soft_one_new as vqmod
+        keep = vqmod.SIDE_STREAM_MIN_CODES
+        vqmod.SIDE_STREAM_MIN_CODES = 0
+        try:
+            wl.step()
+            torch.cuda.synchronize(dev)
+            ops.profile_begin()
+            for _ in range(args.steps):
+                wl.step()
+            torch.cuda.synchronize(dev)
+            prof = ops.profile_end()
+        finally:
+            vqmod.SIDE_STREAM_MIN_CODES = keep
+        prof_note = ("kernel durations from a second pass of the same steps on one stream (event pairs of overlapping streams include each "
+                     "other's kernels); value / ms_per_step are the multi-stream timed region")
 
     # the exact fp32-MFMA path on the same workload (1 step): the filter path returns the same bits, faster
     exact = None
@@ -635,7 +655,7 @@ def main():
                          "binding_roof": "mfma (arithmetic intensity K/4 flop/B >> ridge; the HBM fraction is reported because BASELINE.json asks for it)",
                          "peak_note": ("dense f16 MFMA" if kname == "filter_f16_kernel" else
                                        "dense f16 MFMA / 3: every product is three fp16 passes over (hi, lo) pairs" if f16x3 else "dense f32-input MFMA") + " (MI355X_MICROARCH.md)",
-                         "launches_timed": kp["launches"], "avg_launch_ms": kp["ms"] / max(kp["launches"], 1),
+                         "launches_timed": kp["launches"], "avg_launch_ms": kp["ms"] / max(kp["launches"], 1), "timed_in": prof_note or "the timed region",
                          "algorithmic_flops_per_launch": (kp["flops"] / max(kp["launches"], 1)) if kp["flops"] > 0 else None,
                          "kernel_share_of_step": kp["ms"] / (elapsed * 1e3),
                          "achieved_over_fp32_mfma_peak": (achieved / FP32_MFMA_PEAK_TFLOPS) if achieved is not None else None,
