@@ -7,7 +7,10 @@ one statement wherever the result is consumed by compiler code; this script chec
     python tools/audit_asm_waits.py            # compiles medtok_vq.hip to assembly (~2 min) and scans every kernel
 
 Linear scan per kernel in layout order: registers written by an asm ds_read are 'pending' until an s_waitcnt lgkmcnt (asm or
-compiler-inserted); any compiler instruction that names a pending register is reported."""
+compiler-inserted); any compiler instruction that names a pending register is reported.
+Second check: a VALU write to the data registers of a 96/128-bit LDS store needs two wait states on gfx950, which hipcc counts for
+its own stores only (found as lanes 8-15, 24-31, ... storing the next quad's .xy): every asm ds_write_b96/b128 is followed for
+two wait states and a VALU instruction that writes its data registers inside them is reported."""
 import re, subprocess, sys, tempfile
 from pathlib import Path
 
@@ -55,6 +58,24 @@ def audit(asm_text):
                     used |= regs_of(tok)
             if pending & used:
                 issues.append(t)
+        # wide LDS stores from asm: two wait states before a VALU write to their data registers
+        body = [ln.strip() for ln in asm_text[i:j].split("\n")]
+        body = [b for b in body if b and b[0] not in ";." and not b.endswith(":")]
+        for n, b in enumerate(body):
+            if not (b.startswith("ds_write_b128") or b.startswith("ds_write_b96")):
+                continue
+            data = regs_of(b.split(",")[1].strip().split()[0]) if "," in b else set()
+            states = 0
+            for nxt in body[n + 1:n + 4]:
+                if states >= 2:
+                    break
+                op = nxt.split()[0]
+                if op == "s_nop":
+                    states += int(nxt.split()[1]) + 1
+                    continue
+                if op.startswith("v_") and regs_of(nxt[len(op):].split(",")[0].strip()) & data:
+                    issues.append(b + "   <-   " + nxt)
+                states += 1
         if issues:
             total += len(issues)
             print(k[:90], len(issues))
@@ -73,5 +94,5 @@ if __name__ == "__main__":
                                    "-o", str(out), str(ROOT / "medtok_amd" / "csrc" / "medtok_vq.hip")])
             text = out.read_text()
     n = audit(text)
-    print("uses of an asm ds_read's destination before a wait:", n)
+    print("uses of an asm ds_read's destination before a wait / VALU writes into a wide asm LDS store's data within two wait states:", n)
     sys.exit(1 if n else 0)
