@@ -101,3 +101,38 @@ def test_projection_of_the_specific_searches_matches_nn_linear(dev):
     x = zt.clone().requires_grad_(True)                           # under autograd: the nn.Linear (its backward is torch's)
     v.project(x, "text").sum().backward()
     assert x.grad is not None
+
+
+def test_random_shapes_plain_and_grouped(dev):
+    """Random rows / features / depths / group strides through both tile heights (256- and 192-feature tiles), with and without
+    bias, fp32 and / or split output: every case within 4e-6 of the fp64 product (the staged epilogue masks rows past M and
+    features past the group; a tile's last stage is also the only one when the depth is 32)."""
+    import math, random
+    from medtok_amd import ops
+    rng = random.Random(7)
+    for c in range(40):
+        groups = rng.choice([1, 1, 2, 4, 3])
+        k_g = 32 * rng.randint(1, 24)
+        n_g = 4 * rng.randint(1, 200) if rng.random() < 0.7 else rng.choice([64, 192, 256, 384, 768])
+        m = rng.choice([1, 7, 255, 256, 257, 1000, 4096, rng.randint(1, 20000)])
+        a_cols = k_g if groups == 1 else k_g + 8 * rng.randint(0, 3)
+        b_rows = n_g if groups == 1 else n_g + 4 * rng.randint(0, 5)
+        lda = (groups - 1) * a_cols + k_g + 8 * rng.randint(0, 2)
+        g = torch.Generator(device=dev).manual_seed(c)
+        a = torch.randn(m, lda, device=dev, generator=g)
+        w = torch.randn((groups - 1) * b_rows + n_g, k_g, device=dev, generator=g) / k_g ** 0.5
+        bias = torch.randn(groups * n_g, device=dev, generator=g) if rng.random() < 0.6 else None
+        scale = 2.0 ** (11 - math.floor(math.log2(float(w.abs().max()))))
+        ws = ops.split_half(w.contiguous(), dp=k_g, scale=scale)
+        want_f32, want_split = rng.choice([(True, False), (False, True), (True, True)])
+        cf, cs = ops.split_gemm(ops.split_half(a), ws, n_g=n_g, k_g=k_g, groups=groups, a_group_cols=a_cols, b_group_rows=b_rows, bias=bias,
+                                unscale=1.0 / scale, want_f32=want_f32, want_split=want_split)
+        ref = torch.cat([a[:, h * a_cols: h * a_cols + k_g].double() @ w[h * b_rows: h * b_rows + n_g].double().t() for h in range(groups)], 1)
+        if bias is not None:
+            ref = ref + bias.double()
+        sc = float(ref.abs().max()) + 1e-30
+        what = dict(case=c, m=m, n_g=n_g, k_g=k_g, groups=groups)
+        if cf is not None:
+            assert float((cf.double() - ref).abs().max()) / sc <= 4e-6, what
+        if cs is not None:
+            assert float((cs[0].double() + cs[1].double() - ref).abs().max()) / sc <= 4e-6, what
