@@ -805,9 +805,15 @@ __global__ __launch_bounds__(8 * RR) void rescore_kernel(
         float tv[TOPK];
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) tv[j] = INFINITY;
-        for (int o = 0; o < own_total; ++o) {
+        // (from 16 owners up a lane takes owners l8, l8 + 8, ... instead of every 8th entry of every owner: searches of a few
+        // thousand rows run with dozens of code splits, i.e. dozens of owners with a handful of entries each, and the walk over
+        // them -- a dependent count load per owner -- is the latency of the whole launch.  The k-th smallest value does not depend
+        // on who looked at which entry.)
+        const bool by_owner = own_total >= 16;
+        for (int o = by_owner ? l8 : 0; o < own_total; o += by_owner ? 8 : 1) {
             const int m = cc[o];
-            for (int sidx = l8; sidx < m; sidx += 8) thr_insert<TOPK>(tv, fmaf(__uint_as_float(rc[o * F_CAP + sidx].x), -0x1p-15f, xn));
+            for (int sidx = by_owner ? 0 : l8; sidx < m; sidx += by_owner ? 1 : 8)
+                thr_insert<TOPK>(tv, fmaf(__uint_as_float(rc[o * F_CAP + sidx].x), -0x1p-15f, xn));
         }
 #pragma unroll
         for (int off = 4; off >= 1; off >>= 1) {
@@ -821,9 +827,9 @@ __global__ __launch_bounds__(8 * RR) void rescore_kernel(
 #pragma unroll
         for (int j = 1; j < TOPK; ++j) kth = (j < topk_out) ? tv[j] : kth;
         const float lim = kth + win;
-        for (int o = 0; o < own_total; ++o) {
+        for (int o = by_owner ? l8 : 0; o < own_total; o += by_owner ? 8 : 1) {
             const int m = cc[o];
-            for (int sidx = l8; sidx < m; sidx += 8) {
+            for (int sidx = by_owner ? 0 : l8; sidx < m; sidx += by_owner ? 1 : 8) {
                 const uint2 e = rc[o * F_CAP + sidx];
                 if (fmaf(__uint_as_float(e.x), -0x1p-15f, xn) <= lim && e.y < (unsigned)k_codes) {
                     const int p = atomicAdd(&s_cnt[g], 1);
