@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=None, help="row sample for the CPU baseline (0 disables)")
     ap.add_argument("--no-collectives", action="store_true", help="N > 1, headline workload: skip the extra cfg5 / codeshard strong-scaling block")
     ap.add_argument("--exact-steps", type=int, default=1, help="extra steps on the exact fp32-MFMA path for comparison (0 disables)")
+    ap.add_argument("--no-one-stream-pass", action="store_true",
+                    help="full workload: skip the second, one-stream pass that times the kernels for the roofline object (timeline captures)")
     return ap.parse_args()
 
 
@@ -555,7 +557,7 @@ def main():
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dev)
     prof = ops.profile_end()
     prof_note = None
-    if args.workload == "full":
+    if args.workload == "full" and not args.no_one_stream_pass:
         # The forward enqueues on several HIP streams: an event pair around a launch then also covers the other streams' kernels that
         # share the device with it (a 0.05 ms text-side product is "1.3 ms" beside the graph side's attention).  Kernel durations for
         # the roofline object come from a second pass of the same steps on ONE stream; `value` is the multi-stream timed region above.
