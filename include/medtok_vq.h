@@ -229,7 +229,9 @@ int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const
                                    int64_t n_codes, int64_t max_q_len, int d, float scale,
                                    float *out, void *out_hi, void *out_lo, int exact_f32, void *stream);
 /* (out_hi / out_lo, exact_f32 = 0 only: the (hi, lo) fp16 images [Rq, d] of the result, written by the kernel itself for the
- * dense product that follows (medtok_split_gemm_f16); out may then be NULL.) */
+ * dense product that follows (medtok_split_gemm_f16); out may then be NULL.
+ * exact_f32 = 0 and max_q_len <= 8 -- the text side of get_shared_info, one query row per code and head -- runs one wavefront per
+ * code in plain fp32 FMA arithmetic instead of 32-row matrix tiles: same function, same tolerance class.) */
 
 /* The same core for wide inference batches: 64 query rows per block and the keys given as the (hi, lo) fp16 images of
  * medtok_split_half_f32 (kv_hi / kv_lo [Rk, d], made once per forward: a key row serves every query tile of its code and both

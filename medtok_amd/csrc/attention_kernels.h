@@ -530,6 +530,113 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_f16s_kernel(
     att_store_tile<W, NT>(att_sm, acc, l16, nq - qt * 32, qs + qt * 32, out, out_h, out_l, slice, li, lh, tid);
 }
 
+// ---------------------------------------------------------------- the same core for a FEW query rows per code
+// The text side of get_shared_info (vector_quantization_soft_one_new.py:133-139; only the CLS row of the attended text is used,
+// :139): one query row per code and head against that code's graph nodes -- 4 rows x <= a few dozen keys.  On the 32-row matrix
+// kernels that is one eighth of a tile per 512-thread block with 68 KB of LDS: 0.2 ms per launch alone and, beside the graph
+// side's launches, up to 2.4 ms of waiting for LDS and wave slots.  Here ONE WAVEFRONT owns a code: lane l holds columns
+// 4 l + 256 t of its <= NQ query rows and output rows in registers, the keys stream through once (the next key's loads in
+// flight under the current key's arithmetic), scores are plain fp32 dot products (per lane in increasing column order, then the
+// row-of-16 DPP butterfly and the four row sums in a fixed order), online softmax per key.  No LDS, no barrier, no matrix pipe:
+// fp32 FMA arithmetic (more accurate than the three-pass fp16 form; the same tolerance class).  d % 4 == 0, d <= 768.
+__device__ __forceinline__ float fewq_wave_sum(float v)
+{
+    v += att_dpp<0xB1>(v);
+    v += att_dpp<0x4E>(v);
+    v += att_dpp<0x141>(v);
+    v += att_dpp<0x140>(v);                                   // every lane: the sum of its row of 16
+    const int i = (int)__float_as_uint(v);
+    return (__uint_as_float((unsigned)__builtin_amdgcn_readlane(i, 0)) + __uint_as_float((unsigned)__builtin_amdgcn_readlane(i, 16))) +
+           (__uint_as_float((unsigned)__builtin_amdgcn_readlane(i, 32)) + __uint_as_float((unsigned)__builtin_amdgcn_readlane(i, 48)));
+}
+
+template <int NQ>
+__global__ __launch_bounds__(256) void shared_kv_attention_fewq_kernel(
+    const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
+    const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
+    long n_codes, int d, float scale, float *__restrict__ out, _Float16 *__restrict__ out_h, _Float16 *__restrict__ out_l)
+{
+    constexpr int CT = 3;                                     // column chunks of 256 per lane (d <= 768)
+    const int lane = threadIdx.x & 63;
+    const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_codes) return;
+    const int nq = min((int)q_len[b], NQ);
+    if (nq <= 0) return;
+    const long qs = q_start[b], ks = kv_start[b];
+    const int kl = (int)kv_len[b];
+    bool on[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) on[t] = 4 * lane + 256 * t < d;
+    float4 qv[NQ][CT], acc[NQ][CT];
+    float m[NQ], l[NQ];
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+        m[r] = -INFINITY;
+        l[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            acc[r][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            qv[r][t] = (r < nq && on[t]) ? ld4(q + (qs + r) * (long)d + 4 * lane + 256 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float4 kc[CT], kn[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        kc[t] = (kl > 0 && on[t]) ? ld4(kv + ks * (long)d + 4 * lane + 256 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        kn[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int j = 0; j < kl; ++j) {
+        if (j + 1 < kl) {
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+                if (on[t]) kn[t] = ld4(kv + (ks + j + 1) * (long)d + 4 * lane + 256 * t);
+        }
+#pragma unroll
+        for (int r = 0; r < NQ; ++r) {
+            if (r >= nq) break;                               // (wave-uniform)
+            float p = 0.f;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                p = fmaf(qv[r][t].x, kc[t].x, p); p = fmaf(qv[r][t].y, kc[t].y, p);
+                p = fmaf(qv[r][t].z, kc[t].z, p); p = fmaf(qv[r][t].w, kc[t].w, p);
+            }
+            const float s = fewq_wave_sum(p) * scale;
+            const float m_new = fmaxf(m[r], s);
+            const float a = expf(m[r] - m_new);               // 0 at the first key (m = -inf)
+            const float pr = expf(s - m_new);
+            l[r] = fmaf(l[r], a, pr);
+            m[r] = m_new;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                acc[r][t].x = fmaf(pr, kc[t].x, acc[r][t].x * a); acc[r][t].y = fmaf(pr, kc[t].y, acc[r][t].y * a);
+                acc[r][t].z = fmaf(pr, kc[t].z, acc[r][t].z * a); acc[r][t].w = fmaf(pr, kc[t].w, acc[r][t].w * a);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) kc[t] = kn[t];
+    }
+#pragma unroll
+    for (int r = 0; r < NQ; ++r) {
+        if (r >= nq) break;
+        const float inv = l[r] > 0.f ? 1.f / l[r] : 0.f;      // a code with no key rows attends to nothing: context 0, not 0/0
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            if (!on[t]) continue;
+            const float4 v = make_float4(acc[r][t].x * inv, acc[r][t].y * inv, acc[r][t].z * inv, acc[r][t].w * inv);
+            const long o = (qs + r) * (long)d + 4 * lane + 256 * t;
+            if (out) st4(out + o, v);
+            if (out_h) {
+                half4v hh, ll;
+                hh[0] = (_Float16)v.x; hh[1] = (_Float16)v.y; hh[2] = (_Float16)v.z; hh[3] = (_Float16)v.w;
+                ll[0] = (_Float16)(v.x - (float)hh[0]); ll[1] = (_Float16)(v.y - (float)hh[1]);
+                ll[2] = (_Float16)(v.z - (float)hh[2]); ll[3] = (_Float16)(v.w - (float)hh[3]);
+                *reinterpret_cast<half4v *>(out_h + o) = hh;
+                *reinterpret_cast<half4v *>(out_l + o) = ll;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- around the core: residual + LayerNorm, node mean
 // CrossAttentionLayer's tail (vector_quantization_soft_one_new.py:47-50):  y[r] = LayerNorm(a[r] + b[r]) * gamma + beta  (biased
 // variance, eps inside the square root).  One wavefront per row; the row a + b stays in registers between the three passes

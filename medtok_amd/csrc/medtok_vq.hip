@@ -1441,6 +1441,18 @@ static int attention_forward_f16s(const float *q, const int64_t *q_start, const 
     if (q_tiles * n_codes >= (1ll << 31)) return fail("shared_kv_attention: n_codes * ceil(max_q_len / 32) = %ld exceeds the grid limit", (long)(q_tiles * n_codes));
     const dim3 grid((unsigned)(q_tiles * n_codes));
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+    if (max_q_len <= 8) {
+        // a few query rows per code (the text side: one row per head): one wavefront per code, plain fp32 (attention_kernels.h)
+        const dim3 fgrid((unsigned)((n_codes + 3) / 4));
+        if (max_q_len <= 4)
+            hipLaunchKernelGGL(shared_kv_attention_fewq_kernel<4>, fgrid, dim3(256), 0, s, q, q_start, q_len, kv, kv_start, kv_len, (long)n_codes, d, scale,
+                               out, out_h, out_l);
+        else
+            hipLaunchKernelGGL(shared_kv_attention_fewq_kernel<8>, fgrid, dim3(256), 0, s, q, q_start, q_len, kv, kv_start, kv_len, (long)n_codes, d, scale,
+                               out, out_h, out_l);
+        if (pa) prof_push(pa, prof_mark(s), 0.0, 2);
+        return check_launch("shared_kv_attention(few rows)");
+    }
     const int waves = d == 64 ? 2 : (d % 256 == 0 ? 8 : 4);
     // (hi, lo) key planes of W slices, 32 keys x (d / W + 8) halves each; per-wave partial scores; probabilities (hi, lo); row state
     const size_t lds = (size_t)waves * 2 * 32 * (d / waves + 8) * 2 + (size_t)waves * 32 * 33 * 4 + 2 * 32 * 40 * 2 + 64 * 4;

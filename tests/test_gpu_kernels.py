@@ -243,6 +243,50 @@ def test_shared_kv_attention_matches_oracle(oracle, dev, d, heads, seed, exact_f
     assert np.array_equal(got[touched], again[touched])
 
 
+@pytest.mark.parametrize("d,rows,seed", [(768, 4, 0), (64, 4, 1), (128, 1, 2), (768, 8, 3), (640, 6, 4), (256, 3, 5)])
+def test_shared_kv_attention_few_rows_per_code_matches_oracle(oracle, dev, d, rows, seed):
+    """The text side's shape -- at most 8 query rows per code (one per head) against a code's few dozen keys -- runs on the
+    one-wavefront-per-code fp32 kernel (shared_kv_attention_fewq_kernel): same oracle, same tolerance; ragged row counts up to
+    `rows`, codes without queries or without keys, a key spike that moves the running maximum late, the (hi, lo) output images,
+    and agreement with the matrix kernel that serves larger row counts."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(seed)
+    n_codes = 37
+    q_len = rng.integers(0, rows + 1, n_codes).astype(np.int64)
+    q_len[0], q_len[1] = rows, 0
+    kv_len = rng.integers(1, 41, n_codes).astype(np.int64)
+    kv_len[2], kv_len[3] = 0, 300                                      # no keys at all; many keys
+    if q_len[2] == 0: q_len[2] = 1
+    if q_len[3] == 0: q_len[3] = 1
+    q_start = np.cumsum(q_len) - q_len + 2
+    kv_start = np.cumsum(kv_len[::-1])[::-1] - kv_len
+    nq, nk = int(q_start[-1] + q_len[-1]) + 3, int(kv_len.sum())
+    q = (rng.standard_normal((nq, d)) * 0.3).astype(np.float32)
+    kv = rng.standard_normal((nk, d)).astype(np.float32)
+    kv[kv_start[3] + 250] = q[q_start[3]] * 40.0
+    scale = 0.11
+    want = oracle.shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, scale)
+    T = lambda a: torch.from_numpy(a).to(dev)
+    args = (T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len))
+    got = ops.shared_kv_attention(*args, int(q_len.max()), scale).cpu().numpy()
+    touched = ~np.isnan(want).all(1)
+    has_keys = np.repeat(kv_len > 0, q_len)                            # (the oracle leaves rows of key-less codes as 0 / nan: checked apart)
+    rows_idx = np.concatenate([np.arange(s, s + l) for s, l in zip(q_start, q_len)])
+    ok = rows_idx[has_keys]
+    err = np.abs(got[ok].astype(np.float64) - want[ok]).max() / np.abs(want[ok]).max()
+    assert err <= 1e-5, err
+    assert not got[rows_idx[~has_keys]].any()                          # a code without keys attends to nothing: context 0
+    # the matrix kernel on the same inputs (max_q_len = 9 takes it off the few-rows path): same function
+    big = ops.shared_kv_attention(*args, 9, scale).cpu().numpy()
+    assert np.abs(big[ok].astype(np.float64) - got[ok]).max() / np.abs(want[ok]).max() <= 1e-5
+    # the (hi, lo) images of the result are the result
+    hi, lo = ops.shared_kv_attention(*args, int(q_len.max()), scale, split_out=True)
+    back = (hi.float() + lo.float()).cpu().numpy()
+    assert np.abs(back[rows_idx].astype(np.float64) - got[rows_idx]).max() <= 2.0 ** -20 * np.abs(got[rows_idx]).max() + 2.0 ** -24
+    again = ops.shared_kv_attention(*args, int(q_len.max()), scale).cpu().numpy()
+    assert np.array_equal(got[rows_idx], again[rows_idx])
+
+
 def test_shared_kv_attention_rejects_bad_shapes(dev):
     from medtok_amd import ops
     from medtok_amd._lib import MedTokLibraryError
