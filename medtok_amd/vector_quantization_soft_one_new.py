@@ -55,6 +55,8 @@ USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
 # before the shared searches.  From this many codes per call (below it a forward is launch-bound and a second stream only adds
 # host work); 0 turns it off.
 SIDE_STREAM_MIN_CODES = 512
+STREAM_PRIORITY = (-1, 0, 0)       # text side (high), modality-specific searches, text images
+TEXT_CHAIN_AFTER_LAYER = 0         # the text side's launches are issued behind this graph-side layer (-1: in front of the graph side)
 _side_streams = {}
 
 
@@ -68,7 +70,7 @@ def _side_stream(device, which=0):
     if side is None:
         # (the text side's stream has the higher priority: its kernels are small -- one query row per code and head -- and, at equal
         # priority, wait for slots behind the graph side's chip-filling launches until they END the forward instead of hiding in it)
-        side = _side_streams[key] = torch.cuda.Stream(device=device, priority=-1 if which == 0 else 0)
+        side = _side_streams[key] = torch.cuda.Stream(device=device, priority=STREAM_PRIORITY[which])
     side.wait_stream(cur)
     return side, cur
 
@@ -391,6 +393,9 @@ class CrossAttention(nn.Module):
             # stream.  Its launches are issued behind the graph side's first layer (by then the device has a layer of work queued
             # and the host is ahead of it).
             side, main = _side_stream(text.device)
+            if TEXT_CHAIN_AFTER_LAYER < 0:
+                with torch.cuda.stream(side):
+                    cur = text_chain(cur)
         else:
             cur = text_chain(cur)
         if max_nodes == 0:                                 # nothing to attend from: the node mean of every code is zero
@@ -421,7 +426,7 @@ class CrossAttention(nn.Module):
         graph_attend.library_core = lib_core
         for i, layer in enumerate(self.model):
             g = self._folded_rows(layer, g, graph_attend)
-            if use_side and i == 0:
+            if use_side and i == min(TEXT_CHAIN_AFTER_LAYER, len(self.model) - 1):
                 with torch.cuda.stream(side):
                     cur = text_chain(cur)
         pending = None
