@@ -3,6 +3,10 @@
 import sys, time
 sys.path.insert(0, ".")
 import torch
+from pathlib import Path
+import medtok_amd._lib as L
+if len(sys.argv) > 1 and sys.argv[1] != "tree":
+    L._SO = Path(sys.argv[1]).resolve()          # another build of the library (A/B: one library per process)
 from medtok_amd import ops
 dev = torch.device("cuda:0")
 D, H, hd = 768, 4, 192
@@ -17,7 +21,7 @@ def w(rows, cols):
     m = torch.randn(rows, cols, device=dev) / cols ** 0.5
     return ops.split_half(m, dp=cols, scale=2048.0), m
 
-for M in (84000, 4096, 1024):
+for M in ((84000,) if len(sys.argv) > 2 else (84000, 4096, 1024)):
     x = torch.randn(M, D, device=dev); xs = ops.split_half(x)
     (wq, wq32), (wk, _), (wv, _), (wo, wo32) = w(H * hd, D), w(H * D, hd), w(H * hd, D), w(D, H * hd)
     q = ops.split_gemm(xs, wq, n_g=H * hd, k_g=D, want_f32=False, want_split=True)[1]
