@@ -622,7 +622,10 @@ def main():
     if world > 1 and args.workload == "cfg3" and not args.no_collectives:
         del wl.h, wl.pooled_text, wl.pooled_graph
         torch.cuda.empty_cache()
-        strong = collective_block(args, rank, world, dev)
+        try:
+            strong = collective_block(args, rank, world, dev)
+        except Exception as exc:                 # (the headline line must still be printed: this block is an extra)
+            strong = {"error": f"{type(exc).__name__}: {exc}"[:500]}
 
     if rank == 0:
         total_codes = (float(args.rows or 600000) if args.workload in ("cfg5", "codeshard") else float(rows) * world) * args.steps
