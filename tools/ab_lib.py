@@ -19,3 +19,8 @@ def run():
     for _ in range(steps): w.step()
     torch.cuda.synchronize(); return n * steps / (time.perf_counter() - t0)
 print(f"{sys.argv[1][-12:]:12s} {what}", "  ".join(f"{run()/1e3:8.1f}k" for _ in range(3)), flush=True)
+ops.profile_begin()
+for _ in range(steps): w.step()
+torch.cuda.synchronize()
+prof = ops.profile_end()
+print("   kernel ms per launch:", {k: round(v["ms"] / max(v["launches"], 1), 3) for k, v in prof.items() if v["launches"]}, flush=True)
