@@ -24,3 +24,12 @@ for _ in range(steps): w.step()
 torch.cuda.synchronize()
 prof = ops.profile_end()
 print("   kernel ms per launch:", {k: round(v["ms"] / max(v["launches"], 1), 3) for k, v in prof.items() if v["launches"]}, flush=True)
+if what != "full":
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    from medtok_amd.inference import quantize_pooled
+    x = w.pooled_text
+    w.vq._search(x, "shared", False); torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(5): w.vq._search(x, "shared", False)
+    ev[1].record(); torch.cuda.synchronize()
+    print(f"   one shared search (rownorm + filter + rescore): {ev[0].elapsed_time(ev[1]) / 5:.3f} ms", flush=True)
