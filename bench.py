@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=None, help="row sample for the CPU baseline (0 disables)")
     ap.add_argument("--no-collectives", action="store_true", help="N > 1, headline workload: skip the extra cfg5 / codeshard strong-scaling block")
     ap.add_argument("--exact-steps", type=int, default=1, help="extra steps on the exact fp32-MFMA path for comparison (0 disables)")
+    ap.add_argument("--one-stream", action="store_true", help="full workload: the whole run on ONE HIP stream (no side streams)")
     ap.add_argument("--no-one-stream-pass", action="store_true",
                     help="full workload: skip the second, one-stream pass that times the kernels for the roofline object (timeline captures)")
     return ap.parse_args()
@@ -166,6 +167,12 @@ class Full(Cfg3):
         pairs = float((self.n_nodes * heads * self.tok).sum()) + float((heads * self.n_nodes).sum())
         self.attention_flops = 4.0 * D * pairs * layers
         self.attention_f16x3 = True          # inference: medtok_shared_kv_attention_f32(exact_f32 = 0)
+        # algorithmic bytes of the attention core per step: per layer the graph side reads a code's valid
+        # token rows ONCE as (hi, lo) fp16 images (4 B per element; every query tile of the code shares them), reads its folded
+        # fp32 query rows (nodes x heads) and writes their context as (hi, lo) images; the text side reads the code's node rows
+        # (fp32) and reads / writes its `heads` CLS query rows
+        q_rows = float((self.n_nodes * heads).sum())
+        self.attention_bytes = layers * 4.0 * D * (float(self.tok.sum()) + 2.0 * q_rows + float(self.n_nodes.sum()) + 2.0 * heads * rows)
         self.description = (f"full VectorQuantizer.forward: {rows} codes/GPU/step, ragged cross-attention (<= {self.L} tokens x <= "
                             f"{self.MAX_NODES} nodes per code, 4 heads, 2 layers per direction, D=768) + the 4 searches of cfg3 "
                             f"(n_e = 49152, k=5), eval, fp32")
@@ -453,12 +460,15 @@ def collective_block(args, rank, world, dev):
             wl.step()
         torch.cuda.synchronize(dev); mdist.barrier(); torch.cuda.synchronize(dev)
         mdist.COLLECTIVE_TIMER = []
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            wl.step()
-        torch.cuda.synchronize(dev); mdist.barrier(); torch.cuda.synchronize(dev)
-        dt = mdist.max_over_ranks(time.perf_counter() - t0, dev)
-        recs, mdist.COLLECTIVE_TIMER = mdist.COLLECTIVE_TIMER, None
+        try:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                wl.step()
+            torch.cuda.synchronize(dev); mdist.barrier(); torch.cuda.synchronize(dev)
+            dt = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+            recs = mdist.COLLECTIVE_TIMER
+        finally:
+            mdist.COLLECTIVE_TIMER = None
         ms = [e0.elapsed_time(e1) for _, e0, e1, _ in recs]
         coll_ms = mdist.max_over_ranks(sum(ms) / max(args.steps, 1), dev)
         nbytes = sum(b for _, _, _, b in recs) / max(args.steps, 1)
@@ -523,6 +533,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if args.one_stream:
+        import medtok_amd.vector_quantization_soft_one_new as vqmod
+        vqmod.SIDE_STREAM_MIN_CODES = 0
     if args.workload == "cfg5":
         # BASELINE config 5 (EMA variant): 600k rows in total, row-sharded over the GPUs, one all-reduce of [embed_sum | bins] per step
         total_rows = args.rows or 600000
@@ -557,7 +570,8 @@ def main():
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dev)
     prof = ops.profile_end()
     prof_note = None
-    if args.workload == "full" and not args.no_one_stream_pass:
+    one_stream_elapsed = None
+    if args.workload == "full" and not args.no_one_stream_pass and not args.one_stream:
         # The forward enqueues on several HIP streams: an event pair around a launch then also covers the other streams' kernels that
         # share the device with it (a 0.05 ms text-side product is "1.3 ms" beside the graph side's attention).  Kernel durations for
         # the roofline object come from a second pass of the same steps on ONE stream; `value` is the multi-stream timed region above.
@@ -568,9 +582,11 @@ def main():
             wl.step()
             torch.cuda.synchronize(dev)
             ops.profile_begin()
+            t1 = time.perf_counter()
             for _ in range(args.steps):
                 wl.step()
             torch.cuda.synchronize(dev)
+            one_stream_elapsed = time.perf_counter() - t1
             prof = ops.profile_end()
         finally:
             vqmod.SIDE_STREAM_MIN_CODES = keep
@@ -613,6 +629,22 @@ def main():
     f16x3 = kname == "split_gemm_kernel" or (kname == "shared_kv_attention_kernel" and getattr(wl, "attention_f16x3", False))
     peak = F16_MFMA_PEAK_TFLOPS if kname == "filter_f16_kernel" else (F16_MFMA_PEAK_TFLOPS / 3.0 if f16x3 else FP32_MFMA_PEAK_TFLOPS)
     achieved = (kp["flops"] / (kp["ms"] * 1e-3) / 1e12) if (kp["ms"] > 0 and kp["flops"] > 0) else None
+    # which roof binds THIS kernel: its arithmetic intensity (algorithmic flops / algorithmic bytes) against the ridge of the pipe it
+    # runs on (peak flop rate / 8 TB/s).  The searches sit at K/4 flop/B, far right of every ridge; the attention core of the
+    # `full` workload (raw key rows shared by all heads, D = 768) sits at ~50 flop/B, LEFT of the split-fp16 ridge (~104): HBM-bound.
+    kbytes = wl.attention_bytes * args.steps if (kname == "shared_kv_attention_kernel" and hasattr(wl, "attention_bytes")) else None
+    intensity = (kp["flops"] / kbytes) if (kbytes and kp["flops"] > 0) else None
+    ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+    hbm_bound = intensity is not None and intensity < ridge
+    mfma_view = {"achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved is not None else None}
+    if hbm_bound:
+        k_gbs = kbytes / (kp["ms"] * 1e-3) / 1e9
+        bound_view = {"bound": "hbm", "achieved": k_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k_gbs / HBM_PEAK_GBS,
+                      "algorithmic_bytes_per_launch": kbytes / max(kp["launches"], 1), "mfma_view": mfma_view}
+    else:
+        bound_view = dict(mfma_view, bound="mfma")
+    bound_view["arithmetic_intensity_flop_per_byte"] = intensity
+    bound_view["ridge_flop_per_byte"] = ridge
     traffic, traffic_source = pmc_traffic(wl.name, kname, rows)
     alg_bytes_step = float(wl.bytes_per_code()) * rows                # SURVEY 8d per-code figure x the codes one step processes (per GPU)
     hbm_gbs = alg_bytes_step * args.steps / elapsed / 1e9
@@ -653,11 +685,13 @@ def main():
                        "parallelism": (f"code-shard x{world}: all-gather of the per-rank k-lists (n*k*12 B per rank) + exact merge"
                                        if args.workload == "codeshard" else
                                        f"row-shard x{world}, codebook replicated, no data-path collective")},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved is not None else None,
+            "roofline": {**bound_view,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": kname,
                          "hbm_frac": hbm_gbs / HBM_PEAK_GBS, "hbm_achieved_gbs": hbm_gbs, "hbm_peak_gbs": HBM_PEAK_GBS,
                          "algorithmic_bytes_per_step": alg_bytes_step,
-                         "binding_roof": "mfma (arithmetic intensity K/4 flop/B >> ridge; the HBM fraction is reported because BASELINE.json asks for it)",
+                         "binding_roof": ("hbm for this kernel (intensity left of the ridge of the pipe it runs on); hbm_frac below is the whole STEP's SURVEY-8d bytes"
+                                          if hbm_bound else
+                                          "mfma (arithmetic intensity K/4 flop/B >> ridge; the HBM fraction is reported because BASELINE.json asks for it)"),
                          "peak_note": ("dense f16 MFMA" if kname == "filter_f16_kernel" else
                                        "dense f16 MFMA / 3: every product is three fp16 passes over (hi, lo) pairs" if f16x3 else "dense f32-input MFMA") + " (MI355X_MICROARCH.md)",
                          "launches_timed": kp["launches"], "avg_launch_ms": kp["ms"] / max(kp["launches"], 1), "timed_in": prof_note or "the timed region",
@@ -672,6 +706,13 @@ def main():
         }
         if strong is not None:
             line["extra"] = {"strong_scaling": strong}
+        if args.workload == "full":
+            # both stream settings in one line: `value` is the forward as shipped (side streams from 512 codes up) unless --one-stream
+            line["config"]["streams"] = "one (--one-stream)" if args.one_stream else "main + 3 side streams (modality-specific searches, text images, text side)"
+            if one_stream_elapsed is not None:
+                line["one_stream"] = {"value": float(rows) * world * args.steps / one_stream_elapsed, "unit": "codes/s",
+                                      "ms_per_step": one_stream_elapsed / args.steps * 1e3,
+                                      "note": "the same steps with every launch on ONE HIP stream (per-kernel event timing on; rank-local)"}
         if args.workload == "cfg4":
             enc = wl.encoder_ms()
             line["dtype"] = "bf16 autocast (encoders, projections); the searches, their backward and the losses run in f32"

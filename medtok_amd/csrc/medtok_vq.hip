@@ -131,6 +131,7 @@ static bool set_lds_once(size_t bytes)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline long lmin(long a, long b) { return a < b ? a : b; }
+static inline long lmax(long a, long b) { return a > b ? a : b; }
 
 // ---------------------------------------------------------------- device helpers
 __device__ __forceinline__ float wave_butterfly_sum(float p)
@@ -1613,7 +1614,9 @@ extern "C" int medtok_split_gemm_f16(const void *a_hi, const void *a_lo, int64_t
     p.row_tiles = (int)((m + G_BN - 1) / G_BN); p.ftiles = (n_g + bm - 1) / bm;
     const long ids = (long)((p.row_tiles + 7) / 8) * 8 * p.ftiles * groups;
     if (ids >= (1ll << 31)) return fail("split_gemm: grid too large");
-    const long blocks = lmin(ids, (long)(dev_info().cus / 8) * 8);         // persistent: one block per CU (a multiple of 8: the XCD round-robin)
+    // persistent: one block per CU (a multiple of 8: the XCD round-robin; never fewer than 8 -- a CU-masked or partitioned device
+    // with < 8 CUs still gets a valid launch, its blocks just share CUs)
+    const long blocks = lmin(ids, lmax(8, (long)(dev_info().cus / 8) * 8));
     const size_t lds = mt3 ? GemmShape<3>::LDS_BYTES : GemmShape<4>::LDS_BYTES;
     if (!(mt3 ? set_lds_once<split_gemm_kernel<3>>(lds) : set_lds_once<split_gemm_kernel<4>>(lds))) return fail("split_gemm: cannot reserve %zu bytes of LDS", lds);
     hipEvent_t pa = g_prof_on ? prof_mark((hipStream_t)stream) : nullptr;

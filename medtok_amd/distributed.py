@@ -12,6 +12,7 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from torchrun.
 """
 from __future__ import annotations
 
+import math
 import os
 from typing import Optional, Tuple
 
@@ -135,6 +136,38 @@ def gather_ragged(local: torch.Tensor, group=None) -> torch.Tensor:
     parts = [torch.empty_like(pad) for _ in range(world)]
     _timed("all_gather", pad.numel() * pad.element_size() * world, lambda: dist.all_gather(parts, pad, group=group))
     return torch.cat([p[:m] for p, m in zip(parts, lens)], dim=0)
+
+
+def gather_ragged_to_rank0(local: torch.Tensor, device, chunk_bytes: int = 64 << 20, group=None):
+    """Concatenate per-rank HOST tensors whose first dimension differs (rank order) on rank 0 only; the other ranks get None.
+    The rows travel in chunks of at most `chunk_bytes` per rank (staged through `device` when the backend is RCCL, which only
+    moves device memory), so neither the senders nor rank 0 ever hold more than world x chunk_bytes of it on a GPU -- an
+    inference table of 600k codes x 3072 floats is several GB per rank.  Single-process: returns `local`."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    stage = torch.device(device) if on_gpu else torch.device("cpu")
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=stage)
+    lens = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(lens, n_local, group=group)
+    lens = [int(x.item()) for x in lens]
+    row_shape = tuple(local.shape[1:])
+    row_bytes = local.element_size() * math.prod(row_shape)
+    step = max(int(chunk_bytes) // row_bytes, 1)
+    out = [torch.empty((m,) + row_shape, dtype=local.dtype) for m in lens] if rank == 0 else None
+    for lo in range(0, max(lens), step):
+        send = torch.zeros((step,) + row_shape, dtype=local.dtype, device=stage)
+        mine = local[lo: lo + step]
+        send[: mine.shape[0]].copy_(mine)
+        parts = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+        dist.gather(send, parts, dst=0, group=group)
+        if rank == 0:
+            for r, m in enumerate(lens):
+                take = min(max(m - lo, 0), step)
+                if take:
+                    out[r][lo: lo + take].copy_(parts[r][:take])
+    return torch.cat(out, dim=0) if rank == 0 else None
 
 
 def code_shard(k_codes: int, rank: int, world: int) -> Tuple[int, int]:

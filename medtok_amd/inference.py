@@ -56,42 +56,60 @@ def run_inference(model: MultimodalTokenizer, batches: Iterable, out_dir: Option
     """Loop of inference.py:105-115 over `batches` (objects with the fields MultimodalTokenizer.forward
     reads plus `code_indices`), then order by code index and optionally write the three arrays.
 
-    Multi-rank (reference inference.py:66-93: DistributedSampler + DDP, one process per GPU): every rank passes ITS batches; the
-    per-rank results are gathered over the process group (RCCL on GPUs), ordered by code index -- a sampler that pads the last
-    round by repeating codes leaves duplicates: the first copy is kept -- and rank 0 writes the files.  Every rank returns the
-    full, ordered arrays.  (The reference lets every rank write its own shard over the same three files; the evident intent is
-    one table of all codes, which is what the downstream readers of embeddings_all.npy expect.)"""
+    Every batch's results leave the GPU as they are made (asynchronous copies into pinned host memory, like the reference's
+    per-batch `.cpu()`, :112-114): the table of all codes (several GB at 600k codes x 4 e_dim) is never resident in HBM.
+
+    Multi-rank (reference inference.py:66-93: DistributedSampler, one process per GPU): every rank passes ITS batches; the
+    per-rank results are gathered ON RANK 0 ONLY, in bounded chunks over the process group (RCCL on GPUs), ordered by code index
+    -- a sampler that pads the last round by repeating codes leaves duplicates: the first copy is kept (multi-rank only; a
+    single process keeps what its caller passed, like the reference) -- and rank 0 writes the files and returns the arrays; the
+    other ranks return None.  (The reference lets every rank write its own shard over the same three files; the evident intent
+    is one table of all codes, which is what the downstream readers of embeddings_all.npy expect.)
+    `model` must be the bare module, not a DistributedDataParallel wrapper: inference synchronises no gradients, and DDP's
+    per-forward buffer broadcast would hang when the ranks hold different numbers of batches."""
     from . import distributed as mdist
     model.eval()
     embs, toks, wts, order = [], [], [], []
+
+    def to_host(t):
+        if not t.is_cuda:
+            return t
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        host.copy_(t, non_blocking=True)
+        return host
+    dev = device
     for x in batches:
         if device is not None and hasattr(x, "to"):
             x = x.to(device)
         e, t, w = model(x)
-        embs.append(e); toks.append(t); wts.append(w)
-        order.append(torch.as_tensor(x.code_indices).reshape(-1).to(e.device, torch.int64))
+        dev = e.device
+        embs.append(to_host(e)); toks.append(to_host(t)); wts.append(to_host(w))
+        order.append(torch.as_tensor(x.code_indices).reshape(-1).to("cpu", torch.int64))
     multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    if dev is None:
+        dev = next(model.parameters()).device
     if not embs:
         if not multi:
             raise ValueError("run_inference: no batches")
         k, e_dim = model.quantize.k, model.quantize.e_dim
-        dev = device if device is not None else next(model.parameters()).device
-        embs, toks = [torch.zeros(0, 4 * e_dim, device=dev)], [torch.zeros(0, 4, k, dtype=torch.int64, device=dev)]
-        wts, order = [torch.zeros(0, 4, k, device=dev)], [torch.zeros(0, dtype=torch.int64, device=dev)]
+        embs, toks = [torch.zeros(0, 4 * e_dim)], [torch.zeros(0, 4, k, dtype=torch.int64)]
+        wts, order = [torch.zeros(0, 4, k)], [torch.zeros(0, dtype=torch.int64)]
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize(dev)                  # the pinned copies above
     emb, tok, wt, order = torch.cat(embs), torch.cat(toks), torch.cat(wts), torch.cat(order)
-    rank = 0
     if multi:
-        rank = torch.distributed.get_rank()
-        emb, tok, wt, order = (mdist.gather_ragged(t.contiguous()) for t in (emb, tok, wt, order))
+        emb, tok, wt, order = (mdist.gather_ragged_to_rank0(t, dev) for t in (emb, tok, wt, order))
+        if torch.distributed.get_rank() != 0:
+            return None
     perm = torch.argsort(order, stable=True)
-    sorted_ids = order[perm]
-    if sorted_ids.numel() > 1:                       # drop repeated codes (a padding sampler's wrap-around): keep the first copy
+    if multi and order.numel() > 1:                  # drop repeated codes (a padding sampler's wrap-around): keep the first copy
+        sorted_ids = order[perm]
         keep = torch.ones_like(sorted_ids, dtype=torch.bool)
         keep[1:] = sorted_ids[1:] != sorted_ids[:-1]
         perm = perm[keep]
-    embeddings = emb[perm].cpu().numpy()
-    tokens = tok[perm].cpu().numpy()
-    weights = wt[perm].cpu().numpy()
-    if out_dir is not None and rank == 0:
+    embeddings = emb[perm].numpy()
+    tokens = tok[perm].numpy()
+    weights = wt[perm].numpy()
+    if out_dir is not None:
         save_outputs(out_dir, embeddings, tokens, weights)
     return embeddings, tokens, weights

@@ -2,8 +2,10 @@
 
 Both branches of the reference run on the same two kernels: the assignment is the nearest-code search (Euclidean branch :36-39:
 argmax of -|s - m|^2 is the search's argmin of |s|^2 + |m|^2 - 2 s.m as it stands; cosine branch :34 on l2-normalised samples
-and means: argmax of the dot product == argmin of that distance for unit vectors), the per-cluster sums are the EMA statistics
-kernel; the cosine branch re-normalises the means (:50-51).  The reference's
+and means: argmax of the dot product; the search is handed ZERO squared norms on both sides, so its distance is exactly
+-2 s.m whatever the vectors' lengths -- EmbeddingEMA.init_embed_split feeds column halves of unit rows, whose sampled initial
+means are not unit vectors -- on the exact fp32 kernel: the fp16 shortlist's error bound needs the true norms), the per-cluster
+sums are the EMA statistics kernel; the cosine branch re-normalises the means (:50-51).  The reference's
 only randomness is the choice of the initial means (torch.randperm); with the
 same `init_means` the iteration is deterministic and is checked against the
 reference's own run (fixture F12, tests/test_gpu_modules.py): bucket assignments
@@ -31,11 +33,18 @@ def kmeans(samples, num_clusters, num_iters=10, use_cosine_sim=False, init_means
     initial means; `trace` (a list) receives (buckets, means_used) of every iteration (tests)."""
     samples = samples.detach().float().contiguous()
     means = (sample_vectors(samples, num_clusters) if init_means is None else init_means.detach().float()).contiguous()
-    _, ssq = ops.rownorm(samples, normalize=False, want_xhat=False)
+    if use_cosine_sim:
+        ssq = torch.zeros(samples.shape[0], dtype=torch.float32, device=samples.device)
+        zero_msq = torch.zeros(num_clusters, dtype=torch.float32, device=samples.device)
+    else:
+        _, ssq = ops.rownorm(samples, normalize=False, want_xhat=False)
     bins = None
     for _ in range(num_iters):
-        _, msq = ops.rownorm(means, normalize=False, want_xhat=False)
-        idx, _ = ops.topk_search(samples, ssq, means, msq, 1)
+        if use_cosine_sim:          # :34 `samples @ means.t()` -> max: (0 + 0) - 2 s.m -> min, ties to the lowest index
+            idx, _ = ops.topk_search(samples, ssq, means, zero_msq, 1, ops.PATH_F32_MFMA)
+        else:
+            _, msq = ops.rownorm(means, normalize=False, want_xhat=False)
+            idx, _ = ops.topk_search(samples, ssq, means, msq, 1)
         if trace is not None:
             trace.append((idx.view(-1).clone(), means.clone()))
         bins, sums = ops.ema_stats(samples, idx.view(-1), num_clusters)

@@ -75,13 +75,61 @@ def _side_stream(device, which=0):
     return side, cur
 
 
+def _lend(stream, *tensors):
+    """tensors born on the current stream that kernels enqueued on `stream` read: tell the caching allocator, so that a block the
+    host drops (or re-binds) right after the enqueue is not handed to later current-stream work while `stream` still reads it"""
+    for t in tensors:
+        if isinstance(t, (tuple, list)):
+            _lend(stream, *t)
+        elif isinstance(t, dict):
+            _lend(stream, *t.values())
+        elif isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(stream)
+
+
 def _join_side(side, cur, tensors):
     """the current stream waits for the side stream; tensors born on the side stream are marked as used on the current one, so that
     the caching allocator does not hand their memory to later side-stream work while current-stream readers are still pending"""
     cur.wait_stream(side)
-    for t in tensors:
-        if isinstance(t, torch.Tensor) and t.is_cuda:
-            t.record_stream(cur)
+    _lend(cur, *tensors)
+
+
+class _BuiltOn:
+    """(event, stream) of a cache entry's build.  Copies of a module (copy.deepcopy, pickling) carry no mark: HIP events and
+    streams belong to the process and device that made them."""
+    __slots__ = ("event", "stream")
+
+    def __init__(self, event, stream):
+        self.event, self.stream = event, stream
+
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
+
+def _cached(holder, attr, key, build, device, rebuild=False):
+    """A lazily built, per-(storage, version) cache entry that several HIP streams may read: (key, value, _BuiltOn) on `holder`.
+    The entry is built on whatever stream first needs it; a reader on ANOTHER stream waits for the build's event and pins the
+    memory (the tensors live in the building stream's allocator pool: when the entry is dropped they could otherwise be re-used
+    by that stream while this one still reads).  Without this a forward that forks its side streams right after an invalidation
+    (every bench step; every eval after an optimizer step) was ordered only by timing."""
+    c = getattr(holder, attr, None)
+    cur = torch.cuda.current_stream(device) if device.type == "cuda" else None
+    if rebuild or c is None or c[0] != key:
+        value = build()
+        mark = None
+        if cur is not None:
+            mark = _BuiltOn(torch.cuda.Event(), cur)
+            mark.event.record(cur)
+        setattr(holder, attr, (key, value, mark))
+        return value
+    mark = c[2]
+    if mark is not None and cur is not None and cur != mark.stream:
+        cur.wait_event(mark.event)
+        _lend(cur, c[1])
+    return c[1]
 
 
 class _RaggedAttentionFunction(torch.autograd.Function):
@@ -190,22 +238,19 @@ class CrossAttention(nn.Module):
         mha = layer.multihead_attn
         params = (mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias)
         key = tuple((t.data_ptr(), t._version, t.device) for t in params)
-        cache = getattr(layer, "_medtok_fold_cache", None)
-        if cache is not None and cache[0] == key:
-            return cache[1]
-        heads, hd = mha.num_heads, mha.head_dim
-        dim = heads * hd
-        wq, wk, wv = (t.double() for t in mha.in_proj_weight.detach().chunk(3))
-        bq, _, bv = (t.double() for t in mha.in_proj_bias.detach().chunk(3))
-        wo, bo = mha.out_proj.weight.detach().double(), mha.out_proj.bias.detach().double()
-        sl = [slice(h * hd, (h + 1) * hd) for h in range(heads)]
-        mq = torch.cat([wq[s].t() @ wk[s] for s in sl], dim=1)                   # [D, heads * D]
-        cq = torch.cat([bq[s] @ wk[s] for s in sl])                              # [heads * D]
-        mo = torch.cat([wv[s].t() @ wo[:, s].t() for s in sl], dim=0)            # [heads * D, D]
-        co = bv @ wo.t() + bo
-        out = tuple(t.float().contiguous() for t in (mq, cq, mo, co))
-        layer._medtok_fold_cache = (key, out)
-        return out
+
+        def build():
+            heads, hd = mha.num_heads, mha.head_dim
+            wq, wk, wv = (t.double() for t in mha.in_proj_weight.detach().chunk(3))
+            bq, _, bv = (t.double() for t in mha.in_proj_bias.detach().chunk(3))
+            wo, bo = mha.out_proj.weight.detach().double(), mha.out_proj.bias.detach().double()
+            sl = [slice(h * hd, (h + 1) * hd) for h in range(heads)]
+            mq = torch.cat([wq[s].t() @ wk[s] for s in sl], dim=1)                   # [D, heads * D]
+            cq = torch.cat([bq[s] @ wk[s] for s in sl])                              # [heads * D]
+            mo = torch.cat([wv[s].t() @ wo[:, s].t() for s in sl], dim=0)            # [heads * D, D]
+            co = bv @ wo.t() + bo
+            return tuple(t.float().contiguous() for t in (mq, cq, mo, co))
+        return _cached(layer, "_medtok_fold_cache", key, build, mha.in_proj_weight.device)
 
     @staticmethod
     def _split_weights(layer):
@@ -221,38 +266,37 @@ class CrossAttention(nn.Module):
         mha = layer.multihead_attn
         params = (mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias)
         key = tuple((t.data_ptr(), t._version, t.device) for t in params)
-        cache = getattr(layer, "_medtok_split_cache", None)
-        if cache is not None and cache[0] == key:
-            return cache[1]
-        heads, hd = mha.num_heads, mha.head_dim
-        dim = heads * hd
-        dw, hp = ops.attention_width(dim), (hd + 31) // 32 * 32
-        dev = mha.in_proj_weight.device
-        wq, wk, wv = (t.detach().float() for t in mha.in_proj_weight.chunk(3))
-        bq, _, bv = (t.detach().float() for t in mha.in_proj_bias.chunk(3))
-        wo, bo = mha.out_proj.weight.detach().float(), mha.out_proj.bias.detach().float().contiguous()
 
-        def head_rows(w, b):                    # [D, D] -> [H hd', Dw] and its bias [H hd']
-            out = torch.zeros(heads, hp, dw, device=dev)
-            out[:, :hd, :dim] = w.view(heads, hd, dim)
-            bias = torch.zeros(heads, hp, device=dev)
-            bias[:, :hd] = b.view(heads, hd)
-            return out.view(heads * hp, dw), bias.view(-1).contiguous()
-        m_q, b_q = head_rows(wq, bq)
-        m_v, b_v = head_rows(wv, bv)
-        m_k = torch.zeros(heads, dw, hp, device=dev)
-        m_k[:, :dim, :hd] = wk.view(heads, hd, dim).transpose(1, 2)
-        m_o = torch.zeros(dim, heads, hp, device=dev)
-        m_o[:, :, :hd] = wo.view(dim, heads, hd)
+        def build():
+            heads, hd = mha.num_heads, mha.head_dim
+            dim = heads * hd
+            dw, hp = ops.attention_width(dim), (hd + 31) // 32 * 32
+            dev = mha.in_proj_weight.device
+            wq, wk, wv = (t.detach().float() for t in mha.in_proj_weight.chunk(3))
+            bq, _, bv = (t.detach().float() for t in mha.in_proj_bias.chunk(3))
+            wo, bo = mha.out_proj.weight.detach().float(), mha.out_proj.bias.detach().float().contiguous()
 
-        def split(w):
-            amax = float(w.abs().max())
-            scale = 2.0 ** (11 - math.floor(math.log2(amax))) if amax > 0.0 and math.isfinite(amax) else 1.0
-            return ops.split_half(w.contiguous(), dp=w.shape[1], scale=scale), 1.0 / scale
-        out = dict(heads=heads, hd=hd, hp=hp, dim=dim, dw=dw, wq=split(m_q), bq=b_q, wk=split(m_k.view(heads * dw, hp)),
-                   wv=split(m_v), bv=b_v, wo=split(m_o.view(dim, heads * hp)), bo=bo)
-        layer._medtok_split_cache = (key, out)
-        return out
+            def head_rows(w, b):                    # [D, D] -> [H hd', Dw] and its bias [H hd']
+                out = torch.zeros(heads, hp, dw, device=dev)
+                out[:, :hd, :dim] = w.view(heads, hd, dim)
+                bias = torch.zeros(heads, hp, device=dev)
+                bias[:, :hd] = b.view(heads, hd)
+                return out.view(heads * hp, dw), bias.view(-1).contiguous()
+            m_q, b_q = head_rows(wq, bq)
+            m_v, b_v = head_rows(wv, bv)
+            m_k = torch.zeros(heads, dw, hp, device=dev)
+            m_k[:, :dim, :hd] = wk.view(heads, hd, dim).transpose(1, 2)
+            m_o = torch.zeros(dim, heads, hp, device=dev)
+            m_o[:, :, :hd] = wo.view(dim, heads, hd)
+
+            def split(w):
+                amax = float(w.abs().max())
+                scale = 2.0 ** (11 - math.floor(math.log2(amax))) if amax > 0.0 and math.isfinite(amax) else 1.0
+                return ops.split_half(w.contiguous(), dp=w.shape[1], scale=scale), 1.0 / scale
+            out = dict(heads=heads, hd=hd, hp=hp, dim=dim, dw=dw, wq=split(m_q), bq=b_q, wk=split(m_k.view(heads * dw, hp)),
+                       wv=split(m_v), bv=b_v, wo=split(m_o.view(dim, heads * hp)), bo=bo)
+            return out
+        return _cached(layer, "_medtok_split_cache", key, build, mha.in_proj_weight.device)
 
     @staticmethod
     def _folded_rows_split(layer, rows, attend):
@@ -393,6 +437,8 @@ class CrossAttention(nn.Module):
             # stream.  Its launches are issued behind the graph side's first layer (by then the device has a layer of work queued
             # and the host is ahead of it).
             side, main = _side_stream(text.device)
+            # everything the text chain reads was born on the main stream and may be dropped by the host before the chain has run
+            _lend(side, cur, text, kv_nodes, t_start, t_len, starts, counts)
             if TEXT_CHAIN_AFTER_LAYER < 0:
                 with torch.cuda.stream(side):
                     cur = text_chain(cur)
@@ -533,6 +579,7 @@ class CrossAttention(nn.Module):
             # under the packing prologue and its host read (the kernel's grid leaves wave slots for those small launches).
             lens = text_mask.to(torch.bool).sum(1)
             image_stream, _ = _side_stream(text.device, 2)
+            _lend(image_stream, lens)
             with torch.cuda.stream(image_stream):
                 text_split = ops.split_half(text.view(bsz * seq_len, dim), seg_len=lens, seg_rows=seq_len)
                 ready = torch.cuda.Event()
@@ -696,13 +743,9 @@ class VectorQuantizer(nn.Module):
         dropped on train()/eval() switches, load_state_dict and invalidate_codebook_cache()."""
         wt = self.codebook.weight
         key = (wt.data_ptr(), wt._version, wt.device, wt.shape)
-        fresh = self._norm_cache is not None and self._norm_cache[0] == key
-        if fresh and self.training and not getattr(self, "_in_forward", False):
-            fresh = False                    # training: at most one forward() shares a normalisation
-        if not fresh:
-            what, wsq = ops.rownorm(wt.detach())
-            self._norm_cache = (key, what, wsq)
-        return self._norm_cache[1], self._norm_cache[2]
+        # training: at most one forward() shares a normalisation
+        stale = self.training and not getattr(self, "_in_forward", False)
+        return _cached(self, "_norm_cache", key, lambda: ops.rownorm(wt.detach()), wt.device, rebuild=stale)
 
     def project(self, x, types):
         """proj_text / proj_graph (reference :190,192: nn.Linear(split[i], e_dim)).  Inference on wide batches: the library's own
@@ -714,15 +757,14 @@ class VectorQuantizer(nn.Module):
                 or lin.in_features % 32 or lin.out_features % 4 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16):
             return lin(x)
         key = (lin.weight.data_ptr(), lin.weight._version, lin.bias.data_ptr(), lin.bias._version, lin.weight.device)
-        cache = getattr(lin, "_medtok_split_cache", None)
-        if cache is None or cache[0] != key:
+
+        def build():
             import math
             w = lin.weight.detach().float().contiguous()
             amax = float(w.abs().max())
             scale = 2.0 ** (11 - math.floor(math.log2(amax))) if amax > 0.0 and math.isfinite(amax) else 1.0
-            cache = (key, ops.split_half(w, dp=w.shape[1], scale=scale), 1.0 / scale, lin.bias.detach().float().contiguous())
-            lin._medtok_split_cache = cache
-        _, w_split, unscale, bias = cache
+            return ops.split_half(w, dp=w.shape[1], scale=scale), 1.0 / scale, lin.bias.detach().float().contiguous()
+        w_split, unscale, bias = _cached(lin, "_medtok_split_cache", key, build, lin.weight.device)
         out, _ = ops.split_gemm(ops.split_half(x), w_split, n_g=lin.out_features, k_g=lin.in_features, bias=bias, unscale=unscale)
         return out
 

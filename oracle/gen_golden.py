@@ -286,13 +286,15 @@ def fixture_eval_window(sq, name, B, L, max_nodes, D, n_e, seed):
         usage=np.array([r["shared_codebook_usage"], r["text_specific_usage"], r["graph_specific_usage"]]))
 
 
-def fixture_kmeans(nq, name, N, D, K, seed):
+def fixture_kmeans(nq, name, N, D, K, seed, half=False):
     """kmeans (norm_ema_quantizer.py:24-57) as EmbeddingEMA.init_embed_ calls it (:90: 10 iterations, cosine) on l2-normalised
     samples.  Its only randomness is the choice of the initial means (sample_vectors -> torch.randperm, :14-22): patched to
     return a recorded choice, after which the iteration is deterministic.  Samples come from the seeded recipe (not stored);
     stored: the initial means' sample indices, every iteration's bucket assignment (captured at the reference's own
     torch.bincount call), the final means and bins."""
-    samples = F.normalize(synth.det_randn(name + ".samples", (N, D), 1.0, seed), dim=-1)
+    samples = F.normalize(synth.det_randn(name + ".samples", (N, 2 * D if half else D), 1.0, seed), dim=-1)
+    if half:        # what EmbeddingEMA.init_embed_split feeds (:100): a column half of unit rows -- samples and means are NOT unit vectors
+        samples = samples[:, :D].contiguous()
     g = torch.Generator().manual_seed(seed)
     init_idx = torch.randperm(N, generator=g)[:K]
     buckets = []
@@ -392,6 +394,9 @@ def fixture_state_dict_keys(sq, name):
 def main():
     torch.set_num_threads(8)
     sq, nq, ls = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "--round4-only":        # added in round 4: the rest are unchanged
+        fixture_kmeans(nq, "f17_kmeans_half", N=2048, D=64, K=48, seed=24, half=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--round3-only":        # added in round 3: the rest are unchanged
         fixture_state_dict_keys(sq, "f16_soft_state_dict")
         fixture_cfg2_slice(nq, "f15_cfg2_slice", N=16384, D=768, K=8192, seed=15)
@@ -421,6 +426,7 @@ def main():
     fixture_kmeans(nq, "f12_kmeans_d64", N=4096, D=64, K=32, seed=21)
     fixture_kmeans(nq, "f12_kmeans_d768", N=2048, D=768, K=256, seed=22)
     fixture_eval_window(sq, "f13_eval_window", B=8, L=12, max_nodes=9, D=64, n_e=96, seed=23)
+    fixture_kmeans(nq, "f17_kmeans_half", N=2048, D=64, K=48, seed=24, half=True)
     fixture_state_dict_keys(sq, "f16_soft_state_dict")
     fixture_cfg2_slice(nq, "f15_cfg2_slice", N=16384, D=768, K=8192, seed=15)
     fixture_cfg3_slice(sq, "f14_cfg3_slice", N=16384, D=768, n_e=49152, seed=14)

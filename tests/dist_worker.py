@@ -47,6 +47,7 @@ def mode_ema(out, rank, world, dev, n, k, d):
     z, e0 = ema_problem(n, k, d, dev)
     lo, hi = D.row_shard(n, rank, world)
     q, ids, losses = ema_step(z[lo:hi].contiguous(), e0)
+    del z
     ids_all = [D.gather_rows(i, n).cpu().numpy() for i in ids]
     np.savez(out / f"ema_r{rank}.npz", ids0=ids_all[0], ids1=ids_all[1], cluster_size=q.cluster_size.cpu().numpy(),
              weight=q.embedding.weight.data.cpu().numpy(), lo=lo, hi=hi, loss=np.array([float(x) for x in losses]))

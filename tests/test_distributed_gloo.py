@@ -101,3 +101,30 @@ def test_code_sharded_search_equals_single_process(tmp_path, oracle):
     for r in range(world):
         got = np.load(tmp_path / f"c{r}.npz")
         assert np.array_equal(got["idx"], idx) and np.array_equal(got["dist"], dd)       # bit-exact, tie across the boundary included
+
+
+def _gather_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from medtok_amd import distributed as D
+    D.init_distributed("gloo")
+    # ragged shards (rank 1 holds nothing of the int64 table: the zero-batch branch of run_inference), chunks far smaller than a shard
+    rows = [37, 0][rank] if world == 2 else 5
+    a = (torch.arange(rows * 6, dtype=torch.float32).view(rows, 2, 3) + 1000 * rank)
+    b = torch.arange(rows, dtype=torch.int64) * 2 + rank
+    ga = D.gather_ragged_to_rank0(a, "cpu", chunk_bytes=5 * 24)
+    gb = D.gather_ragged_to_rank0(b, "cpu", chunk_bytes=64)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "g.npz"), a=ga.numpy(), b=gb.numpy())
+    else:
+        assert ga is None and gb is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_chunked_gather_to_rank0(tmp_path):
+    """run_inference's table gather: per-rank host tensors of different lengths end up concatenated in rank order on rank 0 only,
+    moved in bounded chunks (medtok_amd.distributed.gather_ragged_to_rank0)."""
+    mp.spawn(_gather_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    g = np.load(tmp_path / "g.npz")
+    assert np.array_equal(g["a"], np.arange(37 * 6, dtype=np.float32).reshape(37, 2, 3))
+    assert np.array_equal(g["b"], np.arange(37, dtype=np.int64) * 2)

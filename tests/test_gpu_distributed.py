@@ -74,6 +74,70 @@ def test_two_rank_hip_code_sharded_search_is_bit_exact(dev, tmp_path):
     assert int(dup.sum()) > 0          # rows that see the duplicated pair exist, so the cross-rank tie rule was exercised
 
 
+def test_config5_ema_step_at_600k_rows_two_ranks_vs_one_rank_and_oracle(oracle, dev, tmp_path):
+    """BASELINE config 5 (EMA variant) at its STATED size: 600 000 rows x 768 row-sharded over two ranks, K = 16 384, two train
+    steps with one all-reduce of [embed_sum | bins] (50.4 MB) each (norm_ema_quantizer.py:194-210).  Beside the rank-vs-one-rank
+    equalities of the 120k-row test: 300 sampled rows of the gathered step-1 ids == the C oracle's argmin over the start
+    codebook, and a 512-code slice of the all-reduced, updated codebook == oracle.ema_apply fed the exact statistics of the
+    whole batch (the GPU's own single-rank statistics kernel, itself bit-checked against the oracle in test_gpu_kernels.py)."""
+    import dist_worker as W
+    from medtok_amd import ops
+    n, k, d = 600000, 16384, 768
+    run_ranks("ema", tmp_path, n, k, d, timeout=1800)
+    z, e0 = W.ema_problem(n, k, d, dev)
+    q, ids, losses = W.ema_step(z, e0, steps=1)
+    r0, r1 = np.load(tmp_path / "ema_r0.npz"), np.load(tmp_path / "ema_r1.npz")
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, n // 2, n // 2, n)
+    ids1 = ids[0].cpu().numpy()
+    for r in (r0, r1):
+        assert r["ids0"].shape == (n,) and np.array_equal(r["ids0"], ids1), "step-1 ids differ from the single-rank run"
+    assert np.array_equal(r0["ids1"], r1["ids1"]) and np.array_equal(r0["weight"], r1["weight"]) and np.array_equal(r0["cluster_size"], r1["cluster_size"])
+    # sampled rows (both shards, the shard boundary, the last rows) vs the oracle's argmin on the start codebook
+    sel = torch.cat([torch.arange(0, n, 2003, device=dev)[:290], torch.arange(n // 2 - 5, n // 2 + 5, device=dev)])
+    zh_o, zs_o = oracle.rownorm(z[sel].cpu().numpy())
+    e0_np = e0.cpu().numpy()
+    _, es_o = oracle.rownorm(e0_np, normalize=False)
+    idx_o, _ = oracle.topk_search(zh_o, zs_o, e0_np, es_o, 1)
+    assert np.array_equal(r0["ids0"][sel.cpu().numpy()], idx_o[:, 0])
+    # the all-reduced update after step 1 on a 512-code slice: oracle.ema_apply with the whole batch's exact statistics.  The
+    # two-rank run has done a second step by now, so the comparison is with the one-rank module after ITS first step (which the
+    # 120k test ties to the two-rank result step by step) -- and the two-rank result after two steps with two oracle updates.
+    zh, _ = ops.rownorm(z)
+    bins1, es1 = ops.ema_stats(zh, ids[0], k)
+    assert float(bins1.sum()) == n
+    sub = torch.arange(0, k, 32, device=dev)
+    E_o = e0[sub].cpu().numpy().copy(); cs_o = np.zeros(len(sub), np.float32)
+    oracle.ema_apply(E_o, cs_o, bins1[sub].cpu().numpy(), es1[sub].cpu().numpy(), 0.99)
+    assert np.array_equal(q.embedding.weight.data[sub].cpu().numpy(), E_o)
+    assert np.array_equal(q.cluster_size[sub].cpu().numpy(), cs_o)
+    ids2 = torch.from_numpy(r0["ids1"]).to(dev)
+    bins2, es2 = ops.ema_stats(zh, ids2, k)
+    oracle.ema_apply(E_o, cs_o, bins2[sub].cpu().numpy(), es2[sub].cpu().numpy(), 0.99)
+    assert np.abs(r0["weight"][sub.cpu().numpy()] - E_o).max() <= 2e-6        # partial sums associate differently across the shard boundary
+    assert np.array_equal(r0["cluster_size"][sub.cpu().numpy()], cs_o)
+
+
+def test_config5_code_sharded_search_at_600k_rows_K49152_vs_oracle(oracle, dev, tmp_path):
+    """north_star's partitioning at its stated size: 600 000 rows, the 49 152-code codebook split over two ranks; HIP search per
+    slice, ONE packed all-gather of the k-lists, HIP merge.  All rows: bit-equal to one search over the whole codebook; 300
+    sampled rows: ids and distances bit-equal to the C oracle's top-5."""
+    import dist_worker as W
+    from medtok_amd import ops
+    n, k, d = 600000, 49152, 768
+    run_ranks("codeshard", tmp_path, n, k, d, timeout=1800)
+    xh, xs, wh, ws = W.codeshard_problem(n, k, d, dev)
+    idx, dist_ = ops.topk_search(xh, xs, wh, ws, 5)
+    idx_np, dist_np = idx.cpu().numpy(), dist_.cpu().numpy()
+    for r in range(2):
+        got = np.load(tmp_path / f"codeshard_r{r}.npz")
+        assert got["idx"].shape == (n, 5)
+        assert np.array_equal(got["idx"], idx_np) and np.array_equal(got["dist"], dist_np), r
+    sel = torch.cat([torch.arange(0, n, 2003, device=dev)[:290], torch.arange(n - 10, n, device=dev)])
+    idx_o, dist_o = oracle.topk_search(xh[sel].cpu().numpy(), xs[sel].cpu().numpy(), wh.cpu().numpy(), ws.cpu().numpy(), 5)
+    got = np.load(tmp_path / "codeshard_r1.npz")
+    assert np.array_equal(got["idx"][sel.cpu().numpy()], idx_o) and np.array_equal(got["dist"][sel.cpu().numpy()], dist_o)
+
+
 def test_ddp_train_step_equals_the_mean_of_single_rank_steps(dev, tmp_path):
     """train_MedTok.py:185: the model wrapped in DDP(find_unused_parameters=True), two ranks, each on its own batch.  DDP averages
     the ranks' gradients, so they must equal the mean of two single-process steps on those batches -- codebook, projections,

@@ -411,7 +411,7 @@ def test_pooled_outputs_at_full_dims_vs_the_reference_loop(dev):
     assert rel(pt, ref_t) <= 1e-5 and rel(pg, ref_g) <= 1e-5
 
 
-@pytest.mark.parametrize("name", ["f12_kmeans_d64", "f12_kmeans_d768"])
+@pytest.mark.parametrize("name", ["f12_kmeans_d64", "f12_kmeans_d768", "f17_kmeans_half"])
 def test_kmeans_matches_the_reference_run(golden, dev, name):
     """k-means codebook init vs the reference's own kmeans() (norm_ema_quantizer.py:24-57) started from the same means (F12:
     oracle/gen_golden.py patches sample_vectors; everything after it is deterministic).  Every iteration's bucket assignment is
@@ -421,7 +421,11 @@ def test_kmeans_matches_the_reference_run(golden, dev, name):
     from oracle import synth
     g = golden(name)
     N, D, K, seed = int(g["N"]), int(g["D"]), int(g["K"]), int(g["seed"])
-    samples = torch.nn.functional.normalize(synth.det_randn(name + ".samples", (N, D), 1.0, seed), dim=-1).to(dev)
+    half = name == "f17_kmeans_half"     # F17: a column half of unit rows, as EmbeddingEMA.init_embed_split feeds (:100) -- neither the
+    samples = torch.nn.functional.normalize(synth.det_randn(name + ".samples", (N, 2 * D if half else D), 1.0, seed), dim=-1)
+    if half:                             # samples nor the sampled initial means are unit vectors: the assignment must still be argmax s.m
+        samples = samples[:, :D].contiguous()
+    samples = samples.to(dev)
     init = samples[torch.from_numpy(g["init_idx"]).to(dev)]
     trace = []
     means, bins = kmeans(samples, K, 10, use_cosine_sim=True, init_means=init, trace=trace)
