@@ -245,6 +245,24 @@ int medtok_shared_kv_attention_split_f32(const float *q, const int64_t *q_start,
 /* (variant, d = 768 only: 0 = 32 query rows per block and two blocks per CU -- one block's softmax and copy waits overlap the
  * other's matrix work; 1 = 64 rows per block, one block per CU, double-buffered key ring.  Same results.) */
 
+/* The prologue of the batched cross-attention: what the reference's per-code loop reads back with `.item()` and `batch == idx`
+ * (vector_quantization_soft_one_new.py:133-142), for all codes at once, in three small launches and no host round trip:
+ *   valid_len[b] = non-zero entries of mask row b (mask [n_codes, seq_len], elements of mask_elem_bytes = 1 (bool), 4 or 8 bytes);
+ *   counts[b] = nodes with batch id b (exact), starts = their exclusive scan (nodes of a code are adjacent in a sorted `batch`);
+ *   the (start, length) lists of the two attention launches, `heads` query rows per node / per code:
+ *     text side  t_start[b] = b heads, t_len[b] = heads                                  (code order)
+ *     graph side g_start[p] = starts[c] heads, g_len[p] = counts[c] heads, tok_start[p] = c seq_len, g_kv_len[p] = valid_len[c]
+ *                with c = the p-th code in list order: longest key set first when lpt != 0 (a block's time is its key count),
+ *                else code order;
+ *   stats[4] = {largest count, smallest batch id, largest batch id, 1 if `batch` is not sorted} for ONE host read (ids outside
+ *   [0, n_codes) are counted into the nearest valid code and reported through the id range: the caller rejects them).
+ * All outputs are DEVICE int64 buffers of n_codes entries (stats: 4). */
+size_t medtok_pack_codes_workspace_bytes(int64_t n_codes);
+int medtok_pack_codes(const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len, const int64_t *batch, int64_t n_nodes,
+                      int heads, int lpt, int64_t *valid_len, int64_t *counts, int64_t *starts, int64_t *t_start, int64_t *t_len,
+                      int64_t *g_start, int64_t *g_len, int64_t *tok_start, int64_t *g_kv_len, int64_t *stats,
+                      void *ws, size_t ws_bytes, void *stream);
+
 /* Around the core, for packed rows (no batch axis):
  *   medtok_residual_layernorm_f32: the tail of CrossAttentionLayer.forward (vector_quantization_soft_one_new.py:47-50),
  *     y[r] = LayerNorm(a[r] + b[r]) * gamma + beta  with nn.LayerNorm's biased variance and eps inside the square root
@@ -254,6 +272,10 @@ int medtok_shared_kv_attention_split_f32(const float *q, const int64_t *q_start,
  *     seg_start / seg_len are DEVICE int64[n_seg]; d % 4 == 0.  An empty segment gives a zero row. */
 int medtok_residual_layernorm_f32(const float *a, const float *b, const float *gamma, const float *beta,
                                   int64_t n, int d, float eps, float *y, void *stream);
+/* (the same with the (hi, lo) fp16 images [n, dp] of y as a second output -- what medtok_split_half_f32(y, dp) would make, for the
+ * next layer's first dense product; dp >= d, a multiple of 8, zero columns appended; y_hi = y_lo = NULL: the function above) */
+int medtok_residual_layernorm_split_f32(const float *a, const float *b, const float *gamma, const float *beta,
+                                        int64_t n, int d, float eps, float *y, void *y_hi, void *y_lo, int dp, void *stream);
 int medtok_segment_mean_f32(const float *x, const int64_t *seg_start, const int64_t *seg_len, int64_t n_seg, int d,
                             float *out, void *stream);
 

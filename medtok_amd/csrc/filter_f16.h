@@ -861,25 +861,21 @@ __global__ __launch_bounds__(8 * RR) void rescore_kernel(
         const float *wr = what + (long)code * d;
         float accv = 0.f;
         int i = 0;
-        for (; i + 16 <= d; i += 16) {               // canonical order within a group of 8: 0,4,1,5,2,6,3,7
+        // canonical order within a group of 8: 0,4,1,5,2,6,3,7
+#define R_CHAIN8(xa, xb, wa, wb)                                            \
+        accv = fmaf(xa.x, wa.x, accv); accv = fmaf(xb.x, wb.x, accv);       \
+        accv = fmaf(xa.y, wa.y, accv); accv = fmaf(xb.y, wb.y, accv);       \
+        accv = fmaf(xa.z, wa.z, accv); accv = fmaf(xb.z, wb.z, accv);       \
+        accv = fmaf(xa.w, wa.w, accv); accv = fmaf(xb.w, wb.w, accv)
+        for (; i + 16 <= d; i += 16) {
             const float4 x0 = ld4(xr + i), x1 = ld4(xr + i + 4), x2 = ld4(xr + i + 8), x3 = ld4(xr + i + 12);
             const float4 w0 = ld4(wr + i), w1 = ld4(wr + i + 4), w2 = ld4(wr + i + 8), w3 = ld4(wr + i + 12);
-            accv = fmaf(x0.x, w0.x, accv); accv = fmaf(x1.x, w1.x, accv);
-            accv = fmaf(x0.y, w0.y, accv); accv = fmaf(x1.y, w1.y, accv);
-            accv = fmaf(x0.z, w0.z, accv); accv = fmaf(x1.z, w1.z, accv);
-            accv = fmaf(x0.w, w0.w, accv); accv = fmaf(x1.w, w1.w, accv);
-            accv = fmaf(x2.x, w2.x, accv); accv = fmaf(x3.x, w3.x, accv);
-            accv = fmaf(x2.y, w2.y, accv); accv = fmaf(x3.y, w3.y, accv);
-            accv = fmaf(x2.z, w2.z, accv); accv = fmaf(x3.z, w3.z, accv);
-            accv = fmaf(x2.w, w2.w, accv); accv = fmaf(x3.w, w3.w, accv);
+            R_CHAIN8(x0, x1, w0, w1); R_CHAIN8(x2, x3, w2, w3);
         }
         for (; i + 8 <= d; i += 8) {
             const float4 x0 = ld4(xr + i), x1 = ld4(xr + i + 4);
             const float4 w0 = ld4(wr + i), w1 = ld4(wr + i + 4);
-            accv = fmaf(x0.x, w0.x, accv); accv = fmaf(x1.x, w1.x, accv);
-            accv = fmaf(x0.y, w0.y, accv); accv = fmaf(x1.y, w1.y, accv);
-            accv = fmaf(x0.z, w0.z, accv); accv = fmaf(x1.z, w1.z, accv);
-            accv = fmaf(x0.w, w0.w, accv); accv = fmaf(x1.w, w1.w, accv);
+            R_CHAIN8(x0, x1, w0, w1);
         }
         if (i < d) {                                  // D % 8 == 4: the last half group
             const float4 x0 = ld4(xr + i), w0 = ld4(wr + i);
@@ -952,6 +948,186 @@ __global__ __launch_bounds__(8 * RR) void rescore_kernel(
         }
     }
 }
+
+// ---------------------------------------------------------------- exact re-score, few rows: one WAVEFRONT per row
+// Searches of a few thousand rows (a serving batch; the four 4096-row searches of a forward) run the filter with up to 16 code
+// splits, i.e. up to 64 candidate lists per row with a handful of entries each, and the launch's time is one block's LATENCY: the
+// 8-lanes-per-row walk above visits its owners one dependent load after the other (count, then entry by entry: ~80 round trips
+// per lane and pass), and its chains miss on every step.  Here a wave owns a row: the 64 counts come with one load, an owner's
+// entries with one (lane = entry), eight owners in flight at a time; the lines of the survivors' code rows are all requested
+// before the first chain starts.  Same candidates, same exact chains, same (d, index) selection and fused assignment as
+// rescore_kernel: the same bits.  own_total, own_tail <= 64.
+template <int TOPK>
+__global__ __launch_bounds__(256) void rescore_wave_kernel(
+    const uint2 *__restrict__ cand, const int *__restrict__ cand_cnt, int own_total,
+    const uint2 *__restrict__ cand_tail, const int *__restrict__ cnt_tail, int own_tail, long tail_start,
+    const float *__restrict__ xhat, const float *__restrict__ xsq, const float *__restrict__ what,
+    const float *__restrict__ wsq, const float *__restrict__ en_max_ptr, long n, int k_codes, int d, int topk_out,
+    int64_t *__restrict__ out_idx, float *__restrict__ out_dist, int *__restrict__ fb_count, int *__restrict__ fb_rows,
+    const float *__restrict__ xref, float *__restrict__ w_out, float *zq_out, long zq_stride)
+{
+    __shared__ int s_code[4][R_SURV];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wv;
+    if (row >= n) return;                              // (no block-wide barrier below: a wave works alone)
+    const float xn = xsq[row];
+    const float win = 2.0f * filter_eps(xn, en_max_ptr[0], d);
+    const bool in_tail = row >= tail_start;
+    if (in_tail) own_total = own_tail;
+    const uint2 *rc = in_tail ? cand_tail + (row - tail_start) * own_total * F_CAP : cand + row * own_total * F_CAP;
+    const int *cc = in_tail ? cnt_tail + (row - tail_start) * own_total : cand_cnt + row * own_total;
+    const int m_mine = lane < own_total ? cc[lane] : 0;
+    if (__builtin_amdgcn_ballot_w64(m_mine > F_CAP)) {   // the filter gave this row up
+        if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = (int)row;
+        return;
+    }
+    // ---- phase 1: t~ = the k-th smallest d~ over all owners' entries
+    float tv[TOPK];
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j) tv[j] = INFINITY;
+    for (int o0 = 0; o0 < own_total; o0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int o = o0 + u;
+            const int m = o < own_total ? __builtin_amdgcn_readlane(m_mine, o < 64 ? o : 63) : 0;
+            v[u] = lane < m ? fmaf(__uint_as_float(rc[o * F_CAP + lane].x), -0x1p-15f, xn) : INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) thr_insert<TOPK>(tv, v[u]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float pv[TOPK];
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) pv[j] = __shfl_xor(tv[j], off, 64);
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) thr_insert<TOPK>(tv, pv[j]);
+    }
+    float kth = tv[0];
+#pragma unroll
+    for (int j = 1; j < TOPK; ++j) kth = (j < topk_out) ? tv[j] : kth;
+    const float lim = kth + win;
+    // ---- phase 2a: entries with d~ <= t~ + 2 eps, compacted (ballot + prefix count: no atomics)
+    int nsurv = 0;
+    for (int o0 = 0; o0 < own_total; o0 += 8) {
+        uint2 e[8];
+        bool pass[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int o = o0 + u;
+            const int m = o < own_total ? __builtin_amdgcn_readlane(m_mine, o < 64 ? o : 63) : 0;
+            e[u] = lane < m ? rc[o * F_CAP + lane] : make_uint2(0u, 0xffffffffu);
+            pass[u] = lane < m && fmaf(__uint_as_float(e[u].x), -0x1p-15f, xn) <= lim && e[u].y < (unsigned)k_codes;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass[u]);
+            const int p = nsurv + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            if (pass[u] && p < R_SURV) s_code[wv][p] = (int)e[u].y;
+            nsurv += __builtin_popcountll(bal);
+        }
+    }
+    if (nsurv > R_SURV) {                              // more survivors than the list holds: exact path
+        if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = (int)row;
+        return;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes, visible to all its lanes
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase 2b: the survivors' exact chains, one lane each; first every line they will walk is requested (codebook rows nobody
+    // has touched come from the Infinity Cache / HBM: one round trip for all of them instead of one per chain step)
+    {
+        const int lines = (d * 4 + 127) >> 7;
+        float sink = 0.f;
+        for (int ti = lane; ti < (nsurv + 1) * lines; ti += 64) {
+            const int wi = ti / lines, ln = ti - wi * lines;
+            const float *src = wi < nsurv ? what + (long)s_code[wv][wi] * d : xhat + row * d;
+            sink += src[min(ln * 32, d - 1)];
+        }
+        asm volatile("" ::"v"(sink));                  // (keeps the touches; nothing reads them)
+    }
+    float bv[TOPK];
+    int bi[TOPK];
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j) { bv[j] = INFINITY; bi[j] = 0x7fffffff; }
+    if (lane < nsurv) {
+        const int code = s_code[wv][lane];
+        const float *xr = xhat + row * d;
+        const float *wr = what + (long)code * d;
+        float accv = 0.f;
+        int i = 0;
+        for (; i + 32 <= d; i += 32) {                 // a whole 128-byte line of both rows per step, 16 loads in flight
+            const float4 x0 = ld4(xr + i), x1 = ld4(xr + i + 4), x2 = ld4(xr + i + 8), x3 = ld4(xr + i + 12);
+            const float4 x4 = ld4(xr + i + 16), x5 = ld4(xr + i + 20), x6 = ld4(xr + i + 24), x7 = ld4(xr + i + 28);
+            const float4 w0 = ld4(wr + i), w1 = ld4(wr + i + 4), w2 = ld4(wr + i + 8), w3 = ld4(wr + i + 12);
+            const float4 w4 = ld4(wr + i + 16), w5 = ld4(wr + i + 20), w6 = ld4(wr + i + 24), w7 = ld4(wr + i + 28);
+            R_CHAIN8(x0, x1, w0, w1); R_CHAIN8(x2, x3, w2, w3); R_CHAIN8(x4, x5, w4, w5); R_CHAIN8(x6, x7, w6, w7);
+        }
+        for (; i + 8 <= d; i += 8) {
+            const float4 x0 = ld4(xr + i), x1 = ld4(xr + i + 4);
+            const float4 w0 = ld4(wr + i), w1 = ld4(wr + i + 4);
+            R_CHAIN8(x0, x1, w0, w1);
+        }
+        if (i < d) {                                   // D % 8 == 4: the last half group
+            const float4 x0 = ld4(xr + i), w0 = ld4(wr + i);
+            accv = fmaf(x0.x, w0.x, accv); accv = fmaf(x0.y, w0.y, accv);
+            accv = fmaf(x0.z, w0.z, accv); accv = fmaf(x0.w, w0.w, accv);
+        }
+        const float sum = xn + wsq[code];
+        const float two = 2.0f * accv;
+        bv[0] = sum - two;
+        bi[0] = code;
+    }
+    // ---- phase 3: exact (d, index) top-k of the survivors: every lane ends with the merged list
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float pv[TOPK];
+        int pi[TOPK];
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) { pv[j] = __shfl_xor(bv[j], off, 64); pi[j] = __shfl_xor(bi[j], off, 64); }
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) topk_insert_lex<TOPK>(bv, bi, pv[j], pi[j]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j)
+            if (j < topk_out) { out_idx[row * topk_out + j] = valid_code(bi[j], j, k_codes); out_dist[row * topk_out + j] = bv[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j) bi[j] = valid_code(bi[j], j, k_codes);
+    // ---- phase 4 (one-call forward only): the soft assignment, as in rescore_kernel (element-wise the same arithmetic)
+    if (zq_out) {
+        float wj[TOPK];
+        const float m = -bv[0];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j)
+            if (j < topk_out) { wj[j] = expf(-bv[j] - m); sum += wj[j]; }
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j)
+            if (j < topk_out) wj[j] = wj[j] / sum;
+        if (w_out && lane == 0) {
+#pragma unroll
+            for (int j = 0; j < TOPK; ++j)
+                if (j < topk_out) w_out[row * topk_out + j] = wj[j];
+        }
+        const float *xr = xref + row * d;
+        float *o = zq_out + row * zq_stride;
+        for (int i = lane * 4; i < d; i += 256) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < TOPK; ++j)
+                if (j < topk_out) {
+                    const float4 e = ld4(what + (long)bi[j] * d + i);
+                    a.x = fmaf(wj[j], e.x, a.x); a.y = fmaf(wj[j], e.y, a.y);
+                    a.z = fmaf(wj[j], e.z, a.z); a.w = fmaf(wj[j], e.w, a.w);
+                }
+            const float4 x = ld4(xr + i);
+            st4(o + i, make_float4(x.x + (a.x - x.x), x.y + (a.y - x.y), x.z + (a.z - x.z), x.w + (a.w - x.w)));
+        }
+    }
+}
+#undef R_CHAIN8
 
 // the accumulator start values: [k_pad] -2^15 |e|^2 (exact: a power-of-two scale), -inf beyond k_codes so that padded codes never pass
 __global__ __launch_bounds__(256) void pad_wsq_kernel(const float *__restrict__ wsq, int k, int k_pad, float *__restrict__ out)

@@ -983,15 +983,17 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     }
     if (pa) prof_push(pa, prof_mark(s), 2.0 * (double)n * (double)k_codes * (double)d, 0);
     if (check_launch("filter_f16")) return 1;
-    // few rows: 8-row blocks (one wavefront) so that every CU gets several; many rows: 32-row blocks
-#define MEDTOK_RESCORE(RR)                                                                                                       \
-    hipLaunchKernelGGL((rescore_kernel<T, RR>), dim3((unsigned)((n + RR - 1) / RR)), dim3(8 * RR), 0, s, w.cand, w.cand_cnt, f.own_total,   \
-                       w.cand_tail, w.cnt_tail, f.own_tail, f.main_tiles < f.row_tiles ? tail_start : (long)n,                   \
-                       xhat, xsq, what, wsq, w.en_max, (long)n, (int)k_codes, d, topk, idx, dist, w.fb_count, w.fb_rows,         \
-                       fuse ? fuse->xref : (const float *)nullptr, fuse ? fuse->w : (float *)nullptr,                            \
-                       fuse ? fuse->zq : (float *)nullptr, fuse ? fuse->zq_stride : 0L)
-    if (n < 32L * 4 * dev_info().cus) MEDTOK_RESCORE(8); else MEDTOK_RESCORE(32);
-#undef MEDTOK_RESCORE
+    // few rows: one wavefront per row (latency-bound: rescore_wave_kernel); many rows: 32-row blocks
+#define MEDTOK_RESCORE_ARGS                                                                                                      \
+    w.cand, w.cand_cnt, f.own_total, w.cand_tail, w.cnt_tail, f.own_tail, f.main_tiles < f.row_tiles ? tail_start : (long)n,     \
+    xhat, xsq, what, wsq, w.en_max, (long)n, (int)k_codes, d, topk, idx, dist, w.fb_count, w.fb_rows,                             \
+    fuse ? fuse->xref : (const float *)nullptr, fuse ? fuse->w : (float *)nullptr,                                                \
+    fuse ? fuse->zq : (float *)nullptr, fuse ? fuse->zq_stride : 0L
+    if (n < 32L * 4 * dev_info().cus && f.own_total <= 64 && f.own_tail <= 64)
+        hipLaunchKernelGGL((rescore_wave_kernel<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, MEDTOK_RESCORE_ARGS);
+    else
+        hipLaunchKernelGGL((rescore_kernel<T, 32>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, MEDTOK_RESCORE_ARGS);
+#undef MEDTOK_RESCORE_ARGS
     if (check_launch("rescore")) return 1;
     // exact redo of the rows the filter gave up on (normally none: every block exits on *fb_count)
     const long code_tiles = (k_codes + S_BM - 1) / S_BM;
@@ -1397,6 +1399,8 @@ extern "C" int medtok_scale_by_device_scalar_f32(const float *x, int64_t count, 
 
 #include "attention_backward.h"
 #include "attention_dma.h"
+#include "attention_pp.h"
+#include "pack_kernels.h"
 
 static int attention_shape_ok(int d) { return d == 64 || (d > 0 && d % 128 == 0 && d <= 768); }
 
@@ -1481,6 +1485,9 @@ static int attention_forward_f16s(const float *q, const int64_t *q_start, const 
 // 64-row blocks, keys from (hi, lo) fp16 images by LDS-DMA (attention_dma.h)
 static bool attention_dma_shape_ok(int d) { return d == 128 || d == 256 || d == 384 || d == 512 || d == 768; }
 
+static void *g_att_dbg = nullptr;      // DEV (tools/r04): per-wave cycle counts of the pp kernel's phases
+extern "C" void medtok_debug_set_attention_probe(void *p) { g_att_dbg = p; }
+
 extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const void *kv_hi, const void *kv_lo,
                                                     const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
                                                     int d, float scale, float *out, void *out_hi, void *out_lo, int variant, void *stream)
@@ -1504,13 +1511,34 @@ extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_
                            lds, s, q, q_start, q_len, (const _Float16 *)kv_hi, (const _Float16 *)kv_lo, kv_start, kv_len, scale, out, \
                            (_Float16 *)out_hi, (_Float16 *)out_lo, (int)q_tiles, (int)n_codes);                                  \
     } while (0)
+    if ((variant & 15) == 2 && (d == 256 || d == 512 || d == 768)) {
+        // two 32-row tiles of a code per block, run one phase apart on one copy of the keys (attention_pp.h)
+        const int64_t q_pairs = (max_q_len + 63) / 64;
+        if (q_pairs * (n_codes + 8) >= (1ll << 31)) return fail("shared_kv_attention_split: grid limit exceeded");
+#define MEDTOK_ATT_PP(NT, ABL)                                                                                                    \
+    do {                                                                                                                          \
+        const size_t lds = AttPP<NT>::LDS_BYTES;                                                                                  \
+        if (!set_lds_once<shared_kv_attention_pp_kernel<NT, ABL>>(lds)) return fail("shared_kv_attention_split: cannot reserve %zu bytes of LDS", lds); \
+        hipLaunchKernelGGL((shared_kv_attention_pp_kernel<NT, ABL>), dim3((unsigned)(q_pairs * ((n_codes + 7) / 8 * 8))), dim3(512), lds, s, q, q_start, \
+                           q_len, (const _Float16 *)kv_hi, (const _Float16 *)kv_lo, kv_start, kv_len, scale, out, (_Float16 *)out_hi,             \
+                           (_Float16 *)out_lo, (int)q_pairs, (int)n_codes, (unsigned long long *)g_att_dbg);                      \
+    } while (0)
+        const int abl = variant >> 4;
+        if (d == 256) MEDTOK_ATT_PP(2, 0); else if (d == 512) MEDTOK_ATT_PP(4, 0);
+        else if (abl == 1) MEDTOK_ATT_PP(6, 1); else if (abl == 2) MEDTOK_ATT_PP(6, 2); else if (abl == 3) MEDTOK_ATT_PP(6, 3);
+        else if (abl == 4) MEDTOK_ATT_PP(6, 4); else if (abl == 7) MEDTOK_ATT_PP(6, 7); else if (abl == 8) MEDTOK_ATT_PP(6, 8);
+        else MEDTOK_ATT_PP(6, 0);
+#undef MEDTOK_ATT_PP
+        if (pa) prof_push(pa, prof_mark(s), 0.0, 2);
+        return check_launch("shared_kv_attention_split(pp)");
+    }
     switch (d) {
     case 128: MEDTOK_ATT_DMA(4, 1, 2, 2); break;
     case 256: MEDTOK_ATT_DMA(8, 1, 2, 2); break;
     case 384: MEDTOK_ATT_DMA(4, 3, 2, 2); break;
     case 512: MEDTOK_ATT_DMA(8, 2, 2, 2); break;
     default:                               // 768: variant 0 = 32 rows per block, two blocks per CU; 1 = 64 rows per block, one per CU
-        if (variant == 1) MEDTOK_ATT_DMA(8, 3, 2, 2); else MEDTOK_ATT_DMA(4, 6, 1, 1);
+        if (variant == 1) MEDTOK_ATT_DMA(8, 3, 2, 2); else if (variant == 3) MEDTOK_ATT_DMA(4, 6, 2, 2); else MEDTOK_ATT_DMA(4, 6, 1, 1);
         break;
     }
 #undef MEDTOK_ATT_DMA
@@ -1534,18 +1562,63 @@ extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_s
     return attention_forward(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, nullptr, 0.f, 0u, (hipStream_t)stream);
 }
 
+// the prologue of CrossAttention.pooled (pack_kernels.h)
+extern "C" size_t medtok_pack_codes_workspace_bytes(int64_t n_codes)
+{
+    return align_up((size_t)(n_codes > 0 ? n_codes : 1) * 4, 256) * 2 + 256;        // counts32 | order | stats32
+}
+
+extern "C" int medtok_pack_codes(const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len, const int64_t *batch, int64_t n_nodes,
+                                 int heads, int lpt, int64_t *valid_len, int64_t *counts, int64_t *starts, int64_t *t_start, int64_t *t_len,
+                                 int64_t *g_start, int64_t *g_len, int64_t *tok_start, int64_t *g_kv_len, int64_t *stats, void *ws, size_t ws_bytes,
+                                 void *stream)
+{
+    if (n_codes <= 0 || seq_len < 0 || n_nodes < 0 || heads <= 0) return fail("pack_codes: bad sizes n_codes=%ld seq_len=%ld n_nodes=%ld heads=%d", (long)n_codes, (long)seq_len, (long)n_nodes, heads);
+    if (n_codes >= (1ll << 31) - 1 || n_nodes >= (1ll << 31) * 256ll) return fail("pack_codes: too many codes / nodes");
+    if (mask_elem_bytes != 1 && mask_elem_bytes != 4 && mask_elem_bytes != 8) return fail("pack_codes: mask elements of %d bytes (bool / int32 / int64 expected)", mask_elem_bytes);
+    if (!mask || (!batch && n_nodes) || !valid_len || !counts || !starts || !t_start || !t_len || !g_start || !g_len || !tok_start || !g_kv_len || !stats)
+        return fail("pack_codes: NULL argument");
+    const size_t need = medtok_pack_codes_workspace_bytes(n_codes);
+    if (!ws || ws_bytes < need) return fail("pack_codes: workspace too small (%zu < %zu)", ws_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t seg = align_up((size_t)n_codes * 4, 256);
+    int *counts32 = (int *)ws, *order = (int *)((char *)ws + seg), *stats32 = (int *)((char *)ws + 2 * seg);
+    if (hipMemsetAsync(counts32, 0, seg, s) != hipSuccess) return fail("pack_codes: memset failed");
+    const int init[4] = {0, 0x7fffffff, -0x7fffffff, 0};
+    if (hipMemcpyAsync(stats32, init, sizeof init, hipMemcpyHostToDevice, s) != hipSuccess) return fail("pack_codes: stats init failed");
+    const unsigned mgrid = (unsigned)((n_codes + 3) / 4);
+    if (mask_elem_bytes == 1) hipLaunchKernelGGL(pack_mask_len_kernel<uint8_t>, dim3(mgrid), dim3(256), 0, s, (const uint8_t *)mask, (long)n_codes, (long)seq_len, valid_len);
+    else if (mask_elem_bytes == 4) hipLaunchKernelGGL(pack_mask_len_kernel<int32_t>, dim3(mgrid), dim3(256), 0, s, (const int32_t *)mask, (long)n_codes, (long)seq_len, valid_len);
+    else hipLaunchKernelGGL(pack_mask_len_kernel<int64_t>, dim3(mgrid), dim3(256), 0, s, (const int64_t *)mask, (long)n_codes, (long)seq_len, valid_len);
+    if (n_nodes > 0)
+        hipLaunchKernelGGL(pack_count_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, s, batch, (long)n_nodes, (long)n_codes, counts32, stats32);
+    const bool sort = lpt && seq_len < PACK_MAX_KEYS;
+    hipLaunchKernelGGL(pack_lists_kernel, dim3(1), dim3(PACK_THREADS), sort ? (size_t)(seq_len + 2) * 4 : 0, s, counts32, stats32, valid_len, (long)n_codes,
+                       (long)seq_len, heads, lpt, order, counts, starts, t_start, t_len, g_start, g_len, tok_start, g_kv_len, stats);
+    return check_launch("pack_codes");
+}
+
 // the layer tail and the node mean around the attention core (attention_kernels.h)
-extern "C" int medtok_residual_layernorm_f32(const float *a, const float *b, const float *gamma, const float *beta, int64_t n, int d,
-                                             float eps, float *y, void *stream)
+extern "C" int medtok_residual_layernorm_split_f32(const float *a, const float *b, const float *gamma, const float *beta, int64_t n, int d,
+                                                   float eps, float *y, void *y_hi, void *y_lo, int dp, void *stream)
 {
     if (n < 0 || d <= 0 || d % 4 != 0 || d > 4 * 64 * LN_MAXV) return fail("residual_layernorm: bad shape n=%ld d=%d (d %% 4 == 0, d <= %d)", (long)n, d, 4 * 64 * LN_MAXV);
     if (!(eps >= 0.f)) return fail("residual_layernorm: eps=%g must be >= 0", (double)eps);
+    if ((y_hi == nullptr) != (y_lo == nullptr)) return fail("residual_layernorm: y_hi and y_lo go together");
+    if (y_hi && (dp < d || dp % 8 != 0 || dp > 4 * 64 * LN_MAXV)) return fail("residual_layernorm: image width dp=%d (>= d, a multiple of 8)", dp);
     if (n == 0) return 0;
     if (!a || !b || !gamma || !beta || !y) return fail("residual_layernorm: NULL argument");
-    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15) return fail("residual_layernorm: pointers must be 16-byte aligned");
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)y_hi | (uintptr_t)y_lo) & 15) return fail("residual_layernorm: pointers must be 16-byte aligned");
     if ((n + 3) / 4 >= (1ll << 31)) return fail("residual_layernorm: too many rows");
-    hipLaunchKernelGGL(residual_layernorm_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, gamma, beta, (long)n, d, eps, y);
+    hipLaunchKernelGGL(residual_layernorm_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, gamma, beta, (long)n, d, eps, y,
+                       (_Float16 *)y_hi, (_Float16 *)y_lo, dp);
     return check_launch("residual_layernorm");
+}
+
+extern "C" int medtok_residual_layernorm_f32(const float *a, const float *b, const float *gamma, const float *beta, int64_t n, int d,
+                                             float eps, float *y, void *stream)
+{
+    return medtok_residual_layernorm_split_f32(a, b, gamma, beta, n, d, eps, y, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int medtok_segment_mean_f32(const float *x, const int64_t *seg_start, const int64_t *seg_len, int64_t n_seg, int d, float *out,

@@ -328,18 +328,50 @@ def split_gemm(a, b, n_g: int, k_g: int, groups: int = 1, a_group_cols: int = 0,
     return c, ((ch, cl) if want_split else None)
 
 
-def residual_layernorm(a, b, gamma, beta, eps: float):
+def residual_layernorm(a, b, gamma, beta, eps: float, split_dp: int = 0):
     """LayerNorm(a + b) * gamma + beta per row of the contiguous fp32 matrices a, b [n, d] (the tail of CrossAttentionLayer,
-    vector_quantization_soft_one_new.py:47-50); d % 4 == 0, d <= 4096."""
+    vector_quantization_soft_one_new.py:47-50); d % 4 == 0, d <= 4096.  split_dp > 0: returns (y, (y_hi, y_lo)) with the (hi, lo)
+    fp16 images [n, split_dp] of y that split_half(y, dp=split_dp) would make, written by the same kernel."""
     a, b, gamma, beta = _dev(a, "a"), _dev(b, "b"), _dev(gamma, "gamma"), _dev(beta, "beta")
     if a.shape != b.shape or a.dim() != 2 or gamma.shape != (a.shape[1],) or beta.shape != (a.shape[1],):
         raise ValueError(f"residual_layernorm: shapes a={tuple(a.shape)} b={tuple(b.shape)} gamma={tuple(gamma.shape)} beta={tuple(beta.shape)}")
     n, d = a.shape
     y = torch.empty_like(a)
+    hi = lo = None
+    if split_dp:
+        hi = torch.empty((n, split_dp), dtype=torch.float16, device=a.device)
+        lo = torch.empty((n, split_dp), dtype=torch.float16, device=a.device)
     with torch.cuda.device(a.device):
-        _lib.check(_lib.load().medtok_residual_layernorm_f32(a.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, d, float(eps),
-                                                             y.data_ptr(), _stream(a)), "medtok_residual_layernorm_f32")
-    return y
+        _lib.check(_lib.load().medtok_residual_layernorm_split_f32(a.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, d, float(eps),
+                                                                   y.data_ptr(), _ptr(hi), _ptr(lo), int(split_dp), _stream(a)),
+                   "medtok_residual_layernorm_split_f32")
+    return (y, (hi, lo)) if split_dp else y
+
+
+def pack_codes(mask, batch, heads: int, lpt: bool):
+    """The prologue of the batched cross-attention in three small launches (include/medtok_vq.h: medtok_pack_codes): mask [B, L]
+    (bool / int32 / int64), batch [n_nodes] int64 -> dict(valid_len, counts, starts, t_start, t_len, g_start, g_len, tok_start,
+    g_kv_len: int64 [B] device tensors; stats: int64 [4] = largest count, id range, unsorted flag -- not yet read back)."""
+    if not (isinstance(mask, torch.Tensor) and mask.is_cuda and mask.dim() == 2):
+        raise _lib.MedTokLibraryError("pack_codes: expected a [B, L] mask on an MI355X device")
+    if mask.dtype not in (torch.bool, torch.uint8, torch.int32, torch.int64):
+        mask = mask != 0
+    mask = mask.contiguous()
+    batch = _dev(batch.reshape(-1), "batch", torch.int64)
+    bsz, seq_len = mask.shape
+    dev = mask.device
+    out = torch.empty((9, bsz), dtype=torch.int64, device=dev)
+    stats = torch.empty(4, dtype=torch.int64, device=dev)
+    lib = _lib.load()
+    ws = _ws(lib.medtok_pack_codes_workspace_bytes(bsz), mask)
+    with torch.cuda.device(dev):
+        _lib.check(lib.medtok_pack_codes(mask.data_ptr(), mask.element_size(), bsz, seq_len, batch.data_ptr(), batch.numel(), int(heads), int(bool(lpt)),
+                                         *[out[i].data_ptr() for i in range(9)], stats.data_ptr(), ws.data_ptr(), ws.numel(), _stream(mask)),
+                   "medtok_pack_codes")
+    names = ("valid_len", "counts", "starts", "t_start", "t_len", "g_start", "g_len", "tok_start", "g_kv_len")
+    r = {k: out[i] for i, k in enumerate(names)}
+    r["stats"] = stats
+    return r
 
 
 def segment_mean(x, seg_start, seg_len):

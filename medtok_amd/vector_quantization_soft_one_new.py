@@ -45,6 +45,9 @@ LPT_ORDER = True
 SPLIT_PRODUCTS = True
 SPLIT_ATTENTION = True       # the graph side's attention on ops.shared_kv_attention_split (64-row blocks, keys from fp16 images)
 SPLIT_MIN_ROWS = 1024
+# which form of the wide-batch attention core ops.shared_kv_attention_split runs (include/medtok_vq.h): 2 = two 32-row tiles of a
+# code per block, one phase apart on one copy of the keys (D = 256 / 512 / 768; the others fall back to 0 inside the library)
+ATTENTION_VARIANT = 2
 from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
@@ -299,7 +302,7 @@ class CrossAttention(nn.Module):
         return _cached(layer, "_medtok_split_cache", key, build, mha.in_proj_weight.device)
 
     @staticmethod
-    def _folded_rows_split(layer, rows, attend):
+    def _folded_rows_split(layer, rows, attend, next_split=False):
         """_folded_rows at inference on the library's own dense products: the four projections of the layer run as split-fp16 MFMA
         GEMMs (medtok_split_gemm_f16: fp32-accurate, ~5x the fp32 matrix rate; the per-head fold and the per-head W_v product are
         one grouped launch each), every product hands its result to the next as (hi, lo) fp16 images, the tail is the fused
@@ -307,7 +310,10 @@ class CrossAttention(nn.Module):
         w = CrossAttention._split_weights(layer)
         heads, hp, dim, dw = w["heads"], w["hp"], w["dim"], w["dw"]
         n_rows = rows.shape[0]
-        x = ops.split_half(rows, dp=dw)
+        # (the previous layer's tail has already written the images of its output: `next_split`)
+        x = getattr(rows, "_medtok_images", None)
+        if x is None or x[0].shape != (n_rows, dw):
+            x = ops.split_half(rows, dp=dw)
         _, q = ops.split_gemm(x, w["wq"][0], n_g=heads * hp, k_g=dw, bias=w["bq"], unscale=w["wq"][1], want_f32=False, want_split=True)
         qf, _ = ops.split_gemm(q, w["wk"][0], n_g=dw, k_g=hp, groups=heads, a_group_cols=hp, b_group_rows=dw, unscale=w["wk"][1])
         c_hi, c_lo = attend(qf.view(n_rows * heads, dw), split_out=True)       # the kernel writes the (hi, lo) images of the context itself
@@ -316,10 +322,14 @@ class CrossAttention(nn.Module):
                                 want_f32=False, want_split=True)
         out, _ = ops.split_gemm(att, w["wo"][0], n_g=dim, k_g=heads * hp, bias=w["bo"], unscale=w["wo"][1])
         ln = layer.layer_norm
-        return ops.residual_layernorm(rows, out, ln.weight, ln.bias, ln.eps)
+        if not next_split:
+            return ops.residual_layernorm(rows, out, ln.weight, ln.bias, ln.eps)
+        y, images = ops.residual_layernorm(rows, out, ln.weight, ln.bias, ln.eps, split_dp=dw)
+        y._medtok_images = images              # read by the next layer's first product instead of a split_half pass over y
+        return y
 
     @staticmethod
-    def _folded_rows(layer, rows, attend):
+    def _folded_rows(layer, rows, attend, next_split=False):
         """_folded_layer for PACKED query rows [R, D] (no batch axis, nothing padded): the attention core is
         `attend(qf [R*heads, D]) -> ctx [R*heads, D]`, i.e. the ragged gfx950 kernel (ops.shared_kv_attention in eval;
         _RaggedAttentionFunction with the attention-probability dropout under autograd / in training)."""
@@ -333,7 +343,7 @@ class CrossAttention(nn.Module):
         if (plain and not layer.training and rows.is_cuda and rows.dtype == torch.float32 and SPLIT_PRODUCTS and dim % 4 == 0
                 and ln.elementwise_affine and ln.bias is not None and mha.in_proj_bias is not None and n_rows >= SPLIT_MIN_ROWS
                 and getattr(attend, "library_core", False)):
-            return CrossAttention._folded_rows_split(layer, rows, attend)
+            return CrossAttention._folded_rows_split(layer, rows, attend, next_split)
         if plain and not layer.training and rows.is_cuda and 4.0 * n_rows * dim * dim * max(heads - 2, 0) <= COMBINE_MAX_EXTRA_FLOPS:
             # small widths (the reference's default e_dim = 64) are launch-bound: the query-side chain (in_proj -> fold) and the
             # value-side chain (Wv -> out_proj) each collapse into ONE GEMM against products of the layer's weights, formed once
@@ -396,10 +406,10 @@ class CrossAttention(nn.Module):
             if split_out:                                  # (inference on the library's core only: the kernel writes the (hi, lo) images itself)
                 assert qf.shape[1] == dim + pad and not autograd and core is ops.shared_kv_attention
                 if kv_split is not None:
-                    return ops.shared_kv_attention_split(q_in, q_start, q_len, kv_split, kv_start, kv_len, max_q_len, scale, split_out=True)
+                    return ops.shared_kv_attention_split(q_in, q_start, q_len, kv_split, kv_start, kv_len, max_q_len, scale, split_out=True, variant=ATTENTION_VARIANT)
                 return ops.shared_kv_attention(q_in, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale, split_out=True)
             if kv_split is not None:                       # wide inference batches: 64-row blocks, keys by LDS-DMA from their fp16 images
-                out = ops.shared_kv_attention_split(q_in.float(), q_start, q_len, kv_split, kv_start, kv_len, max_q_len, scale)
+                out = ops.shared_kv_attention_split(q_in.float(), q_start, q_len, kv_split, kv_start, kv_len, max_q_len, scale, variant=ATTENTION_VARIANT)
             elif autograd:
                 p = float(mha.dropout) if self.training else 0.0
                 seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0.0 else 0      # host RNG: no device sync
@@ -428,8 +438,8 @@ class CrossAttention(nn.Module):
         want_images = (not autograd and core is ops.shared_kv_attention and text.is_cuda and kv_text.shape[1] in ops.ATTENTION_SPLIT_WIDTHS
                        and SPLIT_ATTENTION and nodes_sorted.shape[0] * heads >= SPLIT_MIN_ROWS and max_nodes > 0)
         def text_chain(cur):
-            for layer in self.model:
-                cur = self._folded_rows(layer, cur, text_attend)
+            for i, layer in enumerate(self.model):
+                cur = self._folded_rows(layer, cur, text_attend, next_split=i + 1 < len(self.model))
             return cur
         use_side = lib_core and max_nodes > 0 and 0 < SIDE_STREAM_MIN_CODES <= bsz and not torch.is_grad_enabled()
         if use_side:
@@ -471,7 +481,7 @@ class CrossAttention(nn.Module):
             return attend(qf, g_start, g_len, kv_text, tok_start, g_kv_len, max_nodes * heads, seq_len, kv_split=text_split, **kw)
         graph_attend.library_core = lib_core
         for i, layer in enumerate(self.model):
-            g = self._folded_rows(layer, g, graph_attend)
+            g = self._folded_rows(layer, g, graph_attend, next_split=i + 1 < len(self.model))
             if use_side and i == min(TEXT_CHAIN_AFTER_LAYER, len(self.model) - 1):
                 with torch.cuda.stream(side):
                     cur = text_chain(cur)
@@ -484,6 +494,8 @@ class CrossAttention(nn.Module):
         if not autograd and not torch.is_grad_enabled() and g.is_cuda and g.dtype == torch.float32 and dim % 4 == 0:
             gm = ops.segment_mean(g, starts, counts)               # rows of a code are adjacent: one ordered chain per column
             return (cur, gm) if join else (cur, gm, pending)
+        if slot is None:                                   # (pooled() leaves the in-code position of a node to this fallback)
+            slot = torch.arange(batch_sorted.numel(), device=batch_sorted.device) - starts[batch_sorted]
         padded = g.new_zeros(bsz, max_nodes, dim)
         padded[batch_sorted, slot] = g                     # deterministic mean (no atomics): pad, sum, divide
         gm = padded.sum(1) / counts.clamp(min=1).unsqueeze(-1).to(g.dtype)
@@ -570,24 +582,41 @@ class CrossAttention(nn.Module):
         autograd = self.training or needs_grad
         heads = self.model[0].multihead_attn.num_heads
         bsz, seq_len, dim = text.shape
+        if bsz == 0:
+            z = text.new_zeros(0, dim)
+            return (z, z) if join else (z, z, None)
+        if nodes.dtype != text.dtype:                      # autocast hands over bf16 text features and fp32 node features
+            common = torch.promote_types(nodes.dtype, text.dtype)
+            nodes, text = nodes.to(common), text.to(common)
+        batch = batch.reshape(-1).to(torch.long)
+        # counts / offsets / launch lists of all codes: three small launches (ops.pack_codes), nothing read back yet
+        pk = ops.pack_codes(text_mask, batch, heads, LPT_ORDER and not autograd)
         images = None
         if (not autograd and not torch.is_grad_enabled() and SPLIT_ATTENTION and 0 < SIDE_STREAM_MIN_CODES <= bsz
                 and text.dtype == torch.float32 and nodes.dtype == torch.float32 and text.is_contiguous()
                 and dim in ops.ATTENTION_SPLIT_WIDTHS and nodes.shape[0] * heads >= SPLIT_MIN_ROWS and nodes.shape[0] > 0):
             # The (hi, lo) fp16 images of the valid text rows -- the keys of the graph side, an HBM-bound pass over the whole text
-            # batch (1.3 ms at BASELINE sizes) that needs nothing but the mask: FIRST thing of the call, on a stream of its own,
-            # under the packing prologue and its host read (the kernel's grid leaves wave slots for those small launches).
-            lens = text_mask.to(torch.bool).sum(1)
+            # batch (1.3 ms at BASELINE sizes) that needs nothing but the token counts: on a stream of its own, under the host
+            # read below and the first dense products.
             image_stream, _ = _side_stream(text.device, 2)
-            _lend(image_stream, lens)
+            _lend(image_stream, pk["valid_len"])
             with torch.cuda.stream(image_stream):
-                text_split = ops.split_half(text.view(bsz * seq_len, dim), seg_len=lens, seg_rows=seq_len)
+                text_split = ops.split_half(text.view(bsz * seq_len, dim), seg_len=pk["valid_len"], seg_rows=seq_len)
                 ready = torch.cuda.Event()
                 ready.record(image_stream)
             images = (text_split, ready)
-        text, valid, valid_len, nodes_in_order, batch_in_order, slot, counts, starts, max_nodes, lists = self._pack(
-            text, text_mask, nodes, batch, heads=heads, lpt=LPT_ORDER and not autograd)
-        return self._pooled_packed(text.contiguous(), valid_len, nodes_in_order.contiguous(), batch_in_order, slot, counts, starts,
+        # ONE host read per call: the largest node count sizes the launches; the same read validates `batch` and tells whether it
+        # is sorted (PyG batch vectors are)
+        max_nodes, id_lo, id_hi, unsorted = pk["stats"].tolist()
+        if batch.numel() == 0:
+            max_nodes, unsorted = 0, 0
+        elif id_lo < 0 or id_hi >= bsz:
+            raise ValueError(f"pooled(): `batch` must hold code ids in [0, {bsz}); range seen: [{id_lo}, {id_hi}]")
+        if unsorted:                        # nodes of one code need not be contiguous in `batch`: bring them together (stable)
+            order = torch.argsort(batch, stable=True)
+            nodes, batch = nodes[order], batch[order]
+        lists = {k: pk[k] for k in ("t_start", "t_len", "g_start", "g_len", "tok_start", "g_kv_len")}
+        return self._pooled_packed(text.contiguous(), pk["valid_len"], nodes.contiguous(), batch, None, pk["counts"], pk["starts"],
                                    max_nodes, ops.shared_kv_attention, autograd=autograd, join=join, lists=lists, images=images)
 
     def pooled_reference(self, text, text_mask, nodes, batch, fold=None, core=None):

@@ -406,7 +406,8 @@ def test_normalized_search_equals_rownorm_plus_search(dev, n, k, d, topk, path_n
     assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
 
 
-@pytest.mark.parametrize("d,heads,seed,variant", [(128, 4, 0, 0), (768, 4, 1, 0), (768, 4, 1, 1), (512, 2, 2, 0), (384, 1, 3, 0), (256, 4, 5, 0)])
+@pytest.mark.parametrize("d,heads,seed,variant", [(128, 4, 0, 0), (768, 4, 1, 0), (768, 4, 1, 1), (512, 2, 2, 0), (384, 1, 3, 0), (256, 4, 5, 0),
+                                                  (768, 4, 1, 2), (512, 2, 2, 2), (256, 4, 5, 2)])
 def test_shared_kv_attention_split_matches_oracle(oracle, dev, d, heads, seed, variant):
     """The wide-batch attention core (64 query rows per block, keys copied into LDS by DMA from their (hi, lo) fp16 images, value
     operands by transposed LDS reads) vs the oracle: same ragged cases as above -- query counts around the 64-row tile, key counts
@@ -460,7 +461,7 @@ def test_attention_split_output_images_equal_the_fp32_output(dev, d):
     if d in ops.ATTENTION_SPLIT_WIDTHS:
         img = ops.split_half(kv)
         b = (q, q_start, q_len, img, kv_start, kv_len, 70, 0.2)
-        for variant in ((0, 1) if d == 768 else (0,)):
+        for variant in ((0, 1, 2) if d == 768 else (0,)):
             ref2 = ops.shared_kv_attention_split(*b, variant=variant)
             hi2, lo2 = ops.shared_kv_attention_split(*b, split_out=True, variant=variant)
             assert float((hi2.double() + lo2.double() - ref2.double()).abs().max()) <= 2.0 ** -21 * float(ref2.abs().max()) + 2.0 ** -24
@@ -499,3 +500,55 @@ def test_attention_dropout_mask_rate_and_independence(dev):
     assert abs(float((c[1:] * c[:-1]).mean()) / var) < 0.01                            # neighbouring rows
     assert torch.equal(mask(11), m1)                                                   # stateless: same seed, same mask
     assert bool((mask(5, 0.0) == 1).all())
+
+
+@pytest.mark.parametrize("mask_dtype", [torch.int64, torch.bool, torch.int32])
+@pytest.mark.parametrize("lpt", [False, True])
+def test_pack_codes_matches_the_torch_prologue(dev, mask_dtype, lpt):
+    """medtok_pack_codes (three small launches) vs the torch ops it replaces in CrossAttention.pooled -- what the reference's loop
+    reads per code with mask[idx].sum().item() and batch == idx (vector_quantization_soft_one_new.py:133-142): token counts, node
+    counts and offsets, the launch lists of both attention sides (integer work: exact), the longest-first order as a permutation
+    sorted by key count, and the stats of the one host read, including an unsorted batch vector and codes without nodes."""
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(3)
+    B, L, heads = 1500, 77, 4
+    tok = torch.randint(0, L + 1, (B,), device=dev, generator=g)
+    mask = (torch.arange(L, device=dev)[None, :] < tok[:, None]).to(mask_dtype)
+    n_nodes = torch.randint(0, 9, (B,), device=dev, generator=g)
+    batch = torch.repeat_interleave(torch.arange(B, device=dev), n_nodes)
+    r = ops.pack_codes(mask, batch, heads, lpt)
+    assert torch.equal(r["valid_len"], tok) and torch.equal(r["counts"], n_nodes)
+    starts = torch.cumsum(n_nodes, 0) - n_nodes
+    assert torch.equal(r["starts"], starts)
+    code = torch.arange(B, device=dev)
+    assert torch.equal(r["t_start"], code * heads) and torch.equal(r["t_len"], torch.full_like(code, heads))
+    order = r["tok_start"] // L
+    assert torch.equal(torch.sort(order).values, code)                     # a permutation of the codes
+    assert torch.equal(r["g_start"], starts[order] * heads) and torch.equal(r["g_len"], n_nodes[order] * heads)
+    assert torch.equal(r["g_kv_len"], tok[order])
+    if lpt:
+        assert bool((r["g_kv_len"][1:] <= r["g_kv_len"][:-1]).all())       # longest key set first
+    else:
+        assert torch.equal(order, code)
+    assert r["stats"].tolist() == [int(n_nodes.max()), int(batch.min()), int(batch.max()), 0]
+    shuffled = batch[torch.randperm(batch.numel(), device=dev, generator=g)]
+    r2 = ops.pack_codes(mask, shuffled, heads, lpt)
+    assert torch.equal(r2["counts"], n_nodes) and r2["stats"].tolist()[3] == 1
+    bad = batch.clone(); bad[5] = B + 3; bad[9] = -2
+    assert ops.pack_codes(mask, bad, heads, lpt)["stats"].tolist()[1:3] == [-2, B + 3]
+    empty = ops.pack_codes(mask, batch[:0], heads, lpt)
+    assert int(empty["counts"].sum()) == 0 and empty["stats"].tolist()[0] == 0
+
+
+@pytest.mark.parametrize("d,dp", [(768, 768), (200, 256), (64, 64)])
+def test_residual_layernorm_split_images_equal_split_half_of_the_output(dev, d, dp):
+    """The layer tail with the (hi, lo) fp16 images of its output as a by-product: y bit-equal to the plain kernel, the images
+    bit-equal to ops.split_half(y, dp) (zero columns appended)."""
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(d)
+    a, b = torch.randn(333, d, device=dev, generator=g), torch.randn(333, d, device=dev, generator=g)
+    gamma, beta = torch.randn(d, device=dev, generator=g), torch.randn(d, device=dev, generator=g)
+    y0 = ops.residual_layernorm(a, b, gamma, beta, 1e-5)
+    y, (hi, lo) = ops.residual_layernorm(a, b, gamma, beta, 1e-5, split_dp=dp)
+    h2, l2 = ops.split_half(y0, dp=dp)
+    assert torch.equal(y, y0) and torch.equal(hi, h2) and torch.equal(lo, l2)

@@ -16,6 +16,8 @@ variants = {
     "searches_high": dict(STREAM_PRIORITY=(-1, -1, 0)),
     "no_lpt": dict(LPT_ORDER=False),
     "one_stream": dict(SIDE_STREAM_MIN_CODES=0),
+    "att0": dict(ATTENTION_VARIANT=0),
+    "att0_one_stream": dict(ATTENTION_VARIANT=0, SIDE_STREAM_MIN_CODES=0),
 }
 name = sys.argv[1]
 for k, v in variants[name].items(): setattr(vq, k, v)
