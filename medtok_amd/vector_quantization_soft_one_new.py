@@ -66,14 +66,20 @@ _side_streams = {}
 def _side_stream(device, which=0):
     """(side, current): a per-device extra stream (`which`: 0 = the cross-attention's text side, 1 = the modality-specific searches,
     2 = the fp16 images of the text)
-    that has just been made to wait for everything enqueued on the current one"""
+    that has just been made to wait for everything enqueued on the current one.
+    All three are created together, in this fixed order, the first time any of them is needed on a device: HIP assigns streams to its
+    few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in creation order, and streams that share a queue serialise -- created
+    lazily in use order (or re-created) the same forward ran at 410 k or 315 k codes/s depending on where they landed
+    (tools/ab_streams.py)."""
     cur = torch.cuda.current_stream(device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
-    side = _side_streams.get(key)
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    side = _side_streams.get((dev_index, which))
     if side is None:
         # (the text side's stream has the higher priority: its kernels are small -- one query row per code and head -- and, at equal
         # priority, wait for slots behind the graph side's chip-filling launches until they END the forward instead of hiding in it)
-        side = _side_streams[key] = torch.cuda.Stream(device=device, priority=STREAM_PRIORITY[which])
+        for w in range(len(STREAM_PRIORITY)):
+            _side_streams.setdefault((dev_index, w), torch.cuda.Stream(device=device, priority=STREAM_PRIORITY[w]))
+        side = _side_streams[(dev_index, which)]
     side.wait_stream(cur)
     return side, cur
 
@@ -734,7 +740,6 @@ class VectorQuantizer(nn.Module):
         if self.show_usage:
             self.register_buffer("codebook_used", torch.zeros(USAGE_WINDOW))
         self._norm_cache = None
-        self._defer_usage = None
 
     # ------------------------------------------------------------------ codebook views
     def _region(self, types):
@@ -765,15 +770,15 @@ class VectorQuantizer(nn.Module):
         self._norm_cache = None
         return super()._load_from_state_dict(*args, **kwargs)
 
-    def _normalised_codebook(self):
+    def _normalised_codebook(self, rebuild=None):
         """normalize(codebook.weight) and its row norms.  The reference re-normalises on every call (:148,198,200);
         so does this in training mode (one K x D pass, ~60 us at n_e = 49152, D = 768 -- and every optimizer step
-        changes the weight anyway).  In eval mode the result is cached per forward() / per (storage, version) and
+        changes the weight anyway): forward() re-normalises once and hands the result to its 4-6 searches, a search
+        called on its own re-normalises itself.  In eval mode the result is cached per (storage, version) and
         dropped on train()/eval() switches, load_state_dict and invalidate_codebook_cache()."""
         wt = self.codebook.weight
         key = (wt.data_ptr(), wt._version, wt.device, wt.shape)
-        # training: at most one forward() shares a normalisation
-        stale = self.training and not getattr(self, "_in_forward", False)
+        stale = self.training if rebuild is None else rebuild
         return _cached(self, "_norm_cache", key, lambda: ops.rownorm(wt.detach()), wt.device, rebuild=stale)
 
     def project(self, x, types):
@@ -803,12 +808,13 @@ class VectorQuantizer(nn.Module):
         return torch.sum(x ** 2, dim=1, keepdim=True) + torch.sum(y ** 2, dim=1) - 2 * x @ y.t()
 
     # ------------------------------------------------------------------ one search
-    def _search(self, x, types, training, out=None):
+    def _search(self, x, types, training, out=None, norm=None):
+        """one search: (zq, vq, commit, xhat, idx, w).  `norm`: the (normalised codebook, squared norms) the caller's forward shares."""
         lo, hi = self._region(types)
         n = x.shape[0]
         x = x.float()                   # autocast callers hand over fp16/bf16; the search is fp32
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.codebook.weight.requires_grad)
-        what, wsq = self._normalised_codebook()
+        what, wsq = norm if norm is not None else self._normalised_codebook()
         if training and needs_grad:
             return _SoftVQFunction.apply(x, self.codebook.weight[lo:hi], what[lo:hi], wsq[lo:hi].contiguous(), self.k,
                                          self.search_path, float(self.beta))
@@ -825,96 +831,96 @@ class VectorQuantizer(nn.Module):
             zq = zq + (x - x.detach())      # eval under autograd: the straight-through estimator's identity gradient (:214)
         return zq, vq, commit, r["xhat"], r["idx"], r["w"]
 
-    # ------------------------------------------------------------------ reference API
-    def get_shared_info(self, z_text, z_graph, text_mask, batch):
+    # Per-call state travels in arguments and return values, never on the module: two threads (or two graph captures) may run one
+    # module.  What IS shared, by design and as in the reference: the weights, the usage window `codebook_used` (in-place state, part
+    # of the state dict) and the caches keyed by weight version (_cached: built once, read-only afterwards).
+    def _shared(self, z_text, z_graph, text_mask, batch, norm=None, usage_counts=None):
+        """get_shared_info plus the token ids / weights of its two searches: (embedding, losses, usage, tokens)."""
         pooled_text, pooled_graph, pending = self.cross_attn.pooled(z_text, text_mask, z_graph, batch, join=False)
         if pending is not None:
             # the text side ran on the second stream: its shared search follows it there, beside the graph side's tail and search
             side, main = pending
             with torch.cuda.stream(side):
-                r_t = self._search(pooled_text, "shared", self.training)
-            r_g = self._search(pooled_graph, "shared", self.training)
+                r_t = self._search(pooled_text, "shared", self.training, norm=norm)
+            r_g = self._search(pooled_graph, "shared", self.training, norm=norm)
             _join_side(side, main, (pooled_text, *r_t))
-            zq_t, vq_t, cm_t, xhat_t, idx_t, w_t = r_t
-            zq_g, vq_g, cm_g, xhat_g, idx_g, w_g = r_g
         else:
-            zq_t, vq_t, cm_t, xhat_t, idx_t, w_t = self._search(pooled_text, "shared", self.training)
-            zq_g, vq_g, cm_g, xhat_g, idx_g, w_g = self._search(pooled_graph, "shared", self.training)
-        usage = self.codebook_usage(torch.cat([idx_t, idx_g], dim=-1), types="shared")
-        self._last_tokens = {"shared_text_tokens": idx_t, "shared_text_tokens_weights": w_t,
-                             "shared_graph_tokens": idx_g, "shared_graph_tokens_weights": w_g}
-        return (torch.cat([zq_t, zq_g], dim=-1),
-                (vq_t + vq_g, cm_t + cm_g, xhat_t, xhat_g, zq_t, zq_g), usage)
+            r_t = self._search(pooled_text, "shared", self.training, norm=norm)
+            r_g = self._search(pooled_graph, "shared", self.training, norm=norm)
+        zq_t, vq_t, cm_t, xhat_t, idx_t, w_t = r_t
+        zq_g, vq_g, cm_g, xhat_g, idx_g, w_g = r_g
+        usage = self.codebook_usage(torch.cat([idx_t, idx_g], dim=-1), types="shared", _counts=usage_counts)
+        tokens = {"shared_text_tokens": idx_t, "shared_text_tokens_weights": w_t,
+                  "shared_graph_tokens": idx_g, "shared_graph_tokens_weights": w_g}
+        return (torch.cat([zq_t, zq_g], dim=-1), (vq_t + vq_g, cm_t + cm_g, xhat_t, xhat_g, zq_t, zq_g), usage, tokens)
 
-    def specific_embedding(self, original_embedding, types="text"):
+    def _specific(self, original_embedding, types, norm=None, usage_counts=None):
+        """specific_embedding plus the ids / weights of its search: (zq, losses, usage, idx, w)."""
         if types in ("text", "graph"):
             original_embedding = self.project(original_embedding, types)
-        zq, vq, commit, xhat, idx, w = self._search(original_embedding, types, self.training)
-        usage = self.codebook_usage(idx, types=types + "-specific")
-        self._last_specific = (idx, w)
-        return zq, (vq, commit, xhat, zq), usage
+        zq, vq, commit, xhat, idx, w = self._search(original_embedding, types, self.training, norm=norm)
+        usage = self.codebook_usage(idx, types=types + "-specific", _counts=usage_counts)
+        return zq, (vq, commit, xhat, zq), usage, idx, w
 
-    def codebook_usage(self, min_encoding_indices, types="shared"):
+    # ------------------------------------------------------------------ reference API
+    def get_shared_info(self, z_text, z_graph, text_mask, batch):
+        return self._shared(z_text, z_graph, text_mask, batch)[:3]
+
+    def specific_embedding(self, original_embedding, types="text", return_tokens=False):
+        """reference :187-217.  return_tokens (additive): also the region-local ids [N, k] and softmax weights the reference computes
+        and drops (R3) -- (zq, losses, usage, idx, w)."""
+        r = self._specific(original_embedding, types)
+        return r if return_tokens else r[:3]
+
+    def codebook_usage(self, min_encoding_indices, types="shared", _counts=None):
         """Fraction of codes seen in the sliding id window (reference :219-236).
         Returns a Python float, which costs one host sync per call as in the
-        reference; forward() batches its three calls into one sync."""
+        reference; forward() batches its three calls into one sync (`_counts`: the caller's list of device counts)."""
         if not self.show_usage:
             return 0.0
         count = ops.usage_update_(self.codebook_used, min_encoding_indices, self.n_e)
-        if getattr(self, "_defer_usage", None) is not None:
-            self._defer_usage.append(count)
+        if _counts is not None:
+            _counts.append(count)
             return count
         return count.item() / self.n_e
 
     def forward(self, z, text_features, graph_node_features, text_attention_mask, batch, z_aug=None):
-        self._defer_usage = []          # collect the usage counts on device, sync once at the end
-        if self.training:
-            self._norm_cache = None     # training: re-normalise once per forward (the 4-6 searches of one forward share it)
-        self._in_forward = True
-        try:
-            z_text_embedding, z_graph_embedding = torch.split(z, self.split, dim=-1)
-            aug = (None, None) if z_aug is None else torch.split(z_aug, self.split, dim=-1)
-            early = None
-            if (not self.training and not torch.is_grad_enabled() and z.is_cuda and not torch.is_autocast_enabled()
-                    and 0 < SIDE_STREAM_MIN_CODES <= z.shape[0]):
-                # inference: the modality-specific searches depend on nothing the cross-attention produces: second stream, joined
-                # below; their usage-window updates stay in the reference's order (shared, text, graph, aug text, aug graph: :241-250)
-                side, main = _side_stream(z.device, 1)
-                with torch.cuda.stream(side):
-                    early = [self._search(self.project(x, types), types, False) for x, types in
-                             ((z_text_embedding, "text"), (z_graph_embedding, "graph"), (aug[0], "text"), (aug[1], "graph")) if x is not None]
-            shared_embedding, shared_embed_loss, u_shared = self.get_shared_info(
-                text_features, graph_node_features, text_attention_mask, batch)
-            tokens = dict(self._last_tokens)
-            shared_text_embedding, shared_graph_embedding = torch.split(shared_embedding, self.split, dim=-1)
-            if early is not None:
-                _join_side(side, main, [t for r in early for t in r])
-                results = []
-                for (zq, vq, commit, xhat, idx, w), types in zip(early, ("text", "graph", "text", "graph")):
-                    usage = self.codebook_usage(idx, types=types + "-specific")
-                    results.append((zq, (vq, commit, xhat, zq), usage, idx, w))
-                spec_text, text_specific_loss, u_text, tokens["text_tokens"], tokens["text_tokens_weights"] = results[0]
-                spec_graph, graph_specific_loss, u_graph, tokens["graph_tokens"], tokens["graph_tokens_weights"] = results[1]
-                spec_text_aug = results[2][0] if z_aug is not None else None
-                spec_graph_aug = results[3][0] if z_aug is not None else None
-            else:
-                spec_text, text_specific_loss, u_text = self.specific_embedding(z_text_embedding, types="text")
-                tokens["text_tokens"], tokens["text_tokens_weights"] = self._last_specific
-                spec_graph, graph_specific_loss, u_graph = self.specific_embedding(z_graph_embedding, types="graph")
-                tokens["graph_tokens"], tokens["graph_tokens_weights"] = self._last_specific
-                if z_aug is not None:
-                    # the reference discards these two usage values but its window still slides (:249-250)
-                    spec_text_aug, _, _ = self.specific_embedding(aug[0], types="text")
-                    spec_graph_aug, _, _ = self.specific_embedding(aug[1], types="graph")
-                else:
-                    spec_text_aug = None
-                    spec_graph_aug = None
-            deferred = self._defer_usage[:3]
-        finally:
-            self._defer_usage = None
-            self._in_forward = False
-        if self.show_usage and deferred:
-            u_shared, u_text, u_graph = (torch.stack(deferred).cpu().double() / self.n_e).tolist()
+        counts = []                     # the usage counts stay on the device: one sync at the end
+        # one normalisation of the codebook per forward (training: re-normalised every forward, like the reference's every call;
+        # eval: the cache per weight version), shared by its 4-6 searches
+        norm = self._normalised_codebook(rebuild=self.training)
+        z_text_embedding, z_graph_embedding = torch.split(z, self.split, dim=-1)
+        aug = (None, None) if z_aug is None else torch.split(z_aug, self.split, dim=-1)
+        early = None
+        if (not self.training and not torch.is_grad_enabled() and z.is_cuda and not torch.is_autocast_enabled()
+                and 0 < SIDE_STREAM_MIN_CODES <= z.shape[0]):
+            # inference: the modality-specific searches depend on nothing the cross-attention produces: second stream, joined
+            # below; their usage-window updates stay in the reference's order (shared, text, graph, aug text, aug graph: :241-250)
+            side, main = _side_stream(z.device, 1)
+            _lend(side, norm)
+            with torch.cuda.stream(side):
+                early = [self._search(self.project(x, types), types, False, norm=norm) for x, types in
+                         ((z_text_embedding, "text"), (z_graph_embedding, "graph"), (aug[0], "text"), (aug[1], "graph")) if x is not None]
+        shared_embedding, shared_embed_loss, u_shared, tokens = self._shared(
+            text_features, graph_node_features, text_attention_mask, batch, norm=norm, usage_counts=counts)
+        shared_text_embedding, shared_graph_embedding = torch.split(shared_embedding, self.split, dim=-1)
+        if early is not None:
+            _join_side(side, main, [t for r in early for t in r])
+            results = []
+            for (zq, vq, commit, xhat, idx, w), types in zip(early, ("text", "graph", "text", "graph")):
+                usage = self.codebook_usage(idx, types=types + "-specific", _counts=counts)
+                results.append((zq, (vq, commit, xhat, zq), usage, idx, w))
+        else:
+            results = [self._specific(z_text_embedding, "text", norm, counts), self._specific(z_graph_embedding, "graph", norm, counts)]
+            if z_aug is not None:
+                # the reference discards these two usage values but its window still slides (:249-250)
+                results += [self._specific(aug[0], "text", norm, counts), self._specific(aug[1], "graph", norm, counts)]
+        spec_text, text_specific_loss, u_text, tokens["text_tokens"], tokens["text_tokens_weights"] = results[0]
+        spec_graph, graph_specific_loss, u_graph, tokens["graph_tokens"], tokens["graph_tokens_weights"] = results[1]
+        spec_text_aug = results[2][0] if z_aug is not None else None
+        spec_graph_aug = results[3][0] if z_aug is not None else None
+        if self.show_usage and counts:
+            u_shared, u_text, u_graph = (torch.stack(counts[:3]).cpu().double() / self.n_e).tolist()
         out = {
             "graph_feature": z_graph_embedding,
             "text_feature": z_text_embedding,

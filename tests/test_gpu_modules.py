@@ -47,8 +47,7 @@ def test_specific_embedding_eval_and_train(golden, dev, name):
         v.eval()
         v.codebook_used.zero_()
         with torch.no_grad():
-            zq, (vq, cm, xhat, zq2), usage = v.specific_embedding(x, types=t)
-        idx, w = v._last_specific
+            zq, (vq, cm, xhat, zq2), usage, idx, w = v.specific_embedding(x, types=t, return_tokens=True)
         assert same_ids(idx, g[f"{t}.idx"])
         assert rel(w, g[f"{t}.w"]) <= RTOL
         assert rel(zq, g[f"{t}.eval.zq"]) <= RTOL and zq2 is zq
@@ -230,8 +229,8 @@ def test_quantize_pooled_equals_forward_searches(dev):
     h = torch.randn(777, 256, device=dev); pt = torch.randn(777, 128, device=dev); pg = torch.randn(777, 128, device=dev)
     emb, tok, w = quantize_pooled(v, h, pt, pg)
     assert emb.shape == (777, 512) and tok.shape == (777, 4, 5) and w.shape == (777, 4, 5)
-    zq, _, _ = v.specific_embedding(h[:, :128], "text")
-    assert torch.equal(zq, emb[:, :128]) and torch.equal(v._last_specific[0], tok[:, 0])
+    zq, _, _, ids_text, _ = v.specific_embedding(h[:, :128], "text", return_tokens=True)
+    assert torch.equal(zq, emb[:, :128]) and torch.equal(ids_text, tok[:, 0])
     assert int(tok[:, :2].max()) < 512 and int(tok[:, 2:].max()) < 1536
     assert torch.allclose(w.sum(-1), torch.ones_like(w.sum(-1)), atol=1e-6)
 

@@ -57,8 +57,7 @@ def test_codebook_cache_follows_data_writes(dev):
 
     def ids():
         with torch.no_grad():
-            v.specific_embedding(x, "text")
-        return v._last_specific[0].clone()
+            return v.specific_embedding(x, "text", return_tokens=True)[3].clone()
 
     v.train()
     a = ids()
@@ -67,8 +66,8 @@ def test_codebook_cache_follows_data_writes(dev):
     w2 = VectorQuantizer(3 * 512, D, 0.25, 0.0, True, False, [D, D]).to(dev).train()
     w2.load_state_dict(v.state_dict())
     with torch.no_grad():
-        w2.specific_embedding(x, "text")
-    assert torch.equal(b, w2._last_specific[0]) and not torch.equal(a, b)
+        ids2 = w2.specific_embedding(x, "text", return_tokens=True)[3]
+    assert torch.equal(b, ids2) and not torch.equal(a, b)
     v.eval()
     c = ids()
     assert torch.equal(c, b)                             # the mode switch dropped the cache
@@ -141,3 +140,51 @@ def test_empty_batch_through_the_modules(dev):
     with torch.no_grad():
         zq, loss, idx = q(torch.empty(0, D, 1, 1, device=dev))
     assert zq.shape == (0, D, 1, 1) and idx.shape == (0,)
+
+
+@pytest.mark.parametrize("bsz", [48, 640])
+def test_two_threads_through_one_module_return_the_single_thread_bits(dev, bsz):
+    """Per-call state travels in arguments and return values, not on the module ("pure w.r.t. inputs except documented
+    in-place state"): two Python threads run forward() of ONE VectorQuantizer on different batches at the same time, many times;
+    each must get exactly what a single-threaded call returns for its batch.  (show_usage=False: the usage window IS shared
+    in-place state, as in the reference.)  bsz = 640 takes the side-stream path, whose streams the threads share."""
+    import threading
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    torch.manual_seed(5)
+    D, L = 128, 24
+    v = VectorQuantizer(3 * 256, D, 0.25, 0.0, True, False, [D, D]).to(dev).eval()
+
+    def batch(seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        tok = torch.randint(1, L + 1, (bsz,), device=dev, generator=g)
+        mask = (torch.arange(L, device=dev)[None, :] < tok[:, None]).to(torch.int64)
+        n_nodes = torch.randint(1, 7, (bsz,), device=dev, generator=g)
+        return (torch.randn(bsz, 2 * D, device=dev, generator=g), torch.randn(bsz, L, D, device=dev, generator=g),
+                torch.randn(int(n_nodes.sum()), D, device=dev, generator=g), mask, torch.repeat_interleave(torch.arange(bsz, device=dev), n_nodes))
+    inputs = [batch(1), batch(2)]
+    keys = ("shared_text_embedding", "shared_graph_embedding", "specific_embedding_text", "specific_embedding_graph", "text_tokens",
+            "graph_tokens", "shared_text_tokens", "shared_graph_tokens", "text_tokens_weights", "shared_graph_tokens_weights")
+    with torch.no_grad():
+        want = [{k: v(*a)[k].clone() for k in keys} for a in inputs]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(dev)
+            with torch.no_grad():
+                for _ in range(15):
+                    r = v(*inputs[i])
+                    got = {k: r[k].clone() for k in keys}
+                    torch.cuda.synchronize()
+                    for k in keys:
+                        if not torch.equal(got[k], want[i][k]):
+                            errors.append((i, k))
+        except Exception as exc:            # (a thread's exception must fail the test, not vanish)
+            errors.append((i, repr(exc)))
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
