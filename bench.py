@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--text-layers", type=int, default=12, help="cfg4: transformer layers of the BERT-shaped stand-in text encoder (12 = BERT-base)")
-    ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg4", "cfg5", "full", "codeshard"], default="cfg3",
+    ap.add_argument("--workload", choices=["cfg3", "cfg2", "cfg4", "cfg5", "full", "codeshard", "refdefault", "fullref"], default="cfg3",
                     help="cfg3: full soft VQ (headline); full: cfg3 plus the ragged cross-attention of get_shared_info in front of it; cfg2: argmin+EMA train step, 100k rows, K=8192; cfg4: BASELINE config 4 -- one train step (stand-in BERT-shaped text encoder + 2-layer GAT -> soft VQ with aug view -> loss.py -> backward -> clip -> Adam) on 256 codes/GPU under bf16 autocast, L=512; codeshard: one K=49152 soft top-5 search with the CODEBOOK sharded over the GPUs (every rank scores all rows "
                          "against its slice; all-gather of the k-lists + exact merge); cfg5: the same step on 600k rows "
                          "TOTAL (split over the GPUs: strong scaling), K=16384, with the RCCL all-reduce of the EMA statistics")
@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-collectives", action="store_true", help="N > 1, headline workload: skip the extra cfg5 / codeshard strong-scaling block")
     ap.add_argument("--exact-steps", type=int, default=1, help="extra steps on the exact fp32-MFMA path for comparison (0 disables)")
     ap.add_argument("--one-stream", action="store_true", help="full workload: the whole run on ONE HIP stream (no side streams)")
+    ap.add_argument("--no-half-text-pass", action="store_true",
+                    help="full workload: skip the extra pass with fp16 text features (what a caller under fp16 autocast hands over)")
     ap.add_argument("--no-one-stream-pass", action="store_true",
                     help="full workload: skip the second, one-stream pass that times the kernels for the roofline object (timeline captures)")
     return ap.parse_args()
@@ -145,6 +147,30 @@ class Cfg3:
         return cpu_protocol(run, sample_rows, 1, "4 searches per code, K=16384/49152, D=768")
 
 
+class RefDefault(Cfg3):
+    """The four searches at the shape MedTok ships (train_MedTok.py:363-368): e_dim = 64, n_e = 21 000 (regions of 7 000
+    codes), k = 5 -- cross-attention pooling already applied, as in cfg3."""
+    name = "refdefault"
+    D, REGION, TOPK = 64, 7000, 5
+    N_E = 21000
+
+    def __init__(self, rows, dev, seed, path):
+        super().__init__(rows, dev, seed, path)
+        self.description = (f"refdefault: the four searches of the soft VQ at the reference's default shape: {rows} codes/GPU, e_dim = 64, "
+                            f"n_e = 21000 (2 x K=7000 regions + 2 x K=21000 shared), k=5, eval, fp32; proj Linear + normalise + search + softmax/mix/STE per code")
+
+    def cpu_baseline(self, sample_rows):
+        from oracle import torch_port as P
+        g = torch.Generator().manual_seed(0)
+        W = torch.randn(self.N_E, self.D, generator=g)
+        xs = [torch.randn(sample_rows, self.D, generator=g) for _ in range(4)]
+
+        def run(rows, threads):
+            torch.set_num_threads(threads)
+            P.full_tokenize(*[x[:rows] for x in xs], W, self.TOPK)
+        return cpu_protocol(run, sample_rows, 1, "4 searches per code, K=7000/21000, D=64")
+
+
 class Full(Cfg3):
     """VectorQuantizer.forward end to end (vector_quantization_soft_one_new.py:238-271): ragged cross-attention over the text tokens
     and graph nodes of every code -> pooled rows -> the four searches of cfg3.  Inputs are the encoders' outputs, resident in HBM."""
@@ -217,6 +243,20 @@ class Full(Cfg3):
         dt = time.perf_counter() - t0
         return dict(value=n / dt, unit="codes/s", cores=threads, kind="port",
                     sample=f"{n} codes: per-code cross-attention loop (the reference's form) + 4 dense searches in CPU PyTorch, {dt:.1f} s")
+
+
+class FullRefDefault(Full):
+    """VectorQuantizer.forward end to end at the reference's default shape and per-GPU batch (train_MedTok.py:363-368,387: e_dim = 64,
+    n_e = 21 000, B = 256, <= 512 tokens): ragged cross-attention + the four searches."""
+    name = "fullref"
+    D, REGION, TOPK = 64, 7000, 5
+    N_E = 21000
+
+    def __init__(self, rows, dev, seed, path):
+        super().__init__(rows, dev, seed, path)
+        self.description = (f"full VectorQuantizer.forward at the reference's default shape: {rows} codes/GPU/step (256 = its per-GPU batch), "
+                            f"ragged cross-attention (<= {self.L} tokens x <= {self.MAX_NODES} nodes per code, 4 heads, 2 layers per direction) + 4 "
+                            f"searches, e_dim = 64, n_e = 21000, k=5, eval, fp32")
 
 
 class CodeShard:
@@ -552,8 +592,8 @@ def main():
         rows = args.rows or 256
         wl = Cfg4(rows, dev, seed=rank, path=args.path, text_layers=args.text_layers)
     else:
-        rows = args.rows or {"cfg3": 600000, "full": 4096}.get(args.workload, 100000)
-        wl = {"cfg3": Cfg3, "full": Full}.get(args.workload, Cfg2)(rows, dev, seed=rank, path=args.path)
+        rows = args.rows or {"cfg3": 600000, "full": 4096, "refdefault": 600000, "fullref": 256}.get(args.workload, 100000)
+        wl = {"cfg3": Cfg3, "full": Full, "refdefault": RefDefault, "fullref": FullRefDefault}.get(args.workload, Cfg2)(rows, dev, seed=rank, path=args.path)
 
     for _ in range(args.warmup):
         wl.step()
@@ -571,7 +611,7 @@ def main():
     prof = ops.profile_end()
     prof_note = None
     one_stream_elapsed = None
-    if args.workload == "full" and not args.no_one_stream_pass and not args.one_stream:
+    if args.workload in ("full", "fullref") and not args.no_one_stream_pass and not args.one_stream:
         # The forward enqueues on several HIP streams: an event pair around a launch then also covers the other streams' kernels that
         # share the device with it (a 0.05 ms text-side product is "1.3 ms" beside the graph side's attention).  Kernel durations for
         # the roofline object come from a second pass of the same steps on ONE stream; `value` is the multi-stream timed region above.
@@ -592,6 +632,25 @@ def main():
             vqmod.SIDE_STREAM_MIN_CODES = keep
         prof_note = ("kernel durations from a second pass of the same steps on one stream (event pairs of overlapping streams include each "
                      "other's kernels); value / ms_per_step are the multi-stream timed region")
+
+    # full workload, extra: the same forward with the text features in fp16 -- what a caller under fp16 autocast hands over (the
+    # reference's default mode, train_MedTok.py:212,394): no image pass, half the key bytes, two matrix passes per product
+    half_text = None
+    if args.workload == "full" and not args.no_half_text_pass:
+        text32 = wl.text
+        try:
+            wl.text = text32.half()
+            wl.step(); wl.step()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                wl.step()
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t1
+            half_text = {"value": float(rows) * world * args.steps / dt, "unit": "codes/s", "ms_per_step": dt / args.steps * 1e3,
+                         "note": "the same steps with the text features handed over in fp16 (rank-local timing; every other input fp32)"}
+        finally:
+            wl.text = text32
 
     # the exact fp32-MFMA path on the same workload (1 step): the filter path returns the same bits, faster
     exact = None
@@ -706,9 +765,11 @@ def main():
         }
         if strong is not None:
             line["extra"] = {"strong_scaling": strong}
-        if args.workload == "full":
+        if args.workload in ("full", "fullref"):
             # both stream settings in one line: `value` is the forward as shipped (side streams from 512 codes up) unless --one-stream
             line["config"]["streams"] = "one (--one-stream)" if args.one_stream else "main + 3 side streams (modality-specific searches, text images, text side)"
+            if half_text is not None:
+                line["half_precision_text"] = half_text
             if one_stream_elapsed is not None:
                 line["one_stream"] = {"value": float(rows) * world * args.steps / one_stream_elapsed, "unit": "codes/s",
                                       "ms_per_step": one_stream_elapsed / args.steps * 1e3,
@@ -720,7 +781,7 @@ def main():
             line["config"]["vq_path_ms_per_step"] = max(line["ms_per_step"] - enc, 0.0)
             line["config"]["note"] = ("stand-in encoders (out of scope, upstream of the path); vq_path = cross-attention + 6 searches + "
                                       "loss.py + backward + clip + AdamW = step - encoders")
-        cpu_rows = args.cpu_rows if args.cpu_rows is not None else {"full": 512, "cfg4": 256}.get(args.workload, 16384)
+        cpu_rows = args.cpu_rows if args.cpu_rows is not None else {"full": 512, "fullref": 512, "cfg4": 256}.get(args.workload, 16384)
         if world == 1 and cpu_rows > 0:
             line["cpu_baseline"] = wl.cpu_baseline(cpu_rows)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -646,10 +646,11 @@ __global__ __launch_bounds__(256) void shared_kv_attention_fewq_kernel(
 // y_hi / y_lo (optional): the (hi, lo) fp16 images [n, dp] of y as medtok_split_half_f32 would make them (dp >= d, zero columns
 // appended) -- the next layer's first dense product reads them, and a separate pass over y is saved.
 constexpr int LN_MAXV = 16;
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void residual_layernorm_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                  long n, int d, float eps, float *__restrict__ y,
-                                                                 _Float16 *__restrict__ y_hi = nullptr, _Float16 *__restrict__ y_lo = nullptr, int dp = 0)
+                                                                 _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int dp)
 {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(256) void residual_layernorm_kernel(const float *__
             const float4 o = make_float4(fmaf(v[t].x * rstd, g.x, h.x), fmaf(v[t].y * rstd, g.y, h.y), fmaf(v[t].z * rstd, g.z, h.z),
                                          fmaf(v[t].w * rstd, g.w, h.w));
             st4(py + 4 * c, o);
-            if (y_hi) {
+            if (SPLIT) {
                 half4v hh, ll;
                 hh[0] = (_Float16)o.x; hh[1] = (_Float16)o.y; hh[2] = (_Float16)o.z; hh[3] = (_Float16)o.w;
                 ll[0] = (_Float16)(o.x - (float)hh[0]); ll[1] = (_Float16)(o.y - (float)hh[1]);
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(256) void residual_layernorm_kernel(const float *__
                 *reinterpret_cast<half4v *>(y_hi + row * dp + 4 * c) = hh;
                 *reinterpret_cast<half4v *>(y_lo + row * dp + 4 * c) = ll;
             }
-        } else if (y_hi && 4 * c < dp) {
+        } else if (SPLIT && 4 * c < dp) {
             const half4v z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
             *reinterpret_cast<half4v *>(y_hi + row * dp + 4 * c) = z;
             *reinterpret_cast<half4v *>(y_lo + row * dp + 4 * c) = z;

@@ -47,7 +47,11 @@ __device__ __forceinline__ float pp_exp(float x) { return __builtin_amdgcn_exp2f
 // ABL (dev builds of tools/r04 only; the product instantiates ABL = 0): timing ablations -- bit 0: no MFMAs, bit 1: no key copies
 // after the first two chunks, bit 2: no softmax step, bit 3: per-wave cycle counts of the phases into `dbg`.  Results are garbage
 // for bits 0-2.
-template <int NT, int ABL = 0>
+// KLO = false: the keys are fp16 as they stand (a caller under fp16 autocast hands over half-precision text features, the
+// reference's default training mode train_MedTok.py:212,394): there is no lo image -- kvl is not read, a chunk is one plane (half
+// the bytes from HBM and through the DMA), and the passes against it drop out of both products (two MFMAs per step instead of
+// three).  With lo = 0 the three-pass form adds exact zeros, so the results equal the KLO form on the widened keys bit for bit.
+template <int NT, int ABL = 0, bool KLO = true>
 __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
     const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
     const _Float16 *__restrict__ kvh, const _Float16 *__restrict__ kvl, const int64_t *__restrict__ kv_start,
@@ -79,15 +83,17 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
     float *alpha_s = reinterpret_cast<float *>(pl + 32 * PSL), *l_s = alpha_s + 32;
 
     // ---- key chunks by LDS-DMA: this wave copies plane `grp` of column slice `w` (attention_dma.h: lane = (key, piece position))
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((grp ? kvl : kvh) + ks * (long)D), 0, (int)0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((KLO && grp) ? kvl : kvh) + ks * (long)D), 0, (int)0x7fffffff, 0x00020000);
+    constexpr int DMA_PER_CHUNK = KLO ? NT : NT / 2;     // (one plane: group g copies the k blocks p = g, g + 2, ... of it)
     const int d_key = lane >> 2, d_col = slice + 8 * ((lane & 3) ^ ((0 - (lane >> 4)) & 3));
     auto stage = [&](int c) __attribute__((always_inline)) {
         const int key = min(16 * c + d_key, kl - 1);                    // past the last key: re-read it (its probability is zero)
         const int voff = (key * D + d_col) * 2;
-        char *base = ring + (c & 1) * CHUNKB + w * 2 * PLANEB + grp * PLANEB;
+        char *base = ring + (c & 1) * CHUNKB + w * 2 * PLANEB + (KLO ? grp * PLANEB : 0);
 #pragma unroll
         for (int p = 0; p < NT; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(base + p * PIECE), 16, voff, 64 * p, 0, 0);
+            if (KLO || (p & 1) == grp)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(base + p * PIECE), 16, voff, 64 * p, 0, 0);
     };
     const int nchunk = (kl + 15) >> 4;
 
@@ -140,8 +146,10 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
 
     // chunk 0 has landed everywhere (chunk 1, issued behind it, may still be in flight: loads complete in order)
     if (nchunk > 1) {
-        if (NT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (NT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (DMA_PER_CHUNK == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (DMA_PER_CHUNK == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (DMA_PER_CHUNK == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (DMA_PER_CHUNK == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -164,21 +172,32 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
         // statement with the registers as in/out operands, so that hipcc cannot schedule a use (or a copy) in front of it.
         const unsigned ka = k_adr + cb;
         u32x4 kbuf[2][2];
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(kbuf[0][0]), "=&v"(kbuf[0][1]) : "v"(ka), "i"(PLANEB) : "memory");
+        if (KLO) asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(kbuf[0][0]), "=&v"(kbuf[0][1]) : "v"(ka), "i"(PLANEB) : "memory");
+        else asm volatile("ds_read_b128 %0, %1" : "=&v"(kbuf[0][0]) : "v"(ka) : "memory");
 #pragma unroll
         for (int s = 0; s < NT; ++s) {
             u32x4 &kh = kbuf[s & 1][0], &kq = kbuf[s & 1][1];
-            if (s + 1 < NT)
-                asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\ts_waitcnt lgkmcnt(2)"
-                             : "=&v"(kbuf[(s + 1) & 1][0]), "=&v"(kbuf[(s + 1) & 1][1]), "+v"(kh), "+v"(kq)
-                             : "v"(ka), "i"((s + 1) * PIECE), "i"(PLANEB + (s + 1) * PIECE) : "memory");
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kh), "+v"(kq) : : "memory");
-            const half8 bh = __builtin_bit_cast(half8, kh), bl = __builtin_bit_cast(half8, kq);
+            if (KLO) {
+                if (s + 1 < NT)
+                    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\ts_waitcnt lgkmcnt(2)"
+                                 : "=&v"(kbuf[(s + 1) & 1][0]), "=&v"(kbuf[(s + 1) & 1][1]), "+v"(kh), "+v"(kq)
+                                 : "v"(ka), "i"((s + 1) * PIECE), "i"(PLANEB + (s + 1) * PIECE) : "memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kh), "+v"(kq) : : "memory");
+            } else {
+                if (s + 1 < NT)
+                    asm volatile("ds_read_b128 %0, %2 offset:%3\n\ts_waitcnt lgkmcnt(1)" : "=&v"(kbuf[(s + 1) & 1][0]), "+v"(kh) : "v"(ka), "i"((s + 1) * PIECE) : "memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kh) : : "memory");
+            }
+            const half8 bh = __builtin_bit_cast(half8, kh);
 #pragma unroll
             for (int i = 0; i < 2; ++i) sacc[i] = PP_MFMA16(qlo[i][s], bh, sacc[i], 0, 0, 0);
+            if (KLO) {
+                const half8 bl = __builtin_bit_cast(half8, kq);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) sacc[i] = PP_MFMA16(qh[i][s], bl, sacc[i], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) sacc[i] = PP_MFMA16(qh[i][s], bl, sacc[i], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) sacc[i] = PP_MFMA16(qh[i][s], bh, sacc[i], 0, 0, 0);
         }
@@ -250,34 +269,54 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
         u32x4 px[2];
         const unsigned p_adr = (unsigned)(size_t)ph + (unsigned)((li * PSL + 8 * lh) * 2);
         const unsigned va0 = v_adr[0] + cb, va1 = v_adr[1] + cb;
-        u32x2 vb[3][4];                                // [set][h0, h1, l0, l1]
+        u32x2 vb[3][4];                                // [set][h0, h1, l0, l1]  (KLO = false: h0, h1 only)
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(px[0]), "=&v"(px[1]) : "v"(p_adr), "i"(32 * PSL * 2) : "memory");
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-            asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %5 offset:%6\n\t"
-                         "ds_read_b64_tr_b16 %2, %4 offset:%7\n\tds_read_b64_tr_b16 %3, %5 offset:%7"
-                         : "=&v"(vb[tt][0]), "=&v"(vb[tt][1]), "=&v"(vb[tt][2]), "=&v"(vb[tt][3])
-                         : "v"(va0), "v"(va1), "i"(tt * PIECE), "i"(PLANEB + tt * PIECE) : "memory");
+        for (int tt = 0; tt < 2; ++tt) {
+            if (KLO)
+                asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %5 offset:%6\n\t"
+                             "ds_read_b64_tr_b16 %2, %4 offset:%7\n\tds_read_b64_tr_b16 %3, %5 offset:%7"
+                             : "=&v"(vb[tt][0]), "=&v"(vb[tt][1]), "=&v"(vb[tt][2]), "=&v"(vb[tt][3])
+                             : "v"(va0), "v"(va1), "i"(tt * PIECE), "i"(PLANEB + tt * PIECE) : "memory");
+            else
+                asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"
+                             : "=&v"(vb[tt][0]), "=&v"(vb[tt][1]) : "v"(va0), "v"(va1), "i"(tt * PIECE) : "memory");
+        }
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
             u32x2 (&cur)[4] = vb[tt % 3];
-            if (tt + 2 < NT) {
-                u32x2 (&nxt)[4] = vb[(tt + 2) % 3];
-                asm volatile("ds_read_b64_tr_b16 %0, %10 offset:%12\n\tds_read_b64_tr_b16 %1, %11 offset:%12\n\t"
-                             "ds_read_b64_tr_b16 %2, %10 offset:%13\n\tds_read_b64_tr_b16 %3, %11 offset:%13\n\ts_waitcnt lgkmcnt(8)"
-                             : "=&v"(nxt[0]), "=&v"(nxt[1]), "=&v"(nxt[2]), "=&v"(nxt[3]), "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]),
-                               "+v"(px[0]), "+v"(px[1])
-                             : "v"(va0), "v"(va1), "i"((tt + 2) * PIECE), "i"(PLANEB + (tt + 2) * PIECE) : "memory");
-            } else if (tt + 1 < NT) {
-                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(px[0]), "+v"(px[1]) : : "memory");
+            if (KLO) {
+                if (tt + 2 < NT) {
+                    u32x2 (&nxt)[4] = vb[(tt + 2) % 3];
+                    asm volatile("ds_read_b64_tr_b16 %0, %10 offset:%12\n\tds_read_b64_tr_b16 %1, %11 offset:%12\n\t"
+                                 "ds_read_b64_tr_b16 %2, %10 offset:%13\n\tds_read_b64_tr_b16 %3, %11 offset:%13\n\ts_waitcnt lgkmcnt(8)"
+                                 : "=&v"(nxt[0]), "=&v"(nxt[1]), "=&v"(nxt[2]), "=&v"(nxt[3]), "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]),
+                                   "+v"(px[0]), "+v"(px[1])
+                                 : "v"(va0), "v"(va1), "i"((tt + 2) * PIECE), "i"(PLANEB + (tt + 2) * PIECE) : "memory");
+                } else if (tt + 1 < NT) {
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(px[0]), "+v"(px[1]) : : "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(px[0]), "+v"(px[1]) : : "memory");
+                }
             } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(px[0]), "+v"(px[1]) : : "memory");
+                if (tt + 2 < NT) {
+                    u32x2 (&nxt)[4] = vb[(tt + 2) % 3];
+                    asm volatile("ds_read_b64_tr_b16 %0, %6 offset:%8\n\tds_read_b64_tr_b16 %1, %7 offset:%8\n\ts_waitcnt lgkmcnt(4)"
+                                 : "=&v"(nxt[0]), "=&v"(nxt[1]), "+v"(cur[0]), "+v"(cur[1]), "+v"(px[0]), "+v"(px[1])
+                                 : "v"(va0), "v"(va1), "i"((tt + 2) * PIECE) : "memory");
+                } else if (tt + 1 < NT) {
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(px[0]), "+v"(px[1]) : : "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(px[0]), "+v"(px[1]) : : "memory");
+                }
             }
             const half8 vh = __builtin_bit_cast(half8, __builtin_shufflevector(cur[0], cur[1], 0, 1, 2, 3));
-            const half8 vl = __builtin_bit_cast(half8, __builtin_shufflevector(cur[2], cur[3], 0, 1, 2, 3));
             const half8 ph0 = __builtin_bit_cast(half8, px[0]), pl0 = __builtin_bit_cast(half8, px[1]);
             acc[tt] = PP_MFMA32(pl0, vh, acc[tt], 0, 0, 0);
-            acc[tt] = PP_MFMA32(ph0, vl, acc[tt], 0, 0, 0);
+            if (KLO) {
+                const half8 vl = __builtin_bit_cast(half8, __builtin_shufflevector(cur[2], cur[3], 0, 1, 2, 3));
+                acc[tt] = PP_MFMA32(ph0, vl, acc[tt], 0, 0, 0);
+            }
             acc[tt] = PP_MFMA32(ph0, vh, acc[tt], 0, 0, 0);
         }
     };

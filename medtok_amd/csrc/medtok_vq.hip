@@ -1496,7 +1496,9 @@ extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_
     if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention_split: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
     if (!attention_dma_shape_ok(d)) return fail("shared_kv_attention_split: d=%d must be 128, 256, 384, 512 or 768", d);
     if (n_codes == 0 || max_q_len == 0) return 0;
-    if (!q || !q_start || !q_len || !kv_hi || !kv_lo || !kv_start || !kv_len || (!out && !out_hi)) return fail("shared_kv_attention_split: NULL argument");
+    const bool pp_shape = (variant & 15) == 2 && (d == 256 || d == 512 || d == 768);
+    if (!q || !q_start || !q_len || !kv_hi || !kv_start || !kv_len || (!out && !out_hi)) return fail("shared_kv_attention_split: NULL argument");
+    if (!kv_lo && !pp_shape) return fail("shared_kv_attention_split: keys without a lo image (fp16 keys as they stand) need variant 2 and d = 256, 512 or 768");
     if (((uintptr_t)q | (uintptr_t)kv_hi | (uintptr_t)kv_lo | (uintptr_t)out) & 15) return fail("shared_kv_attention_split: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
@@ -1511,23 +1513,24 @@ extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_
                            lds, s, q, q_start, q_len, (const _Float16 *)kv_hi, (const _Float16 *)kv_lo, kv_start, kv_len, scale, out, \
                            (_Float16 *)out_hi, (_Float16 *)out_lo, (int)q_tiles, (int)n_codes);                                  \
     } while (0)
-    if ((variant & 15) == 2 && (d == 256 || d == 512 || d == 768)) {
+    if (pp_shape) {
         // two 32-row tiles of a code per block, run one phase apart on one copy of the keys (attention_pp.h)
         const int64_t q_pairs = (max_q_len + 63) / 64;
         if (q_pairs * (n_codes + 8) >= (1ll << 31)) return fail("shared_kv_attention_split: grid limit exceeded");
-#define MEDTOK_ATT_PP(NT, ABL)                                                                                                    \
+#define MEDTOK_ATT_PP(NT, ABL, KLO)                                                                                               \
     do {                                                                                                                          \
         const size_t lds = AttPP<NT>::LDS_BYTES;                                                                                  \
-        if (!set_lds_once<shared_kv_attention_pp_kernel<NT, ABL>>(lds)) return fail("shared_kv_attention_split: cannot reserve %zu bytes of LDS", lds); \
-        hipLaunchKernelGGL((shared_kv_attention_pp_kernel<NT, ABL>), dim3((unsigned)(q_pairs * ((n_codes + 7) / 8 * 8))), dim3(512), lds, s, q, q_start, \
+        if (!set_lds_once<shared_kv_attention_pp_kernel<NT, ABL, KLO>>(lds)) return fail("shared_kv_attention_split: cannot reserve %zu bytes of LDS", lds); \
+        hipLaunchKernelGGL((shared_kv_attention_pp_kernel<NT, ABL, KLO>), dim3((unsigned)(q_pairs * ((n_codes + 7) / 8 * 8))), dim3(512), lds, s, q, q_start, \
                            q_len, (const _Float16 *)kv_hi, (const _Float16 *)kv_lo, kv_start, kv_len, scale, out, (_Float16 *)out_hi,             \
                            (_Float16 *)out_lo, (int)q_pairs, (int)n_codes, (unsigned long long *)g_att_dbg);                      \
     } while (0)
         const int abl = variant >> 4;
-        if (d == 256) MEDTOK_ATT_PP(2, 0); else if (d == 512) MEDTOK_ATT_PP(4, 0);
-        else if (abl == 1) MEDTOK_ATT_PP(6, 1); else if (abl == 2) MEDTOK_ATT_PP(6, 2); else if (abl == 3) MEDTOK_ATT_PP(6, 3);
-        else if (abl == 4) MEDTOK_ATT_PP(6, 4); else if (abl == 7) MEDTOK_ATT_PP(6, 7); else if (abl == 8) MEDTOK_ATT_PP(6, 8);
-        else MEDTOK_ATT_PP(6, 0);
+        if (!kv_lo) { if (d == 256) MEDTOK_ATT_PP(2, 0, false); else if (d == 512) MEDTOK_ATT_PP(4, 0, false); else MEDTOK_ATT_PP(6, 0, false); }
+        else if (d == 256) MEDTOK_ATT_PP(2, 0, true); else if (d == 512) MEDTOK_ATT_PP(4, 0, true);
+        else if (abl == 1) MEDTOK_ATT_PP(6, 1, true); else if (abl == 2) MEDTOK_ATT_PP(6, 2, true); else if (abl == 3) MEDTOK_ATT_PP(6, 3, true);
+        else if (abl == 4) MEDTOK_ATT_PP(6, 4, true); else if (abl == 7) MEDTOK_ATT_PP(6, 7, true); else if (abl == 8) MEDTOK_ATT_PP(6, 8, true);
+        else MEDTOK_ATT_PP(6, 0, true);
 #undef MEDTOK_ATT_PP
         if (pa) prof_push(pa, prof_mark(s), 0.0, 2);
         return check_launch("shared_kv_attention_split(pp)");
@@ -1538,7 +1541,7 @@ extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_
     case 384: MEDTOK_ATT_DMA(4, 3, 2, 2); break;
     case 512: MEDTOK_ATT_DMA(8, 2, 2, 2); break;
     default:                               // 768: variant 0 = 32 rows per block, two blocks per CU; 1 = 64 rows per block, one per CU
-        if (variant == 1) MEDTOK_ATT_DMA(8, 3, 2, 2); else if (variant == 3) MEDTOK_ATT_DMA(4, 6, 2, 2); else MEDTOK_ATT_DMA(4, 6, 1, 1);
+        if (variant == 1) MEDTOK_ATT_DMA(8, 3, 2, 2); else MEDTOK_ATT_DMA(4, 6, 1, 1);
         break;
     }
 #undef MEDTOK_ATT_DMA
@@ -1610,8 +1613,12 @@ extern "C" int medtok_residual_layernorm_split_f32(const float *a, const float *
     if (!a || !b || !gamma || !beta || !y) return fail("residual_layernorm: NULL argument");
     if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)y_hi | (uintptr_t)y_lo) & 15) return fail("residual_layernorm: pointers must be 16-byte aligned");
     if ((n + 3) / 4 >= (1ll << 31)) return fail("residual_layernorm: too many rows");
-    hipLaunchKernelGGL(residual_layernorm_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, gamma, beta, (long)n, d, eps, y,
-                       (_Float16 *)y_hi, (_Float16 *)y_lo, dp);
+    if (y_hi)
+        hipLaunchKernelGGL(residual_layernorm_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, gamma, beta, (long)n, d, eps, y,
+                           (_Float16 *)y_hi, (_Float16 *)y_lo, dp);
+    else
+        hipLaunchKernelGGL(residual_layernorm_kernel<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, gamma, beta, (long)n, d, eps, y,
+                           (_Float16 *)nullptr, (_Float16 *)nullptr, 0);
     return check_launch("residual_layernorm");
 }
 

@@ -426,21 +426,22 @@ def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int,
 
 
 ATTENTION_SPLIT_WIDTHS = (128, 256, 384, 512, 768)
+ATTENTION_HALF_KEY_WIDTHS = (256, 512, 768)        # widths at which fp16 keys are taken as they stand (variant 2, no lo image)
 
 
 def shared_kv_attention_split(q, q_start, q_len, kv_split, kv_start, kv_len, max_q_len: int, scale: float, split_out: bool = False, variant: int = 0):
     """shared_kv_attention for wide batches: the keys as the (hi, lo) fp16 images of split_half (made once per forward), 64 query
     rows per block, keys copied into LDS by DMA.  d in ATTENTION_SPLIT_WIDTHS."""
     q = _dev(q, "q")
-    kh, kl_ = kv_split
+    kh, kl_ = kv_split                          # kl_ = None: fp16 keys as they stand (no lo image; variant 2, d = 256 / 512 / 768)
     for t in (kh, kl_):
-        if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == q.shape[1]):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == q.shape[1]):
             raise _lib.MedTokLibraryError("shared_kv_attention_split: the key images must be contiguous fp16 [Rk, d] device tensors")
     qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
     ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
     out, oh, ol = _attention_outputs(q, split_out)
     with torch.cuda.device(q.device):
-        _lib.check(_lib.load().medtok_shared_kv_attention_split_f32(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kh.data_ptr(), kl_.data_ptr(),
+        _lib.check(_lib.load().medtok_shared_kv_attention_split_f32(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kh.data_ptr(), _ptr(kl_),
                                                                     ks.data_ptr(), kl.data_ptr(), qs.numel(), int(max_q_len), q.shape[1], float(scale),
                                                                     _ptr(out), _ptr(oh), _ptr(ol), int(variant), _stream(q)), "medtok_shared_kv_attention_split_f32")
     return (oh, ol) if split_out else out

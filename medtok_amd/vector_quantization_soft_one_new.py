@@ -402,9 +402,12 @@ class CrossAttention(nn.Module):
         text_flat = text.reshape(bsz * seq_len, dim)
         if nodes_sorted.shape[0] == 0:                     # no graph node anywhere: one zero row no code points at stands in for the key set
             nodes_sorted = text.new_zeros(1, dim)
+        half_keys = images is not None and images[0][1] is None      # fp16 text rows, read as they stand (pooled())
         kv_nodes, kv_text = widen(nodes_sorted), widen(text_flat)
         if not autograd and text.is_cuda:                  # the inference kernel is fp32 whatever autocast hands over
-            kv_nodes, kv_text = kv_nodes.float(), kv_text.float()
+            kv_nodes = kv_nodes.float()
+            if not half_keys:
+                kv_text = kv_text.float()
 
         def attend(qf, q_start, q_len, kv, kv_start, kv_len, max_q_len, max_kv_len, kv_split=None, split_out=False):
             wide_in = qf.shape[1] != dim                   # _folded_rows_split hands over (and takes back) rows at the kernel width
@@ -433,7 +436,7 @@ class CrossAttention(nn.Module):
                     lists[key] = lists[key][order]
         # text side: the CLS row of every code queries that code's nodes
         t_start, t_len = lists["t_start"], lists["t_len"]
-        cur = text[:, 0].contiguous()
+        cur = text[:, 0].float().contiguous() if half_keys else text[:, 0].contiguous()
         lib_core = (not autograd) and core is ops.shared_kv_attention and text.is_cuda     # the split-product layer form needs the library's own core
 
         def text_attend(qf, **kw):
@@ -591,14 +594,23 @@ class CrossAttention(nn.Module):
         if bsz == 0:
             z = text.new_zeros(0, dim)
             return (z, z) if join else (z, z, None)
-        if nodes.dtype != text.dtype:                      # autocast hands over bf16 text features and fp32 node features
+        # fp16 text features (a caller under fp16 autocast, the reference's default mode: train_MedTok.py:212,394) ARE the hi image of
+        # the graph side's keys and have no lo part: no image pass, half the key bytes, two matrix passes per product instead of three
+        half_keys = (not autograd and not torch.is_grad_enabled() and text.dtype == torch.float16 and text.is_contiguous()
+                     and SPLIT_ATTENTION and ATTENTION_VARIANT == 2 and dim in ops.ATTENTION_HALF_KEY_WIDTHS
+                     and nodes.shape[0] * heads >= SPLIT_MIN_ROWS)
+        if half_keys:
+            nodes = nodes.float()                          # (queries and the text side's keys: fp32)
+        elif nodes.dtype != text.dtype:                    # autocast hands over bf16 text features and fp32 node features
             common = torch.promote_types(nodes.dtype, text.dtype)
             nodes, text = nodes.to(common), text.to(common)
         batch = batch.reshape(-1).to(torch.long)
         # counts / offsets / launch lists of all codes: three small launches (ops.pack_codes), nothing read back yet
         pk = ops.pack_codes(text_mask, batch, heads, LPT_ORDER and not autograd)
         images = None
-        if (not autograd and not torch.is_grad_enabled() and SPLIT_ATTENTION and 0 < SIDE_STREAM_MIN_CODES <= bsz
+        if half_keys:
+            images = ((text.view(bsz * seq_len, dim), None), None)
+        elif (not autograd and not torch.is_grad_enabled() and SPLIT_ATTENTION and 0 < SIDE_STREAM_MIN_CODES <= bsz
                 and text.dtype == torch.float32 and nodes.dtype == torch.float32 and text.is_contiguous()
                 and dim in ops.ATTENTION_SPLIT_WIDTHS and nodes.shape[0] * heads >= SPLIT_MIN_ROWS and nodes.shape[0] > 0):
             # The (hi, lo) fp16 images of the valid text rows -- the keys of the graph side, an HBM-bound pass over the whole text
@@ -622,8 +634,12 @@ class CrossAttention(nn.Module):
             order = torch.argsort(batch, stable=True)
             nodes, batch = nodes[order], batch[order]
         lists = {k: pk[k] for k in ("t_start", "t_len", "g_start", "g_len", "tok_start", "g_kv_len")}
-        return self._pooled_packed(text.contiguous(), pk["valid_len"], nodes.contiguous(), batch, None, pk["counts"], pk["starts"],
-                                   max_nodes, ops.shared_kv_attention, autograd=autograd, join=join, lists=lists, images=images)
+        if autograd:
+            return self._pooled_packed(text.contiguous(), pk["valid_len"], nodes.contiguous(), batch, None, pk["counts"], pk["starts"],
+                                       max_nodes, ops.shared_kv_attention, autograd=True, join=join, lists=lists, images=images)
+        with torch.autocast(device_type="cuda", enabled=False):     # inference: fp32(-equivalent) arithmetic whatever autocast says
+            return self._pooled_packed(text.contiguous(), pk["valid_len"], nodes.contiguous(), batch, None, pk["counts"], pk["starts"],
+                                       max_nodes, ops.shared_kv_attention, autograd=False, join=join, lists=lists, images=images)
 
     def pooled_reference(self, text, text_mask, nodes, batch, fold=None, core=None):
         """TEST-SIDE COMPARATOR, never called by the product path: the same function as pooled() in plain torch ops on any device

@@ -146,8 +146,11 @@ def _census(idx_got, dist_got, idx_ref, gapmin, near_rows, near_d64, what):
     return dict(rows=n, inside_tau=int(inside.sum()), ids_differ_inside_tau=int((~same & inside).sum()), mismatches_outside_tau=0)
 
 
-def test_cfg3_ids_pinned_to_the_reference_at_full_codebook_size(dev, golden, capsys):
-    """F14: 16 384 rows x the four searches of BASELINE config 3 (n_e = 49 152, D = 768, k = 5), ids generated by the REFERENCE's own
+@pytest.mark.parametrize("name", ["f14_cfg3_slice", "f18_refdefault_slice"])
+def test_cfg3_ids_pinned_to_the_reference_at_full_codebook_size(dev, golden, capsys, name):
+    """F18: the same at the reference's OWN default shape (train_MedTok.py:363-368: e_dim = 64, n_e = 21 000, regions of 7 000 codes
+    -- not a multiple of the kernels' 256-code tiles -- k = 5), bench.py's `refdefault` workload.
+    F14: 16 384 rows x the four searches of BASELINE config 3 (n_e = 49 152, D = 768, k = 5), ids generated by the REFERENCE's own
     VectorQuantizer on CPU (oracle/gen_golden.py: fixture_cfg3_slice).  The product path (quantize_pooled: proj Linear -> rownorm
     -> fp16 shortlist + exact re-score -> soft assignment) must give the same ids on every row whose fp64 top-6 gaps exceed
     tau = 1e-5 and reference near-ties inside it; the census is printed and bounded (<= 1 % of the rows inside tau: 5 gaps per row at K up to 49 152)."""
@@ -155,7 +158,6 @@ def test_cfg3_ids_pinned_to_the_reference_at_full_codebook_size(dev, golden, cap
     from medtok_amd.inference import quantize_pooled
     from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
     from oracle import synth
-    name = "f14_cfg3_slice"
     g = golden(name)
     n_e, D, k, seed, N = int(g["n_e"]), int(g["e_dim"]), int(g["k"]), int(g["seed"]), int(g["N"])
     v = VectorQuantizer(n_e, D, 0.25, 0.0, True, True, [D, D], k=k)
@@ -185,7 +187,7 @@ def test_cfg3_ids_pinned_to_the_reference_at_full_codebook_size(dev, golden, cap
         ok = (tok[: w_ref.shape[0], s_] == g[f"{key}.idx"][: w_ref.shape[0]].astype(np.int64)).all(1)
         assert np.abs(wts[: w_ref.shape[0], s_].cpu().numpy()[ok] - w_ref[ok]).max() <= 1e-5 * max(w_ref.max(), 1e-30) * 10   # weights: e^-d, d to ~1e-6
     with capsys.disabled():
-        print(f"\n[F14 census] {N} rows x 4 searches vs the reference: 0 mismatches outside tau = {TAU:g}; {total['inside_tau']} of "
+        print(f"\n[{name[:3].upper()} census] {N} rows x 4 searches, n_e = {n_e}, D = {D} vs the reference: 0 mismatches outside tau = {TAU:g}; {total['inside_tau']} of "
               f"{total['rows']} rows inside tau, of which {total['ids_differ_inside_tau']} resolve the near-tie differently")
     assert total["inside_tau"] <= 0.01 * total["rows"]          # (the reference run itself counted 508 of 65 536: oracle/gen_golden.py)
     head = g["emb_head"]

@@ -609,3 +609,33 @@ def test_side_stream_forward_equals_single_stream(dev):
                 assert torch.equal(got[k], t), k
             elif isinstance(t, float):
                 assert got[k] == t, k
+
+
+@pytest.mark.parametrize("D", [256, 768])
+def test_half_precision_text_features_are_read_as_they_stand(dev, D):
+    """A caller under fp16 autocast (the reference's default mode, train_MedTok.py:212,394) hands over fp16 text features: they ARE
+    the hi image of the graph side's keys and have no lo part, so the forward makes no image pass and its attention kernel runs two
+    matrix passes per product.  Adding the exact zeros of an all-zero lo image changes nothing: pooled rows and token ids are
+    bit-identical to the forward on the same values widened to fp32 -- under torch.autocast too."""
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    torch.manual_seed(D)
+    B, L = 96, 40
+    v = VectorQuantizer(3 * 512, D, 0.25, 0.0, True, False, [D, D]).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(1)
+    tok = torch.randint(1, L + 1, (B,), device=dev, generator=g)
+    mask = (torch.arange(L, device=dev)[None, :] < tok[:, None]).to(torch.int64)
+    n_nodes = torch.randint(1, 9, (B,), device=dev, generator=g)
+    batch = torch.repeat_interleave(torch.arange(B, device=dev), n_nodes)
+    nodes = torch.randn(int(n_nodes.sum()), D, device=dev, generator=g)
+    text16 = torch.randn(B, L, D, device=dev, generator=g).half()
+    h = torch.randn(B, 2 * D, device=dev, generator=g)
+    with torch.no_grad():
+        want_t, want_g = v.cross_attn.pooled(text16.float(), mask, nodes, batch)
+        got_t, got_g = v.cross_attn.pooled(text16, mask, nodes, batch)
+        assert torch.equal(got_t, want_t) and torch.equal(got_g, want_g)
+        ref = v(h, text16.float(), nodes, mask, batch)
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = v(h, text16, nodes, mask, batch)
+    for k in ("shared_text_tokens", "shared_graph_tokens"):
+        assert torch.equal(out[k], ref[k]), k
+    assert torch.equal(out["shared_graph_embedding"].float(), ref["shared_graph_embedding"])
