@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-collectives", action="store_true", help="N > 1, headline workload: skip the extra cfg5 / codeshard strong-scaling block")
     ap.add_argument("--exact-steps", type=int, default=1, help="extra steps on the exact fp32-MFMA path for comparison (0 disables)")
     ap.add_argument("--one-stream", action="store_true", help="full workload: the whole run on ONE HIP stream (no side streams)")
+    ap.add_argument("--precomputed-encoders", action="store_true",
+                    help="cfg4: no encoders -- the tokenizer reads pre-computed text / node features (MultimodalTokenizer(None, None)): the step is "
+                         "the VQ side alone (text mapping, cross-attention, 6 searches, loss.py, backward, clip, AdamW)")
     ap.add_argument("--no-half-text-pass", action="store_true",
                     help="full workload: skip the extra pass with fp16 text features (what a caller under fp16 autocast hands over)")
     ap.add_argument("--no-one-stream-pass", action="store_true",
@@ -373,18 +376,32 @@ class Cfg4:
     name = "cfg4"
     D, N_E, L, TOPK = 768, 49152, 512, 5
 
-    def __init__(self, rows, dev, seed, path, text_layers=12):
+    def __init__(self, rows, dev, seed, path, text_layers=12, precomputed=False):
         from medtok_amd.synthetic import StandInGAT, StandInTextEncoder, primekg_shaped_batch
         from medtok_amd.tokenizer import MultimodalTokenizer
-        self.rows, self.dev = rows, dev
+        self.rows, self.dev, self.precomputed = rows, dev, precomputed
         torch.manual_seed(1234)
-        self.model = MultimodalTokenizer(StandInTextEncoder(layers=text_layers), StandInGAT(dim=self.D), text_dim=768, graph_out_channels=self.D,
-                                         codebook_size=self.N_E, codebook_embed_dim=self.D).to(dev).train()
-        for p in self.model.text_model.parameters():
-            p.requires_grad = False                                     # tokenizer.py:80-81
+        self.inputs = primekg_shaped_batch(rows, dev, seed=seed, max_len=self.L)
+        if precomputed:
+            import medtok_amd.vector_quantization_soft_one_new as vqmod
+            vqmod.TRAIN_SPLIT_TEXT_MAPPING = True           # every dense product of the step on the library's own kernels
+            # the VQ side alone: the encoders' outputs are inputs (the node features carry requires_grad, as they would coming out of
+            # a trainable graph encoder, so that the backward reaches them through the cross-attention's dKV kernel)
+            self.model = MultimodalTokenizer(None, None, text_dim=768, graph_out_channels=self.D, codebook_size=self.N_E,
+                                             codebook_embed_dim=self.D).to(dev).train()
+            g = torch.Generator(device=dev).manual_seed(seed + 5)
+            n_nodes = int(self.inputs.batch.numel())
+            self.inputs.text_features = torch.randn(rows, self.L, 768, device=dev, generator=g)
+            self.inputs.text_features_aug = self.inputs.text_features + 0.01 * torch.randn(rows, self.L, 768, device=dev, generator=g)
+            self.inputs.graph_node_features = torch.randn(n_nodes, self.D, device=dev, generator=g).requires_grad_()
+            self.inputs.graph_node_features_aug = torch.randn(n_nodes, self.D, device=dev, generator=g).requires_grad_()
+        else:
+            self.model = MultimodalTokenizer(StandInTextEncoder(layers=text_layers), StandInGAT(dim=self.D), text_dim=768, graph_out_channels=self.D,
+                                             codebook_size=self.N_E, codebook_embed_dim=self.D).to(dev).train()
+            for p in self.model.text_model.parameters():
+                p.requires_grad = False                                     # tokenizer.py:80-81
         self.model.quantize.search_path = path
         self.opt = torch.optim.AdamW([p for p in self.model.parameters() if p.requires_grad], lr=1e-4)
-        self.inputs = primekg_shaped_batch(rows, dev, seed=seed, max_len=self.L)
         # (query row, key) pairs of the cross-attention per layer: every node x head against its code's valid tokens, and the
         # CLS row x head against the code's nodes; forward 2 products (4 D flop per pair), backward 10 D per pair and kernel
         heads, layers = 4, 2
@@ -415,6 +432,8 @@ class Cfg4:
         from medtok_amd import loss as L
         m = self.model
         self.opt.zero_grad(set_to_none=True)
+        if self.precomputed:
+            self.inputs.graph_node_features.grad = self.inputs.graph_node_features_aug.grad = None
         with torch.autocast("cuda", dtype=torch.bfloat16):
             r = m(self.inputs)
             loss, _ = L.total_loss(r, 0.1, 0.1)
@@ -428,6 +447,8 @@ class Cfg4:
 
     def encoder_ms(self, steps=3):
         """time of the stand-in encoders alone (both views, as forward() runs them), outside the timed region"""
+        if self.precomputed:
+            return 0.0
         m, x = self.model, self.inputs
         def enc():
             with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -590,7 +611,9 @@ def main():
         wl = CodeShard(rows, dev, seed=0, path=args.path, rank=rank, world=world)
     elif args.workload == "cfg4":
         rows = args.rows or 256
-        wl = Cfg4(rows, dev, seed=rank, path=args.path, text_layers=args.text_layers)
+        wl = Cfg4(rows, dev, seed=rank, path=args.path, text_layers=args.text_layers, precomputed=args.precomputed_encoders)
+        if args.precomputed_encoders:
+            wl.description = wl.description.replace("stand-in BERT-shaped text encoder", "NO encoders (pre-computed text / node features); was: stand-in BERT-shaped text encoder")
     else:
         rows = args.rows or {"cfg3": 600000, "full": 4096, "refdefault": 600000, "fullref": 256}.get(args.workload, 100000)
         wl = {"cfg3": Cfg3, "full": Full, "refdefault": RefDefault, "fullref": FullRefDefault}.get(args.workload, Cfg2)(rows, dev, seed=rank, path=args.path)

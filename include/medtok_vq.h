@@ -155,6 +155,26 @@ int medtok_split_gemm_f16(const void *a_hi, const void *a_lo, int64_t m, int lda
                           int n_g, int k_g, int groups, const float *bias, float unscale,
                           float *c, int ldc, void *c_hi, void *c_lo, int ldch, void *stream);
 
+/* The same products for TRAINING (the projections of the cross-attention under autograd: forward, data gradient and weight gradient
+ * are all "A . B^T" with fp32-accurate split operands; reference: nn.MultiheadAttention's in/out projections,
+ * vector_quantization_soft_one_new.py:30,45).  Operands whose magnitude is not known on the host (activations, upstream gradients
+ * -- 1e-9 .. 1e+5 under a GradScaler) are prescaled by the power of two that brings their largest magnitude into [2^11, 2^12),
+ * taken from a DEVICE-side |x|_max: no host read anywhere.
+ *   medtok_absmax_f32            amax[0] = max |x[i]| (device float; non-finite inputs give a non-finite amax -> prescale 1)
+ *   medtok_split_half_scaled_f32 the (hi, lo) images of src [n, d] prescaled by pow2(amax) (amax NULL: 1); transpose = 0: [n, dp]
+ *                                (dp >= d); transpose = 1: the images of src^T, [d, dp] with dp >= n (weight gradients contract
+ *                                over the rows) -- with group_cols (0 = dp; else a multiple of 64 dividing dp) written as
+ *                                dp / group_cols groups of [d, group_cols] stacked along the rows, the layout the grouped product
+ *                                reads as "group g = k chunk g": a split-K weight gradient in one launch; zero padding throughout
+ *   medtok_split_gemm_scaled_f16 medtok_split_gemm_f16 (fp32 output) with unscale / (pow2(amax_a) pow2(amax_b)) applied to the
+ *                                accumulators (either amax may be NULL) */
+int medtok_absmax_f32(const float *x, int64_t count, float *amax, void *stream);
+int medtok_split_half_scaled_f32(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp, const float *amax, int transpose,
+                                 int64_t group_cols, void *hi, void *lo, void *stream);
+int medtok_split_gemm_scaled_f16(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols, const void *b_hi, const void *b_lo,
+                                 int64_t b_rows, int ldb, int b_group_rows, int n_g, int k_g, int groups, const float *bias, float unscale,
+                                 const float *amax_a, const float *amax_b, float *c, int ldc, void *stream);
+
 /* ---- training half ------------------------------------------------------------------------------
  * Sparse backward of the soft top-k assignment (the reference back-propagates through a dense
  * N x K distance matrix built at vector_quantization_soft_one_new.py:120-125,157-182,203-214; only

@@ -1662,10 +1662,68 @@ extern "C" int medtok_split_half_f32(const float *src, int64_t n, int d, int64_t
     return check_launch("split_half");
 }
 
+extern "C" int medtok_absmax_f32(const float *x, int64_t count, float *amax, void *stream)
+{
+    if (count < 0 || !amax || (!x && count)) return fail("absmax: bad arguments");
+    if (((uintptr_t)x) & 15) return fail("absmax: x must be 16-byte aligned");
+    if (hipMemsetAsync(amax, 0, 4, (hipStream_t)stream) != hipSuccess) return fail("absmax: memset failed");
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)lmin(512, (count + 4095) / 4096)), dim3(256), 0, (hipStream_t)stream, x, (long)count, amax);
+    return check_launch("absmax");
+}
+
+extern "C" int medtok_split_half_scaled_f32(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp, const float *amax, int transpose,
+                                            int64_t group_cols, void *hi, void *lo, void *stream)
+{
+    if (n < 0 || d <= 0 || (d & 3) || (dp & 7) || src_stride < d || (src_stride & 3) || dp < (transpose ? n : (int64_t)d))
+        return fail("split_half_scaled: bad shape n=%ld d=%d stride=%ld dp=%ld transpose=%d", (long)n, d, (long)src_stride, (long)dp, transpose);
+    if (group_cols == 0) group_cols = dp;
+    if (transpose && (group_cols <= 0 || dp % group_cols || (group_cols != dp && group_cols % 64)))
+        return fail("split_half_scaled: group_cols=%ld must divide dp=%ld and be a multiple of 64", (long)group_cols, (long)dp);
+    if (n == 0 && !transpose) return 0;
+    if ((!src && n) || !hi || !lo) return fail("split_half_scaled: NULL argument");
+    if (((uintptr_t)src | (uintptr_t)hi | (uintptr_t)lo) & 15) return fail("split_half_scaled: pointers must be 16-byte aligned");
+    if (!transpose) {
+        if (dp >= (1ll << 31)) return fail("split_half_scaled: dp too large");
+        const long total = n * (dp / 8);
+        hipLaunchKernelGGL(split_half_kernel<4>, dim3((unsigned)lmin(8192, (total + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, src, (long)n, d,
+                           (long)src_stride, (int)dp, 1.0f, (_Float16 *)hi, (_Float16 *)lo, (const int64_t *)nullptr, 1, amax);
+        return check_launch("split_half_scaled");
+    }
+    // transposed: the images are [d, dp], dp >= n columns (the zero tail is written by the tiles that cover it)
+    const long row_tiles = (dp + 63) / 64;
+    if (row_tiles >= (1ll << 31) || (d + 63) / 64 > 65535) return fail("split_half_scaled: too large");
+    hipLaunchKernelGGL(split_half_t_kernel, dim3((unsigned)row_tiles, (unsigned)((d + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src, (long)n, d,
+                       (long)src_stride, (long)dp, (long)group_cols, 1.0f, (_Float16 *)hi, (_Float16 *)lo, amax);
+    return check_launch("split_half_scaled(transposed)");
+}
+
+static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols,
+                           const void *b_hi, const void *b_lo, int64_t b_rows, int ldb, int b_group_rows,
+                           int n_g, int k_g, int groups, const float *bias, float unscale, const float *amax_a, const float *amax_b,
+                           float *c, int ldc, void *c_hi, void *c_lo, int ldch, void *stream);
+
+extern "C" int medtok_split_gemm_scaled_f16(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols, const void *b_hi, const void *b_lo,
+                                            int64_t b_rows, int ldb, int b_group_rows, int n_g, int k_g, int groups, const float *bias, float unscale,
+                                            const float *amax_a, const float *amax_b, float *c, int ldc, void *stream)
+{
+    return split_gemm_impl(a_hi, a_lo, m, lda, a_group_cols, b_hi, b_lo, b_rows, ldb, b_group_rows, n_g, k_g, groups, bias, unscale, amax_a, amax_b, c, ldc,
+                           nullptr, nullptr, 0, stream);
+}
+
 extern "C" int medtok_split_gemm_f16(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols,
                                      const void *b_hi, const void *b_lo, int64_t b_rows, int ldb, int b_group_rows,
                                      int n_g, int k_g, int groups, const float *bias, float unscale,
                                      float *c, int ldc, void *c_hi, void *c_lo, int ldch, void *stream)
+{
+    return split_gemm_impl(a_hi, a_lo, m, lda, a_group_cols, b_hi, b_lo, b_rows, ldb, b_group_rows, n_g, k_g, groups, bias, unscale, nullptr, nullptr,
+                           c, ldc, c_hi, c_lo, ldch, stream);
+}
+
+static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols,
+                           const void *b_hi, const void *b_lo, int64_t b_rows, int ldb, int b_group_rows,
+                           int n_g, int k_g, int groups, const float *bias, float unscale, const float *amax_a, const float *amax_b,
+                           float *c, int ldc, void *c_hi, void *c_lo, int ldch, void *stream)
 {
     if (m < 0 || groups < 1 || n_g <= 0 || k_g <= 0 || (n_g & 3) || (k_g % G_BK) || (lda & 7) || (ldb & 7) || (a_group_cols & 7) || lda < k_g || ldb < k_g)
         return fail("split_gemm: bad shape m=%ld groups=%d n_g=%d k_g=%d lda=%d ldb=%d a_group_cols=%d (n_g %% 4 == 0, k_g %% 32 == 0, strides %% 8 == 0)",
@@ -1686,7 +1744,7 @@ extern "C" int medtok_split_gemm_f16(const void *a_hi, const void *a_lo, int64_t
     p.bias = bias; p.c = c; p.ch = (_Float16 *)c_hi; p.cl = (_Float16 *)c_lo;
     p.M = (long)m; p.a_bytes = (long)m * lda * 2; p.b_bytes = (long)b_rows * ldb * 2;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldch = ldch; p.n_g = n_g; p.k_g = k_g; p.groups = groups;
-    p.a_group_cols = a_group_cols; p.b_group_rows = b_group_rows; p.unscale = unscale;
+    p.a_group_cols = a_group_cols; p.b_group_rows = b_group_rows; p.unscale = unscale; p.amax_a = amax_a; p.amax_b = amax_b;
     // tile height: 256 features, or 192 where that pads the group's features by > 10 % less (n_g = 192: the per-head W_v product)
     const long pad4 = (long)((n_g + 255) / 256) * 256, pad3 = (long)((n_g + 191) / 192) * 192;
     const bool mt3 = pad3 * 10 < pad4 * 9;

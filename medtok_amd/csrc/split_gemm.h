@@ -51,6 +51,21 @@ struct GemmShape {
     static constexpr size_t LDS_BYTES = (size_t)2 * STG + 8 * 4096;      // two stages + 4 KB of epilogue staging per wave (MT = 4: all 160 KB)
 };
 
+// The power of two that brings a tensor's largest magnitude into [2^11, 2^12): the (hi, lo) fp16 pair of a prescaled value then
+// carries 22 significant bits of every element down to amax 2^-26 (smaller ones fall into the fp16 subnormals -- they move a dot
+// product by < 1e-7 of its scale).  Weights get theirs from a host read once per weight version; the operands of TRAINING products
+// (activations, upstream gradients: anything from 1e-9 to 1e+5 under a GradScaler) take it from a device-side |x|_max, no host
+// read.  1 for amax = 0 / non-finite.  Exact: exponent arithmetic only.
+__device__ __forceinline__ float pow2_prescale(float amax)
+{
+    const unsigned bits = __float_as_uint(amax) & 0x7fffffffu;
+    if (bits == 0u || bits >= 0x7f800000u) return 1.0f;
+    int e = (int)(bits >> 23) - 127;                 // floor(log2 amax) for normal amax (subnormal: -127)
+    int se = 11 - e;                                 // scale = 2^se
+    se = se > 126 ? 126 : (se < -126 ? -126 : se);
+    return __uint_as_float((unsigned)(se + 127) << 23);
+}
+
 struct SplitGemmArgs {
     const _Float16 *ah, *al;        // activations [M, lda]: hi and lo images
     const _Float16 *bh, *bl;        // weights [G * b_group_rows, ldb], prescaled by 1 / unscale
@@ -64,6 +79,7 @@ struct SplitGemmArgs {
     int a_group_cols;               // group g reads A columns [g * a_group_cols, + k_g)
     int b_group_rows;               // ... B rows [g * b_group_rows, + n_g) and writes C columns [g * n_g, + n_g)
     float unscale;                  // applied to the accumulators (undoes the weights' power-of-two prescale)
+    const float *amax_a, *amax_b;   // (training products) the operands were prescaled by pow2_prescale(*amax): undone here too; or nullptr
     int row_tiles, ftiles;          // M / 256 rounded up; feature tiles (of 64 MT) per group
 };
 
@@ -163,6 +179,8 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
     // what the epilogue needs of the arguments, in registers from here on: a kernel argument re-read inside the epilogue is a scalar
     // load, and its s_waitcnt lgkmcnt(0) would also wait for the LDS read-backs in flight
     float e_unscale = p.unscale;
+    if (p.amax_a) e_unscale *= 1.0f / pow2_prescale(p.amax_a[0]);
+    if (p.amax_b) e_unscale *= 1.0f / pow2_prescale(p.amax_b[0]);
     long e_M = p.M;
     int e_ldc = p.ldc, e_ldch = p.ldch, e_ng = p.n_g;
     unsigned long e_c = (unsigned long)p.c, e_ch = (unsigned long)p.ch, e_cl = (unsigned long)p.cl, e_bias = (unsigned long)p.bias;   // (as integers:
@@ -350,8 +368,9 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
 template <int U>
 __global__ __launch_bounds__(256) void split_half_kernel(const float *__restrict__ src, long n, int d, long src_stride, int dp, float scale,
                                                          _Float16 *__restrict__ hi, _Float16 *__restrict__ lo,
-                                                         const int64_t *__restrict__ seg_len, int seg_rows)
+                                                         const int64_t *__restrict__ seg_len, int seg_rows, const float *__restrict__ amax = nullptr)
 {
+    if (amax) scale *= pow2_prescale(amax[0]);
     const int cpr = dp / 8;
     const long total = n * cpr, step = (long)gridDim.x * 256;
     for (long t0 = (long)blockIdx.x * 256 + threadIdx.x; t0 < total; t0 += step * U) {
@@ -386,5 +405,82 @@ __global__ __launch_bounds__(256) void split_half_kernel(const float *__restrict
             *reinterpret_cast<half8 *>(hi + r[u] * dp + c[u]) = h;
             *reinterpret_cast<half8 *>(lo + r[u] * dp + c[u]) = l;
         }
+    }
+}
+
+// |x|_max of a buffer into amax[0] (zeroed by the caller): non-negative floats order like their bit patterns, so the block maxima
+// meet in an integer atomicMax.  NaN / inf propagate as "non-finite" (pow2_prescale then returns 1).
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, long count, float *__restrict__ amax)
+{
+    unsigned m = 0u;
+    const long step = (long)gridDim.x * 256 * 4;
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    for (; i + 3 * step + 4 <= count; i += 4 * step) {                 // four independent 16-byte loads in flight per thread
+        g_f4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const g_f4 *>(x + i + u * step);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m = max(m, __float_as_uint(v[u][j]) & 0x7fffffffu);
+    }
+    for (; i < count; i += step) {
+        if (i + 4 <= count) {
+            const g_f4 v = *reinterpret_cast<const g_f4 *>(x + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m = max(m, __float_as_uint(v[j]) & 0x7fffffffu);
+        } else {
+            for (long j = i; j < count; ++j) m = max(m, __float_as_uint(x[j]) & 0x7fffffffu);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    // one atomic per BLOCK (thousands of wave-level atomics on one address serialise in the L2: 40 us of a 48 us launch)
+    __shared__ unsigned s_m[4];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        if (m) atomicMax(reinterpret_cast<unsigned *>(amax), m);
+    }
+}
+
+// The (hi, lo) images of the TRANSPOSE: src [n, d] fp32 -> hi, lo [d, np] (np >= n, a multiple of 8; columns n .. np - 1 zero) --
+// the operands of a weight-gradient product dW = dY^T X contract over the ROWS, so both need their row index contiguous.  64 x 64
+// tiles through LDS: rows are read as float4 (coalesced), columns leave as 32-byte pieces of 16 consecutive rows.
+__global__ __launch_bounds__(256) void split_half_t_kernel(const float *__restrict__ src, long n, int d, long src_stride, long np, long group_cols,
+                                                           float scale, _Float16 *__restrict__ hi, _Float16 *__restrict__ lo, const float *__restrict__ amax)
+{
+    // group_cols (a multiple of 64 dividing np): the images are written as np / group_cols GROUPS of [d, group_cols] stacked along
+    // the rows -- the layout a grouped product reads as "group g = k chunk g", i.e. a split-K weight gradient in ONE launch
+    __shared__ float tile[64][65];
+    if (amax) scale *= pow2_prescale(amax[0]);
+    const long r0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (t >> 4) + 16 * i, c = (t & 15) * 4;
+        g_f4 v = (g_f4){0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < n && c0 + c < d) v = *reinterpret_cast<const g_f4 *>(src + (r0 + r) * src_stride + c0 + c);      // (d % 4 == 0)
+        tile[r][c] = v[0]; tile[r][c + 1] = v[1]; tile[r][c + 2] = v[2]; tile[r][c + 3] = v[3];
+    }
+    __syncthreads();
+    const int c = t >> 2, rs = (t & 3) * 16;
+    if (c0 + c >= d) return;
+    const long grp = r0 / group_cols, gcol0 = r0 - grp * group_cols;      // (a 64-row tile lies inside one group)
+    _Float16 *oh = hi + ((grp * d + c0 + c) * group_cols + gcol0), *ol = lo + ((grp * d + c0 + c) * group_cols + gcol0);
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) {
+        if (r0 + rs + 8 * h8 >= np) continue;
+        half8 hh, ll;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = tile[rs + 8 * h8 + j][c] * scale;        // (rows past n were loaded as zeros)
+            hh[j] = (_Float16)x;
+            ll[j] = (_Float16)(x - (float)hh[j]);
+        }
+        *reinterpret_cast<half8 *>(oh + rs + 8 * h8) = hh;
+        *reinterpret_cast<half8 *>(ol + rs + 8 * h8) = ll;
     }
 }

@@ -328,6 +328,51 @@ def split_gemm(a, b, n_g: int, k_g: int, groups: int = 1, a_group_cols: int = 0,
     return c, ((ch, cl) if want_split else None)
 
 
+def absmax(x):
+    """0-dim device fp32 tensor max |x| (no host read): feeds the power-of-two prescale of training-mode split operands."""
+    x = _dev(x, "x")
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().medtok_absmax_f32(x.data_ptr(), x.numel(), out.data_ptr(), _stream(x)), "medtok_absmax_f32")
+    return out
+
+
+def split_half_scaled(x, dp: int, amax=None, transpose: bool = False, group_cols: int = 0):
+    """(hi, lo) fp16 images of the fp32 matrix x [n, d], prescaled by the power of two that `amax` (0-dim device tensor, from absmax;
+    None: 1) selects.  transpose=False: [n, dp], dp >= d; transpose=True: the images of x^T, [d, dp], dp >= n -- with group_cols (a
+    multiple of 64 dividing dp) stacked as [dp / group_cols * d, group_cols]: group g holds columns [g group_cols, + group_cols)."""
+    x = _dev(x, "x")
+    n, d = x.shape
+    if transpose:
+        gc = int(group_cols) or int(dp)
+        shape = (int(dp) // gc * d, gc)
+    else:
+        shape = (n, int(dp))
+    hi = torch.empty(shape, dtype=torch.float16, device=x.device)
+    lo = torch.empty(shape, dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().medtok_split_half_scaled_f32(x.data_ptr(), n, d, d, int(dp), _ptr(amax), int(bool(transpose)), int(group_cols),
+                                                            hi.data_ptr(), lo.data_ptr(), _stream(x)), "medtok_split_half_scaled_f32")
+    return hi, lo
+
+
+def split_gemm_scaled(a, b, n_g: int, k_g: int, bias=None, unscale: float = 1.0, amax_a=None, amax_b=None, groups: int = 1, a_group_cols: int = 0,
+                      b_group_rows: int = 0):
+    """c [m, groups * n_g] fp32 = unscale / (pow2(amax_a) pow2(amax_b)) * A . B^T + bias from (hi, lo) images made by split_half_scaled
+    (grouped as medtok_split_gemm_f16)."""
+    (a_hi, a_lo), (b_hi, b_lo) = a, b
+    m, lda = a_hi.shape
+    b_rows, ldb = b_hi.shape
+    c = torch.empty((m, groups * n_g), dtype=torch.float32, device=a_hi.device)
+    bias = None if bias is None else _dev(bias, "bias")
+    with torch.cuda.device(a_hi.device):
+        _lib.check(_lib.load().medtok_split_gemm_scaled_f16(a_hi.data_ptr(), a_lo.data_ptr(), m, lda, int(a_group_cols), b_hi.data_ptr(), b_lo.data_ptr(),
+                                                            b_rows, ldb, int(b_group_rows), int(n_g), int(k_g), int(groups), _ptr(bias), float(unscale),
+                                                            _ptr(amax_a), _ptr(amax_b), c.data_ptr(), groups * n_g, _stream(a_hi)),
+                   "medtok_split_gemm_scaled_f16")
+    return c
+
+
 def residual_layernorm(a, b, gamma, beta, eps: float, split_dp: int = 0):
     """LayerNorm(a + b) * gamma + beta per row of the contiguous fp32 matrices a, b [n, d] (the tail of CrossAttentionLayer,
     vector_quantization_soft_one_new.py:47-50); d % 4 == 0, d <= 4096.  split_dp > 0: returns (y, (y_hi, y_lo)) with the (hi, lo)

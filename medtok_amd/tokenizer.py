@@ -120,11 +120,21 @@ class MultimodalTokenizer(nn.Module):
                                r["shared_text_embedding"], r["shared_graph_embedding"]), dim=-1)
         return embedding, tokens, weights
 
+    def _map_text(self, feats):
+        """text_mapped (reference tokenizer.py:118,221-222).  Under autograd on an MI355X: the library's own dense product, forward and
+        backward (vector_quantization_soft_one_new.split_linear), like the quantiser's projections."""
+        from . import vector_quantization_soft_one_new as vqmod
+        lin = self.text_mapped
+        if (vqmod.SPLIT_PRODUCTS and vqmod.TRAIN_SPLIT_PRODUCTS and vqmod.TRAIN_SPLIT_TEXT_MAPPING and torch.is_grad_enabled() and feats.is_cuda and lin.weight.requires_grad
+                and lin.in_features % 4 == 0 and lin.out_features % 4 == 0):
+            return vqmod.split_linear(feats.reshape(-1, feats.shape[-1]), lin.weight, lin.bias).view(*feats.shape[:-1], lin.out_features)
+        return lin(feats)
+
     def forward(self, inputs, _with_aug=None):
         batch = inputs.batch
         mask = inputs.attention_mask
         bsz = mask.shape[0]
-        text = self.text_mapped(self.tokenize_text(inputs))
+        text = self._map_text(self.tokenize_text(inputs))
         nodes = self.tokenize_graph(inputs)
         pooled = global_mean_pool(nodes, batch, bsz)
         text_aug = nodes_aug = pooled_aug = None
@@ -133,7 +143,7 @@ class MultimodalTokenizer(nn.Module):
             # the reference encodes the text a second time for the aug view with the same frozen model and the same inputs
             # (tokenizer.py:211-212: if_aug is never set); outside training that pass is bit-identical to the first, so the eval
             # forward reuses it (same values, same usage-window trajectory) and only the aug GRAPH view is encoded
-            text_aug = self.text_mapped(self.tokenize_text(inputs, aug=True)) if self.training or hasattr(inputs, "text_features_aug") else text
+            text_aug = self._map_text(self.tokenize_text(inputs, aug=True)) if self.training or hasattr(inputs, "text_features_aug") else text
             nodes_aug = self.tokenize_graph(inputs, aug=True)
             pooled_aug = global_mean_pool(nodes_aug, batch, bsz)
         result = self.quant(text, nodes, pooled, text_aug, nodes_aug, pooled_aug, mask, batch)

@@ -48,6 +48,13 @@ SPLIT_MIN_ROWS = 1024
 # which form of the wide-batch attention core ops.shared_kv_attention_split runs (include/medtok_vq.h): 2 = two 32-row tiles of a
 # code per block, one phase apart on one copy of the keys (D = 256 / 512 / 768; the others fall back to 0 inside the library)
 ATTENTION_VARIANT = 2
+# training / autograd: the cross-attention's dense products (and their backward) on the library's own split-fp16 GEMMs instead
+# of nn.functional.linear / einsum (hipBLASLt)
+TRAIN_SPLIT_PRODUCTS = True
+# ... and the tokenizer's text mapping (tokenizer.py:118, a Linear over every token of the batch: 131 072 rows at B = 256, L = 512) too.
+# Off by default: under autocast the library's half-precision GEMM is ~3x cheaper than the fp32-accurate three-pass product, and
+# that layer is upstream of the quantiser (bench.py --precomputed-encoders turns it on for the all-own-kernels profile).
+TRAIN_SPLIT_TEXT_MAPPING = False
 from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
@@ -161,6 +168,84 @@ class _RaggedAttentionFunction(torch.autograd.Function):
         dq, dkv = ops.shared_kv_attention_backward(qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed,
                                                    out, lse, d_out.float().contiguous())
         return dq.to(qd), dkv.to(kd), None, None, None, None, None, None, None, None, None
+
+
+def _pad32(n):
+    return (int(n) + 31) // 32 * 32
+
+
+class _SplitLinearFunction(torch.autograd.Function):
+    """y = x W^T + b under autograd on the library's own dense product (medtok_split_gemm_scaled_f16: three fp16 MFMA passes over
+    (hi, lo) pairs, fp32-accurate) -- forward, data gradient dX = dY W and weight gradient dW = dY^T X are all "A . B^T" products of
+    split operands; the operands whose magnitude the host does not know (activations, upstream gradients) are prescaled by a power
+    of two taken from a device-side |.|_max, so nothing is read back.  fp32 in and out whatever autocast says (the reference's
+    projections, vector_quantization_soft_one_new.py:30,45, run in the autocast dtype: this is at least as accurate)."""
+
+    @staticmethod
+    def _weight_images(w, wf, npad_t):
+        """(amax, images [n, pad32(k)], transposed images [k, pad32(n)]) of a weight, per (storage, version): a parameter is used by
+        both attention directions of a step and by forward and backward -- one |w|_max and one split each instead of four.  Tensors
+        built inside the graph (the block-diagonal per-head weights) are new objects every forward and are simply split again."""
+        # (a slice of a parameter -- the q / k / v thirds of in_proj_weight -- is cached on the parameter it views)
+        holder = w if isinstance(w, nn.Parameter) else (w._base if isinstance(getattr(w, "_base", None), nn.Parameter) else None)
+        key = (w.data_ptr(), w._version, tuple(w.shape))
+        cache = getattr(holder, "_medtok_train_images", None) if holder is not None else None
+        if cache is not None and key[0] in cache and cache[key[0]][0] == key:
+            return cache[key[0]][1]
+        aw = ops.absmax(wf)
+        val = (aw, ops.split_half_scaled(wf, _pad32(wf.shape[1]), aw), ops.split_half_scaled(wf, npad_t, aw, transpose=True))
+        if holder is not None:
+            if cache is None:
+                cache = holder._medtok_train_images = {}
+            cache[key[0]] = (key, val)
+        return val
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xf, wf = x.detach().float().contiguous(), w.detach().float().contiguous()
+        m, k = xf.shape
+        n = wf.shape[0]
+        kp = _pad32(k)
+        ax = ops.absmax(xf)
+        aw, w_img, wt_img = _SplitLinearFunction._weight_images(w, wf, _pad32(n))
+        y = ops.split_gemm_scaled(ops.split_half_scaled(xf, kp, ax), w_img, n_g=n, k_g=kp,
+                                  bias=None if b is None else b.detach().float().contiguous(), amax_a=ax, amax_b=aw)
+        ctx.save_for_backward(xf, ax, aw, *wt_img)
+        ctx.shape = (m, k, n)
+        ctx.dtypes = (x.dtype, w.dtype, None if b is None else b.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xf, ax, aw, wt_hi, wt_lo = ctx.saved_tensors
+        dxt, dwt, dbt = ctx.dtypes
+        dyf = dy.float().contiguous()
+        m, k, n = ctx.shape
+        ad = ops.absmax(dyf)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:          # dX [m, k] = dY [m, n] . (W^T [k, n])^T
+            npad = _pad32(n)
+            dx = ops.split_gemm_scaled(ops.split_half_scaled(dyf, npad, ad), (wt_hi, wt_lo), n_g=k, k_g=npad, amax_a=ad, amax_b=aw).to(dxt)
+        if ctx.needs_input_grad[1]:          # dW [n, k] = dY^T [n, m] . (X^T [k, m])^T: both operands transposed, contraction over the rows
+            # split-K in one grouped launch: the rows are cut into G chunks, group g multiplies chunk g of both operands into its own
+            # [n, k] block, the G blocks are summed (a [768, 768] gradient is nine 256 x 256 tiles: alone they would walk all the
+            # rows on nine CUs)
+            tiles = ((n + 255) // 256) * ((k + 255) // 256)
+            groups = max(1, min(256 // max(tiles, 1), m // 2048))
+            chunk = (-(-m // groups) + 63) // 64 * 64
+            groups = -(-m // chunk)
+            mp = groups * chunk
+            dw = ops.split_gemm_scaled(ops.split_half_scaled(dyf, mp, ad, transpose=True),
+                                       ops.split_half_scaled(xf, mp, ax, transpose=True, group_cols=chunk),
+                                       n_g=k, k_g=chunk, amax_a=ad, amax_b=ax, groups=groups, a_group_cols=chunk, b_group_rows=k)
+            dw = (dw.view(n, groups, k).sum(1) if groups > 1 else dw).to(dwt)
+        if dbt is not None and ctx.needs_input_grad[2]:
+            db = dyf.sum(0).to(dbt)
+        return dx, dw, db
+
+
+def split_linear(x, w, b=None):
+    return _SplitLinearFunction.apply(x, w, b)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -363,6 +448,22 @@ class CrossAttention(nn.Module):
             if dim % 4 == 0 and ln.elementwise_affine and ln.bias is not None:
                 return ops.residual_layernorm(rows, out, ln.weight, ln.bias, ln.eps)
             return ln(rows + out)
+        if (not plain and rows.is_cuda and SPLIT_PRODUCTS and TRAIN_SPLIT_PRODUCTS and dim % 4 == 0 and hd % 4 == 0
+                and mha.in_proj_bias is not None):
+            # training / autograd: the four dense products and their backward on the library's own split-fp16 GEMMs
+            # (_SplitLinearFunction).  The two per-head products become plain linears against BLOCK-DIAGONAL weights built with
+            # differentiable torch ops (autograd extracts the per-head gradients itself): 4x the flops of the grouped form on two
+            # of the four products -- immaterial at training sizes (a per-GPU batch of 256 codes is launch-bound), and one
+            # autograd function instead of four.
+            q = split_linear(rows, wq, bq)                                                             # [R, D]
+            wk_bd = torch.block_diag(*[wk[h * hd:(h + 1) * hd].t() for h in range(heads)])              # [H D, H hd]
+            qf = split_linear(q, wk_bd).view(n_rows * heads, dim)                                      # row r, head h: Wk_h^T q_{r,h}
+            ctx = attend(qf.contiguous())
+            wv_bd = torch.block_diag(*[wv[h * hd:(h + 1) * hd] for h in range(heads)])                  # [H hd, H D]
+            attended = split_linear(ctx.float().view(n_rows, heads * dim), wv_bd, bv)                   # [R, D]
+            out = split_linear(attended, mha.out_proj.weight, mha.out_proj.bias)
+            with torch.autocast(device_type="cuda", enabled=False):
+                return layer.layer_norm(rows.float() + layer.dropout(out))
         q = torch.nn.functional.linear(rows, wq, bq)
         if plain:
             # one GEMM per head straight into / out of the [R, heads, D] layout the kernel works on (strided operands and
@@ -802,6 +903,9 @@ class VectorQuantizer(nn.Module):
         split-fp16 product (medtok_split_gemm_f16: fp32-accurate, ~2.5x the library fp32 GEMM; weights split once per weight
         version) -- anything else (training, autograd, autocast, small batches, CPU): the nn.Linear as it stands."""
         lin = self.proj_text if types == "text" else self.proj_graph
+        if (SPLIT_PRODUCTS and TRAIN_SPLIT_PRODUCTS and self.training and torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and lin.bias is not None
+                and lin.in_features % 4 == 0 and lin.out_features % 4 == 0 and (x.requires_grad or lin.weight.requires_grad)):
+            return split_linear(x, lin.weight, lin.bias)        # under autograd: forward and backward on the library's own product
         if (not SPLIT_PRODUCTS or self.training or torch.is_grad_enabled() or torch.is_autocast_enabled() or not x.is_cuda
                 or x.dtype != torch.float32 or x.dim() != 2 or x.shape[0] < SPLIT_MIN_ROWS or lin.bias is None
                 or lin.in_features % 32 or lin.out_features % 4 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16):

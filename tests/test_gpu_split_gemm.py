@@ -136,3 +136,32 @@ def test_random_shapes_plain_and_grouped(dev):
             assert float((cf.double() - ref).abs().max()) / sc <= 4e-6, what
         if cs is not None:
             assert float((cs[0].double() + cs[1].double() - ref).abs().max()) / sc <= 4e-6, what
+
+
+@pytest.mark.parametrize("m,k,n,gscale", [(700, 768, 768, 1.0), (333, 768, 3072, 1e-8), (1030, 3072, 768, 3e4), (64, 64, 64, 1.0), (5, 100, 36, 1e-3),
+                                              (9001, 768, 768, 1.0)])
+def test_split_linear_forward_and_backward_match_fp64(dev, m, k, n, gscale):
+    """The training-mode dense product (_SplitLinearFunction: forward, dX = dY W, dW = dY^T X on medtok_split_gemm_scaled_f16, the
+    operands prescaled by powers of two taken from device-side |.|_max values) against torch in fp64: every result to 1e-5 of its
+    own scale -- also for upstream gradients at 1e-8 (a mean over millions of elements) and at 3e4 (under a GradScaler), which an
+    unscaled fp16 split would flush to zero / overflow.  Rows and depths that are not multiples of the 32-deep k blocks included."""
+    from medtok_amd.vector_quantization_soft_one_new import split_linear
+    g = torch.Generator(device=dev).manual_seed(m + n)
+    x = torch.randn(m, k, device=dev, generator=g, requires_grad=True)
+    w = (torch.randn(n, k, device=dev, generator=g) * 0.05).requires_grad_()
+    b = torch.randn(n, device=dev, generator=g, requires_grad=True)
+    dy = torch.randn(m, n, device=dev, generator=g) * gscale
+    y = split_linear(x, w, b)
+    y.backward(dy)
+    x64, w64, b64 = (t.detach().double().requires_grad_() for t in (x, w, b))
+    y64 = x64 @ w64.t() + b64
+    y64.backward(dy.double())
+    def rel(a, r):
+        return float((a.double() - r).abs().max() / r.abs().max())
+    assert rel(y.detach(), y64.detach()) <= 1e-5
+    assert rel(x.grad, x64.grad) <= 1e-5 and rel(w.grad, w64.grad) <= 1e-5 and rel(b.grad, b64.grad) <= 1e-5
+    # no bias, no input gradient wanted: only dW
+    x2 = x.detach()
+    w2 = w.detach().clone().requires_grad_()
+    split_linear(x2, w2).backward(dy)
+    assert rel(w2.grad, w64.grad) <= 1e-5
