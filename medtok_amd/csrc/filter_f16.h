@@ -455,7 +455,11 @@ __device__ __forceinline__ void lds_init_wait(f32x16 (&a)[4][2])
 // ring has ONE block-wide barrier per stage, so whatever one wave does beyond its MFMAs in a stage is added to that stage for
 // all eight -- about +990 cycles per scanning stage for ~140 extra instructions, in 16 of 24 stages, against one exposed scan
 // per tile.  What pays instead is making that one scan short (filter_hit above).
-template <int TOPK, bool DUMP>
+// TIMED (dev probe, tools/r04/filter_probe.py; the product instantiates TIMED = false): every wave accumulates, in shader-clock
+// cycles (s_memtime), how long the five segments of its stage loop take -- MFMA group 1 (+ operand reads), the wait for its own
+// and the block's copies (s_waitcnt, then s_barrier), MFMA group 2 (+ DMA issue), the tile epilogue -- and writes the sums to
+// `dump` (as uint64[blocks][8 waves][8]).
+template <int TOPK, bool DUMP, bool TIMED = false>
 __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     const _Float16 *__restrict__ xh, const _Float16 *__restrict__ wh, const float *__restrict__ xsq,
     const float *__restrict__ wsqs, const float *__restrict__ en_max_ptr, long n, int k_codes, int dp, int d,
@@ -711,6 +715,14 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // -1.5 % when given to the older half instead; flips around the MFMA groups measured -1 %).
     if (late) __builtin_amdgcn_s_setprio(3);
 
+    unsigned long long tm[6] = {0, 0, 0, 0, 0, 0}, tq = 0;       // TIMED: mfma 1, copy wait, barrier, mfma 2, epilogue, stages
+    auto tick = [&](int k) __attribute__((always_inline)) {
+        if (TIMED) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tm[k] += now - tq;
+            tq = now;
+        }
+    };
     // first half of an iteration: MFMA(s, t0) with the operand reads of (s, t1) between them, then the stage barrier
     auto first_half = [&](int s, auto first) __attribute__((always_inline)) {
         if (late && s > 0) stage();         // waves 4-7: stage s+2 (slot s-2, free since the barrier of iteration s-1)
@@ -720,9 +732,12 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         for (int i = 0; i < F_MT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, F_NT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
         // the next step's operands have landed; own part of stage s+1 has landed; then everyone's has
         __builtin_amdgcn_s_waitcnt(LGKM0);
+        tick(0);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        tick(1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        tick(2);
     };
     // second half: (DMA of stage s+3,) MFMA(s, t1) with the operand reads of (s+1, t0) between them
     // (past the last stage the reads fetch stale LDS, never used)
@@ -744,13 +759,23 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
         second_half(s);
     };
     int s = 0;
+    if (TIMED) tq = __builtin_amdgcn_s_memtime();
     for (int ct = 0; ct < nct; ++ct) {
         iteration(s, std::true_type{});
+        tick(3);
         ++s;
-        for (int kb = 1; kb < nkb; ++kb, ++s) iteration(s, std::false_type{});
+        for (int kb = 1; kb < nkb; ++kb, ++s) { iteration(s, std::false_type{}); tick(3); }
         tile_epilogue(ct, ct == 0);
+        tick(4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail re-issues may still be in flight
+    if (TIMED) {
+        if (lane == 0 && dump) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(dump) + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+            o[0] = tm[0]; o[1] = tm[1]; o[2] = tm[2]; o[3] = tm[3]; o[4] = tm[4]; o[5] = (unsigned long long)nstage; o[6] = (unsigned long long)nct;
+            o[7] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
     if (!DUMP) {
 #pragma unroll
         for (int nn = 0; nn < F_NT; ++nn) {

@@ -1062,6 +1062,35 @@ extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64
     return search_impl(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, path, stream, nullptr);
 }
 
+// DEV probe (tools/r04/filter_probe.py): the filter kernel of one search with per-wave cycle counts of its loop segments written to
+// `probe` (uint64 [blocks][8][8]; blocks = *n_blocks on return).  Same plan as the search would take, main launch only; the
+// candidate lists it writes into `ws` are discarded.
+extern "C" int medtok_debug_filter_probe(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq, int64_t k_codes, int d,
+                                         int topk, void *ws, size_t ws_bytes, void *probe, size_t probe_bytes, int64_t *n_blocks, void *stream)
+{
+    if (topk < 2 || topk > 5) return fail("filter_probe: topk 2..5");
+    const PlanOverride ov = decode_plan(MEDTOK_PATH_F16_FILTER);
+    const FilterPlan f = plan_filter(n, k_codes, d, topk, ov);
+    const FilterWs w = filter_ws_layout(ws, n, f);
+    if (!ws || ws_bytes < w.total) return fail("filter_probe: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.n_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, xhat, (long)n, d, f.n_pad, f.dp, w.xh);
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, w.wh);
+    hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, w.en_max);
+    hipLaunchKernelGGL(pad_wsq_kernel, dim3((unsigned)((f.k_pad + 255) / 256)), dim3(256), 0, s, wsq, (int)k_codes, (int)f.k_pad, w.wsqp);
+    (void)set_lds_once<filter_f16_kernel<5, false, true>>(F_SMEM_BYTES);
+    dim3 fgrid((unsigned)f.main_tiles, (unsigned)f.splits);
+    if (f.xcd_rows) fgrid = dim3((unsigned)(((f.main_tiles + 8 * f.xcd_rows - 1) / (8 * f.xcd_rows)) * 256), 1);
+    const size_t blocks = (size_t)fgrid.x * fgrid.y;
+    if (probe_bytes < blocks * 8 * 8 * 8) return fail("filter_probe: probe buffer too small (%zu < %zu)", probe_bytes, blocks * 512);
+    if (hipMemsetAsync(probe, 0, blocks * 512, s) != hipSuccess) return fail("filter_probe: memset failed");
+    hipLaunchKernelGGL((filter_f16_kernel<5, false, true>), fgrid, dim3(F_THREADS), F_SMEM_BYTES, s,
+                       w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
+                       w.cand, w.cand_cnt, (float *)probe, f.xcd_rows, f.splits, 0, (int)f.main_tiles);
+    if (n_blocks) *n_blocks = (int64_t)blocks;
+    return check_launch("filter_probe");
+}
+
 // Test hook: byte offset, inside a filter-path search workspace, of the int32 count of rows the filter handed to the exact kernel
 // (candidate list overflow, norms outside the bound's range, NaN) -- tests and tools read it after a search; (size_t)-1 if the shape
 // does not take the filter path.
