@@ -40,11 +40,14 @@ from . import ops
 # launches of ~8 us saved per layer against ~70 us of fp32 GEMM at the bound).  Negative: never.
 COMBINE_MAX_EXTRA_FLOPS = 8e9
 LPT_ORDER = True
-# Inference: the layers' dense products run on the library's split-fp16 MFMA GEMMs (CrossAttention._folded_rows_split) from this many
-# packed query rows up; below it the launch-bound forms further down (combined weights / library GEMMs) are kept.
+# Inference: the layers' dense products (and proj_text / proj_graph) run on the library's split-fp16 MFMA GEMMs
+# (CrossAttention._folded_rows_split) from this many packed query rows up.  1: always -- no library GEMM on the inference path at any
+# batch size (at the reference's own B = 256 the split form and the launch-bound combined-weight / hipBLASLt forms further down time
+# the same: 0.78-0.80 ms per forward, tools/r04/ab_fullref.py).
 SPLIT_PRODUCTS = True
-SPLIT_ATTENTION = True       # the graph side's attention on ops.shared_kv_attention_split (64-row blocks, keys from fp16 images)
-SPLIT_MIN_ROWS = 1024
+SPLIT_MIN_ROWS = 1
+SPLIT_ATTENTION = True       # the graph side's attention on ops.shared_kv_attention_split (keys from fp16 images, made once per forward)
+SPLIT_ATTENTION_MIN_ROWS = 1024      # ... from this many query rows up (below it the image pass is not worth its launch)
 # which form of the wide-batch attention core ops.shared_kv_attention_split runs (include/medtok_vq.h): 2 = two 32-row tiles of a
 # code per block, one phase apart on one copy of the keys (D = 256 / 512 / 768; the others fall back to 0 inside the library)
 ATTENTION_VARIANT = 2
@@ -546,7 +549,7 @@ class CrossAttention(nn.Module):
         side = None
         text_split = images_ready = None
         want_images = (not autograd and core is ops.shared_kv_attention and text.is_cuda and kv_text.shape[1] in ops.ATTENTION_SPLIT_WIDTHS
-                       and SPLIT_ATTENTION and nodes_sorted.shape[0] * heads >= SPLIT_MIN_ROWS and max_nodes > 0)
+                       and SPLIT_ATTENTION and nodes_sorted.shape[0] * heads >= SPLIT_ATTENTION_MIN_ROWS and max_nodes > 0)
         def text_chain(cur):
             for i, layer in enumerate(self.model):
                 cur = self._folded_rows(layer, cur, text_attend, next_split=i + 1 < len(self.model))
@@ -699,7 +702,7 @@ class CrossAttention(nn.Module):
         # the graph side's keys and have no lo part: no image pass, half the key bytes, two matrix passes per product instead of three
         half_keys = (not autograd and not torch.is_grad_enabled() and text.dtype == torch.float16 and text.is_contiguous()
                      and SPLIT_ATTENTION and ATTENTION_VARIANT == 2 and dim in ops.ATTENTION_HALF_KEY_WIDTHS
-                     and nodes.shape[0] * heads >= SPLIT_MIN_ROWS)
+                     and nodes.shape[0] * heads >= SPLIT_ATTENTION_MIN_ROWS)
         if half_keys:
             nodes = nodes.float()                          # (queries and the text side's keys: fp32)
         elif nodes.dtype != text.dtype:                    # autocast hands over bf16 text features and fp32 node features
@@ -713,7 +716,7 @@ class CrossAttention(nn.Module):
             images = ((text.view(bsz * seq_len, dim), None), None)
         elif (not autograd and not torch.is_grad_enabled() and SPLIT_ATTENTION and 0 < SIDE_STREAM_MIN_CODES <= bsz
                 and text.dtype == torch.float32 and nodes.dtype == torch.float32 and text.is_contiguous()
-                and dim in ops.ATTENTION_SPLIT_WIDTHS and nodes.shape[0] * heads >= SPLIT_MIN_ROWS and nodes.shape[0] > 0):
+                and dim in ops.ATTENTION_SPLIT_WIDTHS and nodes.shape[0] * heads >= SPLIT_ATTENTION_MIN_ROWS and nodes.shape[0] > 0):
             # The (hi, lo) fp16 images of the valid text rows -- the keys of the graph side, an HBM-bound pass over the whole text
             # batch (1.3 ms at BASELINE sizes) that needs nothing but the token counts: on a stream of its own, under the host
             # read below and the first dense products.
@@ -956,23 +959,32 @@ class VectorQuantizer(nn.Module):
     # of the state dict) and the caches keyed by weight version (_cached: built once, read-only afterwards).
     def _shared(self, z_text, z_graph, text_mask, batch, norm=None, usage_counts=None):
         """get_shared_info plus the token ids / weights of its two searches: (embedding, losses, usage, tokens)."""
+        # inference: the two searches write their halves of the [B, 2 e_dim] result in place (no torch.cat).  The buffer is
+        # allocated HERE, before pooled() forks its side stream: a block the allocator hands out on this stream may still be the
+        # scratch of kernels queued on it, and only a stream that has waited for this one (the fork does) may write to it early.
+        emb = None
+        if not self.training and not torch.is_grad_enabled() and z_text.is_cuda and self.e_dim % 4 == 0:
+            emb = torch.empty((z_text.shape[0], 2 * self.e_dim), dtype=torch.float32, device=z_text.device)
         pooled_text, pooled_graph, pending = self.cross_attn.pooled(z_text, text_mask, z_graph, batch, join=False)
+        out_t, out_g = (emb[:, :self.e_dim], emb[:, self.e_dim:]) if emb is not None else (None, None)
         if pending is not None:
             # the text side ran on the second stream: its shared search follows it there, beside the graph side's tail and search
             side, main = pending
+            if emb is not None:
+                _lend(side, emb)
             with torch.cuda.stream(side):
-                r_t = self._search(pooled_text, "shared", self.training, norm=norm)
-            r_g = self._search(pooled_graph, "shared", self.training, norm=norm)
+                r_t = self._search(pooled_text, "shared", self.training, out=out_t, norm=norm)
+            r_g = self._search(pooled_graph, "shared", self.training, out=out_g, norm=norm)
             _join_side(side, main, (pooled_text, *r_t))
         else:
-            r_t = self._search(pooled_text, "shared", self.training, norm=norm)
-            r_g = self._search(pooled_graph, "shared", self.training, norm=norm)
+            r_t = self._search(pooled_text, "shared", self.training, out=out_t, norm=norm)
+            r_g = self._search(pooled_graph, "shared", self.training, out=out_g, norm=norm)
         zq_t, vq_t, cm_t, xhat_t, idx_t, w_t = r_t
         zq_g, vq_g, cm_g, xhat_g, idx_g, w_g = r_g
-        usage = self.codebook_usage(torch.cat([idx_t, idx_g], dim=-1), types="shared", _counts=usage_counts)
+        usage = self.codebook_usage(torch.cat([idx_t, idx_g], dim=-1), types="shared", _counts=usage_counts) if self.show_usage else 0.0
         tokens = {"shared_text_tokens": idx_t, "shared_text_tokens_weights": w_t,
                   "shared_graph_tokens": idx_g, "shared_graph_tokens_weights": w_g}
-        return (torch.cat([zq_t, zq_g], dim=-1), (vq_t + vq_g, cm_t + cm_g, xhat_t, xhat_g, zq_t, zq_g), usage, tokens)
+        return (emb if emb is not None else torch.cat([zq_t, zq_g], dim=-1), (vq_t + vq_g, cm_t + cm_g, xhat_t, xhat_g, zq_t, zq_g), usage, tokens)
 
     def _specific(self, original_embedding, types, norm=None, usage_counts=None):
         """specific_embedding plus the ids / weights of its search: (zq, losses, usage, idx, w)."""

@@ -229,7 +229,8 @@ def test_quantize_pooled_equals_forward_searches(dev):
     h = torch.randn(777, 256, device=dev); pt = torch.randn(777, 128, device=dev); pg = torch.randn(777, 128, device=dev)
     emb, tok, w = quantize_pooled(v, h, pt, pg)
     assert emb.shape == (777, 512) and tok.shape == (777, 4, 5) and w.shape == (777, 4, 5)
-    zq, _, _, ids_text, _ = v.specific_embedding(h[:, :128], "text", return_tokens=True)
+    with torch.no_grad():               # (quantize_pooled runs under no_grad: the same projection kernel then)
+        zq, _, _, ids_text, _ = v.specific_embedding(h[:, :128], "text", return_tokens=True)
     assert torch.equal(zq, emb[:, :128]) and torch.equal(ids_text, tok[:, 0])
     assert int(tok[:, :2].max()) < 512 and int(tok[:, 2:].max()) < 1536
     assert torch.allclose(w.sum(-1), torch.ones_like(w.sum(-1)), atol=1e-6)
@@ -487,13 +488,23 @@ def test_cross_attention_combined_weights_match_two_step_form(dev):
     text, mask, nodes, batch = (t.to(dev) for t in synth.ragged_batch("tf", B, 48, 12, D, 5))
 
     def both():
+        # (the library's split-fp16 products are the default at every size: the combined-weight form and the two-step form on
+        # torch GEMMs are what remains when they are switched off)
+        keep_split, M.SPLIT_PRODUCTS = M.SPLIT_PRODUCTS, False
+        try:
+            with torch.no_grad():
+                a = v.cross_attn.pooled(text, mask, nodes, batch)
+                keep, M.COMBINE_MAX_EXTRA_FLOPS = M.COMBINE_MAX_EXTRA_FLOPS, -1.0
+                try:
+                    b = v.cross_attn.pooled(text, mask, nodes, batch)
+                finally:
+                    M.COMBINE_MAX_EXTRA_FLOPS = keep
+        finally:
+            M.SPLIT_PRODUCTS = keep_split
         with torch.no_grad():
-            a = v.cross_attn.pooled(text, mask, nodes, batch)
-            keep, M.COMBINE_MAX_EXTRA_FLOPS = M.COMBINE_MAX_EXTRA_FLOPS, -1.0
-            try:
-                b = v.cross_attn.pooled(text, mask, nodes, batch)
-            finally:
-                M.COMBINE_MAX_EXTRA_FLOPS = keep
+            c = v.cross_attn.pooled(text, mask, nodes, batch)          # the shipped form: same function
+        for x, y in zip(c, b):
+            assert float((x - y).abs().max()) <= 3e-6 * max(float(y.abs().max()), 1.0)
         return a, b
 
     (a_t, a_g), (b_t, b_g) = both()
@@ -600,7 +611,19 @@ def test_side_stream_forward_equals_single_stream(dev):
         finally:
             M.SIDE_STREAM_MIN_CODES = keep
     ref, used_ref = run(0)
-    for _ in range(4):
+    busy = torch.randn(3072, 3072, device=dev)
+    for it in range(6):
+        if it >= 2:
+            # a block of the size the forward allocates for its outputs, still the target of work QUEUED on this stream when the
+            # forward starts: a side stream that wrote into a fresh allocation without having waited for this stream would lose its
+            # result to the queued fill (found in round 4: the shared searches' common output buffer)
+            for shape in ((B, 2 * D), (B, D), (B, 5)):
+                junk = torch.empty(shape, device=dev)
+                acc = busy
+                for _ in range(6):
+                    acc = (acc @ busy) * 1e-3
+                junk.fill_(float("nan"))
+                del junk, acc
         got, used = run(512)
         torch.empty(64 << 20, device=dev).fill_(float("nan"))          # churn the allocator between the runs
         assert torch.equal(used, used_ref)
