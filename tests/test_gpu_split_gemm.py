@@ -74,9 +74,9 @@ def test_split_half_is_exact_to_22_bits_and_pads_with_zeros(dev):
 
 
 def test_projection_of_the_specific_searches_matches_nn_linear(dev):
-    """VectorQuantizer.project: proj_text / proj_graph (reference :190,192) on the split-fp16 product at inference from 1024 rows up
-    (a column block of a wider [N, 2D] tensor, as forward() hands it over), nn.Linear otherwise; the cached weight images follow
-    weight versions."""
+    """VectorQuantizer.project: proj_text / proj_graph (reference :190,192) on the split-fp16 product at inference at every batch
+    size (a column block of a wider [N, 2D] tensor, as forward() hands it over); the nn.Linear itself in eval mode with autograd on
+    and when the split products are switched off; the cached weight images follow weight versions."""
     from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
     torch.manual_seed(1)
     D = 768
@@ -92,8 +92,14 @@ def test_projection_of_the_specific_searches_matches_nn_linear(dev):
             assert float((got.double() - ref).abs().max()) <= 3e-6 * scale
             assert float((got.double() - ref).abs().max()) <= max(4 * float((lib.double() - ref).abs().max()), 1e-6 * scale)
             assert getattr(lin, "_medtok_split_cache", None) is not None
-        small = v.project(zt[:100], "text")                      # below the row threshold: the nn.Linear itself
-        assert torch.equal(small, v.proj_text(zt[:100]))
+        small = v.project(zt[:100], "text")                      # a small batch: the same product (round 3 kept nn.Linear below 1024 rows)
+        assert torch.equal(small, v.project(zt, "text")[:100])
+        import medtok_amd.vector_quantization_soft_one_new as M
+        keep, M.SPLIT_PRODUCTS = M.SPLIT_PRODUCTS, False
+        try:
+            assert torch.equal(v.project(zt[:100], "text"), v.proj_text(zt[:100]))      # switched off: the nn.Linear itself
+        finally:
+            M.SPLIT_PRODUCTS = keep
         v.proj_text.weight.mul_(2.0)                             # version bump: the images are rebuilt
         got2 = v.project(zt, "text")
         ref2 = torch.nn.functional.linear(zt.double(), v.proj_text.weight.double(), v.proj_text.bias.double())
