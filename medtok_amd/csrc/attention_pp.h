@@ -380,3 +380,11 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
     __syncthreads();
     att_store_tile<W, NT, S::HALVES>(att_sm + grp * S::STAGE_FLOATS, acc, l16, active ? nq - qt * 32 : 0, qs + qt * 32, out, out_h, out_l, slice, li, lh, gt);
 }
+
+// Built and measured in round 4, not kept: the same kernel with TWO phases per chunk -- every wave of a group runs the softmax of all
+// 32 rows itself (lane = (row, 8 keys): joins the four partial tiles, meets the other half through v_permlane32_swap) and ends with
+// P[row][8 keys] in registers, which is the A operand of the 32 x 32 x 16 value MFMA: no probability tile in LDS, no barrier between
+// softmax and values, two barriers per chunk instead of three (the ring then has one slot, not two, for a copy to arrive; with and
+// without a one-dword-per-line L2 touch of the chunk after next).  Correct (same tests), 1.68 ms (1.75 with the touch) against
+// 1.65 ms for the three-phase form above and 1.65-1.78 for attention_dma.h's on the `full` workload's graph-side launch: three
+// different phase structures land within 5 % of each other.

@@ -1525,7 +1525,8 @@ extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_
     if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention_split: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
     if (!attention_dma_shape_ok(d)) return fail("shared_kv_attention_split: d=%d must be 128, 256, 384, 512 or 768", d);
     if (n_codes == 0 || max_q_len == 0) return 0;
-    const bool pp_shape = (variant & 15) == 2 && (d == 256 || d == 512 || d == 768);
+    const int vform = variant & 15;
+    const bool pp_shape = vform == 2 && (d == 256 || d == 512 || d == 768);
     if (!q || !q_start || !q_len || !kv_hi || !kv_start || !kv_len || (!out && !out_hi)) return fail("shared_kv_attention_split: NULL argument");
     if (!kv_lo && !pp_shape) return fail("shared_kv_attention_split: keys without a lo image (fp16 keys as they stand) need variant 2 and d = 256, 512 or 768");
     if (((uintptr_t)q | (uintptr_t)kv_hi | (uintptr_t)kv_lo | (uintptr_t)out) & 15) return fail("shared_kv_attention_split: pointers must be 16-byte aligned");
