@@ -262,8 +262,23 @@ int medtok_shared_kv_attention_split_f32(const float *q, const int64_t *q_start,
                                          const void *kv_hi, const void *kv_lo, const int64_t *kv_start, const int64_t *kv_len,
                                          int64_t n_codes, int64_t max_q_len, int d, float scale, float *out,
                                          void *out_hi, void *out_lo, int variant, void *stream);
-/* (variant, d = 768 only: 0 = 32 query rows per block and two blocks per CU -- one block's softmax and copy waits overlap the
- * other's matrix work; 1 = 64 rows per block, one block per CU, double-buffered key ring.  Same results.) */
+/* variant: 0 = 32 query rows per block and (d = 768) two blocks per CU -- one block's softmax and copy waits overlap the other's
+ * matrix work; 1 (d = 768) = 64 rows per block, one block per CU, double-buffered key ring; 2 (d = 256, 512, 768; what the Python
+ * layer passes) = two 32-row query tiles of a code per block, run one phase apart on ONE two-deep ring of key chunks
+ * (attention_pp.h).  Same function; 0 / 1 agree to the last bits, 2 within 2e-6 of them (exp on v_exp_f32).
+ * kv_lo = NULL (variant 2 only): the keys are fp16 as they stand -- a caller under fp16 autocast hands over half-precision text
+ * features (train_MedTok.py:212,394): no lo image is read, two matrix passes per product instead of three; equal to the call with
+ * an all-zero lo image bit for bit. */
+
+/* Dev probes (tools/r04/att_probe.py, tools/r04/filter_probe.py): per-wave cycle counts (s_memtime) of a kernel's loop segments,
+ * written by a TIMED instantiation that only these entry points launch.  medtok_debug_set_attention_probe(p) arms the next
+ * medtok_shared_kv_attention_split_f32 calls with variant = 2 | (8 << 4), d = 768 (uint64 [blocks][8 waves][8]; NULL disarms; the one
+ * piece of process state besides the bench profiler); medtok_debug_filter_probe runs the filter kernel of one search
+ * (uint64 [blocks][8][8]: MFMA group 1, wait for own copies, stage barrier, MFMA group 2, tile epilogue, stages, code tiles). */
+void medtok_debug_set_attention_probe(void *probe);
+int medtok_debug_filter_probe(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq, int64_t k_codes,
+                              int d, int topk, void *ws, size_t ws_bytes, void *probe, size_t probe_bytes, int64_t *n_blocks,
+                              void *stream);
 
 /* The prologue of the batched cross-attention: what the reference's per-code loop reads back with `.item()` and `batch == idx`
  * (vector_quantization_soft_one_new.py:133-142), for all codes at once, in three small launches and no host round trip:

@@ -44,14 +44,13 @@ struct AttPP {
 // bar of the attention outputs; expf()'s range reduction was a third of the softmax step.
 __device__ __forceinline__ float pp_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
-// ABL (dev builds of tools/r04 only; the product instantiates ABL = 0): timing ablations -- bit 0: no MFMAs, bit 1: no key copies
-// after the first two chunks, bit 2: no softmax step, bit 3: per-wave cycle counts of the phases into `dbg`.  Results are garbage
-// for bits 0-2.
+// TIMED (dev probe, tools/r04/att_probe.py through medtok_debug_set_attention_probe; the product instantiates TIMED = false): per-wave
+// cycle counts (s_memtime) of the three phases and of the waits between them, written to `dbg` (uint64 [blocks][8 waves][8]).
 // KLO = false: the keys are fp16 as they stand (a caller under fp16 autocast hands over half-precision text features, the
 // reference's default training mode train_MedTok.py:212,394): there is no lo image -- kvl is not read, a chunk is one plane (half
 // the bytes from HBM and through the DMA), and the passes against it drop out of both products (two MFMAs per step instead of
 // three).  With lo = 0 the three-pass form adds exact zeros, so the results equal the KLO form on the widened keys bit for bit.
-template <int NT, int ABL = 0, bool KLO = true>
+template <int NT, bool TIMED = false, bool KLO = true>
 __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
     const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
     const _Float16 *__restrict__ kvh, const _Float16 *__restrict__ kvl, const int64_t *__restrict__ kv_start,
@@ -157,10 +156,10 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-#define PP_MFMA16(a, b, c, x, y, z) ((ABL & 1) ? (c) : __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z))
-#define PP_MFMA32(a, b, c, x, y, z) ((ABL & 1) ? (c) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z))
+#define PP_MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
+#define PP_MFMA32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
     unsigned long long t_s = 0, t_x = 0, t_v = 0, t_w = 0, t_0 = 0;
-    if (ABL & 8) t_0 = __builtin_amdgcn_s_memtime();
+    if (TIMED) t_0 = __builtin_amdgcn_s_memtime();
     auto phase_s = [&](int c) __attribute__((always_inline)) {
         const unsigned cb = (unsigned)((c & 1) * CHUNKB);
         // ---- S: partial scores of the group's 32 rows x 16 keys over this wave's columns: NT k steps x 2 tiles x 3 passes
@@ -329,10 +328,10 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
     };
     // the ring: at slot 3c'+1 (c' >= 1) the buffer of chunk c'-1 is free -- its last reader, g1's V(c'-1), ran in slot 3c'
     auto refill = [&](int cp) __attribute__((always_inline)) {
-        if (!(ABL & 2) && cp >= 1 && cp + 1 < nchunk) stage(cp + 1);
+        if (cp >= 1 && cp + 1 < nchunk) stage(cp + 1);
     };
     auto timed = [&](unsigned long long &acc_t, auto &&fn) __attribute__((always_inline)) {
-        if (ABL & 8) {
+        if (TIMED) {
             const unsigned long long a = __builtin_amdgcn_s_memtime();
             fn();
             acc_t += __builtin_amdgcn_s_memtime() - a;
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
             if (active) timed(t_s, [&]() __attribute__((always_inline)) { phase_s(c); });
             timed(t_w, [&]() __attribute__((always_inline)) { slot_end(false); });
             refill(c);
-            if (active && !(ABL & 4)) timed(t_x, [&]() __attribute__((always_inline)) { phase_x(c); });
+            if (active) timed(t_x, [&]() __attribute__((always_inline)) { phase_x(c); });
             timed(t_w, [&]() __attribute__((always_inline)) { slot_end(false); });
             if (active) timed(t_v, [&]() __attribute__((always_inline)) { phase_v(c); });
             timed(t_w, [&]() __attribute__((always_inline)) { slot_end(true); });
@@ -357,7 +356,7 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
             refill(c);
             if (active) timed(t_s, [&]() __attribute__((always_inline)) { phase_s(c); });
             timed(t_w, [&]() __attribute__((always_inline)) { slot_end(false); });
-            if (active && !(ABL & 4)) timed(t_x, [&]() __attribute__((always_inline)) { phase_x(c); });
+            if (active) timed(t_x, [&]() __attribute__((always_inline)) { phase_x(c); });
             timed(t_w, [&]() __attribute__((always_inline)) { slot_end(true); });
             if (active) timed(t_v, [&]() __attribute__((always_inline)) { phase_v(c); });
             timed(t_w, [&]() __attribute__((always_inline)) { slot_end(false); });
@@ -365,7 +364,7 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
     }
 #undef PP_MFMA16
 #undef PP_MFMA32
-    if ((ABL & 8) && dbg && lane == 0) {
+    if (TIMED && dbg && lane == 0) {
         unsigned long long *o = dbg + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 8;
         o[0] = t_s; o[1] = t_x; o[2] = t_v; o[3] = t_w; o[4] = __builtin_amdgcn_s_memtime() - t_0; o[5] = (unsigned long long)nchunk; o[6] = active;
         o[7] = (unsigned long long)__builtin_amdgcn_s_memrealtime();

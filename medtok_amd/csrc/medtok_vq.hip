@@ -1547,20 +1547,19 @@ extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_
         // two 32-row tiles of a code per block, run one phase apart on one copy of the keys (attention_pp.h)
         const int64_t q_pairs = (max_q_len + 63) / 64;
         if (q_pairs * (n_codes + 8) >= (1ll << 31)) return fail("shared_kv_attention_split: grid limit exceeded");
-#define MEDTOK_ATT_PP(NT, ABL, KLO)                                                                                               \
+#define MEDTOK_ATT_PP(NT, TIMED, KLO)                                                                                              \
     do {                                                                                                                          \
         const size_t lds = AttPP<NT>::LDS_BYTES;                                                                                  \
-        if (!set_lds_once<shared_kv_attention_pp_kernel<NT, ABL, KLO>>(lds)) return fail("shared_kv_attention_split: cannot reserve %zu bytes of LDS", lds); \
-        hipLaunchKernelGGL((shared_kv_attention_pp_kernel<NT, ABL, KLO>), dim3((unsigned)(q_pairs * ((n_codes + 7) / 8 * 8))), dim3(512), lds, s, q, q_start, \
+        if (!set_lds_once<shared_kv_attention_pp_kernel<NT, TIMED, KLO>>(lds)) return fail("shared_kv_attention_split: cannot reserve %zu bytes of LDS", lds); \
+        hipLaunchKernelGGL((shared_kv_attention_pp_kernel<NT, TIMED, KLO>), dim3((unsigned)(q_pairs * ((n_codes + 7) / 8 * 8))), dim3(512), lds, s, q, q_start, \
                            q_len, (const _Float16 *)kv_hi, (const _Float16 *)kv_lo, kv_start, kv_len, scale, out, (_Float16 *)out_hi,             \
                            (_Float16 *)out_lo, (int)q_pairs, (int)n_codes, (unsigned long long *)g_att_dbg);                      \
     } while (0)
-        const int abl = variant >> 4;
-        if (!kv_lo) { if (d == 256) MEDTOK_ATT_PP(2, 0, false); else if (d == 512) MEDTOK_ATT_PP(4, 0, false); else MEDTOK_ATT_PP(6, 0, false); }
-        else if (d == 256) MEDTOK_ATT_PP(2, 0, true); else if (d == 512) MEDTOK_ATT_PP(4, 0, true);
-        else if (abl == 1) MEDTOK_ATT_PP(6, 1, true); else if (abl == 2) MEDTOK_ATT_PP(6, 2, true); else if (abl == 3) MEDTOK_ATT_PP(6, 3, true);
-        else if (abl == 4) MEDTOK_ATT_PP(6, 4, true); else if (abl == 7) MEDTOK_ATT_PP(6, 7, true); else if (abl == 8) MEDTOK_ATT_PP(6, 8, true);
-        else MEDTOK_ATT_PP(6, 0, true);
+        const bool timed = (variant >> 4) == 8 && g_att_dbg;          // (dev probe: tools/r04/att_probe.py)
+        if (!kv_lo) { if (d == 256) MEDTOK_ATT_PP(2, false, false); else if (d == 512) MEDTOK_ATT_PP(4, false, false); else MEDTOK_ATT_PP(6, false, false); }
+        else if (d == 256) MEDTOK_ATT_PP(2, false, true); else if (d == 512) MEDTOK_ATT_PP(4, false, true);
+        else if (timed) MEDTOK_ATT_PP(6, true, true);
+        else MEDTOK_ATT_PP(6, false, true);
 #undef MEDTOK_ATT_PP
         if (pa) prof_push(pa, prof_mark(s), 0.0, 2);
         return check_launch("shared_kv_attention_split(pp)");

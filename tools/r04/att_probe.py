@@ -23,8 +23,8 @@ def t(v, ks=k_start, reps=10):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): run(v, ks)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
-names = {0: "dma <4,6,1,1> (shipped)", 1: "dma <8,3,2,2>", 2: "pp", 2 + 16: "pp no MFMA", 2 + 32: "pp no refill copies", 2 + 48: "pp no MFMA, no copies",
-         2 + 64: "pp no softmax", 2 + 7 * 16: "pp skeleton only (no MFMA, copies, softmax)"}
+# (round 4 also timed ablation builds -- no MFMA / no key copies / no softmax: profiles/r04_attention_pp_probe.txt; those template bits are gone)
+names = {0: "dma <4,6,1,1> (round 3)", 1: "dma <8,3,2,2>", 2: "pp (shipped)"}
 for rnd in range(2):
     for v, nm in names.items():
         print(f"round {rnd} {nm:45s} {t(v):7.3f} ms   keys L2-resident: {t(v, k_same):7.3f} ms", flush=True)
@@ -33,7 +33,6 @@ lib = _lib.load()
 pairs = 3
 nblk = pairs * ((B + 7) // 8 * 8)
 dbg = torch.zeros(nblk * 8 * 8, dtype=torch.int64, device=dev)
-lib.medtok_debug_set_attention_probe.argtypes = [ctypes.c_void_p]
 lib.medtok_debug_set_attention_probe(ctypes.c_void_p(dbg.data_ptr()))
 run(2 + 128); torch.cuda.synchronize()
 dbg.zero_(); run(2 + 128); torch.cuda.synchronize()

@@ -12,9 +12,6 @@ g = torch.Generator(device=dev).manual_seed(0)
 xh, xs = ops.rownorm(torch.randn(N, D, device=dev, generator=g))
 wh, ws = ops.rownorm(torch.randn(K, D, device=dev, generator=g))
 lib = _lib.load()
-lib.medtok_debug_filter_probe.restype = ctypes.c_int
-lib.medtok_debug_filter_probe.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
-                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]
 nb = lib.medtok_search_workspace_bytes(N, K, D, 5, ops.PATH_F16_FILTER)
 wsb = torch.empty(nb, dtype=torch.uint8, device=dev)
 probe = torch.zeros(8192 * 64, dtype=torch.int64, device=dev)
