@@ -314,6 +314,23 @@ int medtok_residual_layernorm_split_f32(const float *a, const float *b, const fl
 int medtok_segment_mean_f32(const float *x, const int64_t *seg_start, const int64_t *seg_len, int64_t n_seg, int d,
                             float *out, void *stream);
 
+/* One CrossAttentionLayer (vector_quantization_soft_one_new.py:17-51, projections folded into the queries) at inference in ONE call:
+ * rows [n_rows, d] -> (hi, lo) images (or the caller's, rows_hi / rows_lo [n_rows, dw], e.g. the previous layer's y_hi / y_lo)
+ * -> in_proj -> per-head fold -> attention core over the ragged (q_start, q_len, kv_start, kv_len) lists (keys: kv fp32 [Rk, dw], or
+ * their fp16 images kv_hi / kv_lo as in medtok_shared_kv_attention_split_f32) -> per-head W_v -> out_proj -> LayerNorm(rows + .)
+ * -> y [n_rows, d] (+ its images [n_rows, dw] when y_hi is given).  Weight images and biases as CrossAttention._split_weights lays
+ * them out: wq, wv [heads hp, dw], wk [heads dw, hp], wo [d, heads hp], bq, bv [heads hp], bo [d]; hp = the head width padded to 32.
+ * The seven launches are the entry points above with the same arguments -- the same bits as seven separate calls; the
+ * intermediates live in `ws` (medtok_cross_attention_layer_workspace_bytes). */
+size_t medtok_cross_attention_layer_workspace_bytes(int64_t n_rows, int d, int dw, int heads, int hp);
+int medtok_cross_attention_layer_f32(
+    const float *rows, const void *rows_hi, const void *rows_lo, int64_t n_rows, int d, int dw, int heads, int hp,
+    const void *wq_hi, const void *wq_lo, float wq_unscale, const float *bq, const void *wk_hi, const void *wk_lo, float wk_unscale,
+    const void *wv_hi, const void *wv_lo, float wv_unscale, const float *bv, const void *wo_hi, const void *wo_lo, float wo_unscale,
+    const float *bo, const int64_t *q_start, const int64_t *q_len, int64_t n_codes, int64_t max_q_len, const float *kv,
+    const void *kv_hi, const void *kv_lo, const int64_t *kv_start, const int64_t *kv_len, float scale, int variant,
+    const float *ln_gamma, const float *ln_beta, float ln_eps, float *y, void *y_hi, void *y_lo, void *ws, size_t ws_bytes, void *stream);
+
 /* The same core for TRAINING, and its backward: dropout on the attention probabilities (nn.MultiheadAttention(dropout=0.1),
  * reference :21,30) by a stateless hash mask of (seed, packed query row, key) -- P(keep) = 1 - dropout_p, kept probabilities
  * scaled by 1 / (1 - dropout_p); the forward also returns lse[r] = log sum_j exp(scale <q_r, kv_j>) (-inf for an empty key

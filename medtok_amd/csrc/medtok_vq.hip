@@ -1657,6 +1657,58 @@ extern "C" int medtok_residual_layernorm_f32(const float *a, const float *b, con
     return medtok_residual_layernorm_split_f32(a, b, gamma, beta, n, d, eps, y, nullptr, nullptr, 0, stream);
 }
 
+// One CrossAttentionLayer at inference in ONE call: the seven launches of CrossAttention._folded_rows_split (rows -> images ->
+// in_proj -> per-head fold -> attention core -> per-head W_v -> out_proj -> residual + LayerNorm), composed from the entry points
+// above with the intermediates in caller-provided scratch.  Same kernels, same arguments, same bits as the seven separate calls;
+// what it saves is the host side of six of them (a B = 256 forward is host-bound: ~55 calls of ~15 us against 0.45 ms of kernels).
+extern "C" size_t medtok_cross_attention_layer_workspace_bytes(int64_t n_rows, int d, int dw, int heads, int hp)
+{
+    const size_t r = (size_t)(n_rows > 0 ? n_rows : 1);
+    return 2 * align_up(r * dw * 2, 256) + 2 * align_up(r * heads * hp * 2, 256) + align_up(r * heads * dw * 4, 256) +
+           2 * align_up(r * heads * dw * 2, 256) + 2 * align_up(r * heads * hp * 2, 256) + align_up(r * d * 4, 256);
+}
+
+extern "C" int medtok_cross_attention_layer_f32(
+    const float *rows, const void *rows_hi, const void *rows_lo, int64_t n_rows, int d, int dw, int heads, int hp,
+    const void *wq_hi, const void *wq_lo, float wq_unscale, const float *bq, const void *wk_hi, const void *wk_lo, float wk_unscale,
+    const void *wv_hi, const void *wv_lo, float wv_unscale, const float *bv, const void *wo_hi, const void *wo_lo, float wo_unscale, const float *bo,
+    const int64_t *q_start, const int64_t *q_len, int64_t n_codes, int64_t max_q_len, const float *kv, const void *kv_hi, const void *kv_lo,
+    const int64_t *kv_start, const int64_t *kv_len, float scale, int variant, const float *ln_gamma, const float *ln_beta, float ln_eps,
+    float *y, void *y_hi, void *y_lo, void *ws, size_t ws_bytes, void *stream)
+{
+    if (n_rows < 0 || d <= 0 || dw < d || heads <= 0 || hp <= 0) return fail("cross_attention_layer: bad shape n_rows=%ld d=%d dw=%d heads=%d hp=%d", (long)n_rows, d, dw, heads, hp);
+    if (n_rows == 0) return 0;
+    const size_t need = medtok_cross_attention_layer_workspace_bytes(n_rows, d, dw, heads, hp);
+    if (!ws || ws_bytes < need) return fail("cross_attention_layer: workspace too small (%zu < %zu)", ws_bytes, need);
+    if (!rows || !y || (!kv && !kv_hi)) return fail("cross_attention_layer: NULL argument");
+    char *p = (char *)ws;
+    auto take = [&](size_t bytes) { char *q = p; p += align_up(bytes, 256); return (void *)q; };
+    const size_t r = (size_t)n_rows;
+    void *x_hi = take(r * dw * 2), *x_lo = take(r * dw * 2);
+    void *q_hi = take(r * heads * hp * 2), *q_lo = take(r * heads * hp * 2);
+    float *qf = (float *)take(r * heads * dw * 4);
+    void *c_hi = take(r * heads * dw * 2), *c_lo = take(r * heads * dw * 2);
+    void *a_hi = take(r * heads * hp * 2), *a_lo = take(r * heads * hp * 2);
+    float *o = (float *)take(r * d * 4);
+    if (rows_hi && rows_lo) { x_hi = (void *)rows_hi; x_lo = (void *)rows_lo; }
+    else if (medtok_split_half_f32(rows, n_rows, d, d, dw, 1.0f, x_hi, x_lo, nullptr, 0, stream)) return 1;
+    if (medtok_split_gemm_f16(x_hi, x_lo, n_rows, dw, 0, wq_hi, wq_lo, (int64_t)heads * hp, dw, 0, heads * hp, dw, 1, bq, wq_unscale, nullptr, 0, q_hi, q_lo,
+                              heads * hp, stream)) return 1;
+    if (medtok_split_gemm_f16(q_hi, q_lo, n_rows, heads * hp, hp, wk_hi, wk_lo, (int64_t)heads * dw, hp, dw, dw, hp, heads, nullptr, wk_unscale, qf, heads * dw,
+                              nullptr, nullptr, 0, stream)) return 1;
+    if (kv_hi) {
+        if (medtok_shared_kv_attention_split_f32(qf, q_start, q_len, kv_hi, kv_lo, kv_start, kv_len, n_codes, max_q_len, dw, scale, nullptr, c_hi, c_lo, variant, stream))
+            return 1;
+    } else if (medtok_shared_kv_attention_f32(qf, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, dw, scale, nullptr, c_hi, c_lo, 0, stream)) {
+        return 1;
+    }
+    if (medtok_split_gemm_f16(c_hi, c_lo, n_rows, heads * dw, dw, wv_hi, wv_lo, (int64_t)heads * hp, dw, hp, hp, dw, heads, bv, wv_unscale, nullptr, 0, a_hi, a_lo,
+                              heads * hp, stream)) return 1;
+    if (medtok_split_gemm_f16(a_hi, a_lo, n_rows, heads * hp, 0, wo_hi, wo_lo, d, heads * hp, 0, d, heads * hp, 1, bo, wo_unscale, o, d, nullptr, nullptr, 0, stream))
+        return 1;
+    return medtok_residual_layernorm_split_f32(rows, o, ln_gamma, ln_beta, n_rows, d, ln_eps, y, y_hi, y_lo, y_hi ? dw : 0, stream);
+}
+
 extern "C" int medtok_segment_mean_f32(const float *x, const int64_t *seg_start, const int64_t *seg_len, int64_t n_seg, int d, float *out,
                                        void *stream)
 {

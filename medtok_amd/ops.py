@@ -419,6 +419,34 @@ def pack_codes(mask, batch, heads: int, lpt: bool):
     return r
 
 
+def cross_attention_layer(rows, rows_images, w, q_start, q_len, max_q_len: int, kv, kv_split, kv_start, kv_len, scale: float, variant: int,
+                          gamma, beta, eps: float, want_images: bool):
+    """One CrossAttentionLayer at inference in one C call (include/medtok_vq.h: medtok_cross_attention_layer_f32).  rows [R, d] fp32;
+    rows_images: their (hi, lo) images [R, dw] or None; w: the dict of CrossAttention._split_weights; kv fp32 [Rk, dw] or kv_split =
+    (hi, lo | None) images.  Returns y [R, d] (and its images [R, dw] when want_images)."""
+    rows = _dev(rows, "rows")
+    n_rows, d = rows.shape
+    heads, hp, dw = w["heads"], w["hp"], w["dw"]
+    dev = rows.device
+    y = torch.empty_like(rows)
+    yh = torch.empty((n_rows, dw), dtype=torch.float16, device=dev) if want_images else None
+    yl = torch.empty((n_rows, dw), dtype=torch.float16, device=dev) if want_images else None
+    lib = _lib.load()
+    ws = _ws(lib.medtok_cross_attention_layer_workspace_bytes(n_rows, d, dw, heads, hp), rows)
+    (wq, wq_u), (wk, wk_u), (wv, wv_u), (wo, wo_u) = w["wq"], w["wk"], w["wv"], w["wo"]
+    xh, xl = rows_images if rows_images is not None else (None, None)
+    kh, kl = kv_split if kv_split is not None else (None, None)
+    with torch.cuda.device(dev):
+        _lib.check(lib.medtok_cross_attention_layer_f32(
+            rows.data_ptr(), _ptr(xh), _ptr(xl), n_rows, d, dw, heads, hp,
+            wq[0].data_ptr(), wq[1].data_ptr(), float(wq_u), w["bq"].data_ptr(), wk[0].data_ptr(), wk[1].data_ptr(), float(wk_u),
+            wv[0].data_ptr(), wv[1].data_ptr(), float(wv_u), w["bv"].data_ptr(), wo[0].data_ptr(), wo[1].data_ptr(), float(wo_u), w["bo"].data_ptr(),
+            q_start.data_ptr(), q_len.data_ptr(), q_start.numel(), int(max_q_len), _ptr(kv if kv_split is None else None), _ptr(kh), _ptr(kl),
+            kv_start.data_ptr(), kv_len.data_ptr(), float(scale), int(variant), gamma.data_ptr(), beta.data_ptr(), float(eps),
+            y.data_ptr(), _ptr(yh), _ptr(yl), ws.data_ptr(), ws.numel(), _stream(rows)), "medtok_cross_attention_layer_f32")
+    return (y, (yh, yl)) if want_images else y
+
+
 def segment_mean(x, seg_start, seg_len):
     """out[b] = mean of rows [seg_start[b], seg_start[b] + seg_len[b]) of the contiguous fp32 matrix x [rows, d] (rows added in
     order; an empty segment gives zeros) -- the `.mean(dim=0)` over a code's graph nodes (:140-141).  seg_* int64 device vectors."""

@@ -54,6 +54,9 @@ ATTENTION_VARIANT = 2
 # training / autograd: the cross-attention's dense products (and their backward) on the library's own split-fp16 GEMMs instead
 # of nn.functional.linear / einsum (hipBLASLt)
 TRAIN_SPLIT_PRODUCTS = True
+# inference: a layer's seven launches (images, four dense products, attention core, residual + LayerNorm) through ONE call of the
+# C ABI (medtok_cross_attention_layer_f32: the same kernels and bits; six fewer host round trips per layer and side)
+FUSED_LAYER_CALL = True
 # ... and the tokenizer's text mapping (tokenizer.py:118, a Linear over every token of the batch: 131 072 rows at B = 256, L = 512) too.
 # Off by default: under autocast the library's half-precision GEMM is ~3x cheaper than the fp32-accurate three-pass product, and
 # that layer is upstream of the quantiser (bench.py --precomputed-encoders turns it on for the all-own-kernels profile).
@@ -406,7 +409,20 @@ class CrossAttention(nn.Module):
         n_rows = rows.shape[0]
         # (the previous layer's tail has already written the images of its output: `next_split`)
         x = getattr(rows, "_medtok_images", None)
-        if x is None or x[0].shape != (n_rows, dw):
+        if x is not None and x[0].shape != (n_rows, dw):
+            x = None
+        core_args = getattr(attend, "core_args", None)
+        ln = layer.layer_norm
+        if FUSED_LAYER_CALL and core_args is not None:
+            a = core_args()
+            r = ops.cross_attention_layer(rows, x, w, a["q_start"], a["q_len"], a["max_q_len"], a["kv"], a["kv_split"], a["kv_start"], a["kv_len"],
+                                          a["scale"], ATTENTION_VARIANT, ln.weight, ln.bias, ln.eps, want_images=next_split)
+            if not next_split:
+                return r
+            y, images = r
+            y._medtok_images = images
+            return y
+        if x is None:
             x = ops.split_half(rows, dp=dw)
         _, q = ops.split_gemm(x, w["wq"][0], n_g=heads * hp, k_g=dw, bias=w["bq"], unscale=w["wq"][1], want_f32=False, want_split=True)
         qf, _ = ops.split_gemm(q, w["wk"][0], n_g=dw, k_g=hp, groups=heads, a_group_cols=hp, b_group_rows=dw, unscale=w["wk"][1])
@@ -415,7 +431,6 @@ class CrossAttention(nn.Module):
         _, att = ops.split_gemm(c, w["wv"][0], n_g=hp, k_g=dw, groups=heads, a_group_cols=dw, b_group_rows=hp, bias=w["bv"], unscale=w["wv"][1],
                                 want_f32=False, want_split=True)
         out, _ = ops.split_gemm(att, w["wo"][0], n_g=dim, k_g=heads * hp, bias=w["bo"], unscale=w["wo"][1])
-        ln = layer.layer_norm
         if not next_split:
             return ops.residual_layernorm(rows, out, ln.weight, ln.bias, ln.eps)
         y, images = ops.residual_layernorm(rows, out, ln.weight, ln.bias, ln.eps, split_dp=dw)
@@ -546,6 +561,9 @@ class CrossAttention(nn.Module):
         def text_attend(qf, **kw):
             return attend(qf, t_start, t_len, kv_nodes, starts, counts, heads, max_nodes, **kw)
         text_attend.library_core = lib_core
+        if lib_core:
+            text_attend.core_args = lambda: dict(q_start=t_start, q_len=t_len, max_q_len=heads, kv=kv_nodes, kv_split=None, kv_start=starts,
+                                                 kv_len=counts, scale=scale)
         side = None
         text_split = images_ready = None
         want_images = (not autograd and core is ops.shared_kv_attention and text.is_cuda and kv_text.shape[1] in ops.ATTENTION_SPLIT_WIDTHS
@@ -583,7 +601,7 @@ class CrossAttention(nn.Module):
             else:
                 text_split = ops.split_half(kv_text, seg_len=valid_len, seg_rows=seq_len)
 
-        def graph_attend(qf, **kw):
+        def images_for_use():
             nonlocal images_ready
             make_images()
             if images_ready is not None:                   # first use of the images made on the other stream
@@ -591,8 +609,14 @@ class CrossAttention(nn.Module):
                 for t in text_split:
                     t.record_stream(torch.cuda.current_stream(text.device))
                 images_ready = None
-            return attend(qf, g_start, g_len, kv_text, tok_start, g_kv_len, max_nodes * heads, seq_len, kv_split=text_split, **kw)
+            return text_split
+
+        def graph_attend(qf, **kw):
+            return attend(qf, g_start, g_len, kv_text, tok_start, g_kv_len, max_nodes * heads, seq_len, kv_split=images_for_use(), **kw)
         graph_attend.library_core = lib_core
+        if lib_core:
+            graph_attend.core_args = lambda: dict(q_start=g_start, q_len=g_len, max_q_len=max_nodes * heads, kv=kv_text, kv_split=images_for_use(),
+                                                  kv_start=tok_start, kv_len=g_kv_len, scale=scale)
         for i, layer in enumerate(self.model):
             g = self._folded_rows(layer, g, graph_attend, next_split=i + 1 < len(self.model))
             if use_side and i == min(TEXT_CHAIN_AFTER_LAYER, len(self.model) - 1):

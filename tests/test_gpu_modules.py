@@ -662,3 +662,25 @@ def test_half_precision_text_features_are_read_as_they_stand(dev, D):
     for k in ("shared_text_tokens", "shared_graph_tokens"):
         assert torch.equal(out[k], ref[k]), k
     assert torch.equal(out["shared_graph_embedding"].float(), ref["shared_graph_embedding"])
+
+
+@pytest.mark.parametrize("D,B", [(64, 40), (768, 300), (200, 64)])
+def test_fused_layer_call_equals_the_seven_separate_calls(dev, D, B):
+    """medtok_cross_attention_layer_f32 composes the seven launches of a layer (images, in_proj, per-head fold, attention core, per-head
+    W_v, out_proj, residual + LayerNorm) from the same entry points with the same arguments: pooled() through it must return the bits
+    of the seven separate calls -- native widths, a padded width (200 -> 256), the few-rows and the matrix attention kernels, the
+    fp16-image attention path (B = 300 at D = 768: >= 1024 query rows)."""
+    import medtok_amd.vector_quantization_soft_one_new as M
+    torch.manual_seed(D + B)
+    v = M.VectorQuantizer(3 * 256, D, 0.25, 0.0, True, False, [D, D]).to(dev).eval()
+    text, mask, nodes, batch = (t.to(dev) for t in synth.ragged_batch("fused", B, 30, 10, D, 9))
+    outs = []
+    for fused in (True, False):
+        keep, M.FUSED_LAYER_CALL = M.FUSED_LAYER_CALL, fused
+        try:
+            with torch.no_grad():
+                outs.append(v.cross_attn.pooled(text, mask, nodes, batch))
+        finally:
+            M.FUSED_LAYER_CALL = keep
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
