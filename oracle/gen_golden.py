@@ -398,6 +398,8 @@ def main():
         fixture_kmeans(nq, "f17_kmeans_half", N=2048, D=64, K=48, seed=24, half=True)
         # the reference's own default shape (train_MedTok.py:363-368: e_dim = 64, n_e = 21000, k = 5; regions of 7000 codes)
         fixture_cfg3_slice(sq, "f18_refdefault_slice", N=16384, D=64, n_e=21000, seed=18)
+        # a train step (forward values + the reference's autograd gradients) at four times F4's batch
+        fixture_forward(sq, "f19_forward_b64", B=64, L=20, max_nodes=10, D=128, n_e=768, seed=19)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "--round3-only":        # added in round 3: the rest are unchanged
         fixture_state_dict_keys(sq, "f16_soft_state_dict")
@@ -433,6 +435,7 @@ def main():
     fixture_cfg2_slice(nq, "f15_cfg2_slice", N=16384, D=768, K=8192, seed=15)
     fixture_cfg3_slice(sq, "f14_cfg3_slice", N=16384, D=768, n_e=49152, seed=14)
     fixture_cfg3_slice(sq, "f18_refdefault_slice", N=16384, D=64, n_e=21000, seed=18)
+    fixture_forward(sq, "f19_forward_b64", B=64, L=20, max_nodes=10, D=128, n_e=768, seed=19)
     # BASELINE config 1: 1k codes, 768-d, K=8192 -- inputs regenerated from the seeded recipe
     fixture_forward(sq, "cfg1_inference_1k", B=1000, L=8, max_nodes=6, D=768, n_e=8192, seed=11,
                     train_too=False, store_inputs=False)

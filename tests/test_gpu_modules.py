@@ -76,7 +76,7 @@ def test_specific_embedding_eval_and_train(golden, dev, name):
         assert abs(float(vq_f) - float(g[f"{t}.train.vq"])) <= RTOL * float(g[f"{t}.train.vq"])
 
 
-@pytest.mark.parametrize("name", ["f3_forward_d64", "f4_forward_d128"])
+@pytest.mark.parametrize("name", ["f3_forward_d64", "f4_forward_d128", "f19_forward_b64"])
 def test_full_forward_dict(golden, dev, name):
     g = golden(name)
     v = make_vq(name, g, dev)

@@ -60,7 +60,7 @@ def test_losses_refuse_cpu_tensors_and_oracle_matches_reference_fixture(golden, 
     assert abs(float(oracle.frobenius(m)) - float(g["orth"])) <= 1e-5 * float(g["orth"])
 
 
-@pytest.mark.parametrize("name", ["f3_forward_d64", "f4_forward_d128"])
+@pytest.mark.parametrize("name", ["f3_forward_d64", "f4_forward_d128", "f19_forward_b64"])
 def test_batched_cross_attention_equals_reference_loop(golden, name):
     """CrossAttention.pooled (batched) vs the reference's per-code loop outputs (fixture)."""
     from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
