@@ -51,6 +51,7 @@ extern "C" {
 #define MEDTOK_PLAN_FILTER_XCD(on) (((on) ? 2 : 1) << 16)           /* XCD-aware block order on / off (full 256-CU device only) */
 #define MEDTOK_PLAN_FILTER_TAIL(on) (((on) ? 2 : 1) << 18)          /* tail launch from 256 blocks up / never */
 #define MEDTOK_PLAN_SEARCH_MAX_SPLITS(s) (((s) & 0xFF) << 20)       /* 0 = default */
+#define MEDTOK_PLAN_FILTER_ROWS64(on) (((on) ? 2 : 1) << 28)        /* D <= 64: the 128-byte-row filter kernel on / off (default on) */
 
 /* flags for medtok_soft_assign_f32 */
 #define MEDTOK_ASSIGN_HARD 1        /* NormEMA form: topk == 1, zq = what[idx]        */

@@ -26,9 +26,11 @@ MAX_TOPK = 8
 PATH_AUTO, PATH_F32_MFMA, PATH_F16_FILTER = 0, 1, 2
 
 
-def plan_path(path: int = PATH_AUTO, filter_splits: int = 0, filter_xcd=None, filter_tail=None, search_max_splits: int = 0) -> int:
+def plan_path(path: int = PATH_AUTO, filter_splits: int = 0, filter_xcd=None, filter_tail=None, search_max_splits: int = 0,
+              filter_rows64=None) -> int:
     """Test hook (MEDTOK_PLAN_* in include/medtok_vq.h): a `path` argument that also forces launch-plan branches -- code-range
-    splits, XCD-aware block order on/off, tail launch on/off, the exact kernel's split cap -- for THIS call only (the library
+    splits, XCD-aware block order on/off, tail launch on/off, the exact kernel's split cap, the D <= 64 filter kernel on/off -- for
+    THIS call only (the library
     keeps no plan state).  Results are bit-identical under every plan."""
     p = path & 0xF
     p |= (filter_splits & 0xFF) << 8
@@ -37,6 +39,8 @@ def plan_path(path: int = PATH_AUTO, filter_splits: int = 0, filter_xcd=None, fi
     if filter_tail is not None:
         p |= (2 if filter_tail else 1) << 18
     p |= (search_max_splits & 0xFF) << 20
+    if filter_rows64 is not None:
+        p |= (2 if filter_rows64 else 1) << 28
     return p
 
 _vp, _i64, _int, _sz, _f, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float, C.c_double

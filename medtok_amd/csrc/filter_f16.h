@@ -28,6 +28,7 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef unsigned fu32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int F_BM = 256, F_BN = 256, F_BK = 32;              // codes x rows x k (fp16 elements) per stage
 constexpr int F_THREADS = 512;                                // 8 waves: 2 code-side x 4 row-side, wave tile 128 x 64
@@ -788,6 +789,217 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 #undef F_INIT_GROUP
 #undef F_INIT_LDS
 #undef F_LANE_CB
+}
+
+// ---------------------------------------------------------------- the filter kernel for rows of at most 64 elements
+// The reference's own shape is e_dim = 64 (train_MedTok.py: --embed_dim 64, n_e = 21 000).  There the kernel above spends its time
+// around the matrix work, not in it: a code tile is two 32-deep stages, so the x tile's k blocks are copied again for every code
+// tile although the whole 256 x 64 tile is 32 KB, every stage pays a block-wide barrier, and the scan of a finished tile -- VALU
+// work of about the length of two tiles' MFMAs per wave -- stops all eight waves of the CU's only block at the same time
+// (profiles/r04_kernel_stats_refdefault.csv: 0.155 of the f16 peak).  This form:
+//   * a row is ONE 128-byte line.  The block's x rows live in REGISTERS for its whole life (a wave's 64 rows x 64 k = 8 B
+//     fragments = 32 registers); only code tiles move: 256 codes = 32 KB per tile, LDS-DMA of whole lines (8 rows per
+//     instruction), two ring slots, ONE barrier per code tile (tile t + 1 is copied during tile t's MFMAs and scan);
+//   * blocks of FOUR waves (2 code-side x 2 row-side, tile 256 codes x 128 rows, the same 128 x 64 wave tile and the same
+//     per-lane state as above), 74 KB of LDS: two blocks per CU that drift apart, so that one block's scan (VALU) runs beside
+//     the other's MFMAs on every SIMD -- the overlap the staggered-epilogue experiments above could not get inside one block.
+//     (At D = 768 this block shape lost to the 8-wave one because it moves 1.5 x the L2 -> LDS bytes per flop; with the rows
+//     in registers it moves the same.)
+// Scores, thresholds, candidate lists and their owners (split x 4 + code-side wave x 2 + half-wave) are those of
+// filter_f16_kernel: the re-score kernels do not know which one ran.
+constexpr int R64_BM = 256, R64_BN = 128, R64_THREADS = 256;
+constexpr int R64_ROWB = 128;                                   // bytes of a staged code row: all 64 halves
+constexpr int R64_TILEB = R64_BM * R64_ROWB;                        // 32 KB per code tile
+constexpr size_t R64_RING_BYTES = 2 * (size_t)R64_TILEB;
+constexpr size_t R64_THR_BYTES = R64_BN * 64;                     // per row: the k-lists of the two code-side waves
+constexpr size_t R64_INIT_BYTES = 2 * R64_BM * 4;                 // accumulator start values of two code tiles
+constexpr size_t R64_SMEM_BYTES = R64_RING_BYTES + R64_THR_BYTES + R64_INIT_BYTES;      // 74 KB -> two blocks per CU
+
+template <int TOPK>
+__global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
+    const _Float16 *__restrict__ xh, const _Float16 *__restrict__ wh, const float *__restrict__ xsq,
+    const float *__restrict__ wsqs, const float *__restrict__ en_max_ptr, long n, int k_codes, int d,
+    int codes_per_split, int own_total, uint2 *__restrict__ cand, int *__restrict__ cand_cnt)
+{
+    static_assert(F_MT == 4 && F_NT == 2, "the wave tile is 128 codes x 64 rows");
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave >> 1, wn = wave & 1, wm_s = wave_s >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const long row0 = (long)blockIdx.x * R64_BN;
+    const int split = blockIdx.y;
+    const int code_lo = split * codes_per_split;
+    const int code_hi = min(k_codes, code_lo + codes_per_split);
+    const int nct = (code_hi - code_lo + R64_BM - 1) / R64_BM;
+    (void)wm_s;
+
+    // ---- the wave's x rows as B operands of all four k16 steps (the fp16 image is padded to a multiple of 256 rows)
+    half8 xf[F_NT][4];
+#pragma unroll
+    for (int nn = 0; nn < F_NT; ++nn)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            xf[nn][t] = *reinterpret_cast<const half8 *>(xh + (row0 + wn * 64 + nn * 32 + li) * 64 + 16 * t + 8 * lh);
+
+    // ---- code tiles by LDS-DMA: wave w copies tile rows [64 w, 64 w + 64), 8 rows (of 128 B) per instruction; LDS chunk position
+    // p of row r holds source chunk p ^ (r & 7) (the permutation is on the per-lane source address: the image is lane-linear)
+    const unsigned lane_off = (unsigned)((wave * 64 + (lane >> 3)) * 64 + (((lane & 7) ^ (lane >> 3)) << 3)) * 2u;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)(wh + (long)code_lo * 64), 0, -1, 0x00020000);
+    auto stage = [&](int tile) __attribute__((always_inline)) {
+        char *base = fsm + (tile & 1) * R64_TILEB + wave_s * (64 * R64_ROWB);
+        const int so = __builtin_amdgcn_readfirstlane(min(tile, nct - 1) * R64_TILEB);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(base + q * 8 * R64_ROWB), 16, (int)lane_off,
+                                                     so + q * 8 * R64_ROWB, 0, 0);
+    };
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(wsqs + code_lo), 0, -1, 0x00020000);
+    auto stage_init = [&](int tile) __attribute__((always_inline)) {
+        if (wave_s == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (__attribute__((address_space(3))) void *)(fsm + R64_RING_BYTES + R64_THR_BYTES + (tile & 1) * (R64_BM * 4)),
+                                                     16, lane * 16, __builtin_amdgcn_readfirstlane(min(tile, nct - 1) * (R64_BM * 4)), 0, 0);
+    };
+    const unsigned init_adr = (unsigned)(size_t)(fsm + R64_RING_BYTES + R64_THR_BYTES) + (unsigned)(wm * (32 * F_MT) + 4 * lh) * 4u;
+#define R64_INIT_LDS(M, tile) \
+    do { acc[M][0] = lds_init_issue(init_adr + (unsigned)(((tile) & 1) * (R64_BM * 4) + (M) * 128)); } while (0)
+#define R64_LANE_CB(M, tile) (code_lo + (tile) * R64_BM + wm * (32 * F_MT) + (M) * 32 + 4 * lh)
+
+    // ---- per-lane state (as filter_f16_kernel)
+    float *thr_share = reinterpret_cast<float *>(fsm + R64_RING_BYTES);
+    const float en_max = en_max_ptr[0];
+    const bool sane = en_max <= F_NORM_LIMIT;
+    const int owner = split * F_OWN_PER_SPLIT + wm * 2 + lh;
+    const char *cbase = reinterpret_cast<const char *>(cand + row0 * own_total * F_CAP);
+    FilterRow<TOPK> row[F_NT];
+    unsigned list_start[F_NT];
+#pragma unroll
+    for (int nn = 0; nn < F_NT; ++nn) {
+        const int rl = wn * (32 * F_NT) + nn * 32 + li;
+        const long xr = row0 + rl;
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) row[nn].tv[j] = INFINITY;
+        row[nn].L = INFINITY;
+        row[nn].xn = xsq[min(xr, n - 1)];
+        row[nn].win = xr < n ? 2.0f * filter_eps(row[nn].xn, en_max, d) : -INFINITY;
+        list_start[nn] = (unsigned)((rl * own_total + owner) * F_CAP) * 8u;
+        row[nn].pos = list_start[nn];
+        row[nn].endm8 = list_start[nn] + (F_CAP - 1) * 8u;
+        row[nn].lst = (unsigned)(size_t)(fsm + R64_RING_BYTES) + (unsigned)rl * F_LST_ROWB;
+    }
+    for (int i = tid; i < (int)(R64_THR_BYTES / 4); i += R64_THREADS) thr_share[i] = INFINITY;
+
+    f32x16 acc[F_MT][F_NT];
+    {   // start values of the first code tile by vector loads (nothing is in flight yet)
+#pragma unroll
+        for (int m = 0; m < F_MT; ++m) {
+            float4 e4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e4[g] = ld4(wsqs + R64_LANE_CB(m, 0) + 8 * g);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float4 q4 = e4[r >> 2];
+                acc[m][0][r] = (r & 3) == 0 ? q4.x : (r & 3) == 1 ? q4.y : (r & 3) == 2 ? q4.z : q4.w;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (x fragments, norms and start values in registers before the first DMA)
+    stage_init(1);
+    stage(0);
+
+    // A fragments: row i = wm 128 + m 32 + li of the tile, source chunk 2 t + lh at position (2 t + lh) ^ (i & 7); rows 32 apart
+    // share the swizzle term
+    unsigned a_adr[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        a_adr[t] = (unsigned)(size_t)fsm + (unsigned)((wm * 128 + li) * R64_ROWB + (((2 * t + lh) ^ (li & 7)) << 4));
+
+    // the 32 MFMAs of a code tile; the A operands of k16 step t + 1 are read while step t's MFMAs issue (asm reads with counted
+    // waits: a C++ ds_read would be ordered behind the pending LDS-DMA of the next tile)
+    auto mfma_tile = [&](int tile) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)((tile & 1) * R64_TILEB);
+        fu32x4 fa[2][F_MT];
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\tds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %4 offset:12288"
+                     : "=&v"(fa[0][0]), "=&v"(fa[0][1]), "=&v"(fa[0][2]), "=&v"(fa[0][3]) : "v"(a_adr[0] + so) : "memory");
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            fu32x4 (&cur)[F_MT] = fa[t & 1];
+            if (t + 1 < 4) {
+                fu32x4 (&nxt)[F_MT] = fa[(t + 1) & 1];
+                asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:4096\n\tds_read_b128 %2, %8 offset:8192\n\t"
+                             "ds_read_b128 %3, %8 offset:12288\n\ts_waitcnt lgkmcnt(4)"
+                             : "=&v"(nxt[0]), "=&v"(nxt[1]), "=&v"(nxt[2]), "=&v"(nxt[3]), "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])
+                             : "v"(a_adr[t + 1] + so) : "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : : "memory");
+            }
+#pragma unroll
+            for (int m = 0; m < F_MT; ++m) {
+                const half8 a = __builtin_bit_cast(half8, cur[m]);
+                if (t == 0) {       // only the first row tile's registers hold the start values (D != C for the second)
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[1][0], acc[m][0], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[0][0], acc[m][0], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int nn = 0; nn < F_NT; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[nn][t], acc[m][nn], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    unsigned long multi = 0;
+    auto tile_epilogue = [&](int tile, bool warm) __attribute__((always_inline)) {
+        if (warm) {
+#pragma unroll
+            for (int m = 0; m < F_MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int nn = 0; nn < F_NT; ++nn) {
+                        const float u = acc[m][nn][r] * -0x1p-15f;
+                        thr_insert_med3<TOPK>(row[nn].tv, u == u ? u : INFINITY);
+                    }
+#pragma unroll
+            for (int nn = 0; nn < F_NT; ++nn) row[nn].L = filter_limit(row[nn].tv[TOPK - 1], row[nn].win);
+        }
+#define R64_ONE(M)                                                                                                   \
+        do {                                                                                                       \
+            const int cb_ = R64_LANE_CB(M, tile);                                                                    \
+            _Pragma("unroll") for (int nn = 0; nn < F_NT; ++nn) {                                                  \
+                if (warm) filter_scan_rest<TOPK, false>(row[nn], acc[M][nn], cb_, cbase);                          \
+                else {                                                                                             \
+                    filter_scan<TOPK>(row[nn], acc[M][nn], cb_, cbase, multi);                                     \
+                    if (multi) { filter_scan_rest<TOPK, true>(row[nn], acc[M][nn], cb_, cbase); multi = 0; }       \
+                }                                                                                                  \
+            }                                                                                                      \
+            R64_INIT_LDS(M, tile + 1);                                                                               \
+        } while (0)
+        R64_ONE(0); R64_ONE(1); R64_ONE(2); R64_ONE(3);
+#undef R64_ONE
+        filter_merge_pair<TOPK>(row[0], row[1], wm, lh);
+        lds_init_wait(acc);
+    };
+
+    for (int t = 0; t < nct; ++t) {
+        // this wave's share of tile t (and wave 0's start values of tile t + 1) has landed; then everyone's has, and everyone is
+        // past the MFMAs of tile t - 1 (the other ring slot) and past the start-value reads of tile t (buffer t & 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage_init(t + 2);
+        stage(t + 1);                   // (past the end: the last tile again, into the slot nobody reads any more)
+        mfma_tile(t);
+        tile_epilogue(t, t == 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int nn = 0; nn < F_NT; ++nn) {
+        const long xr = row0 + wn * (32 * F_NT) + nn * 32 + li;
+        const bool ok = sane && row[nn].xn <= F_NORM_LIMIT;
+        if (xr < n) cand_cnt[xr * own_total + owner] = ok ? (int)((row[nn].pos - list_start[nn]) >> 3) : F_CAP + 1;
+    }
+#undef R64_INIT_LDS
+#undef R64_LANE_CB
 }
 
 // ---------------------------------------------------------------- exact re-score

@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict
 // Test hook: plan branches that the default heuristics only take at very large shapes can be forced PER CALL through the upper
 // bits of the `path` argument (MEDTOK_PLAN_* in medtok_vq.h), so small parity tests cover them.  No process state: the
 // workspace query and the launch decode the same argument.  The product path never reads the environment.
-struct PlanOverride { long filter_splits = -1, filter_xcd = -1, filter_tail_min_blocks = -1, search_max_splits = -1; };
+struct PlanOverride { long filter_splits = -1, filter_xcd = -1, filter_tail_min_blocks = -1, search_max_splits = -1, filter_rows64 = -1; };
 static PlanOverride decode_plan(int path)
 {
     PlanOverride o;
@@ -658,6 +658,8 @@ static PlanOverride decode_plan(int path)
     if (xcd) o.filter_xcd = xcd - 1;
     if (tail) o.filter_tail_min_blocks = tail == 1 ? 0 : 256;
     if (ss) o.search_max_splits = ss;
+    const int r64 = (path >> 28) & 3;
+    if (r64) o.filter_rows64 = r64 - 1;
     return o;
 }
 static inline int path_id(int path) { return path & MEDTOK_PATH_MASK; }
@@ -738,6 +740,8 @@ struct FilterPlan {
     long n_pad, k_pad, row_tiles;
     int dp, splits, codes_per_split, own_total, tslots;
     int xcd_rows;      // > 0: XCD-aware block order with this many row tiles per XCD at a time (32 / splits)
+    bool rows64;       // dp == 64: filter_rows64_kernel (row tiles of 128, two 4-wave blocks per CU, no tail launch)
+    int row_bn;        // rows per row tile of the kernel that runs
     // tail launch: the last main_tiles..row_tiles row tiles with more, shorter splits (0 tiles = none)
     long main_tiles;
     int tail_splits, tail_codes_per_split, own_tail;
@@ -753,6 +757,27 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk, const
     f.dp = (d + F_BK - 1) / F_BK * F_BK;
     f.row_tiles = f.n_pad / F_BN;
     const long code_tiles = f.k_pad / F_BM;
+    f.rows64 = f.dp == 64 && ov.filter_rows64 != 0;
+    f.row_bn = f.rows64 ? R64_BN : F_BN;
+    if (f.rows64) {
+        // two blocks per CU, every one walking its whole code range with the x rows in registers: nothing is shared between
+        // blocks but the codebook (K x 128 B, L2-resident), so one split as soon as the chip is full four times over --
+        // every split adds four candidate lists per row and restarts the thresholds
+        f.row_tiles = f.n_pad / R64_BN;
+        const long slots = 2L * di.cus;
+        long want = f.row_tiles >= 4 * slots ? 1 : (4 * slots + f.row_tiles - 1) / f.row_tiles;
+        if (ov.filter_splits > 0) want = ov.filter_splits;
+        if (want > code_tiles) want = code_tiles;
+        if (want > 16) want = 16;
+        if (want < 1) want = 1;
+        const long tiles_per_split = (code_tiles + want - 1) / want;
+        f.codes_per_split = (int)(tiles_per_split * R64_BM);
+        f.splits = (int)((code_tiles + tiles_per_split - 1) / tiles_per_split);
+        f.own_total = f.splits * F_OWN_PER_SPLIT;
+        f.xcd_rows = 0;
+        f.main_tiles = f.row_tiles; f.tail_splits = 0; f.tail_codes_per_split = 0; f.own_tail = 0;
+        return f;
+    }
     // every split adds 4 candidate lists per row, so split only as far as filling the chip needs
     // one 8-wave block per CU: a launch of B equal blocks wastes up to one round of 256
     long want = f.row_tiles >= 4L * di.cus ? 2 : (4L * di.cus + f.row_tiles - 1) / f.row_tiles;
@@ -826,7 +851,7 @@ static FilterWs filter_ws_layout(void *ws, int64_t n, const FilterPlan &f)
     w.fb_rows = (int *)take((size_t)n * 4);
     w.fb_pval = (float *)take((size_t)FB_SPLITS * FB_ROWS * MEDTOK_MAX_TOPK * 4);
     w.fb_pidx = (int *)take((size_t)FB_SPLITS * FB_ROWS * MEDTOK_MAX_TOPK * 4);
-    const size_t n_main = (size_t)lmin(n, f.main_tiles * F_BN), n_tail = (size_t)n - n_main;
+    const size_t n_main = (size_t)lmin(n, f.main_tiles * f.row_bn), n_tail = (size_t)n - n_main;
     w.cand_cnt = (int *)take(n_main * f.own_total * 4);
     w.cand = (uint2 *)take(n_main * f.own_total * F_CAP * 8);
     w.cnt_tail = (int *)take(n_tail * f.own_tail * 4);
@@ -966,14 +991,20 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, w.en_max);
     hipLaunchKernelGGL(pad_wsq_kernel, dim3((unsigned)((f.k_pad + 255) / 256)), dim3(256), 0, s, wsq, (int)k_codes, (int)f.k_pad, w.wsqp);
     if (hipMemsetAsync(w.fb_count, 0, 4, s) != hipSuccess) return fail("search(filter): memset failed");
-    (void)set_lds_once<filter_f16_kernel<T, false>>(F_SMEM_BYTES);
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
-    dim3 fgrid((unsigned)f.main_tiles, (unsigned)f.splits);
-    if (f.xcd_rows) fgrid = dim3((unsigned)(((f.main_tiles + 8 * f.xcd_rows - 1) / (8 * f.xcd_rows)) * 256), 1);
-    hipLaunchKernelGGL((filter_f16_kernel<T, false>), fgrid, dim3(F_THREADS), F_SMEM_BYTES, s,
-                       w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
-                       w.cand, w.cand_cnt, (float *)nullptr, f.xcd_rows, f.splits, 0, (int)f.main_tiles);
-    const long tail_start = f.main_tiles * F_BN;
+    if (f.rows64) {
+        (void)set_lds_once<filter_rows64_kernel<T>>(R64_SMEM_BYTES);
+        hipLaunchKernelGGL((filter_rows64_kernel<T>), dim3((unsigned)f.row_tiles, (unsigned)f.splits), dim3(R64_THREADS), R64_SMEM_BYTES, s,
+                           w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, d, f.codes_per_split, f.own_total, w.cand, w.cand_cnt);
+    } else {
+        (void)set_lds_once<filter_f16_kernel<T, false>>(F_SMEM_BYTES);
+        dim3 fgrid((unsigned)f.main_tiles, (unsigned)f.splits);
+        if (f.xcd_rows) fgrid = dim3((unsigned)(((f.main_tiles + 8 * f.xcd_rows - 1) / (8 * f.xcd_rows)) * 256), 1);
+        hipLaunchKernelGGL((filter_f16_kernel<T, false>), fgrid, dim3(F_THREADS), F_SMEM_BYTES, s,
+                           w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
+                           w.cand, w.cand_cnt, (float *)nullptr, f.xcd_rows, f.splits, 0, (int)f.main_tiles);
+    }
+    const long tail_start = f.main_tiles * f.row_bn;
     if (f.main_tiles < f.row_tiles) {
         // the kernel indexes its lists by absolute row: bias the tail region's base pointers accordingly
         hipLaunchKernelGGL((filter_f16_kernel<T, false>), dim3((unsigned)(f.row_tiles - f.main_tiles), (unsigned)f.tail_splits), dim3(F_THREADS),
@@ -1069,7 +1100,8 @@ extern "C" int medtok_debug_filter_probe(const float *xhat, const float *xsq, in
                                          int topk, void *ws, size_t ws_bytes, void *probe, size_t probe_bytes, int64_t *n_blocks, void *stream)
 {
     if (topk < 2 || topk > 5) return fail("filter_probe: topk 2..5");
-    const PlanOverride ov = decode_plan(MEDTOK_PATH_F16_FILTER);
+    PlanOverride ov = decode_plan(MEDTOK_PATH_F16_FILTER);
+    ov.filter_rows64 = 0;               // (the probe is an instantiation of the general kernel)
     const FilterPlan f = plan_filter(n, k_codes, d, topk, ov);
     const FilterWs w = filter_ws_layout(ws, n, f);
     if (!ws || ws_bytes < w.total) return fail("filter_probe: workspace too small (%zu < %zu)", ws_bytes, w.total);
@@ -1106,7 +1138,8 @@ extern "C" size_t medtok_debug_filter_fallback_count_offset(int64_t n, int64_t k
 extern "C" size_t medtok_debug_filter_scores_workspace_bytes(int64_t n, int64_t k_codes, int d)
 {
     if (n <= 0 || k_codes <= 0 || d <= 0) return 0;
-    FilterPlan f = plan_filter(n, k_codes, d, 5, PlanOverride());
+    PlanOverride gen; gen.filter_rows64 = 0;     // (the score dump is an instantiation of the general kernel: same MFMA order at any D)
+    FilterPlan f = plan_filter(n, k_codes, d, 5, gen);
     return align_up((size_t)f.n_pad * f.dp * 2, 256) + align_up((size_t)f.k_pad * f.dp * 2, 256) + 512 + align_up((size_t)f.k_pad * 4, 256);
 }
 
@@ -1114,7 +1147,8 @@ extern "C" int medtok_debug_filter_scores_f32(const float *xhat, const float *xs
                                               int64_t k_codes, int d, float *scores, void *ws, size_t ws_bytes, void *stream)
 {
     if (n <= 0 || k_codes <= 0 || d <= 0 || (d & 3)) return fail("debug_filter_scores: bad shape");
-    FilterPlan f = plan_filter(n, k_codes, d, 5, PlanOverride());
+    PlanOverride gen; gen.filter_rows64 = 0;
+    FilterPlan f = plan_filter(n, k_codes, d, 5, gen);
     const size_t xb = align_up((size_t)f.n_pad * f.dp * 2, 256), wb = align_up((size_t)f.k_pad * f.dp * 2, 256);
     if (!ws || ws_bytes < xb + wb + 512 + (size_t)f.k_pad * 4) return fail("debug_filter_scores: workspace too small");
     hipStream_t s = (hipStream_t)stream;
