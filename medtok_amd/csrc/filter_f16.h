@@ -230,7 +230,9 @@ __device__ __forceinline__ void filter_append(unsigned &pos, unsigned endm8, con
 // (t_j' = med3(t_{j-1}, t_j, u): no dependent chain), and note in `multi` whether the quad's SECOND largest value passes as well
 // (p ~ 4e-5 per lane and quad on random data): the tile is then revisited by filter_scan_rest.  L is not moved here: the
 // merge at the end of the code tile recomputes it from the lists.
-#define F_HIT_HEAD                                                                       \
+// (UCALC: how u = -2^-15 acc is formed -- a multiply, or, for filter_rows64_kernel, an fma with a wave-uniform bias that is 0 or
+// +inf: with +inf the med3 chain leaves the list as it is, i.e. the same instructions append without inserting.)
+#define F_HIT_HEAD(UCALC)                                                                \
     "v_cmp_ge_f32 vcc, %[mx], %[L]\n\t"                                                  \
     "s_and_saveexec_b64 %[sv], vcc\n\t"                                                  \
     "v_cmp_eq_f32 vcc, %[a2], %[mx]\n\t"                                                 \
@@ -247,7 +249,7 @@ __device__ __forceinline__ void filter_append(unsigned &pos, unsigned endm8, con
     "v_max3_f32 %[p], %[p], %[q], %[u]\n\t"                                              \
     "v_cmp_ge_f32 vcc, %[p], %[L]\n\t"                                                   \
     "s_or_b64 %[multi], %[multi], vcc\n\t"                                               \
-    "v_mul_f32 %[u], 0xb8000000, %[mx]\n\t"                                              \
+    UCALC                                                                                \
     "v_add_u32 %[j], %[j], %[cbg]\n\t"                                                   \
     "v_min_u32 %[q], %[pos], %[endm8]\n\t"                                               \
     "global_store_dword %[q], %[mx], %[base]\n\t"                                        \
@@ -256,41 +258,48 @@ __device__ __forceinline__ void filter_append(unsigned &pos, unsigned endm8, con
 #define F_HIT_TAIL "s_mov_b64 exec, %[sv]"
 #define F_HIT_OUT(r) [pos] "+v"(r.pos), [multi] "+s"(multi), [sv] "=&s"(sv), [j] "=&v"(j), [p] "=&v"(p), [q] "=&v"(q), [u] "=&v"(u)
 #define F_HIT_IN(r) [mx] "v"(mx), [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [L] "v"(r.L), [cbg] "v"(cbg), [endm8] "v"(r.endm8), [base] "s"(cbase)
-template <int TOPK>
+#define F_HIT_ASM(UCALC, ...)                                                                                                                   \
+    if constexpr (TOPK == 1) {                                                                                                                  \
+        asm volatile(F_HIT_HEAD(UCALC) "v_min_f32 %[t0], %[t0], %[u]\n\t" F_HIT_TAIL                                                            \
+                     : F_HIT_OUT(r), [t0] "+v"(r.tv[0]) : F_HIT_IN(r) __VA_ARGS__ : "vcc");                                                     \
+    } else if constexpr (TOPK == 5) {                                                                                                           \
+        asm volatile(F_HIT_HEAD(UCALC)                                                                                                          \
+                     "v_med3_f32 %[t4], %[t3], %[t4], %[u]\n\t"                                                                                 \
+                     "v_med3_f32 %[t3], %[t2], %[t3], %[u]\n\t"                                                                                 \
+                     "v_med3_f32 %[t2], %[t1], %[t2], %[u]\n\t"                                                                                 \
+                     "v_med3_f32 %[t1], %[t0], %[t1], %[u]\n\t"                                                                                 \
+                     "v_min_f32 %[t0], %[t0], %[u]\n\t" F_HIT_TAIL                                                                              \
+                     : F_HIT_OUT(r), [t0] "+v"(r.tv[0]), [t1] "+v"(r.tv[1]), [t2] "+v"(r.tv[2]), [t3] "+v"(r.tv[3]), [t4] "+v"(r.tv[4])         \
+                     : F_HIT_IN(r) __VA_ARGS__ : "vcc");                                                                                        \
+    } else {                                                                                                                                    \
+        static_assert(TOPK == 8, "k-lists of 1, 5 or 8");                                                                                       \
+        asm volatile(F_HIT_HEAD(UCALC)                                                                                                          \
+                     "v_med3_f32 %[t7], %[t6], %[t7], %[u]\n\t"                                                                                 \
+                     "v_med3_f32 %[t6], %[t5], %[t6], %[u]\n\t"                                                                                 \
+                     "v_med3_f32 %[t5], %[t4], %[t5], %[u]\n\t"                                                                                 \
+                     "v_med3_f32 %[t4], %[t3], %[t4], %[u]\n\t"                                                                                 \
+                     "v_med3_f32 %[t3], %[t2], %[t3], %[u]\n\t"                                                                                 \
+                     "v_med3_f32 %[t2], %[t1], %[t2], %[u]\n\t"                                                                                 \
+                     "v_med3_f32 %[t1], %[t0], %[t1], %[u]\n\t"                                                                                 \
+                     "v_min_f32 %[t0], %[t0], %[u]\n\t" F_HIT_TAIL                                                                              \
+                     : F_HIT_OUT(r), [t0] "+v"(r.tv[0]), [t1] "+v"(r.tv[1]), [t2] "+v"(r.tv[2]), [t3] "+v"(r.tv[3]), [t4] "+v"(r.tv[4]),        \
+                       [t5] "+v"(r.tv[5]), [t6] "+v"(r.tv[6]), [t7] "+v"(r.tv[7])                                                               \
+                     : F_HIT_IN(r) __VA_ARGS__ : "vcc");                                                                                        \
+    }
+template <int TOPK, bool BIASED = false>
 __device__ __forceinline__ void filter_hit(FilterRow<TOPK> &r, float a0, float a1, float a2, float a3, float mx, int cbg, const char *cbase,
-                                           unsigned long &multi)
+                                           unsigned long &multi, float cc = 0.f, float bias = 0.f)
 {
     unsigned long sv;
     unsigned j;
     float p, q, u;
-    if constexpr (TOPK == 1) {
-        asm volatile(F_HIT_HEAD "v_min_f32 %[t0], %[t0], %[u]\n\t" F_HIT_TAIL
-                     : F_HIT_OUT(r), [t0] "+v"(r.tv[0]) : F_HIT_IN(r) : "vcc");
-    } else if constexpr (TOPK == 5) {
-        asm volatile(F_HIT_HEAD
-                     "v_med3_f32 %[t4], %[t3], %[t4], %[u]\n\t"
-                     "v_med3_f32 %[t3], %[t2], %[t3], %[u]\n\t"
-                     "v_med3_f32 %[t2], %[t1], %[t2], %[u]\n\t"
-                     "v_med3_f32 %[t1], %[t0], %[t1], %[u]\n\t"
-                     "v_min_f32 %[t0], %[t0], %[u]\n\t" F_HIT_TAIL
-                     : F_HIT_OUT(r), [t0] "+v"(r.tv[0]), [t1] "+v"(r.tv[1]), [t2] "+v"(r.tv[2]), [t3] "+v"(r.tv[3]), [t4] "+v"(r.tv[4])
-                     : F_HIT_IN(r) : "vcc");
+    if constexpr (BIASED) {
+        F_HIT_ASM("v_fma_f32 %[u], %[mx], %[cc], %[bias]\n\t", , [cc] "v"(cc), [bias] "s"(bias))
     } else {
-        static_assert(TOPK == 8, "k-lists of 1, 5 or 8");
-        asm volatile(F_HIT_HEAD
-                     "v_med3_f32 %[t7], %[t6], %[t7], %[u]\n\t"
-                     "v_med3_f32 %[t6], %[t5], %[t6], %[u]\n\t"
-                     "v_med3_f32 %[t5], %[t4], %[t5], %[u]\n\t"
-                     "v_med3_f32 %[t4], %[t3], %[t4], %[u]\n\t"
-                     "v_med3_f32 %[t3], %[t2], %[t3], %[u]\n\t"
-                     "v_med3_f32 %[t2], %[t1], %[t2], %[u]\n\t"
-                     "v_med3_f32 %[t1], %[t0], %[t1], %[u]\n\t"
-                     "v_min_f32 %[t0], %[t0], %[u]\n\t" F_HIT_TAIL
-                     : F_HIT_OUT(r), [t0] "+v"(r.tv[0]), [t1] "+v"(r.tv[1]), [t2] "+v"(r.tv[2]), [t3] "+v"(r.tv[3]), [t4] "+v"(r.tv[4]),
-                       [t5] "+v"(r.tv[5]), [t6] "+v"(r.tv[6]), [t7] "+v"(r.tv[7])
-                     : F_HIT_IN(r) : "vcc");
+        F_HIT_ASM("v_mul_f32 %[u], 0xb8000000, %[mx]\n\t")
     }
 }
+#undef F_HIT_ASM
 #undef F_HIT_HEAD
 #undef F_HIT_TAIL
 #undef F_HIT_OUT
@@ -301,22 +310,34 @@ __device__ __forceinline__ void filter_hit(FilterRow<TOPK> &r, float a0, float a
 // runs the hit sequence above.  cb = the lane's first code of this 32-code group.
 // (Round 1 parked hits in LDS and flushed them once per 128 values; with 16 values per scan and row the parking only added
 // LDS round trips -- each behind a drain of the DMA ring, see above.)
-template <int TOPK>
-__device__ __forceinline__ void filter_scan(FilterRow<TOPK> &r, const f32x16 &a, int cb, const char *cbase, unsigned long &multi)
+template <int TOPK, bool COUNT = false, bool BIASED = false>
+__device__ __forceinline__ void filter_scan(FilterRow<TOPK> &r, const f32x16 &a, int cb, const char *cbase, unsigned long &multi, unsigned *n_hit = nullptr,
+                                            float cc = 0.f, float bias = 0.f)
 {
+    // all four quad maxima and their tests first (the limit does not move inside a tile: filter_hit leaves L alone), then scalar
+    // branches on masks that are long since in SGPRs: a compare followed at once by the branch on it costs the VALU's latency and,
+    // with the common no-hit case as the taken branch, a refetch per quad
+    float mx[4];
+    unsigned long h[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float a0 = a[4 * g], a1 = a[4 * g + 1], a2 = a[4 * g + 2], a3 = a[4 * g + 3];
-        const float mx = v_max(v_max3(a0, a1, a2), a3);
-        if (__builtin_amdgcn_ballot_w64(mx >= r.L)) filter_hit<TOPK>(r, a0, a1, a2, a3, mx, cb + 8 * g, cbase, multi);
+    for (int g = 0; g < 4; ++g) mx[g] = v_max(v_max3(a[4 * g], a[4 * g + 1], a[4 * g + 2]), a[4 * g + 3]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) h[g] = __builtin_amdgcn_ballot_w64(mx[g] >= r.L);
+    if (__builtin_expect((h[0] | h[1] | h[2] | h[3]) != 0, 0)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (h[g]) {
+                filter_hit<TOPK, BIASED>(r, a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], mx[g], cb + 8 * g, cbase, multi, cc, bias);
+                if (COUNT) ++*n_hit;      // (dev probe: how many of the wave's quad tests run the hit sequence)
+            }
     }
 }
 
 // Everything of a tile that passes and is NOT its quad's maximum (first position holding it) -- the revisit after `multi`.
 // With INSERT = false: ALL passing values, appended but not folded into the k-list -- the warm-up tile, whose values the
 // lists have seen already.  Plain divergent code: rare (multi) or once per block (warm-up).
-template <int TOPK, bool INSERT>
-__device__ __forceinline__ void filter_scan_rest(FilterRow<TOPK> &r, const f32x16 &a, int cb, const char *cbase)
+template <int TOPK, bool INSERT, bool BIASED = false>
+__device__ __forceinline__ void filter_scan_rest(FilterRow<TOPK> &r, const f32x16 &a, int cb, const char *cbase, float cc = 0.f, float bias = 0.f)
 {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -329,7 +350,7 @@ __device__ __forceinline__ void filter_scan_rest(FilterRow<TOPK> &r, const f32x1
                 const float v = j == 0 ? a0 : j == 1 ? a1 : j == 2 ? a2 : a3;
                 if (j != jm && v >= r.L) {
                     filter_append(r.pos, r.endm8, cbase, v, (unsigned)(cb + j + 8 * g));
-                    if (INSERT) thr_insert_bf<TOPK>(r.tv, v * -0x1p-15f);
+                    if (INSERT) thr_insert_bf<TOPK>(r.tv, BIASED ? fmaf(v, cc, bias) : v * -0x1p-15f);
                 }
             }
         }
@@ -392,6 +413,42 @@ __device__ __forceinline__ void filter_merge_pair(FilterRow<TOPK> &r0, FilterRow
     }
     r0.L = filter_limit(t0, r0.win);
     r1.L = filter_limit(t1, r1.win);
+}
+
+// The same for ONE row (filter_rows64_kernel merges its two rows one after the other: half the temporaries live at a time, in a
+// kernel that has no register to spare), on single-instruction min / max: the lists never hold NaN (the learning pass maps it to
+// +inf), so the canonicalising v_max that fminf / fmaxf put in front of every operand is not needed.
+template <int TOPK>
+__device__ __forceinline__ void filter_merge_one(FilterRow<TOPK> &r, unsigned lst, int wm, int lh)
+{
+    constexpr int TL = TOPK < 5 ? TOPK : 5;
+    float t;
+    if (TOPK <= 5) {
+        f32x4 oq;
+        float oe;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %2 offset:16" : "=&v"(oq), "=&v"(oe) : "v"(lst + (unsigned)((wm ^ 1) * 32)) : "memory");
+        float c[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) c[i] = INFINITY;
+#pragma unroll
+        for (int i = 0; i < TL; ++i) c[i] = v_min(r.tv[i], other_half(r.tv[TL - 1 - i], lh));
+#pragma unroll
+        for (int pass = 0; pass < TL; ++pass)              // odd-even transposition: ascending
+#pragma unroll
+            for (int i = pass & 1; i + 1 < TL; i += 2) {
+                const float lo = v_min(c[i], c[i + 1]), hi = v_max(c[i], c[i + 1]);
+                c[i] = lo; c[i + 1] = hi;
+            }
+        if (lh == 0) lds_store_list(lst + (unsigned)(wm * 32), c);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(oq), "+v"(oe)::"memory");
+        const float o[5] = {oq[0], oq[1], oq[2], oq[3], oe};
+        t = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < TL; ++i) t = v_max(t, v_min(c[i], o[TL - 1 - i]));
+    } else {
+        t = v_min(r.tv[TOPK - 1], other_half(r.tv[TOPK - 1], lh));
+    }
+    r.L = filter_limit(t, r.win);
 }
 
 // accumulator start values of one 32-code group: -2^15 |e|^2 of this lane's 16 codes, both row tiles.  sp is wave-uniform ->
@@ -633,6 +690,11 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
     // The scan of a finished code tile: all four groups of the wave.
     unsigned long multi = 0;             // wave-uniform: some lane had a second passing value in one quad (filter_hit)
     auto tile_epilogue = [&](int tile, bool warm) __attribute__((always_inline)) {
+        // (the scan reads the accumulators with inline-asm v_max3, which hipcc's hazard recognizer does not protect: the 18 wait
+        // states a 16-pass XDL result needs before a VALU read are held here, once per code tile, by a statement that owns all
+        // eight tiles -- see filter_rows64_kernel, where a reordered asm consumer did read half-finished sums)
+        asm volatile("s_nop 15\n\ts_nop 1"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
         if (DUMP) {
 #pragma unroll
             for (int m = 0; m < F_MT; ++m)
@@ -805,6 +867,15 @@ __global__ __launch_bounds__(F_THREADS, 2) void filter_f16_kernel(
 //     the other's MFMAs on every SIMD -- the overlap the staggered-epilogue experiments above could not get inside one block.
 //     (At D = 768 this block shape lost to the 8-wave one because it moves 1.5 x the L2 -> LDS bytes per flop; with the rows
 //     in registers it moves the same.)
+//   * the scan is what this kernel does most of the time (a tile's 32 MFMAs are ~850 cycles, its scan several thousand: every
+//     instruction of a wave, scalar ones and no-ops included, takes a 4-cycle issue slot), and the first tiles are the dear ones:
+//     with limits learnt from 256 codes, tile t still has ~160 / t lanes per wave passing, each one a 30-instruction hit
+//     sequence.  So the block LEARNS first: for its first R64_LEARN tiles it only keeps, per lane and 16-code accumulator tile,
+//     the best score (8 x v_max3) and folds that into the lane's k-list -- the k smallest of those per-tile bests are scores
+//     of k DIFFERENT codes, so their largest is a valid limit, and it is within one rank of the k-th best of all 2048 codes seen
+//     -- appends nothing, and comes back to those tiles at the END (32 MFMAs each, again) to collect their candidates with the
+//     final limits, appending without inserting (the lists have seen these codes: a second insertion of the same code would
+//     make the k-th entry smaller than the k-th best).  Tiles in between: the scan of filter_f16_kernel.
 // Scores, thresholds, candidate lists and their owners (split x 4 + code-side wave x 2 + half-wave) are those of
 // filter_f16_kernel: the re-score kernels do not know which one ran.
 constexpr int R64_BM = 256, R64_BN = 128, R64_THREADS = 256;
@@ -814,12 +885,15 @@ constexpr size_t R64_RING_BYTES = 2 * (size_t)R64_TILEB;
 constexpr size_t R64_THR_BYTES = R64_BN * 64;                     // per row: the k-lists of the two code-side waves
 constexpr size_t R64_INIT_BYTES = 2 * R64_BM * 4;                 // accumulator start values of two code tiles
 constexpr size_t R64_SMEM_BYTES = R64_RING_BYTES + R64_THR_BYTES + R64_INIT_BYTES;      // 74 KB -> two blocks per CU
+constexpr int R64_LEARN = 8;                                  // code tiles a block only learns its limits from (and revisits last)
 
-template <int TOPK>
+// TIMED (dev probe, tools/r04/filter_probe.py): per-wave s_memtime sums of the loop's segments and the number of hit sequences run,
+// written to `probe` (uint64 [blocks][4 waves][8]).
+template <int TOPK, bool TIMED = false>
 __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
     const _Float16 *__restrict__ xh, const _Float16 *__restrict__ wh, const float *__restrict__ xsq,
     const float *__restrict__ wsqs, const float *__restrict__ en_max_ptr, long n, int k_codes, int d,
-    int codes_per_split, int own_total, uint2 *__restrict__ cand, int *__restrict__ cand_cnt)
+    int codes_per_split, int own_total, uint2 *__restrict__ cand, int *__restrict__ cand_cnt, unsigned long long *__restrict__ probe = nullptr)
 {
     static_assert(F_MT == 4 && F_NT == 2, "the wave tile is 128 codes x 64 rows");
     extern __shared__ __attribute__((aligned(16))) char fsm[];
@@ -846,23 +920,30 @@ __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
     // p of row r holds source chunk p ^ (r & 7) (the permutation is on the per-lane source address: the image is lane-linear)
     const unsigned lane_off = (unsigned)((wave * 64 + (lane >> 3)) * 64 + (((lane & 7) ^ (lane >> 3)) << 3)) * 2u;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)(wh + (long)code_lo * 64), 0, -1, 0x00020000);
-    auto stage = [&](int tile) __attribute__((always_inline)) {
-        char *base = fsm + (tile & 1) * R64_TILEB + wave_s * (64 * R64_ROWB);
-        const int so = __builtin_amdgcn_readfirstlane(min(tile, nct - 1) * R64_TILEB);
+    // step s of the block works on code tile tile_of(s): the learning tiles 0 .. W-1, the rest, tiles 0 .. W-1 again
+    const int W = min(R64_LEARN, nct), nsteps = nct + W;
+    auto tile_of = [&](int st) __attribute__((always_inline)) -> int {
+        st = min(st, nsteps - 1);
+        return __builtin_amdgcn_readfirstlane(st < nct ? st : st - nct);
+    };
+    auto stage = [&](int st) __attribute__((always_inline)) {
+        char *base = fsm + (st & 1) * R64_TILEB + wave_s * (64 * R64_ROWB);
+        const int so = tile_of(st) * R64_TILEB;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(base + q * 8 * R64_ROWB), 16, (int)lane_off,
                                                      so + q * 8 * R64_ROWB, 0, 0);
     };
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(wsqs + code_lo), 0, -1, 0x00020000);
-    auto stage_init = [&](int tile) __attribute__((always_inline)) {
+    auto stage_init = [&](int st) __attribute__((always_inline)) {
+        const int so = tile_of(st) * (R64_BM * 4);      // (a local: hipcc's host pass rejects the lambda call inside the builtin's argument list)
         if (wave_s == 0)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (__attribute__((address_space(3))) void *)(fsm + R64_RING_BYTES + R64_THR_BYTES + (tile & 1) * (R64_BM * 4)),
-                                                     16, lane * 16, __builtin_amdgcn_readfirstlane(min(tile, nct - 1) * (R64_BM * 4)), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (__attribute__((address_space(3))) void *)(fsm + R64_RING_BYTES + R64_THR_BYTES + (st & 1) * (R64_BM * 4)),
+                                                     16, lane * 16, so, 0, 0);
     };
     const unsigned init_adr = (unsigned)(size_t)(fsm + R64_RING_BYTES + R64_THR_BYTES) + (unsigned)(wm * (32 * F_MT) + 4 * lh) * 4u;
-#define R64_INIT_LDS(M, tile) \
-    do { acc[M][0] = lds_init_issue(init_adr + (unsigned)(((tile) & 1) * (R64_BM * 4) + (M) * 128)); } while (0)
+#define R64_INIT_LDS(M, st) \
+    do { acc[M][0] = lds_init_issue(init_adr + (unsigned)(((st) & 1) * (R64_BM * 4) + (M) * 128)); } while (0)
 #define R64_LANE_CB(M, tile) (code_lo + (tile) * R64_BM + wm * (32 * F_MT) + (M) * 32 + 4 * lh)
 
     // ---- per-lane state (as filter_f16_kernel)
@@ -872,7 +953,7 @@ __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
     const int owner = split * F_OWN_PER_SPLIT + wm * 2 + lh;
     const char *cbase = reinterpret_cast<const char *>(cand + row0 * own_total * F_CAP);
     FilterRow<TOPK> row[F_NT];
-    unsigned list_start[F_NT];
+    const unsigned lst0 = (unsigned)(size_t)(fsm + R64_RING_BYTES) + (unsigned)(wn * (32 * F_NT) + li) * F_LST_ROWB;     // (the second row's: + 32 rows)
 #pragma unroll
     for (int nn = 0; nn < F_NT; ++nn) {
         const int rl = wn * (32 * F_NT) + nn * 32 + li;
@@ -880,12 +961,12 @@ __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) row[nn].tv[j] = INFINITY;
         row[nn].L = INFINITY;
-        row[nn].xn = xsq[min(xr, n - 1)];
-        row[nn].win = xr < n ? 2.0f * filter_eps(row[nn].xn, en_max, d) : -INFINITY;
-        list_start[nn] = (unsigned)((rl * own_total + owner) * F_CAP) * 8u;
-        row[nn].pos = list_start[nn];
-        row[nn].endm8 = list_start[nn] + (F_CAP - 1) * 8u;
-        row[nn].lst = (unsigned)(size_t)(fsm + R64_RING_BYTES) + (unsigned)rl * F_LST_ROWB;
+        // (per-lane values that are only needed once more -- the row's norm, the start of its list -- are formed again at the end)
+        row[nn].xn = 0.f;
+        row[nn].win = xr < n ? 2.0f * filter_eps(xsq[min(xr, n - 1)], en_max, d) : -INFINITY;
+        row[nn].pos = (unsigned)((rl * own_total + owner) * F_CAP) * 8u;
+        row[nn].endm8 = row[nn].pos + (F_CAP - 1) * 8u;
+        row[nn].lst = 0;
     }
     for (int i = tid; i < (int)(R64_THR_BYTES / 4); i += R64_THREADS) thr_share[i] = INFINITY;
 
@@ -914,89 +995,146 @@ __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
     for (int t = 0; t < 4; ++t)
         a_adr[t] = (unsigned)(size_t)fsm + (unsigned)((wm * 128 + li) * R64_ROWB + (((2 * t + lh) ^ (li & 7)) << 4));
 
-    // the 32 MFMAs of a code tile; the A operands of k16 step t + 1 are read while step t's MFMAs issue (asm reads with counted
-    // waits: a C++ ds_read would be ordered behind the pending LDS-DMA of the next tile)
-    auto mfma_tile = [&](int tile) __attribute__((always_inline)) {
-        const unsigned so = (unsigned)((tile & 1) * R64_TILEB);
-        fu32x4 fa[2][F_MT];
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\tds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %4 offset:12288"
-                     : "=&v"(fa[0][0]), "=&v"(fa[0][1]), "=&v"(fa[0][2]), "=&v"(fa[0][3]) : "v"(a_adr[0] + so) : "memory");
+    // the 32 MFMAs of a code tile: 16 (k16 step, code group) pairs; the A operand of pair i + 2 is read while pair i's two MFMAs
+    // issue -- three rotating 4-register fragments, not two sets of four: the registers are what this kernel is short of (asm reads
+    // with counted waits: LDS reads return in order, and a C++ ds_read would be ordered behind the pending LDS-DMA of the next tile)
+    auto mfma_tile = [&](int st) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)((st & 1) * R64_TILEB);
+        unsigned adr[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            fu32x4 (&cur)[F_MT] = fa[t & 1];
-            if (t + 1 < 4) {
-                fu32x4 (&nxt)[F_MT] = fa[(t + 1) & 1];
-                asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:4096\n\tds_read_b128 %2, %8 offset:8192\n\t"
-                             "ds_read_b128 %3, %8 offset:12288\n\ts_waitcnt lgkmcnt(4)"
-                             : "=&v"(nxt[0]), "=&v"(nxt[1]), "=&v"(nxt[2]), "=&v"(nxt[3]), "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])
-                             : "v"(a_adr[t + 1] + so) : "memory");
+        for (int t = 0; t < 4; ++t) adr[t] = a_adr[t] + so;
+        fu32x4 fa[3];
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096" : "=&v"(fa[0]), "=&v"(fa[1]) : "v"(adr[0]) : "memory");
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = i >> 2, m = i & 3;
+            fu32x4 &cur = fa[i % 3];
+            if (i + 2 < 16) {
+                fu32x4 &nxt = fa[(i + 2) % 3];
+                const int t2 = (i + 2) >> 2, m2 = (i + 2) & 3;
+                asm volatile("ds_read_b128 %0, %2 offset:%3\n\ts_waitcnt lgkmcnt(2)" : "=&v"(nxt), "+v"(cur) : "v"(adr[t2]), "i"(m2 * 4096) : "memory");
+            } else if (i + 1 < 16) {
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cur) : : "memory");
             } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur) : : "memory");
             }
+            const half8 av = __builtin_bit_cast(half8, cur);
+            if (t == 0) {       // only the first row tile's registers hold the start values (D != C for the second)
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, xf[1][0], acc[m][0], 0, 0, 0);
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, xf[0][0], acc[m][0], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int m = 0; m < F_MT; ++m) {
-                const half8 a = __builtin_bit_cast(half8, cur[m]);
-                if (t == 0) {       // only the first row tile's registers hold the start values (D != C for the second)
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[1][0], acc[m][0], 0, 0, 0);
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[0][0], acc[m][0], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int nn = 0; nn < F_NT; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, xf[nn][t], acc[m][nn], 0, 0, 0);
-                }
+                for (int nn = 0; nn < F_NT; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, xf[nn][t], acc[m][nn], 0, 0, 0);
             }
         }
     };
 
     unsigned long multi = 0;
-    auto tile_epilogue = [&](int tile, bool warm) __attribute__((always_inline)) {
-        if (warm) {
+    unsigned n_hit = 0;
+    float cc = -0x1p-15f;                   // (in a VGPR: the hit sequence's fma takes its one scalar operand for the bias)
+    asm volatile("" : "+v"(cc));
+    // learning step: the best of each accumulator tile into the lane's list; no appends.  The limits are set by the merges of
+    // the last two learning steps (the second one sees the other code-side wave's list of the first).
+    auto learn_epilogue = [&](int st) __attribute__((always_inline)) {
 #pragma unroll
-            for (int m = 0; m < F_MT; ++m)
+        for (int m = 0; m < F_MT; ++m) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
+            for (int nn = 0; nn < F_NT; ++nn) {
+                const f32x16 &a = acc[m][nn];
+                float mx = v_max3(a[0], a[1], a[2]);
 #pragma unroll
-                    for (int nn = 0; nn < F_NT; ++nn) {
-                        const float u = acc[m][nn][r] * -0x1p-15f;
-                        thr_insert_med3<TOPK>(row[nn].tv, u == u ? u : INFINITY);
-                    }
-#pragma unroll
-            for (int nn = 0; nn < F_NT; ++nn) row[nn].L = filter_limit(row[nn].tv[TOPK - 1], row[nn].win);
+                for (int r = 3; r + 1 < 16; r += 2) mx = v_max3(mx, a[r], a[r + 1]);
+                mx = v_max(mx, a[15]);
+                const float u = mx * -0x1p-15f;
+                thr_insert_med3<TOPK>(row[nn].tv, u == u ? u : INFINITY);
+            }
+            R64_INIT_LDS(m, st + 1);
         }
-#define R64_ONE(M)                                                                                                   \
-        do {                                                                                                       \
-            const int cb_ = R64_LANE_CB(M, tile);                                                                    \
-            _Pragma("unroll") for (int nn = 0; nn < F_NT; ++nn) {                                                  \
-                if (warm) filter_scan_rest<TOPK, false>(row[nn], acc[M][nn], cb_, cbase);                          \
-                else {                                                                                             \
-                    filter_scan<TOPK>(row[nn], acc[M][nn], cb_, cbase, multi);                                     \
-                    if (multi) { filter_scan_rest<TOPK, true>(row[nn], acc[M][nn], cb_, cbase); multi = 0; }       \
-                }                                                                                                  \
-            }                                                                                                      \
-            R64_INIT_LDS(M, tile + 1);                                                                               \
+        if (st + 2 >= W) {
+            filter_merge_one<TOPK>(row[0], lst0, wm, lh);
+            filter_merge_one<TOPK>(row[1], lst0 + 32 * F_LST_ROWB, wm, lh);
+        }
+        lds_init_wait(acc);
+    };
+    // scanning step: bias = 0 -> append and insert (tiles W .. nct-1); bias = +inf -> append only (the learning tiles, revisited)
+    auto scan_epilogue = [&](int st, float bias) __attribute__((always_inline)) {
+        const int tile = tile_of(st);
+#define R64_ONE(M)                                                                                                           \
+        do {                                                                                                                 \
+            const int cb_ = R64_LANE_CB(M, tile);                                                                            \
+            _Pragma("unroll") for (int nn = 0; nn < F_NT; ++nn) {                                                            \
+                filter_scan<TOPK, TIMED, true>(row[nn], acc[M][nn], cb_, cbase, multi, &n_hit, cc, bias);                    \
+                if (multi) { filter_scan_rest<TOPK, true, true>(row[nn], acc[M][nn], cb_, cbase, cc, bias); multi = 0; }     \
+            }                                                                                                                \
+            R64_INIT_LDS(M, st + 1);                                                                                         \
         } while (0)
         R64_ONE(0); R64_ONE(1); R64_ONE(2); R64_ONE(3);
 #undef R64_ONE
-        filter_merge_pair<TOPK>(row[0], row[1], wm, lh);
+        // the limits are recomputed from the lists after each of the first four scanned tiles, then after every fourth and after
+        // the last one: a limit that is a few tiles old is still the k-th best of real codes (valid, slightly looser)
+        const int since = st - W;
+                if (st < nct && (since < 4 || (since & 3) == 3 || st == nct - 1)) {
+            filter_merge_one<TOPK>(row[0], lst0, wm, lh);
+            filter_merge_one<TOPK>(row[1], lst0 + 32 * F_LST_ROWB, wm, lh);
+        }
         lds_init_wait(acc);
     };
 
-    for (int t = 0; t < nct; ++t) {
-        // this wave's share of tile t (and wave 0's start values of tile t + 1) has landed; then everyone's has, and everyone is
-        // past the MFMAs of tile t - 1 (the other ring slot) and past the start-value reads of tile t (buffer t & 1)
+    unsigned long long tm[5] = {0, 0, 0, 0, 0}, tq = 0;        // TIMED: copy wait, barrier, DMA issue, MFMAs, epilogue
+    auto tick = [&](int k) __attribute__((always_inline)) {
+        if (TIMED) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tm[k] += now - tq;
+            tq = now;
+        }
+    };
+    if (TIMED) tq = __builtin_amdgcn_s_memtime();
+    // one step up to its epilogue: this wave's share of step t's tile (and wave 0's start values of step t + 1) has landed; then
+    // everyone's has, and everyone is past the MFMAs of step t - 1 (the other ring slot) and past the start-value reads of step t
+    // (buffer t & 1); the next tile's copy goes out, then the MFMAs.  (Two loops, not one with a branch on the phase: with both
+    // epilogues behind one loop head hipcc spilled the x fragments.)
+    auto step_head = [&](int t) __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tick(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        tick(1);
         stage_init(t + 2);
-        stage(t + 1);                   // (past the end: the last tile again, into the slot nobody reads any more)
+        stage(t + 1);                   // (past the end: the last step's tile again, into the slot nobody reads any more)
+        tick(2);
         mfma_tile(t);
-        tile_epilogue(t, t == 0);
+        // The epilogues read the accumulators with inline-asm v_max3: hipcc's hazard recognizer does not count the wait states an
+        // XDL result needs before a VALU read for asm consumers (18 for a 16-pass MFMA), and its scheduler is free to move such a
+        // statement up to right behind the MFMA that feeds it.  Measured: with the learning epilogue, 335 of 600 000 rows lost
+        // their k-th code to limits computed from half-finished sums.  One statement that owns all eight tiles and holds the
+        // wait states: nothing reads an accumulator before it, nothing after it is early.
+        asm volatile("s_nop 15\n\ts_nop 1"
+                     : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
+        tick(3);
+    };
+    int t = 0;
+    for (; t < W; ++t) {
+        step_head(t);
+        learn_epilogue(t);
+        tick(4);
+    }
+    for (; t < nsteps; ++t) {
+        step_head(t);
+        scan_epilogue(t, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(t < nct ? 0 : 0x7f800000)));
+        tick(4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (TIMED && probe && lane == 0) {
+        unsigned long long *o = probe + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        o[0] = tm[0]; o[1] = tm[1]; o[2] = tm[2]; o[3] = tm[3]; o[4] = tm[4]; o[5] = (unsigned long long)nsteps; o[6] = n_hit;
+        o[7] = __builtin_amdgcn_s_memrealtime();
+    }
 #pragma unroll
     for (int nn = 0; nn < F_NT; ++nn) {
         const long xr = row0 + wn * (32 * F_NT) + nn * 32 + li;
-        const bool ok = sane && row[nn].xn <= F_NORM_LIMIT;
-        if (xr < n) cand_cnt[xr * own_total + owner] = ok ? (int)((row[nn].pos - list_start[nn]) >> 3) : F_CAP + 1;
+        const bool ok = sane && xsq[min(xr, n - 1)] <= F_NORM_LIMIT;
+        const unsigned first = row[nn].endm8 - (F_CAP - 1) * 8u;
+        if (xr < n) cand_cnt[xr * own_total + owner] = ok ? (int)((row[nn].pos - first) >> 3) : F_CAP + 1;
     }
 #undef R64_INIT_LDS
 #undef R64_LANE_CB

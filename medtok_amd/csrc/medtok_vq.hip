@@ -1094,14 +1094,13 @@ extern "C" int medtok_topk_search_f32(const float *xhat, const float *xsq, int64
 }
 
 // DEV probe (tools/r04/filter_probe.py): the filter kernel of one search with per-wave cycle counts of its loop segments written to
-// `probe` (uint64 [blocks][8][8]; blocks = *n_blocks on return).  Same plan as the search would take, main launch only; the
+// `probe` (uint64 [blocks][8][8] -- [blocks][4][8] for D <= 64, whose kernel has four waves; blocks = *n_blocks on return).  Same plan as the search would take, main launch only; the
 // candidate lists it writes into `ws` are discarded.
 extern "C" int medtok_debug_filter_probe(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq, int64_t k_codes, int d,
                                          int topk, void *ws, size_t ws_bytes, void *probe, size_t probe_bytes, int64_t *n_blocks, void *stream)
 {
     if (topk < 2 || topk > 5) return fail("filter_probe: topk 2..5");
-    PlanOverride ov = decode_plan(MEDTOK_PATH_F16_FILTER);
-    ov.filter_rows64 = 0;               // (the probe is an instantiation of the general kernel)
+    const PlanOverride ov = decode_plan(MEDTOK_PATH_F16_FILTER);
     const FilterPlan f = plan_filter(n, k_codes, d, topk, ov);
     const FilterWs w = filter_ws_layout(ws, n, f);
     if (!ws || ws_bytes < w.total) return fail("filter_probe: workspace too small (%zu < %zu)", ws_bytes, w.total);
@@ -1110,6 +1109,17 @@ extern "C" int medtok_debug_filter_probe(const float *xhat, const float *xsq, in
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, w.wh);
     hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, w.en_max);
     hipLaunchKernelGGL(pad_wsq_kernel, dim3((unsigned)((f.k_pad + 255) / 256)), dim3(256), 0, s, wsq, (int)k_codes, (int)f.k_pad, w.wsqp);
+    if (f.rows64) {         // D <= 64: uint64 [blocks][4][8]
+        const size_t blocks = (size_t)f.row_tiles * f.splits;
+        if (probe_bytes < blocks * 256) return fail("filter_probe: probe buffer too small (%zu < %zu)", probe_bytes, blocks * 256);
+        if (hipMemsetAsync(probe, 0, blocks * 256, s) != hipSuccess) return fail("filter_probe: memset failed");
+        (void)set_lds_once<filter_rows64_kernel<5, true>>(R64_SMEM_BYTES);
+        hipLaunchKernelGGL((filter_rows64_kernel<5, true>), dim3((unsigned)f.row_tiles, (unsigned)f.splits), dim3(R64_THREADS), R64_SMEM_BYTES, s,
+                           w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, d, f.codes_per_split, f.own_total, w.cand, w.cand_cnt,
+                           (unsigned long long *)probe);
+        if (n_blocks) *n_blocks = (int64_t)blocks;
+        return check_launch("filter_probe(rows64)");
+    }
     (void)set_lds_once<filter_f16_kernel<5, false, true>>(F_SMEM_BYTES);
     dim3 fgrid((unsigned)f.main_tiles, (unsigned)f.splits);
     if (f.xcd_rows) fgrid = dim3((unsigned)(((f.main_tiles + 8 * f.xcd_rows - 1) / (8 * f.xcd_rows)) * 256), 1);

@@ -247,3 +247,55 @@ def test_scan_hit_path_with_several_passing_values_per_quad(oracle, dev, n, K, D
     sub = slice(0, 300)
     io, do = oracle.topk_search(xh[sub].cpu().numpy(), xs[sub].cpu().numpy(), wh.cpu().numpy(), ws.cpu().numpy(), topk)
     assert np.array_equal(i_s[sub].cpu().numpy(), io) and np.array_equal(d_s[sub].cpu().numpy(), do)
+
+
+@pytest.mark.parametrize("n,K,D,topk,splits", [
+    (4000, 256, 64, 5, 1),            # one code tile: it is learnt from and revisited (W = nct = 1)
+    (70000, 2048, 64, 5, 0),          # default plan: 4 splits of 2 tiles -> every tile is a learning tile
+    (3000, 256 * 5 + 40, 64, 5, 1),   # nct = 6 < R64_LEARN, ragged last tile
+    (3000, 256 * 20, 64, 1, 1),       # learning tiles + scanned tiles + revisit, k-list of 1
+    (3000, 256 * 20 + 8, 60, 8, 2),   # D < 64 (zero-padded to 64), k-list of 8, two splits
+    (129, 256 * 9, 36, 3, 1),         # one partly filled row tile (forced onto the filter path below its size threshold)
+    (600000, 21000, 64, 5, 0),        # the reference's shape: the size at which a scheduling hazard of the learning step showed
+])
+def test_rows64_kernel_equals_exact_path_and_general_kernel(oracle, dev, n, K, D, topk, splits):
+    """filter_rows64_kernel (rows of <= 64 elements: x in registers, learning tiles revisited last) against the exact fp32 path,
+    against the general filter kernel on the same search, and against the oracle on a slice: ids and distances, bit for bit."""
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(n + K + D)
+    xh, xs = ops.rownorm(torch.randn(n, D, device=dev, generator=g))
+    wh, ws = ops.rownorm(torch.randn(K, D, device=dev, generator=g))
+    i_ref, d_ref = ops.topk_search(xh, xs, wh, ws, topk, ops.PATH_F32_MFMA)
+    ops.SEARCH_STATS = {}
+    try:
+        i_r, d_r = ops.topk_search(xh, xs, wh, ws, topk, _filter_path(filter_splits=splits, filter_rows64=True))
+        assert ops.SEARCH_STATS["fallback_rows"] <= n // 100      # the filter decided the rows, not the exact redo
+    finally:
+        ops.SEARCH_STATS = None
+    i_g, d_g = ops.topk_search(xh, xs, wh, ws, topk, _filter_path(filter_splits=splits, filter_rows64=False))
+    assert torch.equal(i_r, i_ref) and torch.equal(d_r, d_ref)
+    assert torch.equal(i_g, i_ref) and torch.equal(d_g, d_ref)
+    sub = slice(0, 200)
+    io, do = oracle.topk_search(xh[sub].cpu().numpy(), xs[sub].cpu().numpy(), wh.cpu().numpy(), ws.cpu().numpy(), topk)
+    assert np.array_equal(i_r[sub].cpu().numpy(), io) and np.array_equal(d_r[sub].cpu().numpy(), do)
+
+
+def test_rows64_kernel_with_near_copies_of_codes(oracle, dev):
+    """Runs of near-identical codes at D = 64: whole quads pass together in the scanned tiles AND in the revisited learning tiles
+    (append without insert, the revisit of a quad with several passing values), with exact ties."""
+    from medtok_amd import ops
+    n, K, D = 2500, 256 * 14, 64
+    g = torch.Generator(device=dev).manual_seed(5)
+    xh, xs = ops.rownorm(torch.randn(n, D, device=dev, generator=g))
+    base = torch.randn((K + 5) // 6, D, device=dev, generator=g)
+    W = base.repeat_interleave(6, 0)[:K].clone()
+    W[1::6] += 1e-3 * torch.randn(W[1::6].shape, device=dev, generator=g)
+    W[2::6] += 1e-4 * torch.randn(W[2::6].shape, device=dev, generator=g)
+    W[4::6] += 1e-2 * torch.randn(W[4::6].shape, device=dev, generator=g)
+    wh, ws = ops.rownorm(W)
+    for topk in (1, 5, 8):
+        i_ref, d_ref = ops.topk_search(xh, xs, wh, ws, topk, ops.PATH_F32_MFMA)
+        i_r, d_r = ops.topk_search(xh, xs, wh, ws, topk, _filter_path(filter_splits=1, filter_rows64=True))
+        assert torch.equal(i_r, i_ref) and torch.equal(d_r, d_ref), topk
+    io, do = oracle.topk_search(xh[:200].cpu().numpy(), xs[:200].cpu().numpy(), wh.cpu().numpy(), ws.cpu().numpy(), 8)
+    assert np.array_equal(i_r[:200].cpu().numpy(), io) and np.array_equal(d_r[:200].cpu().numpy(), do)
