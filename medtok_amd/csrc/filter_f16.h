@@ -324,12 +324,15 @@ __device__ __forceinline__ void filter_scan(FilterRow<TOPK> &r, const f32x16 &a,
 #pragma unroll
     for (int g = 0; g < 4; ++g) h[g] = __builtin_amdgcn_ballot_w64(mx[g] >= r.L);
     if (__builtin_expect((h[0] | h[1] | h[2] | h[3]) != 0, 0)) {
+        unsigned long long t0 = 0;
+        if (COUNT) t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             if (h[g]) {
                 filter_hit<TOPK, BIASED>(r, a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3], mx[g], cb + 8 * g, cbase, multi, cc, bias);
-                if (COUNT) ++*n_hit;      // (dev probe: how many of the wave's quad tests run the hit sequence)
+                if (COUNT) ++n_hit[0];    // (dev probe: how many of the wave's quad tests run the hit sequence, and for how long)
             }
+        if (COUNT) n_hit[1] += (unsigned)(__builtin_amdgcn_s_memtime() - t0);
     }
 }
 
@@ -1030,7 +1033,7 @@ __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
     };
 
     unsigned long multi = 0;
-    unsigned n_hit = 0;
+    unsigned n_hit[2] = {0, 0};
     float cc = -0x1p-15f;                   // (in a VGPR: the hit sequence's fma takes its one scalar operand for the bias)
     asm volatile("" : "+v"(cc));
     // learning step: the best of each accumulator tile into the lane's list; no appends.  The limits are set by the merges of
@@ -1063,7 +1066,7 @@ __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
         do {                                                                                                                 \
             const int cb_ = R64_LANE_CB(M, tile);                                                                            \
             _Pragma("unroll") for (int nn = 0; nn < F_NT; ++nn) {                                                            \
-                filter_scan<TOPK, TIMED, true>(row[nn], acc[M][nn], cb_, cbase, multi, &n_hit, cc, bias);                    \
+                filter_scan<TOPK, TIMED, true>(row[nn], acc[M][nn], cb_, cbase, multi, n_hit, cc, bias);                      \
                 if (multi) { filter_scan_rest<TOPK, true, true>(row[nn], acc[M][nn], cb_, cbase, cc, bias); multi = 0; }     \
             }                                                                                                                \
             R64_INIT_LDS(M, st + 1);                                                                                         \
@@ -1126,7 +1129,7 @@ __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (TIMED && probe && lane == 0) {
         unsigned long long *o = probe + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
-        o[0] = tm[0]; o[1] = tm[1]; o[2] = tm[2]; o[3] = tm[3]; o[4] = tm[4]; o[5] = (unsigned long long)nsteps; o[6] = n_hit;
+        o[0] = tm[0]; o[1] = tm[1]; o[2] = tm[2]; o[3] = tm[3]; o[4] = tm[4]; o[5] = (unsigned long long)nsteps; o[6] = n_hit[0] | ((unsigned long long)n_hit[1] << 32);
         o[7] = __builtin_amdgcn_s_memrealtime();
     }
 #pragma unroll

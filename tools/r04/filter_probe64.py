@@ -23,7 +23,10 @@ def run():
     assert rc == 0, lib.medtok_last_error()
 run(); torch.cuda.synchronize()
 t0 = time.perf_counter(); run(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-d = probe[: nblk.value * 32].view(nblk.value, 4, 8).cpu().double()
+raw = probe[: nblk.value * 32].view(nblk.value, 4, 8).cpu()
+hit_cycles = (raw[:, :, 6] >> 32).double()
+raw[:, :, 6] &= 0xFFFFFFFF
+d = raw.double()
 tiles = d[:, :, 5].sum()
 seg = ["wait for own copies (s_waitcnt vmcnt(0): DMA and candidate stores)", "tile barrier", "DMA issue (8 + 1 instructions)", "32 MFMAs + 16 operand reads", "epilogue (scan, hits, merge, restart)"]
 tot = d[:, :, :5].sum()
@@ -31,6 +34,8 @@ out = {"workload": f"one search, {N} rows x K={K}, D={D}, k=5", "timed_launch_in
        "tiles_per_wave_mean": float(d[:, :, 5].mean()), "cycles_per_tile_and_wave": float(tot / tiles), "hit_sequences_per_tile_and_wave": float(d[:, :, 6].sum() / tiles), "segments": {}}
 print(f"{nblk.value} blocks, {float(d[:, :, 5].mean()):.0f} code tiles per wave; timed launch with operand prep {dt * 1e3:.2f} ms")
 print(f"cycles per code tile and wave: {float(tot / tiles):.0f}  (32 MFMAs of 32 cycles = 1024); hit sequences per tile and wave: {float(d[:, :, 6].sum() / tiles):.2f} of 32 quad tests")
+print(f"  of the epilogue, inside the hit blocks (quad hit sequences of an accumulator tile, with the scalar branches around them): {float(hit_cycles.sum() / tiles):.0f} cycles/tile")
+out["hit_block_cycles_per_tile"] = float(hit_cycles.sum() / tiles)
 for i, nm in enumerate(seg):
     c = float(d[:, :, i].sum() / tiles)
     out["segments"][nm] = {"cycles_per_tile": c, "share": c / float(tot / tiles)}
