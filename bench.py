@@ -768,7 +768,9 @@ def main():
                                        if args.workload == "codeshard" else
                                        f"row-shard x{world}, codebook replicated, no data-path collective")},
             "roofline": {**bound_view,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kname,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         # (rows of <= 64 elements take the fp16 filter's narrow-row kernel: the name rocprofv3 shows)
+                         "kernel": ("filter_rows64_kernel" if kname == "filter_f16_kernel" and wl.D <= 64 else kname),
                          "hbm_frac": hbm_gbs / HBM_PEAK_GBS, "hbm_achieved_gbs": hbm_gbs, "hbm_peak_gbs": HBM_PEAK_GBS,
                          "algorithmic_bytes_per_step": alg_bytes_step,
                          "binding_roof": ("hbm for this kernel (intensity left of the ridge of the pipe it runs on); hbm_frac below is the whole STEP's SURVEY-8d bytes"
