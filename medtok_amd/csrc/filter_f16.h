@@ -931,13 +931,16 @@ __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
         st = min(st, nsteps - 1);
         return __builtin_amdgcn_readfirstlane(st < nct ? st : st - nct);
     };
-    auto stage = [&](int st) __attribute__((always_inline)) {
+    // (piece q of a tile's copy: the first tile's pieces go out together, later ones ride between the MFMAs of the tile before)
+    auto stage_piece = [&](int st, int so, int q) __attribute__((always_inline)) {
         char *base = fsm + (st & 1) * R64_TILEB + wave_s * (64 * R64_ROWB);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(base + q * 8 * R64_ROWB), 16, (int)lane_off,
+                                                 so + q * 8 * R64_ROWB, 0, 0);
+    };
+    auto stage = [&](int st) __attribute__((always_inline)) {
         const int so = tile_of(st) * R64_TILEB;
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(base + q * 8 * R64_ROWB), 16, (int)lane_off,
-                                                     so + q * 8 * R64_ROWB, 0, 0);
+        for (int q = 0; q < 8; ++q) stage_piece(st, so, q);
     };
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(wsqs + code_lo), 0, -1, 0x00020000);
     auto stage_init = [&](int st) __attribute__((always_inline)) {
@@ -1005,6 +1008,7 @@ __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
     // with counted waits: LDS reads return in order, and a C++ ds_read would be ordered behind the pending LDS-DMA of the next tile)
     auto mfma_tile = [&](int st) __attribute__((always_inline)) {
         const unsigned so = (unsigned)((st & 1) * R64_TILEB);
+        const int dma_so = tile_of(st + 1) * R64_TILEB;
         unsigned adr[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) adr[t] = a_adr[t] + so;
@@ -1031,6 +1035,10 @@ __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
 #pragma unroll
                 for (int nn = 0; nn < F_NT; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, xf[nn][t], acc[m][nn], 0, 0, 0);
             }
+            // the next tile's copy, one piece behind every second MFMA pair: an LDS-DMA instruction holds its wave for ~50 cycles,
+            // which here pass under the two MFMAs just issued (64 cycles of the pipe) instead of in front of the tile's first one
+            if (i & 1) stage_piece(st + 1, dma_so, i >> 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -1105,9 +1113,8 @@ __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
         asm volatile("" ::: "memory");
         tick(1);
         stage_init(t + 2);
-        stage(t + 1);                   // (past the end: the last step's tile again, into the slot nobody reads any more)
         tick(2);
-        mfma_tile(t);
+        mfma_tile(t);                   // (with the copy of step t + 1's tile woven in; past the end: the last tile again, into the slot nobody reads any more)
         // The epilogues read the accumulators with inline-asm v_max3: hipcc's hazard recognizer does not count the wait states an
         // XDL result needs before a VALU read for asm consumers (18 for a 16-pass MFMA), and its scheduler is free to move such a
         // statement up to right behind the MFMA that feeds it.  Measured: with the learning epilogue, 335 of 600 000 rows lost

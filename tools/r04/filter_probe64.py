@@ -5,6 +5,9 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import torch
 from medtok_amd import _lib, ops
+import os
+if os.environ.get('DBGLIB'):
+    _lib.use_library(os.environ['DBGLIB'])
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 600000
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 21000
