@@ -792,7 +792,7 @@ def main():
             line["extra"] = {"strong_scaling": strong}
         if args.workload in ("full", "fullref"):
             # both stream settings in one line: `value` is the forward as shipped (side streams from 512 codes up) unless --one-stream
-            line["config"]["streams"] = "one (--one-stream)" if args.one_stream else "main + 3 side streams (modality-specific searches, text images, text side)"
+            line["config"]["streams"] = "one (--one-stream)" if args.one_stream else "main + side streams (modality-specific searches, text side; the image pass over fp32 text rows has its own only where the attention kernel does not split the keys itself)"
             if half_text is not None:
                 line["half_precision_text"] = half_text
             if one_stream_elapsed is not None:

@@ -269,7 +269,11 @@ int medtok_shared_kv_attention_split_f32(const float *q, const int64_t *q_start,
  * (attention_pp.h).  Same function; 0 / 1 agree to the last bits, 2 within 2e-6 of them (exp on v_exp_f32).
  * kv_lo = NULL (variant 2 only): the keys are fp16 as they stand -- a caller under fp16 autocast hands over half-precision text
  * features (train_MedTok.py:212,394): no lo image is read, two matrix passes per product instead of three; equal to the call with
- * an all-zero lo image bit for bit. */
+ * an all-zero lo image bit for bit.
+ * variant | MEDTOK_ATTENTION_F32_KEYS (variant 2 only): kv_hi points at the fp32 key rows [Rk, d] themselves and kv_lo is ignored;
+ * the kernel forms the (hi, lo) images of every key chunk in LDS (the arithmetic of medtok_split_half_f32: same bits as the call
+ * on its images) -- no image pass over the key batch, no image buffers. */
+#define MEDTOK_ATTENTION_F32_KEYS 0x100
 
 /* Dev probes (tools/r04/att_probe.py, tools/r04/filter_probe.py): per-wave cycle counts (s_memtime) of a kernel's loop segments,
  * written by a TIMED instantiation that only these entry points launch.  medtok_debug_set_attention_probe(p) arms the next

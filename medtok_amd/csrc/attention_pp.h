@@ -50,7 +50,15 @@ __device__ __forceinline__ float pp_exp(float x) { return __builtin_amdgcn_exp2f
 // reference's default training mode train_MedTok.py:212,394): there is no lo image -- kvl is not read, a chunk is one plane (half
 // the bytes from HBM and through the DMA), and the passes against it drop out of both products (two MFMAs per step instead of
 // three).  With lo = 0 the three-pass form adds exact zeros, so the results equal the KLO form on the widened keys bit for bit.
-template <int NT, bool TIMED = false, bool KLO = true>
+// KF32: the keys are the caller's fp32 rows (kvh points at them, kvl is not read) and become their (hi, lo) fp16 images INSIDE the
+// kernel: the image pass over the whole text batch (read 4 B + write 4 B per element, 1.4 ms at BASELINE sizes, and its 3.2 GB of
+// images read back by both layers) is gone, the kernel reads the same 4 B per element it read as images.  A wave's share of a
+// chunk's copy is then both planes of HALF its group's pieces, and every 16-byte DMA slot of the hi plane receives the first four
+// floats of the eight columns whose hi image belongs there, the slot of the lo plane at the same position the other four: when
+// its own copies have landed, a lane reads its two slots, forms hi = fp16(x), lo = fp16(x - hi) (the arithmetic of
+// split_half_kernel: same bits), and writes the two 16-byte images back into the two slots it read -- lane-local and in place, no
+// staging area, no extra barrier; the slot's closing barrier publishes the images.
+template <int NT, bool TIMED = false, bool KLO = true, bool KF32 = false>
 __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
     const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
     const _Float16 *__restrict__ kvh, const _Float16 *__restrict__ kvl, const int64_t *__restrict__ kv_start,
@@ -61,6 +69,7 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
     constexpr int D = S::D, PIECE = S::PIECE, PLANEB = S::PLANEB, CHUNKB = S::CHUNKB, PSL = S::PSL, W = S::W;
     constexpr int EPT = 2, TPR = 8;                // softmax step: 256 threads of a group on 32 rows x 16 keys
     static_assert(NT % 2 == 0 && NT <= 6, "column tiles come in pairs; D <= 768");
+    static_assert(!KF32 || KLO, "fp32 keys become (hi, lo) images");
     extern __shared__ __attribute__((aligned(16))) float att_sm[];
     char *ring = reinterpret_cast<char *>(att_sm);                                              // [2][W][2][NT][1 KB]
     // block -> (code, tile pair): as attention_dma.h -- round-robin over the 8 XCDs, the pairs of one code consecutive within an XCD
@@ -82,17 +91,58 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
     float *alpha_s = reinterpret_cast<float *>(pl + 32 * PSL), *l_s = alpha_s + 32;
 
     // ---- key chunks by LDS-DMA: this wave copies plane `grp` of column slice `w` (attention_dma.h: lane = (key, piece position))
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((KLO && grp) ? kvl : kvh) + ks * (long)D), 0, (int)0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        KF32 ? (void *)(reinterpret_cast<const float *>(kvh) + ks * (long)D) : (void *)(((KLO && grp) ? kvl : kvh) + ks * (long)D), 0, (int)0x7fffffff, 0x00020000);
     constexpr int DMA_PER_CHUNK = KLO ? NT : NT / 2;     // (one plane: group g copies the k blocks p = g, g + 2, ... of it)
     const int d_key = lane >> 2, d_col = slice + 8 * ((lane & 3) ^ ((0 - (lane >> 4)) & 3));
     auto stage = [&](int c) __attribute__((always_inline)) {
         const int key = min(16 * c + d_key, kl - 1);                    // past the last key: re-read it (its probability is zero)
+        if (KF32) {     // pieces grp NT/2 .. of BOTH planes: the two halves of each 8-column unit (see the head comment)
+            const int voff = (key * D + d_col) * 4;
+            char *base = ring + (c & 1) * CHUNKB + w * 2 * PLANEB;
+#pragma unroll
+            for (int pp = 0; pp < NT / 2; ++pp) {
+                const int p = grp * (NT / 2) + pp;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(base + p * PIECE), 16, voff, 128 * p, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(base + PLANEB + p * PIECE), 16, voff, 128 * p + 16, 0, 0);
+            }
+            return;
+        }
         const int voff = (key * D + d_col) * 2;
         char *base = ring + (c & 1) * CHUNKB + w * 2 * PLANEB + (KLO ? grp * PLANEB : 0);
 #pragma unroll
         for (int p = 0; p < NT; ++p)
             if (KLO || (p & 1) == grp)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(base + p * PIECE), 16, voff, 64 * p, 0, 0);
+    };
+    // KF32: this wave's pieces of chunk c from fp32 to (hi, lo), in place (its own copies have landed: the caller has waited)
+    auto convert = [&](int c) __attribute__((always_inline)) {
+        if (!KF32) return;
+        const unsigned a0 = (unsigned)(size_t)ring + (unsigned)((c & 1) * CHUNKB + w * 2 * PLANEB + grp * (NT / 2) * PIECE + lane * 16);
+        // (all reads first: one LDS round trip for the wave's NT / 2 units, not one each)
+        f32x4v fa_[NT / 2], fb_[NT / 2];
+#pragma unroll
+        for (int pp = 0; pp < NT / 2; ++pp)
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                         : "=&v"(fa_[pp]), "=&v"(fb_[pp]) : "v"(a0), "i"(pp * PIECE), "i"(PLANEB + pp * PIECE) : "memory");
+#pragma unroll
+        for (int pp = 0; pp < NT / 2; ++pp) {
+            f32x4v &fa = fa_[pp], &fb = fb_[pp];
+            // (in-order returns: the 2 (NT / 2 - 1 - pp) reads behind this unit's may still be out)
+            if (NT / 2 - 1 - pp == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa), "+v"(fb) : : "memory");
+            else if (NT / 2 - 1 - pp == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa), "+v"(fb) : : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa), "+v"(fb) : : "memory");
+            const float f[8] = {fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3]};
+            half8 hh, ll;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                hh[e] = (_Float16)f[e];
+                ll[e] = (_Float16)(f[e] - (float)hh[e]);
+            }
+            const u32x4 hv = __builtin_bit_cast(u32x4, hh), lv = __builtin_bit_cast(u32x4, ll);
+            asm volatile("ds_write_b128 %0, %1 offset:%3\n\tds_write_b128 %0, %2 offset:%4"
+                         : : "v"(a0), "v"(hv), "v"(lv), "i"(pp * PIECE), "i"(PLANEB + pp * PIECE) : "memory");
+        }
     };
     const int nchunk = (kl + 15) >> 4;
 
@@ -153,6 +203,8 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if (nchunk > 0) convert(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
@@ -320,9 +372,17 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
         }
     };
     // a slot ends with one block-wide barrier; at the end of slots 3c'+2 this wave's share of chunk c'+1's copy must have landed
-    auto slot_end = [&](bool copies) __attribute__((always_inline)) {
-        if (copies) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // (copies = the chunk whose copy this slot's end waits for, or -1: with fp32 keys the wave then turns its pieces into images)
+    auto slot_end = [&](int copies) __attribute__((always_inline)) {
+        if (copies >= 0) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (KF32 && copies < nchunk) {
+                convert(copies);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
@@ -342,24 +402,24 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
     if (grp == 0) {
         for (int c = 0; c < nchunk; ++c) {
             if (active) timed(t_s, [&]() __attribute__((always_inline)) { phase_s(c); });
-            timed(t_w, [&]() __attribute__((always_inline)) { slot_end(false); });
+            timed(t_w, [&]() __attribute__((always_inline)) { slot_end(-1); });
             refill(c);
             if (active) timed(t_x, [&]() __attribute__((always_inline)) { phase_x(c); });
-            timed(t_w, [&]() __attribute__((always_inline)) { slot_end(false); });
+            timed(t_w, [&]() __attribute__((always_inline)) { slot_end(-1); });
             if (active) timed(t_v, [&]() __attribute__((always_inline)) { phase_v(c); });
-            timed(t_w, [&]() __attribute__((always_inline)) { slot_end(true); });
+            timed(t_w, [&]() __attribute__((always_inline)) { slot_end(c + 1); });
         }
-        timed(t_w, [&]() __attribute__((always_inline)) { slot_end(false); });                           // (slot 3 nchunk: g1's last V)
+        timed(t_w, [&]() __attribute__((always_inline)) { slot_end(-1); });                           // (slot 3 nchunk: g1's last V)
     } else {
-        timed(t_w, [&]() __attribute__((always_inline)) { slot_end(false); });                           // (slot 0: g0's first S)
+        timed(t_w, [&]() __attribute__((always_inline)) { slot_end(-1); });                           // (slot 0: g0's first S)
         for (int c = 0; c < nchunk; ++c) {
             refill(c);
             if (active) timed(t_s, [&]() __attribute__((always_inline)) { phase_s(c); });
-            timed(t_w, [&]() __attribute__((always_inline)) { slot_end(false); });
+            timed(t_w, [&]() __attribute__((always_inline)) { slot_end(-1); });
             if (active) timed(t_x, [&]() __attribute__((always_inline)) { phase_x(c); });
-            timed(t_w, [&]() __attribute__((always_inline)) { slot_end(true); });
+            timed(t_w, [&]() __attribute__((always_inline)) { slot_end(c + 1); });
             if (active) timed(t_v, [&]() __attribute__((always_inline)) { phase_v(c); });
-            timed(t_w, [&]() __attribute__((always_inline)) { slot_end(false); });
+            timed(t_w, [&]() __attribute__((always_inline)) { slot_end(-1); });
         }
     }
 #undef PP_MFMA16

@@ -1571,8 +1571,11 @@ extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_
     if (n_codes == 0 || max_q_len == 0) return 0;
     const int vform = variant & 15;
     const bool pp_shape = vform == 2 && (d == 256 || d == 512 || d == 768);
+    // MEDTOK_ATTENTION_F32_KEYS: kv_hi points at the caller's fp32 key rows, which the kernel turns into their (hi, lo) images itself
+    const bool f32_keys = (variant & MEDTOK_ATTENTION_F32_KEYS) != 0;
+    if (f32_keys && !pp_shape) return fail("shared_kv_attention_split: fp32 keys converted in the kernel need variant 2 and d = 256, 512 or 768");
     if (!q || !q_start || !q_len || !kv_hi || !kv_start || !kv_len || (!out && !out_hi)) return fail("shared_kv_attention_split: NULL argument");
-    if (!kv_lo && !pp_shape) return fail("shared_kv_attention_split: keys without a lo image (fp16 keys as they stand) need variant 2 and d = 256, 512 or 768");
+    if (!kv_lo && !f32_keys && !pp_shape) return fail("shared_kv_attention_split: keys without a lo image (fp16 keys as they stand) need variant 2 and d = 256, 512 or 768");
     if (((uintptr_t)q | (uintptr_t)kv_hi | (uintptr_t)kv_lo | (uintptr_t)out) & 15) return fail("shared_kv_attention_split: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
@@ -1591,16 +1594,17 @@ extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_
         // two 32-row tiles of a code per block, run one phase apart on one copy of the keys (attention_pp.h)
         const int64_t q_pairs = (max_q_len + 63) / 64;
         if (q_pairs * (n_codes + 8) >= (1ll << 31)) return fail("shared_kv_attention_split: grid limit exceeded");
-#define MEDTOK_ATT_PP(NT, TIMED, KLO)                                                                                              \
+#define MEDTOK_ATT_PP(NT, TIMED, KLO, ...)                                                                                         \
     do {                                                                                                                          \
         const size_t lds = AttPP<NT>::LDS_BYTES;                                                                                  \
-        if (!set_lds_once<shared_kv_attention_pp_kernel<NT, TIMED, KLO>>(lds)) return fail("shared_kv_attention_split: cannot reserve %zu bytes of LDS", lds); \
-        hipLaunchKernelGGL((shared_kv_attention_pp_kernel<NT, TIMED, KLO>), dim3((unsigned)(q_pairs * ((n_codes + 7) / 8 * 8))), dim3(512), lds, s, q, q_start, \
+        if (!set_lds_once<shared_kv_attention_pp_kernel<NT, TIMED, KLO __VA_ARGS__>>(lds)) return fail("shared_kv_attention_split: cannot reserve %zu bytes of LDS", lds); \
+        hipLaunchKernelGGL((shared_kv_attention_pp_kernel<NT, TIMED, KLO __VA_ARGS__>), dim3((unsigned)(q_pairs * ((n_codes + 7) / 8 * 8))), dim3(512), lds, s, q, q_start, \
                            q_len, (const _Float16 *)kv_hi, (const _Float16 *)kv_lo, kv_start, kv_len, scale, out, (_Float16 *)out_hi,             \
                            (_Float16 *)out_lo, (int)q_pairs, (int)n_codes, (unsigned long long *)g_att_dbg);                      \
     } while (0)
-        const bool timed = (variant >> 4) == 8 && g_att_dbg;          // (dev probe: tools/r04/att_probe.py)
-        if (!kv_lo) { if (d == 256) MEDTOK_ATT_PP(2, false, false); else if (d == 512) MEDTOK_ATT_PP(4, false, false); else MEDTOK_ATT_PP(6, false, false); }
+        const bool timed = ((variant >> 4) & 15) == 8 && g_att_dbg;   // (dev probe: tools/r04/att_probe.py)
+        if (f32_keys) { if (d == 256) MEDTOK_ATT_PP(2, false, true, , true); else if (d == 512) MEDTOK_ATT_PP(4, false, true, , true); else MEDTOK_ATT_PP(6, false, true, , true); }
+        else if (!kv_lo) { if (d == 256) MEDTOK_ATT_PP(2, false, false); else if (d == 512) MEDTOK_ATT_PP(4, false, false); else MEDTOK_ATT_PP(6, false, false); }
         else if (d == 256) MEDTOK_ATT_PP(2, false, true); else if (d == 512) MEDTOK_ATT_PP(4, false, true);
         else if (timed) MEDTOK_ATT_PP(6, true, true);
         else MEDTOK_ATT_PP(6, false, true);

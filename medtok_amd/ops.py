@@ -423,7 +423,7 @@ def cross_attention_layer(rows, rows_images, w, q_start, q_len, max_q_len: int, 
                           gamma, beta, eps: float, want_images: bool):
     """One CrossAttentionLayer at inference in one C call (include/medtok_vq.h: medtok_cross_attention_layer_f32).  rows [R, d] fp32;
     rows_images: their (hi, lo) images [R, dw] or None; w: the dict of CrossAttention._split_weights; kv fp32 [Rk, dw] or kv_split =
-    (hi, lo | None) images.  Returns y [R, d] (and its images [R, dw] when want_images)."""
+    (hi, lo | None) images, or kv_split = the fp32 rows themselves (split inside the kernel: shared_kv_attention_split).  Returns y [R, d] (and its images [R, dw] when want_images)."""
     rows = _dev(rows, "rows")
     n_rows, d = rows.shape
     heads, hp, dw = w["heads"], w["hp"], w["dw"]
@@ -435,7 +435,10 @@ def cross_attention_layer(rows, rows_images, w, q_start, q_len, max_q_len: int, 
     ws = _ws(lib.medtok_cross_attention_layer_workspace_bytes(n_rows, d, dw, heads, hp), rows)
     (wq, wq_u), (wk, wk_u), (wv, wv_u), (wo, wo_u) = w["wq"], w["wk"], w["wv"], w["wo"]
     xh, xl = rows_images if rows_images is not None else (None, None)
-    kh, kl = kv_split if kv_split is not None else (None, None)
+    if torch.is_tensor(kv_split):               # fp32 key rows, turned into their images inside the attention kernel
+        kh, kl, variant = _dev(kv_split, "kv"), None, int(variant) | ATTENTION_F32_KEYS
+    else:
+        kh, kl = kv_split if kv_split is not None else (None, None)
     with torch.cuda.device(dev):
         _lib.check(lib.medtok_cross_attention_layer_f32(
             rows.data_ptr(), _ptr(xh), _ptr(xl), n_rows, d, dw, heads, hp,
@@ -502,14 +505,23 @@ ATTENTION_SPLIT_WIDTHS = (128, 256, 384, 512, 768)
 ATTENTION_HALF_KEY_WIDTHS = (256, 512, 768)        # widths at which fp16 keys are taken as they stand (variant 2, no lo image)
 
 
+ATTENTION_F32_KEYS = 0x100                 # MEDTOK_ATTENTION_F32_KEYS (include/medtok_vq.h)
+
+
 def shared_kv_attention_split(q, q_start, q_len, kv_split, kv_start, kv_len, max_q_len: int, scale: float, split_out: bool = False, variant: int = 0):
     """shared_kv_attention for wide batches: the keys as the (hi, lo) fp16 images of split_half (made once per forward), 64 query
     rows per block, keys copied into LDS by DMA.  d in ATTENTION_SPLIT_WIDTHS."""
     q = _dev(q, "q")
-    kh, kl_ = kv_split                          # kl_ = None: fp16 keys as they stand (no lo image; variant 2, d = 256 / 512 / 768)
-    for t in (kh, kl_):
-        if t is not None and not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == q.shape[1]):
-            raise _lib.MedTokLibraryError("shared_kv_attention_split: the key images must be contiguous fp16 [Rk, d] device tensors")
+    if torch.is_tensor(kv_split):               # fp32 key rows, turned into their images inside the kernel (variant 2, d = 256 / 512 / 768)
+        kh, kl_ = _dev(kv_split, "kv"), None
+        if kh.dim() != 2 or kh.shape[1] != q.shape[1]:
+            raise _lib.MedTokLibraryError("shared_kv_attention_split: fp32 keys must be [Rk, d]")
+        variant = int(variant) | ATTENTION_F32_KEYS
+    else:
+        kh, kl_ = kv_split                      # kl_ = None: fp16 keys as they stand (no lo image; variant 2, d = 256 / 512 / 768)
+        for t in (kh, kl_):
+            if t is not None and not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == q.shape[1]):
+                raise _lib.MedTokLibraryError("shared_kv_attention_split: the key images must be contiguous fp16 [Rk, d] device tensors")
     qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
     ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
     out, oh, ol = _attention_outputs(q, split_out)

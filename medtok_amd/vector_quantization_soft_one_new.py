@@ -51,6 +51,9 @@ SPLIT_ATTENTION_MIN_ROWS = 1024      # ... from this many query rows up (below i
 # which form of the wide-batch attention core ops.shared_kv_attention_split runs (include/medtok_vq.h): 2 = two 32-row tiles of a
 # code per block, one phase apart on one copy of the keys (D = 256 / 512 / 768; the others fall back to 0 inside the library)
 ATTENTION_VARIANT = 2
+# fp32 text rows go to the graph side's attention core as they are and become their (hi, lo) images inside the kernel, chunk by
+# chunk (variant 2 at D = 256 / 512 / 768): no image pass over the whole text batch, no image buffers
+KEYS_SPLIT_IN_KERNEL = True
 # training / autograd: the cross-attention's dense products (and their backward) on the library's own split-fp16 GEMMs instead
 # of nn.functional.linear / einsum (hipBLASLt)
 TRAIN_SPLIT_PRODUCTS = True
@@ -598,6 +601,9 @@ class CrossAttention(nn.Module):
                 return
             if images is not None:                         # (pooled() issued them before anything else)
                 text_split, images_ready = images
+            elif (KEYS_SPLIT_IN_KERNEL and ATTENTION_VARIANT == 2 and kv_text.dtype == torch.float32 and kv_text.is_contiguous()
+                    and kv_text.shape[1] in ops.ATTENTION_HALF_KEY_WIDTHS):
+                text_split = kv_text                       # the fp32 rows themselves: the kernel splits every chunk it copies
             else:
                 text_split = ops.split_half(kv_text, seg_len=valid_len, seg_rows=seq_len)
 
@@ -607,7 +613,8 @@ class CrossAttention(nn.Module):
             if images_ready is not None:                   # first use of the images made on the other stream
                 torch.cuda.current_stream(text.device).wait_event(images_ready)
                 for t in text_split:
-                    t.record_stream(torch.cuda.current_stream(text.device))
+                    if t is not None:
+                        t.record_stream(torch.cuda.current_stream(text.device))
                 images_ready = None
             return text_split
 
@@ -739,6 +746,7 @@ class CrossAttention(nn.Module):
         if half_keys:
             images = ((text.view(bsz * seq_len, dim), None), None)
         elif (not autograd and not torch.is_grad_enabled() and SPLIT_ATTENTION and 0 < SIDE_STREAM_MIN_CODES <= bsz
+                and not (KEYS_SPLIT_IN_KERNEL and ATTENTION_VARIANT == 2 and dim in ops.ATTENTION_HALF_KEY_WIDTHS)
                 and text.dtype == torch.float32 and nodes.dtype == torch.float32 and text.is_contiguous()
                 and dim in ops.ATTENTION_SPLIT_WIDTHS and nodes.shape[0] * heads >= SPLIT_ATTENTION_MIN_ROWS and nodes.shape[0] > 0):
             # The (hi, lo) fp16 images of the valid text rows -- the keys of the graph side, an HBM-bound pass over the whole text

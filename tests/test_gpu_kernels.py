@@ -442,6 +442,17 @@ def test_shared_kv_attention_split_matches_oracle(oracle, dev, d, heads, seed, v
     # and the 32-row kernel on the same problem: same function
     other = ops.shared_kv_attention(T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len), int(q_len.max()), scale).cpu().numpy()
     assert np.abs(other[touched] - got[touched]).max() <= 2e-6 * np.abs(want[touched]).max()
+    if variant == 2:
+        # the same kernel fed the fp32 key rows (it forms the images of every chunk in LDS itself): the bits of the call on the images,
+        # fp32 output and output images alike; key rows no code owns may hold anything
+        kv_dev = T(kv).clone()
+        kv_dev[~valid] = float("nan")
+        own = ops.shared_kv_attention_split(T(q), T(q_start), T(q_len), kv_dev, T(kv_start), T(kv_len), int(q_len.max()), scale, variant=2)
+        assert np.array_equal(own.cpu().numpy()[touched], got[touched])
+        h1, l1 = ops.shared_kv_attention_split(T(q), T(q_start), T(q_len), images, T(kv_start), T(kv_len), int(q_len.max()), scale, split_out=True, variant=2)
+        h2, l2 = ops.shared_kv_attention_split(T(q), T(q_start), T(q_len), kv_dev, T(kv_start), T(kv_len), int(q_len.max()), scale, split_out=True, variant=2)
+        tt = torch.from_numpy(touched).to(dev)
+        assert torch.equal(h1[tt], h2[tt]) and torch.equal(l1[tt], l2[tt])
 
 
 @pytest.mark.parametrize("d", [64, 128, 768, 384])
