@@ -684,3 +684,26 @@ def test_fused_layer_call_equals_the_seven_separate_calls(dev, D, B):
             M.FUSED_LAYER_CALL = keep
     torch.cuda.synchronize()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("D,B,fused", [(768, 300, True), (768, 600, False), (256, 700, True), (200, 700, True)])
+def test_keys_split_inside_the_attention_kernel_equal_the_image_pass(dev, D, B, fused):
+    """KEYS_SPLIT_IN_KERNEL: fp32 text rows go to the graph side's attention core as they are and become their (hi, lo) images in
+    LDS, chunk by chunk -- the arithmetic of the image pass it replaces, so pooled() must return the bits of the forward that makes
+    the images first (side-stream image pass included: B >= 512), through the one-call layer and through the seven separate
+    calls, at a native and at a padded width."""
+    import medtok_amd.vector_quantization_soft_one_new as M
+    torch.manual_seed(D + B)
+    v = M.VectorQuantizer(3 * 256, D, 0.25, 0.0, True, False, [D, D]).to(dev).eval()
+    text, mask, nodes, batch = (t.to(dev) for t in synth.ragged_batch("keys", B, 40, 10, D, 9))
+    outs = []
+    for in_kernel in (True, False):
+        keep = (M.KEYS_SPLIT_IN_KERNEL, M.FUSED_LAYER_CALL)
+        M.KEYS_SPLIT_IN_KERNEL, M.FUSED_LAYER_CALL = in_kernel, fused
+        try:
+            with torch.no_grad():
+                outs.append(v.cross_attn.pooled(text, mask, nodes, batch))
+        finally:
+            M.KEYS_SPLIT_IN_KERNEL, M.FUSED_LAYER_CALL = keep
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
