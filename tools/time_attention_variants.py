@@ -7,7 +7,7 @@ import torch
 from medtok_amd import ops
 dev = torch.device("cuda:0")
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-variants = [int(a) for a in args] or [0, 2]
+variants = [int(a) for a in args] or [0, 2, 258]          # (258 = 2 | 0x100: fp32 keys, split inside the kernel)
 B = int(sys.argv[sys.argv.index("--codes") + 1]) if "--codes" in sys.argv else 4096
 D, H, L = 768, 4, 512
 g = torch.Generator(device=dev).manual_seed(77)
@@ -22,7 +22,8 @@ q_start, q_len, k_start, k_len = (starts * H)[order], (n_nodes * H)[order], (tor
 pairs = float((n_nodes * H * tok).sum())
 nbytes = 4.0 * D * (float(tok.sum()) + 2.0 * float((n_nodes * H).sum()))
 def run(v, split_out=False):
-    return ops.shared_kv_attention_split(q, q_start, q_len, images, k_start, k_len, 160, 192 ** -0.5, split_out=split_out, variant=v)
+    keys = text if v & 0x100 else images
+    return ops.shared_kv_attention_split(q, q_start, q_len, keys, k_start, k_len, 160, 192 ** -0.5, split_out=split_out, variant=v & 0xFF)
 outs = {v: run(v) for v in variants}
 torch.cuda.synchronize()
 ref = outs[variants[0]]
