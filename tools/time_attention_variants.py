@@ -4,7 +4,10 @@ in one process; checks that the variants return the same bits.   python tools/ti
 import sys, time
 sys.path.insert(0, ".")
 import torch
-from medtok_amd import ops
+from medtok_amd import ops, _lib
+import os
+if os.environ.get('DBGLIB'):
+    _lib.use_library(os.environ['DBGLIB'])
 dev = torch.device("cuda:0")
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 variants = [int(a) for a in args] or [0, 2, 258]          # (258 = 2 | 0x100: fp32 keys, split inside the kernel)
