@@ -754,7 +754,11 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk, const
     f.tslots = topk == 1 ? 1 : (topk <= 5 ? 5 : 8);
     f.n_pad = (n + F_BN - 1) / F_BN * F_BN;
     f.k_pad = (k_codes + F_BM - 1) / F_BM * F_BM;
-    f.dp = (d + F_BK - 1) / F_BK * F_BK;
+    // at least TWO 32-deep stages per code tile: the start values of code tile t + 2 are copied (LDS-DMA, wave 0) at the end of tile
+    // t's scan and read at the end of tile t + 1's, and what guarantees that they have landed is the counted vmcnt wait of a LATER
+    // stage -- with one stage per tile there is none in between (found by tools/fuzz_search.py at D = 4 / 32: one wave's 64 rows
+    // wrong in ~1 % of the searches).  D <= 32 is zero-padded to 64 and takes the narrow-row kernel like every D <= 64.
+    f.dp = (int)lmax(2 * F_BK, (d + F_BK - 1) / F_BK * F_BK);
     f.row_tiles = f.n_pad / F_BN;
     const long code_tiles = f.k_pad / F_BM;
     f.rows64 = f.dp == 64 && ov.filter_rows64 != 0;

@@ -299,3 +299,26 @@ def test_rows64_kernel_with_near_copies_of_codes(oracle, dev):
         assert torch.equal(i_r, i_ref) and torch.equal(d_r, d_ref), topk
     io, do = oracle.topk_search(xh[:200].cpu().numpy(), xs[:200].cpu().numpy(), wh.cpu().numpy(), ws.cpu().numpy(), 8)
     assert np.array_equal(i_r[:200].cpu().numpy(), io) and np.array_equal(d_r[:200].cpu().numpy(), do)
+
+
+def test_rows_of_at_most_32_elements_repeated_searches(dev):
+    """D <= 32 used to be ONE 32-deep stage per code tile of the general kernel, where nothing guaranteed that the start values of a
+    tile (copied by LDS-DMA two tiles ahead) had landed before they were read: a wave's 64 rows wrong in about 1 % of the searches
+    (tools/fuzz_search.py found it; fixed by padding such rows to 64 columns, i.e. two stages or the narrow-row kernel).  A timing
+    bug shows up only in repetition: 4 shapes x 12 seeds x 3 searches each on both filter kernels, every one against the exact path."""
+    from medtok_amd import ops
+    bad = []
+    for seed in range(12):
+        for (n, K, D, k, near, env) in ((4097, 20001, 32, 1, True, {}), (20000, 20001, 4, 1, False, dict(filter_splits=8, filter_xcd=True)),
+                                        (4097, 20001, 32, 5, True, dict(filter_rows64=False)), (4097, 8191, 16, 1, False, {})):
+            g = torch.Generator(device=dev).manual_seed(seed * 7 + D)
+            x = torch.randn(n, D, device=dev, generator=g); W = torch.randn(K, D, device=dev, generator=g)
+            if near:
+                x = x * 0.01 + W[torch.randint(0, K, (n,), device=dev, generator=g)]
+            xh, xs = ops.rownorm(x); wh, ws = ops.rownorm(W)
+            i0, d0 = ops.topk_search(xh, xs, wh, ws, k, ops.PATH_F32_MFMA)
+            for rep in range(3):
+                i1, d1 = ops.topk_search(xh, xs, wh, ws, k, _filter_path(**env))
+                if not (torch.equal(i0, i1) and torch.equal(d0, d1)):
+                    bad.append((seed, n, K, D, k, rep, int((i0 != i1).any(1).sum())))
+    assert not bad, bad

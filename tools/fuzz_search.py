@@ -3,7 +3,9 @@ bit-identical.  usage: python tools/fuzz_search.py [cases] [seed]"""
 import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch
-from medtok_amd import ops
+from medtok_amd import ops, _lib
+if os.environ.get('DBGLIB'):           # (a variant build of the library)
+    _lib.use_library(os.environ['DBGLIB'])
 dev = torch.device("cuda:0")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
