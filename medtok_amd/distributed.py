@@ -44,7 +44,15 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
                 raise RuntimeError(f"LOCAL_RANK={local} but only {n_dev} GPU(s) are visible: RCCL needs one GPU per rank "
                                    f"(oversubscribed launch or wrong LOCAL_RANK)")
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
+        kw = {}
+        if backend == "gloo":
+            # gloo picks its interface by resolving the machine's hostname, which a container may not be able to do (a rendezvous
+            # that then hangs until its default 30-minute timeout): on a loopback rendezvous bind to loopback, and give up early
+            if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=int(os.environ.get("MEDTOK_DIST_TIMEOUT_S", "300")))
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world, **kw)
     elif torch.cuda.is_available():
         local = local % max(torch.cuda.device_count(), 1)
     return rank, local, world
