@@ -1340,9 +1340,9 @@ __global__ __launch_bounds__(8 * RR) void rescore_kernel(
 // Searches of a few thousand rows (a serving batch; the four 4096-row searches of a forward) run the filter with up to 16 code
 // splits, i.e. up to 64 candidate lists per row with a handful of entries each, and the launch's time is one block's LATENCY: the
 // 8-lanes-per-row walk above visits its owners one dependent load after the other (count, then entry by entry: ~80 round trips
-// per lane and pass), and its chains miss on every step.  Here a wave owns a row: the 64 counts come with one load, an owner's
-// entries with one (lane = entry), eight owners in flight at a time; the lines of the survivors' code rows are all requested
-// before the first chain starts.  Same candidates, same exact chains, same (d, index) selection and fused assignment as
+// per lane and pass), and its chains miss on every step.  Here a wave owns a row: the 64 counts come with one load, the entries
+// with lane = owner, four entry indices in flight at a time; the lines of the survivors' code rows are all requested before the
+// first chain starts.  Same candidates, same exact chains, same (d, index) selection and fused assignment as
 // rescore_kernel: the same bits.  own_total, own_tail <= 64.
 template <int TOPK>
 __global__ __launch_bounds__(256) void rescore_wave_kernel(
@@ -1372,16 +1372,18 @@ __global__ __launch_bounds__(256) void rescore_wave_kernel(
     float tv[TOPK];
 #pragma unroll
     for (int j = 0; j < TOPK; ++j) tv[j] = INFINITY;
-    for (int o0 = 0; o0 < own_total; o0 += 8) {
-        float v[8];
+    // lane = owner, four entry indices per step: an owner's list is a handful of entries (a few dozen per row over all owners), so
+    // the walk is max(count) / 4 steps of four loads with most lanes busy -- not eight loads per eight owners with one or two
+    // lanes busy each (-10 us of ~120 at 4096 rows; which lane sees which entry changes neither t~ nor the (d, index) selection)
+    int m_max = m_mine;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int o = o0 + u;
-            const int m = o < own_total ? __builtin_amdgcn_readlane(m_mine, o < 64 ? o : 63) : 0;
-            v[u] = lane < m ? fmaf(__uint_as_float(rc[o * F_CAP + lane].x), -0x1p-15f, xn) : INFINITY;
-        }
+    for (int off = 32; off >= 1; off >>= 1) m_max = max(m_max, __shfl_xor(m_max, off, 64));
+    for (int e0 = 0; e0 < m_max; e0 += 4) {
+        float v[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) thr_insert<TOPK>(tv, v[u]);
+        for (int u = 0; u < 4; ++u) v[u] = e0 + u < m_mine ? fmaf(__uint_as_float(rc[lane * F_CAP + e0 + u].x), -0x1p-15f, xn) : INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) thr_insert<TOPK>(tv, v[u]);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -1397,18 +1399,17 @@ __global__ __launch_bounds__(256) void rescore_wave_kernel(
     const float lim = kth + win;
     // ---- phase 2a: entries with d~ <= t~ + 2 eps, compacted (ballot + prefix count: no atomics)
     int nsurv = 0;
-    for (int o0 = 0; o0 < own_total; o0 += 8) {
-        uint2 e[8];
-        bool pass[8];
+    for (int e0 = 0; e0 < m_max; e0 += 4) {
+        uint2 e[4];
+        bool pass[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int o = o0 + u;
-            const int m = o < own_total ? __builtin_amdgcn_readlane(m_mine, o < 64 ? o : 63) : 0;
-            e[u] = lane < m ? rc[o * F_CAP + lane] : make_uint2(0u, 0xffffffffu);
-            pass[u] = lane < m && fmaf(__uint_as_float(e[u].x), -0x1p-15f, xn) <= lim && e[u].y < (unsigned)k_codes;
+        for (int u = 0; u < 4; ++u) {
+            const bool have = e0 + u < m_mine;
+            e[u] = have ? rc[lane * F_CAP + e0 + u] : make_uint2(0u, 0xffffffffu);
+            pass[u] = have && fmaf(__uint_as_float(e[u].x), -0x1p-15f, xn) <= lim && e[u].y < (unsigned)k_codes;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass[u]);
             const int p = nsurv + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
             if (pass[u] && p < R_SURV) s_code[wv][p] = (int)e[u].y;
