@@ -38,3 +38,22 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+def run_with_retry(make_cmd, timeout=420, **kw):
+    """subprocess.run for the multi-process launches of the GPU tests (torch.distributed.run / bench.py --gpus 2, two ranks over gloo
+    on this box's one GPU): a legitimate run takes seconds, so a launch that has not returned after `timeout` seconds is a stuck
+    rendezvous of the environment (seen once: one box, one test, its whole 900-second limit) and is tried ONCE more on a fresh port.
+    make_cmd(port) -> argv.  Product-side, medtok_amd.distributed gives gloo a 300-second timeout of its own."""
+    import socket
+    import subprocess
+    last = None
+    for attempt in range(2):
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        try:
+            return subprocess.run(make_cmd(port), capture_output=True, text=True, timeout=timeout, **kw)
+        except subprocess.TimeoutExpired as exc:
+            last = exc
+    raise last

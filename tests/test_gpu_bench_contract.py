@@ -51,12 +51,11 @@ def test_two_rank_bench_on_one_gpu(dev, workload):
     """The N > 1 code paths of bench.py (barrier, max-over-ranks timing, the EMA all-reduce, the k-list all-gather) with two
     ranks sharing this box's GPU over gloo (MEDTOK_DIST_BACKEND: RCCL itself needs one GPU per rank)."""
     import os
-    import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    from conftest import run_with_retry
     env = dict(os.environ, MEDTOK_DIST_BACKEND="gloo")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--workload", workload, "--rows", "20000"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    out = run_with_retry(lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                       "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                       "--workload", workload, "--rows", "20000"], cwd=ROOT, env=env)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -72,8 +71,9 @@ def test_bench_gpus_2_starts_its_own_ranks(dev):
     env = dict(os.environ, MEDTOK_DIST_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "20000"],
-                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    from conftest import run_with_retry
+    out = run_with_retry(lambda port: [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "20000"],
+                         cwd=ROOT, env=env)              # (bench.py picks its own port; the argument is unused here)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout[-2000:]

@@ -20,14 +20,14 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "tests"))
 
 
-def run_ranks(mode, out_dir, *sizes, world=2, timeout=900):
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+def run_ranks(mode, out_dir, *sizes, world=2, timeout=420):
+    from conftest import run_with_retry
     env = dict(os.environ, MEDTOK_DIST_BACKEND="gloo")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "dist_worker.py"), mode, str(out_dir),
-                          *[str(v) for v in sizes]], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    out = run_with_retry(lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                                       "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "dist_worker.py"), mode, str(out_dir),
+                                       *[str(v) for v in sizes]], timeout=timeout, cwd=ROOT, env=env)
     assert out.returncode == 0, (out.stdout + out.stderr)[-4000:]
 
 
