@@ -618,6 +618,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float *__restrict
     const int l8 = threadIdx.x & (LPR - 1);
     const long pos = (long)blockIdx.x * RPB + (threadIdx.x / LPR);
     const long limit = row_list ? min(n, (long)*row_count) : n;
+    if ((long)blockIdx.x * RPB >= limit) return;         // (block-uniform: the redo of the rows the filter gave up on normally has none)
     const long row = min(pos, n - 1);                    // lanes past the end keep shuffling with their group, write nothing
     float bv[TOPK];
     int bi[TOPK];
