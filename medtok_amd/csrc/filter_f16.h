@@ -99,15 +99,23 @@ __global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ 
     }
 }
 
-// max of wsq[0..k) -> out[0] (single block; NaN propagates as +inf so the filter bails out)
-__global__ __launch_bounds__(1024) void wsq_max_kernel(const float *__restrict__ wsq, int k, float *__restrict__ out)
+// max of wsq[0..k) -> out[0] (single block; NaN propagates as +inf so the filter bails out).  The search's other two bits of
+// per-codebook preparation ride along (they were a launch and a memset of their own: ~10 us per search at serving sizes): wsqp (if
+// given) = the accumulator start values [k_pad], -2^15 |e|^2 (exact: a power-of-two scale), -inf beyond k so that padded codes never
+// pass; *zero_me (if given) = 0 (the count of rows handed to the exact kernel).
+__global__ __launch_bounds__(1024) void wsq_max_kernel(const float *__restrict__ wsq, int k, float *__restrict__ out,
+                                                       float *__restrict__ wsqp = nullptr, int k_pad = 0, int *__restrict__ zero_me = nullptr)
 {
     __shared__ float sh[1024];
     float m = 0.f;
     for (int i = threadIdx.x; i < k; i += 1024) {
         const float v = wsq[i];
         m = (v > m || !(v == v)) ? (v == v ? v : INFINITY) : m;
+        if (wsqp) wsqp[i] = v * -32768.0f;
     }
+    if (wsqp)
+        for (int i = k + threadIdx.x; i < k_pad; i += 1024) wsqp[i] = -INFINITY;
+    if (zero_me && threadIdx.x == 0) *zero_me = 0;
     sh[threadIdx.x] = m;
     __syncthreads();
     for (int off = 512; off >= 1; off >>= 1) {
