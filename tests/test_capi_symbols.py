@@ -49,3 +49,28 @@ def test_product_does_not_import_the_oracle():
     for p in (ROOT / "medtok_amd").rglob("*.py"):
         src = p.read_text()
         assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), f"{p} mentions the oracle"
+
+
+def test_header_macros_agree_with_the_python_binding():
+    """The bit layout of the `path` / `variant` arguments is written twice (include/medtok_vq.h and medtok_amd/_lib.py, ops.py):
+    the two must say the same thing.  Host-only: the workspace query decodes the plan bits (a search with more code splits needs
+    more candidate lists, i.e. more workspace; rows of <= 32 elements are padded to 64 columns on either filter kernel)."""
+    from medtok_amd import _lib, ops
+    text = (ROOT / "include" / "medtok_vq.h").read_text()
+    macro = lambda name: re.search(r"#define\s+" + name + r"(?:\([^)]*\))?\s+(.+?)\s*(?:/\*|$)", text, re.M).group(1)
+    assert int(macro("MEDTOK_PATH_MASK"), 0) == 0xF
+    assert int(macro("MEDTOK_ATTENTION_F32_KEYS"), 0) == ops.ATTENTION_F32_KEYS
+    for m in re.finditer(r"#define\s+MEDTOK_PATH_(AUTO|F32_MFMA|F16_FILTER)\s+(\d+)", text):
+        assert getattr(_lib, "PATH_" + m.group(1)) == int(m.group(2))
+    ev = lambda name, arg: eval(macro(name).replace("(s)", f"({arg})").replace("(on)", f"({arg})").replace("?", " and ").replace(":", " or "))  # noqa: S307
+    assert _lib.plan_path(_lib.PATH_F16_FILTER, filter_splits=5) == _lib.PATH_F16_FILTER | ev("MEDTOK_PLAN_FILTER_SPLITS", 5)
+    assert _lib.plan_path(0, filter_xcd=True) == ev("MEDTOK_PLAN_FILTER_XCD", 1) and _lib.plan_path(0, filter_xcd=False) == ev("MEDTOK_PLAN_FILTER_XCD", 0)
+    assert _lib.plan_path(0, filter_tail=True) == ev("MEDTOK_PLAN_FILTER_TAIL", 1) and _lib.plan_path(0, filter_tail=False) == ev("MEDTOK_PLAN_FILTER_TAIL", 0)
+    assert _lib.plan_path(0, search_max_splits=7) == ev("MEDTOK_PLAN_SEARCH_MAX_SPLITS", 7)
+    assert _lib.plan_path(0, filter_rows64=True) == ev("MEDTOK_PLAN_FILTER_ROWS64", 1) and _lib.plan_path(0, filter_rows64=False) == ev("MEDTOK_PLAN_FILTER_ROWS64", 0)
+    lib = _lib.load()
+    ws = lambda n, k, d, path: lib.medtok_search_workspace_bytes(n, k, d, 5, path)
+    f = _lib.PATH_F16_FILTER
+    assert ws(100000, 8192, 768, _lib.plan_path(f, filter_splits=4)) > ws(100000, 8192, 768, _lib.plan_path(f, filter_splits=1))
+    assert ws(100000, 8192, 64, _lib.plan_path(f, filter_rows64=True, filter_splits=2)) == ws(100000, 8192, 64, _lib.plan_path(f, filter_rows64=False, filter_splits=2))
+    assert ws(100000, 8192, 16, _lib.plan_path(f, filter_splits=2)) == ws(100000, 8192, 64, _lib.plan_path(f, filter_splits=2))      # D <= 32: 64 columns
