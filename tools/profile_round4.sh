@@ -33,7 +33,7 @@ for w in fullref full; do
   rm -rf $out/tr_$w
 done
 # PMC traffic, its own passes (no --stats, no trace domains besides the kernel trace)
-for w in cfg3 full; do
+for w in cfg3 full refdefault; do
   extra=""; [ $w = full ] && extra="--one-stream --no-one-stream-pass --no-half-text-pass"
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${w}_$c -o p -- python3 bench.py --workload $w --steps 1 --warmup 1 --cpu-rows 0 --exact-steps 0 $extra > $out/pmc_${w}_$c.log 2>&1
@@ -49,5 +49,5 @@ for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_AN
   [ -n "$f" ] && cp "$f" $out/pmcm_full_$c.csv
   rm -rf $out/pmcm_$c
 done
-python3 tools/pmc_summary.py $out cfg3 full > $out/pmc_summary.txt 2>&1
+python3 tools/pmc_summary.py $out cfg3 full refdefault > $out/pmc_summary.txt 2>&1
 ls -la $out | head -60; cat $out/pmc_summary.txt | head -60
