@@ -182,7 +182,8 @@ __device__ __forceinline__ void lds_store_list(unsigned addr, const float (&c)[5
     f32x4 q = {c[0], c[1], c[2], c[3]};
     // (s_nop: a VALU write to the data registers of a 128-bit LDS store needs two wait states on gfx950; hipcc counts them for its own
     // stores only)
-    asm volatile("ds_write_b128 %0, %1\n\tds_write_b32 %0, %2 offset:16\n\ts_nop 0" ::"v"(addr), "v"(q), "v"(c[4]) : "memory");
+    // (leading s_nop: the same hazard in the other direction -- the instruction in front may be the asm v_min / v_max that wrote q)
+    asm volatile("s_nop 0\n\tds_write_b128 %0, %1\n\tds_write_b32 %0, %2 offset:16\n\ts_nop 0" ::"v"(addr), "v"(q), "v"(c[4]) : "memory");
 }
 // The other code-side wave's lists of both rows: four reads issued early (they may be a few stages stale anyway), waited for
 // where the values are needed.  Between the two statements the destination registers belong to the hardware: the wait
