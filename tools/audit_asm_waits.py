@@ -10,7 +10,8 @@ Linear scan per kernel in layout order: registers written by an asm ds_read are 
 compiler-inserted); any compiler instruction that names a pending register is reported.
 Second check: a VALU write to the data registers of a 96/128-bit LDS store needs two wait states on gfx950, which hipcc counts for
 its own stores only (found as lanes 8-15, 24-31, ... storing the next quad's .xy): every asm ds_write_b96/b128 is followed for
-two wait states and a VALU instruction that writes its data registers inside them is reported."""
+two wait states and a VALU instruction that writes its data registers inside them is reported; so is a VALU write to those
+registers by the instruction directly in front of the store (one wait state in that direction)."""
 import re, subprocess, sys, tempfile
 from pathlib import Path
 
@@ -76,6 +77,13 @@ def audit(asm_text):
                 if op.startswith("v_") and regs_of(nxt[len(op):].split(",")[0].strip()) & data:
                     issues.append(b + "   <-   " + nxt)
                 states += 1
+            # the other direction: the instruction right in front of the store must not be a VALU write to its data registers
+            # (one wait state; every wide LDS store of this library is an asm statement, so all of them are checked)
+            if n > 0:
+                prv = body[n - 1]
+                op = prv.split()[0]
+                if op.startswith("v_") and not op.startswith("v_cmp") and regs_of(prv[len(op):].split(",")[0].strip()) & data:
+                    issues.append(prv + "   ->   " + b)
         if issues:
             total += len(issues)
             print(k[:90], len(issues))
