@@ -140,9 +140,9 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
                 ll[e] = (_Float16)(f[e] - (float)hh[e]);
             }
             const u32x4 hv = __builtin_bit_cast(u32x4, hh), lv = __builtin_bit_cast(u32x4, ll);
-            // (s_nop: a wide LDS store whose data a VALU instruction wrote just before it needs a wait state, which hipcc counts for its
-            // own stores only)
-            asm volatile("s_nop 0\n\tds_write_b128 %0, %1 offset:%3\n\tds_write_b128 %0, %2 offset:%4"
+            // (s_nop: a wide LDS store needs a wait state behind a VALU write to its data registers and two in front of the next one,
+            // which hipcc counts for its own stores only: tools/audit_asm_waits.py checks every asm store of the library)
+            asm volatile("s_nop 0\n\tds_write_b128 %0, %1 offset:%3\n\tds_write_b128 %0, %2 offset:%4\n\ts_nop 1"
                          : : "v"(a0), "v"(hv), "v"(lv), "i"(pp * PIECE), "i"(PLANEB + pp * PIECE) : "memory");
         }
     };

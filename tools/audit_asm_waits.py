@@ -28,10 +28,12 @@ def regs_of(tok):
 
 def audit(asm_text):
     total = 0
-    for k in re.findall(r"^(_Z[\w]+):\n", asm_text, re.M):
-        i = asm_text.find(k + ":\n")
+    for k in re.findall(r"^(_Z[\w]+):[^\n]*\n", asm_text, re.M):      # (the label line may carry a comment)
+        i = asm_text.find("\n" + k + ":") + 1
         j = asm_text.find("s_endpgm", i)
         pending, in_asm, issues = set(), False, []
+        dead_end = False                                 # the last instruction was an unconditional branch: the next label starts afresh
+        body = []                                        # (instruction, inside an asm statement) in layout order, for the store checks
         for ln in asm_text[i:j].split("\n"):
             t = ln.strip()
             if t.startswith(";;#ASMSTART"):
@@ -40,9 +42,14 @@ def audit(asm_text):
             if t.startswith(";;#ASMEND"):
                 in_asm = False
                 continue
+            if t.endswith(":") and dead_end:             # a block only reached by jumps: what was pending on the fall-through path is not here
+                pending.clear()
+                body.append(("s_nop 15", False))         # (and the store checks do not look across it)
             if not t or t[0] in ";." or t.endswith(":"):
                 continue
             op = t.split()[0]
+            dead_end = op == "s_branch"
+            body.append((t, in_asm))
             args = [a.strip() for a in t[len(op):].split(",")]
             if in_asm:
                 if op.startswith("ds_read"):
@@ -59,15 +66,14 @@ def audit(asm_text):
                     used |= regs_of(tok)
             if pending & used:
                 issues.append(t)
-        # wide LDS stores from asm: two wait states before a VALU write to their data registers
-        body = [ln.strip() for ln in asm_text[i:j].split("\n")]
-        body = [b for b in body if b and b[0] not in ";." and not b.endswith(":")]
-        for n, b in enumerate(body):
-            if not (b.startswith("ds_write_b128") or b.startswith("ds_write_b96")):
+        # wide LDS stores FROM ASM STATEMENTS (hipcc looks after its own): two wait states before a VALU write to their data
+        # registers, one behind a VALU write to them
+        for n, (b, b_asm) in enumerate(body):
+            if not b_asm or not (b.startswith("ds_write_b128") or b.startswith("ds_write_b96")):
                 continue
             data = regs_of(b.split(",")[1].strip().split()[0]) if "," in b else set()
             states = 0
-            for nxt in body[n + 1:n + 4]:
+            for nxt, _ in body[n + 1:n + 4]:
                 if states >= 2:
                     break
                 op = nxt.split()[0]
@@ -77,10 +83,8 @@ def audit(asm_text):
                 if op.startswith("v_") and regs_of(nxt[len(op):].split(",")[0].strip()) & data:
                     issues.append(b + "   <-   " + nxt)
                 states += 1
-            # the other direction: the instruction right in front of the store must not be a VALU write to its data registers
-            # (one wait state; every wide LDS store of this library is an asm statement, so all of them are checked)
             if n > 0:
-                prv = body[n - 1]
+                prv = body[n - 1][0]
                 op = prv.split()[0]
                 if op.startswith("v_") and not op.startswith("v_cmp") and regs_of(prv[len(op):].split(",")[0].strip()) & data:
                     issues.append(prv + "   ->   " + b)
@@ -88,6 +92,51 @@ def audit(asm_text):
             total += len(issues)
             print(k[:90], len(issues))
             for x in issues[:8]:
+                print("      ", x)
+    return total
+
+
+def audit_mfma_asm_readers(asm_text):
+    """Third check: an XDL (MFMA) result needs passes + 2 wait states before a VALU instruction may read it; hipcc's hazard recognizer
+    counts them for its own VALU instructions, not for inline-asm readers (found as limits computed from half-finished sums in
+    filter_rows64_kernel).  Per kernel, in layout order: behind every v_mfma its destination registers are 'cooking' for passes + 2
+    wait states (16 passes for 32x32x16, 8 for 16x16x32; an instruction is one wait state, s_nop N is N + 1); an instruction INSIDE
+    an asm statement that reads a cooking register (other than another MFMA: those interlock) is reported."""
+    total = 0
+    for k in re.findall(r"^(_Z[\w]+):[^\n]*\n", asm_text, re.M):      # (the label line may carry a comment)
+        i = asm_text.find("\n" + k + ":") + 1
+        j = asm_text.find("s_endpgm", i)
+        cooking, in_asm, issues = [], False, []          # [registers, wait states left]
+        for ln in asm_text[i:j].split("\n"):
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not t or t[0] in ";." or t.endswith(":"):
+                continue
+            op = t.split()[0]
+            args = [a.strip() for a in t[len(op):].split(",")]
+            states = (int(args[0]) + 1) if op == "s_nop" else 1
+            if in_asm and op.startswith("v_") and not op.startswith("v_mfma"):
+                used = set()
+                for a in args[1:]:
+                    for tok in re.findall(r"v\[\d+:\d+\]|v\d+", a):
+                        used |= regs_of(tok)
+                for regs, left in cooking:
+                    if left > 0 and regs & used:
+                        issues.append(f"{t}   (an MFMA result with {left} wait states to go)")
+                        break
+            cooking = [(r, left - states) for r, left in cooking if left - states > 0]
+            if op.startswith("v_mfma"):
+                passes = 16 if "32x32" in op else 8
+                cooking.append((regs_of(args[0]), passes + 2))
+        if issues:
+            total += len(issues)
+            print(k[:90], len(issues))
+            for x in issues[:6]:
                 print("      ", x)
     return total
 
@@ -101,6 +150,9 @@ if __name__ == "__main__":
             subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
                                    "-o", str(out), str(ROOT / "medtok_amd" / "csrc" / "medtok_vq.hip")])
             text = out.read_text()
+    print("kernels scanned:", len(re.findall(r"^(_Z[\w]+):[^\n]*\n", text, re.M)))
     n = audit(text)
     print("uses of an asm ds_read's destination before a wait / VALU writes into a wide asm LDS store's data within two wait states:", n)
-    sys.exit(1 if n else 0)
+    m = audit_mfma_asm_readers(text)
+    print("asm VALU readers of an MFMA result inside its wait states:", m)
+    sys.exit(1 if n or m else 0)
