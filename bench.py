@@ -60,6 +60,7 @@ def parse():
                          "the VQ side alone (text mapping, cross-attention, 6 searches, loss.py, backward, clip, AdamW)")
     ap.add_argument("--no-half-text-pass", action="store_true",
                     help="full workload: skip the extra pass with fp16 text features (what a caller under fp16 autocast hands over)")
+    ap.add_argument("--no-clock-probe", action="store_true", help="do not run the shader-clock probe beside the timed region")
     ap.add_argument("--no-one-stream-pass", action="store_true",
                     help="full workload: skip the second, one-stream pass that times the kernels for the roofline object (timeline captures)")
     return ap.parse_args()
@@ -618,20 +619,36 @@ def main():
         rows = args.rows or {"cfg3": 600000, "full": 4096, "refdefault": 600000, "fullref": 256}.get(args.workload, 100000)
         wl = {"cfg3": Cfg3, "full": Full, "refdefault": RefDefault, "fullref": FullRefDefault}.get(args.workload, Cfg2)(rows, dev, seed=rank, path=args.path)
 
+    tw = time.perf_counter()
     for _ in range(args.warmup):
         wl.step()
     torch.cuda.synchronize(dev)
+    warm_s = (time.perf_counter() - tw) / max(args.warmup, 1)
+    # The shader clock of the timed region (the chip clocks to its power budget, and boxes differ): one idle wavefront per XCD on a
+    # stream of its own counts shader cycles against the 100 MHz counter from here to the end of the K steps.  Only where the
+    # measured work runs on ONE stream (a probe stream that lands on a hardware queue of a side stream would serialise with it);
+    # the `full` workload takes it in its one-stream pass below.
+    single_stream = args.workload not in ("full", "fullref") or args.one_stream
+    probe = None
+    if single_stream and not args.no_clock_probe:
+        probe = ops.ClockProbe(dev, max_seconds=(3.0 * warm_s * args.steps + 5.0) if args.warmup else 120.0)
     mdist.barrier()
     torch.cuda.synchronize(dev)
     ops.profile_begin()                  # library brackets each search-kernel launch with HIP events on its stream
+    if probe is not None:
+        probe.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
+    if probe is not None:
+        torch.cuda.current_stream(dev).synchronize()      # the K steps are done (one stream); the probe ends with them, in front of
+        probe.__exit__(None, None, None)                  # the device-wide synchronize (which would otherwise wait for the probe's cap)
     torch.cuda.synchronize(dev)
     mdist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dev)
     prof = ops.profile_end()
+    clock = probe.result() if probe is not None else None
     prof_note = None
     one_stream_elapsed = None
     if args.workload in ("full", "fullref") and not args.no_one_stream_pass and not args.one_stream:
@@ -645,9 +662,16 @@ def main():
             wl.step()
             torch.cuda.synchronize(dev)
             ops.profile_begin()
+            probe1 = None if args.no_clock_probe else ops.ClockProbe(dev, max_seconds=3.0 * warm_s * args.steps + 5.0)
+            if probe1 is not None:
+                probe1.__enter__()
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 wl.step()
+            if probe1 is not None:
+                torch.cuda.current_stream(dev).synchronize()
+                probe1.__exit__(None, None, None)
+                clock = dict(probe1.result(), region="the one-stream pass")
             torch.cuda.synchronize(dev)
             one_stream_elapsed = time.perf_counter() - t1
             prof = ops.profile_end()
@@ -787,6 +811,9 @@ def main():
                                                "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)}
                                            for k, v in prof.items() if k != kname and v["launches"]}},
             "exact_fp32_path": exact,
+            # shader clock DURING the timed region (ops.ClockProbe): separates the box (its power budget / silicon) from the code when
+            # two lines differ by a few per cent; the dense-MFMA peaks above are quoted at 2.4 GHz
+            "clock": clock,
         }
         if strong is not None:
             line["extra"] = {"strong_scaling": strong}

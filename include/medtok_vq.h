@@ -72,6 +72,13 @@ int medtok_profile_begin(void);
 int medtok_profile_end(double ms[MEDTOK_PROFILE_KINDS], double flops[MEDTOK_PROFILE_KINDS],
                        int launches[MEDTOK_PROFILE_KINDS]);
 
+/* Shader-clock probe for bench.py: one idle wavefront on each of 8 blocks (one per XCD on the full chip) samples the shader-cycle
+ * counter and the constant 100 MHz counter from launch until *stop_flag (a word of PINNED HOST memory the device polls) becomes
+ * non-zero, or max_ticks_100mhz ticks have passed, whichever is first; out = uint64 [8][4] (device memory): shader cycles, 100 MHz
+ * ticks, XCC id, polls.  Launch on a stream of its own that shares no hardware queue with the measured work.  No reference
+ * counterpart: measurement infrastructure (the chip clocks to its power budget; a bench line should say at which clock it ran). */
+int medtok_debug_clock_probe(const int *stop_flag, uint64_t max_ticks_100mhz, uint64_t *out, void *stream);
+
 /* F.normalize(x, p=2, dim=-1, eps=1e-12) and the squared norm of the result.
  * Replaces vector_quantization_soft_one_new.py:148,150-151,196,198,200 and
  * norm_ema_quantizer.py:8-9,170 plus the two torch.sum(..**2) terms of

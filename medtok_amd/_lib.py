@@ -51,6 +51,7 @@ SIGNATURES = {
     "medtok_last_error": (C.c_char_p, []),
     "medtok_profile_begin": (_int, []),
     "medtok_profile_end": (_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "medtok_debug_clock_probe": (_int, [_vp, C.c_uint64, _vp, _vp]),
     "medtok_rownorm_f32": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
     "medtok_search_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int]),
     "medtok_topk_search_f32": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _int, _vp]),

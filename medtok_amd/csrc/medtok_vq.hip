@@ -115,6 +115,40 @@ extern "C" int medtok_profile_end(double *ms, double *flops, int *launches)
     return 0;
 }
 
+// ---------------------------------------------------------------- shader-clock probe (bench.py)
+// The chip clocks to its power budget: a fp16-MFMA-bound kernel sags to ~1.7 of 2.4 GHz, and how far differs from box to box by a few
+// per cent -- as much as a round's kernel work moves the headline.  One idle wavefront per XCD (blocks 0..7 go round-robin to the 8
+// XCDs) reads the shader-cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) when it starts and when the host
+// raises `stop` (a word of pinned host memory, polled every ~20 us between s_sleeps; `max_ticks` of the 100 MHz counter bound the
+// wait whatever happens to the flag), so that a bench line can state the clock its timed region ran at.  Launch it on a stream of its
+// own, NOT one the measured work uses (streams that share a hardware queue serialise).  out: uint64 [8][4] = shader cycles, 100 MHz
+// ticks, XCC id, polls.
+__global__ __launch_bounds__(64) void clock_probe_kernel(const int *stop, unsigned long long max_ticks, unsigned long long *__restrict__ out)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long polls = 0, c1 = c0, r1 = r0;
+    for (;;) {
+        for (int i = 0; i < 16; ++i) __builtin_amdgcn_s_sleep(127);
+        c1 = __builtin_amdgcn_s_memtime();
+        r1 = __builtin_amdgcn_s_memrealtime();
+        ++polls;
+        if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || r1 - r0 >= max_ticks) break;
+    }
+    unsigned long long *o = out + (size_t)blockIdx.x * 4;
+    o[0] = c1 - c0; o[1] = r1 - r0;
+    o[2] = (unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xf);       // HW_REG_XCC_ID[3:0]
+    o[3] = polls;
+}
+
+extern "C" int medtok_debug_clock_probe(const int *stop_flag, uint64_t max_ticks_100mhz, uint64_t *out, void *stream)
+{
+    if (!stop_flag || !out) return fail("clock_probe: NULL argument");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(8), dim3(64), 0, (hipStream_t)stream, stop_flag, (unsigned long long)max_ticks_100mhz,
+                       (unsigned long long *)out);
+    return check_launch("clock_probe");
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of the launch: set it once per instantiation
 // (and device), not before every launch.
 template <auto Kernel>
@@ -1666,17 +1700,16 @@ extern "C" int medtok_pack_codes(const void *mask, int mask_elem_bytes, int64_t 
     hipStream_t s = (hipStream_t)stream;
     const size_t seg = align_up((size_t)n_codes * 4, 256);
     int *counts32 = (int *)ws, *order = (int *)((char *)ws + seg), *stats32 = (int *)((char *)ws + 2 * seg);
-    if (hipMemsetAsync(counts32, 0, seg, s) != hipSuccess) return fail("pack_codes: memset failed");
-    const int init[4] = {0, 0x7fffffff, -0x7fffffff, 0};
-    if (hipMemcpyAsync(stats32, init, sizeof init, hipMemcpyHostToDevice, s) != hipSuccess) return fail("pack_codes: stats init failed");
     const unsigned mgrid = (unsigned)((n_codes + 3) / 4);
-    if (mask_elem_bytes == 1) hipLaunchKernelGGL(pack_mask_len_kernel<uint8_t>, dim3(mgrid), dim3(256), 0, s, (const uint8_t *)mask, (long)n_codes, (long)seq_len, valid_len);
-    else if (mask_elem_bytes == 4) hipLaunchKernelGGL(pack_mask_len_kernel<int32_t>, dim3(mgrid), dim3(256), 0, s, (const int32_t *)mask, (long)n_codes, (long)seq_len, valid_len);
-    else hipLaunchKernelGGL(pack_mask_len_kernel<int64_t>, dim3(mgrid), dim3(256), 0, s, (const int64_t *)mask, (long)n_codes, (long)seq_len, valid_len);
+    if (mask_elem_bytes == 1) hipLaunchKernelGGL(pack_mask_len_kernel<uint8_t>, dim3(mgrid), dim3(256), 0, s, (const uint8_t *)mask, (long)n_codes, (long)seq_len, valid_len, counts32, stats32);
+    else if (mask_elem_bytes == 4) hipLaunchKernelGGL(pack_mask_len_kernel<int32_t>, dim3(mgrid), dim3(256), 0, s, (const int32_t *)mask, (long)n_codes, (long)seq_len, valid_len, counts32, stats32);
+    else hipLaunchKernelGGL(pack_mask_len_kernel<int64_t>, dim3(mgrid), dim3(256), 0, s, (const int64_t *)mask, (long)n_codes, (long)seq_len, valid_len, counts32, stats32);
     if (n_nodes > 0)
         hipLaunchKernelGGL(pack_count_kernel, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, s, batch, (long)n_nodes, (long)n_codes, counts32, stats32);
-    const bool sort = lpt && seq_len < PACK_MAX_KEYS;
-    hipLaunchKernelGGL(pack_lists_kernel, dim3(1), dim3(PACK_THREADS), sort ? (size_t)(seq_len + 2) * 4 : 0, s, counts32, stats32, valid_len, (long)n_codes,
+    const bool sort = lpt && seq_len < PACK_MAX_KEYS && n_codes <= PACK_SORT_MAX_CODES;
+    size_t pw = 1;
+    while ((int64_t)pw < n_codes) pw <<= 1;
+    hipLaunchKernelGGL(pack_lists_kernel, dim3(1), dim3(PACK_THREADS), sort ? pw * 4 : 0, s, counts32, stats32, valid_len, (long)n_codes,
                        (long)seq_len, heads, lpt, order, counts, starts, t_start, t_len, g_start, g_len, tok_start, g_kv_len, stats);
     return check_launch("pack_codes");
 }

@@ -7,13 +7,19 @@
 //   pack_mask_len_kernel   valid_len[b] = number of non-zero entries of mask row b           one wavefront per row
 //   pack_count_kernel      counts[b] = nodes whose batch id is b (integer atomics: exact); id range; is `batch` sorted?
 //   pack_lists_kernel      ONE block: starts = exclusive scan of counts, the largest count, the codes ordered longest key set
-//                          first (counting sort by valid_len; blocks of the attention launch are taken in list order and a block's
-//                          time is its key count), and the (start, length) lists of both attention sides.
+//                          first (ties in code order: a stable, run-to-run identical list; blocks of the attention launch are
+//                          taken in list order and a block's time is its key count), and the (start, length) lists of both sides.
 #pragma once
 
+// (also the first launch of the three: it zeroes the node counts and sets the id-range statistics to their start values -- a
+// hipMemsetAsync and a host-to-device copy of four ints before; the copy, from the caller's stack, could not be captured into a graph)
 template <typename M>
-__global__ __launch_bounds__(256) void pack_mask_len_kernel(const M *__restrict__ mask, long n_codes, long seq_len, int64_t *__restrict__ valid_len)
+__global__ __launch_bounds__(256) void pack_mask_len_kernel(const M *__restrict__ mask, long n_codes, long seq_len, int64_t *__restrict__ valid_len,
+                                                            int *__restrict__ counts32, int *__restrict__ stats32)
 {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    for (long c = gid; c < n_codes; c += (long)gridDim.x * 256) counts32[c] = 0;
+    if (gid < 4) stats32[gid] = gid == 1 ? 0x7fffffff : (gid == 2 ? -0x7fffffff : 0);
     const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= n_codes) return;
     const int lane = threadIdx.x & 63;
@@ -54,6 +60,7 @@ __global__ __launch_bounds__(256) void pack_count_kernel(const int64_t *__restri
 
 constexpr int PACK_THREADS = 1024;
 constexpr int PACK_MAX_KEYS = 8192;        // longest key set the longest-first order is computed for (beyond: list order = code order)
+constexpr int PACK_SORT_MAX_CODES = 8192;  // ... and the largest batch (a bitonic sort of one 32-bit key per code in LDS; beyond: code order)
 
 __global__ __launch_bounds__(PACK_THREADS) void pack_lists_kernel(
     const int *__restrict__ counts32, const int *__restrict__ stats32, const int64_t *__restrict__ valid_len, long n_codes, long seq_len, int heads, int lpt,
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_lists_kernel(
     __shared__ long s_wave[PACK_THREADS / 64];
     __shared__ long s_carry;
     __shared__ int s_max;
-    extern __shared__ int s_hist[];                // [seq_len + 2] when lpt
+    extern __shared__ unsigned s_key[];            // [next power of two >= n_codes] when the list is ordered
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) { s_carry = 0; s_max = 0; }
     __syncthreads();
@@ -94,25 +101,33 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_lists_kernel(
         __syncthreads();
     }
     atomicMax(&s_max, my_max);
-    // ---- the list order: longest key set first (counting sort over the key counts), or code order
-    const bool sort = lpt && seq_len < PACK_MAX_KEYS;
+    // ---- the list order: longest key set first, codes of equal length in code order (a bitonic sort of (seq_len - length, code)
+    // keys: the SAME list on every run and rank -- the counting sort of round 4 placed equal-length codes by atomicAdd, i.e. in an
+    // order that changed from run to run: same outputs, but different block-to-code assignments, timings and profiles), or code order.
+    // valid_len counts the NON-ZERO mask entries of a row; the reference takes mask.sum() (:135): the same for 0/1 masks.
+    const bool sort = lpt && seq_len < PACK_MAX_KEYS && n_codes <= PACK_SORT_MAX_CODES;
     if (sort) {
-        for (long i = tid; i < seq_len + 2; i += PACK_THREADS) s_hist[i] = 0;
-        __syncthreads();
-        for (long c = tid; c < n_codes; c += PACK_THREADS) {
-            const long len = valid_len[c];
-            atomicAdd(&s_hist[len < 0 ? 0 : (len > seq_len ? seq_len : len)], 1);
+        long pw = 1;
+        while (pw < n_codes) pw <<= 1;
+        for (long i = tid; i < pw; i += PACK_THREADS) {
+            unsigned key = 0xffffffffu;
+            if (i < n_codes) {
+                const long len = valid_len[i];
+                key = (unsigned)(seq_len - (len < 0 ? 0 : (len > seq_len ? seq_len : len))) * (unsigned)PACK_SORT_MAX_CODES + (unsigned)i;
+            }
+            s_key[i] = key;
         }
         __syncthreads();
-        if (tid == 0) {                            // descending offsets: bucket seq_len first
-            int run = 0;
-            for (long len = seq_len; len >= 0; --len) { const int h = s_hist[len]; s_hist[len] = run; run += h; }
-        }
-        __syncthreads();
-        for (long c = tid; c < n_codes; c += PACK_THREADS) {
-            const long len = valid_len[c];
-            order[atomicAdd(&s_hist[len < 0 ? 0 : (len > seq_len ? seq_len : len)], 1)] = (int)c;
-        }
+        for (long k = 2; k <= pw; k <<= 1)
+            for (long j = k >> 1; j > 0; j >>= 1) {
+                for (long t = tid; t < pw / 2; t += PACK_THREADS) {
+                    const long i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;       // the pair (i, i + j), i without bit j
+                    const unsigned a = s_key[i], b = s_key[p];
+                    if ((a > b) == ((i & k) == 0)) { s_key[i] = b; s_key[p] = a; }
+                }
+                __syncthreads();
+            }
+        for (long i = tid; i < n_codes; i += PACK_THREADS) order[i] = (int)(s_key[i] % (unsigned)PACK_SORT_MAX_CODES);
     }
     __threadfence_block();
     __syncthreads();

@@ -50,9 +50,19 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
             # that then hangs until its default 30-minute timeout): on a loopback rendezvous bind to loopback, and give up early
             if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
                 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            # ... and give up EARLY on a rendezvous that never completes (300 s, not torch's 30 minutes) -- the rendezvous only: see below
             import datetime
             kw["timeout"] = datetime.timedelta(seconds=int(os.environ.get("MEDTOK_DIST_TIMEOUT_S", "300")))
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world, **kw)
+        if "timeout" in kw:
+            # The timeout handed to init_process_group also bounds every later collective and barrier, and a rank may legitimately
+            # work alone for longer than 300 s (rank 0 sorting and writing the inference table while the others wait at the barrier,
+            # a k-means init, a checkpoint write): once the group stands, collectives get torch's default back.
+            dist.barrier()
+            try:
+                dist.distributed_c10d._set_pg_timeout(dist.distributed_c10d.default_pg_timeout)
+            except Exception:           # (a private hook: without it the short timeout simply stays, as before)
+                pass
     elif torch.cuda.is_available():
         local = local % max(torch.cuda.device_count(), 1)
     return rank, local, world

@@ -71,20 +71,52 @@ def run_inference(model: MultimodalTokenizer, batches: Iterable, out_dir: Option
     model.eval()
     embs, toks, wts, order = [], [], [], []
 
-    def to_host(t):
-        if not t.is_cuda:
-            return t
-        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        host.copy_(t, non_blocking=True)
-        return host
+    # Results leave the GPU batch by batch through TWO reusable pinned staging buffers per output (an event per buffer: the copy of
+    # batch i overlaps the forward of batch i + 1) into pageable host tensors -- not one freshly page-locked tensor per output and
+    # batch, all kept to the end (at 600k codes x 3072 floats that was 7+ GB of pinned memory and one hipHostMalloc per tensor).
+    class _Stage:
+        def __init__(self):
+            self.buf, self.event, self.pending = [None, None], [None, None], [None, None]
+            self.turn = 0
+
+        def drain(self, i, sink):
+            if self.pending[i] is not None:
+                self.event[i].synchronize()
+                shape, n = self.pending[i]
+                sink.append(self.buf[i][:n].view(shape).clone())
+                self.pending[i] = None
+
+        def push(self, t, sink):
+            if not t.is_cuda:
+                sink.append(t)
+                return
+            i = self.turn
+            self.turn ^= 1
+            self.drain(i, sink)                      # the copy issued two batches ago from this buffer
+            n = t.numel()
+            if self.buf[i] is None or self.buf[i].numel() < n or self.buf[i].dtype != t.dtype:
+                self.buf[i] = torch.empty(max(n, 1), dtype=t.dtype, pin_memory=True)
+                self.event[i] = torch.cuda.Event()
+            self.buf[i][:n].view(t.shape).copy_(t, non_blocking=True)
+            self.event[i].record(torch.cuda.current_stream(t.device))
+            self.pending[i] = (tuple(t.shape), n)
+
+        def flush(self, sink):
+            for i in (self.turn, self.turn ^ 1):     # oldest first: batch order is kept
+                self.drain(i, sink)
+    stages = (_Stage(), _Stage(), _Stage())
     dev = device
     for x in batches:
+        # (the code indices are taken BEFORE x.to(device): afterwards this would be a blocking device-to-host copy per batch)
+        order.append(torch.as_tensor(x.code_indices).reshape(-1).to("cpu", torch.int64))
         if device is not None and hasattr(x, "to"):
             x = x.to(device)
         e, t, w = model(x)
         dev = e.device
-        embs.append(to_host(e)); toks.append(to_host(t)); wts.append(to_host(w))
-        order.append(torch.as_tensor(x.code_indices).reshape(-1).to("cpu", torch.int64))
+        for st, val, sink in zip(stages, (e, t, w), (embs, toks, wts)):
+            st.push(val, sink)
+    for st, sink in zip(stages, (embs, toks, wts)):
+        st.flush(sink)
     multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
     if dev is None:
         dev = next(model.parameters()).device
@@ -94,8 +126,6 @@ def run_inference(model: MultimodalTokenizer, batches: Iterable, out_dir: Option
         k, e_dim = model.quantize.k, model.quantize.e_dim
         embs, toks = [torch.zeros(0, 4 * e_dim)], [torch.zeros(0, 4, k, dtype=torch.int64)]
         wts, order = [torch.zeros(0, 4, k)], [torch.zeros(0, dtype=torch.int64)]
-    if torch.device(dev).type == "cuda":
-        torch.cuda.synchronize(dev)                  # the pinned copies above
     emb, tok, wt, order = torch.cat(embs), torch.cat(toks), torch.cat(wts), torch.cat(order)
     if multi:
         emb, tok, wt, order = (mdist.gather_ragged_to_rank0(t, dev) for t in (emb, tok, wt, order))

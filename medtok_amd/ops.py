@@ -35,6 +35,39 @@ def profile_end() -> dict:
 MedTokLibraryError = _lib.MedTokLibraryError
 
 
+class ClockProbe:
+    """Shader clock of a timed region (bench.py): `with ClockProbe(device, max_seconds) as p: ...timed work on OTHER streams...`;
+    afterwards p.result() = dict(ghz_mean, ghz_min, ghz_max, per_xcd).  One idle wavefront per XCD on a stream of its own; it ends
+    when the context exits (a pinned host flag) or after max_seconds, whichever is first."""
+
+    def __init__(self, device, max_seconds: float = 30.0):
+        self.device = torch.device(device)
+        self.max_ticks = int(max_seconds * 1e8)
+        self.flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.out = torch.zeros((8, 4), dtype=torch.int64, device=self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def __enter__(self):
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().medtok_debug_clock_probe(self.flag.data_ptr(), self.max_ticks, self.out.data_ptr(), self.stream.cuda_stream),
+                       "medtok_debug_clock_probe")
+        return self
+
+    def __exit__(self, *exc):
+        self.flag[0] = 1
+        self.stream.synchronize()
+        return False
+
+    def result(self) -> dict:
+        o = self.out.cpu().tolist()
+        ghz = [c / (r * 10.0) for c, r, _, _ in o if r > 0]          # cycles per 10 ns tick -> GHz
+        if not ghz:
+            return {}
+        return dict(ghz_mean=sum(ghz) / len(ghz), ghz_min=min(ghz), ghz_max=max(ghz), seconds=max(r for _, r, _, _ in o) / 1e8,
+                    per_xcd={int(x): c / (r * 10.0) for c, r, x, _ in o if r > 0},
+                    how="s_memtime cycles / s_memrealtime (100 MHz) ticks of one idle wavefront per XCD over the timed region")
+
+
 def attention_width(d: int) -> int:
     """Width the ragged attention kernels run a D-wide problem at: D itself for 64 and multiples of 128 up to 768, else the next
     such width (the caller appends zero columns).  Wider than 768 is refused: a 32-key chunk of fp32 rows would not fit the LDS."""

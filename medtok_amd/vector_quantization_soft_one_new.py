@@ -215,6 +215,10 @@ class _SplitLinearFunction(torch.autograd.Function):
         m, k = xf.shape
         n = wf.shape[0]
         kp = _pad32(k)
+        if m == 0:
+            ctx.shape = (0, k, n)
+            ctx.dtypes = (x.dtype, w.dtype, None if b is None else b.dtype)
+            return xf.new_zeros(0, n)
         ax = ops.absmax(xf)
         aw, w_img, wt_img = _SplitLinearFunction._weight_images(w, wf, _pad32(n))
         y = ops.split_gemm_scaled(ops.split_half_scaled(xf, kp, ax), w_img, n_g=n, k_g=kp,
@@ -230,6 +234,10 @@ class _SplitLinearFunction(torch.autograd.Function):
         dxt, dwt, dbt = ctx.dtypes
         dyf = dy.float().contiguous()
         m, k, n = ctx.shape
+        if m == 0:                           # no rows (a batch without graph nodes, an empty z): empty / zero gradients, like F.linear
+            return (dyf.new_zeros(0, k).to(dxt) if ctx.needs_input_grad[0] else None,
+                    dyf.new_zeros(n, k).to(dwt) if ctx.needs_input_grad[1] else None,
+                    dyf.new_zeros(n).to(dbt) if (dbt is not None and ctx.needs_input_grad[2]) else None)
         ad = ops.absmax(dyf)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:          # dX [m, k] = dY [m, n] . (W^T [k, n])^T

@@ -145,10 +145,19 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         text = Path(sys.argv[1]).read_text()
     else:
+        # the SHIPPED flags (medtok_amd/csrc/build.py), with the link step swapped for an assembly listing: if the build's flags
+        # change, the audited ISA changes with them
+        sys.path.insert(0, str(ROOT))
+        from medtok_amd.csrc import build as hip_build
+        try:
+            cc = hip_build.hipcc()
+        except RuntimeError as exc:
+            print("SKIP:", exc)
+            sys.exit(77)
+        flags = [f for f in hip_build.FLAGS if f not in ("-shared", "-fPIC")]
         with tempfile.TemporaryDirectory() as tmp:
             out = Path(tmp) / "vq.s"
-            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
-                                   "-o", str(out), str(ROOT / "medtok_amd" / "csrc" / "medtok_vq.hip")])
+            subprocess.check_call([cc, *flags, "-S", "--cuda-device-only", "-o", str(out), str(hip_build.SRC)])
             text = out.read_text()
     print("kernels scanned:", len(re.findall(r"^(_Z[\w]+):[^\n]*\n", text, re.M)))
     n = audit(text)
