@@ -292,6 +292,22 @@ int medtok_debug_filter_probe(const float *xhat, const float *xsq, int64_t n, co
                               int d, int topk, void *ws, size_t ws_bytes, void *probe, size_t probe_bytes, int64_t *n_blocks,
                               void *stream);
 
+/* CrossAttention over a whole batch at the reference's default width (vector_quantization_soft_one_new.py:17-88,133-142 with
+ * e_dim = 64, num_head = 4: train_MedTok.py:363-368) in TWO launches and no host round trip: for every code b
+ *     pooled[b * pooled_stride ...]             = the CLS row of text[b] after `layers` cross-attention layers against b's nodes
+ *     pooled[b * pooled_stride + graph_off ...] = the mean over b's nodes after `layers` layers against text[b, :valid_b]
+ * text [n_codes, seq_len, 64] fp32; mask [n_codes, seq_len] (1 / 4 / 8 bytes per element, non-zero = valid, left-aligned: the
+ * number of non-zero entries of a row is its token count -- the reference's mask.sum()); nodes [n_nodes, 64] with a NON-DECREASING
+ * batch vector (PyG-style); weights: per layer 4 * 64 * 64 + 6 * 64 floats = Wq^T [in][out] | Wk [out][in] | Wv^T [in][out] |
+ * Wo^T [in][out] | bq | bv | bo | ln gamma | ln beta | 64 unused; y_nodes [n_nodes, 64]: the attended node rows (scratch the
+ * mean reads).  status: int32 [4] the CALLER zeroes once; the kernels OR bit 0 (batch vector not sorted) / bit 1 (id outside
+ * [0, n_codes)) into word 0 -- results are then undefined for the codes involved, but every access stays in bounds.
+ * fp32 throughout: FMAs for the 64 x 64 products, v_mfma_f32_32x32x2_f32 (exact fmaf chains) for the attention core. */
+int medtok_cross_attention_small_f32(const float *text, const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len,
+                                     const float *nodes, const int64_t *batch, int64_t n_nodes, int d, int heads, int layers,
+                                     const float *weights, float scale, float ln_eps, float *y_nodes, float *pooled,
+                                     int64_t pooled_stride, int64_t graph_off, int32_t *status, void *stream);
+
 /* The prologue of the batched cross-attention: what the reference's per-code loop reads back with `.item()` and `batch == idx`
  * (vector_quantization_soft_one_new.py:133-142), for all codes at once, in three small launches and no host round trip:
  *   valid_len[b] = non-zero entries of mask row b (mask [n_codes, seq_len], elements of mask_elem_bytes = 1 (bool), 4 or 8 bytes);

@@ -86,6 +86,7 @@ SIGNATURES = {
     "medtok_cross_attention_layer_f32": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int,
                                                 _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp,
                                                 _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _f, _int, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "medtok_cross_attention_small_f32": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _vp, _i64, _int, _int, _int, _vp, _f, _f, _vp, _vp, _i64, _i64, _vp, _vp]),
     "medtok_segment_mean_f32": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp]),
     "medtok_pack_codes_workspace_bytes": (_sz, [_i64]),
     "medtok_pack_codes": (_int, [_vp, _int, _i64, _i64, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

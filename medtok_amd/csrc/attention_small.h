@@ -1,0 +1,399 @@
+// attention_small.h -- CrossAttention.pooled at the reference's own width (e_dim = 64, 4 heads: train_MedTok.py:363-368) in ONE launch:
+// both layers of both directions, from the raw text / node features to the pooled rows the shared searches read.
+// Included by medtok_vq.hip after attention_pp.h; gfx950 only.
+//
+//     for every code b (vector_quantization_soft_one_new.py:133-142, 17-88):
+//         pooled_text[b]  = CrossAttention(text[b, :valid], nodes_b)[0][0]          (the CLS row of the attended text)
+//         pooled_graph[b] = CrossAttention(text[b, :valid], nodes_b)[1].mean(0)     (the mean of the attended nodes)
+//
+// Why a kernel of its own.  At this width the layer-by-layer path (seven launches per layer and side: images, four dense products,
+// attention core, residual + LayerNorm) is 28 launches of 5-40 us for a few MFLOP each -- a B = 256 forward spent 0.32 ms of its
+// 0.45 ms of kernel time (and most of its 0.9 ms of wall time) there.  But cross-attention couples nothing across query rows: a
+// node's two layers depend on that node and on the ORIGINAL text rows of its code only (:83,86).  So one block takes a tile of 8
+// consecutive nodes through both layers without leaving the CU:
+//   * query tile = 8 nodes x 4 heads = 32 rows.  Per layer: q' = Wq x + bq, the per-head fold qf_h = Wk_h^T q'_h (the key bias is
+//     the same for every key: softmax drops it), the attention core softmax(scale qf K^T) K over the raw rows of the other modality,
+//     att_h = Wv_h ctx_h + bv_h, out_proj, residual + LayerNorm.  The five small dense steps are fp32 FMAs with lane = output column
+//     (64 columns = one wavefront; the weights arrive transposed where that makes the loads coalesced: one 256-byte line per wave
+//     and k, L2-resident); cross-wave partial sums meet in LDS.
+//   * attention core on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fmaf chains, no precision argument to make), keys as
+//     the A rows: S^T = K qf^T leaves every lane with 16 keys of ONE query row, so the online softmax is lane-local (its partner
+//     half-wave by v_permlane32_swap), and the probabilities it ends with ARE the B operand of the second product
+//     ctx^T += K^T P^T -- the contraction runs over the keys in the order the accumulator registers hold them.  The four waves of
+//     a block walk the key chunks (32 keys) round-robin, each with its own running maximum / sum / context, and merge at the end of
+//     the layer; no block-wide barrier inside the key loop.  A wave prefetches its next chunk into registers under the MFMAs of
+//     the current one and parks it in its own LDS slice (rows padded to 68 floats: conflict-free for both operand shapes).
+//   * no prologue launches and no host read: a tile is 8 consecutive rows of the node array (grid = ceil(N / 8) + B from the shapes
+//     alone); it may span several codes of the (sorted, PyG-style) batch vector and runs one key pass per code it touches.  A code's
+//     token count is counted from its mask row by the block that needs it; its node range comes from a binary search of the batch
+//     vector.  Blocks ceil(N / 8) .. + B - 1 are the text side (the CLS row of code b against b's nodes).
+//   * the node mean needs all tiles of a code: a second, tiny launch (cross_attention64_mean_kernel: rows added in node order).
+// `status` (int32 [4], zeroed by the caller once; OR-ed): bit 0 = the batch vector is not sorted, bit 1 = an id outside [0, B).
+// Results are then wrong for the codes involved -- the host-side wrapper checks the word where it synchronises anyway.
+#pragma once
+
+constexpr int XS_D = 64, XS_H = 4, XS_HD = 16, XS_G = 8, XS_ROWS = XS_G * XS_H;      // 32 query rows per tile
+constexpr int XS_LD = 68;                         // padded row length (floats) of the LDS tiles
+constexpr int XS_LAYER_FLOATS = 4 * XS_D * XS_D + 6 * XS_D;       // WqT | Wk | WvT | WoT | bq | bv | bo | gamma | beta | (pad)
+
+struct XSmallArgs {
+    const float *text;            // [B, L, 64]
+    const void *mask;             // [B, L], mask_bytes per element (1 / 4 / 8); non-zero = valid, left-aligned
+    const float *nodes;           // [N, 64], rows of one code adjacent (sorted batch vector)
+    const int64_t *batch;         // [N]
+    const float *weights;         // [layers][XS_LAYER_FLOATS]
+    float *y_nodes;               // [N, 64]: the attended nodes (read by the mean kernel)
+    float *pooled;                // text row of code b at pooled + b * pooled_stride, graph row at pooled + b * pooled_stride + graph_off
+    int *status;
+    long n_codes, seq_len, n_nodes, pooled_stride, graph_off;
+    int mask_bytes, layers, n_graph_tiles;
+    float scale, ln_eps;
+};
+
+__device__ __forceinline__ float xs_other_half(float v, int lh)
+{
+    const unsigned b = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return __uint_as_float(lh ? r[0] : r[1]);
+}
+
+__device__ __forceinline__ float xs_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
+// first index i in [0, n) with batch[i] >= v (batch non-decreasing)
+__device__ __forceinline__ long xs_lower_bound(const int64_t *__restrict__ batch, long n, long v)
+{
+    long lo = 0, hi = n;
+    while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if (batch[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256, 2) void cross_attention64_kernel(XSmallArgs a)
+{
+    // ---- LDS
+    __shared__ __attribute__((aligned(16))) float s_x[XS_G][XS_D];            // the tile's rows: layer input, then its output
+    __shared__ __attribute__((aligned(16))) float s_q[XS_G][XS_D];            // q' = Wq x + bq; later att = Wv ctx + bv
+    // folded queries [4 n + h][c]; once every wave holds them as MFMA operands the same bytes receive the contexts [4 n + h][c]
+    // (first written behind the block-wide barrier of the first merge; read by the W_v step, which ends before the next fold)
+    __shared__ __attribute__((aligned(16))) float s_qf[XS_ROWS][XS_LD];
+    float (*s_ctx)[XS_LD] = s_qf;
+    __shared__ __attribute__((aligned(16))) float s_kv[4][32][XS_LD];         // one key chunk per wave; after the key loop: its partial contexts
+    __shared__ __attribute__((aligned(16))) float s_part[4][XS_G][XS_D];      // cross-wave partial sums of the dense steps
+    __shared__ float s_ml[4][2][XS_ROWS];                                     // per wave: running maximum, running sum
+    __shared__ long s_seg[XS_G + 1][3];                                        // segments of the tile: code, first local row, rows
+    __shared__ int s_nseg;
+    __shared__ int s_cnt[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const bool text_side = (int)blockIdx.x >= a.n_graph_tiles;
+    const long B = a.n_codes, L = a.seq_len, N = a.n_nodes;
+
+    // ---- the tile's query rows and its segments (runs of one code)
+    int n_live;                 // query "nodes" in the tile (1 on the text side)
+    long row0 = 0;              // graph side: first node row of the tile
+    if (text_side) {
+        const long b = (long)blockIdx.x - a.n_graph_tiles;
+        n_live = 1;
+        if (tid < XS_D) s_x[0][tid] = a.text[b * L * XS_D + tid];             // the CLS row
+        for (int i = tid; i < (XS_G - 1) * XS_D; i += 256) s_x[1 + i / XS_D][i % XS_D] = 0.f;
+        if (tid == 0) { s_seg[0][0] = b; s_seg[0][1] = 0; s_seg[0][2] = 1; s_nseg = 1; }
+    } else {
+        row0 = (long)blockIdx.x * XS_G;
+        n_live = (int)min((long)XS_G, N - row0);
+        for (int i = tid; i < XS_G * XS_D; i += 256) {
+            const int n = i / XS_D, c = i % XS_D;
+            s_x[n][c] = n < n_live ? a.nodes[(row0 + n) * XS_D + c] : 0.f;
+        }
+        if (tid == 0) {
+            int ns = 0, bad = 0;
+            long prev = row0 > 0 ? a.batch[row0 - 1] : -0x7fffffffffffffffL;
+            for (int n = 0; n < n_live; ++n) {
+                const long id = a.batch[row0 + n];
+                if (id < prev) bad |= 1;
+                if (id < 0 || id >= B) bad |= 2;
+                const long code = id < 0 ? 0 : (id >= B ? B - 1 : id);
+                if (ns > 0 && s_seg[ns - 1][0] == code) ++s_seg[ns - 1][2];
+                else { s_seg[ns][0] = code; s_seg[ns][1] = n; s_seg[ns][2] = 1; ++ns; }
+                prev = id;
+            }
+            s_nseg = ns;
+            if (bad) atomicOr(a.status, bad);
+        }
+    }
+    __syncthreads();
+    const int nseg = s_nseg;
+
+    // ---- MFMA helpers (v_mfma_f32_32x32x2_f32: A [32 x 2], B [2 x 32]; lane (i, k) holds A[i][k] / B[k][i])
+    const float *kvw = &s_kv[wv][0][0];
+
+    for (int layer = 0; layer < a.layers; ++layer) {
+        const float *W = a.weights + (long)layer * XS_LAYER_FLOATS;
+        const float *WqT = W, *Wk = W + 4096, *WvT = W + 8192, *WoT = W + 12288;
+        const float *bq = W + 16384, *bv = bq + 64, *bo = bq + 128, *gamma = bq + 192, *beta = bq + 256;
+
+        // ---- q'[n][o] = sum_i x[n][i] WqT[i][o] + bq[o]: wave = quarter of i, lane = o
+        {
+            float acc[XS_G];
+#pragma unroll
+            for (int n = 0; n < XS_G; ++n) acc[n] = 0.f;
+            float w[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w[i] = WqT[(16 * wv + i) * XS_D + lane];
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                for (int n = 0; n < XS_G; ++n) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(&s_x[n][16 * wv + 4 * i4]);
+                    acc[n] = fmaf(xv.x, w[4 * i4], acc[n]); acc[n] = fmaf(xv.y, w[4 * i4 + 1], acc[n]);
+                    acc[n] = fmaf(xv.z, w[4 * i4 + 2], acc[n]); acc[n] = fmaf(xv.w, w[4 * i4 + 3], acc[n]);
+                }
+#pragma unroll
+            for (int n = 0; n < XS_G; ++n) s_part[wv][n][lane] = acc[n];
+        }
+        __syncthreads();
+        for (int i = tid; i < XS_G * XS_D; i += 256) {
+            const int n = i >> 6, o = i & 63;
+            s_q[n][o] = ((s_part[0][n][o] + s_part[1][n][o]) + (s_part[2][n][o] + s_part[3][n][o])) + bq[o];
+        }
+        __syncthreads();
+        // ---- the fold: qf[4 n + h][c] = sum_j q'[n][16 h + j] Wk[16 h + j][c]: wave = head, lane = c
+        {
+            float acc[XS_G];
+#pragma unroll
+            for (int n = 0; n < XS_G; ++n) acc[n] = 0.f;
+            float w[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[j] = Wk[(16 * wv + j) * XS_D + lane];
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+                for (int n = 0; n < XS_G; ++n) {
+                    const float4 qv = *reinterpret_cast<const float4 *>(&s_q[n][16 * wv + 4 * j4]);
+                    acc[n] = fmaf(qv.x, w[4 * j4], acc[n]); acc[n] = fmaf(qv.y, w[4 * j4 + 1], acc[n]);
+                    acc[n] = fmaf(qv.z, w[4 * j4 + 2], acc[n]); acc[n] = fmaf(qv.w, w[4 * j4 + 3], acc[n]);
+                }
+#pragma unroll
+            for (int n = 0; n < XS_G; ++n) s_qf[4 * n + wv][lane] = acc[n] * a.scale;        // (the score scale rides on the queries)
+        }
+        __syncthreads();
+
+        // ---- the attention core, one pass per code the tile touches
+        // the queries as B operands: lane (row li, half lh) holds qf[li][8 g + 4 lh + e], g = 0..7, e = 0..3
+        float4 qb[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) qb[g] = *reinterpret_cast<const float4 *>(&s_qf[li][8 * g + 4 * lh]);
+
+        for (int sg = 0; sg < nseg; ++sg) {
+            const long code = s_seg[sg][0];
+            // the key set of this pass: graph side -> the code's valid text rows; text side -> the code's nodes
+            const float *kbase;
+            long klen;
+            if (text_side) {
+                const long lo = xs_lower_bound(a.batch, N, code), hi = xs_lower_bound(a.batch, N, code + 1);
+                kbase = a.nodes + lo * XS_D;
+                klen = hi - lo;
+            } else {
+                // token count of the code: non-zero entries of its mask row (left-aligned), counted by the whole block
+                if (tid < 4) s_cnt[tid] = 0;
+                __syncthreads();
+                int cnt = 0;
+                const char *mrow = reinterpret_cast<const char *>(a.mask) + code * L * a.mask_bytes;
+                for (long i = tid; i < L; i += 256) {
+                    const bool nz = a.mask_bytes == 1 ? mrow[i] != 0 : (a.mask_bytes == 4 ? reinterpret_cast<const int *>(mrow)[i] != 0
+                                                                                           : reinterpret_cast<const long *>(mrow)[i] != 0);
+                    cnt += nz ? 1 : 0;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+                if (lane == 0) s_cnt[wv] = cnt;
+                __syncthreads();
+                klen = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+                kbase = a.text + code * L * XS_D;
+            }
+            const int nchunk = (int)((klen + 31) >> 5);
+
+            f32x16 ctx0, ctx1;                   // ctx^T: lane = query row li; registers = columns (r & 3) + 8 (r >> 2) + 4 lh (+ 32 for ctx1)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ctx0[r] = 0.f; ctx1[r] = 0.f; }
+            float m_run = -INFINITY, l_run = 0.f;
+
+            // this wave's chunks: wv, wv + 4, ...; a chunk is 32 rows of 256 B, fetched as 8 x (64 lanes x 16 B): lane -> row 4 q + (lane >> 4)
+            // (eight named registers and a macro: hipcc leaves an array that is filled under a condition and lives across iterations --
+            // or one captured by reference in a lambda -- in scratch memory)
+            float4 pf0, pf1, pf2, pf3, pf4, pf5, pf6, pf7;
+            pf0 = pf1 = pf2 = pf3 = pf4 = pf5 = pf6 = pf7 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define XS_FETCH1(cc, q, dst) dst = *reinterpret_cast<const float4 *>(kbase + min((long)32 * (cc) + 4 * (q) + (lane >> 4), klen - 1) * XS_D + 4 * (lane & 15));
+            // (past the end of the key set: the last key again -- its score is masked below)
+#define XS_FETCH(cc) XS_FETCH1(cc, 0, pf0) XS_FETCH1(cc, 1, pf1) XS_FETCH1(cc, 2, pf2) XS_FETCH1(cc, 3, pf3) XS_FETCH1(cc, 4, pf4) XS_FETCH1(cc, 5, pf5) XS_FETCH1(cc, 6, pf6) XS_FETCH1(cc, 7, pf7)
+            if (wv < nchunk) { XS_FETCH(wv) }
+            for (int c = wv; c < nchunk; c += 4) {
+                // park the fetched chunk in this wave's LDS slice (the previous chunk's readers -- this wave -- are done)
+#define XS_PARK(q, src) *reinterpret_cast<float4 *>(&s_kv[wv][4 * (q) + (lane >> 4)][4 * (lane & 15)]) = src;
+                XS_PARK(0, pf0) XS_PARK(1, pf1) XS_PARK(2, pf2) XS_PARK(3, pf3) XS_PARK(4, pf4) XS_PARK(5, pf5) XS_PARK(6, pf6) XS_PARK(7, pf7)
+#undef XS_PARK
+                if (c + 4 < nchunk) { XS_FETCH(c + 4) }
+                // ---- S^T [32 keys x 32 rows] = K qf^T: A = keys (lane: key li, columns 8 g + 4 lh + e)
+                f32x16 sacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float4 ka = *reinterpret_cast<const float4 *>(kvw + li * XS_LD + 8 * g + 4 * lh);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.x, qb[g].x, sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, qb[g].y, sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.z, qb[g].z, sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.w, qb[g].w, sacc, 0, 0, 0);
+                }
+                // ---- online softmax of row li over the chunk's keys: this lane holds keys (r & 3) + 8 (r >> 2) + 4 lh, its partner the rest
+                const long kfirst = (long)32 * c + 4 * lh;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool valid = kfirst + (r & 3) + 8 * (r >> 2) < klen;
+                    sacc[r] = valid ? sacc[r] : -INFINITY;
+                    mx = fmaxf(mx, sacc[r]);
+                }
+                mx = fmaxf(mx, xs_other_half(mx, lh));
+                const float m_new = fmaxf(m_run, mx);              // finite: every chunk holds at least one valid key
+                const float alpha = xs_exp(m_run - m_new);         // 0 on the wave's first chunk
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] = xs_exp(sacc[r] - m_new);
+                    psum += sacc[r];
+                }
+                psum += xs_other_half(psum, lh);
+                l_run = fmaf(l_run, alpha, psum);
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { ctx0[r] *= alpha; ctx1[r] *= alpha; }
+                // ---- ctx^T [64 columns x 32 rows] += K^T P^T: contraction index of step s = the key register s holds
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int key = (s & 3) + 8 * (s >> 2) + 4 * lh;
+                    const float a0 = kvw[key * XS_LD + li], a1 = kvw[key * XS_LD + 32 + li];
+                    ctx0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, sacc[s], ctx0, 0, 0, 0);
+                    ctx1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, sacc[s], ctx1, 0, 0, 0);
+                }
+            }
+#undef XS_FETCH
+#undef XS_FETCH1
+            // ---- merge the four waves' partial (maximum, sum, context): through each wave's own LDS slice
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                s_kv[wv][li][col] = ctx0[r];
+                s_kv[wv][li][32 + col] = ctx1[r];
+            }
+            if (lh == 0) { s_ml[wv][0][li] = m_run; s_ml[wv][1][li] = l_run; }
+            __syncthreads();
+            {
+                const int row = tid >> 3, c0 = 8 * (tid & 7);
+                const int r_lo = 4 * (int)s_seg[sg][1], r_hi = r_lo + 4 * (int)s_seg[sg][2];
+                if (row >= r_lo && row < r_hi) {
+                    float mm = fmaxf(fmaxf(s_ml[0][0][row], s_ml[1][0][row]), fmaxf(s_ml[2][0][row], s_ml[3][0][row]));
+                    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    float lsum = 0.f;
+                    if (mm > -INFINITY) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const float f = xs_exp(s_ml[w][0][row] - mm);            // 0 for a wave that saw no chunk (its maximum is -inf)
+                            lsum = fmaf(s_ml[w][1][row], f, lsum);
+                            const float4 u = *reinterpret_cast<const float4 *>(&s_kv[w][row][c0]), v = *reinterpret_cast<const float4 *>(&s_kv[w][row][c0 + 4]);
+                            o[0] = fmaf(u.x, f, o[0]); o[1] = fmaf(u.y, f, o[1]); o[2] = fmaf(u.z, f, o[2]); o[3] = fmaf(u.w, f, o[3]);
+                            o[4] = fmaf(v.x, f, o[4]); o[5] = fmaf(v.y, f, o[5]); o[6] = fmaf(v.z, f, o[6]); o[7] = fmaf(v.w, f, o[7]);
+                        }
+                    }
+                    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;                   // no key at all: the context is zero
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s_ctx[row][c0 + e] = o[e] * inv;
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- att[n][o] = sum_c ctx[4 n + (o >> 4)][c] WvT[c][o] + bv[o]: wave = quarter of c, lane = o
+        {
+            float acc[XS_G];
+#pragma unroll
+            for (int n = 0; n < XS_G; ++n) acc[n] = 0.f;
+            float w[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w[i] = WvT[(16 * wv + i) * XS_D + lane];
+            const int hh = lane >> 4;
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                for (int n = 0; n < XS_G; ++n) {
+                    const float4 cv = *reinterpret_cast<const float4 *>(&s_ctx[4 * n + hh][16 * wv + 4 * i4]);
+                    acc[n] = fmaf(cv.x, w[4 * i4], acc[n]); acc[n] = fmaf(cv.y, w[4 * i4 + 1], acc[n]);
+                    acc[n] = fmaf(cv.z, w[4 * i4 + 2], acc[n]); acc[n] = fmaf(cv.w, w[4 * i4 + 3], acc[n]);
+                }
+#pragma unroll
+            for (int n = 0; n < XS_G; ++n) s_part[wv][n][lane] = acc[n];
+        }
+        __syncthreads();
+        for (int i = tid; i < XS_G * XS_D; i += 256) {
+            const int n = i >> 6, o = i & 63;
+            s_q[n][o] = ((s_part[0][n][o] + s_part[1][n][o]) + (s_part[2][n][o] + s_part[3][n][o])) + bv[o];
+        }
+        __syncthreads();
+        // ---- out[n][o] = sum_i att[n][i] WoT[i][o] + bo[o]
+        {
+            float acc[XS_G];
+#pragma unroll
+            for (int n = 0; n < XS_G; ++n) acc[n] = 0.f;
+            float w[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w[i] = WoT[(16 * wv + i) * XS_D + lane];
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                for (int n = 0; n < XS_G; ++n) {
+                    const float4 av = *reinterpret_cast<const float4 *>(&s_q[n][16 * wv + 4 * i4]);
+                    acc[n] = fmaf(av.x, w[4 * i4], acc[n]); acc[n] = fmaf(av.y, w[4 * i4 + 1], acc[n]);
+                    acc[n] = fmaf(av.z, w[4 * i4 + 2], acc[n]); acc[n] = fmaf(av.w, w[4 * i4 + 3], acc[n]);
+                }
+#pragma unroll
+            for (int n = 0; n < XS_G; ++n) s_part[wv][n][lane] = acc[n];
+        }
+        __syncthreads();
+        // ---- residual + LayerNorm (:47-50): wave = rows wv, wv + 4; lane = column
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int n = wv + 4 * k;
+            const float v = s_x[n][lane] + (((s_part[0][n][lane] + s_part[1][n][lane]) + (s_part[2][n][lane] + s_part[3][n][lane])) + bo[lane]);
+            const float mean = wave_butterfly_sum(v) * (1.0f / XS_D);
+            const float dlt = v - mean;
+            const float var = wave_butterfly_sum(dlt * dlt) * (1.0f / XS_D);
+            const float y = dlt * rsqrtf(var + a.ln_eps) * gamma[lane] + beta[lane];
+            s_x[n][lane] = n < n_live ? y : 0.f;
+        }
+        __syncthreads();
+    }
+
+    // ---- results
+    if (text_side) {
+        const long b = (long)blockIdx.x - a.n_graph_tiles;
+        if (tid < XS_D) a.pooled[b * a.pooled_stride + tid] = s_x[0][tid];
+    } else {
+        for (int i = tid; i < n_live * XS_D; i += 256) a.y_nodes[(row0 + (i >> 6)) * XS_D + (i & 63)] = s_x[i >> 6][i & 63];
+    }
+}
+
+// pooled_graph[b] = mean of the attended rows of code b, rows added in node order (one ordered chain per column; a code without
+// nodes gives zeros) -- the `.mean(dim=0)` of :140-141.  One wavefront per code; its node range by binary search of the batch vector.
+__global__ __launch_bounds__(256) void cross_attention64_mean_kernel(const float *__restrict__ y_nodes, const int64_t *__restrict__ batch, long n_nodes,
+                                                                     long n_codes, float *__restrict__ pooled, long pooled_stride, long graph_off)
+{
+    const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_codes) return;
+    const int lane = threadIdx.x & 63;
+    const long lo = xs_lower_bound(batch, n_nodes, b), hi = xs_lower_bound(batch, n_nodes, b + 1);
+    float s = 0.f;
+    for (long r = lo; r < hi; ++r) s += y_nodes[r * XS_D + lane];
+    pooled[b * pooled_stride + graph_off + lane] = hi > lo ? s / (float)(hi - lo) : 0.f;
+}

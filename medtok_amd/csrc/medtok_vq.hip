@@ -1510,6 +1510,7 @@ extern "C" int medtok_scale_by_device_scalar_f32(const float *x, int64_t count, 
 #include "attention_backward.h"
 #include "attention_dma.h"
 #include "attention_pp.h"
+#include "attention_small.h"
 #include "pack_kernels.h"
 
 static int attention_shape_ok(int d) { return d == 64 || (d > 0 && d % 128 == 0 && d <= 768); }
@@ -1677,6 +1678,34 @@ extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_s
     if (!exact_f32) return attention_forward_f16s(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, (_Float16 *)out_hi,
                                                   (_Float16 *)out_lo, (hipStream_t)stream);
     return attention_forward(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, nullptr, 0.f, 0u, (hipStream_t)stream);
+}
+
+// CrossAttention.pooled at e_dim = 64, 4 heads (the reference's default shape) in two launches (attention_small.h)
+extern "C" int medtok_cross_attention_small_f32(const float *text, const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len,
+                                                const float *nodes, const int64_t *batch, int64_t n_nodes, int d, int heads, int layers,
+                                                const float *weights, float scale, float ln_eps, float *y_nodes, float *pooled,
+                                                int64_t pooled_stride, int64_t graph_off, int32_t *status, void *stream)
+{
+    if (d != XS_D || heads != XS_H) return fail("cross_attention_small: d=%d heads=%d (this path is e_dim = 64 with 4 heads)", d, heads);
+    if (n_codes < 0 || seq_len <= 0 || n_nodes < 0 || layers <= 0) return fail("cross_attention_small: bad sizes n_codes=%ld seq_len=%ld n_nodes=%ld layers=%d", (long)n_codes, (long)seq_len, (long)n_nodes, layers);
+    if (mask_elem_bytes != 1 && mask_elem_bytes != 4 && mask_elem_bytes != 8) return fail("cross_attention_small: mask elements of %d bytes (bool / int32 / int64 expected)", mask_elem_bytes);
+    if (n_codes == 0) return 0;
+    if (!text || !mask || !weights || !pooled || !status || (n_nodes && (!nodes || !batch || !y_nodes))) return fail("cross_attention_small: NULL argument");
+    if (((uintptr_t)text | (uintptr_t)nodes | (uintptr_t)weights | (uintptr_t)y_nodes) & 15) return fail("cross_attention_small: pointers must be 16-byte aligned");
+    if (pooled_stride < XS_D || graph_off < 0) return fail("cross_attention_small: bad output layout");
+    const int64_t tiles = (n_nodes + XS_G - 1) / XS_G;
+    if (tiles + n_codes >= (1ll << 31)) return fail("cross_attention_small: grid limit exceeded");
+    XSmallArgs a;
+    a.text = text; a.mask = mask; a.nodes = nodes; a.batch = batch; a.weights = weights; a.y_nodes = y_nodes; a.pooled = pooled; a.status = status;
+    a.n_codes = (long)n_codes; a.seq_len = (long)seq_len; a.n_nodes = (long)n_nodes; a.pooled_stride = (long)pooled_stride; a.graph_off = (long)graph_off;
+    a.mask_bytes = mask_elem_bytes; a.layers = layers; a.n_graph_tiles = (int)tiles; a.scale = scale; a.ln_eps = ln_eps;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+    hipLaunchKernelGGL(cross_attention64_kernel, dim3((unsigned)(tiles + n_codes)), dim3(256), 0, s, a);
+    if (pa) prof_push(pa, prof_mark(s), 0.0, 2);
+    hipLaunchKernelGGL(cross_attention64_mean_kernel, dim3((unsigned)((n_codes + 3) / 4)), dim3(256), 0, s, y_nodes, batch, (long)n_nodes, (long)n_codes,
+                       pooled, (long)pooled_stride, (long)graph_off);
+    return check_launch("cross_attention_small");
 }
 
 // the prologue of CrossAttention.pooled (pack_kernels.h)

@@ -117,6 +117,9 @@ def run_inference(model: MultimodalTokenizer, batches: Iterable, out_dir: Option
             st.push(val, sink)
     for st, sink in zip(stages, (embs, toks, wts)):
         st.flush(sink)
+    quant = getattr(model, "quantize", None)
+    if quant is not None and hasattr(quant, "cross_attn"):
+        quant.cross_attn.check_small_status()        # (the small-width path validates the batch vectors on the device: read it once, here)
     multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
     if dev is None:
         dev = next(model.parameters()).device

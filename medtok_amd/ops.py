@@ -483,6 +483,34 @@ def cross_attention_layer(rows, rows_images, w, q_start, q_len, max_q_len: int, 
     return (y, (yh, yl)) if want_images else y
 
 
+SMALL_ATTENTION_LAYER_FLOATS = 4 * 64 * 64 + 6 * 64
+
+
+def cross_attention_small(text, mask, nodes, batch, weights, layers: int, scale: float, ln_eps: float, pooled, status):
+    """CrossAttention.pooled at e_dim = 64 with 4 heads in two launches and no host read (include/medtok_vq.h:
+    medtok_cross_attention_small_f32).  text [B, L, 64] fp32, mask [B, L] (bool / int32 / int64), nodes [N, 64] fp32 with a sorted
+    batch vector [N] int64, weights [layers, SMALL_ATTENTION_LAYER_FLOATS] (CrossAttention._small_weights), pooled [B, 2, 64] fp32
+    (written: [:, 0] the attended CLS rows, [:, 1] the node means), status int32 [4] (zeroed once by its owner)."""
+    text, nodes, weights = _dev(text, "text"), _dev(nodes, "nodes"), _dev(weights, "weights")
+    batch = _dev(batch.reshape(-1), "batch", torch.int64)
+    if not (isinstance(mask, torch.Tensor) and mask.is_cuda and mask.dim() == 2):
+        raise _lib.MedTokLibraryError("cross_attention_small: expected a [B, L] mask on an MI355X device")
+    if mask.dtype not in (torch.bool, torch.uint8, torch.int32, torch.int64):
+        mask = mask != 0
+    mask = mask.contiguous()
+    bsz, seq_len, d = text.shape
+    n_nodes = nodes.shape[0]
+    if pooled.shape != (bsz, 2, d) or pooled.dtype != torch.float32 or not pooled.is_contiguous():
+        raise ValueError("cross_attention_small: pooled must be a contiguous fp32 [B, 2, d] tensor")
+    y_nodes = torch.empty((max(n_nodes, 1), d), dtype=torch.float32, device=text.device)
+    with torch.cuda.device(text.device):
+        _lib.check(_lib.load().medtok_cross_attention_small_f32(
+            text.data_ptr(), mask.data_ptr(), mask.element_size(), bsz, seq_len, nodes.data_ptr() if n_nodes else 0, batch.data_ptr() if n_nodes else 0,
+            n_nodes, d, 4, int(layers), weights.data_ptr(), float(scale), float(ln_eps), y_nodes.data_ptr(), pooled.data_ptr(), 2 * d, d,
+            status.data_ptr(), _stream(text)), "medtok_cross_attention_small_f32")
+    return pooled
+
+
 def segment_mean(x, seg_start, seg_len):
     """out[b] = mean of rows [seg_start[b], seg_start[b] + seg_len[b]) of the contiguous fp32 matrix x [rows, d] (rows added in
     order; an empty segment gives zeros) -- the `.mean(dim=0)` over a code's graph nodes (:140-141).  seg_* int64 device vectors."""

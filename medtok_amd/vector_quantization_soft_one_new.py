@@ -64,6 +64,13 @@ FUSED_LAYER_CALL = True
 # Off by default: under autocast the library's half-precision GEMM is ~3x cheaper than the fp32-accurate three-pass product, and
 # that layer is upstream of the quantiser (bench.py --precomputed-encoders turns it on for the all-own-kernels profile).
 TRAIN_SPLIT_TEXT_MAPPING = False
+# inference at the reference's own width (e_dim = 64, 4 heads): the whole cross-attention of a forward -- both layers, both
+# directions, node mean -- in two launches with no host read (ops.cross_attention_small); needs a SORTED batch vector (PyG's are;
+# the kernels flag anything else in CrossAttention.small_status, checked wherever the forward synchronises anyway)
+SMALL_WIDTH_FUSED = True
+# inference: the two shared searches of a forward as ONE search over the interleaved rows [text_0, graph_0, text_1, ...] (one
+# codebook pass, twice the rows per launch; its [2 B, e] result IS the [B, 2 e] shared embedding)
+MERGE_SHARED_SEARCHES = True
 from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
@@ -142,16 +149,20 @@ def _cached(holder, attr, key, build, device, rebuild=False):
     (every bench step; every eval after an optimizer step) was ordered only by timing."""
     c = getattr(holder, attr, None)
     cur = torch.cuda.current_stream(device) if device.type == "cuda" else None
+    # Under HIP-graph capture no event of the outside world may be waited for (and none recorded here may be waited for outside):
+    # a capture is preceded by a warm-up and a synchronisation (the caches are built and complete), so entries are read as they are;
+    # one built inside a capture carries no mark.
+    capturing = cur is not None and torch.cuda.is_current_stream_capturing()
     if rebuild or c is None or c[0] != key:
         value = build()
         mark = None
-        if cur is not None:
+        if cur is not None and not capturing:
             mark = _BuiltOn(torch.cuda.Event(), cur)
             mark.event.record(cur)
         setattr(holder, attr, (key, value, mark))
         return value
     mark = c[2]
-    if mark is not None and cur is not None and cur != mark.stream:
+    if mark is not None and cur is not None and cur != mark.stream and not capturing:
         cur.wait_event(mark.event)
         _lend(cur, c[1])
     return c[1]
@@ -711,6 +722,68 @@ class CrossAttention(nn.Module):
             return text, valid, nodes, batch, slot, counts, starts, max_nodes
         return text, valid, valid_len, nodes, batch, slot, counts, starts, max_nodes, lists
 
+    def _small_weights(self):
+        """The layers' weights in the layout medtok_cross_attention_small_f32 reads (include/medtok_vq.h), [layers, 4 * 64 * 64 + 6 * 64]
+        fp32: Wq^T | Wk | Wv^T | Wo^T | bq | bv | bo | ln gamma | ln beta | pad -- cached per (storage, version) of every tensor."""
+        params = []
+        for layer in self.model:
+            mha, ln = layer.multihead_attn, layer.layer_norm
+            params += [mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias, ln.weight, ln.bias]
+        key = tuple((t.data_ptr(), t._version, t.device) for t in params)
+
+        def build():
+            rows = []
+            for layer in self.model:
+                mha, ln = layer.multihead_attn, layer.layer_norm
+                wq, wk, wv = (t.detach().float() for t in mha.in_proj_weight.chunk(3))
+                bq, _, bv = (t.detach().float() for t in mha.in_proj_bias.chunk(3))
+                wo, bo = mha.out_proj.weight.detach().float(), mha.out_proj.bias.detach().float()
+                rows.append(torch.cat([wq.t().reshape(-1), wk.reshape(-1), wv.t().reshape(-1), wo.t().reshape(-1), bq, bv, bo,
+                                       ln.weight.detach().float(), ln.bias.detach().float(), torch.zeros_like(bo)]))
+            return torch.stack(rows).contiguous()
+        return _cached(self, "_medtok_small_cache", key, build, params[0].device)
+
+    def small_eligible(self, text, nodes) -> bool:
+        """inference at e_dim = 64 with 4 heads on fp32 device tensors: the two-launch path (ops.cross_attention_small)"""
+        mha, ln = self.model[0].multihead_attn, self.model[0].layer_norm
+        return (SMALL_WIDTH_FUSED and not self.training and not torch.is_grad_enabled() and text.is_cuda and nodes.is_cuda
+                and text.dim() == 3 and text.shape[-1] == 64 and mha.num_heads == 4 and mha.in_proj_bias is not None
+                and mha._qkv_same_embed_dim and all(l.layer_norm.elementwise_affine and l.layer_norm.bias is not None for l in self.model)
+                and all(abs(l.layer_norm.eps - ln.eps) == 0 for l in self.model)
+                and text.dtype in (torch.float32, torch.float16, torch.bfloat16) and text.shape[0] > 0)
+
+    def pooled_small(self, text, text_mask, nodes, batch):
+        """pooled() for small_eligible() inputs: [B, 2, 64] fp32 = (attended CLS row, mean of the attended nodes) per code, in two
+        launches, nothing read back -- the call captures into a HIP graph.  `batch` must be non-decreasing (PyG batch vectors are);
+        the kernels OR what they see otherwise into self.small_status (int32 [4] on the device; bit 0: not sorted, bit 1: an id
+        outside [0, B)), which check_small_status() turns into the ValueError pooled() raises -- called by VectorQuantizer.forward
+        where it synchronises anyway, by the inference driver per batch, or by the caller."""
+        bsz, seq_len, dim = text.shape
+        dev = text.device
+        st = getattr(self, "small_status", None)
+        if st is None or st.device != dev:
+            st = self.small_status = torch.zeros(4, dtype=torch.int32, device=dev)
+        with torch.autocast(device_type="cuda", enabled=False):
+            pooled2 = torch.empty((bsz, 2, dim), dtype=torch.float32, device=dev)
+            heads = self.model[0].multihead_attn.num_heads
+            ops.cross_attention_small(text.float().contiguous(), text_mask, nodes.float().contiguous(), batch.reshape(-1).to(torch.long),
+                                      self._small_weights(), len(self.model), (dim // heads) ** -0.5, self.model[0].layer_norm.eps, pooled2, st)
+        return pooled2
+
+    def check_small_status(self):
+        """Host read of small_status (a synchronisation): raises what pooled() raises for a batch vector the two-launch path cannot
+        take, and clears the word."""
+        st = getattr(self, "small_status", None)
+        if st is None:
+            return
+        word = int(st[0].item())
+        if word:
+            st.zero_()
+            if word & 2:
+                raise ValueError("pooled(): `batch` holds code ids outside [0, B)")
+            raise ValueError("pooled(): the two-launch small-width path needs a non-decreasing `batch` vector (PyG-style); sort the nodes by "
+                             "code, or set medtok_amd.vector_quantization_soft_one_new.SMALL_WIDTH_FUSED = False")
+
     def pooled(self, text, text_mask, nodes, batch, join=True):
         """Batched equivalent of the reference's per-code loop (:133-142) -- the PRODUCT path: gfx950 kernels only.
 
@@ -1005,6 +1078,24 @@ class VectorQuantizer(nn.Module):
         emb = None
         if not self.training and not torch.is_grad_enabled() and z_text.is_cuda and self.e_dim % 4 == 0:
             emb = torch.empty((z_text.shape[0], 2 * self.e_dim), dtype=torch.float32, device=z_text.device)
+        small = emb is not None and self.cross_attn.small_eligible(z_text, z_graph)
+        if small or (emb is not None and MERGE_SHARED_SEARCHES and z_text.shape[0] > 0):
+            # inference: ONE search over the interleaved rows [text_0, graph_0, text_1, ...]: its [2 B, e] result is the [B, 2 e]
+            # shared embedding, its ids [2 B, k] are both token lists
+            bsz, e = z_text.shape[0], self.e_dim
+            if small:
+                both = self.cross_attn.pooled_small(z_text, text_mask, z_graph, batch)                  # [B, 2, e]
+            else:
+                pooled_text, pooled_graph, pending = self.cross_attn.pooled(z_text, text_mask, z_graph, batch, join=False)
+                if pending is not None:
+                    _join_side(*pending, (pooled_text,))
+                both = torch.stack((pooled_text.float(), pooled_graph.float()), dim=1)
+            zq, vq, cm, xhat, idx, w = self._search(both.view(2 * bsz, e), "shared", False, out=emb.view(2 * bsz, e), norm=norm)
+            xhat, idx, w = xhat.view(bsz, 2, e), idx.view(bsz, 2, -1), w.view(bsz, 2, -1)
+            usage = self.codebook_usage(idx.reshape(bsz, -1), types="shared", _counts=usage_counts) if self.show_usage else 0.0
+            tokens = {"shared_text_tokens": idx[:, 0], "shared_text_tokens_weights": w[:, 0],
+                      "shared_graph_tokens": idx[:, 1], "shared_graph_tokens_weights": w[:, 1]}
+            return emb, (vq + vq, cm + cm, xhat[:, 0], xhat[:, 1], emb[:, :e], emb[:, e:]), usage, tokens
         pooled_text, pooled_graph, pending = self.cross_attn.pooled(z_text, text_mask, z_graph, batch, join=False)
         out_t, out_g = (emb[:, :self.e_dim], emb[:, self.e_dim:]) if emb is not None else (None, None)
         if pending is not None:
@@ -1092,7 +1183,14 @@ class VectorQuantizer(nn.Module):
         spec_text_aug = results[2][0] if z_aug is not None else None
         spec_graph_aug = results[3][0] if z_aug is not None else None
         if self.show_usage and counts:
-            u_shared, u_text, u_graph = (torch.stack(counts[:3]).cpu().double() / self.n_e).tolist()
+            st = getattr(self.cross_attn, "small_status", None)
+            if st is not None and st.device == counts[0].device:          # one read for the usage counts and the small path's status word
+                vals = torch.cat([torch.stack(counts[:3]), st[:1]]).cpu()
+                if int(vals[3]):
+                    self.cross_attn.check_small_status()
+                u_shared, u_text, u_graph = (vals[:3].double() / self.n_e).tolist()
+            else:
+                u_shared, u_text, u_graph = (torch.stack(counts[:3]).cpu().double() / self.n_e).tolist()
         out = {
             "graph_feature": z_graph_embedding,
             "text_feature": z_text_embedding,

@@ -1,0 +1,158 @@
+"""GPU: the two-launch cross-attention at the reference's own width (e_dim = 64, 4 heads; medtok_cross_attention_small_f32) against the
+layer-by-layer product path, the padded torch comparator and the reference-generated forward fixtures; the forward without a host
+read replayed from a HIP graph."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def _ragged(dev, seed, bsz, seq_len, max_nodes, zero_nodes=(), zero_tokens=()):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    text = torch.randn(bsz, seq_len, 64, device=dev, generator=g)
+    tok = torch.randint(1, seq_len + 1, (bsz,), device=dev, generator=g)
+    n_nodes = torch.randint(1, max_nodes + 1, (bsz,), device=dev, generator=g)
+    for b in zero_nodes:
+        n_nodes[b] = 0
+    for b in zero_tokens:
+        tok[b] = 0
+    mask = (torch.arange(seq_len, device=dev)[None, :] < tok[:, None]).to(torch.int64)
+    batch = torch.repeat_interleave(torch.arange(bsz, device=dev), n_nodes)
+    nodes = torch.randn(int(n_nodes.sum()), 64, device=dev, generator=g)
+    return text, mask, nodes, batch
+
+
+def _module(dev, seed=0):
+    from medtok_amd.vector_quantization_soft_one_new import CrossAttention
+    torch.manual_seed(seed)
+    ca = CrossAttention(64, 4, dropout=0.1, layers=2).to(dev).eval()
+    with torch.no_grad():                       # non-trivial biases and LayerNorm parameters
+        for layer in ca.model:
+            layer.multihead_attn.in_proj_bias.normal_(0, 0.2)
+            layer.multihead_attn.out_proj.bias.normal_(0, 0.2)
+            layer.layer_norm.weight.normal_(1.0, 0.2)
+            layer.layer_norm.bias.normal_(0, 0.2)
+    return ca
+
+
+def _close(a, b, what):
+    err = float((a.double() - b.double()).abs().max()) / max(float(b.double().abs().max()), 1e-30)
+    assert err <= RTOL, f"{what}: relative error {err:.3g}"
+
+
+@pytest.mark.parametrize("shape", [(37, 50, 25), (256, 512, 40), (5, 7, 3), (64, 33, 1), (9, 300, 70)])
+def test_small_width_path_equals_the_layer_by_layer_path(dev, shape):
+    """pooled_small (two launches, fp32 FMA / fp32 MFMA) against pooled() (pack + seven launches per layer and side on the split-fp16
+    kernels): 1e-5 of the output scale, incl. codes without nodes, codes without valid tokens, tiles that span many codes (one
+    node per code), node counts that are not a multiple of the tile, and more nodes per code than one tile."""
+    bsz, seq_len, max_nodes = shape
+    ca = _module(dev)
+    text, mask, nodes, batch = _ragged(dev, 11 + bsz, bsz, seq_len, max_nodes, zero_nodes=(1, bsz - 1) if bsz > 4 else (), zero_tokens=(2,) if bsz > 4 else ())
+    with torch.no_grad():
+        assert ca.small_eligible(text, nodes)
+        both = ca.pooled_small(text, mask, nodes, batch)
+        ca.check_small_status()
+        pt, pg = ca.pooled(text, mask, nodes, batch)
+    _close(both[:, 0], pt, "attended CLS rows")
+    _close(both[:, 1], pg, "node means")
+
+
+def test_small_width_path_equals_the_padded_torch_comparator(dev):
+    ca = _module(dev, 3)
+    text, mask, nodes, batch = _ragged(dev, 5, 23, 40, 12)
+    with torch.no_grad():
+        both = ca.pooled_small(text, mask, nodes, batch)
+        pt, pg = ca.pooled_reference(text, mask, nodes, batch, fold=False)          # nn.MultiheadAttention on padded batches
+    _close(both[:, 0], pt, "attended CLS rows vs nn.MultiheadAttention")
+    _close(both[:, 1], pg, "node means vs nn.MultiheadAttention")
+
+
+def test_small_width_path_flags_an_unsorted_batch_vector(dev):
+    ca = _module(dev)
+    text, mask, nodes, batch = _ragged(dev, 7, 16, 20, 6)
+    perm = torch.randperm(batch.numel(), device=dev)
+    with torch.no_grad():
+        ca.pooled_small(text, mask, nodes[perm], batch[perm])
+    with pytest.raises(ValueError, match="non-decreasing"):
+        ca.check_small_status()
+    ca.check_small_status()                       # cleared
+    bad = batch.clone()
+    bad[-1] = 16
+    with torch.no_grad():
+        ca.pooled_small(text, mask, nodes, bad)
+    with pytest.raises(ValueError, match="outside"):
+        ca.check_small_status()
+
+
+def _quantizer(dev, show_usage=False):
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    torch.manual_seed(1)
+    return VectorQuantizer(21000, 64, 0.25, 0.0, True, show_usage, [64, 64], k=5).to(dev).eval()
+
+
+def _forward_inputs(dev, bsz=256, seq_len=512, max_nodes=40):
+    text, mask, nodes, batch = _ragged(dev, 21, bsz, seq_len, max_nodes)
+    g = torch.Generator(device=dev).manual_seed(22)
+    return torch.randn(bsz, 128, device=dev, generator=g), text, nodes, mask, batch
+
+
+def test_forward_small_width_equals_the_layer_by_layer_forward(dev):
+    """VectorQuantizer.forward at the reference's default shape and batch through the two-launch cross-attention + ONE shared search
+    over the interleaved rows, against the round-4 form (layer-by-layer cross-attention, two shared searches): embeddings 1e-5; token
+    ids equal wherever the pooled rows' 1e-6 differences do not meet a near-tie (counted, bounded)."""
+    import medtok_amd.vector_quantization_soft_one_new as vqmod
+    vq = _quantizer(dev)
+    inp = _forward_inputs(dev)
+    with torch.no_grad():
+        new = vq(*inp)
+        vq.cross_attn.check_small_status()
+        keep = (vqmod.SMALL_WIDTH_FUSED, vqmod.MERGE_SHARED_SEARCHES)
+        vqmod.SMALL_WIDTH_FUSED = vqmod.MERGE_SHARED_SEARCHES = False
+        try:
+            old = vq(*inp)
+        finally:
+            vqmod.SMALL_WIDTH_FUSED, vqmod.MERGE_SHARED_SEARCHES = keep
+    for k in ("text_tokens", "graph_tokens", "text_tokens_weights", "graph_tokens_weights", "specific_embedding_text", "specific_embedding_graph"):
+        assert torch.equal(new[k], old[k]), k                    # the modality-specific searches do not see the cross-attention
+    for k in ("shared_text_tokens", "shared_graph_tokens"):
+        differ = int((new[k] != old[k]).any(1).sum())
+        assert differ <= 2, f"{k}: {differ} of {new[k].shape[0]} rows pick different codes"
+        same = (new[k] == old[k]).all(1)
+        e = "shared_text_embedding" if "text" in k else "shared_graph_embedding"
+        _close(new[e][same], old[e][same], e)
+
+
+def test_forward_replayed_from_a_hip_graph_is_bit_equal_to_eager(dev):
+    """No host read anywhere in the eval forward at the reference's shape (show_usage = False): it captures into a HIP graph, and the
+    replay -- on NEW input values in the captured buffers -- equals the eager forward bit for bit."""
+    vq = _quantizer(dev)
+    inp = [t.clone() for t in _forward_inputs(dev)]
+    keys = ("shared_text_embedding", "shared_graph_embedding", "specific_embedding_text", "specific_embedding_graph", "text_tokens", "graph_tokens",
+            "shared_text_tokens", "shared_graph_tokens", "text_tokens_weights", "graph_tokens_weights", "shared_text_tokens_weights",
+            "shared_graph_tokens_weights")
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                # warm-up on the side stream (caches, workspaces), as torch.cuda.graph wants it
+            for _ in range(3):
+                vq(*inp)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = vq(*inp)
+        # new values in the captured input buffers (same shapes, same batch vector)
+        g = torch.Generator(device=dev).manual_seed(99)
+        inp[0].copy_(torch.randn(inp[0].shape, device=dev, generator=g))
+        inp[1].copy_(torch.randn(inp[1].shape, device=dev, generator=g))
+        inp[2].copy_(torch.randn(inp[2].shape, device=dev, generator=g))
+        graph.replay()
+        torch.cuda.synchronize()
+        replayed = {k: out[k].clone() for k in keys}
+        eager = vq(*inp)
+        vq.cross_attn.check_small_status()
+    for k in keys:
+        assert torch.equal(replayed[k], eager[k]), k
