@@ -258,9 +258,47 @@ class FullRefDefault(Full):
 
     def __init__(self, rows, dev, seed, path):
         super().__init__(rows, dev, seed, path)
+        from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+        # the reference builds its quantiser with show_usage = True (tokenizer.py:72,126): every forward slides the 300 000-entry usage
+        # window three times and returns three Python floats (one host synchronisation per forward: part of the reference's interface)
+        torch.manual_seed(1234)
+        self.vq = VectorQuantizer(self.N_E, self.D, 0.25, 0.0, True, True, [self.D, self.D], k=self.TOPK).to(dev).eval()
+        self.vq.search_path = path
         self.description = (f"full VectorQuantizer.forward at the reference's default shape: {rows} codes/GPU/step (256 = its per-GPU batch), "
                             f"ragged cross-attention (<= {self.L} tokens x <= {self.MAX_NODES} nodes per code, 4 heads, 2 layers per direction) + 4 "
-                            f"searches, e_dim = 64, n_e = 21000, k=5, eval, fp32")
+                            f"searches, e_dim = 64, n_e = 21000, k=5, show_usage = True (the reference's default: three usage-window "
+                            f"updates and one host read per forward), eval, fp32")
+
+    def graph_replay(self, steps):
+        """the same forward without the usage window (no host read), captured into a HIP graph and replayed: (codes/s, ms per forward)"""
+        from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+        torch.manual_seed(1234)
+        vq = VectorQuantizer(self.N_E, self.D, 0.25, 0.0, True, False, [self.D, self.D], k=self.TOPK).to(self.dev).eval()
+        args = (self.h, self.text, self.nodes, self.mask, self.batch)
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    vq(*args)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize(self.dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = vq(*args)
+            for _ in range(3):
+                graph.replay()
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                graph.replay()
+            torch.cuda.synchronize(self.dev)
+            dt = time.perf_counter() - t0
+            eager = vq(*args)
+            same = all(torch.equal(out[k], eager[k]) for k in out if isinstance(out[k], torch.Tensor))
+            vq.cross_attn.check_small_status()
+        return {"value": self.rows * steps / dt, "unit": "codes/s", "ms_per_step": dt / steps * 1e3, "replay_equals_eager": bool(same),
+                "note": "VectorQuantizer.forward (eval, show_usage = False: no host read) captured into a HIP graph and replayed; rank-local"}
 
 
 class CodeShard:
@@ -822,6 +860,11 @@ def main():
             line["config"]["streams"] = "one (--one-stream)" if args.one_stream else "main + side streams (modality-specific searches, text side; the image pass over fp32 text rows has its own only where the attention kernel does not split the keys itself)"
             if half_text is not None:
                 line["half_precision_text"] = half_text
+            if args.workload == "fullref" and hasattr(wl, "graph_replay"):
+                try:
+                    line["hip_graph_replay"] = wl.graph_replay(max(args.steps, 20))
+                except Exception as exc:           # (an extra: the headline line is printed regardless)
+                    line["hip_graph_replay"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             if one_stream_elapsed is not None:
                 line["one_stream"] = {"value": float(rows) * world * args.steps / one_stream_elapsed, "unit": "codes/s",
                                       "ms_per_step": one_stream_elapsed / args.steps * 1e3,

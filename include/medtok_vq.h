@@ -72,6 +72,30 @@ int medtok_profile_begin(void);
 int medtok_profile_end(double ms[MEDTOK_PROFILE_KINDS], double flops[MEDTOK_PROFILE_KINDS],
                        int launches[MEDTOK_PROFILE_KINDS]);
 
+/* Several SMALL soft top-k searches in one call and three launches (normalise, search, merge + assign) instead of four launches each:
+ * the B = 256 forward of the reference's default configuration (train_MedTok.py:363-368,387) runs its two modality-specific
+ * searches (:187-217) and its shared searches (:147-165) on 256-512 rows each -- 16 launches of 4-30 us for 2 GFLOP.  Every
+ * descriptor is one medtok_soft_vq_forward_f32 call (eval: no squared-error output) and yields the same bits; all searches share
+ * d and topk.  Only searches that medtok_soft_vq_multi_eligible() accepts (the exact fp32-MFMA path, at most 4096 rows).
+ * xhat [n, d], idx [n, topk], dist [n, topk], w [n, topk] (may be NULL), zq [n, d] with row stride zq_stride (0 = d). */
+typedef struct medtok_search_desc {
+    const float *x; int64_t n;
+    const float *what, *wsq; int64_t k_codes;
+    float *xhat; int64_t *idx; float *dist, *w, *zq; int64_t zq_stride;
+} medtok_search_desc;
+#define MEDTOK_MULTI_SEARCH_MAX 6
+int medtok_soft_vq_multi_eligible(int64_t n, int64_t k_codes, int d, int topk);
+size_t medtok_soft_vq_forward_multi_workspace_bytes(const medtok_search_desc *descs, int count, int d, int topk);
+int medtok_soft_vq_forward_multi_f32(const medtok_search_desc *descs, int count, int d, int topk, void *ws, size_t ws_bytes, void *stream);
+
+/* The forward's three to five updates of the usage window (vector_quantization_soft_one_new.py:219-236 called at :183,216 via
+ * :241-250: shared, text, graph and, with an aug view, its two) in one call of two launches: ids[u] (int64 [m[u]]) are appended in
+ * order; counts_out[u] = distinct window values after update u (what medtok_usage_update reports for each, one by one). */
+#define MEDTOK_USAGE_MULTI_MAX 6
+size_t medtok_usage_multi_workspace_bytes(int64_t window_len, int64_t n_codes, int count);
+int medtok_usage_update_multi(float *window, int64_t window_len, const int64_t *const *ids, const int64_t *m, int count, int64_t n_codes,
+                              int32_t *counts_out, void *ws, size_t ws_bytes, void *stream);
+
 /* Shader-clock probe for bench.py: one idle wavefront on each of 8 blocks (one per XCD on the full chip) samples the shader-cycle
  * counter and the constant 100 MHz counter from launch until *stop_flag (a word of PINNED HOST memory the device polls) becomes
  * non-zero, or max_ticks_100mhz ticks have passed, whichever is first; out = uint64 [8][4] (device memory): shader cycles, 100 MHz

@@ -51,6 +51,11 @@ SIGNATURES = {
     "medtok_last_error": (C.c_char_p, []),
     "medtok_profile_begin": (_int, []),
     "medtok_profile_end": (_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "medtok_soft_vq_multi_eligible": (_int, [_i64, _i64, _int, _int]),
+    "medtok_soft_vq_forward_multi_workspace_bytes": (_sz, [_vp, _int, _int, _int]),
+    "medtok_soft_vq_forward_multi_f32": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp]),
+    "medtok_usage_multi_workspace_bytes": (_sz, [_i64, _i64, _int]),
+    "medtok_usage_update_multi": (_int, [_vp, _i64, _vp, _vp, _int, _i64, _vp, _vp, _sz, _vp]),
     "medtok_debug_clock_probe": (_int, [_vp, C.c_uint64, _vp, _vp]),
     "medtok_rownorm_f32": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
     "medtok_search_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int]),
@@ -112,6 +117,16 @@ SIGNATURES = {
 
 class MedTokLibraryError(RuntimeError):
     pass
+
+
+class SearchDesc(C.Structure):
+    """medtok_search_desc (include/medtok_vq.h)"""
+    _fields_ = [("x", _vp), ("n", _i64), ("what", _vp), ("wsq", _vp), ("k_codes", _i64), ("xhat", _vp), ("idx", _vp), ("dist", _vp), ("w", _vp),
+                ("zq", _vp), ("zq_stride", _i64)]
+
+
+MULTI_SEARCH_MAX = 6
+USAGE_MULTI_MAX = 6
 
 
 def library_path() -> Path:

@@ -320,19 +320,21 @@ constexpr int S_WPS = S_BK == 32 ? 2 : 3;                 // waves per SIMD the 
 
 // INDIRECT: the block's rows are row_list[row0 .. row0+128) (count read from *row_count on the
 // device) -- the exact fallback for rows the fp16 filter could not shortlist.
+// (the body is a force-inlined function of the block's coordinates: search_f32_kernel takes them from blockIdx, the batched kernel
+// of the small-batch forward -- several searches in one launch -- from its descriptor table)
 template <int TOPK, bool FINAL, bool KTAIL, bool INDIRECT>
-__global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
+__device__ __forceinline__ void search_f32_body(
     const float *__restrict__ xhat, const float *__restrict__ xsq, const float *__restrict__ what,
     const float *__restrict__ wsq, long n, int k_codes, int d, int codes_per_split, int topk_out,
     float *__restrict__ pval, int *__restrict__ pidx, int64_t *__restrict__ out_idx,
     float *__restrict__ out_dist, const int *__restrict__ row_list, const int *__restrict__ row_count,
-    int list_begin, int list_end)
+    int list_begin, int list_end, const unsigned block_x, const unsigned block_y)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     // direct form: this launch covers rows from list_begin on; its partial-result buffers span list_end rows (0 = all n)
-    long row0 = (long)blockIdx.x * S_BN + (INDIRECT ? 0 : list_begin);
+    long row0 = (long)block_x * S_BN + (INDIRECT ? 0 : list_begin);
     const long part_rows = INDIRECT ? (long)(list_end - list_begin) : (list_end > 0 ? (long)list_end : n);     // row extent of the partial-result buffers
     if (INDIRECT) {
         // this launch covers list positions [list_begin, min(*row_count, list_end)); uniform for the whole grid
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
         const long c = min(pos, n - 1);
         return INDIRECT ? (long)row_list[c] : c;
     };
-    const int split = blockIdx.y;
+    const int split = (int)block_y;
     const int code_lo = split * codes_per_split;
     const int code_hi = min(k_codes, code_lo + codes_per_split);
     const int nct = (code_hi - code_lo + S_BM - 1) / S_BM;
@@ -635,6 +637,71 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
             for (int j = 0; j < TOPK; ++j) { pval[base + j] = bv[j]; pidx[base + j] = bi[j]; }
         }
     }
+}
+
+template <int TOPK, bool FINAL, bool KTAIL, bool INDIRECT>
+__global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
+    const float *__restrict__ xhat, const float *__restrict__ xsq, const float *__restrict__ what,
+    const float *__restrict__ wsq, long n, int k_codes, int d, int codes_per_split, int topk_out,
+    float *__restrict__ pval, int *__restrict__ pidx, int64_t *__restrict__ out_idx,
+    float *__restrict__ out_dist, const int *__restrict__ row_list, const int *__restrict__ row_count,
+    int list_begin, int list_end)
+{
+    search_f32_body<TOPK, FINAL, KTAIL, INDIRECT>(xhat, xsq, what, wsq, n, k_codes, d, codes_per_split, topk_out, pval, pidx, out_idx, out_dist,
+                                                  row_list, row_count, list_begin, list_end, blockIdx.x, blockIdx.y);
+}
+
+// ---- several small searches in ONE launch each of three kernels (the B = 256 forward of the reference's default configuration runs
+// its specific and shared searches as four calls of four launches each: 16 launches of 4-30 us for 2 GFLOP; batched: 3 launches).
+// Same kernels' bodies, same arithmetic, same bits; a descriptor per search, selected by blockIdx.z.
+constexpr int MS_MAX = MEDTOK_MULTI_SEARCH_MAX;   // shared (merged) + text + graph + the two aug views
+struct MultiSearchOne {
+    const float *x;                             // [n, d] rows to quantise
+    const float *what, *wsq;                    // the normalised codebook region [k_codes, d] and its squared norms
+    float *xhat, *xsq;                          // out: F.normalize(x) [n, d], its squared norms [n] (scratch)
+    float *pval; int *pidx;                     // scratch: per-split lists [splits][n][TOPK]
+    int64_t *idx; float *dist, *w, *zq;         // out: [n, topk] ids / distances / weights; [n, d] rows with a row stride
+    long n, zq_stride;
+    int k_codes, codes_per_split, splits, row_tiles;
+};
+struct MultiSearchArgs { MultiSearchOne s[MS_MAX]; int count, d, topk; };
+
+__global__ __launch_bounds__(256) void rownorm_multi_kernel(MultiSearchArgs a)
+{
+    const MultiSearchOne &m = a.s[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m.n) return;
+    const int d = a.d;
+    const float *src = m.x + row * d;
+    float *dst = m.xhat + row * d;
+    // (rownorm_kernel<true>, statement for statement: the same bits)
+    float p = 0.f;
+    for (int i = lane * 4; i < d; i += 256) {
+        float4 v = ld4(src + i);
+        p = fmaf(v.x, v.x, p); p = fmaf(v.y, v.y, p); p = fmaf(v.z, v.z, p); p = fmaf(v.w, v.w, p);
+    }
+    const float nrm = sqrtf(wave_butterfly_sum(p));
+    const float den = fmaxf(nrm, 1e-12f);
+    p = 0.f;
+    for (int i = lane * 4; i < d; i += 256) {
+        float4 v = ld4(src + i);
+        v.x = v.x / den; v.y = v.y / den; v.z = v.z / den; v.w = v.w / den;
+        st4(dst + i, v);
+        p = fmaf(v.x, v.x, p); p = fmaf(v.y, v.y, p); p = fmaf(v.z, v.z, p); p = fmaf(v.w, v.w, p);
+    }
+    p = wave_butterfly_sum(p);
+    if (lane == 0) m.xsq[row] = p;
+}
+
+template <int TOPK, bool KTAIL>
+__global__ __launch_bounds__(256, S_WPS) void search_f32_multi_kernel(MultiSearchArgs a)
+{
+    const MultiSearchOne &m = a.s[blockIdx.z];
+    if ((int)blockIdx.x >= m.row_tiles || (int)blockIdx.y >= m.splits) return;
+    search_f32_body<TOPK, false, KTAIL, false>(m.xhat, m.xsq, m.what, m.wsq, m.n, m.k_codes, a.d, m.codes_per_split, a.topk, m.pval, m.pidx,
+                                               (int64_t *)nullptr, (float *)nullptr, (const int *)nullptr, (const int *)nullptr, 0, 0,
+                                               blockIdx.x, blockIdx.y);
 }
 
 // Joins the per-split candidate lists of one row: 8 lanes per row, each folds every 8th split, then three shuffle rounds.
@@ -1337,6 +1404,174 @@ extern "C" int medtok_soft_assign_f32(const float *xref, const float *what, cons
                        xref, what, idx, dist, (long)n, d, topk, flags, w, zq_ste, (long)zq_stride, row_sqerr,
                        (const int *)nullptr, (const int *)nullptr);
     return check_launch("soft_assign");
+}
+
+// ================================================================= several small searches, batched (kernels next to search_f32_kernel)
+// Joins the per-split lists of a row (merge_topk_kernel<T, 64>: a wavefront per row, (d, index) total order) and does the row's soft
+// assignment at once (soft_assign_kernel's arithmetic on the values it would have read back: the same bits).
+template <int TOPK>
+__global__ __launch_bounds__(256) void merge_assign_multi_kernel(MultiSearchArgs a)
+{
+    const MultiSearchOne &m = a.s[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m.n) return;
+    const int d = a.d, topk = a.topk;
+    float bv[TOPK];
+    int bi[TOPK];
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j) { bv[j] = INFINITY; bi[j] = 0x7fffffff; }
+    for (int sp = lane; sp < m.splits; sp += 64) {
+        const long base = ((long)sp * m.n + row) * TOPK;
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) topk_insert_lex<TOPK>(bv, bi, m.pval[base + j], m.pidx[base + j]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float pv[TOPK];
+        int pi[TOPK];
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) { pv[j] = __shfl_xor(bv[j], off, 64); pi[j] = __shfl_xor(bi[j], off, 64); }
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) topk_insert_lex<TOPK>(bv, bi, pv[j], pi[j]);
+    }
+    long cj[TOPK];
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j) cj[j] = valid_code(bi[j], j, m.k_codes);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j)
+            if (j < topk) { m.idx[row * topk + j] = cj[j]; m.dist[row * topk + j] = bv[j]; }
+    }
+    float wj[TOPK];
+    const float mx = -bv[0];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j)
+        if (j < topk) { wj[j] = expf(-bv[j] - mx); sum += wj[j]; }
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j)
+        if (j < topk) wj[j] = wj[j] / sum;
+    if (m.w && lane < topk) {
+        float v = wj[0];
+#pragma unroll
+        for (int j = 1; j < TOPK; ++j) v = (lane == j) ? wj[j] : v;
+        m.w[row * topk + lane] = v;
+    }
+    const float *xr = m.x + row * d;
+    float *out = m.zq + row * m.zq_stride;
+    for (int i = lane * 4; i < d; i += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j)
+            if (j < topk) {
+                const float4 e = ld4(m.what + cj[j] * d + i);
+                acc.x = fmaf(wj[j], e.x, acc.x); acc.y = fmaf(wj[j], e.y, acc.y);
+                acc.z = fmaf(wj[j], e.z, acc.z); acc.w = fmaf(wj[j], e.w, acc.w);
+            }
+        const float4 x = ld4(xr + i);
+        st4(out + i, make_float4(x.x + (acc.x - x.x), x.y + (acc.y - x.y), x.z + (acc.z - x.z), x.w + (acc.w - x.w)));
+    }
+}
+
+constexpr int64_t MS_MAX_ROWS = 4096;
+
+extern "C" int medtok_soft_vq_multi_eligible(int64_t n, int64_t k_codes, int d, int topk)
+{
+    return n >= 1 && n <= MS_MAX_ROWS && k_codes >= 1 && k_codes < (1ll << 31) && d > 0 && !(d & 3) && topk >= 1 && topk <= MEDTOK_MAX_TOPK &&
+           topk <= k_codes && resolve_path(MEDTOK_PATH_AUTO, n, k_codes, d, topk) == MEDTOK_PATH_F32_MFMA;
+}
+
+// code splits of every search of a batched call: about two rounds' worth of blocks over the whole call (two 256-thread blocks are
+// resident per CU), every search's code tiles cut into splits of equal length
+static void multi_plan(const medtok_search_desc *descs, int count, int *splits, int *cps)
+{
+    const DevInfo di = dev_info();
+    long tiles_total = 0;
+    for (int i = 0; i < count; ++i) tiles_total += ((descs[i].n + S_BN - 1) / S_BN) * ((descs[i].k_codes + S_BM - 1) / S_BM);
+    const long per_block = lmax(1, (tiles_total + 2L * di.cus - 1) / (2L * di.cus));
+    for (int i = 0; i < count; ++i) {
+        const long code_tiles = (descs[i].k_codes + S_BM - 1) / S_BM;
+        const long tps = lmin(per_block, code_tiles);
+        cps[i] = (int)(tps * S_BM);
+        splits[i] = (int)((code_tiles + tps - 1) / tps);
+    }
+}
+
+extern "C" size_t medtok_soft_vq_forward_multi_workspace_bytes(const medtok_search_desc *descs, int count, int d, int topk)
+{
+    if (!descs || count < 1 || count > MS_MAX) return 0;
+    int splits[MS_MAX], cps[MS_MAX];
+    multi_plan(descs, count, splits, cps);
+    const int tslots = topk == 1 ? 1 : (topk <= 5 ? 5 : 8);
+    size_t total = 0;
+    for (int i = 0; i < count; ++i) {
+        const size_t n = (size_t)(descs[i].n > 0 ? descs[i].n : 1);
+        total += align_up(n * 4, 256) + 2 * align_up((size_t)splits[i] * n * tslots * 4, 256);
+    }
+    return total + 256;
+}
+
+extern "C" int medtok_soft_vq_forward_multi_f32(const medtok_search_desc *descs, int count, int d, int topk, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!descs || count < 1 || count > MS_MAX) return fail("soft_vq_forward_multi: 1..%d searches per call", MS_MAX);
+    for (int i = 0; i < count; ++i) {
+        const medtok_search_desc &q = descs[i];
+        if (!medtok_soft_vq_multi_eligible(q.n, q.k_codes, d, topk))
+            return fail("soft_vq_forward_multi: search %d (n=%ld K=%ld d=%d topk=%d) does not take the batched exact path", i, (long)q.n, (long)q.k_codes, d, topk);
+        if (!q.x || !q.what || !q.wsq || !q.xhat || !q.idx || !q.dist || !q.zq) return fail("soft_vq_forward_multi: NULL argument in search %d", i);
+        const int64_t zs = q.zq_stride ? q.zq_stride : d;
+        if (zs < d || (zs & 3)) return fail("soft_vq_forward_multi: zq_stride must be >= d and a multiple of 4");
+        if (((uintptr_t)q.x | (uintptr_t)q.what | (uintptr_t)q.xhat | (uintptr_t)q.zq) & 15) return fail("soft_vq_forward_multi: pointers must be 16-byte aligned");
+    }
+    const size_t need = medtok_soft_vq_forward_multi_workspace_bytes(descs, count, d, topk);
+    if (!ws || ws_bytes < need) return fail("soft_vq_forward_multi: workspace too small (%zu < %zu)", ws_bytes, need);
+    int splits[MS_MAX], cps[MS_MAX];
+    multi_plan(descs, count, splits, cps);
+    const int tslots = topk == 1 ? 1 : (topk <= 5 ? 5 : 8);
+    MultiSearchArgs a;
+    memset(&a, 0, sizeof a);
+    a.count = count; a.d = d; a.topk = topk;
+    char *p = (char *)ws;
+    auto take = [&](size_t bytes) { char *q = p; p += align_up(bytes, 256); return (void *)q; };
+    long max_rows = 0;
+    int max_tiles = 0, max_splits = 0;
+    for (int i = 0; i < count; ++i) {
+        const medtok_search_desc &q = descs[i];
+        MultiSearchOne &m = a.s[i];
+        m.x = q.x; m.what = q.what; m.wsq = q.wsq; m.xhat = q.xhat; m.idx = q.idx; m.dist = q.dist; m.w = q.w; m.zq = q.zq;
+        m.n = (long)q.n; m.zq_stride = (long)(q.zq_stride ? q.zq_stride : d);
+        m.k_codes = (int)q.k_codes; m.codes_per_split = cps[i]; m.splits = splits[i]; m.row_tiles = (int)((q.n + S_BN - 1) / S_BN);
+        m.xsq = (float *)take((size_t)q.n * 4);
+        m.pval = (float *)take((size_t)splits[i] * q.n * tslots * 4);
+        m.pidx = (int *)take((size_t)splits[i] * q.n * tslots * 4);
+        max_rows = lmax(max_rows, m.n); max_tiles = max_tiles > m.row_tiles ? max_tiles : m.row_tiles; max_splits = max_splits > m.splits ? max_splits : m.splits;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(rownorm_multi_kernel, dim3((unsigned)((max_rows + 3) / 4), (unsigned)count), dim3(256), 0, s, a);
+    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+    double pflops = 0.0;
+    for (int i = 0; i < count; ++i) pflops += 2.0 * (double)descs[i].n * (double)descs[i].k_codes * (double)d;
+    const dim3 grid((unsigned)max_tiles, (unsigned)max_splits, (unsigned)count);
+#define MEDTOK_MS(T)                                                                                                          \
+    do {                                                                                                                      \
+        if (d % S_BK) {                                                                                                       \
+            (void)set_lds_once<search_f32_multi_kernel<T, true>>(S_LDS_BYTES);                                                \
+            hipLaunchKernelGGL((search_f32_multi_kernel<T, true>), grid, dim3(256), S_LDS_BYTES, s, a);                       \
+        } else {                                                                                                              \
+            (void)set_lds_once<search_f32_multi_kernel<T, false>>(S_LDS_BYTES);                                               \
+            hipLaunchKernelGGL((search_f32_multi_kernel<T, false>), grid, dim3(256), S_LDS_BYTES, s, a);                      \
+        }                                                                                                                     \
+        if (pa) prof_push(pa, prof_mark(s), pflops, 1);                                                                       \
+        hipLaunchKernelGGL((merge_assign_multi_kernel<T>), dim3((unsigned)((max_rows + 3) / 4), (unsigned)count), dim3(256), 0, s, a); \
+    } while (0)
+    switch (tslots) {
+    case 1: MEDTOK_MS(1); break;
+    case 5: MEDTOK_MS(5); break;
+    default: MEDTOK_MS(8); break;
+    }
+#undef MEDTOK_MS
+    return check_launch("soft_vq_forward_multi");
 }
 
 // ================================================================= fixed-order fp64 sum
@@ -2436,6 +2671,87 @@ extern "C" int medtok_usage_update(float *window, int64_t window_len, const int6
     hipLaunchKernelGGL(usage_mark_kernel, dim3(blocks), dim3(256), 0, s, tmp, (long)window_len, (long)n_codes, window, flags);
     hipLaunchKernelGGL(usage_sum_kernel, dim3(1), dim3(1024), 0, s, flags, (long)n_codes + 1, count_out);
     return check_launch("usage_update");
+}
+
+// ---- the forward's three to five window updates (:241-250: shared, text, graph, and the aug views') in ONE call of two launches
+// (twelve to twenty before: each update a memset and three launches over the 300 000-entry window).  Conceptually the updates slide
+// one window over U = [old window | ids_1 | ids_2 | ...]: after update u the window is U[off_u, off_u + W), off_u = m_1 + ... + m_u.
+// One pass over U marks every entry in the flag map of each update whose window holds it and writes the final window
+// U[M, M + W) to scratch; a second pass copies it back and sums the maps.  Same values as the updates one by one.
+constexpr int USAGE_MULTI_MAX = 6;
+struct UsageMultiArgs { const int64_t *ids[USAGE_MULTI_MAX]; long m[USAGE_MULTI_MAX]; int count; };
+
+__global__ __launch_bounds__(256) void usage_multi_mark_kernel(const float *__restrict__ win, long wlen, UsageMultiArgs a, long n_codes,
+                                                               float *__restrict__ tmp, unsigned char *__restrict__ flags)
+{
+    long total = 0;
+    for (int u = 0; u < a.count; ++u) total += a.m[u];
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < wlen + total; p += (long)gridDim.x * 256) {
+        float v;
+        if (p < wlen) v = win[p];
+        else {
+            long q = p - wlen;
+            int u = 0;
+            while (q >= a.m[u]) { q -= a.m[u]; ++u; }
+            v = (float)a.ids[u][q];
+        }
+        long c = (long)v;
+        if (c < 0 || c >= n_codes) c = n_codes;
+        long off = 0;
+        for (int u = 0; u < a.count; ++u) {
+            off += a.m[u];
+            if (p >= off && p < off + wlen) flags[(long)u * (n_codes + 1) + c] = 1;
+        }
+        if (p >= total) tmp[p - total] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void usage_multi_finish_kernel(const float *__restrict__ tmp, long wlen, float *__restrict__ win,
+                                                                 const unsigned char *__restrict__ flags, long n_codes, int count, int *__restrict__ counts)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < wlen; i += (long)gridDim.x * 256) win[i] = tmp[i];
+    const int lane = threadIdx.x & 63;
+    for (int u = 0; u < count; ++u) {
+        int part = 0;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_codes + 1; i += (long)gridDim.x * 256) part += flags[(long)u * (n_codes + 1) + i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (lane == 0 && part) atomicAdd(&counts[u], part);                // (integer: exact in any order)
+    }
+}
+
+extern "C" size_t medtok_usage_multi_workspace_bytes(int64_t window_len, int64_t n_codes, int count)
+{
+    if (window_len <= 0 || n_codes <= 0 || count < 1 || count > USAGE_MULTI_MAX) return 0;
+    return align_up((size_t)window_len * 4, 256) + align_up((size_t)count * ((size_t)n_codes + 1), 256);
+}
+
+extern "C" int medtok_usage_update_multi(float *window, int64_t window_len, const int64_t *const *ids, const int64_t *m, int count, int64_t n_codes,
+                                         int32_t *counts_out, void *ws, size_t ws_bytes, void *stream)
+{
+    if (window_len <= 0 || n_codes <= 0 || count < 1 || count > USAGE_MULTI_MAX || !ids || !m || !counts_out || !window)
+        return fail("usage_update_multi: bad args (1..%d updates)", USAGE_MULTI_MAX);
+    const size_t need = medtok_usage_multi_workspace_bytes(window_len, n_codes, count);
+    if (!ws || ws_bytes < need) return fail("usage_update_multi: workspace too small (%zu < %zu)", ws_bytes, need);
+    UsageMultiArgs a;
+    a.count = count;
+    long total = 0;
+    for (int u = 0; u < USAGE_MULTI_MAX; ++u) {
+        a.ids[u] = u < count ? ids[u] : nullptr;
+        a.m[u] = u < count ? (long)m[u] : 0;
+        if (u < count && (m[u] < 0 || (m[u] > 0 && !ids[u]))) return fail("usage_update_multi: update %d has no ids", u);
+        total += a.m[u];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float *tmp = (float *)ws;
+    unsigned char *flags = (unsigned char *)ws + align_up((size_t)window_len * 4, 256);
+    if (hipMemsetAsync(flags, 0, (size_t)count * ((size_t)n_codes + 1), s) != hipSuccess) return fail("usage_update_multi: memset failed");
+    if (hipMemsetAsync(counts_out, 0, (size_t)count * 4, s) != hipSuccess) return fail("usage_update_multi: memset failed");
+    const unsigned blocks = (unsigned)lmin(1024, (window_len + total + 255) / 256);
+    hipLaunchKernelGGL(usage_multi_mark_kernel, dim3(blocks), dim3(256), 0, s, window, (long)window_len, a, (long)n_codes, tmp, flags);
+    hipLaunchKernelGGL(usage_multi_finish_kernel, dim3((unsigned)lmin(256, (window_len + 255) / 256)), dim3(256), 0, s, tmp, (long)window_len, window, flags,
+                       (long)n_codes, count, counts_out);
+    return check_launch("usage_update_multi");
 }
 
 // ================================================================= one-call soft VQ forward

@@ -708,6 +708,67 @@ def usage_update_(window: torch.Tensor, ids: torch.Tensor, n_codes: int) -> torc
     return count
 
 
+def multi_search_eligible(n: int, k_codes: int, d: int, topk: int) -> bool:
+    """may this search go into a soft_vq_forward_multi call (small: the exact fp32-MFMA path, at most 4096 rows)?"""
+    return bool(_lib.load().medtok_soft_vq_multi_eligible(int(n), int(k_codes), int(d), int(topk)))
+
+
+def soft_vq_forward_multi(searches, topk: int):
+    """Several small soft top-k searches in one C call and three launches (include/medtok_vq.h: medtok_soft_vq_forward_multi_f32).
+    searches: list of dict(x [n, d] fp32, what [K, d], wsq [K], out = optional [n, d] view for zq); every entry must be
+    multi_search_eligible.  Returns a list of dict(xhat, idx, dist, w, zq, row_sqerr=None) -- the bits of soft_vq_forward per entry."""
+    import ctypes as C
+    lib = _lib.load()
+    count = len(searches)
+    if not 1 <= count <= _lib.MULTI_SEARCH_MAX:
+        raise ValueError(f"soft_vq_forward_multi: 1..{_lib.MULTI_SEARCH_MAX} searches per call")
+    descs = (_lib.SearchDesc * count)()
+    outs, keep = [], []
+    d = None
+    for i, q in enumerate(searches):
+        x, what, wsq = _dev(q["x"], "x"), _dev(q["what"], "what"), _dev(q["wsq"], "wsq")
+        n, di = x.shape
+        d = di if d is None else d
+        if di != d or what.shape[1] != d:
+            raise ValueError("soft_vq_forward_multi: all searches share one width")
+        dev = x.device
+        xhat = torch.empty_like(x)
+        idx = torch.empty((n, topk), dtype=torch.int64, device=dev)
+        dist = torch.empty((n, topk), dtype=torch.float32, device=dev)
+        w = torch.empty((n, topk), dtype=torch.float32, device=dev)
+        zq, zstride = _zq_out(q.get("out"), n, d, x)
+        keep.append((x, what, wsq))
+        descs[i] = _lib.SearchDesc(x.data_ptr(), n, what.data_ptr(), wsq.data_ptr(), what.shape[0], xhat.data_ptr(), idx.data_ptr(), dist.data_ptr(),
+                                   w.data_ptr(), zq.data_ptr(), zstride)
+        outs.append(dict(xhat=xhat, idx=idx, dist=dist, w=w, zq=zq, row_sqerr=None))
+    ws = _ws(lib.medtok_soft_vq_forward_multi_workspace_bytes(descs, count, d, topk), keep[0][0])
+    with torch.cuda.device(keep[0][0].device):
+        _lib.check(lib.medtok_soft_vq_forward_multi_f32(descs, count, d, topk, ws.data_ptr(), ws.numel(), _stream(keep[0][0])),
+                   "medtok_soft_vq_forward_multi_f32")
+    return outs
+
+
+def usage_update_multi_(window: torch.Tensor, ids_list, n_codes: int) -> torch.Tensor:
+    """usage_update_ for several id sets appended in order, in two launches: int32 [len(ids_list)] device tensor of the distinct-value
+    counts after each update (no host sync)."""
+    import ctypes as C
+    if not (window.is_cuda and window.dtype == torch.float32 and window.is_contiguous()):
+        raise _lib.MedTokLibraryError("usage_update_multi_: window must be a contiguous fp32 device tensor")
+    count = len(ids_list)
+    if not 1 <= count <= _lib.USAGE_MULTI_MAX:
+        raise ValueError(f"usage_update_multi_: 1..{_lib.USAGE_MULTI_MAX} updates per call")
+    ids = [_dev(t.reshape(-1), "ids", torch.int64) for t in ids_list]
+    ptrs = (C.c_void_p * count)(*[t.data_ptr() for t in ids])
+    ms = (C.c_int64 * count)(*[t.numel() for t in ids])
+    lib = _lib.load()
+    counts = torch.empty(count, dtype=torch.int32, device=window.device)
+    ws = _ws(lib.medtok_usage_multi_workspace_bytes(window.numel(), n_codes, count), window)
+    with torch.cuda.device(window.device):
+        _lib.check(lib.medtok_usage_update_multi(window.data_ptr(), window.numel(), ptrs, ms, count, n_codes, counts.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 _stream(window)), "medtok_usage_update_multi")
+    return counts
+
+
 def normalized_search(z, what, wsq, topk: int = 1, path: int = PATH_AUTO):
     """(zhat, |zhat|^2, idx [n, topk], dist [n, topk]): F.normalize(z) and its nearest codes in one C call -- the head of
     NormEMAVectorQuantizer.forward (norm_ema_quantizer.py:169-179).  Same bits as rownorm() + topk_search()."""

@@ -71,6 +71,10 @@ SMALL_WIDTH_FUSED = True
 # inference: the two shared searches of a forward as ONE search over the interleaved rows [text_0, graph_0, text_1, ...] (one
 # codebook pass, twice the rows per launch; its [2 B, e] result IS the [B, 2 e] shared embedding)
 MERGE_SHARED_SEARCHES = True
+# inference on small batches (every search of the forward on the exact fp32 path with at most 4096 rows: ops.multi_search_eligible):
+# the forward's three to five searches in ONE call of three launches (ops.soft_vq_forward_multi) and its three to five updates of
+# the usage window in one call of two (ops.usage_update_multi_)
+BATCHED_SMALL_SEARCHES = True
 from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
@@ -1147,11 +1151,76 @@ class VectorQuantizer(nn.Module):
             return count
         return count.item() / self.n_e
 
+    def _forward_small_batch(self, z, text_features, graph_node_features, text_attention_mask, batch, z_aug, norm):
+        """forward() at inference for batches whose searches all take the exact path with few rows (a serving batch; the reference's
+        own per-GPU batch of 256): cross-attention, then ALL searches of the forward in one call of three launches, then all updates
+        of the usage window in one call of two.  Same values as the general form below; None when it does not apply."""
+        bsz, e, k = z.shape[0], self.e_dim, self.k
+        if not (BATCHED_SMALL_SEARCHES and not self.training and not torch.is_grad_enabled() and z.is_cuda and bsz > 0 and self.e_dim % 4 == 0
+                and not torch.is_autocast_enabled()):
+            return None
+        region = self.codebook.weight.shape[0] // 3
+        if not (ops.multi_search_eligible(bsz, region, e, k) and ops.multi_search_eligible(2 * bsz, self.n_e, e, k)):
+            return None
+        what, wsq = norm
+        z_text, z_graph = torch.split(z, self.split, dim=-1)
+        aug = (None, None) if z_aug is None else torch.split(z_aug, self.split, dim=-1)
+        emb = torch.empty((bsz, 2 * e), dtype=torch.float32, device=z.device)
+        if self.cross_attn.small_eligible(text_features, graph_node_features):
+            both = self.cross_attn.pooled_small(text_features, text_attention_mask, graph_node_features, batch)
+        else:
+            pooled_text, pooled_graph = self.cross_attn.pooled(text_features, text_attention_mask, graph_node_features, batch)
+            both = torch.stack((pooled_text.float(), pooled_graph.float()), dim=1)
+        searches = [dict(x=both.view(2 * bsz, e), what=what, wsq=wsq, out=emb.view(2 * bsz, e))]
+        kinds = ["text", "graph"] + (["text", "graph"] if z_aug is not None else [])
+        for x, types in zip((z_text, z_graph) + (tuple(aug) if z_aug is not None else ()), kinds):
+            lo, hi = self._region(types)
+            searches.append(dict(x=self.project(x, types).float(), what=what[lo:hi], wsq=wsq[lo:hi].contiguous()))
+        res = ops.soft_vq_forward_multi(searches, k)
+        sh = res[0]
+        xhat_s, idx_s, w_s = sh["xhat"].view(bsz, 2, e), sh["idx"].view(bsz, 2, k), sh["w"].view(bsz, 2, k)
+        zero = torch.tensor(0.0)
+        u_shared = u_text = u_graph = 0.0
+        if self.show_usage:
+            cnt = ops.usage_update_multi_(self.codebook_used, [idx_s.reshape(bsz, 2 * k)] + [r["idx"] for r in res[1:]], self.n_e)
+            st = getattr(self.cross_attn, "small_status", None)
+            if st is not None and st.device == cnt.device:        # one read: the usage counts and the small-width path's status word
+                vals = torch.cat([cnt[:3], st[:1]]).cpu()
+                if int(vals[3]):
+                    self.cross_attn.check_small_status()
+            else:
+                vals = cnt[:3].cpu()
+            u_shared, u_text, u_graph = (vals[:3].double() / self.n_e).tolist()
+        out = {
+            "graph_feature": z_graph,
+            "text_feature": z_text,
+            "shared_text_embedding": emb[:, :e],
+            "shared_graph_embedding": emb[:, e:],
+            "shared_embed_loss": (zero + zero, zero + zero, xhat_s[:, 0], xhat_s[:, 1], emb[:, :e], emb[:, e:]),
+            "shared_codebook_usage": u_shared,
+            "specific_embedding_text": res[1]["zq"],
+            "text_specific_loss": (torch.tensor(0.0), torch.tensor(0.0), res[1]["xhat"], res[1]["zq"]),
+            "text_specific_usage": u_text,
+            "specific_embedding_graph": res[2]["zq"],
+            "graph_specific_loss": (torch.tensor(0.0), torch.tensor(0.0), res[2]["xhat"], res[2]["zq"]),
+            "graph_specific_usage": u_graph,
+            "specific_embedding_text_aug": res[3]["zq"] if z_aug is not None else None,
+            "specific_embedding_graph_aug": res[4]["zq"] if z_aug is not None else None,
+            "shared_text_tokens": idx_s[:, 0], "shared_text_tokens_weights": w_s[:, 0],
+            "shared_graph_tokens": idx_s[:, 1], "shared_graph_tokens_weights": w_s[:, 1],
+            "text_tokens": res[1]["idx"], "text_tokens_weights": res[1]["w"],
+            "graph_tokens": res[2]["idx"], "graph_tokens_weights": res[2]["w"],
+        }
+        return out
+
     def forward(self, z, text_features, graph_node_features, text_attention_mask, batch, z_aug=None):
         counts = []                     # the usage counts stay on the device: one sync at the end
         # one normalisation of the codebook per forward (training: re-normalised every forward, like the reference's every call;
         # eval: the cache per weight version), shared by its 4-6 searches
         norm = self._normalised_codebook(rebuild=self.training)
+        small = self._forward_small_batch(z, text_features, graph_node_features, text_attention_mask, batch, z_aug, norm)
+        if small is not None:
+            return small
         z_text_embedding, z_graph_embedding = torch.split(z, self.split, dim=-1)
         aug = (None, None) if z_aug is None else torch.split(z_aug, self.split, dim=-1)
         early = None

@@ -156,3 +156,78 @@ def test_forward_replayed_from_a_hip_graph_is_bit_equal_to_eager(dev):
         vq.cross_attn.check_small_status()
     for k in keys:
         assert torch.equal(replayed[k], eager[k]), k
+
+
+@pytest.mark.parametrize("d,topk", [(64, 5), (64, 1), (768, 5), (40, 8), (128, 2)])
+def test_batched_small_searches_equal_the_single_calls(dev, d, topk):
+    """ops.soft_vq_forward_multi (three launches for all searches) against ops.soft_vq_forward per search: every output, bit for bit --
+    ragged code counts, a region slice of a larger codebook, widths that are not a multiple of the k block, a [2B, d] view output."""
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(100 + d + topk)
+    W = torch.randn(3000 if d > 64 else 21000, d, device=dev, generator=g)
+    what, wsq = ops.rownorm(W)
+    region = W.shape[0] // 3
+    shapes = [(512, 0, W.shape[0]), (256, 0, region), (256, W.shape[0] - region, W.shape[0]), (1, 5, 5 + max(topk, 130)), (77, 0, 129)]
+    emb = torch.empty(256, 2 * d, device=dev)
+    searches, singles = [], []
+    for i, (n, lo, hi) in enumerate(shapes):
+        x = torch.randn(n, d, device=dev, generator=g)
+        assert ops.multi_search_eligible(n, hi - lo, d, topk)
+        out = emb.view(512, d) if i == 0 else None
+        searches.append(dict(x=x, what=what[lo:hi], wsq=wsq[lo:hi].contiguous(), out=out))
+    res = ops.soft_vq_forward_multi(searches, topk)
+    zq0 = res[0]["zq"].clone()
+    for q, r in zip(searches, res):
+        one = ops.soft_vq_forward(q["x"], q["what"], q["wsq"], topk, want_sqerr=False)
+        for key in ("xhat", "idx", "dist", "w"):
+            assert torch.equal(one[key], r[key]), (key, q["x"].shape, q["what"].shape)
+        assert torch.equal(one["zq"], r["zq"] if q["out"] is None else zq0), ("zq", q["x"].shape)
+        exact = ops.topk_search(*ops.rownorm(q["x"]), q["what"], q["wsq"], topk, ops.PATH_F32_MFMA)
+        assert torch.equal(exact[0], r["idx"]) and torch.equal(exact[1], r["dist"])
+
+
+def test_batched_usage_updates_equal_the_updates_one_by_one(dev):
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    for wlen, sizes, n_codes in ((300000, (2560, 1280, 1280), 21000), (1000, (300, 800, 1500, 7, 1), 50), (64, (10, 0, 3), 9)):
+        win_a = torch.randint(0, n_codes, (wlen,), device=dev, generator=g).float()
+        win_a[: wlen // 3] = 0.0
+        win_b = win_a.clone()
+        ids = [torch.randint(0, n_codes, (m,), device=dev, generator=g) for m in sizes]
+        one_by_one = [int(ops.usage_update_(win_a, t, n_codes).item()) for t in ids]
+        together = ops.usage_update_multi_(win_b, ids, n_codes).cpu().tolist()
+        assert together == one_by_one, (wlen, sizes)
+        assert torch.equal(win_a, win_b)
+
+
+@pytest.mark.parametrize("aug", [False, True])
+def test_small_batch_forward_equals_the_general_forward(dev, aug):
+    """the B = 256 forward through ONE batched search call + ONE usage call against the per-search form: every tensor of the dict bit
+    for bit, the usage floats and the window too (show_usage = True: the reference's default, tokenizer.py:72)."""
+    import medtok_amd.vector_quantization_soft_one_new as vqmod
+    inp = list(_forward_inputs(dev))
+    if aug:
+        inp.append(inp[0] + 0.05 * torch.randn_like(inp[0]))
+    outs, wins = [], []
+    for batched in (True, False):
+        vq = _quantizer(dev, show_usage=True)
+        keep = vqmod.BATCHED_SMALL_SEARCHES
+        vqmod.BATCHED_SMALL_SEARCHES = batched
+        try:
+            with torch.no_grad():
+                outs.append([vq(*inp), vq(*inp)][1])           # (twice: the window carries state from call to call)
+        finally:
+            vqmod.BATCHED_SMALL_SEARCHES = keep
+        wins.append(vq.codebook_used.clone())
+    a, b = outs
+    assert list(a) == list(b)
+    for k in a:
+        x, y = a[k], b[k]
+        if isinstance(x, torch.Tensor):
+            assert torch.equal(x, y), k
+        elif isinstance(x, tuple):
+            for i, (p, q) in enumerate(zip(x, y)):
+                assert torch.equal(p, q), (k, i)
+        else:
+            assert x == y, k
+    assert torch.equal(wins[0], wins[1])
