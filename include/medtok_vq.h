@@ -82,6 +82,7 @@ typedef struct medtok_search_desc {
     const float *x; int64_t n;
     const float *what, *wsq; int64_t k_codes;
     float *xhat; int64_t *idx; float *dist, *w, *zq; int64_t zq_stride;
+    int64_t x_stride;                       /* row stride of x in floats (0 = d): x may be a column block of a wider matrix */
 } medtok_search_desc;
 #define MEDTOK_MULTI_SEARCH_MAX 6
 int medtok_soft_vq_multi_eligible(int64_t n, int64_t k_codes, int d, int topk);

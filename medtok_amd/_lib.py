@@ -122,7 +122,7 @@ class MedTokLibraryError(RuntimeError):
 class SearchDesc(C.Structure):
     """medtok_search_desc (include/medtok_vq.h)"""
     _fields_ = [("x", _vp), ("n", _i64), ("what", _vp), ("wsq", _vp), ("k_codes", _i64), ("xhat", _vp), ("idx", _vp), ("dist", _vp), ("w", _vp),
-                ("zq", _vp), ("zq_stride", _i64)]
+                ("zq", _vp), ("zq_stride", _i64), ("x_stride", _i64)]
 
 
 MULTI_SEARCH_MAX = 6

@@ -59,13 +59,23 @@ __device__ __forceinline__ float xs_other_half(float v, int lh)
 
 __device__ __forceinline__ float xs_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
-// first index i in [0, n) with batch[i] >= v (batch non-decreasing)
+// first index i in [0, n) with batch[i] >= v (batch non-decreasing), by a whole wavefront: every round the 64 lanes probe 64 evenly
+// spaced positions of the remaining range at once (one memory round trip narrows it 65-fold: 5 000 nodes take two rounds, where a
+// binary search makes thirteen dependent loads).  All lanes return the same value.
 __device__ __forceinline__ long xs_lower_bound(const int64_t *__restrict__ batch, long n, long v)
 {
-    long lo = 0, hi = n;
-    while (lo < hi) {
-        const long mid = (lo + hi) >> 1;
-        if (batch[mid] < v) lo = mid + 1; else hi = mid;
+    const int lane = threadIdx.x & 63;
+    long lo = 0, hi = n;                       // answer in [lo, hi]
+    while (hi - lo > 0) {
+        const long span = hi - lo, step = (span + 63) / 64;
+        const long pos = lo + (long)lane * step;                        // lane's probe (positions >= hi count as "not less")
+        const bool less = pos < hi && batch[pos] < v;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(less);
+        const int cnt = __builtin_popcountll(m);                      // probes 0 .. cnt-1 are < v (monotone)
+        if (cnt == 0) { hi = lo; break; }
+        const long last_less = lo + (long)(cnt - 1) * step;
+        lo = last_less + 1;
+        hi = min(hi, last_less + step);
     }
     return lo;
 }
@@ -82,9 +92,8 @@ __global__ __launch_bounds__(256, 2) void cross_attention64_kernel(XSmallArgs a)
     __shared__ __attribute__((aligned(16))) float s_kv[4][32][XS_LD];         // one key chunk per wave; after the key loop: its partial contexts
     __shared__ __attribute__((aligned(16))) float s_part[4][XS_G][XS_D];      // cross-wave partial sums of the dense steps
     __shared__ float s_ml[4][2][XS_ROWS];                                     // per wave: running maximum, running sum
-    __shared__ long s_seg[XS_G + 1][3];                                        // segments of the tile: code, first local row, rows
+    __shared__ long s_seg[XS_G + 1][5];                                        // segments of the tile: code, first local row, rows, keys, first key row
     __shared__ int s_nseg;
-    __shared__ int s_cnt[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -125,6 +134,30 @@ __global__ __launch_bounds__(256, 2) void cross_attention64_kernel(XSmallArgs a)
     }
     __syncthreads();
     const int nseg = s_nseg;
+
+    // ---- the key set of every segment, once for both layers: graph side -> the code's valid text rows (its token count = the non-zero
+    // entries of its mask row: wave w counts segments w, w + 4, ...); text side -> the code's nodes (their range in the batch vector)
+    if (text_side) {
+        if (wv == 0) {
+            const long code = s_seg[0][0];
+            const long lo = xs_lower_bound(a.batch, N, code), hi = xs_lower_bound(a.batch, N, code + 1);
+            if (lane == 0) { s_seg[0][3] = hi - lo; s_seg[0][4] = lo; }
+        }
+    } else {
+        for (int sg = wv; sg < nseg; sg += 4) {
+            const char *mrow = reinterpret_cast<const char *>(a.mask) + s_seg[sg][0] * L * a.mask_bytes;
+            int cnt = 0;
+            for (long i = lane; i < L; i += 64) {
+                const bool nz = a.mask_bytes == 1 ? mrow[i] != 0 : (a.mask_bytes == 4 ? reinterpret_cast<const int *>(mrow)[i] != 0
+                                                                                       : reinterpret_cast<const long *>(mrow)[i] != 0);
+                cnt += nz ? 1 : 0;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+            if (lane == 0) { s_seg[sg][3] = cnt; s_seg[sg][4] = 0; }
+        }
+    }
+    __syncthreads();
 
     // ---- MFMA helpers (v_mfma_f32_32x32x2_f32: A [32 x 2], B [2 x 32]; lane (i, k) holds A[i][k] / B[k][i])
     const float *kvw = &s_kv[wv][0][0];
@@ -188,31 +221,8 @@ __global__ __launch_bounds__(256, 2) void cross_attention64_kernel(XSmallArgs a)
 
         for (int sg = 0; sg < nseg; ++sg) {
             const long code = s_seg[sg][0];
-            // the key set of this pass: graph side -> the code's valid text rows; text side -> the code's nodes
-            const float *kbase;
-            long klen;
-            if (text_side) {
-                const long lo = xs_lower_bound(a.batch, N, code), hi = xs_lower_bound(a.batch, N, code + 1);
-                kbase = a.nodes + lo * XS_D;
-                klen = hi - lo;
-            } else {
-                // token count of the code: non-zero entries of its mask row (left-aligned), counted by the whole block
-                if (tid < 4) s_cnt[tid] = 0;
-                __syncthreads();
-                int cnt = 0;
-                const char *mrow = reinterpret_cast<const char *>(a.mask) + code * L * a.mask_bytes;
-                for (long i = tid; i < L; i += 256) {
-                    const bool nz = a.mask_bytes == 1 ? mrow[i] != 0 : (a.mask_bytes == 4 ? reinterpret_cast<const int *>(mrow)[i] != 0
-                                                                                           : reinterpret_cast<const long *>(mrow)[i] != 0);
-                    cnt += nz ? 1 : 0;
-                }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-                if (lane == 0) s_cnt[wv] = cnt;
-                __syncthreads();
-                klen = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-                kbase = a.text + code * L * XS_D;
-            }
+            const long klen = s_seg[sg][3];
+            const float *kbase = text_side ? a.nodes + s_seg[sg][4] * XS_D : a.text + code * L * XS_D;
             const int nchunk = (int)((klen + 31) >> 5);
 
             f32x16 ctx0, ctx1;                   // ctx^T: lane = query row li; registers = columns (r & 3) + 8 (r >> 2) + 4 lh (+ 32 for ctx1)

@@ -661,7 +661,7 @@ struct MultiSearchOne {
     float *xhat, *xsq;                          // out: F.normalize(x) [n, d], its squared norms [n] (scratch)
     float *pval; int *pidx;                     // scratch: per-split lists [splits][n][TOPK]
     int64_t *idx; float *dist, *w, *zq;         // out: [n, topk] ids / distances / weights; [n, d] rows with a row stride
-    long n, zq_stride;
+    long n, zq_stride, x_stride;                // (x rows may be a column block of a wider matrix)
     int k_codes, codes_per_split, splits, row_tiles;
 };
 struct MultiSearchArgs { MultiSearchOne s[MS_MAX]; int count, d, topk; };
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void rownorm_multi_kernel(MultiSearchArgs a)
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= m.n) return;
     const int d = a.d;
-    const float *src = m.x + row * d;
+    const float *src = m.x + row * m.x_stride;
     float *dst = m.xhat + row * d;
     // (rownorm_kernel<true>, statement for statement: the same bits)
     float p = 0.f;
@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(256) void merge_assign_multi_kernel(MultiSearchArgs
         for (int j = 1; j < TOPK; ++j) v = (lane == j) ? wj[j] : v;
         m.w[row * topk + lane] = v;
     }
-    const float *xr = m.x + row * d;
+    const float *xr = m.x + row * m.x_stride;
     float *out = m.zq + row * m.zq_stride;
     for (int i = lane * 4; i < d; i += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1520,8 +1520,8 @@ extern "C" int medtok_soft_vq_forward_multi_f32(const medtok_search_desc *descs,
         if (!medtok_soft_vq_multi_eligible(q.n, q.k_codes, d, topk))
             return fail("soft_vq_forward_multi: search %d (n=%ld K=%ld d=%d topk=%d) does not take the batched exact path", i, (long)q.n, (long)q.k_codes, d, topk);
         if (!q.x || !q.what || !q.wsq || !q.xhat || !q.idx || !q.dist || !q.zq) return fail("soft_vq_forward_multi: NULL argument in search %d", i);
-        const int64_t zs = q.zq_stride ? q.zq_stride : d;
-        if (zs < d || (zs & 3)) return fail("soft_vq_forward_multi: zq_stride must be >= d and a multiple of 4");
+        const int64_t zs = q.zq_stride ? q.zq_stride : d, xs = q.x_stride ? q.x_stride : d;
+        if (zs < d || (zs & 3) || xs < d || (xs & 3)) return fail("soft_vq_forward_multi: zq_stride / x_stride must be >= d and multiples of 4");
         if (((uintptr_t)q.x | (uintptr_t)q.what | (uintptr_t)q.xhat | (uintptr_t)q.zq) & 15) return fail("soft_vq_forward_multi: pointers must be 16-byte aligned");
     }
     const size_t need = medtok_soft_vq_forward_multi_workspace_bytes(descs, count, d, topk);
@@ -1540,7 +1540,7 @@ extern "C" int medtok_soft_vq_forward_multi_f32(const medtok_search_desc *descs,
         const medtok_search_desc &q = descs[i];
         MultiSearchOne &m = a.s[i];
         m.x = q.x; m.what = q.what; m.wsq = q.wsq; m.xhat = q.xhat; m.idx = q.idx; m.dist = q.dist; m.w = q.w; m.zq = q.zq;
-        m.n = (long)q.n; m.zq_stride = (long)(q.zq_stride ? q.zq_stride : d);
+        m.n = (long)q.n; m.zq_stride = (long)(q.zq_stride ? q.zq_stride : d); m.x_stride = (long)(q.x_stride ? q.x_stride : d);
         m.k_codes = (int)q.k_codes; m.codes_per_split = cps[i]; m.splits = splits[i]; m.row_tiles = (int)((q.n + S_BN - 1) / S_BN);
         m.xsq = (float *)take((size_t)q.n * 4);
         m.pval = (float *)take((size_t)splits[i] * q.n * tslots * 4);

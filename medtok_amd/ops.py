@@ -726,20 +726,24 @@ def soft_vq_forward_multi(searches, topk: int):
     outs, keep = [], []
     d = None
     for i, q in enumerate(searches):
-        x, what, wsq = _dev(q["x"], "x"), _dev(q["what"], "what"), _dev(q["wsq"], "wsq")
+        x, what, wsq = q["x"], _dev(q["what"], "what"), _dev(q["wsq"], "wsq")
+        # (x may be a column block of a wider row-major matrix: its row stride travels in the descriptor)
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+                and x.stride(0) >= x.shape[1] and x.data_ptr() % 16 == 0):
+            x = _dev(x, "x")
         n, di = x.shape
         d = di if d is None else d
         if di != d or what.shape[1] != d:
             raise ValueError("soft_vq_forward_multi: all searches share one width")
         dev = x.device
-        xhat = torch.empty_like(x)
+        xhat = torch.empty((n, d), dtype=torch.float32, device=dev)
         idx = torch.empty((n, topk), dtype=torch.int64, device=dev)
         dist = torch.empty((n, topk), dtype=torch.float32, device=dev)
         w = torch.empty((n, topk), dtype=torch.float32, device=dev)
         zq, zstride = _zq_out(q.get("out"), n, d, x)
         keep.append((x, what, wsq))
         descs[i] = _lib.SearchDesc(x.data_ptr(), n, what.data_ptr(), wsq.data_ptr(), what.shape[0], xhat.data_ptr(), idx.data_ptr(), dist.data_ptr(),
-                                   w.data_ptr(), zq.data_ptr(), zstride)
+                                   w.data_ptr(), zq.data_ptr(), zstride, x.stride(0) if n > 1 else d)
         outs.append(dict(xhat=xhat, idx=idx, dist=dist, w=w, zq=zq, row_sqerr=None))
     ws = _ws(lib.medtok_soft_vq_forward_multi_workspace_bytes(descs, count, d, topk), keep[0][0])
     with torch.cuda.device(keep[0][0].device):

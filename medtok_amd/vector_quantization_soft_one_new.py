@@ -997,6 +997,7 @@ class VectorQuantizer(nn.Module):
             layer._medtok_split_cache = None
         self.proj_text._medtok_split_cache = None
         self.proj_graph._medtok_split_cache = None
+        self._medtok_proj_both_cache = None
 
     def train(self, mode: bool = True):
         if mode != self.training:
@@ -1040,6 +1041,29 @@ class VectorQuantizer(nn.Module):
             return ops.split_half(w, dp=w.shape[1], scale=scale), 1.0 / scale, lin.bias.detach().float().contiguous()
         w_split, unscale, bias = _cached(lin, "_medtok_split_cache", key, build, lin.weight.device)
         out, _ = ops.split_gemm(ops.split_half(x), w_split, n_g=lin.out_features, k_g=lin.in_features, bias=bias, unscale=unscale)
+        return out
+
+    def project_both(self, z):
+        """proj_text and proj_graph of z = [text | graph] ([B, 2 e]) as ONE grouped product (two launches: the images of z, the
+        grouped GEMM) instead of two products of two launches each -- the same kernel on the same operands, group by group, as two
+        project() calls.  Returns [B, 2 e] (text projection | graph projection), or None where project()'s split path does not
+        apply (training, autograd, autocast, non-fp32, odd shapes)."""
+        lt, lg = self.proj_text, self.proj_graph
+        e = self.e_dim
+        if (not SPLIT_PRODUCTS or self.training or torch.is_grad_enabled() or torch.is_autocast_enabled() or not z.is_cuda or z.dtype != torch.float32
+                or z.dim() != 2 or z.shape[1] != 2 * e or lt.bias is None or lg.bias is None or e % 32 or not z.is_contiguous()
+                or lt.in_features != e or lg.in_features != e or lt.out_features != e or lg.out_features != e):
+            return None
+        key = tuple((t.data_ptr(), t._version) for t in (lt.weight, lt.bias, lg.weight, lg.bias)) + (lt.weight.device,)
+
+        def build():
+            import math
+            w = torch.cat([lt.weight.detach().float(), lg.weight.detach().float()], 0).contiguous()            # [2 e, e]
+            amax = float(w.abs().max())
+            scale = 2.0 ** (11 - math.floor(math.log2(amax))) if amax > 0.0 and math.isfinite(amax) else 1.0
+            return ops.split_half(w, dp=e, scale=scale), 1.0 / scale, torch.cat([lt.bias.detach().float(), lg.bias.detach().float()]).contiguous()
+        w_split, unscale, bias = _cached(self, "_medtok_proj_both_cache", key, build, lt.weight.device)
+        out, _ = ops.split_gemm(ops.split_half(z, dp=2 * e), w_split, n_g=e, k_g=e, groups=2, a_group_cols=e, b_group_rows=e, bias=bias, unscale=unscale)
         return out
 
     def get_distance(self, x, y):
@@ -1172,10 +1196,12 @@ class VectorQuantizer(nn.Module):
             pooled_text, pooled_graph = self.cross_attn.pooled(text_features, text_attention_mask, graph_node_features, batch)
             both = torch.stack((pooled_text.float(), pooled_graph.float()), dim=1)
         searches = [dict(x=both.view(2 * bsz, e), what=what, wsq=wsq, out=emb.view(2 * bsz, e))]
-        kinds = ["text", "graph"] + (["text", "graph"] if z_aug is not None else [])
-        for x, types in zip((z_text, z_graph) + (tuple(aug) if z_aug is not None else ()), kinds):
-            lo, hi = self._region(types)
-            searches.append(dict(x=self.project(x, types).float(), what=what[lo:hi], wsq=wsq[lo:hi].contiguous()))
+        for zz, parts in ((z, (z_text, z_graph)),) + (((z_aug, aug),) if z_aug is not None else ()):
+            proj = self.project_both(zz)
+            for i, types in enumerate(("text", "graph")):
+                lo, hi = self._region(types)
+                x = proj[:, i * e:(i + 1) * e] if proj is not None else self.project(parts[i], types).float()
+                searches.append(dict(x=x, what=what[lo:hi], wsq=wsq[lo:hi].contiguous()))
         res = ops.soft_vq_forward_multi(searches, k)
         sh = res[0]
         xhat_s, idx_s, w_s = sh["xhat"].view(bsz, 2, e), sh["idx"].view(bsz, 2, k), sh["w"].view(bsz, 2, k)
