@@ -116,20 +116,33 @@ __global__ __launch_bounds__(256, 2) void cross_attention64_kernel(XSmallArgs a)
             const int n = i / XS_D, c = i % XS_D;
             s_x[n][c] = n < n_live ? a.nodes[(row0 + n) * XS_D + c] : 0.f;
         }
-        if (tid == 0) {
-            int ns = 0, bad = 0;
-            long prev = row0 > 0 ? a.batch[row0 - 1] : -0x7fffffffffffffffL;
-            for (int n = 0; n < n_live; ++n) {
-                const long id = a.batch[row0 + n];
-                if (id < prev) bad |= 1;
-                if (id < 0 || id >= B) bad |= 2;
-                const long code = id < 0 ? 0 : (id >= B ? B - 1 : id);
-                if (ns > 0 && s_seg[ns - 1][0] == code) ++s_seg[ns - 1][2];
-                else { s_seg[ns][0] = code; s_seg[ns][1] = n; s_seg[ns][2] = 1; ++ns; }
-                prev = id;
+        if (wv == 0) {
+            // lane n < 8: node n of the tile, lane 8: the node in front of the tile (one load each); a segment starts where the id changes
+            const long node = lane < XS_G ? row0 + lane : row0 - 1;
+            const bool have = lane < XS_G ? lane < n_live : row0 > 0;
+            const long id = have ? a.batch[node] : -0x7fffffffffffffffL;
+            const long prev = __shfl(id, lane == 0 ? XS_G : (lane - 1) & 63, 64);       // (lane 0 looks at the node in front of the tile)
+            const bool live = lane < n_live;
+            int bad = 0;
+            if (live && id < prev) bad |= 1;
+            if (live && (id < 0 || id >= B)) bad |= 2;
+            const long code = id < 0 ? 0 : (id >= B ? B - 1 : id);
+            const long pcode = prev < 0 ? 0 : (prev >= B ? B - 1 : prev);
+            const bool start = live && (lane == 0 || code != pcode);
+            const unsigned long long starts = __builtin_amdgcn_ballot_w64(start);
+            const int sidx = __builtin_popcountll(starts & ((2ull << lane) - 1)) - 1;         // segment of this node
+            if (start) {
+                const unsigned long long later = starts & ~((2ull << lane) - 1);
+                const int next = later ? __builtin_ctzll(later) : n_live;
+                s_seg[sidx][0] = code; s_seg[sidx][1] = lane; s_seg[sidx][2] = next - lane;
             }
-            s_nseg = ns;
-            if (bad) atomicOr(a.status, bad);
+            if (lane == 0) s_nseg = __builtin_popcountll(starts);
+            const unsigned long long anybad = __builtin_amdgcn_ballot_w64(bad != 0);
+            if (anybad) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) bad |= __shfl_xor(bad, off, 64);
+                if (lane == 0) atomicOr(a.status, bad);
+            }
         }
     }
     __syncthreads();
@@ -403,7 +416,16 @@ __global__ __launch_bounds__(256) void cross_attention64_mean_kernel(const float
     if (b >= n_codes) return;
     const int lane = threadIdx.x & 63;
     const long lo = xs_lower_bound(batch, n_nodes, b), hi = xs_lower_bound(batch, n_nodes, b + 1);
+    // (eight loads in flight, added in node order: one ordered chain per column whatever the batching)
     float s = 0.f;
-    for (long r = lo; r < hi; ++r) s += y_nodes[r * XS_D + lane];
+    long r = lo;
+    for (; r + 8 <= hi; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = y_nodes[(r + i) * XS_D + lane];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    for (; r < hi; ++r) s += y_nodes[r * XS_D + lane];
     pooled[b * pooled_stride + graph_off + lane] = hi > lo ? s / (float)(hi - lo) : 0.f;
 }

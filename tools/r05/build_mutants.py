@@ -1,0 +1,79 @@
+"""Dev tool (this container): variant builds of the library made by TEXT SUBSTITUTION on a copy of the sources (the product sources
+carry no build-time switch), into devlib/<name>/libmedtok_vq.so (git-ignored; travels to the GPU box with gpurun).
+
+    python tools/r05/build_mutants.py [name ...]
+
+  nowait     the statement that holds the MFMA -> VALU wait states in front of the filter kernels' epilogues removed
+             (round 4's 335-of-600 000-rows bug): tests/fuzzers.py must FAIL on it
+  d32stage   rows of <= 32 elements padded to 32, not 64, columns and sent to the general filter kernel (one 32-deep stage per code
+             tile: round 4's start-value race): tests/fuzzers.py must FAIL on it
+  halfbar    TIMING ONLY (wrong results): filter_f16_kernel with its stage barrier and copy wait in every OTHER stage only
+  k64emu     TIMING ONLY (wrong results): halfbar + the copies of two stages issued together in every other stage -- the instruction
+             stream of a 64-deep stage (half the barriers, bursts of eight copies per wave) on the 32-deep ring
+  nobar      TIMING ONLY (wrong results): no stage barrier at all
+"""
+import shutil, subprocess, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+from medtok_amd.csrc import build as B
+
+def sub(text, old, new, count=1):
+    assert text.count(old) >= 1, f"pattern not found: {old[:60]!r}"
+    return text.replace(old, new, count)
+
+def mutate(name, src):
+    f = src / "filter_f16.h"
+    t = f.read_text()
+    hip = src / "medtok_vq.hip"
+    h = hip.read_text()
+    if name == "nowait":
+        t = t.replace('asm volatile("s_nop 15\\n\\ts_nop 1"', 'asm volatile(""')
+        assert 's_nop 15' not in t
+    elif name == "d32stage":
+        h = sub(h, "f.dp = (int)lmax(2 * F_BK, (d + F_BK - 1) / F_BK * F_BK);", "f.dp = (int)lmax(F_BK, (d + F_BK - 1) / F_BK * F_BK);")
+    elif name in ("halfbar", "k64emu", "nobar"):
+        old = '''        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        tick(1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        tick(2);'''
+        if name == "nobar":
+            new = '''        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        tick(1);
+        asm volatile("" ::: "memory");
+        tick(2);'''
+        else:
+            new = '''        if (!(s & 1)) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        tick(1);
+        if (!(s & 1)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        tick(2);'''
+        t = sub(t, old, new)
+        if name == "k64emu":
+            t = sub(t, "        if (late && s > 0) stage();         // waves 4-7: stage s+2 (slot s-2, free since the barrier of iteration s-1)",
+                    "        if (late && s > 0 && !(s & 1)) { stage(); stage(); }")
+            t = sub(t, "        if (!late) stage();             // waves 0-3: stage s+3 (slot s-1: everyone is past reading it)",
+                    "        if (!late && !(s & 1)) { stage(); stage(); }")
+    else:
+        raise SystemExit(f"unknown mutant {name}")
+    f.write_text(t); hip.write_text(h)
+
+def main(names):
+    for name in names:
+        out = ROOT / "devlib" / name
+        src = out / "src" / "medtok_amd" / "csrc"
+        if out.exists(): shutil.rmtree(out)
+        src.mkdir(parents=True)
+        for p in B.HERE.glob("*.h"): shutil.copy(p, src / p.name)
+        shutil.copy(B.SRC, src / B.SRC.name)
+        (out / "src" / "include").mkdir()
+        shutil.copy(B.HEADER, out / "src" / "include" / B.HEADER.name)
+        mutate(name, src)
+        so = out / "libmedtok_vq.so"
+        subprocess.check_call([B.hipcc(), *B.FLAGS, str(src / B.SRC.name), "-o", str(so)])
+        shutil.rmtree(out / "src")
+        print("built", so)
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or ["nowait", "d32stage", "halfbar", "k64emu", "nobar"])
