@@ -14,6 +14,12 @@ GOLDEN = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Mutation runs (dev, tools/r05/build_mutants.py): MEDTOK_TEST_LIB=<path> binds a VARIANT BUILD of the library for this test
+    # session -- to record which tests catch a re-introduced bug.  Never set in the driver's runs; the product reads no environment.
+    lib = os.environ.get("MEDTOK_TEST_LIB")
+    if lib:
+        from medtok_amd import _lib
+        _lib.use_library(lib)
 
 
 @pytest.fixture(scope="session")

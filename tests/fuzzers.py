@@ -31,6 +31,9 @@ def fuzz_search(cases=100, seed=0, budget_s=None, max_rows=300000, log=None):
     over, elapsed = _timer(budget_s)
     bad, c = [], 0
     rows_all = [1, 7, 255, 256, 257, 1000, 4097, 20000, 70001, 300000]
+    # every third case is a shape that exposed a past bug: rows of <= 32 elements against many code tiles (round 4's start-value race
+    # of the general kernel showed in ~1 % of such searches: they are what repetition is for)
+    hot = [(4097, 20001, 32, 1), (20000, 20001, 4, 1), (4097, 20001, 32, 5), (4097, 8191, 16, 1), (20000, 16384, 16, 5)]
     for c in range(cases):
         if over():
             break
@@ -38,6 +41,8 @@ def fuzz_search(cases=100, seed=0, budget_s=None, max_rows=300000, log=None):
         K = int(rng.choice([1, 5, 31, 256, 257, 1000, 4096, 8191, 16384, 20001]))
         D = int(rng.choice([4, 16, 32, 60, 64, 100, 128, 260, 768, 1028]))
         k = int(rng.choice([1, 2, 5, 8]))
+        if c % 3 == 2:
+            n, K, D, k = hot[(c // 3) % len(hot)]
         if k > K:
             k = 1
         kind = int(rng.integers(0, 5))
