@@ -97,6 +97,13 @@ size_t medtok_usage_multi_workspace_bytes(int64_t window_len, int64_t n_codes, i
 int medtok_usage_update_multi(float *window, int64_t window_len, const int64_t *const *ids, const int64_t *m, int count, int64_t n_codes,
                               int32_t *counts_out, void *ws, size_t ws_bytes, void *stream);
 
+/* C = unscale * (A . B^T) + bias as ONE half-precision pass with fp32 accumulation: what torch.autocast makes of nn.Linear and of
+ * nn.MultiheadAttention's projections (train_MedTok.py:212,394 -> vector_quantization_soft_one_new.py:30,45,106-107).  a [m, lda] and
+ * b [b_rows, ldb]: fp16 (bf16 = 0) or bf16 (bf16 = 1) matrices; grouping, shapes and alignment as medtok_split_gemm_f16 (k_g % 32 == 0,
+ * strides % 8 == 0, n_g % 4 == 0); c fp32 [m, ldc]. */
+int medtok_half_gemm_f32(const void *a, int64_t m, int lda, int a_group_cols, const void *b, int64_t b_rows, int ldb, int b_group_rows,
+                         int n_g, int k_g, int groups, const float *bias, float unscale, float *c, int ldc, int bf16, void *stream);
+
 /* Shader-clock probe for bench.py: one idle wavefront on each of 8 blocks (one per XCD on the full chip) samples the shader-cycle
  * counter and the constant 100 MHz counter from launch until *stop_flag (a word of PINNED HOST memory the device polls) becomes
  * non-zero, or max_ticks_100mhz ticks have passed, whichever is first; out = uint64 [8][4] (device memory): shader cycles, 100 MHz

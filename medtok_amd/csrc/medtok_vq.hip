@@ -2130,7 +2130,16 @@ extern "C" int medtok_split_half_scaled_f32(const float *src, int64_t n, int d, 
 static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols,
                            const void *b_hi, const void *b_lo, int64_t b_rows, int ldb, int b_group_rows,
                            int n_g, int k_g, int groups, const float *bias, float unscale, const float *amax_a, const float *amax_b,
-                           float *c, int ldc, void *c_hi, void *c_lo, int ldch, void *stream);
+                           float *c, int ldc, void *c_hi, void *c_lo, int ldch, void *stream, int one_pass = 0);
+
+// C = unscale * (A . B^T) + bias in ONE half-precision pass with fp32 accumulation: a [m, lda], b [b_rows, ldb] are fp16 (bf16 = 0) or
+// bf16 (bf16 = 1) matrices -- the product torch.autocast makes of an nn.Linear (train_MedTok.py:212,394); grouped as medtok_split_gemm_f16.
+extern "C" int medtok_half_gemm_f32(const void *a, int64_t m, int lda, int a_group_cols, const void *b, int64_t b_rows, int ldb, int b_group_rows,
+                                    int n_g, int k_g, int groups, const float *bias, float unscale, float *c, int ldc, int bf16, void *stream)
+{
+    return split_gemm_impl(a, a, m, lda, a_group_cols, b, b, b_rows, ldb, b_group_rows, n_g, k_g, groups, bias, unscale, nullptr, nullptr, c, ldc,
+                           nullptr, nullptr, 0, stream, bf16 ? 2 : 1);
+}
 
 extern "C" int medtok_split_gemm_scaled_f16(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols, const void *b_hi, const void *b_lo,
                                             int64_t b_rows, int ldb, int b_group_rows, int n_g, int k_g, int groups, const float *bias, float unscale,
@@ -2152,7 +2161,7 @@ extern "C" int medtok_split_gemm_f16(const void *a_hi, const void *a_lo, int64_t
 static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols,
                            const void *b_hi, const void *b_lo, int64_t b_rows, int ldb, int b_group_rows,
                            int n_g, int k_g, int groups, const float *bias, float unscale, const float *amax_a, const float *amax_b,
-                           float *c, int ldc, void *c_hi, void *c_lo, int ldch, void *stream)
+                           float *c, int ldc, void *c_hi, void *c_lo, int ldch, void *stream, int one_pass)
 {
     if (m < 0 || groups < 1 || n_g <= 0 || k_g <= 0 || (n_g & 3) || (k_g % G_BK) || (lda & 7) || (ldb & 7) || (a_group_cols & 7) || lda < k_g || ldb < k_g)
         return fail("split_gemm: bad shape m=%ld groups=%d n_g=%d k_g=%d lda=%d ldb=%d a_group_cols=%d (n_g %% 4 == 0, k_g %% 32 == 0, strides %% 8 == 0)",
@@ -2185,10 +2194,17 @@ static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int ld
     // with < 8 CUs still gets a valid launch, its blocks just share CUs)
     const long blocks = lmin(ids, lmax(8, (long)(dev_info().cus / 8) * 8));
     const size_t lds = mt3 ? GemmShape<3>::LDS_BYTES : GemmShape<4>::LDS_BYTES;
-    if (!(mt3 ? set_lds_once<split_gemm_kernel<3>>(lds) : set_lds_once<split_gemm_kernel<4>>(lds))) return fail("split_gemm: cannot reserve %zu bytes of LDS", lds);
-    hipEvent_t pa = g_prof_on ? prof_mark((hipStream_t)stream) : nullptr;
-    if (mt3) hipLaunchKernelGGL(split_gemm_kernel<3>, dim3((unsigned)blocks), dim3(G_THREADS), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(split_gemm_kernel<4>, dim3((unsigned)blocks), dim3(G_THREADS), lds, (hipStream_t)stream, p);
+    hipEvent_t pa = nullptr;
+#define MEDTOK_GEMM_LAUNCH(...)                                                                                                   \
+    do {                                                                                                                          \
+        if (!set_lds_once<split_gemm_kernel<__VA_ARGS__>>(lds)) return fail("split_gemm: cannot reserve %zu bytes of LDS", lds);  \
+        pa = g_prof_on ? prof_mark((hipStream_t)stream) : nullptr;                                                                \
+        hipLaunchKernelGGL((split_gemm_kernel<__VA_ARGS__>), dim3((unsigned)blocks), dim3(G_THREADS), lds, (hipStream_t)stream, p); \
+    } while (0)
+    if (one_pass == 0) { if (mt3) MEDTOK_GEMM_LAUNCH(3); else MEDTOK_GEMM_LAUNCH(4); }
+    else if (one_pass == 1) { if (mt3) MEDTOK_GEMM_LAUNCH(3, true, false); else MEDTOK_GEMM_LAUNCH(4, true, false); }
+    else { if (mt3) MEDTOK_GEMM_LAUNCH(3, true, true); else MEDTOK_GEMM_LAUNCH(4, true, true); }
+#undef MEDTOK_GEMM_LAUNCH
     if (pa) prof_push(pa, prof_mark((hipStream_t)stream), 2.0 * (double)m * (double)n_g * (double)k_g * (double)groups, 4);     // fp32-equivalent flops (x3 on the fp16 pipe)
     return check_launch("split_gemm");
 }

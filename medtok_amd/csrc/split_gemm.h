@@ -95,7 +95,19 @@ __device__ __forceinline__ void gemm_weave()            // scheduling hints for 
     }
 }
 
-template <int MT>
+// ONE (the autocast form): ONE pass over the hi images alone -- a plain half-precision product with fp32 accumulation, the precision
+// class of the reference's projections under torch.autocast (train_MedTok.py:212,394: nn.Linear / nn.MultiheadAttention compute in
+// fp16 or bf16 there).  BF: the images are bf16 (v_mfma_f32_32x32x16_bf16, same rate; fp32's exponent range: no prescale).  Same
+// ring, same tiles, same epilogue; a stage copies two tiles instead of four and holds two groups of MFMAs instead of six.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <bool BF>
+__device__ __forceinline__ f32x16 gemm_mfma(half8 a, half8 b, f32x16 c)
+{
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <int MT, bool ONE = false, bool BF = false>
 __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGemmArgs p)
 {
     using S = GemmShape<MT>;
@@ -162,10 +174,12 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
             char *dst = base + q * 8 * 16 * G_ROWB;
             if (q == 0 || w_second) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(bh_rs, (__attribute__((address_space(3))) void *)dst, 16, (int)b_off[q], uk, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(bl_rs, (__attribute__((address_space(3))) void *)(dst + WTILEB), 16, (int)b_off[q], uk, 0, 0);
+                if constexpr (!ONE)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(bl_rs, (__attribute__((address_space(3))) void *)(dst + WTILEB), 16, (int)b_off[q], uk, 0, 0);
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ah_rs, (__attribute__((address_space(3))) void *)(dst + XOFF), 16, (int)a_off[q], uk, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(al_rs, (__attribute__((address_space(3))) void *)(dst + XOFF + G_XTILEB), 16, (int)a_off[q], uk, 0, 0);
+            if constexpr (!ONE)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(al_rs, (__attribute__((address_space(3))) void *)(dst + XOFF + G_XTILEB), 16, (int)a_off[q], uk, 0, 0);
         }
         ++islot;
         if (ikb + 1 < nkb) { ++ikb; return; }
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int nn = 0; nn < G_NT; ++nn)
-                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[m], fx[nn], acc[m][nn], 0, 0, 0);
+                acc[m][nn] = gemm_mfma<BF>(fw[m], fx[nn], acc[m][nn]);
             if (w_next) read_w(m, slot, tt, lo);
         }
     };
@@ -260,6 +274,25 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
 #pragma unroll
                     for (int m = 0; m < MT; ++m) bzs[m] = (g_f4){0.f, 0.f, 0.f, 0.f};
                 }
+            }
+            if constexpr (ONE) {
+                // one pass: W_hi . X_hi of k step 0 (operands in registers), the barrier in front of k step 1's group as below
+                read_x(xb, sl, 1, 0);
+                group(xa, 1, sl, 1, 0);             gemm_weave<MT, G_NT, true, 0>();                // fw <- W_hi(step 1)
+                if (owe) { stage(); owe = false; }
+                __builtin_amdgcn_s_waitcnt(LGKM0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if constexpr (LAST) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(bzs[m]));
+                }
+                if (more) { if (late) owe = true; else stage(); }
+                read_x(xa, nx, 0, 0);
+                group(xb, 1, nx, 0, 0);             gemm_weave<MT, G_NT, true, 2>();                // fw <- W_hi(next stage, step 0)
+                ++gs;
+                return;
             }
             // k step 0
             read_x(xl, sl, 0, 1);

@@ -361,6 +361,25 @@ def split_gemm(a, b, n_g: int, k_g: int, groups: int = 1, a_group_cols: int = 0,
     return c, ((ch, cl) if want_split else None)
 
 
+def half_gemm(a, b, n_g: int, k_g: int, groups: int = 1, a_group_cols: int = 0, b_group_rows: int = 0, bias=None, unscale: float = 1.0):
+    """c [m, groups * n_g] fp32 = unscale * (A . B^T) + bias in ONE half-precision pass with fp32 accumulation (medtok_half_gemm_f32):
+    a [m, lda], b [b_rows, ldb] both torch.float16 or both torch.bfloat16, contiguous; grouped as split_gemm."""
+    if a.dtype != b.dtype or a.dtype not in (torch.float16, torch.bfloat16):
+        raise TypeError("half_gemm: operands must both be float16 or both bfloat16")
+    for t in (a, b):
+        if not (t.is_cuda and t.is_contiguous() and t.dim() == 2):
+            raise _lib.MedTokLibraryError("half_gemm: operands must be contiguous 2-d matrices on an MI355X device")
+    m, lda = a.shape
+    b_rows, ldb = b.shape
+    bias = None if bias is None else _dev(bias, "bias")
+    c = torch.empty((m, groups * n_g), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().medtok_half_gemm_f32(a.data_ptr(), m, lda, int(a_group_cols), b.data_ptr(), b_rows, ldb, int(b_group_rows), int(n_g), int(k_g),
+                                                    int(groups), _ptr(bias), float(unscale), c.data_ptr(), groups * n_g, int(a.dtype == torch.bfloat16),
+                                                    _stream(a)), "medtok_half_gemm_f32")
+    return c
+
+
 def absmax(x):
     """0-dim device fp32 tensor max |x| (no host read): feeds the power-of-two prescale of training-mode split operands."""
     x = _dev(x, "x")

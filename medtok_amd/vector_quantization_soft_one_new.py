@@ -64,6 +64,10 @@ FUSED_LAYER_CALL = True
 # Off by default: under autocast the library's half-precision GEMM is ~3x cheaper than the fp32-accurate three-pass product, and
 # that layer is upstream of the quantiser (bench.py --precomputed-encoders turns it on for the all-own-kernels profile).
 TRAIN_SPLIT_TEXT_MAPPING = False
+# ... under torch.autocast those products run as ONE half-precision pass with fp32 accumulation (ops.half_gemm: the precision class
+# autocast gives the reference's nn.Linear / nn.MultiheadAttention, train_MedTok.py:212,394) instead of the fp32-accurate three-pass
+# form (3x the matrix work, device-side |x|_max prescales, lo images); fp32 callers keep the three-pass form
+AUTOCAST_HALF_PRODUCTS = True
 # inference at the reference's own width (e_dim = 64, 4 heads): the whole cross-attention of a forward -- both layers, both
 # directions, node mean -- in two launches with no host read (ops.cross_attention_small); needs a SORTED batch vector (PyG's are;
 # the kernels flag anything else in CrossAttention.small_status, checked wherever the forward synchronises anyway)
@@ -225,7 +229,76 @@ class _SplitLinearFunction(torch.autograd.Function):
         return val
 
     @staticmethod
+    def _half_images(w, dt, kp, npad):
+        """(w [n, pad32(k)], w^T [k, pad32(n)]) as dt (fp16 / bf16) matrices, per (storage, version, dtype) for parameters"""
+        holder = w if isinstance(w, nn.Parameter) else (w._base if isinstance(getattr(w, "_base", None), nn.Parameter) else None)
+        key = (w.data_ptr(), w._version, tuple(w.shape), dt)
+        cache = getattr(holder, "_medtok_half_images", None) if holder is not None else None
+        if cache is not None and (key[0], dt) in cache and cache[(key[0], dt)][0] == key:
+            return cache[(key[0], dt)][1]
+        w16 = w.detach().to(dt)
+        n, k = w16.shape
+        val = (torch.nn.functional.pad(w16, (0, kp - k)).contiguous() if kp != k else w16.contiguous(),
+               torch.nn.functional.pad(w16.t(), (0, npad - n)).contiguous())
+        if holder is not None:
+            if cache is None:
+                cache = holder._medtok_half_images = {}
+            cache[(key[0], dt)] = (key, val)
+        return val
+
+    @staticmethod
+    def _forward_half(ctx, x, w, b, dt):
+        """the autocast form: y = x16 w16^T + b, one half-precision pass with fp32 accumulation"""
+        m, k = x.shape
+        n = w.shape[0]
+        kp, npad = _pad32(k), _pad32(n)
+        x16 = x.detach().to(dt)
+        x16 = torch.nn.functional.pad(x16, (0, kp - k)) if kp != k else x16
+        x16 = x16.contiguous()
+        w16, wt16 = _SplitLinearFunction._half_images(w, dt, kp, npad)
+        y = ops.half_gemm(x16, w16, n_g=n, k_g=kp, bias=None if b is None else b.detach().float().contiguous())
+        ctx.save_for_backward(x16, wt16)
+        ctx.shape = (m, k, n)
+        ctx.half = dt
+        ctx.dtypes = (x.dtype, w.dtype, None if b is None else b.dtype)
+        return y
+
+    @staticmethod
+    def _backward_half(ctx, dy):
+        x16, wt16 = ctx.saved_tensors
+        dxt, dwt, dbt = ctx.dtypes
+        m, k, n = ctx.shape
+        dt = ctx.half
+        npad = wt16.shape[1]
+        dy16 = dy.detach().to(dt)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:          # dX [m, k] = dY [m, n] . (W^T [k, n])^T
+            a = (torch.nn.functional.pad(dy16, (0, npad - n)) if npad != n else dy16).contiguous()
+            dx = ops.half_gemm(a, wt16, n_g=k, k_g=npad).to(dxt)
+        if ctx.needs_input_grad[1]:          # dW [n, k] = dY^T [n, m] . (X^T [k, m])^T, split over the rows in one grouped launch
+            tiles = ((n + 255) // 256) * ((k + 255) // 256)
+            groups = max(1, min(256 // max(tiles, 1), m // 2048))
+            chunk = (-(-m // groups) + 63) // 64 * 64
+            groups = -(-m // chunk)
+            mp = groups * chunk
+            a = torch.nn.functional.pad(dy16.t(), (0, mp - m)).contiguous()                                   # [n, mp]
+            xs = x16[:, :k]
+            xs = torch.nn.functional.pad(xs, (0, 0, 0, mp - m)) if mp != m else xs
+            bmat = xs.reshape(groups, chunk, k).transpose(1, 2).contiguous().view(groups * k, chunk)               # group g: X^T[:, g chunk : (g + 1) chunk]
+            dw = ops.half_gemm(a, bmat, n_g=k, k_g=chunk, groups=groups, a_group_cols=chunk, b_group_rows=k)
+            dw = (dw.view(n, groups, k).sum(1) if groups > 1 else dw).to(dwt)
+        if dbt is not None and ctx.needs_input_grad[2]:
+            db = dy.float().sum(0).to(dbt)
+        return dx, dw, db
+
+    @staticmethod
     def forward(ctx, x, w, b):
+        m, k = x.shape
+        n = w.shape[0]
+        ctx.half = None
+        if (AUTOCAST_HALF_PRODUCTS and torch.is_autocast_enabled() and m > 0 and k % 8 == 0 and n % 4 == 0 and k % 4 == 0
+                and torch.get_autocast_dtype("cuda") in (torch.float16, torch.bfloat16)):
+            return _SplitLinearFunction._forward_half(ctx, x, w, b, torch.get_autocast_dtype("cuda"))
         xf, wf = x.detach().float().contiguous(), w.detach().float().contiguous()
         m, k = xf.shape
         n = wf.shape[0]
@@ -245,7 +318,8 @@ class _SplitLinearFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xf, ax, aw, wt_hi, wt_lo = ctx.saved_tensors
+        if ctx.half is not None:
+            return _SplitLinearFunction._backward_half(ctx, dy)
         dxt, dwt, dbt = ctx.dtypes
         dyf = dy.float().contiguous()
         m, k, n = ctx.shape
@@ -253,6 +327,7 @@ class _SplitLinearFunction(torch.autograd.Function):
             return (dyf.new_zeros(0, k).to(dxt) if ctx.needs_input_grad[0] else None,
                     dyf.new_zeros(n, k).to(dwt) if ctx.needs_input_grad[1] else None,
                     dyf.new_zeros(n).to(dbt) if (dbt is not None and ctx.needs_input_grad[2]) else None)
+        xf, ax, aw, wt_hi, wt_lo = ctx.saved_tensors
         ad = ops.absmax(dyf)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:          # dX [m, k] = dY [m, n] . (W^T [k, n])^T

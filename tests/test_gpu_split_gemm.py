@@ -171,3 +171,44 @@ def test_split_linear_forward_and_backward_match_fp64(dev, m, k, n, gscale):
     w2 = w.detach().clone().requires_grad_()
     split_linear(x2, w2).backward(dy)
     assert rel(w2.grad, w64.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_one_pass_half_precision_gemm_matches_fp32_accumulation(dev, dt):
+    """medtok_half_gemm_f32 (one pass over fp16 / bf16 operands, fp32 accumulation: what torch.autocast makes of nn.Linear) against the
+    same operands multiplied in fp64: products of two half-precision numbers are exact in fp32, so only the accumulation order
+    differs -- 2e-6 of the row scale; plain and grouped, both tile heights, ragged row counts."""
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(3)
+    for (m, n_g, k_g, groups) in ((1000, 768, 768, 1), (257, 192, 768, 4), (5000, 64, 64, 2), (1, 4, 32, 1), (4096, 3072, 96, 1)):
+        lda, b_rows = groups * k_g, groups * n_g
+        a = (torch.randn(m, lda, device=dev, generator=g)).to(dt)
+        b = (torch.randn(b_rows, k_g, device=dev, generator=g) / k_g ** 0.5).to(dt)
+        bias = torch.randn(groups * n_g, device=dev, generator=g)
+        c = ops.half_gemm(a, b, n_g=n_g, k_g=k_g, groups=groups, a_group_cols=k_g, b_group_rows=n_g, bias=bias, unscale=0.5)
+        ref = torch.cat([a[:, h * k_g:(h + 1) * k_g].double() @ b[h * n_g:(h + 1) * n_g].double().t() for h in range(groups)], 1) * 0.5 + bias.double()
+        err = float((c.double() - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 2e-6, (m, n_g, k_g, groups, err)
+
+
+def test_autocast_linear_takes_the_one_pass_form_and_matches_torch(dev):
+    """split_linear under torch.autocast: forward and all three gradients against F.linear under the same autocast (torch's half-precision
+    GEMM, fp32 accumulation) -- the same precision class, so they agree to accumulation order (1e-2 of the scale covers bf16's own
+    rounding of torch's half-precision OUTPUT; ours stays fp32)."""
+    from medtok_amd.vector_quantization_soft_one_new import split_linear
+    g = torch.Generator(device=dev).manual_seed(4)
+    for dt in (torch.bfloat16, torch.float16):
+        for (m, k, n) in ((5000, 768, 768), (300, 3072, 768), (4100, 64, 64)):
+            x = torch.randn(m, k, device=dev, generator=g, requires_grad=True)
+            w = (torch.randn(n, k, device=dev, generator=g) / k ** 0.5).requires_grad_(True)
+            b = torch.randn(n, device=dev, generator=g, requires_grad=True)
+            go = torch.randn(m, n, device=dev, generator=g)
+            with torch.autocast("cuda", dtype=dt):
+                y = split_linear(x, w, b)
+                yr = torch.nn.functional.linear(x, w, b)
+            assert y.dtype == torch.float32
+            gx, gw, gb = torch.autograd.grad(y, (x, w, b), go)
+            rx, rw, rb = torch.autograd.grad(yr.float(), (x, w, b), go)
+            for got, ref, what in ((y, yr.float(), "y"), (gx, rx, "dx"), (gw, rw, "dw"), (gb, rb, "db")):
+                err = float((got.double() - ref.double()).abs().max()) / float(ref.double().abs().max())
+                assert err <= 1.5e-2, (dt, m, k, n, what, err)
