@@ -104,6 +104,12 @@ int medtok_usage_update_multi(float *window, int64_t window_len, const int64_t *
 int medtok_half_gemm_f32(const void *a, int64_t m, int lda, int a_group_cols, const void *b, int64_t b_rows, int ldb, int b_group_rows,
                          int n_g, int k_g, int groups, const float *bias, float unscale, float *c, int ldc, int bf16, void *stream);
 
+/* The 16-bit image (fp16; bf16 != 0: bf16) of the fp32 matrix src [n, d] (row stride src_stride): [n, dp] with zero columns past d, or with
+ * transpose != 0 the image of src^T, [d, dp] with dp >= n, written as dp / group_cols groups of [d, group_cols] stacked along the rows
+ * (group_cols = 0: one group) -- the operands of medtok_half_gemm_f32, made without torch's strided copies. */
+int medtok_half_image_f32(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp, int transpose, int64_t group_cols, int bf16,
+                          void *out, void *stream);
+
 /* Shader-clock probe for bench.py: one idle wavefront on each of 8 blocks (one per XCD on the full chip) samples the shader-cycle
  * counter and the constant 100 MHz counter from launch until *stop_flag (a word of PINNED HOST memory the device polls) becomes
  * non-zero, or max_ticks_100mhz ticks have passed, whichever is first; out = uint64 [8][4] (device memory): shader cycles, 100 MHz

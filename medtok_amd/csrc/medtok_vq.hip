@@ -2127,6 +2127,36 @@ extern "C" int medtok_split_half_scaled_f32(const float *src, int64_t n, int d, 
     return check_launch("split_half_scaled(transposed)");
 }
 
+// The 16-bit image (fp16, or bf16 with bf16 != 0) of an fp32 matrix [n, d]: row-major [n, dp] with zero columns past d, or (transpose) the
+// image of the transpose [d, dp], dp >= n, grouped along the rows like medtok_split_half_scaled_f32 -- operands of medtok_half_gemm_f32.
+extern "C" int medtok_half_image_f32(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp, int transpose, int64_t group_cols, int bf16,
+                                     void *out, void *stream)
+{
+    if (n < 0 || d <= 0 || (d & 3) || (dp & 7) || src_stride < d || (src_stride & 3) || dp < (transpose ? n : (int64_t)d))
+        return fail("half_image: bad shape n=%ld d=%d stride=%ld dp=%ld transpose=%d", (long)n, d, (long)src_stride, (long)dp, transpose);
+    if (group_cols == 0) group_cols = dp;
+    if (transpose && (group_cols <= 0 || dp % group_cols || (group_cols != dp && group_cols % 64)))
+        return fail("half_image: group_cols=%ld must divide dp=%ld and be a multiple of 64", (long)group_cols, (long)dp);
+    if (n == 0 && !transpose) return 0;
+    if ((!src && n) || !out) return fail("half_image: NULL argument");
+    if (((uintptr_t)src | (uintptr_t)out) & 15) return fail("half_image: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (!transpose) {
+        if (dp >= (1ll << 31)) return fail("half_image: dp too large");
+        const long total = n * (dp / 8);
+        const dim3 grid((unsigned)lmin(8192, (total + 255) / 256));
+        if (bf16) hipLaunchKernelGGL(half_image_kernel<true>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (int)dp, (unsigned short *)out);
+        else hipLaunchKernelGGL(half_image_kernel<false>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (int)dp, (unsigned short *)out);
+        return check_launch("half_image");
+    }
+    const long row_tiles = (dp + 63) / 64;
+    if (row_tiles >= (1ll << 31) || (d + 63) / 64 > 65535) return fail("half_image: too large");
+    const dim3 grid((unsigned)row_tiles, (unsigned)((d + 63) / 64));
+    if (bf16) hipLaunchKernelGGL(half_image_t_kernel<true>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (long)dp, (long)group_cols, (unsigned short *)out);
+    else hipLaunchKernelGGL(half_image_t_kernel<false>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (long)dp, (long)group_cols, (unsigned short *)out);
+    return check_launch("half_image(transposed)");
+}
+
 static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols,
                            const void *b_hi, const void *b_lo, int64_t b_rows, int ldb, int b_group_rows,
                            int n_g, int k_g, int groups, const float *bias, float unscale, const float *amax_a, const float *amax_b,

@@ -517,3 +517,62 @@ __global__ __launch_bounds__(256) void split_half_t_kernel(const float *__restri
         *reinterpret_cast<half8 *>(ol + rs + 8 * h8) = ll;
     }
 }
+
+// ---- single 16-bit images (fp16 or bf16, no lo part) of an fp32 matrix: the operands of the one-pass products under autocast.
+// Row-major [n, dp] (zero columns past d), or the TRANSPOSE [d, np] with the same grouping as split_half_t_kernel -- the operands of
+// a weight-gradient product contract over the rows.  (torch's strided copies made these transposes: 2.7 ms of a 22 ms train step.)
+template <bool BF>
+__device__ __forceinline__ unsigned short half_bits(float x)
+{
+    if constexpr (BF) { const __bf16 b = (__bf16)x; return __builtin_bit_cast(unsigned short, b); }
+    else { const _Float16 h = (_Float16)x; return __builtin_bit_cast(unsigned short, h); }
+}
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+template <bool BF>
+__global__ __launch_bounds__(256) void half_image_kernel(const float *__restrict__ src, long n, int d, long src_stride, int dp, unsigned short *__restrict__ out)
+{
+    const int cpr = dp / 8;
+    const long total = n * cpr;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long r = t / cpr;
+        const int c = (int)(t - r * cpr) * 8;
+        g_f4 va = (g_f4){0.f, 0.f, 0.f, 0.f}, vb = va;
+        if (c < d) va = *reinterpret_cast<const g_f4 *>(src + r * src_stride + c);
+        if (c + 4 < d) vb = *reinterpret_cast<const g_f4 *>(src + r * src_stride + c + 4);
+        u16x8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = half_bits<BF>(j < 4 ? va[j] : vb[j - 4]);
+        *reinterpret_cast<u16x8 *>(out + r * dp + c) = h;
+    }
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256) void half_image_t_kernel(const float *__restrict__ src, long n, int d, long src_stride, long np, long group_cols,
+                                                           unsigned short *__restrict__ out)
+{
+    __shared__ float tile[64][65];
+    const long r0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (t >> 4) + 16 * i, c = (t & 15) * 4;
+        g_f4 v = (g_f4){0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < n && c0 + c < d) v = *reinterpret_cast<const g_f4 *>(src + (r0 + r) * src_stride + c0 + c);
+        tile[r][c] = v[0]; tile[r][c + 1] = v[1]; tile[r][c + 2] = v[2]; tile[r][c + 3] = v[3];
+    }
+    __syncthreads();
+    const int c = t >> 2, rs = (t & 3) * 16;
+    if (c0 + c >= d) return;
+    const long grp = r0 / group_cols, gcol0 = r0 - grp * group_cols;
+    unsigned short *o = out + ((grp * d + c0 + c) * group_cols + gcol0);
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) {
+        if (r0 + rs + 8 * h8 >= np) continue;
+        u16x8 hh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hh[j] = half_bits<BF>(tile[rs + 8 * h8 + j][c]);
+        *reinterpret_cast<u16x8 *>(o + rs + 8 * h8) = hh;
+    }
+}

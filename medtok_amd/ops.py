@@ -380,6 +380,24 @@ def half_gemm(a, b, n_g: int, k_g: int, groups: int = 1, a_group_cols: int = 0, 
     return c
 
 
+def half_image(x, dp: int, dtype, transpose: bool = False, group_cols: int = 0):
+    """the fp16 / bf16 image of the fp32 matrix x [n, d] (unit column stride): [n, dp] with zero columns past d, or (transpose) of x^T,
+    [d, dp] with dp >= n, stacked as dp / group_cols groups of [d, group_cols] (medtok_half_image_f32)"""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise _lib.MedTokLibraryError("half_image: expected an fp32 [n, d] matrix with contiguous rows on an MI355X device")
+    n, d = x.shape
+    if transpose:
+        gc = int(group_cols) or int(dp)
+        shape = (int(dp) // gc * d, gc)
+    else:
+        shape = (n, int(dp))
+    out = torch.empty(shape, dtype=dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().medtok_half_image_f32(x.data_ptr(), n, d, x.stride(0) if n > 1 else d, int(dp), int(bool(transpose)), int(group_cols),
+                                                     int(dtype == torch.bfloat16), out.data_ptr(), _stream(x)), "medtok_half_image_f32")
+    return out
+
+
 def absmax(x):
     """0-dim device fp32 tensor max |x| (no host read): feeds the power-of-two prescale of training-mode split operands."""
     x = _dev(x, "x")

@@ -248,16 +248,16 @@ class _SplitLinearFunction(torch.autograd.Function):
 
     @staticmethod
     def _forward_half(ctx, x, w, b, dt):
-        """the autocast form: y = x16 w16^T + b, one half-precision pass with fp32 accumulation"""
+        """the autocast form: y = x16 w16^T + b, one half-precision pass with fp32 accumulation; the 16-bit operand images (and, in
+        the backward, their transposes) come from the library's own cast / transpose kernels"""
         m, k = x.shape
         n = w.shape[0]
         kp, npad = _pad32(k), _pad32(n)
-        x16 = x.detach().to(dt)
-        x16 = torch.nn.functional.pad(x16, (0, kp - k)) if kp != k else x16
-        x16 = x16.contiguous()
+        xf = x.detach().float()
+        xf = xf if xf.stride(1) == 1 and xf.stride(0) % 4 == 0 and xf.data_ptr() % 16 == 0 else xf.contiguous()
         w16, wt16 = _SplitLinearFunction._half_images(w, dt, kp, npad)
-        y = ops.half_gemm(x16, w16, n_g=n, k_g=kp, bias=None if b is None else b.detach().float().contiguous())
-        ctx.save_for_backward(x16, wt16)
+        y = ops.half_gemm(ops.half_image(xf, kp, dt), w16, n_g=n, k_g=kp, bias=None if b is None else b.detach().float().contiguous())
+        ctx.save_for_backward(xf, wt16)
         ctx.shape = (m, k, n)
         ctx.half = dt
         ctx.dtypes = (x.dtype, w.dtype, None if b is None else b.dtype)
@@ -265,30 +265,26 @@ class _SplitLinearFunction(torch.autograd.Function):
 
     @staticmethod
     def _backward_half(ctx, dy):
-        x16, wt16 = ctx.saved_tensors
+        xf, wt16 = ctx.saved_tensors
         dxt, dwt, dbt = ctx.dtypes
         m, k, n = ctx.shape
         dt = ctx.half
         npad = wt16.shape[1]
-        dy16 = dy.detach().to(dt)
+        dyf = dy.detach().float().contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:          # dX [m, k] = dY [m, n] . (W^T [k, n])^T
-            a = (torch.nn.functional.pad(dy16, (0, npad - n)) if npad != n else dy16).contiguous()
-            dx = ops.half_gemm(a, wt16, n_g=k, k_g=npad).to(dxt)
+            dx = ops.half_gemm(ops.half_image(dyf, npad, dt), wt16, n_g=k, k_g=npad).to(dxt)
         if ctx.needs_input_grad[1]:          # dW [n, k] = dY^T [n, m] . (X^T [k, m])^T, split over the rows in one grouped launch
             tiles = ((n + 255) // 256) * ((k + 255) // 256)
             groups = max(1, min(256 // max(tiles, 1), m // 2048))
             chunk = (-(-m // groups) + 63) // 64 * 64
             groups = -(-m // chunk)
             mp = groups * chunk
-            a = torch.nn.functional.pad(dy16.t(), (0, mp - m)).contiguous()                                   # [n, mp]
-            xs = x16[:, :k]
-            xs = torch.nn.functional.pad(xs, (0, 0, 0, mp - m)) if mp != m else xs
-            bmat = xs.reshape(groups, chunk, k).transpose(1, 2).contiguous().view(groups * k, chunk)               # group g: X^T[:, g chunk : (g + 1) chunk]
-            dw = ops.half_gemm(a, bmat, n_g=k, k_g=chunk, groups=groups, a_group_cols=chunk, b_group_rows=k)
+            dw = ops.half_gemm(ops.half_image(dyf, mp, dt, transpose=True), ops.half_image(xf, mp, dt, transpose=True, group_cols=chunk),
+                               n_g=k, k_g=chunk, groups=groups, a_group_cols=chunk, b_group_rows=k)
             dw = (dw.view(n, groups, k).sum(1) if groups > 1 else dw).to(dwt)
         if dbt is not None and ctx.needs_input_grad[2]:
-            db = dy.float().sum(0).to(dbt)
+            db = dyf.sum(0).to(dbt)
         return dx, dw, db
 
     @staticmethod
