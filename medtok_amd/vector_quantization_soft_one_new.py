@@ -68,6 +68,9 @@ TRAIN_SPLIT_TEXT_MAPPING = False
 # autocast gives the reference's nn.Linear / nn.MultiheadAttention, train_MedTok.py:212,394) instead of the fp32-accurate three-pass
 # form (3x the matrix work, device-side |x|_max prescales, lo images); fp32 callers keep the three-pass form
 AUTOCAST_HALF_PRODUCTS = True
+# training: the two directions of the cross-attention share every layer's weights, so their rows go through the layer's dense
+# products in one launch per product (CrossAttention._pooled_packed)
+MERGE_SIDES_IN_TRAINING = True
 # inference at the reference's own width (e_dim = 64, 4 heads): the whole cross-attention of a forward -- both layers, both
 # directions, node mean -- in two launches with no host read (ops.cross_attention_small); needs a SORTED batch vector (PyG's are;
 # the kernels flag anything else in CrossAttention.small_status, checked wherever the forward synchronises anyway)
@@ -670,6 +673,28 @@ class CrossAttention(nn.Module):
                 cur = self._folded_rows(layer, cur, text_attend, next_split=i + 1 < len(self.model))
             return cur
         use_side = lib_core and max_nodes > 0 and 0 < SIDE_STREAM_MIN_CODES <= bsz and not torch.is_grad_enabled()
+        if autograd and MERGE_SIDES_IN_TRAINING and max_nodes > 0 and nodes_sorted.dtype == cur.dtype:
+            # training: both directions share the layers' weights (:83,86), so the graph side's rows and the text side's CLS rows go
+            # through every dense product of a layer TOGETHER -- one launch per product (and per gradient) instead of two, one
+            # accumulation into each weight's .grad instead of two; only the attention core runs per side, on its row range
+            g_start, g_len, tok_start, g_kv_len = lists["g_start"], lists["g_len"], lists["tok_start"], lists["g_kv_len"]
+            n_g = nodes_sorted.shape[0]
+
+            def both_attend(qf, **kw):
+                cut = n_g * heads
+                return torch.cat([attend(qf[:cut], g_start, g_len, kv_text, tok_start, g_kv_len, max_nodes * heads, seq_len, **kw),
+                                  attend(qf[cut:], t_start, t_len, kv_nodes, starts, counts, heads, max_nodes, **kw)], dim=0)
+            both_attend.library_core = False
+            rows = torch.cat([nodes_sorted, cur], dim=0)
+            for layer in self.model:
+                rows = self._folded_rows(layer, rows, both_attend)
+            g, cur = rows[:n_g], rows[n_g:]
+            if slot is None:
+                slot = torch.arange(batch_sorted.numel(), device=batch_sorted.device) - starts[batch_sorted]
+            padded = g.new_zeros(bsz, max_nodes, dim)
+            padded[batch_sorted, slot] = g                     # deterministic mean (no atomics): pad, sum, divide
+            gm = padded.sum(1) / counts.clamp(min=1).unsqueeze(-1).to(g.dtype)
+            return (cur, gm) if join else (cur, gm, None)
         if use_side:
             # the text side (one query row per code and head) is independent of the graph side until the shared searches: second
             # stream.  Its launches are issued behind the graph side's first layer (by then the device has a layer of work queued
