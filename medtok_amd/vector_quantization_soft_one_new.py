@@ -6,18 +6,22 @@ state_dict keys (`codebook.weight`, `codebook_used`, `proj_text.*`,
 `proj_graph.*`, `cross_attn.model.{i}.{multihead_attn,layer_norm}.*`), so a
 reference checkpoint loads with strict=True.
 
-What runs where
-  - normalise / distance / top-k / softmax / code mix / straight-through /
-    squared error / usage window: gfx950 kernels through medtok_amd.ops;
-  - cross-attention (:17-88,133-142): batched over the codes instead of the
-    reference's per-sample Python loop, with the key/value projections folded
-    into the queries; at inference the ragged attention core is a gfx950 kernel
-    (ops.shared_kv_attention), the small per-row projections stay nn.Linear /
-    einsum on rocBLAS; training keeps the padded torch form for autograd;
-  - the two nn.Linear projections proj_text / proj_graph: stock torch modules;
-  - backward: autograd.Function around ONE sparse gfx950 kernel that only touches
-    the k selected codes per row (the reference back-propagates through a dense
-    N x K matrix); the code gradients are summed per code without atomics.
+What runs where (every device computation is a gfx950 kernel of medtok_amd/csrc behind the C ABI; there is no eager-PyTorch
+or library-GEMM path on the inference side at any batch size)
+  - normalise / distance / top-k / softmax / code mix / straight-through / squared error / usage window: medtok_amd.ops
+    (fp16-MFMA shortlist + exact fp32 re-score, or the exact fp32-MFMA kernel; small batches: all searches of a forward in
+    one call of three launches, ops.soft_vq_forward_multi);
+  - cross-attention (:17-88,133-142): batched over the codes instead of the reference's per-sample Python loop, the key / value
+    projections folded into the queries.  e_dim = 64 with 4 heads (the reference's default): ops.cross_attention_small -- both
+    layers, both directions and the node mean in two launches, no host read.  Other widths (<= 768): per layer the four dense
+    products on the split-fp16 GEMM (ops.split_gemm, three MFMA passes over (hi, lo) images: fp32-accurate), the ragged
+    attention core (ops.shared_kv_attention_split / shared_kv_attention), residual + LayerNorm in one kernel -- one C call per
+    layer and side (ops.cross_attention_layer).  Training / autograd: the same packed rows through _SplitLinearFunction
+    (three-pass products for fp32 callers, ONE half-precision pass under torch.autocast: ops.half_gemm) and
+    _RaggedAttentionFunction (HIP forward with dropout + HIP dQ / dKV backward);
+  - proj_text / proj_graph: the same GEMM kernels (project(), project_both());
+  - backward of a search: autograd.Function around ONE sparse kernel that only touches the k selected codes per row (the
+    reference back-propagates through a dense N x K matrix); the code gradients are summed per code without atomics.
 
 Deviations from the reference, all additive or bug-compatible by intent
 (SURVEY.md section 0):
@@ -1123,7 +1127,10 @@ class VectorQuantizer(nn.Module):
         if (SPLIT_PRODUCTS and TRAIN_SPLIT_PRODUCTS and self.training and torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and lin.bias is not None
                 and lin.in_features % 4 == 0 and lin.out_features % 4 == 0 and (x.requires_grad or lin.weight.requires_grad)):
             return split_linear(x, lin.weight, lin.bias)        # under autograd: forward and backward on the library's own product
-        if (not SPLIT_PRODUCTS or self.training or torch.is_grad_enabled() or torch.is_autocast_enabled() or not x.is_cuda
+        # (inference: fp32-accurate whatever autocast says -- an autocast caller's half-precision rows are widened, like fp16 tensors)
+        if not self.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
+            x = x.float()
+        if (not SPLIT_PRODUCTS or self.training or torch.is_grad_enabled() or not x.is_cuda
                 or x.dtype != torch.float32 or x.dim() != 2 or x.shape[0] < SPLIT_MIN_ROWS or lin.bias is None
                 or lin.in_features % 32 or lin.out_features % 4 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16):
             return lin(x)
@@ -1146,7 +1153,7 @@ class VectorQuantizer(nn.Module):
         apply (training, autograd, autocast, non-fp32, odd shapes)."""
         lt, lg = self.proj_text, self.proj_graph
         e = self.e_dim
-        if (not SPLIT_PRODUCTS or self.training or torch.is_grad_enabled() or torch.is_autocast_enabled() or not z.is_cuda or z.dtype != torch.float32
+        if (not SPLIT_PRODUCTS or self.training or torch.is_grad_enabled() or not z.is_cuda or z.dtype != torch.float32
                 or z.dim() != 2 or z.shape[1] != 2 * e or lt.bias is None or lg.bias is None or e % 32 or not z.is_contiguous()
                 or lt.in_features != e or lg.in_features != e or lt.out_features != e or lg.out_features != e):
             return None
@@ -1277,8 +1284,10 @@ class VectorQuantizer(nn.Module):
         of the usage window in one call of two.  Same values as the general form below; None when it does not apply."""
         bsz, e, k = z.shape[0], self.e_dim, self.k
         if not (BATCHED_SMALL_SEARCHES and not self.training and not torch.is_grad_enabled() and z.is_cuda and bsz > 0 and self.e_dim % 4 == 0
-                and not torch.is_autocast_enabled()):
+                and z.dtype in (torch.float32, torch.float16, torch.bfloat16)):
             return None
+        z = z.float()
+        z_aug = None if z_aug is None else z_aug.float()
         region = self.codebook.weight.shape[0] // 3
         if not (ops.multi_search_eligible(bsz, region, e, k) and ops.multi_search_eligible(2 * bsz, self.n_e, e, k)):
             return None
@@ -1346,7 +1355,7 @@ class VectorQuantizer(nn.Module):
         z_text_embedding, z_graph_embedding = torch.split(z, self.split, dim=-1)
         aug = (None, None) if z_aug is None else torch.split(z_aug, self.split, dim=-1)
         early = None
-        if (not self.training and not torch.is_grad_enabled() and z.is_cuda and not torch.is_autocast_enabled()
+        if (not self.training and not torch.is_grad_enabled() and z.is_cuda
                 and 0 < SIDE_STREAM_MIN_CODES <= z.shape[0]):
             # inference: the modality-specific searches depend on nothing the cross-attention produces: second stream, joined
             # below; their usage-window updates stay in the reference's order (shared, text, graph, aug text, aug graph: :241-250)

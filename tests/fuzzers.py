@@ -1,8 +1,8 @@
 """Randomised checks of the HIP library against its own exact path / the C oracle / fp64 -- test infrastructure.
 
 Every function takes (cases, seed, budget_s): it stops after `cases` cases or `budget_s` seconds, whichever comes first, and returns
-(cases_run, mismatches: list[str]).  tests/test_gpu_fuzz.py runs them time-boxed with fixed seeds inside `-m gpu`; tools/fuzz_*.py
-and tools/soak_forward.py are their command lines (long runs, variant builds of the library).
+(cases_run, mismatches: list[str]).  tests/test_gpu_fuzz.py runs them time-boxed with fixed seeds inside `-m gpu`; tools/fuzz_search.py
+is their command line (long runs, variant builds of the library).
 
 Why they are in the suite: round 4's three wrong-result bugs (asm readers of MFMA results inside their wait states; the start-value
 race of the general filter kernel at D <= 32; a cross-stream buffer overwrite) were all found by these loops, none by a fixed-shape
