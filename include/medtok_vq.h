@@ -415,6 +415,14 @@ int medtok_shared_kv_attention_backward_f32(const float *q, const int64_t *q_sta
                                             int64_t kv_rows, int d, float scale, float dropout_p, uint32_t seed,
                                             const float *out, const float *lse, const float *d_out, float *dq, float *dkv,
                                             void *ws, size_t ws_bytes, void *stream);
+/* ... the same with its four matrix products as ONE half-precision pass (fp16; bf16 != 0: bf16) with fp32 accumulation: what
+ * torch.autocast makes of nn.MultiheadAttention's Q K^T and P V (train_MedTok.py:212,394).  Operands, the softmax rebuilt from the
+ * forward's log-sum-exp, and the outputs stay fp32. */
+int medtok_shared_kv_attention_backward_half_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
+                                                 const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
+                                                 int64_t max_kv_len, int64_t q_rows, int64_t kv_rows, int d, float scale, float dropout_p,
+                                                 uint32_t seed, const float *out, const float *lse, const float *d_out, float *dq,
+                                                 float *dkv, void *ws, size_t ws_bytes, int bf16, void *stream);
 
 /* EMA statistics of norm_ema_quantizer.py:183,194,202 without the one-hot:
  * bins[c] = #rows with idx == c (exact), embed_sum[c][:] = sum of those rows of

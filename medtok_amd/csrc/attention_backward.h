@@ -86,6 +86,85 @@ __device__ __forceinline__ void att_accumulate(f32x16 (&acc)[NT], const float (*
     }
 }
 
+// ---- the same two primitives in ONE half-precision pass (fp16, or bf16 with BF) with fp32 accumulation: the precision class
+// torch.autocast gives the reference's attention products (nn.MultiheadAttention under autocast computes Q K^T and P V in half
+// precision, train_MedTok.py:212,394).  The chunk stays parked as fp32 (same LDS traffic: eight floats per lane and step either way);
+// operands are rounded on the way into v_mfma_f32_32x32x16_{f16,bf16} -- 1/16 of the matrix time of the fp32 form.  A lane of a
+// 32 x 32 x 16 operand holds 8 CONSECUTIVE k (columns 16 s + 8 lh ..) where the 32 x 32 x 2 form holds 4 + 4 interleaved: the
+// register operands are loaded in that order (att_load_rows_h).
+typedef unsigned short att_u16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 att_bf16x8 __attribute__((ext_vector_type(8)));
+template <bool BF>
+__device__ __forceinline__ half8 att_pack8(const float (&v)[8])
+{
+    att_u16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if constexpr (BF) { const __bf16 b = (__bf16)v[e]; r[e] = __builtin_bit_cast(unsigned short, b); }
+        else { const _Float16 h = (_Float16)v[e]; r[e] = __builtin_bit_cast(unsigned short, h); }
+    }
+    return __builtin_bit_cast(half8, r);
+}
+template <bool BF>
+__device__ __forceinline__ f32x16 att_mfma16(half8 a, half8 b, f32x16 c)
+{
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a), __builtin_bit_cast(att_bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// row `src` (pointing at the wave's column slice of the row): the lane's 2 NT operands of 8 consecutive columns
+template <int NT, bool BF>
+__device__ __forceinline__ void att_load_rows_h(half8 (&reg)[2 * NT], const float *src, int lh)
+{
+#pragma unroll
+    for (int st = 0; st < 2 * NT; ++st) {
+        const float4 a = ld4(src + 16 * st + 8 * lh), b = ld4(src + 16 * st + 8 * lh + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        reg[st] = att_pack8<BF>(v);
+    }
+}
+template <int W, int NT, bool BF, typename Hook = AttNoHook>
+__device__ __forceinline__ f32x16 att_partial_h(const half8 (&reg)[2 * NT], const float *kvs, int slice, int li, int lh, Hook hook = Hook())
+{
+    constexpr int LD = AttShape<W, NT>::LD;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const float *krow = kvs + li * LD + slice + 8 * lh;
+#pragma unroll
+    for (int st = 0; st < 2 * NT; ++st) {
+        const float4 a = *reinterpret_cast<const float4 *>(krow + 16 * st), b = *reinterpret_cast<const float4 *>(krow + 16 * st + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        s = att_mfma16<BF>(reg[st], att_pack8<BF>(v), s);
+        hook(2 * st);
+        hook(2 * st + 1);
+        asm volatile("" ::: "memory");
+    }
+    return s;
+}
+template <int W, int NT, bool BF, typename Hook = AttNoHook>
+__device__ __forceinline__ void att_accumulate_h(f32x16 (&acc)[NT], const float (*x)[33], const float *kvs, int slice, int li, int lh, Hook hook = Hook())
+{
+    constexpr int LD = AttShape<W, NT>::LD;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const int k0 = 16 * st + 8 * lh;
+        float av[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] = x[k0 + e][li];
+        const half8 a = att_pack8<BF>(av);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float bv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = kvs[(k0 + e) * LD + slice + 32 * t + li];
+            acc[t] = att_mfma16<BF>(a, att_pack8<BF>(bv), acc[t]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hook(8 * st + e);
+        asm volatile("" ::: "memory");
+    }
+}
+
 #define ATT_LDS_BARRIER()                                                   \
     do {                                                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  \
@@ -94,7 +173,8 @@ __device__ __forceinline__ void att_accumulate(f32x16 (&acc)[NT], const float (*
     } while (0)
 
 // ---------------------------------------------------------------- dQ
-template <int W, int NT>
+// HM: 0 = exact fp32 MFMA; 1 / 2 = one fp16 / bf16 pass (autocast callers)
+template <int W, int NT, int HM = 0>
 __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
     const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
     const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
@@ -133,12 +213,18 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
             for (int ci = 0; ci < CI; ++ci) *reinterpret_cast<float4 *>(dst + RP * ri * LD + 4 * FT * ci) = kf[ri * CI + ci];
     };
     if (kl > 0) fetch(0);
-    float4 qf[4 * NT], dof[4 * NT];
+    float4 qf[HM ? 1 : 4 * NT], dof[HM ? 1 : 4 * NT];
+    half8 qh[HM ? 2 * NT : 1], doh[HM ? 2 * NT : 1];
     {
         const long r = qs + min(qt * 32 + li, ql - 1);
-        const float *qrow = q + r * (long)D + slice + 4 * lh, *drow = d_out + r * (long)D + slice + 4 * lh;
+        if constexpr (HM) {
+            att_load_rows_h<NT, HM == 2>(qh, q + r * (long)D + slice, lh);
+            att_load_rows_h<NT, HM == 2>(doh, d_out + r * (long)D + slice, lh);
+        } else {
+            const float *qrow = q + r * (long)D + slice + 4 * lh, *drow = d_out + r * (long)D + slice + 4 * lh;
 #pragma unroll
-        for (int g = 0; g < 4 * NT; ++g) { qf[g] = ld4(qrow + 8 * g); dof[g] = ld4(drow + 8 * g); }
+            for (int g = 0; g < 4 * NT; ++g) { qf[g] = ld4(qrow + 8 * g); dof[g] = ld4(drow + 8 * g); }
+        }
     }
     if (tid < 32) {
         const long r = qs + min(qt * 32 + tid, ql - 1);
@@ -159,7 +245,10 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri) fsrc[ri] = kv + (ks + min(k0 + 32 + f_r0 + RP * ri, kl - 1)) * (long)D + f_c;
         ATT_LDS_BARRIER();
-        f32x16 s = att_partial<W, NT>(qf, kvs, slice, li, lh, [&](int g) { kf[g] = ld4(fsrc[g / CI] + 4 * FT * (g % CI)); });   // S partial: [query row][key]
+        auto weave = [&](int g) { kf[g] = ld4(fsrc[g / CI] + 4 * FT * (g % CI)); };
+        f32x16 s;                                                                  // S partial: [query row][key]
+        if constexpr (HM) s = att_partial_h<W, NT, HM == 2>(qh, kvs, slice, li, lh, weave);
+        else s = att_partial<W, NT>(qf, kvs, slice, li, lh, weave);
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
         ATT_LDS_BARRIER();
@@ -172,7 +261,8 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
             sc[j] = a * scale;
         }
         ATT_LDS_BARRIER();                                                         // everyone has read the S partials
-        s = att_partial<W, NT>(dof, kvs, slice, li, lh);                           // dPm partial = dO . KV^T
+        if constexpr (HM) s = att_partial_h<W, NT, HM == 2>(doh, kvs, slice, li, lh);      // dPm partial = dO . KV^T
+        else s = att_partial<W, NT>(dof, kvs, slice, li, lh);
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
         ATT_LDS_BARRIER();
@@ -187,7 +277,8 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
             pt[kq + j][row] = p * (dp - del_s[row]) * scale;                       // scale dS, [key][row]
         }
         ATT_LDS_BARRIER();
-        att_accumulate<W, NT>(acc, pt, kvs, slice, li, lh);                        // dQ += (scale dS) . KV
+        if constexpr (HM) att_accumulate_h<W, NT, HM == 2>(acc, pt, kvs, slice, li, lh);   // dQ += (scale dS) . KV
+        else att_accumulate<W, NT>(acc, pt, kvs, slice, li, lh);
         ATT_LDS_BARRIER();
     }
 #pragma unroll
@@ -202,7 +293,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
 }
 
 // ---------------------------------------------------------------- dKV
-template <int W, int NT>
+template <int W, int NT, int HM = 0>
 __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
     const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
     const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
@@ -241,11 +332,16 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
 #pragma unroll
             for (int ci = 0; ci < CI; ++ci) *reinterpret_cast<float4 *>(dst + RP * ri * LD + 4 * FT * ci) = kf[ri * CI + ci];
     };
-    float4 kvf[4 * NT];                                   // this block's 32 key rows, the wave's column slice
+    float4 kvf[HM ? 1 : 4 * NT];                          // this block's 32 key rows, the wave's column slice
+    half8 kvh[HM ? 2 * NT : 1];
     {
-        const float *krow = kv + (ks + min(kt * 32 + li, kl - 1)) * (long)D + slice + 4 * lh;
+        if constexpr (HM) {
+            att_load_rows_h<NT, HM == 2>(kvh, kv + (ks + min(kt * 32 + li, kl - 1)) * (long)D + slice, lh);
+        } else {
+            const float *krow = kv + (ks + min(kt * 32 + li, kl - 1)) * (long)D + slice + 4 * lh;
 #pragma unroll
-        for (int g = 0; g < 4 * NT; ++g) kvf[g] = ld4(krow + 8 * g);
+            for (int g = 0; g < 4 * NT; ++g) kvf[g] = ld4(krow + 8 * g);
+        }
     }
     f32x16 acc[NT];
 #pragma unroll
@@ -275,7 +371,9 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
         }
         park();                                                                    // Q chunk (fetched during the previous iteration)
         ATT_LDS_BARRIER();
-        f32x16 s = att_partial<W, NT>(kvf, kvs, slice, li, lh, woven(d_out, c0));  // S^T partial: [key][query]; dO chunk on its way
+        f32x16 s;                                                                  // S^T partial: [key][query]; dO chunk on its way
+        if constexpr (HM) s = att_partial_h<W, NT, HM == 2>(kvh, kvs, slice, li, lh, woven(d_out, c0));
+        else s = att_partial<W, NT>(kvf, kvs, slice, li, lh, woven(d_out, c0));
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
         ATT_LDS_BARRIER();
@@ -294,7 +392,8 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
         ATT_LDS_BARRIER();                                                         // S partials and the Q chunk are consumed
         park();                                                                    // dO chunk
         ATT_LDS_BARRIER();
-        s = att_partial<W, NT>(kvf, kvs, slice, li, lh);                           // dPm^T partial = KV . dO^T
+        if constexpr (HM) s = att_partial_h<W, NT, HM == 2>(kvh, kvs, slice, li, lh);      // dPm^T partial = KV . dO^T
+        else s = att_partial<W, NT>(kvf, kvs, slice, li, lh);
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
         ATT_LDS_BARRIER();
@@ -306,11 +405,15 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
             dp = keep[j] ? dp * keep_scale : 0.f;
             ds[qc + j][krow_t] = p[j] * (dp - del_s[qc + j]) * scale;
         }
-        att_accumulate<W, NT>(acc, pm, kvs, slice, li, lh, woven(q, c0));          // dKV += (P o M)^T . dO   (pm was complete two barriers ago); Q again on its way
+        // dKV += (P o M)^T . dO   (pm was complete two barriers ago); Q again on its way
+        if constexpr (HM) att_accumulate_h<W, NT, HM == 2>(acc, pm, kvs, slice, li, lh, woven(q, c0));
+        else att_accumulate<W, NT>(acc, pm, kvs, slice, li, lh, woven(q, c0));
         ATT_LDS_BARRIER();                                                         // dO chunk consumed, ds complete
         park();                                                                    // Q chunk again
         ATT_LDS_BARRIER();
-        att_accumulate<W, NT>(acc, ds, kvs, slice, li, lh, woven(q, c0 + 32));     // dKV += (scale dS)^T . Q; the next iteration's Q on its way
+        // dKV += (scale dS)^T . Q; the next iteration's Q on its way
+        if constexpr (HM) att_accumulate_h<W, NT, HM == 2>(acc, ds, kvs, slice, li, lh, woven(q, c0 + 32));
+        else att_accumulate<W, NT>(acc, ds, kvs, slice, li, lh, woven(q, c0 + 32));
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

@@ -2253,11 +2253,39 @@ extern "C" int medtok_shared_kv_attention_train_f32(const float *q, const int64_
 
 extern "C" size_t medtok_shared_kv_attention_backward_workspace_bytes(int64_t q_rows) { return q_rows > 0 ? align_up((size_t)q_rows * 4, 256) : 256; }
 
+static int attention_backward_impl(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
+                                   const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
+                                   int64_t max_kv_len, int64_t q_rows, int64_t kv_rows, int d, float scale, float dropout_p,
+                                   uint32_t seed, const float *out, const float *lse, const float *d_out, float *dq,
+                                   float *dkv, void *ws, size_t ws_bytes, void *stream, int hm);
+
 extern "C" int medtok_shared_kv_attention_backward_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
                                                        const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
                                                        int64_t max_kv_len, int64_t q_rows, int64_t kv_rows, int d, float scale, float dropout_p,
                                                        uint32_t seed, const float *out, const float *lse, const float *d_out, float *dq,
                                                        float *dkv, void *ws, size_t ws_bytes, void *stream)
+{
+    return attention_backward_impl(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, max_kv_len, q_rows, kv_rows, d, scale, dropout_p, seed, out,
+                                   lse, d_out, dq, dkv, ws, ws_bytes, stream, 0);
+}
+
+// the same backward with its four matrix products in ONE half-precision pass (fp16; bf16 != 0: bf16) with fp32 accumulation -- the
+// precision class of nn.MultiheadAttention under torch.autocast (train_MedTok.py:212,394); operands, softmax rebuild and outputs fp32
+extern "C" int medtok_shared_kv_attention_backward_half_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
+                                                            const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
+                                                            int64_t max_kv_len, int64_t q_rows, int64_t kv_rows, int d, float scale, float dropout_p,
+                                                            uint32_t seed, const float *out, const float *lse, const float *d_out, float *dq,
+                                                            float *dkv, void *ws, size_t ws_bytes, int bf16, void *stream)
+{
+    return attention_backward_impl(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, max_kv_len, q_rows, kv_rows, d, scale, dropout_p, seed, out,
+                                   lse, d_out, dq, dkv, ws, ws_bytes, stream, bf16 ? 2 : 1);
+}
+
+static int attention_backward_impl(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
+                                   const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
+                                   int64_t max_kv_len, int64_t q_rows, int64_t kv_rows, int d, float scale, float dropout_p,
+                                   uint32_t seed, const float *out, const float *lse, const float *d_out, float *dq,
+                                   float *dkv, void *ws, size_t ws_bytes, void *stream, int hm)
 {
     if (n_codes < 0 || max_q_len < 0 || max_kv_len < 0 || q_rows < 0 || kv_rows < 0) return fail("shared_kv_attention_backward: bad sizes");
     if (!attention_shape_ok(d)) return fail("shared_kv_attention_backward: d=%d must be 64 or a multiple of 128, at most 768", d);
@@ -2278,17 +2306,21 @@ extern "C" int medtok_shared_kv_attention_backward_f32(const float *q, const int
     const unsigned thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
     const float keep_scale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
     hipEvent_t pa_bwd = g_prof_on ? prof_mark(s) : nullptr;
-#define MEDTOK_ATT_BWD(W, NT)                                                                                                    \
+#define MEDTOK_ATT_BWD_HM(W, NT, HM)                                                                                             \
     do {                                                                                                                         \
         const size_t lds = AttShape<W, NT>::LDS_FLOATS * sizeof(float);                                                          \
-        if (lds > 64 * 1024 && (!set_lds_once<shared_kv_attention_dq_kernel<W, NT>>(lds) || !set_lds_once<shared_kv_attention_dkv_kernel<W, NT>>(lds))) \
+        if (lds > 64 * 1024 && (!set_lds_once<shared_kv_attention_dq_kernel<W, NT, HM>>(lds) || !set_lds_once<shared_kv_attention_dkv_kernel<W, NT, HM>>(lds))) \
             return fail("shared_kv_attention_backward: cannot reserve %zu bytes of LDS", lds);                                   \
         if (q_tiles > 0)                                                                                                         \
-            hipLaunchKernelGGL((shared_kv_attention_dq_kernel<W, NT>), dim3((unsigned)(q_tiles * n_codes)), dim3(64 * W), lds, s, q, q_start, q_len, \
+            hipLaunchKernelGGL((shared_kv_attention_dq_kernel<W, NT, HM>), dim3((unsigned)(q_tiles * n_codes)), dim3(64 * W), lds, s, q, q_start, q_len, \
                                kv, kv_start, kv_len, d_out, lse, delta, scale, dq, (int)q_tiles, thresh, seed, keep_scale);      \
         if (kv_tiles > 0)                                                                                                        \
-            hipLaunchKernelGGL((shared_kv_attention_dkv_kernel<W, NT>), dim3((unsigned)(kv_tiles * n_codes)), dim3(64 * W), lds, s, q, q_start, q_len, \
+            hipLaunchKernelGGL((shared_kv_attention_dkv_kernel<W, NT, HM>), dim3((unsigned)(kv_tiles * n_codes)), dim3(64 * W), lds, s, q, q_start, q_len, \
                                kv, kv_start, kv_len, d_out, lse, delta, scale, dkv, (int)kv_tiles, thresh, seed, keep_scale);    \
+    } while (0)
+#define MEDTOK_ATT_BWD(W, NT)                                                                                                    \
+    do {                                                                                                                         \
+        if (hm == 0) MEDTOK_ATT_BWD_HM(W, NT, 0); else if (hm == 1) MEDTOK_ATT_BWD_HM(W, NT, 1); else MEDTOK_ATT_BWD_HM(W, NT, 2); \
     } while (0)
     switch (d / 128) {
     case 0: MEDTOK_ATT_BWD(2, 1); break;
@@ -2299,6 +2331,7 @@ extern "C" int medtok_shared_kv_attention_backward_f32(const float *q, const int
     case 5: MEDTOK_ATT_BWD(4, 5); break;
     default: MEDTOK_ATT_BWD(8, 3); break;
     }
+#undef MEDTOK_ATT_BWD_HM
 #undef MEDTOK_ATT_BWD
     if (pa_bwd) prof_push(pa_bwd, prof_mark(s), 0.0, 3);     // dQ + dKV; the caller prices the pair (ragged counts live on the device)
     return check_launch("shared_kv_attention_backward");

@@ -646,20 +646,23 @@ def shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, max_q_len
 
 
 def shared_kv_attention_backward(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, max_kv_len: int, scale: float, dropout_p: float,
-                                 seed: int, out, lse, d_out):
-    """(dq, dkv) of shared_kv_attention_train for the upstream gradient d_out."""
+                                 seed: int, out, lse, d_out, half=None):
+    """(dq, dkv) of shared_kv_attention_train for the upstream gradient d_out.  half = torch.float16 / torch.bfloat16: the four matrix
+    products in one half-precision pass with fp32 accumulation (autocast callers); None: exact fp32 MFMA."""
     q, kv, out, lse, d_out = _dev(q, "q"), _dev(kv, "kv"), _dev(out, "out"), _dev(lse, "lse"), _dev(d_out, "d_out")
     qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
     ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
     dq, dkv = torch.empty_like(q), torch.empty_like(kv)
     lib = _lib.load()
     ws = _ws(lib.medtok_shared_kv_attention_backward_workspace_bytes(q.shape[0]), q)
+    args = (q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(), kl.data_ptr(), qs.numel(), int(max_q_len), int(max_kv_len),
+            q.shape[0], kv.shape[0], q.shape[1], float(scale), float(dropout_p), int(seed) & 0xFFFFFFFF, out.data_ptr(), lse.data_ptr(),
+            d_out.data_ptr(), dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(), ws.numel())
     with torch.cuda.device(q.device):
-        _lib.check(lib.medtok_shared_kv_attention_backward_f32(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(), kl.data_ptr(),
-                                                               qs.numel(), int(max_q_len), int(max_kv_len), q.shape[0], kv.shape[0], q.shape[1],
-                                                               float(scale), float(dropout_p), int(seed) & 0xFFFFFFFF, out.data_ptr(), lse.data_ptr(),
-                                                               d_out.data_ptr(), dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(), ws.numel(), _stream(q)),
-                   "medtok_shared_kv_attention_backward_f32")
+        if half in (torch.float16, torch.bfloat16):
+            _lib.check(lib.medtok_shared_kv_attention_backward_half_f32(*args, int(half == torch.bfloat16), _stream(q)), "medtok_shared_kv_attention_backward_half_f32")
+        else:
+            _lib.check(lib.medtok_shared_kv_attention_backward_f32(*args, _stream(q)), "medtok_shared_kv_attention_backward_f32")
     return dq, dkv
 
 

@@ -194,6 +194,10 @@ class _RaggedAttentionFunction(torch.autograd.Function):
         out, lse = ops.shared_kv_attention_train(qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, scale, dropout_p, seed)
         ctx.save_for_backward(qf, kvf, out, lse, q_start, q_len, kv_start, kv_len)
         ctx.cfg = (max_q_len, max_kv_len, scale, dropout_p, seed, q.dtype, kv.dtype)
+        # under torch.autocast the backward's four matrix products run as ONE half-precision pass (the reference's class there);
+        # the forward stays on the exact fp32 kernel (its log-sum-exp feeds the backward's softmax rebuild)
+        ctx.half = (torch.get_autocast_dtype("cuda") if (AUTOCAST_HALF_PRODUCTS and torch.is_autocast_enabled()
+                                                         and torch.get_autocast_dtype("cuda") in (torch.float16, torch.bfloat16)) else None)
         return out
 
     @staticmethod
@@ -201,7 +205,7 @@ class _RaggedAttentionFunction(torch.autograd.Function):
         qf, kvf, out, lse, q_start, q_len, kv_start, kv_len = ctx.saved_tensors
         max_q_len, max_kv_len, scale, dropout_p, seed, qd, kd = ctx.cfg
         dq, dkv = ops.shared_kv_attention_backward(qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed,
-                                                   out, lse, d_out.float().contiguous())
+                                                   out, lse, d_out.float().contiguous(), half=ctx.half)
         return dq.to(qd), dkv.to(kd), None, None, None, None, None, None, None, None, None
 
 

@@ -334,6 +334,31 @@ def test_attention_train_forward_and_backward_match_oracle(oracle, dev, d, p):
         assert not torch.equal(out3, out)
 
 
+@pytest.mark.parametrize("d,half", [(64, torch.bfloat16), (128, torch.float16), (768, torch.bfloat16), (768, torch.float16), (384, torch.bfloat16)])
+def test_attention_backward_in_one_half_precision_pass_tracks_the_fp32_backward(dev, d, half):
+    """The autocast form of the attention backward (four matrix products as ONE fp16 / bf16 pass, fp32 accumulation, softmax rebuilt in
+    fp32 from the forward's log-sum-exp) against the exact fp32 kernels on the same operands: the difference is the rounding of the
+    operands to 11 / 8 significant bits -- 2e-3 / 2e-2 of the gradient's scale; rows that belong to no code stay zero; with dropout."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(d)
+    q_len = np.array([40, 7, 0, 64, 33, 5, 150], np.int64); kv_len = np.array([50, 33, 12, 100, 0, 1, 300], np.int64)
+    q_start, kv_start = np.cumsum(q_len) - q_len, np.cumsum(kv_len) - kv_len
+    nq, nk = int(q_len.sum()) + 2, int(kv_len.sum())
+    T = lambda a: torch.from_numpy(a).to(dev)
+    q, kv = T((rng.standard_normal((nq, d)) * 0.3).astype(np.float32)), T(rng.standard_normal((nk, d)).astype(np.float32))
+    d_out = T(rng.standard_normal((nq, d)).astype(np.float32))
+    for p in (0.0, 0.1):
+        args = (q, T(q_start), T(q_len), kv, T(kv_start), T(kv_len))
+        out, lse = ops.shared_kv_attention_train(*args, int(q_len.max()), 0.2, p, 7)
+        dq0, dkv0 = ops.shared_kv_attention_backward(*args, int(q_len.max()), int(kv_len.max()), 0.2, p, 7, out, lse, d_out)
+        dq1, dkv1 = ops.shared_kv_attention_backward(*args, int(q_len.max()), int(kv_len.max()), 0.2, p, 7, out, lse, d_out, half=half)
+        tol = 2e-3 if half == torch.float16 else 2e-2
+        for a, b, what in ((dq1, dq0, "dq"), (dkv1, dkv0, "dkv")):
+            err = float((a - b).abs().max()) / float(b.abs().max())
+            assert err <= tol, (what, p, err)
+        assert not dq1[-2:].any()
+
+
 @pytest.mark.parametrize("n,d", [(1, 4), (130, 768), (1000, 64), (7, 4096), (33, 132)])
 def test_residual_layernorm_bit_exact(oracle, dev, n, d):
     """The tail of CrossAttentionLayer (residual + LayerNorm) in one kernel: the oracle restates its summation order."""
