@@ -338,7 +338,7 @@ def test_attention_train_forward_and_backward_match_oracle(oracle, dev, d, p):
 def test_attention_backward_in_one_half_precision_pass_tracks_the_fp32_backward(dev, d, half):
     """The autocast form of the attention backward (four matrix products as ONE fp16 / bf16 pass, fp32 accumulation, softmax rebuilt in
     fp32 from the forward's log-sum-exp) against the exact fp32 kernels on the same operands: the difference is the rounding of the
-    operands to 11 / 8 significant bits -- 2e-3 / 2e-2 of the gradient's scale; rows that belong to no code stay zero; with dropout."""
+    operands to 11 / 8 significant bits -- 4e-3 / 4e-2 of the gradient's largest entry; rows that belong to no code stay zero; with dropout."""
     from medtok_amd import ops
     rng = np.random.default_rng(d)
     q_len = np.array([40, 7, 0, 64, 33, 5, 150], np.int64); kv_len = np.array([50, 33, 12, 100, 0, 1, 300], np.int64)
@@ -352,7 +352,7 @@ def test_attention_backward_in_one_half_precision_pass_tracks_the_fp32_backward(
         out, lse = ops.shared_kv_attention_train(*args, int(q_len.max()), 0.2, p, 7)
         dq0, dkv0 = ops.shared_kv_attention_backward(*args, int(q_len.max()), int(kv_len.max()), 0.2, p, 7, out, lse, d_out)
         dq1, dkv1 = ops.shared_kv_attention_backward(*args, int(q_len.max()), int(kv_len.max()), 0.2, p, 7, out, lse, d_out, half=half)
-        tol = 2e-3 if half == torch.float16 else 2e-2
+        tol = 4e-3 if half == torch.float16 else 4e-2
         for a, b, what in ((dq1, dq0, "dq"), (dkv1, dkv0, "dkv")):
             err = float((a - b).abs().max()) / float(b.abs().max())
             assert err <= tol, (what, p, err)
