@@ -666,7 +666,9 @@ def main():
     # stream of its own counts shader cycles against the 100 MHz counter from here to the end of the K steps.  Only where the
     # measured work runs on ONE stream (a probe stream that lands on a hardware queue of a side stream would serialise with it);
     # the `full` workload takes it in its one-stream pass below.
-    single_stream = args.workload not in ("full", "fullref") or args.one_stream
+    # Not for cfg4 (torch's encoders / autograd use queues of their own: measured 107 -> 132 ms per step with the probe beside them) and
+    # not for timed regions under 0.2 s (stopping the probe costs ~0.1 ms inside the region).
+    single_stream = (args.workload not in ("full", "fullref", "cfg4") or (args.one_stream and args.workload != "cfg4")) and warm_s * args.steps >= 0.2
     probe = None
     if single_stream and not args.no_clock_probe:
         probe = ops.ClockProbe(dev, max_seconds=(3.0 * warm_s * args.steps + 5.0) if args.warmup else 120.0)
