@@ -75,6 +75,8 @@ AUTOCAST_HALF_PRODUCTS = True
 # training: the two directions of the cross-attention share every layer's weights, so their rows go through the layer's dense
 # products in one launch per product (CrossAttention._pooled_packed)
 MERGE_SIDES_IN_TRAINING = True
+# training: all searches of a forward under one autograd node, so that the codebook receives ONE dense gradient (_SoftVQMultiFunction)
+TRAIN_SINGLE_CODEBOOK_GRADIENT = True
 # inference at the reference's own width (e_dim = 64, 4 heads): the whole cross-attention of a forward -- both layers, both
 # directions, node mean -- in two launches with no host read (ops.cross_attention_small); needs a SORTED batch vector (PyG's are;
 # the kernels flag anything else in CrossAttention.small_status, checked wherever the forward synchronises anyway)
@@ -1047,6 +1049,58 @@ class _SoftVQFunction(torch.autograd.Function):
         return gx, gw, None, None, None, None, None
 
 
+class _SoftVQMultiFunction(torch.autograd.Function):
+    """All searches of a training forward under ONE autograd node: (zq_ste, vq, commit, xhat, idx, w) per search from its rows and its
+    region of the codebook -- the per-search forward of _SoftVQFunction, search by search.  What changes is the BACKWARD of the codebook:
+    the per-(row, slot) code gradients of all searches are summed per code in ONE segmented sum over global code ids and taken through
+    F.normalize once, so the weight receives ONE dense gradient.  (Six _SoftVQFunction nodes on six slices of the weight hand autograd
+    six dense [n_e, D] gradients -- a zero fill and a copy each for the slices -- that it then adds up: 1.9 ms of fills and adds per
+    step at n_e = 49152, D = 768.)"""
+
+    @staticmethod
+    def forward(ctx, weight, what, wsq, topk, path, beta, regions, *xs):
+        ctx.set_materialize_grads(False)
+        outs, saved, nondiff = [], [], []
+        for x, (lo, hi) in zip(xs, regions):
+            r = ops.soft_vq_forward(x.detach(), what[lo:hi], wsq[lo:hi].contiguous(), topk, path, want_sqerr=True)
+            n, d = x.shape
+            outs += [r["zq"], ops.sum_scale(r["row_sqerr"], (1.0 / (n * d)) if n else float("nan")), ops.sum_scale(r["row_sqerr"], beta / (n * d) if n else float("nan")),
+                     r["xhat"], r["idx"], r["w"]]
+            saved += [x, r["xhat"], r["idx"], r["w"]]
+            nondiff += [r["idx"], r["w"]]
+        ctx.save_for_backward(weight, what, *saved)
+        ctx.regions, ctx.beta, ctx.m = tuple(regions), beta, len(xs)
+        ctx.mark_non_differentiable(*nondiff)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        weight, what, *saved = ctx.saved_tensors
+        want_w = ctx.needs_input_grad[0]
+        as_f32 = lambda t: None if t is None else t.float()
+        gxs, g_codes, ids = [], [], []
+        for i in range(ctx.m):
+            x, xhat, idx, w = saved[4 * i: 4 * i + 4]
+            lo, hi = ctx.regions[i]
+            g_zq, g_vq, g_commit, g_xhat = grads[6 * i: 6 * i + 4]
+            n, d = x.shape
+            gx, g_code = ops.soft_vq_backward(x.detach(), xhat, what[lo:hi], idx, w, g_xhat=as_f32(g_xhat), g_out=as_f32(g_zq), g_vq=as_f32(g_vq),
+                                              g_commit=as_f32(g_commit), vq_scale=2.0 / (n * d), commit_scale=2.0 * ctx.beta / (n * d),
+                                              want_gx=ctx.needs_input_grad[7 + i], want_g_code=want_w)
+            gxs.append(gx)
+            if want_w and n:
+                g_codes.append(g_code)
+                ids.append(idx.reshape(-1) + lo if lo else idx.reshape(-1))
+        gw = None
+        if want_w:
+            if g_codes:
+                _, g_what = ops.ema_stats(torch.cat(g_codes), torch.cat(ids), what.shape[0])
+                gw = ops.normalize_backward(g_what, what, weight.detach())
+            else:
+                gw = torch.zeros_like(weight)
+        return (gw, None, None, None, None, None, None, *gxs)
+
+
 class VectorQuantizer(nn.Module):
     def __init__(self, n_e, e_dim, beta, entropy_loss_ratio, l2_norm, show_usage, split, kmeans=False,
                  num_head=4, k=5):
@@ -1348,6 +1402,50 @@ class VectorQuantizer(nn.Module):
         }
         return out
 
+    def _forward_train(self, z, text_features, graph_node_features, text_attention_mask, batch, z_aug, norm):
+        """forward() in training mode under autograd with a trainable codebook: the cross-attention, then ALL searches under one
+        autograd node (_SoftVQMultiFunction: one dense codebook gradient instead of six), then all usage-window updates in one call.
+        Same values as the general form below; None when it does not apply."""
+        if not (TRAIN_SINGLE_CODEBOOK_GRADIENT and self.training and torch.is_grad_enabled() and z.is_cuda and z.shape[0] > 0
+                and self.codebook.weight.requires_grad and self.e_dim % 4 == 0):
+            return None
+        what, wsq = norm
+        z_text, z_graph = torch.split(z, self.split, dim=-1)
+        aug = None if z_aug is None else torch.split(z_aug, self.split, dim=-1)
+        pooled_text, pooled_graph = self.cross_attn.pooled(text_features, text_attention_mask, graph_node_features, batch)
+        xs = [pooled_text, pooled_graph, self.project(z_text, "text"), self.project(z_graph, "graph")]
+        regions = [self._region("shared"), self._region("shared"), self._region("text"), self._region("graph")]
+        if aug is not None:
+            xs += [self.project(aug[0], "text"), self.project(aug[1], "graph")]
+            regions += [self._region("text"), self._region("graph")]
+        res = _SoftVQMultiFunction.apply(self.codebook.weight, what, wsq, self.k, self.search_path, float(self.beta), regions, *[x.float() for x in xs])
+        r = [res[6 * i: 6 * i + 6] for i in range(len(xs))]               # (zq, vq, commit, xhat, idx, w) per search
+        u_shared = u_text = u_graph = 0.0
+        if self.show_usage:
+            cnt = ops.usage_update_multi_(self.codebook_used, [torch.cat([r[0][4], r[1][4]], dim=-1)] + [q[4] for q in r[2:]], self.n_e)
+            u_shared, u_text, u_graph = (cnt[:3].cpu().double() / self.n_e).tolist()
+        out = {
+            "graph_feature": z_graph,
+            "text_feature": z_text,
+            "shared_text_embedding": r[0][0],
+            "shared_graph_embedding": r[1][0],
+            "shared_embed_loss": (r[0][1] + r[1][1], r[0][2] + r[1][2], r[0][3], r[1][3], r[0][0], r[1][0]),
+            "shared_codebook_usage": u_shared,
+            "specific_embedding_text": r[2][0],
+            "text_specific_loss": (r[2][1], r[2][2], r[2][3], r[2][0]),
+            "text_specific_usage": u_text,
+            "specific_embedding_graph": r[3][0],
+            "graph_specific_loss": (r[3][1], r[3][2], r[3][3], r[3][0]),
+            "graph_specific_usage": u_graph,
+            "specific_embedding_text_aug": r[4][0] if aug is not None else None,
+            "specific_embedding_graph_aug": r[5][0] if aug is not None else None,
+            "shared_text_tokens": r[0][4], "shared_text_tokens_weights": r[0][5],
+            "shared_graph_tokens": r[1][4], "shared_graph_tokens_weights": r[1][5],
+            "text_tokens": r[2][4], "text_tokens_weights": r[2][5],
+            "graph_tokens": r[3][4], "graph_tokens_weights": r[3][5],
+        }
+        return out
+
     def forward(self, z, text_features, graph_node_features, text_attention_mask, batch, z_aug=None):
         counts = []                     # the usage counts stay on the device: one sync at the end
         # one normalisation of the codebook per forward (training: re-normalised every forward, like the reference's every call;
@@ -1356,6 +1454,9 @@ class VectorQuantizer(nn.Module):
         small = self._forward_small_batch(z, text_features, graph_node_features, text_attention_mask, batch, z_aug, norm)
         if small is not None:
             return small
+        train = self._forward_train(z, text_features, graph_node_features, text_attention_mask, batch, z_aug, norm)
+        if train is not None:
+            return train
         z_text_embedding, z_graph_embedding = torch.split(z, self.split, dim=-1)
         aug = (None, None) if z_aug is None else torch.split(z_aug, self.split, dim=-1)
         early = None
