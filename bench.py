@@ -657,38 +657,37 @@ def main():
         rows = args.rows or {"cfg3": 600000, "full": 4096, "refdefault": 600000, "fullref": 256}.get(args.workload, 100000)
         wl = {"cfg3": Cfg3, "full": Full, "refdefault": RefDefault, "fullref": FullRefDefault}.get(args.workload, Cfg2)(rows, dev, seed=rank, path=args.path)
 
-    tw = time.perf_counter()
     for _ in range(args.warmup):
         wl.step()
     torch.cuda.synchronize(dev)
-    warm_s = (time.perf_counter() - tw) / max(args.warmup, 1)
-    # The shader clock of the timed region (the chip clocks to its power budget, and boxes differ): one idle wavefront per XCD on a
-    # stream of its own counts shader cycles against the 100 MHz counter from here to the end of the K steps.  Only where the
-    # measured work runs on ONE stream (a probe stream that lands on a hardware queue of a side stream would serialise with it);
-    # the `full` workload takes it in its one-stream pass below.
-    # Not for cfg4 (torch's encoders / autograd use queues of their own: measured 107 -> 132 ms per step with the probe beside them) and
-    # not for timed regions under 0.2 s (stopping the probe costs ~0.1 ms inside the region).
-    single_stream = (args.workload not in ("full", "fullref", "cfg4") or (args.one_stream and args.workload != "cfg4")) and warm_s * args.steps >= 0.2
-    probe = None
-    if single_stream and not args.no_clock_probe:
-        probe = ops.ClockProbe(dev, max_seconds=(3.0 * warm_s * args.steps + 5.0) if args.warmup else 120.0)
     mdist.barrier()
     torch.cuda.synchronize(dev)
     ops.profile_begin()                  # library brackets each search-kernel launch with HIP events on its stream
-    if probe is not None:
-        probe.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
-    if probe is not None:
-        torch.cuda.current_stream(dev).synchronize()      # the K steps are done (one stream); the probe ends with them, in front of
-        probe.__exit__(None, None, None)                  # the device-wide synchronize (which would otherwise wait for the probe's cap)
     torch.cuda.synchronize(dev)
     mdist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dev)
     prof = ops.profile_end()
-    clock = probe.result() if probe is not None else None
+    # The shader clock the steps run at (the chip clocks to its power budget, and boxes differ by a few per cent -- as much as a round's
+    # kernel work moves the headline): one idle wavefront per XCD on a stream of its own counts shader cycles against the 100 MHz
+    # counter over `clock_steps` FURTHER steps right behind the timed region (same state of the chip; the timed region itself runs
+    # with nothing beside it).  Only where the work is on ONE stream (a probe stream that lands on a hardware queue of a side stream
+    # would serialise with it; the `full` workload takes it in its one-stream pass below), not for cfg4 (torch's encoders / autograd
+    # use queues of their own: measured 107 -> 132 ms per step with the probe beside them), not where a step is too short to matter.
+    clock = None
+    step_s = elapsed / max(args.steps, 1)
+    single_stream = (args.workload not in ("full", "fullref", "cfg4") or (args.one_stream and args.workload != "cfg4")) and step_s >= 0.005
+    if single_stream and not args.no_clock_probe:
+        clock_steps = max(2, min(args.steps, int(0.5 / max(step_s, 1e-4))))
+        with ops.ClockProbe(dev, max_seconds=3.0 * step_s * clock_steps + 5.0) as probe:
+            for _ in range(clock_steps):
+                wl.step()
+            torch.cuda.current_stream(dev).synchronize()
+        clock = dict(probe.result(), region=f"{clock_steps} further steps right behind the timed region")
+        torch.cuda.synchronize(dev)
     prof_note = None
     one_stream_elapsed = None
     if args.workload in ("full", "fullref") and not args.no_one_stream_pass and not args.one_stream:
@@ -702,19 +701,19 @@ def main():
             wl.step()
             torch.cuda.synchronize(dev)
             ops.profile_begin()
-            probe1 = None if args.no_clock_probe else ops.ClockProbe(dev, max_seconds=3.0 * warm_s * args.steps + 5.0)
-            if probe1 is not None:
-                probe1.__enter__()
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 wl.step()
-            if probe1 is not None:
-                torch.cuda.current_stream(dev).synchronize()
-                probe1.__exit__(None, None, None)
-                clock = dict(probe1.result(), region="the one-stream pass")
             torch.cuda.synchronize(dev)
             one_stream_elapsed = time.perf_counter() - t1
             prof = ops.profile_end()
+            if not args.no_clock_probe and step_s >= 0.005:
+                with ops.ClockProbe(dev, max_seconds=3.0 * step_s * args.steps + 5.0) as probe1:
+                    for _ in range(max(2, args.steps)):
+                        wl.step()
+                    torch.cuda.current_stream(dev).synchronize()
+                clock = dict(probe1.result(), region="further one-stream steps behind the one-stream pass")
+                torch.cuda.synchronize(dev)
         finally:
             vqmod.SIDE_STREAM_MIN_CODES = keep
         prof_note = ("kernel durations from a second pass of the same steps on one stream (event pairs of overlapping streams include each "
@@ -851,8 +850,8 @@ def main():
                                                "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0)}
                                            for k, v in prof.items() if k != kname and v["launches"]}},
             "exact_fp32_path": exact,
-            # shader clock DURING the timed region (ops.ClockProbe): separates the box (its power budget / silicon) from the code when
-            # two lines differ by a few per cent; the dense-MFMA peaks above are quoted at 2.4 GHz
+            # shader clock of further steps of the same workload right behind the timed region (ops.ClockProbe): separates the box (its power
+            # budget / silicon) from the code when two lines differ by a few per cent; the dense-MFMA peaks above are quoted at 2.4 GHz
             "clock": clock,
         }
         if strong is not None:
