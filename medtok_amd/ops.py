@@ -65,7 +65,7 @@ class ClockProbe:
             return {}
         return dict(ghz_mean=sum(ghz) / len(ghz), ghz_min=min(ghz), ghz_max=max(ghz), seconds=max(r for _, r, _, _ in o) / 1e8,
                     per_xcd={int(x): c / (r * 10.0) for c, r, x, _ in o if r > 0},
-                    how="s_memtime cycles / s_memrealtime (100 MHz) ticks of one idle wavefront per XCD over the timed region")
+                    how="s_memtime cycles / s_memrealtime (100 MHz) ticks of one idle wavefront per XCD while the probe ran")
 
 
 def attention_width(d: int) -> int:
