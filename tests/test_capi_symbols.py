@@ -37,6 +37,24 @@ def test_library_loads_and_reports_version():
     assert lib.medtok_usage_workspace_bytes(300000, 21000) >= 300000 * 4
 
 
+def test_batched_search_planning_is_host_only():
+    """medtok_soft_vq_multi_eligible / ..._workspace_bytes are host arithmetic: which searches a batched call takes (the exact path, at
+    most 4096 rows) and what scratch it needs -- checked without a GPU"""
+    from medtok_amd import _lib
+    lib = _lib.load()
+    assert lib.medtok_soft_vq_multi_eligible(256, 7000, 64, 5) == 1 and lib.medtok_soft_vq_multi_eligible(512, 21000, 64, 5) == 1
+    assert lib.medtok_soft_vq_multi_eligible(4097, 21000, 64, 5) == 0            # too many rows
+    assert lib.medtok_soft_vq_multi_eligible(4096, 49152, 768, 5) == 0           # the fp16-filter path's territory
+    assert lib.medtok_soft_vq_multi_eligible(256, 7000, 62, 5) == 0              # d % 4
+    descs = (_lib.SearchDesc * 3)()
+    for i, (n, k) in enumerate(((512, 21000), (256, 7000), (256, 7000))):
+        descs[i] = _lib.SearchDesc(0, n, 0, 0, k, 0, 0, 0, 0, 0, 0, 0)
+    need = lib.medtok_soft_vq_forward_multi_workspace_bytes(descs, 3, 64, 5)
+    assert need > 512 * 4 + 2 * 256 * 4                                          # at least the squared norms
+    assert lib.medtok_soft_vq_forward_multi_workspace_bytes(descs, 7, 64, 5) == 0   # more searches than a call takes
+    assert lib.medtok_usage_multi_workspace_bytes(300000, 21000, 3) >= 300000 * 4 + 3 * 21001
+
+
 def test_code_object_targets_gfx950_only():
     from medtok_amd import _lib
     blob = _lib.library_path().read_bytes()

@@ -231,3 +231,42 @@ def test_small_batch_forward_equals_the_general_forward(dev, aug):
         else:
             assert x == y, k
     assert torch.equal(wins[0], wins[1])
+
+
+def test_small_batch_forward_at_d768_equals_the_general_forward(dev):
+    """a serving batch at BASELINE's width (B = 200, D = 768, n_e = 49152: every search on the exact path): the batched search / usage
+    calls behind the layer-by-layer cross-attention (the two-launch path is e_dim = 64 only) against the per-search form, bit for bit"""
+    import medtok_amd.vector_quantization_soft_one_new as vqmod
+    from medtok_amd import ops
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    bsz, d = 200, 768
+    g = torch.Generator(device=dev).manual_seed(8)
+    text = torch.randn(bsz, 64, d, device=dev, generator=g)
+    tok = torch.randint(1, 65, (bsz,), device=dev, generator=g)
+    mask = (torch.arange(64, device=dev)[None, :] < tok[:, None]).to(torch.int64)
+    n_nodes = torch.randint(1, 12, (bsz,), device=dev, generator=g)
+    batch = torch.repeat_interleave(torch.arange(bsz, device=dev), n_nodes)
+    nodes = torch.randn(int(n_nodes.sum()), d, device=dev, generator=g)
+    z = torch.randn(bsz, 2 * d, device=dev, generator=g)
+    assert ops.multi_search_eligible(2 * bsz, 49152, d, 5) and ops.multi_search_eligible(bsz, 16384, d, 5)
+    outs = []
+    for batched in (True, False):
+        torch.manual_seed(2)
+        vq = VectorQuantizer(49152, d, 0.25, 0.0, True, True, [d, d], k=5).to(dev).eval()
+        keep = vqmod.BATCHED_SMALL_SEARCHES
+        vqmod.BATCHED_SMALL_SEARCHES = batched
+        try:
+            with torch.no_grad():
+                outs.append(vq(z, text, nodes, mask, batch))
+        finally:
+            vqmod.BATCHED_SMALL_SEARCHES = keep
+    a, b = outs
+    for k in a:
+        x, y = a[k], b[k]
+        if isinstance(x, torch.Tensor):
+            assert torch.equal(x, y), k
+        elif isinstance(x, tuple):
+            for i, (p, q) in enumerate(zip(x, y)):
+                assert torch.equal(p, q), (k, i)
+        else:
+            assert x == y, k
