@@ -221,6 +221,96 @@ def fuzz_split_gemm(cases=200, seed=0, budget_s=None, log=None):
     return c + 1, bad
 
 
+def fuzz_small_width(cases=100, seed=0, budget_s=None, log=None):
+    """Random ragged batches through the two-launch cross-attention at e_dim = 64 (tiles that span many codes, codes without nodes /
+    without valid tokens, node counts around the tile size, every mask dtype, one to three layers) against the layer-by-layer
+    product path: 1e-5 of the output scale; and the device-side status word stays clear for sorted batch vectors."""
+    from medtok_amd.vector_quantization_soft_one_new import CrossAttention
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    over, elapsed = _timer(budget_s)
+    bad, c = [], 0
+    for c in range(cases):
+        if over():
+            break
+        bsz = int(rng.choice([1, 2, 7, 33, 64, 200]))
+        seq_len = int(rng.choice([1, 5, 31, 32, 33, 100, 512]))
+        max_nodes = int(rng.choice([1, 3, 8, 9, 17, 40, 90]))
+        layers = int(rng.choice([1, 2, 2, 3]))
+        g = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
+        torch.manual_seed(int(rng.integers(1 << 30)))
+        ca = CrossAttention(64, 4, dropout=0.1, layers=layers).to(dev).eval()
+        with torch.no_grad():
+            for layer in ca.model:
+                layer.multihead_attn.in_proj_bias.normal_(0, 0.3)
+                layer.multihead_attn.out_proj.bias.normal_(0, 0.3)
+                layer.layer_norm.weight.normal_(1.0, 0.3)
+                layer.layer_norm.bias.normal_(0, 0.3)
+        text = torch.randn(bsz, seq_len, 64, device=dev, generator=g) * float(rng.choice([0.1, 1.0, 3.0]))
+        tok = torch.randint(0 if c % 3 == 0 else 1, seq_len + 1, (bsz,), device=dev, generator=g)
+        n_nodes = torch.randint(0 if c % 2 == 0 else 1, max_nodes + 1, (bsz,), device=dev, generator=g)
+        mask = torch.arange(seq_len, device=dev)[None, :] < tok[:, None]
+        mask = mask if c % 4 == 0 else mask.to([torch.int64, torch.int32, torch.uint8][c % 3])
+        batch = torch.repeat_interleave(torch.arange(bsz, device=dev), n_nodes)
+        nodes = torch.randn(int(n_nodes.sum()), 64, device=dev, generator=g)
+        with torch.no_grad():
+            both = ca.pooled_small(text, mask, nodes, batch)
+            try:
+                ca.check_small_status()
+                flagged = False
+            except ValueError:
+                flagged = True
+            pt, pg = ca.pooled(text, mask, nodes, batch)
+        err = max(float((both[:, 0] - pt).abs().max()) / max(float(pt.abs().max()), 1e-30),
+                  float((both[:, 1] - pg).abs().max()) / max(float(pg.abs().max()), 1e-30))
+        if flagged or not (err <= 1e-5):
+            bad.append(f"small_width case {c}: B={bsz} L={seq_len} max_nodes={max_nodes} layers={layers} rel err {err:.3g} flagged={flagged}")
+            if log:
+                log(bad[-1])
+    return c + 1, bad
+
+
+def fuzz_multi_search(cases=100, seed=0, budget_s=None, log=None):
+    """Random batched search calls (1 to 6 searches, ragged row and code counts, region slices, k in {1, 2, 5, 8}, widths with and without
+    a k tail, strided x, strided zq output) against the single calls: every output bit for bit."""
+    from medtok_amd import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    over, elapsed = _timer(budget_s)
+    bad, c = [], 0
+    for c in range(cases):
+        if over():
+            break
+        d = int(rng.choice([4, 36, 64, 64, 128, 200, 768]))
+        topk = int(rng.choice([1, 2, 5, 5, 8]))
+        n_e = int(rng.choice([300, 1000, 3000, 21000])) if d <= 128 else int(rng.choice([300, 1000, 4000]))
+        g = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
+        what, wsq = ops.rownorm(torch.randn(n_e, d, device=dev, generator=g))
+        count = int(rng.integers(1, 7))
+        searches = []
+        for i in range(count):
+            n = int(rng.choice([1, 2, 31, 128, 129, 256, 500, 1000]))
+            lo = int(rng.integers(0, n_e - max(topk, 8)))
+            hi = int(rng.integers(lo + max(topk, 8), n_e + 1))
+            if not ops.multi_search_eligible(n, hi - lo, d, topk):
+                continue
+            wide = torch.randn(n, 2 * d, device=dev, generator=g)
+            x = wide[:, d:] if (i % 2 and d % 4 == 0 and (d * 4) % 16 == 0) else torch.randn(n, d, device=dev, generator=g)
+            out = torch.empty(n, 3 * d, device=dev)[:, d:2 * d] if i % 3 == 0 else None
+            searches.append(dict(x=x, what=what[lo:hi], wsq=wsq[lo:hi].contiguous(), out=out))
+        if not searches:
+            continue
+        res = ops.soft_vq_forward_multi(searches, topk)
+        for i, (q, r) in enumerate(zip(searches, res)):
+            one = ops.soft_vq_forward(q["x"].contiguous(), q["what"], q["wsq"], topk, want_sqerr=False)
+            diff = [key for key in ("xhat", "idx", "dist", "w", "zq") if not torch.equal(one[key], r[key])]
+            if diff:
+                bad.append(f"multi_search case {c} search {i}: n={q['x'].shape[0]} K={q['what'].shape[0]} d={d} k={topk} differs in {diff}")
+                if log:
+                    log(bad[-1])
+    return c + 1, bad
+
+
 def _same_outputs(a, b):
     bad = []
     for k in a:

@@ -40,3 +40,15 @@ def test_soak_forward_multi_stream_is_bit_stable(dev):
     import fuzzers
     ran, bad = fuzzers.soak_forward(runs=60, seed=0, budget_s=30)
     _report("soak_forward", ran, bad, 5)
+
+
+def test_fuzz_small_width_cross_attention_equals_the_layer_path(dev):
+    import fuzzers
+    ran, bad = fuzzers.fuzz_small_width(cases=400, seed=20255, budget_s=40)
+    _report("fuzz_small_width", ran, bad, 15)
+
+
+def test_fuzz_batched_searches_equal_the_single_calls(dev):
+    import fuzzers
+    ran, bad = fuzzers.fuzz_multi_search(cases=400, seed=20256, budget_s=30)
+    _report("fuzz_multi_search", ran, bad, 15)

@@ -11,6 +11,7 @@ carry no build-time switch), into devlib/<name>/libmedtok_vq.so (git-ignored; tr
   k64emu     TIMING ONLY (wrong results): halfbar + the copies of two stages issued together in every other stage -- the instruction
              stream of a 64-deep stage (half the barriers, bursts of eight copies per wave) on the 32-deep ring
   nobar      TIMING ONLY (wrong results): no stage barrier at all
+  rr16, rr8  the re-score kernel with 16 / 8 rows per block instead of 32 (same results)
 """
 import shutil, subprocess, sys
 from pathlib import Path
@@ -55,6 +56,11 @@ def mutate(name, src):
                     "        if (late && s > 0 && !(s & 1)) { stage(); stage(); }")
             t = sub(t, "        if (!late) stage();             // waves 0-3: stage s+3 (slot s-1: everyone is past reading it)",
                     "        if (!late && !(s & 1)) { stage(); stage(); }")
+    elif name in ("rr16", "rr8"):
+        # TIMING + results stay right: the re-score's rows per block (32 in the product)
+        rr = name[2:]
+        h = sub(h, "hipLaunchKernelGGL((rescore_kernel<T, 32>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, MEDTOK_RESCORE_ARGS);",
+                f"hipLaunchKernelGGL((rescore_kernel<T, {rr}>), dim3((unsigned)((n + {rr} - 1) / {rr})), dim3(8 * {rr}), 0, s, MEDTOK_RESCORE_ARGS);")
     else:
         raise SystemExit(f"unknown mutant {name}")
     f.write_text(t); hip.write_text(h)
