@@ -1,5 +1,6 @@
-// attention_small.h -- CrossAttention.pooled at the reference's own width (e_dim = 64, 4 heads: train_MedTok.py:363-368) in ONE launch:
-// both layers of both directions, from the raw text / node features to the pooled rows the shared searches read.
+// attention_small.h -- CrossAttention.pooled at the reference's own width (e_dim = 64, 4 heads: train_MedTok.py:363-368) in TWO launches
+// (the layers, then the node mean): both layers of both directions, from the raw text / node features to the pooled rows the shared
+// searches read.
 // Included by medtok_vq.hip after attention_pp.h; gfx950 only.
 //
 //     for every code b (vector_quantization_soft_one_new.py:133-142, 17-88):
