@@ -51,7 +51,8 @@ extern "C" {
 #define MEDTOK_PLAN_FILTER_XCD(on) (((on) ? 2 : 1) << 16)           /* XCD-aware block order on / off (full 256-CU device only) */
 #define MEDTOK_PLAN_FILTER_TAIL(on) (((on) ? 2 : 1) << 18)          /* tail launch from 256 blocks up / never */
 #define MEDTOK_PLAN_SEARCH_MAX_SPLITS(s) (((s) & 0xFF) << 20)       /* 0 = default */
-#define MEDTOK_PLAN_FILTER_ROWS64(on) (((on) ? 2 : 1) << 28)        /* D <= 64: the 128-byte-row filter kernel on / off (default on) */
+#define MEDTOK_PLAN_FILTER_ROWS64(on) (((on) ? 2 : 1) << 28)        /* D <= 64: the 128-byte-row filter kernels on / off (default on) */
+#define MEDTOK_PLAN_FILTER_ROWS64_WIDE (3 << 28)                    /* D <= 64: the 128 x 64 wave-tile form (two blocks per CU) instead of the 128 x 32 one */
 
 /* flags for medtok_soft_assign_f32 */
 #define MEDTOK_ASSIGN_HARD 1        /* NormEMA form: topk == 1, zq = what[idx]        */

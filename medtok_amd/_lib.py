@@ -39,8 +39,8 @@ def plan_path(path: int = PATH_AUTO, filter_splits: int = 0, filter_xcd=None, fi
     if filter_tail is not None:
         p |= (2 if filter_tail else 1) << 18
     p |= (search_max_splits & 0xFF) << 20
-    if filter_rows64 is not None:
-        p |= (2 if filter_rows64 else 1) << 28
+    if filter_rows64 is not None:      # False / True; "wide": the 128 x 64 wave-tile form of the D <= 64 kernel
+        p |= (3 if filter_rows64 == "wide" else 2 if filter_rows64 else 1) << 28
     return p
 
 _vp, _i64, _int, _sz, _f, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_float, C.c_double

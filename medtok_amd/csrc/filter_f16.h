@@ -1161,6 +1161,220 @@ __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
 #undef R64_LANE_CB
 }
 
+// ---------------------------------------------------------------- the same with 32-row wave tiles: three blocks per CU
+// Where filter_rows64_kernel stands (profiles/r05_valu_refdefault.txt, counters per launch): the VALU is busy 45 % of the SIMD
+// cycles, the matrix pipe 33 %, and a wave has an instruction in flight during 42 % of its cycles -- neither pipe binds; what binds
+// is that a SIMD has TWO waves to cover the serial pieces of each other's tile (32 dependent-issue MFMAs, then a scan full of
+// compare -> scalar branch chains, then a block-wide barrier), and the 128-register accumulator tile is what limits it to two.
+// This form halves the wave tile instead: 128 codes x 32 rows = 4 accumulator tiles (64 registers), ONE row per lane, 16 registers
+// of x fragments -- under 168 registers, three waves per SIMD.  Blocks of four waves, all row-side (tile 128 codes x 128 rows: the
+// same L2 -> LDS bytes per flop as the 256 x 128 tile of two code-side waves), code tiles of 128 codes = 16 KB, LDS 33 KB -> three
+// blocks per CU, each with its own barrier.  A wave reads the whole code tile as A operands (one ds_read_b128 per MFMA, twice the
+// LDS traffic per flop: 1 KB per 32 matrix-pipe cycles and SIMD, half the LDS's rate if all four SIMDs are in their MFMA phase
+// at once).  With one code-side wave a row's lists are complete inside the wave: the limit comes from the two half-waves' k-lists
+// by one permlane exchange, after EVERY tile (no LDS lists, no sort), and a row has two candidate lists per split, not four.
+// Scores, thresholds and list format are those of the kernels above; the learning phase covers the same 2048 codes.
+constexpr int R64N_BM = 128, R64N_BN = 128, R64N_THREADS = 256;
+constexpr int R64N_TILEB = R64N_BM * R64_ROWB;                      // 16 KB per code tile
+constexpr size_t R64N_RING_BYTES = 2 * (size_t)R64N_TILEB;
+constexpr size_t R64N_SMEM_BYTES = R64N_RING_BYTES + 2 * R64N_BM * 4;      // + start values of two code tiles: 33 KB
+constexpr int R64N_LEARN = 16;
+constexpr int R64N_OWN_PER_SPLIT = 2;                              // candidate lists per row and split: the two half-waves
+
+// the k-th best of a row over the codes both half-waves have seen: {min(a_i, b_{k-1-i})} are the k smallest of the union of two
+// sorted lists, their maximum is the k-th
+template <int TOPK>
+__device__ __forceinline__ void filter_merge_halves(FilterRow<TOPK> &r, int lh)
+{
+    float t = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < TOPK; ++i) t = v_max(t, v_min(r.tv[i], other_half(r.tv[TOPK - 1 - i], lh)));
+    r.L = filter_limit(t, r.win);
+}
+
+template <int TOPK>
+__global__ __launch_bounds__(R64N_THREADS, 3) void filter_rows64n_kernel(
+    const _Float16 *__restrict__ xh, const _Float16 *__restrict__ wh, const float *__restrict__ xsq,
+    const float *__restrict__ wsqs, const float *__restrict__ en_max_ptr, long n, int k_codes, int d,
+    int codes_per_split, int own_total, uint2 *__restrict__ cand, int *__restrict__ cand_cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int li = lane & 31, lh = lane >> 5;
+    const long row0 = (long)blockIdx.x * R64N_BN;
+    const int split = blockIdx.y;
+    const int code_lo = split * codes_per_split;
+    const int code_hi = min(k_codes, code_lo + codes_per_split);
+    const int nct = (code_hi - code_lo + R64N_BM - 1) / R64N_BM;
+
+    // ---- the wave's 32 x rows as B operands of the four k16 steps (the fp16 image is padded to a multiple of 256 rows)
+    half8 xf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xf[t] = *reinterpret_cast<const half8 *>(xh + (row0 + wave * 32 + li) * 64 + 16 * t + 8 * lh);
+
+    // ---- code tiles by LDS-DMA: wave w copies tile rows [32 w, 32 w + 32), 8 rows per instruction, chunk swizzle as above
+    const unsigned lane_off = (unsigned)((wave * 32 + (lane >> 3)) * 64 + (((lane & 7) ^ (lane >> 3)) << 3)) * 2u;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)(wh + (long)code_lo * 64), 0, -1, 0x00020000);
+    const int W = min(R64N_LEARN, nct), nsteps = nct + W;
+    auto tile_of = [&](int st) __attribute__((always_inline)) -> int {
+        st = min(st, nsteps - 1);
+        return __builtin_amdgcn_readfirstlane(st < nct ? st : st - nct);
+    };
+    auto stage_piece = [&](int st, int so, int q) __attribute__((always_inline)) {
+        char *base = fsm + (st & 1) * R64N_TILEB + wave_s * (32 * R64_ROWB);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(base + q * 8 * R64_ROWB), 16, (int)lane_off,
+                                                 so + q * 8 * R64_ROWB, 0, 0);
+    };
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(wsqs + code_lo), 0, -1, 0x00020000);
+    auto stage_init = [&](int st) __attribute__((always_inline)) {
+        const int so = tile_of(st) * (R64N_BM * 4);
+        if (wave_s == 0 && lane < 32)          // 128 start values = 512 bytes: half a wavefront of 16-byte lanes
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (__attribute__((address_space(3))) void *)(fsm + R64N_RING_BYTES + (st & 1) * (R64N_BM * 4)),
+                                                     16, lane * 16, so, 0, 0);
+    };
+    const unsigned init_adr = (unsigned)(size_t)(fsm + R64N_RING_BYTES) + (unsigned)(4 * lh) * 4u;
+#define R64N_INIT_LDS(M, st) \
+    do { acc[M] = lds_init_issue(init_adr + (unsigned)(((st) & 1) * (R64N_BM * 4) + (M) * 128)); } while (0)
+#define R64N_LANE_CB(M, tile) (code_lo + (tile) * R64N_BM + (M) * 32 + 4 * lh)
+
+    // ---- per-lane state
+    const float en_max = en_max_ptr[0];
+    const bool sane = en_max <= F_NORM_LIMIT;
+    const int owner = split * R64N_OWN_PER_SPLIT + lh;
+    const char *cbase = reinterpret_cast<const char *>(cand + row0 * own_total * F_CAP);
+    FilterRow<TOPK> row;
+    const int rl = wave * 32 + li;
+    const long xr = row0 + rl;
+#pragma unroll
+    for (int j = 0; j < TOPK; ++j) row.tv[j] = INFINITY;
+    row.L = INFINITY;
+    row.xn = 0.f;
+    row.win = xr < n ? 2.0f * filter_eps(xsq[min(xr, n - 1)], en_max, d) : -INFINITY;
+    row.pos = (unsigned)((rl * own_total + owner) * F_CAP) * 8u;
+    row.endm8 = row.pos + (F_CAP - 1) * 8u;
+    row.lst = 0;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {       // start values of the first code tile by vector loads (nothing is in flight yet)
+        float4 e4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e4[g] = ld4(wsqs + R64N_LANE_CB(m, 0) + 8 * g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float4 q4 = e4[r >> 2];
+            acc[m][r] = (r & 3) == 0 ? q4.x : (r & 3) == 1 ? q4.y : (r & 3) == 2 ? q4.z : q4.w;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage_init(1);
+    {
+        const int so = tile_of(0) * R64N_TILEB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stage_piece(0, so, q);
+    }
+
+    // A fragments: row i = m 32 + li of the tile, source chunk 2 t + lh at position (2 t + lh) ^ (i & 7)
+    unsigned a_adr[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a_adr[t] = (unsigned)(size_t)fsm + (unsigned)(li * R64_ROWB + (((2 * t + lh) ^ (li & 7)) << 4));
+
+    // the 16 MFMAs of a code tile, (k16 step, code group) by (k16 step, code group): the A operand of MFMA i + 2 is read while
+    // MFMA i issues (three rotating fragments, counted waits); one piece of the next tile's copy behind every fourth
+    auto mfma_tile = [&](int st) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)((st & 1) * R64N_TILEB);
+        const int dma_so = tile_of(st + 1) * R64N_TILEB;
+        unsigned adr[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) adr[t] = a_adr[t] + so;
+        fu32x4 fa[3];
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096" : "=&v"(fa[0]), "=&v"(fa[1]) : "v"(adr[0]) : "memory");
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = i >> 2, m = i & 3;
+            fu32x4 &cur = fa[i % 3];
+            if (i + 2 < 16) {
+                fu32x4 &nxt = fa[(i + 2) % 3];
+                const int t2 = (i + 2) >> 2, m2 = (i + 2) & 3;
+                asm volatile("ds_read_b128 %0, %2 offset:%3\n\ts_waitcnt lgkmcnt(2)" : "=&v"(nxt), "+v"(cur) : "v"(adr[t2]), "i"(m2 * 4096) : "memory");
+            } else if (i + 1 < 16) {
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cur) : : "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur) : : "memory");
+            }
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, cur), xf[t], acc[m], 0, 0, 0);
+            if ((i & 3) == 3) stage_piece(st + 1, dma_so, i >> 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    unsigned long multi = 0;
+    float cc = -0x1p-15f;
+    asm volatile("" : "+v"(cc));
+    auto init_wait = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    };
+    // learning step: the best of each accumulator tile into the lane's list, no appends; the limit is set after the last one
+    auto learn_epilogue = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x16 &a = acc[m];
+            float mx = v_max3(a[0], a[1], a[2]);
+#pragma unroll
+            for (int r = 3; r + 1 < 16; r += 2) mx = v_max3(mx, a[r], a[r + 1]);
+            mx = v_max(mx, a[15]);
+            const float u = mx * -0x1p-15f;
+            thr_insert_med3<TOPK>(row.tv, u == u ? u : INFINITY);
+            R64N_INIT_LDS(m, st + 1);
+        }
+        if (st + 1 >= W) filter_merge_halves<TOPK>(row, lh);
+        init_wait();
+    };
+    // scanning step: bias = 0 -> append and insert (tiles W .. nct-1); bias = +inf -> append only (the learning tiles, revisited)
+    auto scan_epilogue = [&](int st, float bias) __attribute__((always_inline)) {
+        const int tile = tile_of(st);
+#define R64N_ONE(M)                                                                                                      \
+        do {                                                                                                             \
+            const int cb_ = R64N_LANE_CB(M, tile);                                                                       \
+            filter_scan<TOPK, false, true>(row, acc[M], cb_, cbase, multi, nullptr, cc, bias);                            \
+            if (multi) { filter_scan_rest<TOPK, true, true>(row, acc[M], cb_, cbase, cc, bias); multi = 0; }             \
+            R64N_INIT_LDS(M, st + 1);                                                                                    \
+        } while (0)
+        R64N_ONE(0); R64N_ONE(1); R64N_ONE(2); R64N_ONE(3);
+#undef R64N_ONE
+        if (st < nct) filter_merge_halves<TOPK>(row, lh);
+        init_wait();
+    };
+    // one step up to its epilogue (see filter_rows64_kernel: the same protocol on a ring of 16 KB slots)
+    auto step_head = [&](int t) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage_init(t + 2);
+        mfma_tile(t);
+        // (the wait states an asm reader of an MFMA result needs: see filter_rows64_kernel)
+        asm volatile("s_nop 15\n\ts_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    };
+    int t = 0;
+    for (; t < W; ++t) {
+        step_head(t);
+        learn_epilogue(t);
+    }
+    for (; t < nsteps; ++t) {
+        step_head(t);
+        scan_epilogue(t, __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(t < nct ? 0 : 0x7f800000)));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        const bool ok = sane && xsq[min(xr, n - 1)] <= F_NORM_LIMIT;
+        const unsigned first = row.endm8 - (F_CAP - 1) * 8u;
+        if (xr < n) cand_cnt[xr * own_total + owner] = ok ? (int)((row.pos - first) >> 3) : F_CAP + 1;
+    }
+#undef R64N_INIT_LDS
+#undef R64N_LANE_CB
+}
+
 // ---------------------------------------------------------------- exact re-score
 // Block = RR rows x 8 lanes (RR = 32; 8 for searches of a few thousand rows, where 32-row blocks would leave most CUs without one
 // and each block would crawl through its ~220 chains alone: 4096 rows: 0.24 -> see DESIGN).  Phase 1 (per row, 8 lanes): the row's true t~ = k-th smallest d~ over all

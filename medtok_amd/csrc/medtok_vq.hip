@@ -230,16 +230,67 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ 
     if (sqn && lane == 0) sqn[row] = p;
 }
 
+// Rows of at most 64 floats (the reference's e_dim): rownorm_kernel leaves 48 of a wavefront's 64 lanes without an element.  Here a
+// row has 16 lanes (lane l of its group owns float4 #l, as there), four rows share a wavefront, and the butterfly runs over the
+// offsets 8..1 only -- the offsets 32 and 16 of the one-row kernel add the zeros of idle lanes, so the bits are the same.
+template <bool NORMALIZE>
+__global__ __launch_bounds__(256) void rownorm16_kernel(const float *__restrict__ x, long n, int d,
+                                                        float *xhat, float *__restrict__ sqn, _Float16 *__restrict__ xh = nullptr, int dp = 0)
+{
+    const int sub = threadIdx.x & 15;
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = row < n, mine = live && sub * 4 < d;
+    const long r = live ? row : 0;
+    const float *src = x + r * d + sub * 4;
+    float4 v = mine ? ld4(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float p = 0.f;
+    p = fmaf(v.x, v.x, p); p = fmaf(v.y, v.y, p); p = fmaf(v.z, v.z, p); p = fmaf(v.w, v.w, p);
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    if (NORMALIZE) {
+        const float den = fmaxf(sqrtf(p), 1e-12f);
+        v.x = v.x / den; v.y = v.y / den; v.z = v.z / den; v.w = v.w / den;
+        if (mine) {
+            st4(xhat + r * d + sub * 4, v);
+            if (xh) {
+                rn_half4 h;
+                h[0] = (_Float16)(v.x * 256.0f); h[1] = (_Float16)(v.y * 256.0f); h[2] = (_Float16)(v.z * 256.0f); h[3] = (_Float16)(v.w * 256.0f);
+                *reinterpret_cast<rn_half4 *>(xh + r * dp + sub * 4) = h;
+            }
+        } else if (live && xh && sub * 4 < dp) {
+            rn_half4 z;
+            z[0] = z[1] = z[2] = z[3] = (_Float16)0.f;
+            *reinterpret_cast<rn_half4 *>(xh + r * dp + sub * 4) = z;
+        }
+        p = 0.f;
+        p = fmaf(v.x, v.x, p); p = fmaf(v.y, v.y, p); p = fmaf(v.z, v.z, p); p = fmaf(v.w, v.w, p);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    } else if (mine && xhat && xhat != x) {
+        st4(xhat + r * d + sub * 4, v);
+    }
+    if (sqn && live && sub == 0) sqn[row] = p;
+}
+
+// the launch every caller of the row-norm kernels goes through: the 16-lanes-per-row form where a row fits it
+template <bool NORMALIZE>
+static inline void launch_rownorm(hipStream_t s, const float *x, long n, int d, float *xhat, float *sqn, _Float16 *xh = nullptr, int dp = 0)
+{
+    if (d <= 64 && (!xh || dp <= 64))
+        hipLaunchKernelGGL(rownorm16_kernel<NORMALIZE>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, x, n, d, xhat, sqn, xh, dp);
+    else
+        hipLaunchKernelGGL(rownorm_kernel<NORMALIZE>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, n, d, xhat, sqn, xh, dp);
+}
+
 extern "C" int medtok_rownorm_f32(const float *x, int64_t n, int d, int normalize, float *xhat,
                                   float *sqn, void *stream)
 {
     if (n < 0 || d <= 0 || (d & 3)) return fail("rownorm: need n >= 0, d > 0, d %% 4 == 0 (n=%ld d=%d)", (long)n, d);
     if (n == 0) return 0;                      // (an empty torch tensor has a null data pointer: sizes first, pointers after)
     if (normalize && !xhat) return fail("rownorm: xhat required when normalize != 0");
-    dim3 grid((unsigned)((n + 3) / 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (normalize) hipLaunchKernelGGL(rownorm_kernel<true>, grid, block, 0, s, x, (long)n, d, xhat, sqn);
-    else hipLaunchKernelGGL(rownorm_kernel<false>, grid, block, 0, s, x, (long)n, d, xhat, sqn);
+    if (normalize) launch_rownorm<true>(s, x, (long)n, d, xhat, sqn);
+    else launch_rownorm<false>(s, x, (long)n, d, xhat, sqn);
     return check_launch("rownorm");
 }
 
@@ -760,7 +811,7 @@ static PlanOverride decode_plan(int path)
     if (xcd) o.filter_xcd = xcd - 1;
     if (tail) o.filter_tail_min_blocks = tail == 1 ? 0 : 256;
     if (ss) o.search_max_splits = ss;
-    const int r64 = (path >> 28) & 3;
+    const int r64 = (path >> 28) & 3;          // 1 = off, 2 = on (the default at D <= 64), 3 = on, the earlier 128 x 64 wave-tile kernel
     if (r64) o.filter_rows64 = r64 - 1;
     return o;
 }
@@ -842,7 +893,8 @@ struct FilterPlan {
     long n_pad, k_pad, row_tiles;
     int dp, splits, codes_per_split, own_total, tslots;
     int xcd_rows;      // > 0: XCD-aware block order with this many row tiles per XCD at a time (32 / splits)
-    bool rows64;       // dp == 64: filter_rows64_kernel (row tiles of 128, two 4-wave blocks per CU, no tail launch)
+    bool rows64;       // dp == 64: the narrow-row kernels (row tiles of 128, 4-wave blocks, no tail launch)
+    bool rows64_wide;  // ... of which filter_rows64_kernel (128 x 64 wave tiles, two blocks per CU) instead of filter_rows64n_kernel (plan bit)
     int row_bn;        // rows per row tile of the kernel that runs
     // tail launch: the last main_tiles..row_tiles row tiles with more, shorter splits (0 tiles = none)
     long main_tiles;
@@ -864,13 +916,14 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk, const
     f.row_tiles = f.n_pad / F_BN;
     const long code_tiles = f.k_pad / F_BM;
     f.rows64 = f.dp == 64 && ov.filter_rows64 != 0;
+    f.rows64_wide = f.rows64 && ov.filter_rows64 == 2;
     f.row_bn = f.rows64 ? R64_BN : F_BN;
     if (f.rows64) {
-        // two blocks per CU, every one walking its whole code range with the x rows in registers: nothing is shared between
+        // two or three blocks per CU, every one walking its whole code range with the x rows in registers: nothing is shared between
         // blocks but the codebook (K x 128 B, L2-resident), so one split as soon as the chip is full four times over --
-        // every split adds four candidate lists per row and restarts the thresholds
+        // every split adds candidate lists per row (four; two with 32-row wave tiles) and restarts the thresholds
         f.row_tiles = f.n_pad / R64_BN;
-        const long slots = 2L * di.cus;
+        const long slots = (f.rows64_wide ? 2L : 3L) * di.cus;
         long want = f.row_tiles >= 4 * slots ? 1 : (4 * slots + f.row_tiles - 1) / f.row_tiles;
         if (ov.filter_splits > 0) want = ov.filter_splits;
         if (want > code_tiles) want = code_tiles;
@@ -879,7 +932,7 @@ static FilterPlan plan_filter(int64_t n, int64_t k_codes, int d, int topk, const
         const long tiles_per_split = (code_tiles + want - 1) / want;
         f.codes_per_split = (int)(tiles_per_split * R64_BM);
         f.splits = (int)((code_tiles + tiles_per_split - 1) / tiles_per_split);
-        f.own_total = f.splits * F_OWN_PER_SPLIT;
+        f.own_total = f.splits * (f.rows64_wide ? F_OWN_PER_SPLIT : R64N_OWN_PER_SPLIT);
         f.xcd_rows = 0;
         f.main_tiles = f.row_tiles; f.tail_splits = 0; f.tail_codes_per_split = 0; f.own_tail = 0;
         return f;
@@ -1096,7 +1149,10 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, w.wh);
     hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, w.en_max, w.wsqp, (int)f.k_pad, w.fb_count);
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
-    if (f.rows64) {
+    if (f.rows64 && !f.rows64_wide) {
+        hipLaunchKernelGGL((filter_rows64n_kernel<T>), dim3((unsigned)f.row_tiles, (unsigned)f.splits), dim3(R64N_THREADS), R64N_SMEM_BYTES, s,
+                           w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, d, f.codes_per_split, f.own_total, w.cand, w.cand_cnt);
+    } else if (f.rows64) {
         (void)set_lds_once<filter_rows64_kernel<T>>(R64_SMEM_BYTES);
         hipLaunchKernelGGL((filter_rows64_kernel<T>), dim3((unsigned)f.row_tiles, (unsigned)f.splits), dim3(R64_THREADS), R64_SMEM_BYTES, s,
                            w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, d, f.codes_per_split, f.own_total, w.cand, w.cand_cnt);
@@ -1204,7 +1260,8 @@ extern "C" int medtok_debug_filter_probe(const float *xhat, const float *xsq, in
                                          int topk, void *ws, size_t ws_bytes, void *probe, size_t probe_bytes, int64_t *n_blocks, void *stream)
 {
     if (topk < 2 || topk > 5) return fail("filter_probe: topk 2..5");
-    const PlanOverride ov = decode_plan(MEDTOK_PATH_F16_FILTER);
+    // (at D <= 64 the timed instantiation is the 128 x 64 wave-tile kernel's: size the workspace with MEDTOK_PLAN_FILTER_ROWS64_WIDE)
+    const PlanOverride ov = decode_plan(MEDTOK_PATH_F16_FILTER | MEDTOK_PLAN_FILTER_ROWS64_WIDE);
     const FilterPlan f = plan_filter(n, k_codes, d, topk, ov);
     const FilterWs w = filter_ws_layout(ws, n, f);
     if (!ws || ws_bytes < w.total) return fail("filter_probe: workspace too small (%zu < %zu)", ws_bytes, w.total);
@@ -1723,7 +1780,7 @@ extern "C" int medtok_frobenius_f32(const float *x, int64_t rows, int d, float *
     if (!x || !out || !ws || ws_bytes < (size_t)rows * 4) return fail("frobenius: NULL argument or workspace too small");
     hipStream_t s = (hipStream_t)stream;
     float *sq = (float *)ws;
-    hipLaunchKernelGGL(rownorm_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, (long)rows, d, (float *)nullptr, sq, (_Float16 *)nullptr, 0);
+    launch_rownorm<false>(s, x, (long)rows, d, (float *)nullptr, sq);
     hipLaunchKernelGGL(frobenius_kernel, dim3(1), dim3(1024), 0, s, sq, (long)rows, out);
     return check_launch("frobenius");
 }
@@ -2856,7 +2913,7 @@ extern "C" int medtok_normalized_search_f32(const float *z, int64_t n, int d, co
         const FilterWs fw = filter_ws_layout(ws, n, f);
         if (!ws || ws_bytes < fw.total) return fail("normalized_search: workspace too small (%zu < %zu)", ws_bytes, fw.total);
         hipStream_t s = (hipStream_t)stream;
-        hipLaunchKernelGGL(rownorm_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, z, (long)n, d, zhat, zsq, fw.xh, f.dp);
+        launch_rownorm<true>(s, z, (long)n, d, zhat, zsq, fw.xh, f.dp);
         if (f.n_pad > n && hipMemsetAsync(fw.xh + (size_t)n * f.dp, 0, (size_t)(f.n_pad - n) * f.dp * 2, s) != hipSuccess)
             return fail("normalized_search: memset failed");
         if (check_launch("rownorm(+fp16)")) return 1;
@@ -2893,7 +2950,7 @@ extern "C" int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d, cons
         const FilterPlan f = plan_filter(n, k_codes, d, topk, decode_plan(path));
         const FilterWs fw = filter_ws_layout(sws, n, f);
         hipStream_t s = (hipStream_t)stream;
-        hipLaunchKernelGGL(rownorm_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, (long)n, d, xhat, xsq, fw.xh, f.dp);
+        launch_rownorm<true>(s, x, (long)n, d, xhat, xsq, fw.xh, f.dp);
         if (f.n_pad > n && hipMemsetAsync(fw.xh + (size_t)n * f.dp, 0, (size_t)(f.n_pad - n) * f.dp * 2, s) != hipSuccess)
             return fail("soft_vq_forward: memset failed");
         if (check_launch("rownorm(+fp16)")) return 1;

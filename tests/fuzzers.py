@@ -111,7 +111,8 @@ def fuzz_rows64(cases=100, seed=0, budget_s=None, max_rows=200000, log=None):
         xh, xs = ops.rownorm(x)
         wh, ws = ops.rownorm(W)
         i0, d0 = ops.topk_search(xh, xs, wh, ws, k, ops.PATH_F32_MFMA)
-        for env in (dict(filter_rows64=True), dict(filter_rows64=True, filter_splits=int(rng.choice([1, 2, 4, 8]))), dict(filter_rows64=False)):
+        for env in (dict(filter_rows64=True), dict(filter_rows64=True, filter_splits=int(rng.choice([1, 2, 4, 8]))), dict(filter_rows64=False),
+                    dict(filter_rows64="wide", filter_splits=int(rng.choice([0, 1, 2, 4])))):      # both wave-tile forms of the narrow-row kernel
             i1, d1 = ops.topk_search(xh, xs, wh, ws, k, ops.plan_path(ops.PATH_F16_FILTER, **env))
             if not (torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32))):
                 bad.append(f"rows64 case {c}: n={n} K={K} D={D} k={k} kind={kind} env={env} rows differing {(i0 != i1).any(1).sum().item()}")

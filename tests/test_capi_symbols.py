@@ -90,5 +90,8 @@ def test_header_macros_agree_with_the_python_binding():
     ws = lambda n, k, d, path: lib.medtok_search_workspace_bytes(n, k, d, 5, path)
     f = _lib.PATH_F16_FILTER
     assert ws(100000, 8192, 768, _lib.plan_path(f, filter_splits=4)) > ws(100000, 8192, 768, _lib.plan_path(f, filter_splits=1))
-    assert ws(100000, 8192, 64, _lib.plan_path(f, filter_rows64=True, filter_splits=2)) == ws(100000, 8192, 64, _lib.plan_path(f, filter_rows64=False, filter_splits=2))
+    assert _lib.plan_path(0, filter_rows64="wide") == int(macro("MEDTOK_PLAN_FILTER_ROWS64_WIDE").replace("(", "").replace(")", "").split("<<")[0]) << 28
+    # D <= 64: the 128 x 64 wave-tile kernel keeps four candidate lists per row and split like the general one, the 128 x 32 one two
+    assert ws(100000, 8192, 64, _lib.plan_path(f, filter_rows64="wide", filter_splits=2)) == ws(100000, 8192, 64, _lib.plan_path(f, filter_rows64=False, filter_splits=2))
+    assert ws(100000, 8192, 64, _lib.plan_path(f, filter_rows64=True, filter_splits=2)) < ws(100000, 8192, 64, _lib.plan_path(f, filter_rows64=False, filter_splits=2))
     assert ws(100000, 8192, 16, _lib.plan_path(f, filter_splits=2)) == ws(100000, 8192, 64, _lib.plan_path(f, filter_splits=2))      # D <= 32: 64 columns

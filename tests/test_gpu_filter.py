@@ -273,8 +273,10 @@ def test_rows64_kernel_equals_exact_path_and_general_kernel(oracle, dev, n, K, D
     finally:
         ops.SEARCH_STATS = None
     i_g, d_g = ops.topk_search(xh, xs, wh, ws, topk, _filter_path(filter_splits=splits, filter_rows64=False))
+    i_w, d_w = ops.topk_search(xh, xs, wh, ws, topk, _filter_path(filter_splits=splits, filter_rows64="wide"))     # 128 x 64 wave tiles
     assert torch.equal(i_r, i_ref) and torch.equal(d_r, d_ref)
     assert torch.equal(i_g, i_ref) and torch.equal(d_g, d_ref)
+    assert torch.equal(i_w, i_ref) and torch.equal(d_w, d_ref)
     sub = slice(0, 200)
     io, do = oracle.topk_search(xh[sub].cpu().numpy(), xs[sub].cpu().numpy(), wh.cpu().numpy(), ws.cpu().numpy(), topk)
     assert np.array_equal(i_r[sub].cpu().numpy(), io) and np.array_equal(d_r[sub].cpu().numpy(), do)
@@ -295,8 +297,9 @@ def test_rows64_kernel_with_near_copies_of_codes(oracle, dev):
     wh, ws = ops.rownorm(W)
     for topk in (1, 5, 8):
         i_ref, d_ref = ops.topk_search(xh, xs, wh, ws, topk, ops.PATH_F32_MFMA)
-        i_r, d_r = ops.topk_search(xh, xs, wh, ws, topk, _filter_path(filter_splits=1, filter_rows64=True))
-        assert torch.equal(i_r, i_ref) and torch.equal(d_r, d_ref), topk
+        for kind in ("wide", True):
+            i_r, d_r = ops.topk_search(xh, xs, wh, ws, topk, _filter_path(filter_splits=1, filter_rows64=kind))
+            assert torch.equal(i_r, i_ref) and torch.equal(d_r, d_ref), (topk, kind)
     io, do = oracle.topk_search(xh[:200].cpu().numpy(), xs[:200].cpu().numpy(), wh.cpu().numpy(), ws.cpu().numpy(), 8)
     assert np.array_equal(i_r[:200].cpu().numpy(), io) and np.array_equal(d_r[:200].cpu().numpy(), do)
 
@@ -310,7 +313,8 @@ def test_rows_of_at_most_32_elements_repeated_searches(dev):
     bad = []
     for seed in range(12):
         for (n, K, D, k, near, env) in ((4097, 20001, 32, 1, True, {}), (20000, 20001, 4, 1, False, dict(filter_splits=8, filter_xcd=True)),
-                                        (4097, 20001, 32, 5, True, dict(filter_rows64=False)), (4097, 8191, 16, 1, False, {})):
+                                        (4097, 20001, 32, 5, True, dict(filter_rows64=False)), (4097, 8191, 16, 1, False, {}),
+                                        (4097, 20001, 32, 5, True, dict(filter_rows64="wide"))):
             g = torch.Generator(device=dev).manual_seed(seed * 7 + D)
             x = torch.randn(n, D, device=dev, generator=g); W = torch.randn(K, D, device=dev, generator=g)
             if near:

@@ -14,7 +14,8 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-@pytest.mark.parametrize("n,d", [(1, 4), (7, 64), (130, 768), (33, 100), (5, 1028)])
+@pytest.mark.parametrize("n,d", [(1, 4), (7, 64), (130, 768), (33, 100), (5, 1028),
+                                 (1000, 64), (37, 60), (19, 8), (50, 32), (17, 68)])   # d <= 64: sixteen lanes per row
 def test_rownorm_bit_exact(oracle, dev, n, d):
     from medtok_amd import ops
     rng = np.random.default_rng(n * 1000 + d)

@@ -20,15 +20,15 @@ W = torch.randn(K, D, device=dev, generator=g)
 xh, xs = ops.rownorm(x)
 wh, ws = ops.rownorm(W)
 paths = {"general": _lib.plan_path(ops.PATH_F16_FILTER, filter_rows64=False), "rows64": _lib.plan_path(ops.PATH_F16_FILTER, filter_rows64=True),
-         "exact": ops.PATH_F32_MFMA}
+         "rows64wide": _lib.plan_path(ops.PATH_F16_FILTER, filter_rows64="wide"), "exact": ops.PATH_F32_MFMA}
 out = {}
 for name, p in paths.items():
     out[name] = ops.topk_search(xh, xs, wh, ws, k, p)
 torch.cuda.synchronize()
-for name in ("rows64", "exact"):
+for name in ("rows64", "rows64wide", "exact"):
     print(f"{name} vs general: ids equal {torch.equal(out[name][0], out['general'][0])}  distances equal {torch.equal(out[name][1], out['general'][1])}")
 for rnd in range(3):
-    for name in ("general", "rows64"):
+    for name in ("general", "rows64wide", "rows64"):
         ops.profile_begin()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(5):
@@ -36,5 +36,5 @@ for rnd in range(3):
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
         pr = ops.profile_end()["filter_f16_kernel"]
         fms = pr["ms"] / max(pr["launches"], 1)
-        print(f"round {rnd} {name:8s} {dt * 1e3:8.3f} ms per search   filter kernel {fms:7.3f} ms = {pr['flops'] / max(pr['launches'], 1) / fms / 1e9:7.1f} TFLOP/s "
+        print(f"round {rnd} {name:10s} {dt * 1e3:8.3f} ms per search   filter kernel {fms:7.3f} ms = {pr['flops'] / max(pr['launches'], 1) / fms / 1e9:7.1f} TFLOP/s "
               f"= {pr['flops'] / max(pr['launches'], 1) / fms / 1e9 / 2500:.3f} of the f16 peak")

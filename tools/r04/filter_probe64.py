@@ -16,7 +16,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 xh, xs = ops.rownorm(torch.randn(N, D, device=dev, generator=g))
 wh, ws = ops.rownorm(torch.randn(K, D, device=dev, generator=g))
 lib = _lib.load()
-nb = lib.medtok_search_workspace_bytes(N, K, D, 5, ops.PATH_F16_FILTER)
+nb = lib.medtok_search_workspace_bytes(N, K, D, 5, _lib.plan_path(ops.PATH_F16_FILTER, filter_rows64="wide"))   # (the timed kernel's plan)
 wsb = torch.empty(nb, dtype=torch.uint8, device=dev)
 probe = torch.zeros(16384 * 32, dtype=torch.int64, device=dev)
 nblk = ctypes.c_int64(0)
