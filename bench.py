@@ -543,6 +543,36 @@ def pmc_traffic(workload, kernel, rows):
         return None, None
 
 
+def issue_roofs(workload, kernel, rows, avg_launch_ms, clock_ghz):
+    """The D <= 64 filter is not priced by the f16 MFMA roof alone: its scan is VALU work of the same order as its matrix work.  From
+    the instruction counts RECORDED in profiles/pipe_counters.json (own rocprofv3 --pmc passes) and THIS run's launch time and clock:
+    the time the kernel's VALU instructions need at one per 4 cycles and SIMD, the time its MFMAs need at 32 cycles each, and the
+    fraction of each roof the launch reaches (1.0 = that pipe never idles)."""
+    try:
+        rec = json.loads((ROOT / "profiles" / "pipe_counters.json").read_text())
+        if rec.get("_meta", {}).get("rows", {}).get(workload) != rows or not clock_ghz:
+            return None
+        c = rec[workload][kernel]
+        simd_hz = 1024 * clock_ghz * 1e9
+        valu_ms = c["valu_instructions"] * 4 / simd_hz * 1e3
+        mfma_ms = c["mfma_instructions"] * 32 / simd_hz * 1e3
+        simd_cycles = c["grbm_gui_active"] / 8 * 1024
+        scores = c["mfma_instructions"] * 1024 / 4
+        return {"kernel": c["kernel"], "valu_issue_roof_ms": valu_ms, "frac_of_valu_issue_roof": valu_ms / avg_launch_ms,
+                "mfma_roof_ms_at_this_clock": mfma_ms, "frac_of_mfma_roof_at_this_clock": mfma_ms / avg_launch_ms,
+                "valu_lane_ops_per_score": c["valu_instructions"] * 64 / scores,
+                "recorded_busy": {"valu": c["valu_instructions"] * 4 / simd_cycles, "matrix_pipe": c["valu_mfma_busy_cycles"] / simd_cycles,
+                                  "both_at_once": c["valu_mfma_coexec_cycles"] / simd_cycles,
+                                  "waves_per_simd": c["wave_cycles_x4"] * 4 / simd_cycles,
+                                  "wave_cycles_waiting_on_s_waitcnt": c["wait_inst_any_x4"] / c["wave_cycles_x4"]},
+                "clock_ghz": clock_ghz,
+                "source": "instruction counts recorded, not measured in this run: profiles/pipe_counters.json (" + rec["_meta"]["taken"] + "); launch time and clock from this run",
+                "reading": "neither pipe binds alone: the matrix pipe and the VALU are each busy about half of the SIMD cycles and overlap in a sixth -- the kernel is bound by how "
+                           "well three to four waves per SIMD interleave their MFMA phase with each other's scan (DESIGN 6.0)"}
+    except Exception:
+        return None
+
+
 def collective_block(args, rank, world, dev):
     """N > 1 only: the two partitionings of BASELINE config 5 that DO exchange data, so that the driver's unchanged command line
     (`bench.py --gpus N`, whose headline workload shards rows with no data-path collective) also measures RCCL over xGMI.
@@ -833,7 +863,7 @@ def main():
             "roofline": {**bound_view,
                          "traffic": traffic, "traffic_source": traffic_source,
                          # (rows of <= 64 elements take the fp16 filter's narrow-row kernel: the name rocprofv3 shows)
-                         "kernel": ("filter_rows64_kernel" if kname == "filter_f16_kernel" and wl.D <= 64 else kname),
+                         "kernel": ("filter_rows64n_kernel" if kname == "filter_f16_kernel" and wl.D <= 64 else kname),
                          "hbm_frac": hbm_gbs / HBM_PEAK_GBS, "hbm_achieved_gbs": hbm_gbs, "hbm_peak_gbs": HBM_PEAK_GBS,
                          "algorithmic_bytes_per_step": alg_bytes_step,
                          "binding_roof": ("hbm for this kernel (intensity left of the ridge of the pipe it runs on); hbm_frac below is the whole STEP's SURVEY-8d bytes"
@@ -854,6 +884,9 @@ def main():
             # budget / silicon) from the code when two lines differ by a few per cent; the dense-MFMA peaks above are quoted at 2.4 GHz
             "clock": clock,
         }
+        ir = issue_roofs(wl.name, kname, rows, kp["ms"] / max(kp["launches"], 1), (clock or {}).get("ghz_mean"))
+        if ir is not None:
+            line["roofline"]["issue_roofs"] = ir
         if strong is not None:
             line["extra"] = {"strong_scaling": strong}
         if args.workload in ("full", "fullref"):

@@ -1172,13 +1172,20 @@ __global__ __launch_bounds__(R64_THREADS, 2) void filter_rows64_kernel(
 // blocks per CU, each with its own barrier.  A wave reads the whole code tile as A operands (one ds_read_b128 per MFMA, twice the
 // LDS traffic per flop: 1 KB per 32 matrix-pipe cycles and SIMD, half the LDS's rate if all four SIMDs are in their MFMA phase
 // at once).  With one code-side wave a row's lists are complete inside the wave: the limit comes from the two half-waves' k-lists
-// by one permlane exchange, after EVERY tile (no LDS lists, no sort), and a row has two candidate lists per split, not four.
-// Scores, thresholds and list format are those of the kernels above; the learning phase covers the same 2048 codes.
+// by one permlane exchange (no LDS lists, no sort), and a row has two candidate lists per split, not four.
+// Scores, thresholds and list format are those of the kernels above; the learning phase covers 1024 codes.
+// K = 21 000 / 7 000, 600 000 rows: 1.94 / 0.80 ms against 2.16 / 0.97 (0.33 / 0.27 of the f16 peak against 0.30 / 0.22).  Counters of
+// this form: VALU 51 %, matrix pipe 45 %, both at once 17 % of the SIMD cycles, 3.4 waves per SIMD.  Two further forms, both correct,
+// both slower (tools/r04/ab_rows64.py, one box): (a) 64 codes x 64 rows per wave in 2 x 2 blocks (an A fragment feeds two MFMAs
+// again, 167 registers, three waves per SIMD, list exchange through LDS): 2.00 / 0.86 ms -- less LDS traffic, but the fourth wave
+// hides more than that saves; (b) this kernel with the scan of code group m - 1 issued between the MFMAs of group m (code-group-
+// major MFMA order, counted waits that allow for the start-value reads in between): 2.12 / 0.87 ms -- as in filter_f16_kernel,
+// work woven into a wave's own MFMA phase loses to what the SIMD's other waves do with those issue slots by themselves.
 constexpr int R64N_BM = 128, R64N_BN = 128, R64N_THREADS = 256;
 constexpr int R64N_TILEB = R64N_BM * R64_ROWB;                      // 16 KB per code tile
 constexpr size_t R64N_RING_BYTES = 2 * (size_t)R64N_TILEB;
 constexpr size_t R64N_SMEM_BYTES = R64N_RING_BYTES + 2 * R64N_BM * 4;      // + start values of two code tiles: 33 KB
-constexpr int R64N_LEARN = 16;
+constexpr int R64N_LEARN = 8;                                      // (1024 codes; 16 / 12 / 4 tiles measured 2-4 % slower)
 constexpr int R64N_OWN_PER_SPLIT = 2;                              // candidate lists per row and split: the two half-waves
 
 // the k-th best of a row over the codes both half-waves have seen: {min(a_i, b_{k-1-i})} are the k smallest of the union of two
@@ -1343,7 +1350,10 @@ __global__ __launch_bounds__(R64N_THREADS, 3) void filter_rows64n_kernel(
         } while (0)
         R64N_ONE(0); R64N_ONE(1); R64N_ONE(2); R64N_ONE(3);
 #undef R64N_ONE
-        if (st < nct) filter_merge_halves<TOPK>(row, lh);
+        // the limit moves after each of the first four scanned tiles, then after every fourth and after the last one (a limit that is
+        // a few tiles old is still the k-th best of real codes: valid, slightly looser; after every tile: 3-5 % slower)
+        const int since = st - W;
+        if (st < nct && (since < 4 || (since & 3) == 3 || st == nct - 1)) filter_merge_halves<TOPK>(row, lh);
         init_wait();
     };
     // one step up to its epilogue (see filter_rows64_kernel: the same protocol on a ring of 16 KB slots)

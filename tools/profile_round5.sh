@@ -27,12 +27,15 @@ for w in cfg3 full fullref refdefault; do
   rm -rf $out/prof_$w
 done
 bash tools/r05/timeline_fullref.sh > /dev/null 2>&1; cp gpurun_out/tl/timeline.txt $out/timeline_fullref_graph_mode.txt
-# PMC traffic of the headline's kernels, their own passes
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_cfg3_$c -o p -- python3 bench.py --workload cfg3 --steps 1 --warmup 1 --cpu-rows 0 --exact-steps 0 --no-clock-probe > $out/pmc_cfg3_$c.log 2>&1
-  f=$(find $out/pmc_cfg3_$c -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && cp "$f" $out/pmc_cfg3_$c.csv
-  rm -rf $out/pmc_cfg3_$c
+# PMC traffic of the headline's kernels and of the reference-shape searches', their own passes
+for w in cfg3 refdefault; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${w}_$c -o p -- python3 bench.py --workload $w --steps 1 --warmup 1 --cpu-rows 0 --exact-steps 0 --no-clock-probe > $out/pmc_${w}_$c.log 2>&1
+    f=$(find $out/pmc_${w}_$c -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && cp "$f" $out/pmc_${w}_$c.csv
+    rm -rf $out/pmc_${w}_$c
+  done
 done
-python3 tools/pmc_summary.py $out cfg3 > $out/pmc_summary.txt 2>&1
+python3 tools/pmc_summary.py $out cfg3 refdefault > $out/pmc_summary.txt 2>&1
+bash tools/r05/pmc_valu_refdefault.sh > /dev/null 2>&1; cp gpurun_out/valu/summary.txt $out/valu_counters_refdefault.txt
 ls -la $out | head -50

@@ -1,5 +1,5 @@
 """Dev tool (GPU box): the fp16 filter kernel's time under variant builds of the library (tools/r05/build_mutants.py), one fresh process
-per build (a library is bound once per process), alternated ROUNDS times.   python tools/r05/ab_filter_libs.py K name [name ...]
+per build (a library is bound once per process), alternated ROUNDS times.   python tools/r05/ab_filter_libs.py K[:D] name [name ...]   (D = 768 unless given)
 ('shipped' = the product library).  Prints the mean filter-kernel milliseconds per 600 000-row search of every build and round."""
 import json, os, subprocess, sys
 from pathlib import Path
@@ -9,9 +9,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import torch
     from medtok_amd import _lib, ops
     if os.environ.get("DBGLIB"): _lib.use_library(os.environ["DBGLIB"])
-    K = int(sys.argv[2]); dev = torch.device("cuda:0")
+    K, _, D = sys.argv[2].partition(":"); K = int(K); D = int(D or 768); dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
-    x = torch.randn(600000, 768, device=dev, generator=g); W = torch.randn(K, 768, device=dev, generator=g)
+    x = torch.randn(600000, D, device=dev, generator=g); W = torch.randn(K, D, device=dev, generator=g)
     xh, xs = ops.rownorm(x); wh, ws = ops.rownorm(W)
     for _ in range(2): ops.topk_search(xh, xs, wh, ws, 5, ops.PATH_F16_FILTER)
     torch.cuda.synchronize()

@@ -12,6 +12,9 @@ carry no build-time switch), into devlib/<name>/libmedtok_vq.so (git-ignored; tr
              stream of a 64-deep stage (half the barriers, bursts of eight copies per wave) on the 32-deep ring
   nobar      TIMING ONLY (wrong results): no stage barrier at all
   rr16, rr8  the re-score kernel with 16 / 8 rows per block instead of 32 (same results)
+  n_noscan   TIMING ONLY (wrong results): filter_rows64n_kernel without its scans (MFMAs, copies, barriers and start-value reads only)
+  n_l<A>m<B> filter_rows64n_kernel learning from A code tiles (16 in the product) and recomputing the limits after every B-th scanned
+             tile (1 in the product); same results
 """
 import shutil, subprocess, sys
 from pathlib import Path
@@ -61,6 +64,15 @@ def mutate(name, src):
         rr = name[2:]
         h = sub(h, "hipLaunchKernelGGL((rescore_kernel<T, 32>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, MEDTOK_RESCORE_ARGS);",
                 f"hipLaunchKernelGGL((rescore_kernel<T, {rr}>), dim3((unsigned)((n + {rr} - 1) / {rr})), dim3(8 * {rr}), 0, s, MEDTOK_RESCORE_ARGS);")
+    elif name == "n_noscan":
+        t = sub(t, "            filter_scan<TOPK, false, true>(row, acc[M], cb_, cbase, multi, nullptr, cc, bias);                            \\\n", "            (void)cb_;                                                                                               \\\n")
+        t = sub(t, "            thr_insert_med3<TOPK>(row.tv, u == u ? u : INFINITY);\n            R64N_INIT_LDS(m, st + 1);", "            (void)u;\n            R64N_INIT_LDS(m, st + 1);")
+    elif name.startswith("n_l") and "m" in name[3:]:
+        A, B_ = name[3:].split("m")
+        t = sub(t, "constexpr int R64N_LEARN = 16;", f"constexpr int R64N_LEARN = {int(A)};")
+        if int(B_) > 1:
+            t = sub(t, "        if (st < nct) filter_merge_halves<TOPK>(row, lh);\n        init_wait();",
+                    f"        if (st < nct && (st - W < 4 || (st - W) % {int(B_)} == {int(B_)} - 1 || st == nct - 1)) filter_merge_halves<TOPK>(row, lh);\n        init_wait();")
     else:
         raise SystemExit(f"unknown mutant {name}")
     f.write_text(t); hip.write_text(h)
