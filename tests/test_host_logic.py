@@ -217,6 +217,28 @@ def test_bench_parent_spawns_ranks_without_touching_the_gpu(monkeypatch):
     assert bench.spawn_ranks(bench.parse()) == 2          # RCCL: one GPU per rank, checked before anything is started
 
 
+def test_bench_recorded_counter_figures_carry_their_provenance():
+    """What bench.py cannot measure inside its own process (PMC counters need their own rocprofv3 passes) comes from files under
+    profiles/ -- only for the workload and row count they were taken at, always with the source spelled out, never as a live figure."""
+    import importlib.util
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    spec = importlib.util.spec_from_file_location("bench_mod2", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    val, src = bench.pmc_traffic("cfg3", "filter_f16_kernel", 600000)
+    assert val > 1e10 and "recorded, not measured in this run" in src
+    assert bench.pmc_traffic("cfg3", "filter_f16_kernel", 1000) == (None, None)                 # other sizes: no figure
+    ir = bench.issue_roofs("refdefault", "filter_f16_kernel", 600000, 1.35, 2.0)
+    assert ir["kernel"] == "filter_rows64n_kernel" and "recorded, not measured in this run" in ir["source"]
+    assert 0.3 < ir["frac_of_valu_issue_roof"] < 0.7 and 0.3 < ir["frac_of_mfma_roof_at_this_clock"] < 0.7
+    assert abs(ir["recorded_busy"]["valu"] - 0.49) < 0.05 and abs(ir["recorded_busy"]["matrix_pipe"] - 0.43) < 0.05
+    # the roofs scale with the clock of THIS run and the fractions with its launch time
+    ir2 = bench.issue_roofs("refdefault", "filter_f16_kernel", 600000, 2.70, 1.0)
+    assert abs(ir2["valu_issue_roof_ms"] / ir["valu_issue_roof_ms"] - 2.0) < 1e-9 and abs(ir2["frac_of_valu_issue_roof"] - ir["frac_of_valu_issue_roof"]) < 1e-9
+    assert bench.issue_roofs("refdefault", "filter_f16_kernel", 1000, 1.35, 2.0) is None and bench.issue_roofs("cfg3", "filter_f16_kernel", 600000, 1.0, 2.0) is None
+    assert bench.issue_roofs("refdefault", "filter_f16_kernel", 600000, 1.35, None) is None       # no clock probe: no figure
+
+
 def test_unsupported_k_fails_at_construction():
     """k beyond the kernels' list length (or beyond a region's size) is refused when the module is built, not at the first search."""
     from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
