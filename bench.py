@@ -221,6 +221,55 @@ class Full(Cfg3):
         self.set_path(ops.PATH_AUTO)
         return all(torch.equal(u, v) for u, v in zip(*outs))
 
+    def no_host_read(self, steps):
+        """The same forward with CrossAttention.max_nodes_bound set to the generator's largest subgraph: the attention launches are
+        sized from the bound, nothing is read back (the batch checks stay on the device), so the forward also records into a HIP
+        graph.  Eager and replayed, on ONE stream (side streams off for this pass), outputs compared with the default forward."""
+        import medtok_amd.vector_quantization_soft_one_new as vqmod
+        ca = self.vq.cross_attn
+        keep_streams, keep_bound = vqmod.SIDE_STREAM_MIN_CODES, ca.max_nodes_bound
+        ref = self.step()
+        out = {}
+        try:
+            vqmod.SIDE_STREAM_MIN_CODES = 0
+            ca.max_nodes_bound = self.MAX_NODES
+            r = self.step()
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            torch.cuda.synchronize(self.dev)
+            dt = time.perf_counter() - t0
+            ca.check_status()
+            same = all(torch.equal(r[k], ref[k]) for k in r if isinstance(r[k], torch.Tensor))
+            out["eager_one_stream"] = {"value": self.rows * steps / dt, "unit": "codes/s", "ms_per_step": dt / steps * 1e3, "equals_default_forward": bool(same)}
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize(self.dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g_out = self.step()
+            for _ in range(2):
+                graph.replay()
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                graph.replay()
+            torch.cuda.synchronize(self.dev)
+            dt = time.perf_counter() - t0
+            ca.check_status()
+            same = all(torch.equal(g_out[k], ref[k]) for k in g_out if isinstance(g_out[k], torch.Tensor))
+            out["hip_graph_replay"] = {"value": self.rows * steps / dt, "unit": "codes/s", "ms_per_step": dt / steps * 1e3, "replay_equals_default_forward": bool(same)}
+        finally:
+            vqmod.SIDE_STREAM_MIN_CODES, ca.max_nodes_bound = keep_streams, keep_bound
+        out["note"] = (f"cross_attn.max_nodes_bound = {self.MAX_NODES} (not in the reference: an upper bound on the nodes of one code, here the generator's); "
+                       "show_usage = False; rank-local; `value` above is the default forward (one host read per call, any batch vector)")
+        return out
+
     def cpu_baseline(self, sample_rows):
         """The reference's own form on the host cores: per-code Python loop over nn.MultiheadAttention layers (:133-142), then the
         dense searches."""
@@ -894,6 +943,11 @@ def main():
             line["config"]["streams"] = "one (--one-stream)" if args.one_stream else "main + side streams (modality-specific searches, text side; the image pass over fp32 text rows has its own only where the attention kernel does not split the keys itself)"
             if half_text is not None:
                 line["half_precision_text"] = half_text
+            if args.workload == "full" and not args.no_one_stream_pass:
+                try:
+                    line["no_host_read"] = wl.no_host_read(max(args.steps, 5))
+                except Exception as exc:           # (an extra: the headline line is printed regardless)
+                    line["no_host_read"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
             if args.workload == "fullref" and hasattr(wl, "graph_replay"):
                 try:
                     line["hip_graph_replay"] = wl.graph_replay(max(args.steps, 20))

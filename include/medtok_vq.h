@@ -364,6 +364,15 @@ int medtok_pack_codes(const void *mask, int mask_elem_bytes, int64_t n_codes, in
                       int heads, int lpt, int64_t *valid_len, int64_t *counts, int64_t *starts, int64_t *t_start, int64_t *t_len,
                       int64_t *g_start, int64_t *g_len, int64_t *tok_start, int64_t *g_kv_len, int64_t *stats,
                       void *ws, size_t ws_bytes, void *stream);
+/* The same for a caller that does NOT read stats back (a forward recorded into a HIP graph sizes its attention launches from a bound
+ * on the nodes per code that it brings along): what the host read would have checked is OR-ed into the device word status[0]
+ * (int32, zeroed by the caller once; NULL: no check) -- bit 0: `batch` is not sorted, bit 1: an id outside [0, n_codes), bit 2: a
+ * code with more than count_bound nodes (count_bound = 0: no bound).  With a bit set the attention results of the codes involved
+ * are wrong; the caller reads the word wherever it synchronises anyway. */
+int medtok_pack_codes_checked(const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len, const int64_t *batch, int64_t n_nodes,
+                              int heads, int lpt, int64_t *valid_len, int64_t *counts, int64_t *starts, int64_t *t_start, int64_t *t_len,
+                              int64_t *g_start, int64_t *g_len, int64_t *tok_start, int64_t *g_kv_len, int64_t *stats,
+                              int64_t count_bound, int *status, void *ws, size_t ws_bytes, void *stream);
 
 /* Around the core, for packed rows (no batch axis):
  *   medtok_residual_layernorm_f32: the tail of CrossAttentionLayer.forward (vector_quantization_soft_one_new.py:47-50),

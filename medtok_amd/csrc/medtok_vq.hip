@@ -2006,11 +2006,25 @@ extern "C" size_t medtok_pack_codes_workspace_bytes(int64_t n_codes)
     return align_up((size_t)(n_codes > 0 ? n_codes : 1) * 4, 256) * 2 + 256;        // counts32 | order | stats32
 }
 
+extern "C" int medtok_pack_codes_checked(const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len, const int64_t *batch, int64_t n_nodes,
+                                         int heads, int lpt, int64_t *valid_len, int64_t *counts, int64_t *starts, int64_t *t_start, int64_t *t_len,
+                                         int64_t *g_start, int64_t *g_len, int64_t *tok_start, int64_t *g_kv_len, int64_t *stats,
+                                         int64_t count_bound, int *status, void *ws, size_t ws_bytes, void *stream);
 extern "C" int medtok_pack_codes(const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len, const int64_t *batch, int64_t n_nodes,
                                  int heads, int lpt, int64_t *valid_len, int64_t *counts, int64_t *starts, int64_t *t_start, int64_t *t_len,
                                  int64_t *g_start, int64_t *g_len, int64_t *tok_start, int64_t *g_kv_len, int64_t *stats, void *ws, size_t ws_bytes,
                                  void *stream)
 {
+    return medtok_pack_codes_checked(mask, mask_elem_bytes, n_codes, seq_len, batch, n_nodes, heads, lpt, valid_len, counts, starts, t_start, t_len,
+                                     g_start, g_len, tok_start, g_kv_len, stats, 0, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int medtok_pack_codes_checked(const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len, const int64_t *batch, int64_t n_nodes,
+                                         int heads, int lpt, int64_t *valid_len, int64_t *counts, int64_t *starts, int64_t *t_start, int64_t *t_len,
+                                         int64_t *g_start, int64_t *g_len, int64_t *tok_start, int64_t *g_kv_len, int64_t *stats,
+                                         int64_t count_bound, int *status, void *ws, size_t ws_bytes, void *stream)
+{
+    if (count_bound < 0) return fail("pack_codes: count_bound=%ld must be >= 0 (0 = none)", (long)count_bound);
     if (n_codes <= 0 || seq_len < 0 || n_nodes < 0 || heads <= 0) return fail("pack_codes: bad sizes n_codes=%ld seq_len=%ld n_nodes=%ld heads=%d", (long)n_codes, (long)seq_len, (long)n_nodes, heads);
     if (n_codes >= (1ll << 31) - 1 || n_nodes >= (1ll << 31) * 256ll) return fail("pack_codes: too many codes / nodes");
     if (mask_elem_bytes != 1 && mask_elem_bytes != 4 && mask_elem_bytes != 8) return fail("pack_codes: mask elements of %d bytes (bool / int32 / int64 expected)", mask_elem_bytes);
@@ -2031,7 +2045,7 @@ extern "C" int medtok_pack_codes(const void *mask, int mask_elem_bytes, int64_t 
     size_t pw = 1;
     while ((int64_t)pw < n_codes) pw <<= 1;
     hipLaunchKernelGGL(pack_lists_kernel, dim3(1), dim3(PACK_THREADS), sort ? pw * 4 : 0, s, counts32, stats32, valid_len, (long)n_codes,
-                       (long)seq_len, heads, lpt, order, counts, starts, t_start, t_len, g_start, g_len, tok_start, g_kv_len, stats);
+                       (long)seq_len, heads, lpt, order, counts, starts, t_start, t_len, g_start, g_len, tok_start, g_kv_len, stats, (long)count_bound, status);
     return check_launch("pack_codes");
 }
 

@@ -65,7 +65,8 @@ constexpr int PACK_SORT_MAX_CODES = 8192;  // ... and the largest batch (a biton
 __global__ __launch_bounds__(PACK_THREADS) void pack_lists_kernel(
     const int *__restrict__ counts32, const int *__restrict__ stats32, const int64_t *__restrict__ valid_len, long n_codes, long seq_len, int heads, int lpt,
     int *__restrict__ order, int64_t *__restrict__ counts, int64_t *__restrict__ starts, int64_t *__restrict__ t_start, int64_t *__restrict__ t_len,
-    int64_t *__restrict__ g_start, int64_t *__restrict__ g_len, int64_t *__restrict__ tok_start, int64_t *__restrict__ g_kv_len, int64_t *__restrict__ stats)
+    int64_t *__restrict__ g_start, int64_t *__restrict__ g_len, int64_t *__restrict__ tok_start, int64_t *__restrict__ g_kv_len, int64_t *__restrict__ stats,
+    long count_bound = 0, int *__restrict__ status = nullptr)
 {
     __shared__ long s_wave[PACK_THREADS / 64];
     __shared__ long s_carry;
@@ -143,5 +144,14 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_lists_kernel(
         stats[1] = stats32[1];
         stats[2] = stats32[2];
         stats[3] = stats32[3];
+        // a caller that sizes its launches from a BOUND on the node count instead of reading stats back (no host synchronisation: the
+        // forward records into a HIP graph) finds out here whether the batch kept to it: bit 0 = batch vector not sorted, bit 1 = an
+        // id outside [0, n_codes), bit 2 = a code with more nodes than the bound
+        if (status) {
+            int f = stats32[3] ? 1 : 0;
+            if (stats32[1] <= stats32[2] && (stats32[1] < 0 || stats32[2] >= n_codes)) f |= 2;
+            if (count_bound > 0 && s_max > count_bound) f |= 4;
+            if (f) atomicOr(status, f);
+        }
     }
 }

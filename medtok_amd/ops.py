@@ -463,10 +463,12 @@ def residual_layernorm(a, b, gamma, beta, eps: float, split_dp: int = 0):
     return (y, (hi, lo)) if split_dp else y
 
 
-def pack_codes(mask, batch, heads: int, lpt: bool):
-    """The prologue of the batched cross-attention in three small launches (include/medtok_vq.h: medtok_pack_codes): mask [B, L]
+def pack_codes(mask, batch, heads: int, lpt: bool, count_bound: int = 0, status=None):
+    """The prologue of the batched cross-attention in three small launches (include/medtok_vq.h: medtok_pack_codes_checked): mask [B, L]
     (bool / int32 / int64), batch [n_nodes] int64 -> dict(valid_len, counts, starts, t_start, t_len, g_start, g_len, tok_start,
-    g_kv_len: int64 [B] device tensors; stats: int64 [4] = largest count, id range, unsorted flag -- not yet read back)."""
+    g_kv_len: int64 [B] device tensors; stats: int64 [4] = largest count, id range, unsorted flag -- not yet read back).
+    status (int32 device tensor, optional): what a caller that never reads stats back needs flagged -- bit 0 unsorted, bit 1 id out of
+    range, bit 2 a code with more than count_bound nodes -- OR-ed into status[0] on the device."""
     if not (isinstance(mask, torch.Tensor) and mask.is_cuda and mask.dim() == 2):
         raise _lib.MedTokLibraryError("pack_codes: expected a [B, L] mask on an MI355X device")
     if mask.dtype not in (torch.bool, torch.uint8, torch.int32, torch.int64):
@@ -480,8 +482,11 @@ def pack_codes(mask, batch, heads: int, lpt: bool):
     lib = _lib.load()
     ws = _ws(lib.medtok_pack_codes_workspace_bytes(bsz), mask)
     with torch.cuda.device(dev):
-        _lib.check(lib.medtok_pack_codes(mask.data_ptr(), mask.element_size(), bsz, seq_len, batch.data_ptr(), batch.numel(), int(heads), int(bool(lpt)),
-                                         *[out[i].data_ptr() for i in range(9)], stats.data_ptr(), ws.data_ptr(), ws.numel(), _stream(mask)),
+        if status is not None and not (status.is_cuda and status.dtype == torch.int32 and status.device == dev):
+            raise _lib.MedTokLibraryError("pack_codes: status must be an int32 tensor on the mask's device")
+        _lib.check(lib.medtok_pack_codes_checked(mask.data_ptr(), mask.element_size(), bsz, seq_len, batch.data_ptr(), batch.numel(), int(heads),
+                                                 int(bool(lpt)), *[out[i].data_ptr() for i in range(9)], stats.data_ptr(), int(count_bound),
+                                                 _ptr(status), ws.data_ptr(), ws.numel(), _stream(mask)),
                    "medtok_pack_codes")
     names = ("valid_len", "counts", "starts", "t_start", "t_len", "g_start", "g_len", "tok_start", "g_kv_len")
     r = {k: out[i] for i, k in enumerate(names)}

@@ -389,6 +389,12 @@ class CrossAttention(nn.Module):
     def __init__(self, embed_dim, num_heads, dropout=0.1, layers=2):
         super().__init__()
         self.model = nn.ModuleList([CrossAttentionLayer(embed_dim, num_heads, dropout) for _ in range(layers)])
+        # (not in the reference) An upper bound on the nodes of one code, e.g. the dataset's largest subgraph.  With it pooled() at
+        # inference sizes its attention launches from the bound instead of reading the batch's largest node count back: no host
+        # synchronisation, so VectorQuantizer.forward (eval, show_usage = False) records into a HIP graph at any width.  `batch`
+        # must then be non-decreasing (PyG batch vectors are); a batch that is not, holds ids outside [0, B) or exceeds the bound is
+        # flagged on the device (small_status) and raised by check_status().  None: one host read per call, any batch vector.
+        self.max_nodes_bound = None
 
     def forward(self, vector1, vector2, attn_mask=None):
         out1, out2 = vector1, vector2
@@ -870,9 +876,7 @@ class CrossAttention(nn.Module):
         where it synchronises anyway, by the inference driver per batch, or by the caller."""
         bsz, seq_len, dim = text.shape
         dev = text.device
-        st = getattr(self, "small_status", None)
-        if st is None or st.device != dev:
-            st = self.small_status = torch.zeros(4, dtype=torch.int32, device=dev)
+        st = self._status_word(dev)
         with torch.autocast(device_type="cuda", enabled=False):
             pooled2 = torch.empty((bsz, 2, dim), dtype=torch.float32, device=dev)
             heads = self.model[0].multihead_attn.num_heads
@@ -880,9 +884,15 @@ class CrossAttention(nn.Module):
                                       self._small_weights(), len(self.model), (dim // heads) ** -0.5, self.model[0].layer_norm.eps, pooled2, st)
         return pooled2
 
-    def check_small_status(self):
-        """Host read of small_status (a synchronisation): raises what pooled() raises for a batch vector the two-launch path cannot
-        take, and clears the word."""
+    def _status_word(self, dev):
+        st = getattr(self, "small_status", None)
+        if st is None or st.device != dev:
+            st = self.small_status = torch.zeros(4, dtype=torch.int32, device=dev)
+        return st
+
+    def check_status(self):
+        """Host read of small_status (a synchronisation): raises what pooled() raises for a batch vector the paths without a host
+        read (the two-launch small-width path; any width with max_nodes_bound set) cannot take, and clears the word."""
         st = getattr(self, "small_status", None)
         if st is None:
             return
@@ -891,8 +901,13 @@ class CrossAttention(nn.Module):
             st.zero_()
             if word & 2:
                 raise ValueError("pooled(): `batch` holds code ids outside [0, B)")
-            raise ValueError("pooled(): the two-launch small-width path needs a non-decreasing `batch` vector (PyG-style); sort the nodes by "
-                             "code, or set medtok_amd.vector_quantization_soft_one_new.SMALL_WIDTH_FUSED = False")
+            if word & 4:
+                raise ValueError(f"pooled(): a code has more nodes than max_nodes_bound = {self.max_nodes_bound}; raise the bound, or set it to "
+                                 "None (one host read per call)")
+            raise ValueError("pooled(): the paths without a host read (the two-launch small-width path; max_nodes_bound) need a non-decreasing "
+                             "`batch` vector (PyG-style); sort the nodes by code, or set SMALL_WIDTH_FUSED = False / max_nodes_bound = None")
+
+    check_small_status = check_status
 
     def pooled(self, text, text_mask, nodes, batch, join=True):
         """Batched equivalent of the reference's per-code loop (:133-142) -- the PRODUCT path: gfx950 kernels only.
@@ -932,7 +947,14 @@ class CrossAttention(nn.Module):
             nodes, text = nodes.to(common), text.to(common)
         batch = batch.reshape(-1).to(torch.long)
         # counts / offsets / launch lists of all codes: three small launches (ops.pack_codes), nothing read back yet
-        pk = ops.pack_codes(text_mask, batch, heads, LPT_ORDER and not autograd)
+        bound = None if autograd or torch.is_grad_enabled() else self.max_nodes_bound
+        if bound is not None:
+            bound = int(bound)
+            if bound <= 0:
+                raise ValueError(f"max_nodes_bound = {bound} must be a positive node count (or None)")
+            pk = ops.pack_codes(text_mask, batch, heads, LPT_ORDER, count_bound=bound, status=self._status_word(text.device))
+        else:
+            pk = ops.pack_codes(text_mask, batch, heads, LPT_ORDER and not autograd)
         images = None
         if half_keys:
             images = ((text.view(bsz * seq_len, dim), None), None)
@@ -952,7 +974,10 @@ class CrossAttention(nn.Module):
             images = (text_split, ready)
         # ONE host read per call: the largest node count sizes the launches; the same read validates `batch` and tells whether it
         # is sorted (PyG batch vectors are)
-        max_nodes, id_lo, id_hi, unsorted = pk["stats"].tolist()
+        if bound is not None:               # ... or none: launches sized from the bound, the checks left to the device word (check_status)
+            max_nodes, id_lo, id_hi, unsorted = min(bound, batch.numel()), 0, bsz - 1, 0
+        else:
+            max_nodes, id_lo, id_hi, unsorted = pk["stats"].tolist()
         if batch.numel() == 0:
             max_nodes, unsorted = 0, 0
         elif id_lo < 0 or id_hi >= bsz:
@@ -1376,7 +1401,7 @@ class VectorQuantizer(nn.Module):
             if st is not None and st.device == cnt.device:        # one read: the usage counts and the small-width path's status word
                 vals = torch.cat([cnt[:3], st[:1]]).cpu()
                 if int(vals[3]):
-                    self.cross_attn.check_small_status()
+                    self.cross_attn.check_status()
             else:
                 vals = cnt[:3].cpu()
             u_shared, u_text, u_graph = (vals[:3].double() / self.n_e).tolist()
@@ -1492,7 +1517,7 @@ class VectorQuantizer(nn.Module):
             if st is not None and st.device == counts[0].device:          # one read for the usage counts and the small path's status word
                 vals = torch.cat([torch.stack(counts[:3]), st[:1]]).cpu()
                 if int(vals[3]):
-                    self.cross_attn.check_small_status()
+                    self.cross_attn.check_status()
                 u_shared, u_text, u_graph = (vals[:3].double() / self.n_e).tolist()
             else:
                 u_shared, u_text, u_graph = (torch.stack(counts[:3]).cpu().double() / self.n_e).tolist()
