@@ -1,3 +1,6 @@
+#!/bin/bash
+# Dev tool (GPU box): the VQ-side training step (cfg 4 with precomputed encoder outputs) -- bench line, rocprofv3 kernel stats, launches per step:
+# profiles/r05_bench_cfg4_vq_only.json, r05_kernel_stats_cfg4_vq_only.csv, r05_launches_per_step_cfg4_vq_only.txt.   usage: bash tools/r05/prof_cfg4.sh
 export TMPDIR=/tmp
 out=gpurun_out/c4; mkdir -p $out
 python3 bench.py --workload cfg4 --precomputed-encoders 2>/dev/null | tail -1 > $out/bench_cfg4_vq_only.json

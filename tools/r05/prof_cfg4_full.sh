@@ -1,3 +1,5 @@
+#!/bin/bash
+# Dev tool (GPU box): rocprofv3 kernel stats of the whole cfg 4 step (stand-in encoders included).   usage: bash tools/r05/prof_cfg4_full.sh
 export TMPDIR=/tmp
 out=gpurun_out/c4full; mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python3 bench.py --workload cfg4 --steps 3 --warmup 2 --cpu-rows 0 --no-clock-probe > $out/prof.log 2>&1
