@@ -6,6 +6,8 @@ rejected: there is no fallback path.
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 
 from . import _lib
@@ -48,7 +50,7 @@ class ClockProbe:
         self.stream = torch.cuda.Stream(device=self.device)
 
     def __enter__(self):
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.load().medtok_debug_clock_probe(self.flag.data_ptr(), self.max_ticks, self.out.data_ptr(), self.stream.cuda_stream),
                        "medtok_debug_clock_probe")
         return self
@@ -80,8 +82,28 @@ def attention_width(d: int) -> int:
     return w
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_SAME_DEVICE = contextlib.nullcontext()
+
+
 def _stream(t: torch.Tensor) -> int:
+    """the raw handle of torch's current stream on t's device (the C accessor where this torch has it: every wrapper below asks once per
+    launch, and the Python-level Stream object costs more than some of the launches)"""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _stream_of(dev: torch.device) -> int:
+    """raw handle of torch's current stream on `dev`"""
+    if _raw_stream is not None:
+        return _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _on(dev: torch.device):
+    """`with torch.cuda.device(dev)` only where it changes something: a tensor on another device than the current one"""
+    return _SAME_DEVICE if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
 
 
 def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
@@ -117,7 +139,7 @@ def rownorm(x: torch.Tensor, normalize: bool = True, want_xhat: bool = True):
         xhat = torch.empty_like(x)
     else:
         xhat = x if want_xhat else None
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(lib.medtok_rownorm_f32(x.data_ptr(), n, d, int(normalize), _ptr(xhat), sqn.data_ptr(),
                                           _stream(x)), "medtok_rownorm_f32")
     return xhat, sqn
@@ -142,7 +164,7 @@ def topk_search(xhat, xsq, what, wsq, topk: int, path: int = PATH_AUTO):
     nb = lib.medtok_search_workspace_bytes(n, k, d, topk, path)
     ws = _ws(nb, xhat)
     timer = SEARCH_TIMER
-    with torch.cuda.device(xhat.device):
+    with _on(xhat.device):
         if timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -167,7 +189,7 @@ def merge_topk_lists(dist_parts, idx_parts):
     lib = _lib.load()
     idx = torch.empty((n, k), dtype=torch.int64, device=dist_parts.device)
     dist = torch.empty((n, k), dtype=torch.float32, device=dist_parts.device)
-    with torch.cuda.device(dist_parts.device):
+    with _on(dist_parts.device):
         _lib.check(lib.medtok_merge_topk_lists_f32(dist_parts.data_ptr(), idx_parts.data_ptr(), n, parts, k, idx.data_ptr(),
                                                    dist.data_ptr(), _stream(dist_parts)), "medtok_merge_topk_lists_f32")
     return idx, dist
@@ -181,7 +203,7 @@ def debug_filter_scores(xhat, xsq, what, wsq):
     lib = _lib.load()
     out = torch.empty((n, k), dtype=torch.float32, device=xhat.device)
     ws = _ws(lib.medtok_debug_filter_scores_workspace_bytes(n, k, d), xhat)
-    with torch.cuda.device(xhat.device):
+    with _on(xhat.device):
         _lib.check(lib.medtok_debug_filter_scores_f32(xhat.data_ptr(), xsq.data_ptr(), n, what.data_ptr(), wsq.data_ptr(), k, d,
                                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(xhat)),
                    "medtok_debug_filter_scores_f32")
@@ -211,7 +233,7 @@ def soft_assign(xref, what, idx, dist, hard: bool = False, want_w: bool = True, 
     w = torch.empty((n, topk), dtype=torch.float32, device=xref.device) if want_w else None
     zq, zstride = _zq_out(out, n, d, xref)
     se = torch.empty(n, dtype=torch.float32, device=xref.device) if want_sqerr else None
-    with torch.cuda.device(xref.device):
+    with _on(xref.device):
         _lib.check(lib.medtok_soft_assign_f32(xref.data_ptr(), what.data_ptr(), idx.data_ptr(), _ptr(dist), n, d, topk,
                                               int(hard) | (2 if raw else 0), _ptr(w), zq.data_ptr(), zstride, _ptr(se), _stream(xref)),
                    "medtok_soft_assign_f32")
@@ -235,7 +257,7 @@ def soft_vq_backward(x, xhat, what, idx, w, g_zq=None, g_xhat=None, g_out=None, 
     gx = torch.empty((n, d), dtype=torch.float32, device=x.device) if want_gx else None
     g_code = torch.empty((n * topk, d), dtype=torch.float32, device=x.device) if want_g_code else None
     lib = _lib.load()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(lib.medtok_soft_vq_backward_f32(x.data_ptr(), xhat.data_ptr(), what.data_ptr(), idx.data_ptr(), w.data_ptr(),
                                                    n, d, topk, *[_ptr(t) for t in opt], float(vq_scale), float(commit_scale),
                                                    _ptr(gx), _ptr(g_code), _stream(x)), "medtok_soft_vq_backward_f32")
@@ -248,7 +270,7 @@ def normalize_backward(g, vhat, v):
     n, d = v.shape
     out = torch.empty_like(v)
     lib = _lib.load()
-    with torch.cuda.device(v.device):
+    with _on(v.device):
         _lib.check(lib.medtok_normalize_backward_f32(g.data_ptr(), vhat.data_ptr(), v.data_ptr(), n, d, out.data_ptr(), _stream(v)),
                    "medtok_normalize_backward_f32")
     return out
@@ -264,7 +286,7 @@ def info_nce_forward(q, k, temperature: float):
     loss = torch.empty((), dtype=torch.float32, device=q.device)
     prob = torch.empty((b, b), dtype=torch.float32, device=q.device)
     ws = _ws(lib.medtok_info_nce_workspace_bytes(b, d), q)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         _lib.check(lib.medtok_info_nce_forward_f32(q.data_ptr(), k.data_ptr(), b, d, float(temperature), loss.data_ptr(),
                                                    prob.data_ptr(), ws.data_ptr(), ws.numel(), _stream(q)), "medtok_info_nce_forward_f32")
     return loss, prob, ws
@@ -276,7 +298,7 @@ def info_nce_backward(q, k, prob, ws, g_loss, temperature: float):
     b, d = q.shape
     gq, gk = torch.empty_like(q), torch.empty_like(k)
     lib = _lib.load()
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         _lib.check(lib.medtok_info_nce_backward_f32(q.data_ptr(), k.data_ptr(), prob.data_ptr(), g_loss.data_ptr(), b, d,
                                                     float(temperature), gq.data_ptr(), gk.data_ptr(), ws.data_ptr(), ws.numel(),
                                                     _stream(q)), "medtok_info_nce_backward_f32")
@@ -288,7 +310,7 @@ def row_dot(a, b):
     a, b = _dev(a, "a"), _dev(b, "b")
     n, d = a.shape
     out = torch.empty(n, dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         _lib.check(_lib.load().medtok_row_dot_f32(a.data_ptr(), b.data_ptr(), n, d, out.data_ptr(), _stream(a)), "medtok_row_dot_f32")
     return out
 
@@ -302,7 +324,7 @@ def small_gemm(A, B, trans_a: bool = False, trans_b: bool = False):
     if k != k2:
         raise ValueError(f"small_gemm: inner dimensions differ ({k} vs {k2})")
     C = torch.empty((m, n), dtype=torch.float32, device=A.device)
-    with torch.cuda.device(A.device):
+    with _on(A.device):
         _lib.check(_lib.load().medtok_small_gemm_f32(A.data_ptr(), sam, sak, B.data_ptr(), sbk, sbn, m, n, k, C.data_ptr(), _stream(A)),
                    "medtok_small_gemm_f32")
     return C
@@ -315,7 +337,7 @@ def frobenius(x):
     lib = _lib.load()
     out = torch.empty((), dtype=torch.float32, device=x.device)
     ws = _ws(lib.medtok_frobenius_workspace_bytes(rows), x)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(lib.medtok_frobenius_f32(x.data_ptr(), rows, d, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(x)), "medtok_frobenius_f32")
     return out
 
@@ -330,7 +352,7 @@ def split_half(x, dp: int = None, scale: float = 1.0, seg_len=None, seg_rows: in
     dp = (d + 7) // 8 * 8 if dp is None else int(dp)
     hi = torch.empty((n, dp), dtype=torch.float16, device=x.device)
     lo = torch.empty((n, dp), dtype=torch.float16, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.load().medtok_split_half_f32(x.data_ptr(), n, d, x.stride(0) if n > 1 else d, dp, float(scale), hi.data_ptr(), lo.data_ptr(),
                                                      _ptr(None if seg_len is None else _dev(seg_len, "seg_len", torch.int64)), int(seg_rows), _stream(x)),
                    "medtok_split_half_f32")
@@ -354,7 +376,7 @@ def split_gemm(a, b, n_g: int, k_g: int, groups: int = 1, a_group_cols: int = 0,
     c = torch.empty((m, n_out), dtype=torch.float32, device=a_hi.device) if want_f32 else None
     ch = torch.empty((m, n_out), dtype=torch.float16, device=a_hi.device) if want_split else None
     cl = torch.empty((m, n_out), dtype=torch.float16, device=a_hi.device) if want_split else None
-    with torch.cuda.device(a_hi.device):
+    with _on(a_hi.device):
         _lib.check(_lib.load().medtok_split_gemm_f16(a_hi.data_ptr(), a_lo.data_ptr(), m, lda, int(a_group_cols), b_hi.data_ptr(), b_lo.data_ptr(),
                                                      b_rows, ldb, int(b_group_rows), int(n_g), int(k_g), int(groups), _ptr(bias), float(unscale),
                                                      _ptr(c), n_out, _ptr(ch), _ptr(cl), n_out, _stream(a_hi)), "medtok_split_gemm_f16")
@@ -373,7 +395,7 @@ def half_gemm(a, b, n_g: int, k_g: int, groups: int = 1, a_group_cols: int = 0, 
     b_rows, ldb = b.shape
     bias = None if bias is None else _dev(bias, "bias")
     c = torch.empty((m, groups * n_g), dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         _lib.check(_lib.load().medtok_half_gemm_f32(a.data_ptr(), m, lda, int(a_group_cols), b.data_ptr(), b_rows, ldb, int(b_group_rows), int(n_g), int(k_g),
                                                     int(groups), _ptr(bias), float(unscale), c.data_ptr(), groups * n_g, int(a.dtype == torch.bfloat16),
                                                     _stream(a)), "medtok_half_gemm_f32")
@@ -392,7 +414,7 @@ def half_image(x, dp: int, dtype, transpose: bool = False, group_cols: int = 0):
     else:
         shape = (n, int(dp))
     out = torch.empty(shape, dtype=dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.load().medtok_half_image_f32(x.data_ptr(), n, d, x.stride(0) if n > 1 else d, int(dp), int(bool(transpose)), int(group_cols),
                                                      int(dtype == torch.bfloat16), out.data_ptr(), _stream(x)), "medtok_half_image_f32")
     return out
@@ -402,7 +424,7 @@ def absmax(x):
     """0-dim device fp32 tensor max |x| (no host read): feeds the power-of-two prescale of training-mode split operands."""
     x = _dev(x, "x")
     out = torch.empty((), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.load().medtok_absmax_f32(x.data_ptr(), x.numel(), out.data_ptr(), _stream(x)), "medtok_absmax_f32")
     return out
 
@@ -420,7 +442,7 @@ def split_half_scaled(x, dp: int, amax=None, transpose: bool = False, group_cols
         shape = (n, int(dp))
     hi = torch.empty(shape, dtype=torch.float16, device=x.device)
     lo = torch.empty(shape, dtype=torch.float16, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.load().medtok_split_half_scaled_f32(x.data_ptr(), n, d, d, int(dp), _ptr(amax), int(bool(transpose)), int(group_cols),
                                                             hi.data_ptr(), lo.data_ptr(), _stream(x)), "medtok_split_half_scaled_f32")
     return hi, lo
@@ -435,7 +457,7 @@ def split_gemm_scaled(a, b, n_g: int, k_g: int, bias=None, unscale: float = 1.0,
     b_rows, ldb = b_hi.shape
     c = torch.empty((m, groups * n_g), dtype=torch.float32, device=a_hi.device)
     bias = None if bias is None else _dev(bias, "bias")
-    with torch.cuda.device(a_hi.device):
+    with _on(a_hi.device):
         _lib.check(_lib.load().medtok_split_gemm_scaled_f16(a_hi.data_ptr(), a_lo.data_ptr(), m, lda, int(a_group_cols), b_hi.data_ptr(), b_lo.data_ptr(),
                                                             b_rows, ldb, int(b_group_rows), int(n_g), int(k_g), int(groups), _ptr(bias), float(unscale),
                                                             _ptr(amax_a), _ptr(amax_b), c.data_ptr(), groups * n_g, _stream(a_hi)),
@@ -456,7 +478,7 @@ def residual_layernorm(a, b, gamma, beta, eps: float, split_dp: int = 0):
     if split_dp:
         hi = torch.empty((n, split_dp), dtype=torch.float16, device=a.device)
         lo = torch.empty((n, split_dp), dtype=torch.float16, device=a.device)
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         _lib.check(_lib.load().medtok_residual_layernorm_split_f32(a.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, d, float(eps),
                                                                    y.data_ptr(), _ptr(hi), _ptr(lo), int(split_dp), _stream(a)),
                    "medtok_residual_layernorm_split_f32")
@@ -481,7 +503,7 @@ def pack_codes(mask, batch, heads: int, lpt: bool, count_bound: int = 0, status=
     stats = torch.empty(4, dtype=torch.int64, device=dev)
     lib = _lib.load()
     ws = _ws(lib.medtok_pack_codes_workspace_bytes(bsz), mask)
-    with torch.cuda.device(dev):
+    with _on(dev):
         if status is not None and not (status.is_cuda and status.dtype == torch.int32 and status.device == dev):
             raise _lib.MedTokLibraryError("pack_codes: status must be an int32 tensor on the mask's device")
         _lib.check(lib.medtok_pack_codes_checked(mask.data_ptr(), mask.element_size(), bsz, seq_len, batch.data_ptr(), batch.numel(), int(heads),
@@ -514,7 +536,7 @@ def cross_attention_layer(rows, rows_images, w, q_start, q_len, max_q_len: int, 
         kh, kl, variant = _dev(kv_split, "kv"), None, int(variant) | ATTENTION_F32_KEYS
     else:
         kh, kl = kv_split if kv_split is not None else (None, None)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.medtok_cross_attention_layer_f32(
             rows.data_ptr(), _ptr(xh), _ptr(xl), n_rows, d, dw, heads, hp,
             wq[0].data_ptr(), wq[1].data_ptr(), float(wq_u), w["bq"].data_ptr(), wk[0].data_ptr(), wk[1].data_ptr(), float(wk_u),
@@ -545,7 +567,7 @@ def cross_attention_small(text, mask, nodes, batch, weights, layers: int, scale:
     if pooled.shape != (bsz, 2, d) or pooled.dtype != torch.float32 or not pooled.is_contiguous():
         raise ValueError("cross_attention_small: pooled must be a contiguous fp32 [B, 2, d] tensor")
     y_nodes = torch.empty((max(n_nodes, 1), d), dtype=torch.float32, device=text.device)
-    with torch.cuda.device(text.device):
+    with _on(text.device):
         _lib.check(_lib.load().medtok_cross_attention_small_f32(
             text.data_ptr(), mask.data_ptr(), mask.element_size(), bsz, seq_len, nodes.data_ptr() if n_nodes else 0, batch.data_ptr() if n_nodes else 0,
             n_nodes, d, 4, int(layers), weights.data_ptr(), float(scale), float(ln_eps), y_nodes.data_ptr(), pooled.data_ptr(), 2 * d, d,
@@ -562,7 +584,7 @@ def segment_mean(x, seg_start, seg_len):
     if seg_len.numel() != n_seg:
         raise ValueError("segment_mean: seg_start and seg_len differ in length")
     out = torch.empty((n_seg, d), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.load().medtok_segment_mean_f32(x.data_ptr(), seg_start.data_ptr(), seg_len.data_ptr(), n_seg, d, out.data_ptr(), _stream(x)),
                    "medtok_segment_mean_f32")
     return out
@@ -573,7 +595,7 @@ def scale_by_device_scalar(x, num, den=None, c: float = 1.0):
     x, num = _dev(x, "x"), _dev(num, "num")
     den = None if den is None else _dev(den, "den")
     out = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.load().medtok_scale_by_device_scalar_f32(x.data_ptr(), x.numel(), num.data_ptr(), _ptr(den), float(c), out.data_ptr(),
                                                                  _stream(x)), "medtok_scale_by_device_scalar_f32")
     return out
@@ -597,7 +619,7 @@ def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int,
     ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
     out, oh, ol = _attention_outputs(q, split_out)
     lib = _lib.load()
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         _lib.check(lib.medtok_shared_kv_attention_f32(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(),
                                                       kl.data_ptr(), qs.numel(), int(max_q_len), q.shape[1], float(scale),
                                                       _ptr(out), _ptr(oh), _ptr(ol), int(bool(exact_f32)), _stream(q)), "medtok_shared_kv_attention_f32")
@@ -628,7 +650,7 @@ def shared_kv_attention_split(q, q_start, q_len, kv_split, kv_start, kv_len, max
     qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
     ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
     out, oh, ol = _attention_outputs(q, split_out)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         _lib.check(_lib.load().medtok_shared_kv_attention_split_f32(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kh.data_ptr(), _ptr(kl_),
                                                                     ks.data_ptr(), kl.data_ptr(), qs.numel(), int(max_q_len), q.shape[1], float(scale),
                                                                     _ptr(out), _ptr(oh), _ptr(ol), int(variant), _stream(q)), "medtok_shared_kv_attention_split_f32")
@@ -642,7 +664,7 @@ def shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, max_q_len
     ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
     out = torch.zeros_like(q)                 # rows that belong to no code stay zero
     lse = torch.full((q.shape[0],), float("-inf"), dtype=torch.float32, device=q.device)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         _lib.check(_lib.load().medtok_shared_kv_attention_train_f32(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(),
                                                                     kl.data_ptr(), qs.numel(), int(max_q_len), q.shape[1], float(scale),
                                                                     float(dropout_p), int(seed) & 0xFFFFFFFF, out.data_ptr(), lse.data_ptr(),
@@ -663,7 +685,7 @@ def shared_kv_attention_backward(q, q_start, q_len, kv, kv_start, kv_len, max_q_
     args = (q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(), kl.data_ptr(), qs.numel(), int(max_q_len), int(max_kv_len),
             q.shape[0], kv.shape[0], q.shape[1], float(scale), float(dropout_p), int(seed) & 0xFFFFFFFF, out.data_ptr(), lse.data_ptr(),
             d_out.data_ptr(), dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(), ws.numel())
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         if half in (torch.float16, torch.bfloat16):
             _lib.check(lib.medtok_shared_kv_attention_backward_half_f32(*args, int(half == torch.bfloat16), _stream(q)), "medtok_shared_kv_attention_backward_half_f32")
         else:
@@ -676,7 +698,7 @@ def sum_scale(vals: torch.Tensor, scale: float) -> torch.Tensor:
     vals = _dev(vals, "vals")
     out = torch.empty((), dtype=torch.float32, device=vals.device)
     lib = _lib.load()
-    with torch.cuda.device(vals.device):
+    with _on(vals.device):
         _lib.check(lib.medtok_sum_scale_f32(vals.data_ptr(), vals.numel(), float(scale), out.data_ptr(),
                                             _stream(vals)), "medtok_sum_scale_f32")
     return out
@@ -694,7 +716,7 @@ def ema_stats(zhat, idx, k_codes: int, fused: bool = False):
     es = stats[: k_codes * d].view(k_codes, d)
     bins = stats[k_codes * d:]
     ws = _ws(lib.medtok_ema_stats_workspace_bytes(n, k_codes), zhat)
-    with torch.cuda.device(zhat.device):
+    with _on(zhat.device):
         _lib.check(lib.medtok_ema_stats_f32(zhat.data_ptr(), idx.data_ptr(), n, d, k_codes, bins.data_ptr(),
                                             es.data_ptr(), ws.data_ptr(), ws.numel(), _stream(zhat)),
                    "medtok_ema_stats_f32")
@@ -707,7 +729,7 @@ def code_histogram(idx, k_codes: int) -> torch.Tensor:
     lib = _lib.load()
     bins = torch.empty(k_codes, dtype=torch.float32, device=idx.device)
     ws = _ws(lib.medtok_code_histogram_workspace_bytes(k_codes), idx)
-    with torch.cuda.device(idx.device):
+    with _on(idx.device):
         _lib.check(lib.medtok_code_histogram_f32(idx.data_ptr(), idx.numel(), k_codes, bins.data_ptr(), ws.data_ptr(),
                                                  ws.numel(), _stream(idx)), "medtok_code_histogram_f32")
     return bins
@@ -721,7 +743,7 @@ def ema_apply_(E, cluster_size, bins, embed_sum, decay: float) -> None:
     bins, embed_sum = _dev(bins, "bins"), _dev(embed_sum, "embed_sum")
     k, d = E.shape
     lib = _lib.load()
-    with torch.cuda.device(E.device):
+    with _on(E.device):
         _lib.check(lib.medtok_ema_apply_f32(E.data_ptr(), cluster_size.data_ptr(), bins.data_ptr(), embed_sum.data_ptr(),
                                             k, d, float(decay), float(1 - decay), _stream(E)), "medtok_ema_apply_f32")
 
@@ -731,7 +753,7 @@ def ema_cluster_size_(cluster_size, bins, decay: float) -> None:
         raise _lib.MedTokLibraryError("ema_cluster_size_: cluster_size must be a contiguous fp32 device tensor")
     bins = _dev(bins, "bins")
     lib = _lib.load()
-    with torch.cuda.device(bins.device):
+    with _on(bins.device):
         _lib.check(lib.medtok_ema_cluster_size_f32(cluster_size.data_ptr(), bins.data_ptr(), cluster_size.numel(),
                                                    float(decay), float(1 - decay), _stream(bins)),
                    "medtok_ema_cluster_size_f32")
@@ -746,7 +768,7 @@ def usage_update_(window: torch.Tensor, ids: torch.Tensor, n_codes: int) -> torc
     lib = _lib.load()
     count = torch.empty((), dtype=torch.int32, device=window.device)
     ws = _ws(lib.medtok_usage_workspace_bytes(window.numel(), n_codes), window)
-    with torch.cuda.device(window.device):
+    with _on(window.device):
         _lib.check(lib.medtok_usage_update(window.data_ptr(), window.numel(), ids.data_ptr(), ids.numel(), n_codes,
                                            count.data_ptr(), ws.data_ptr(), ws.numel(), _stream(window)),
                    "medtok_usage_update")
@@ -791,7 +813,7 @@ def soft_vq_forward_multi(searches, topk: int):
                                    w.data_ptr(), zq.data_ptr(), zstride, x.stride(0) if n > 1 else d)
         outs.append(dict(xhat=xhat, idx=idx, dist=dist, w=w, zq=zq, row_sqerr=None))
     ws = _ws(lib.medtok_soft_vq_forward_multi_workspace_bytes(descs, count, d, topk), keep[0][0])
-    with torch.cuda.device(keep[0][0].device):
+    with _on(keep[0][0].device):
         _lib.check(lib.medtok_soft_vq_forward_multi_f32(descs, count, d, topk, ws.data_ptr(), ws.numel(), _stream(keep[0][0])),
                    "medtok_soft_vq_forward_multi_f32")
     return outs
@@ -812,7 +834,7 @@ def usage_update_multi_(window: torch.Tensor, ids_list, n_codes: int) -> torch.T
     lib = _lib.load()
     counts = torch.empty(count, dtype=torch.int32, device=window.device)
     ws = _ws(lib.medtok_usage_multi_workspace_bytes(window.numel(), n_codes, count), window)
-    with torch.cuda.device(window.device):
+    with _on(window.device):
         _lib.check(lib.medtok_usage_update_multi(window.data_ptr(), window.numel(), ptrs, ms, count, n_codes, counts.data_ptr(), ws.data_ptr(), ws.numel(),
                                                  _stream(window)), "medtok_usage_update_multi")
     return counts
@@ -831,7 +853,7 @@ def normalized_search(z, what, wsq, topk: int = 1, path: int = PATH_AUTO):
     idx = torch.empty((n, topk), dtype=torch.int64, device=dev)
     dist = torch.empty((n, topk), dtype=torch.float32, device=dev)
     ws = _ws(lib.medtok_normalized_search_workspace_bytes(n, k, d, topk, path), z)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.medtok_normalized_search_f32(z.data_ptr(), n, d, what.data_ptr(), wsq.data_ptr(), k, topk, path, zhat.data_ptr(),
                                                     zsq.data_ptr(), idx.data_ptr(), dist.data_ptr(), ws.data_ptr(), ws.numel(), _stream(z)),
                    "medtok_normalized_search_f32")
@@ -858,7 +880,7 @@ def soft_vq_forward(x, what, wsq, topk: int, path: int = PATH_AUTO, want_sqerr: 
     zq, zstride = _zq_out(out, n, d, x)
     se = torch.empty(n, dtype=torch.float32, device=dev) if want_sqerr else None
     ws = _ws(lib.medtok_soft_vq_workspace_bytes(n, k, d, topk, path), x)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.medtok_soft_vq_forward_f32(x.data_ptr(), n, d, what.data_ptr(), wsq.data_ptr(), k, topk, path,
                                                   xhat.data_ptr(), idx.data_ptr(), dist.data_ptr(), w.data_ptr(),
                                                   zq.data_ptr(), zstride, _ptr(se), ws.data_ptr(), ws.numel(), _stream(x)),

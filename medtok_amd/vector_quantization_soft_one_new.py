@@ -165,6 +165,11 @@ def _cached(holder, attr, key, build, device, rebuild=False):
     by that stream while this one still reads).  Without this a forward that forks its side streams right after an invalidation
     (every bench step; every eval after an optimizer step) was ordered only by timing."""
     c = getattr(holder, attr, None)
+    if not rebuild and c is not None and c[0] == key:
+        # the hit on the building stream -- the common case, several times per forward -- without making a Stream object
+        mark = c[2]
+        if mark is None or device.type != "cuda" or mark.stream.cuda_stream == ops._stream_of(device):
+            return c[1]
     cur = torch.cuda.current_stream(device) if device.type == "cuda" else None
     # Under HIP-graph capture no event of the outside world may be waited for (and none recorded here may be waited for outside):
     # a capture is preceded by a warm-up and a synchronisation (the caches are built and complete), so entries are read as they are;
@@ -1410,13 +1415,13 @@ class VectorQuantizer(nn.Module):
             "text_feature": z_text,
             "shared_text_embedding": emb[:, :e],
             "shared_graph_embedding": emb[:, e:],
-            "shared_embed_loss": (zero + zero, zero + zero, xhat_s[:, 0], xhat_s[:, 1], emb[:, :e], emb[:, e:]),
+            "shared_embed_loss": (zero.clone(), zero.clone(), xhat_s[:, 0], xhat_s[:, 1], emb[:, :e], emb[:, e:]),
             "shared_codebook_usage": u_shared,
             "specific_embedding_text": res[1]["zq"],
-            "text_specific_loss": (torch.tensor(0.0), torch.tensor(0.0), res[1]["xhat"], res[1]["zq"]),
+            "text_specific_loss": (zero.clone(), zero.clone(), res[1]["xhat"], res[1]["zq"]),
             "text_specific_usage": u_text,
             "specific_embedding_graph": res[2]["zq"],
-            "graph_specific_loss": (torch.tensor(0.0), torch.tensor(0.0), res[2]["xhat"], res[2]["zq"]),
+            "graph_specific_loss": (zero.clone(), zero.clone(), res[2]["xhat"], res[2]["zq"]),
             "graph_specific_usage": u_graph,
             "specific_embedding_text_aug": res[3]["zq"] if z_aug is not None else None,
             "specific_embedding_graph_aug": res[4]["zq"] if z_aug is not None else None,
