@@ -347,6 +347,29 @@ int medtok_cross_attention_small_f32(const float *text, const void *mask, int ma
                                      const float *weights, float scale, float ln_eps, float *y_nodes, float *pooled,
                                      int64_t pooled_stride, int64_t graph_off, int32_t *status, void *stream);
 
+/* A codebook prepared once per weight version.  Every filter-path search turns its codebook region into an fp16 image, pads its
+ * squared norms into accumulator start values and takes their maximum: three passes over the region PER SEARCH, four to six times
+ * per forward on one codebook (vector_quantization_soft_one_new.py:107-117 searches three overlapping regions of one weight).
+ *   medtok_filter_image_width(d)   the image's row width dp (fp16 elements) at row width d;
+ *   medtok_rownorm_image_f32       medtok_rownorm_f32(normalize = 1) that also writes the image of the normalised rows,
+ *                                  [image_rows, dp] with rows >= n zero: image_rows >= n + 255 so that every region's last code tile
+ *                                  is inside it.  A region [lo, lo + k) of the codebook reads the image from row lo on;
+ *   medtok_codebook_prepare_f32    per region: wsqp [k rounded up to 256] = -2^15 wsq (padding -inf) and en_max [1], one launch;
+ *   medtok_soft_vq_forward_prepared_f32   medtok_soft_vq_forward_f32 (row_sqerr = NULL) for one region with its prepared image /
+ *                                  wsqp / en_max: the same bits, without the three passes.  `what` / `wsq` are still the region's
+ *                                  fp32 rows and norms (the exact re-score reads them); a search that takes the exact path
+ *                                  ignores the prepared arguments. */
+typedef struct medtok_region_desc { int64_t lo, k; float *wsqp; float *en_max; } medtok_region_desc;
+int medtok_filter_image_width(int d);
+int medtok_rownorm_image_f32(const float *x, int64_t n, int d, float *xhat, float *sqn, void *image, int64_t image_rows, int dp, void *stream);
+int medtok_codebook_image_f32(const float *what, int64_t n, int d, void *image, int64_t image_rows, int dp, void *stream);   /* the image alone, from rows that are normalised already */
+int medtok_codebook_prepare_f32(const float *wsq, const medtok_region_desc *regions, int count, void *stream);
+int medtok_search_resolved_path(int64_t n, int64_t k_codes, int d, int topk, int path);   /* MEDTOK_PATH_F32_MFMA or MEDTOK_PATH_F16_FILTER: what `path` (e.g. AUTO) comes to at this shape */
+int medtok_soft_vq_forward_prepared_f32(const float *x, int64_t n, int d, const float *what, const float *wsq, int64_t k_codes,
+                                        int topk, int path, const void *image, const float *wsqp, const float *en_max,
+                                        float *xhat, int64_t *idx, float *dist, float *w, float *zq_ste,
+                                        int64_t zq_stride, void *ws, size_t ws_bytes, void *stream);
+
 /* The prologue of the batched cross-attention: what the reference's per-code loop reads back with `.item()` and `batch == idx`
  * (vector_quantization_soft_one_new.py:133-142), for all codes at once, in three small launches and no host round trip:
  *   valid_len[b] = non-zero entries of mask row b (mask [n_codes, seq_len], elements of mask_elem_bytes = 1 (bool), 4 or 8 bytes);

@@ -95,6 +95,12 @@ SIGNATURES = {
                                                 _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _f, _int, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "medtok_cross_attention_small_f32": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _vp, _i64, _int, _int, _int, _vp, _f, _f, _vp, _vp, _i64, _i64, _vp, _vp]),
     "medtok_segment_mean_f32": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp]),
+    "medtok_filter_image_width": (_int, [_int]),
+    "medtok_rownorm_image_f32": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _i64, _int, _vp]),
+    "medtok_codebook_prepare_f32": (_int, [_vp, _vp, _int, _vp]),
+    "medtok_codebook_image_f32": (_int, [_vp, _i64, _int, _vp, _i64, _int, _vp]),
+    "medtok_search_resolved_path": (_int, [_i64, _i64, _int, _int, _int]),
+    "medtok_soft_vq_forward_prepared_f32": (_int, [_vp, _i64, _int, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "medtok_pack_codes_workspace_bytes": (_sz, [_i64]),
     "medtok_pack_codes": (_int, [_vp, _int, _i64, _i64, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "medtok_pack_codes_checked": (_int, [_vp, _int, _i64, _i64, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
@@ -122,6 +128,14 @@ SIGNATURES = {
 
 class MedTokLibraryError(RuntimeError):
     pass
+
+
+class RegionDesc(C.Structure):
+    """medtok_region_desc (include/medtok_vq.h)"""
+    _fields_ = [("lo", C.c_int64), ("k", C.c_int64), ("wsqp", C.c_void_p), ("en_max", C.c_void_p)]
+
+
+PREP_MAX_REGIONS = 4
 
 
 class SearchDesc(C.Structure):

@@ -78,8 +78,9 @@ __device__ __forceinline__ float filter_eps(float xn, float en_max, int d)
 // (A k-blocked image [n/16][dp/32][16][32], which makes every LDS-DMA instruction read 8 full 128-byte lines instead of
 // 16 half-used ones, measured 5-9 % SLOWER: with row-major rows the second stage that touches a line finds it in the L2.)
 __global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ src, long n, int d, long n_pad, int dp,
-                                                      _Float16 *__restrict__ dst)
+                                                      _Float16 *__restrict__ dst, int *__restrict__ zero_word = nullptr)
 {
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;      // (see rownorm_kernel)
     const int cpr = dp / 8;                                   // 16-byte chunks per row
     const long total = n_pad * cpr;
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(256) void to_half_kernel(const float *__restrict__ 
 // per-codebook preparation ride along (they were a launch and a memset of their own: ~10 us per search at serving sizes): wsqp (if
 // given) = the accumulator start values [k_pad], -2^15 |e|^2 (exact: a power-of-two scale), -inf beyond k so that padded codes never
 // pass; *zero_me (if given) = 0 (the count of rows handed to the exact kernel).
-__global__ __launch_bounds__(1024) void wsq_max_kernel(const float *__restrict__ wsq, int k, float *__restrict__ out,
-                                                       float *__restrict__ wsqp = nullptr, int k_pad = 0, int *__restrict__ zero_me = nullptr)
+__device__ __forceinline__ void wsq_max_body(const float *__restrict__ wsq, int k, float *__restrict__ out,
+                                             float *__restrict__ wsqp, int k_pad, int *__restrict__ zero_me)
 {
     __shared__ float sh[1024];
     float m = 0.f;
@@ -123,6 +124,21 @@ __global__ __launch_bounds__(1024) void wsq_max_kernel(const float *__restrict__
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = sh[0];
+}
+__global__ __launch_bounds__(1024) void wsq_max_kernel(const float *__restrict__ wsq, int k, float *__restrict__ out,
+                                                       float *__restrict__ wsqp = nullptr, int k_pad = 0, int *__restrict__ zero_me = nullptr)
+{
+    wsq_max_body(wsq, k, out, wsqp, k_pad, zero_me);
+}
+// The same for several code ranges of one codebook in one launch (block = range): what a search's preparation computes per call,
+// once per weight version for every region the caller searches (medtok_codebook_prepare_f32).
+constexpr int PREP_MAX_REGIONS = 4;
+struct RegionPrep { const float *wsq; int k; float *en_max; float *wsqp; int k_pad; };
+struct RegionPrepArgs { RegionPrep r[PREP_MAX_REGIONS]; };
+__global__ __launch_bounds__(1024) void wsq_max_regions_kernel(const RegionPrepArgs a)
+{
+    const RegionPrep q = a.r[blockIdx.x];
+    wsq_max_body(q.wsq, q.k, q.en_max, q.wsqp, q.k_pad, nullptr);
 }
 
 // ---------------------------------------------------------------- value-only top-k (thresholds)

@@ -185,13 +185,25 @@ __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<floa
 typedef _Float16 rn_half4 __attribute__((ext_vector_type(4)));
 // xh (optional, NORMALIZE only): the fp16 filter's operand image of the normalised rows, [*, dp] prescaled by 2^8 exactly as
 // to_half_kernel writes it -- the one-call forward saves that kernel's pass over xhat.
+// n_img (with xh): the image has that many rows; those from n on are written as zeros (the filter reads whole row tiles).
+// zero_word: an int the launch clears (the filter's count of rows handed to the exact kernel, when nothing else of the search's
+// preparation runs: a prepared codebook).
 template <bool NORMALIZE>
 __global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ x, long n, int d,
-                                                      float *xhat, float *__restrict__ sqn, _Float16 *__restrict__ xh = nullptr, int dp = 0)
+                                                      float *xhat, float *__restrict__ sqn, _Float16 *__restrict__ xh = nullptr, int dp = 0,
+                                                      long n_img = 0, int *__restrict__ zero_word = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;
+    if (row >= n) {
+        if (NORMALIZE && xh && row < n_img) {
+            rn_half4 z;
+            z[0] = z[1] = z[2] = z[3] = (_Float16)0.f;
+            for (int i = lane * 4; i < dp; i += 256) *reinterpret_cast<rn_half4 *>(xh + row * dp + i) = z;
+        }
+        return;
+    }
     const float *src = x + row * d;
     float *dst = xhat ? xhat + row * d : nullptr;
     float p = 0.f;
@@ -235,10 +247,17 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float *__restrict__ 
 // offsets 8..1 only -- the offsets 32 and 16 of the one-row kernel add the zeros of idle lanes, so the bits are the same.
 template <bool NORMALIZE>
 __global__ __launch_bounds__(256) void rownorm16_kernel(const float *__restrict__ x, long n, int d,
-                                                        float *xhat, float *__restrict__ sqn, _Float16 *__restrict__ xh = nullptr, int dp = 0)
+                                                        float *xhat, float *__restrict__ sqn, _Float16 *__restrict__ xh = nullptr, int dp = 0,
+                                                        long n_img = 0, int *__restrict__ zero_word = nullptr)
 {
     const int sub = threadIdx.x & 15;
     const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;
+    if (NORMALIZE && xh && row >= n && row < n_img && sub * 4 < dp) {      // image rows past the last input row: zeros
+        rn_half4 z;
+        z[0] = z[1] = z[2] = z[3] = (_Float16)0.f;
+        *reinterpret_cast<rn_half4 *>(xh + row * dp + sub * 4) = z;
+    }
     const bool live = row < n, mine = live && sub * 4 < d;
     const long r = live ? row : 0;
     const float *src = x + r * d + sub * 4;
@@ -274,12 +293,14 @@ __global__ __launch_bounds__(256) void rownorm16_kernel(const float *__restrict_
 
 // the launch every caller of the row-norm kernels goes through: the 16-lanes-per-row form where a row fits it
 template <bool NORMALIZE>
-static inline void launch_rownorm(hipStream_t s, const float *x, long n, int d, float *xhat, float *sqn, _Float16 *xh = nullptr, int dp = 0)
+static inline void launch_rownorm(hipStream_t s, const float *x, long n, int d, float *xhat, float *sqn, _Float16 *xh = nullptr, int dp = 0,
+                                  long n_img = 0, int *zero_word = nullptr)
 {
+    const long rows = xh && n_img > n ? n_img : n;
     if (d <= 64 && (!xh || dp <= 64))
-        hipLaunchKernelGGL(rownorm16_kernel<NORMALIZE>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, x, n, d, xhat, sqn, xh, dp);
+        hipLaunchKernelGGL(rownorm16_kernel<NORMALIZE>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, x, n, d, xhat, sqn, xh, dp, n_img, zero_word);
     else
-        hipLaunchKernelGGL(rownorm_kernel<NORMALIZE>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, n, d, xhat, sqn, xh, dp);
+        hipLaunchKernelGGL(rownorm_kernel<NORMALIZE>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, n, d, xhat, sqn, xh, dp, n_img, zero_word);
 }
 
 extern "C" int medtok_rownorm_f32(const float *x, int64_t n, int d, int normalize, float *xhat,
@@ -1134,7 +1155,10 @@ static int launch_search_t(const float *xhat, const float *xsq, int64_t n, const
 
 // Handed by medtok_soft_vq_forward_f32 to its search call: when the filter path runs, its re-score kernel also does the
 // soft assignment (and the exact-path leftovers get it from soft_assign_kernel through the row list).
-struct FuseAssign { const float *xref; float *w; float *zq; long zq_stride; bool done; const int *fb_rows, *fb_count; bool xh_done; };
+struct FuseAssign { const float *xref; float *w; float *zq; long zq_stride; bool done; const int *fb_rows, *fb_count; bool xh_done;
+                    // a codebook region prepared once per weight version (medtok_codebook_prepare_f32): its fp16 image, its padded start
+                    // values and its largest squared norm -- the search then skips its own passes over the codebook
+                    const _Float16 *p_wh = nullptr; const float *p_wsqp = nullptr; const float *p_en_max = nullptr; bool fb_zeroed = false; };
 
 template <int T, bool KTAIL>
 static int launch_filter(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
@@ -1144,31 +1168,39 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     const FilterPlan f = plan_filter(n, k_codes, d, topk, ov);
     const FilterWs w = filter_ws_layout(ws, n, f);
     if (!ws || ws_bytes < w.total) return fail("search(filter): workspace too small (%zu < %zu)", ws_bytes, w.total);
+    const bool prep = fuse && fuse->p_wh && fuse->p_wsqp && fuse->p_en_max;
+    const _Float16 *const c_wh = prep ? fuse->p_wh : w.wh;
+    const float *const c_wsqp = prep ? fuse->p_wsqp : w.wsqp, *const c_en_max = prep ? fuse->p_en_max : w.en_max;
     if (!(fuse && fuse->xh_done))      // (the one-call forward's rownorm has already written the fp16 image of x)
-        hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.n_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, xhat, (long)n, d, f.n_pad, f.dp, w.xh);
-    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, w.wh);
-    hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, w.en_max, w.wsqp, (int)f.k_pad, w.fb_count);
+        hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.n_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, xhat, (long)n, d, f.n_pad, f.dp, w.xh,
+                           prep ? w.fb_count : (int *)nullptr);
+    else if (prep && !fuse->fb_zeroed && hipMemsetAsync(w.fb_count, 0, 4, s) != hipSuccess)
+        return fail("search(filter): memset failed");
+    if (!prep) {
+        hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, w.wh);
+        hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, w.en_max, w.wsqp, (int)f.k_pad, w.fb_count);
+    }
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
     if (f.rows64 && !f.rows64_wide) {
         hipLaunchKernelGGL((filter_rows64n_kernel<T>), dim3((unsigned)f.row_tiles, (unsigned)f.splits), dim3(R64N_THREADS), R64N_SMEM_BYTES, s,
-                           w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, d, f.codes_per_split, f.own_total, w.cand, w.cand_cnt);
+                           w.xh, c_wh, xsq, c_wsqp, c_en_max, (long)n, (int)k_codes, d, f.codes_per_split, f.own_total, w.cand, w.cand_cnt);
     } else if (f.rows64) {
         (void)set_lds_once<filter_rows64_kernel<T>>(R64_SMEM_BYTES);
         hipLaunchKernelGGL((filter_rows64_kernel<T>), dim3((unsigned)f.row_tiles, (unsigned)f.splits), dim3(R64_THREADS), R64_SMEM_BYTES, s,
-                           w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, d, f.codes_per_split, f.own_total, w.cand, w.cand_cnt);
+                           w.xh, c_wh, xsq, c_wsqp, c_en_max, (long)n, (int)k_codes, d, f.codes_per_split, f.own_total, w.cand, w.cand_cnt);
     } else {
         (void)set_lds_once<filter_f16_kernel<T, false>>(F_SMEM_BYTES);
         dim3 fgrid((unsigned)f.main_tiles, (unsigned)f.splits);
         if (f.xcd_rows) fgrid = dim3((unsigned)(((f.main_tiles + 8 * f.xcd_rows - 1) / (8 * f.xcd_rows)) * 256), 1);
         hipLaunchKernelGGL((filter_f16_kernel<T, false>), fgrid, dim3(F_THREADS), F_SMEM_BYTES, s,
-                           w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
+                           w.xh, c_wh, xsq, c_wsqp, c_en_max, (long)n, (int)k_codes, f.dp, d, f.codes_per_split, f.own_total,
                            w.cand, w.cand_cnt, (float *)nullptr, f.xcd_rows, f.splits, 0, (int)f.main_tiles);
     }
     const long tail_start = f.main_tiles * f.row_bn;
     if (f.main_tiles < f.row_tiles) {
         // the kernel indexes its lists by absolute row: bias the tail region's base pointers accordingly
         hipLaunchKernelGGL((filter_f16_kernel<T, false>), dim3((unsigned)(f.row_tiles - f.main_tiles), (unsigned)f.tail_splits), dim3(F_THREADS),
-                           F_SMEM_BYTES, s, w.xh, w.wh, xsq, w.wsqp, w.en_max, (long)n, (int)k_codes, f.dp, d, f.tail_codes_per_split, f.own_tail,
+                           F_SMEM_BYTES, s, w.xh, c_wh, xsq, c_wsqp, c_en_max, (long)n, (int)k_codes, f.dp, d, f.tail_codes_per_split, f.own_tail,
                            w.cand_tail - tail_start * f.own_tail * F_CAP, w.cnt_tail - tail_start * f.own_tail, (float *)nullptr, 0, f.tail_splits,
                            (int)f.main_tiles, (int)f.row_tiles);
     }
@@ -1177,7 +1209,7 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
     // few rows: one wavefront per row (latency-bound: rescore_wave_kernel); many rows: 32-row blocks
 #define MEDTOK_RESCORE_ARGS                                                                                                      \
     w.cand, w.cand_cnt, f.own_total, w.cand_tail, w.cnt_tail, f.own_tail, f.main_tiles < f.row_tiles ? tail_start : (long)n,     \
-    xhat, xsq, what, wsq, w.en_max, (long)n, (int)k_codes, d, topk, idx, dist, w.fb_count, w.fb_rows,                             \
+    xhat, xsq, what, wsq, c_en_max, (long)n, (int)k_codes, d, topk, idx, dist, w.fb_count, w.fb_rows,                             \
     fuse ? fuse->xref : (const float *)nullptr, fuse ? fuse->w : (float *)nullptr,                                                \
     fuse ? fuse->zq : (float *)nullptr, fuse ? fuse->zq_stride : 0L
     if (n < 32L * 4 * dev_info().cus && f.own_total <= 64 && f.own_tail <= 64)
@@ -2944,9 +2976,80 @@ extern "C" size_t medtok_soft_vq_workspace_bytes(int64_t n, int64_t k_codes, int
     return align_up((size_t)n * 4, 256) + medtok_search_workspace_bytes(n, k_codes, d, topk, path);
 }
 
+static int soft_vq_forward_impl(const float *x, int64_t n, int d, const float *what, const float *wsq, int64_t k_codes,
+                                int topk, int path, float *xhat, int64_t *idx, float *dist, float *w, float *zq_ste,
+                                int64_t zq_stride, float *row_sqerr, void *ws, size_t ws_bytes, void *stream,
+                                const _Float16 *p_wh, const float *p_wsqp, const float *p_en_max);
+
 extern "C" int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d, const float *what, const float *wsq, int64_t k_codes,
                                           int topk, int path, float *xhat, int64_t *idx, float *dist, float *w, float *zq_ste,
                                           int64_t zq_stride, float *row_sqerr, void *ws, size_t ws_bytes, void *stream)
+{
+    return soft_vq_forward_impl(x, n, d, what, wsq, k_codes, topk, path, xhat, idx, dist, w, zq_ste, zq_stride, row_sqerr, ws, ws_bytes, stream,
+                                nullptr, nullptr, nullptr);
+}
+
+// ---- a codebook prepared once per weight version
+extern "C" int medtok_filter_image_width(int d)
+{
+    return d > 0 ? (int)lmax(2 * F_BK, (d + F_BK - 1) / F_BK * F_BK) : 0;
+}
+
+extern "C" int medtok_rownorm_image_f32(const float *x, int64_t n, int d, float *xhat, float *sqn, void *image, int64_t image_rows, int dp, void *stream)
+{
+    if (n <= 0 || d <= 0 || (d & 3)) return fail("rownorm_image: need n > 0, d > 0, d %% 4 == 0 (n=%ld d=%d)", (long)n, d);
+    if (!x || !xhat || !sqn || !image) return fail("rownorm_image: NULL argument");
+    if (dp != medtok_filter_image_width(d)) return fail("rownorm_image: dp=%d, the filter reads images of width %d at d=%d", dp, medtok_filter_image_width(d), d);
+    if (image_rows < n) return fail("rownorm_image: image_rows=%ld < n=%ld", (long)image_rows, (long)n);
+    if (((uintptr_t)x | (uintptr_t)xhat | (uintptr_t)image) & 15) return fail("rownorm_image: pointers must be 16-byte aligned");
+    launch_rownorm<true>((hipStream_t)stream, x, (long)n, d, xhat, sqn, (_Float16 *)image, dp, (long)image_rows);
+    return check_launch("rownorm_image");
+}
+
+extern "C" int medtok_codebook_image_f32(const float *what, int64_t n, int d, void *image, int64_t image_rows, int dp, void *stream)
+{
+    if (n <= 0 || d <= 0 || (d & 3) || !what || !image) return fail("codebook_image: bad arguments (n=%ld d=%d)", (long)n, d);
+    if (dp != medtok_filter_image_width(d) || image_rows < n) return fail("codebook_image: dp=%d (expected %d), image_rows=%ld (>= %ld)", dp, medtok_filter_image_width(d), (long)image_rows, (long)n);
+    if (((uintptr_t)what | (uintptr_t)image) & 15) return fail("codebook_image: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (image_rows * (dp / 8) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, what, (long)n, d,
+                       (long)image_rows, dp, (_Float16 *)image, (int *)nullptr);
+    return check_launch("codebook_image");
+}
+
+extern "C" int medtok_search_resolved_path(int64_t n, int64_t k_codes, int d, int topk, int path)
+{
+    if (n <= 0 || k_codes <= 0 || d <= 0 || topk < 1 || topk > MEDTOK_MAX_TOPK) return MEDTOK_PATH_F32_MFMA;
+    return resolve_path(path, n, k_codes, d, topk);
+}
+
+extern "C" int medtok_codebook_prepare_f32(const float *wsq, const medtok_region_desc *regions, int count, void *stream)
+{
+    if (!wsq || !regions || count < 1 || count > PREP_MAX_REGIONS) return fail("codebook_prepare: 1..%d regions", PREP_MAX_REGIONS);
+    RegionPrepArgs a;
+    for (int i = 0; i < count; ++i) {
+        const medtok_region_desc &r = regions[i];
+        if (r.lo < 0 || r.k <= 0 || r.lo + r.k >= (1ll << 31) || !r.wsqp || !r.en_max) return fail("codebook_prepare: bad region %d", i);
+        a.r[i] = RegionPrep{wsq + r.lo, (int)r.k, r.en_max, r.wsqp, (int)((r.k + F_BM - 1) / F_BM * F_BM)};
+    }
+    hipLaunchKernelGGL(wsq_max_regions_kernel, dim3((unsigned)count), dim3(1024), 0, (hipStream_t)stream, a);
+    return check_launch("codebook_prepare");
+}
+
+extern "C" int medtok_soft_vq_forward_prepared_f32(const float *x, int64_t n, int d, const float *what, const float *wsq, int64_t k_codes,
+                                                   int topk, int path, const void *image, const float *wsqp, const float *en_max,
+                                                   float *xhat, int64_t *idx, float *dist, float *w, float *zq_ste,
+                                                   int64_t zq_stride, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!image || !wsqp || !en_max) return fail("soft_vq_forward_prepared: NULL prepared argument");
+    if ((uintptr_t)image & 15) return fail("soft_vq_forward_prepared: the image must be 16-byte aligned");
+    return soft_vq_forward_impl(x, n, d, what, wsq, k_codes, topk, path, xhat, idx, dist, w, zq_ste, zq_stride, nullptr, ws, ws_bytes, stream,
+                                (const _Float16 *)image, wsqp, en_max);
+}
+
+static int soft_vq_forward_impl(const float *x, int64_t n, int d, const float *what, const float *wsq, int64_t k_codes,
+                                int topk, int path, float *xhat, int64_t *idx, float *dist, float *w, float *zq_ste,
+                                int64_t zq_stride, float *row_sqerr, void *ws, size_t ws_bytes, void *stream,
+                                const _Float16 *p_wh, const float *p_wsqp, const float *p_en_max)
 {
     if (n == 0) return 0;
     const size_t need = medtok_soft_vq_workspace_bytes(n, k_codes, d, topk, path);
@@ -2957,6 +3060,7 @@ extern "C" int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d, cons
     // does the soft assignment itself, bit for bit the same, while the top-k code rows are hot in the L2.
     if (zq_stride == 0) zq_stride = d;
     FuseAssign fuse = {x, w, zq_ste, (long)zq_stride, false, nullptr, nullptr, false};
+    fuse.p_wh = p_wh; fuse.p_wsqp = p_wsqp; fuse.p_en_max = p_en_max;
     const bool try_fuse = !row_sqerr && zq_ste && zq_stride >= d && !(zq_stride & 3) && topk <= MEDTOK_MAX_TOPK;
     const bool filter_path = topk >= 1 && topk <= MEDTOK_MAX_TOPK && resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER;
     if (try_fuse && filter_path && xhat && !(d & 3)) {
@@ -2964,11 +3068,12 @@ extern "C" int medtok_soft_vq_forward_f32(const float *x, int64_t n, int d, cons
         const FilterPlan f = plan_filter(n, k_codes, d, topk, decode_plan(path));
         const FilterWs fw = filter_ws_layout(sws, n, f);
         hipStream_t s = (hipStream_t)stream;
-        launch_rownorm<true>(s, x, (long)n, d, xhat, xsq, fw.xh, f.dp);
-        if (f.n_pad > n && hipMemsetAsync(fw.xh + (size_t)n * f.dp, 0, (size_t)(f.n_pad - n) * f.dp * 2, s) != hipSuccess)
-            return fail("soft_vq_forward: memset failed");
+        // (the image's padding rows are written by the same launch; with a prepared codebook it also clears the count of rows the
+        // filter hands to the exact kernel -- nothing else of the search's preparation runs then)
+        launch_rownorm<true>(s, x, (long)n, d, xhat, xsq, fw.xh, f.dp, (long)f.n_pad, p_wh ? fw.fb_count : (int *)nullptr);
         if (check_launch("rownorm(+fp16)")) return 1;
         fuse.xh_done = true;
+        fuse.fb_zeroed = p_wh != nullptr;
     } else if (medtok_rownorm_f32(x, n, d, 1, xhat, xsq, stream)) {
         return 1;
     }

@@ -860,12 +860,74 @@ def normalized_search(z, what, wsq, topk: int = 1, path: int = PATH_AUTO):
     return zhat, zsq, idx, dist
 
 
-def soft_vq_forward(x, what, wsq, topk: int, path: int = PATH_AUTO, want_sqerr: bool = True, out=None):
+def takes_filter_path(n: int, k_codes: int, d: int, topk: int, path: int = PATH_AUTO) -> bool:
+    """does a search of this shape run the fp16 shortlist (and so profit from a prepared codebook)?"""
+    return _lib.load().medtok_search_resolved_path(int(n), int(k_codes), int(d), int(topk), int(path)) == PATH_F16_FILTER
+
+
+def prepare_codebook(weight: torch.Tensor, regions, normalised=None):
+    """normalize(weight) plus everything the fp16-filter searches derive from it, once per weight version (include/medtok_vq.h:
+    medtok_rownorm_image_f32 + medtok_codebook_prepare_f32; two launches): (what [K, d], wsq [K], {region name: prepared}) for
+    regions = {name: (lo, hi)}.  A `prepared` entry goes to soft_vq_forward(..., prepared=...) together with what[lo:hi] / wsq[lo:hi].
+    normalised = (what, wsq) of an earlier rownorm(weight): only the image and the regions' values are made (weight is not read)."""
+    import ctypes as C
+    w = _dev(weight if normalised is None else normalised[0], "weight")
+    n, d = w.shape
+    if not 1 <= len(regions) <= _lib.PREP_MAX_REGIONS:
+        raise ValueError(f"prepare_codebook: 1..{_lib.PREP_MAX_REGIONS} regions")
+    lib = _lib.load()
+    dp = lib.medtok_filter_image_width(d)
+    dev = w.device
+    rows = n + 256
+    what = torch.empty_like(w) if normalised is None else None
+    wsq = torch.empty(n, dtype=torch.float32, device=dev) if normalised is None else None
+    image = torch.empty((rows, dp), dtype=torch.float16, device=dev)
+    descs = (_lib.RegionDesc * len(regions))()
+    prepared = {}
+    for i, (name, (lo, hi)) in enumerate(regions.items()):
+        k = hi - lo
+        if not 0 <= lo < hi <= n:
+            raise ValueError(f"prepare_codebook: region {name} = [{lo}, {hi}) outside the codebook")
+        wsqp = torch.empty((k + 255) // 256 * 256, dtype=torch.float32, device=dev)
+        en_max = torch.empty(1, dtype=torch.float32, device=dev)
+        descs[i] = _lib.RegionDesc(lo, k, wsqp.data_ptr(), en_max.data_ptr())
+        prepared[name] = dict(image=image[lo:], wsqp=wsqp, en_max=en_max, k=k, d=d)
+    with _on(dev):
+        if normalised is None:
+            _lib.check(lib.medtok_rownorm_image_f32(w.data_ptr(), n, d, what.data_ptr(), wsq.data_ptr(), image.data_ptr(), rows, dp, _stream(w)),
+                       "medtok_rownorm_image_f32")
+        else:
+            what, wsq = w, _dev(normalised[1], "wsq")
+            _lib.check(lib.medtok_codebook_image_f32(what.data_ptr(), n, d, image.data_ptr(), rows, dp, _stream(w)), "medtok_codebook_image_f32")
+        _lib.check(lib.medtok_codebook_prepare_f32(wsq.data_ptr(), descs, len(regions), _stream(w)), "medtok_codebook_prepare_f32")
+    return what, wsq, prepared
+
+
+def soft_vq_forward(x, what, wsq, topk: int, path: int = PATH_AUTO, want_sqerr: bool = True, out=None, prepared=None):
     """rownorm -> search -> soft assign in one C call.
-    Returns dict(xhat, idx, dist, w, zq, row_sqerr); `out` as in soft_assign."""
+    Returns dict(xhat, idx, dist, w, zq, row_sqerr); `out` as in soft_assign.  prepared (inference, want_sqerr = False): the region's
+    entry of prepare_codebook -- the same bits without the search's own passes over the codebook."""
     x, what, wsq = _dev(x, "x"), _dev(what, "what"), _dev(wsq, "wsq")
     n, d = x.shape
     k = what.shape[0]
+    if prepared is not None and not want_sqerr and SEARCH_TIMER is None and n > 0:
+        if prepared["k"] != k or prepared["d"] != d or prepared["image"].device != x.device:
+            raise ValueError("soft_vq_forward: `prepared` belongs to another region / width / device")
+        lib = _lib.load()
+        dev = x.device
+        xhat = torch.empty_like(x)
+        idx = torch.empty((n, topk), dtype=torch.int64, device=dev)
+        dist = torch.empty((n, topk), dtype=torch.float32, device=dev)
+        w = torch.empty((n, topk), dtype=torch.float32, device=dev)
+        zq, zstride = _zq_out(out, n, d, x)
+        ws = _ws(lib.medtok_soft_vq_workspace_bytes(n, k, d, topk, path), x)
+        with _on(dev):
+            _lib.check(lib.medtok_soft_vq_forward_prepared_f32(x.data_ptr(), n, d, what.data_ptr(), wsq.data_ptr(), k, topk, path,
+                                                               prepared["image"].data_ptr(), prepared["wsqp"].data_ptr(), prepared["en_max"].data_ptr(),
+                                                               xhat.data_ptr(), idx.data_ptr(), dist.data_ptr(), w.data_ptr(),
+                                                               zq.data_ptr(), zstride, ws.data_ptr(), ws.numel(), _stream(x)),
+                       "medtok_soft_vq_forward_prepared_f32")
+        return dict(xhat=xhat, idx=idx, dist=dist, w=w, zq=zq, row_sqerr=None)
     if SEARCH_TIMER is not None:         # same kernels, launched piecewise so the search can be bracketed
         xhat, xsq = rownorm(x)
         idx, dist = topk_search(xhat, xsq, what, wsq, topk, path)

@@ -88,6 +88,10 @@ MERGE_SHARED_SEARCHES = True
 # the forward's three to five searches in ONE call of three launches (ops.soft_vq_forward_multi) and its three to five updates of
 # the usage window in one call of two (ops.usage_update_multi_)
 BATCHED_SMALL_SEARCHES = True
+# inference: what every fp16-shortlist search derives from its codebook region (fp16 image, accumulator start values, largest norm)
+# is made ONCE per weight version, for all three regions together with the normalisation (ops.prepare_codebook: two launches),
+# instead of three passes over its region in each of a forward's three to five searches
+PREPARED_CODEBOOK = True
 from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
@@ -1131,6 +1135,12 @@ class _SoftVQMultiFunction(torch.autograd.Function):
         return (gw, None, None, None, None, None, None, *gxs)
 
 
+class _Norm(tuple):
+    """(what, wsq) of the normalised codebook; `prepared`: ops.prepare_codebook's entry per region ("text", "graph", "shared") when a
+    search of the caller takes the fp16 shortlist, else None.  Read-only once in the cache."""
+    prepared = None
+
+
 class VectorQuantizer(nn.Module):
     def __init__(self, n_e, e_dim, beta, entropy_loss_ratio, l2_norm, show_usage, split, kmeans=False,
                  num_head=4, k=5):
@@ -1196,7 +1206,7 @@ class VectorQuantizer(nn.Module):
         self._norm_cache = None
         return super()._load_from_state_dict(*args, **kwargs)
 
-    def _normalised_codebook(self, rebuild=None):
+    def _normalised_codebook(self, rebuild=None, prepare=False):
         """normalize(codebook.weight) and its row norms.  The reference re-normalises on every call (:148,198,200);
         so does this in training mode (one K x D pass, ~60 us at n_e = 49152, D = 768 -- and every optimizer step
         changes the weight anyway): forward() re-normalises once and hands the result to its 4-6 searches, a search
@@ -1205,7 +1215,29 @@ class VectorQuantizer(nn.Module):
         wt = self.codebook.weight
         key = (wt.data_ptr(), wt._version, wt.device, wt.shape)
         stale = self.training if rebuild is None else rebuild
-        return _cached(self, "_norm_cache", key, lambda: ops.rownorm(wt.detach()), wt.device, rebuild=stale)
+        # prepare (inference, some search of the caller takes the fp16 shortlist): the three regions' fp16 image / start values /
+        # largest norm come out of the same two launches, once per weight version, instead of three passes over its region in
+        # every search (ops.prepare_codebook)
+        prepare = (prepare and PREPARED_CODEBOOK and not self.training and not torch.is_grad_enabled() and wt.is_cuda
+                   and wt.dtype == torch.float32 and self.e_dim % 4 == 0)
+        regions = lambda: {t: self._region(t) for t in ("text", "graph", "shared")}
+
+        def build():
+            if not prepare:
+                return _Norm(ops.rownorm(wt.detach()))
+            what, wsq, prepared = ops.prepare_codebook(wt.detach(), regions())
+            norm = _Norm((what, wsq))
+            norm.prepared = prepared
+            return norm
+        norm = _cached(self, "_norm_cache", key, build, wt.device, rebuild=stale)
+        if prepare and getattr(norm, "prepared", None) is None:
+            def upgrade(old=norm):           # an entry built by a caller that had no use for the image: add it (a new entry: readers
+                _, _, prepared = ops.prepare_codebook(None, regions(), normalised=(old[0], old[1]))     # on other streams wait for it)
+                new = _Norm((old[0], old[1]))
+                new.prepared = prepared
+                return new
+            norm = _cached(self, "_norm_cache", key, upgrade, wt.device, rebuild=True)
+        return norm
 
     def project(self, x, types):
         """proj_text / proj_graph (reference :190,192: nn.Linear(split[i], e_dim)).  Inference on wide batches: the library's own
@@ -1269,12 +1301,16 @@ class VectorQuantizer(nn.Module):
         n = x.shape[0]
         x = x.float()                   # autocast callers hand over fp16/bf16; the search is fp32
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.codebook.weight.requires_grad)
-        what, wsq = norm if norm is not None else self._normalised_codebook()
+        if norm is None:
+            norm = self._normalised_codebook(prepare=not training and ops.takes_filter_path(n, hi - lo, x.shape[1], self.k, self.search_path))
+        what, wsq = norm
+        prepared = getattr(norm, "prepared", None)
+        prepared = None if prepared is None or training else prepared["text" if types == "text" else "graph" if types == "graph" else "shared"]
         if training and needs_grad:
             return _SoftVQFunction.apply(x, self.codebook.weight[lo:hi], what[lo:hi], wsq[lo:hi].contiguous(), self.k,
                                          self.search_path, float(self.beta))
         r = ops.soft_vq_forward(x.detach().float(), what[lo:hi], wsq[lo:hi].contiguous(), self.k, self.search_path,
-                                want_sqerr=training, out=out)
+                                want_sqerr=training, out=out, prepared=prepared)
         if training:
             vq = ops.sum_scale(r["row_sqerr"], (1.0 / (n * x.shape[1])) if n else float("nan"))
             commit = self.beta * vq
@@ -1480,7 +1516,11 @@ class VectorQuantizer(nn.Module):
         counts = []                     # the usage counts stay on the device: one sync at the end
         # one normalisation of the codebook per forward (training: re-normalised every forward, like the reference's every call;
         # eval: the cache per weight version), shared by its 4-6 searches
-        norm = self._normalised_codebook(rebuild=self.training)
+        bsz_, region_ = z.shape[0], self.codebook.weight.shape[0] // 3
+        norm = self._normalised_codebook(rebuild=self.training,
+                                         prepare=not self.training and z.is_cuda and bsz_ > 0 and self.e_dim % 4 == 0
+                                         and (ops.takes_filter_path(2 * bsz_, self.n_e, self.e_dim, self.k, self.search_path)
+                                              or ops.takes_filter_path(bsz_, region_, self.e_dim, self.k, self.search_path)))
         small = self._forward_small_batch(z, text_features, graph_node_features, text_attention_mask, batch, z_aug, norm)
         if small is not None:
             return small

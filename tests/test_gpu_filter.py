@@ -326,3 +326,76 @@ def test_rows_of_at_most_32_elements_repeated_searches(dev):
                 if not (torch.equal(i0, i1) and torch.equal(d0, d1)):
                     bad.append((seed, n, K, D, k, rep, int((i0 != i1).any(1).sum())))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("n,K,D,topk", [(20000, 3 * 4096, 768, 5), (9000, 3 * 7000, 64, 5), (5000, 3 * 2731, 100, 1), (70001, 3 * 1500, 36, 8)])
+def test_prepared_codebook_searches_equal_the_unprepared_ones(dev, n, K, D, topk):
+    """ops.prepare_codebook (normalisation + fp16 image + start values + largest norm of the three regions, two launches, once per weight
+    version) against searches that prepare their region themselves: every output of soft_vq_forward, bit for bit -- regions that
+    start inside the codebook and end at its last row, widths the image pads, both filter kernels; also from rows that were
+    normalised earlier (the image made from `what`)."""
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(n + K + D)
+    W = torch.randn(K, D, device=dev, generator=g)
+    W[5] = 0
+    regions = {"text": (0, K // 3), "graph": (K - K // 3, K), "shared": (0, K)}
+    what0, wsq0 = ops.rownorm(W)
+    what, wsq, prepared = ops.prepare_codebook(W, regions)
+    assert torch.equal(what, what0) and torch.equal(wsq, wsq0)
+    _, _, prepared2 = ops.prepare_codebook(None, regions, normalised=(what0, wsq0))
+    x = torch.randn(n, D, device=dev, generator=g)
+    for name, (lo, hi) in regions.items():
+        assert ops.takes_filter_path(n, hi - lo, D, topk, ops.PATH_F16_FILTER)
+        ref = ops.soft_vq_forward(x, what[lo:hi], wsq[lo:hi].contiguous(), topk, ops.PATH_F16_FILTER, want_sqerr=False)
+        for prep in (prepared, prepared2):
+            assert torch.equal(prep[name]["wsqp"], prepared[name]["wsqp"]) and torch.equal(prep[name]["en_max"], prepared[name]["en_max"])
+            got = ops.soft_vq_forward(x, what[lo:hi], wsq[lo:hi].contiguous(), topk, ops.PATH_F16_FILTER, want_sqerr=False, prepared=prep[name])
+            for k in ("xhat", "idx", "dist", "w", "zq"):
+                assert torch.equal(got[k], ref[k]), (name, k)
+        exact = ops.soft_vq_forward(x, what[lo:hi], wsq[lo:hi].contiguous(), topk, ops.PATH_F32_MFMA, want_sqerr=False, prepared=prepared[name])
+        assert torch.equal(exact["idx"], ref["idx"]) and torch.equal(exact["dist"], ref["dist"])       # (the exact path ignores `prepared`)
+    with pytest.raises(ValueError):
+        ops.soft_vq_forward(x, what[: K // 3], wsq[: K // 3].contiguous(), topk, ops.PATH_F16_FILTER, want_sqerr=False, prepared=prepared["shared"])
+
+
+def test_forward_with_and_without_a_prepared_codebook(dev, monkeypatch):
+    """VectorQuantizer.forward (eval) at a size whose searches take the fp16 shortlist: PREPARED_CODEBOOK on / off, the same bits; the
+    cache entry made by a caller without use for the image (a small search) is upgraded, and a weight update invalidates it."""
+    import medtok_amd.vector_quantization_soft_one_new as vqmod
+    from medtok_amd import ops
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    torch.manual_seed(11)
+    dim, bsz = 128, 6000
+    vq = VectorQuantizer(3 * 2048, dim, 0.25, 0.0, True, False, [dim, dim], k=5).to(dev).eval()
+    vq.search_path = ops.PATH_F16_FILTER
+    g = torch.Generator(device=dev).manual_seed(2)
+    h = torch.randn(bsz, 2 * dim, device=dev, generator=g)
+    text = torch.randn(bsz, 6, dim, device=dev, generator=g)
+    mask = torch.ones(bsz, 6, dtype=torch.int64, device=dev)
+    n_nodes = torch.randint(1, 4, (bsz,), device=dev, generator=g)
+    batch = torch.repeat_interleave(torch.arange(bsz, device=dev), n_nodes)
+    nodes = torch.randn(int(n_nodes.sum()), dim, device=dev, generator=g)
+    keys = ("shared_text_embedding", "shared_graph_embedding", "specific_embedding_text", "specific_embedding_graph", "text_tokens", "graph_tokens",
+            "shared_text_tokens", "shared_graph_tokens", "text_tokens_weights", "shared_graph_tokens_weights")
+    with torch.no_grad():
+        monkeypatch.setattr(vqmod, "PREPARED_CODEBOOK", False)
+        ref = vq(h, text, nodes, mask, batch)
+        assert getattr(vq._norm_cache[1], "prepared", None) is None
+        monkeypatch.setattr(vqmod, "PREPARED_CODEBOOK", True)
+        got = vq(h, text, nodes, mask, batch)                       # upgrades the entry the first forward left
+        assert vq._norm_cache[1].prepared is not None
+        for k in keys:
+            assert torch.equal(got[k], ref[k]), k
+        vq.invalidate_codebook_cache()
+        got = vq(h, text, nodes, mask, batch)                       # built in one go
+        for k in keys:
+            assert torch.equal(got[k], ref[k]), k
+        with torch.no_grad():
+            vq.codebook.weight.mul_(-1.0)                             # a new weight version: nothing stale may be read
+        new = vq(h, text, nodes, mask, batch)
+        monkeypatch.setattr(vqmod, "PREPARED_CODEBOOK", False)
+        vq.invalidate_codebook_cache()
+        new_ref = vq(h, text, nodes, mask, batch)
+        for k in keys:
+            assert torch.equal(new[k], new_ref[k]), k
+        assert not torch.equal(new["text_tokens"], ref["text_tokens"])
