@@ -2319,14 +2319,22 @@ static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int ld
     // tile height: 256 features, or 192 where that pads the group's features by > 10 % less (n_g = 192: the per-head W_v product)
     const long pad4 = (long)((n_g + 255) / 256) * 256, pad3 = (long)((n_g + 191) / 192) * 192;
     const bool mt3 = pad3 * 10 < pad4 * 9;
-    const int bm = mt3 ? 192 : 256;
-    p.row_tiles = (int)((m + G_BN - 1) / G_BN); p.ftiles = (n_g + bm - 1) / bm;
-    const long ids = (long)((p.row_tiles + 7) / 8) * 8 * p.ftiles * groups;
+    p.row_tiles = (int)((m + G_BN - 1) / G_BN);
+    const long row_ids = (long)((p.row_tiles + 7) / 8) * 8;
+    // ... or fewer where the 256-feature tiles would leave most of the chip without a block (a product of a few thousand rows: the
+    // text side of a forward, the node side of a training batch): 128 or 64 features per tile double / quadruple the blocks at the
+    // same bytes per block-stage of the activation tile -- a launch of that size is latency, not throughput
+    int mt = mt3 ? 3 : 4;
+    const long half_chip = dev_info().cus / 2;
+    if (!mt3 && row_ids * ((n_g + 255) / 256) * groups < half_chip) mt = row_ids * ((n_g + 127) / 128) * groups < half_chip ? 1 : 2;
+    const int bm = 64 * mt;
+    p.ftiles = (n_g + bm - 1) / bm;
+    const long ids = row_ids * p.ftiles * groups;
     if (ids >= (1ll << 31)) return fail("split_gemm: grid too large");
     // persistent: one block per CU (a multiple of 8: the XCD round-robin; never fewer than 8 -- a CU-masked or partitioned device
     // with < 8 CUs still gets a valid launch, its blocks just share CUs)
     const long blocks = lmin(ids, lmax(8, (long)(dev_info().cus / 8) * 8));
-    const size_t lds = mt3 ? GemmShape<3>::LDS_BYTES : GemmShape<4>::LDS_BYTES;
+    const size_t lds = mt == 3 ? GemmShape<3>::LDS_BYTES : mt == 4 ? GemmShape<4>::LDS_BYTES : mt == 2 ? GemmShape<2>::LDS_BYTES : GemmShape<1>::LDS_BYTES;
     hipEvent_t pa = nullptr;
 #define MEDTOK_GEMM_LAUNCH(...)                                                                                                   \
     do {                                                                                                                          \
@@ -2334,9 +2342,15 @@ static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int ld
         pa = g_prof_on ? prof_mark((hipStream_t)stream) : nullptr;                                                                \
         hipLaunchKernelGGL((split_gemm_kernel<__VA_ARGS__>), dim3((unsigned)blocks), dim3(G_THREADS), lds, (hipStream_t)stream, p); \
     } while (0)
-    if (one_pass == 0) { if (mt3) MEDTOK_GEMM_LAUNCH(3); else MEDTOK_GEMM_LAUNCH(4); }
-    else if (one_pass == 1) { if (mt3) MEDTOK_GEMM_LAUNCH(3, true, false); else MEDTOK_GEMM_LAUNCH(4, true, false); }
-    else { if (mt3) MEDTOK_GEMM_LAUNCH(3, true, true); else MEDTOK_GEMM_LAUNCH(4, true, true); }
+#define MEDTOK_GEMM_BY_MT(...)                                                                                                    \
+    do {                                                                                                                          \
+        if (mt == 3) MEDTOK_GEMM_LAUNCH(3 __VA_ARGS__); else if (mt == 4) MEDTOK_GEMM_LAUNCH(4 __VA_ARGS__);                      \
+        else if (mt == 2) MEDTOK_GEMM_LAUNCH(2 __VA_ARGS__); else MEDTOK_GEMM_LAUNCH(1 __VA_ARGS__);                              \
+    } while (0)
+    if (one_pass == 0) MEDTOK_GEMM_BY_MT();
+    else if (one_pass == 1) MEDTOK_GEMM_BY_MT(, true, false);
+    else MEDTOK_GEMM_BY_MT(, true, true);
+#undef MEDTOK_GEMM_BY_MT
 #undef MEDTOK_GEMM_LAUNCH
     if (pa) prof_push(pa, prof_mark((hipStream_t)stream), 2.0 * (double)m * (double)n_g * (double)k_g * (double)groups, 4);     // fp32-equivalent flops (x3 on the fp16 pipe)
     return check_launch("split_gemm");

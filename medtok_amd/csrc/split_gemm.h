@@ -147,7 +147,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
         a_off[q] = (unsigned)(r * p.lda + c * 8) * 2u;
         b_off[q] = (unsigned)(r * p.ldb + c * 8) * 2u;
     }
-    const bool w_second = wave_s + 8 < BM / 16;
+    const bool w_first = wave_s < BM / 16, w_second = wave_s + 8 < BM / 16;     // (MT = 1: the weight tile is four row blocks, waves 0-3)
     // descriptors start at the tile's first row / the group's first column; num_records = what is left of the image from there
     auto rsrc = [](const _Float16 *img, long base, long bytes) {
         const long left = bytes - base;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             char *dst = base + q * 8 * 16 * G_ROWB;
-            if (q == 0 || w_second) {
+            if (q == 0 ? w_first : w_second) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(bh_rs, (__attribute__((address_space(3))) void *)dst, 16, (int)b_off[q], uk, 0, 0);
                 if constexpr (!ONE)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(bl_rs, (__attribute__((address_space(3))) void *)(dst + WTILEB), 16, (int)b_off[q], uk, 0, 0);
