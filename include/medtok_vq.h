@@ -110,6 +110,10 @@ int medtok_half_gemm_f32(const void *a, int64_t m, int lda, int a_group_cols, co
  * (group_cols = 0: one group) -- the operands of medtok_half_gemm_f32, made without torch's strided copies. */
 int medtok_half_image_f32(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp, int transpose, int64_t group_cols, int bf16,
                           void *out, void *stream);
+/* both images of one matrix in one pass over it (a training-mode product needs its upstream gradient and its input both ways):
+ * out_plain = medtok_half_image_f32(transpose = 0, dp = dp_plain <= d rounded up to 64), out_t = medtok_half_image_f32(transpose = 1, dp = np, group_cols) */
+int medtok_half_image_pair_f32(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp_plain, int64_t np, int64_t group_cols,
+                               int bf16, void *out_plain, void *out_t, void *stream);
 
 /* Shader-clock probe for bench.py: one idle wavefront on each of 8 blocks (one per XCD on the full chip) samples the shader-cycle
  * counter and the constant 100 MHz counter from launch until *stop_flag (a word of PINNED HOST memory the device polls) becomes

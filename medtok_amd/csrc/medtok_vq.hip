@@ -2260,6 +2260,26 @@ extern "C" int medtok_half_image_f32(const float *src, int64_t n, int d, int64_t
     return check_launch("half_image(transposed)");
 }
 
+// both images of one matrix in one pass over it: out_plain [n, dp_plain] (zero columns past d; dp_plain <= d rounded up to 64) and
+// out_t = the transposed image of medtok_half_image_f32(transpose = 1, dp = np, group_cols)
+extern "C" int medtok_half_image_pair_f32(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp_plain, int64_t np, int64_t group_cols,
+                                          int bf16, void *out_plain, void *out_t, void *stream)
+{
+    if (n <= 0 || d <= 0 || (d & 3) || (np & 7) || (dp_plain & 7) || src_stride < d || (src_stride & 3) || np < n || dp_plain < d || dp_plain > (d + 63) / 64 * 64)
+        return fail("half_image_pair: bad shape n=%ld d=%d stride=%ld dp_plain=%ld np=%ld", (long)n, d, (long)src_stride, (long)dp_plain, (long)np);
+    if (group_cols == 0) group_cols = np;
+    if (group_cols <= 0 || np % group_cols || (group_cols != np && group_cols % 64)) return fail("half_image_pair: group_cols=%ld must divide np=%ld and be a multiple of 64", (long)group_cols, (long)np);
+    if (!src || !out_plain || !out_t) return fail("half_image_pair: NULL argument");
+    if (((uintptr_t)src | (uintptr_t)out_plain | (uintptr_t)out_t) & 15) return fail("half_image_pair: pointers must be 16-byte aligned");
+    const long row_tiles = (np + 63) / 64;
+    if (row_tiles >= (1ll << 31) || (d + 63) / 64 > 65535) return fail("half_image_pair: too large");
+    const dim3 grid((unsigned)row_tiles, (unsigned)((d + 63) / 64));
+    hipStream_t s = (hipStream_t)stream;
+    if (bf16) hipLaunchKernelGGL(half_image_t_kernel<true>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (long)np, (long)group_cols, (unsigned short *)out_t, (unsigned short *)out_plain, (int)dp_plain);
+    else hipLaunchKernelGGL(half_image_t_kernel<false>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (long)np, (long)group_cols, (unsigned short *)out_t, (unsigned short *)out_plain, (int)dp_plain);
+    return check_launch("half_image_pair");
+}
+
 static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols,
                            const void *b_hi, const void *b_lo, int64_t b_rows, int ldb, int b_group_rows,
                            int n_g, int k_g, int groups, const float *bias, float unscale, const float *amax_a, const float *amax_b,

@@ -547,20 +547,29 @@ __global__ __launch_bounds__(256) void half_image_kernel(const float *__restrict
     }
 }
 
+// plain (optional): the row-major image [n, plain_dp] of the same matrix (half_image_kernel's output) from the same pass -- a
+// training-mode product needs both images of its upstream gradient and of its input (medtok_half_image_pair_f32).
 template <bool BF>
 __global__ __launch_bounds__(256) void half_image_t_kernel(const float *__restrict__ src, long n, int d, long src_stride, long np, long group_cols,
-                                                           unsigned short *__restrict__ out)
+                                                           unsigned short *__restrict__ out, unsigned short *__restrict__ plain = nullptr, int plain_dp = 0)
 {
     __shared__ float tile[64][65];
     const long r0 = (long)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
     const int t = threadIdx.x;
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (t >> 4) + 16 * i, c = (t & 15) * 4;
         g_f4 v = (g_f4){0.f, 0.f, 0.f, 0.f};
         if (r0 + r < n && c0 + c < d) v = *reinterpret_cast<const g_f4 *>(src + (r0 + r) * src_stride + c0 + c);
         tile[r][c] = v[0]; tile[r][c + 1] = v[1]; tile[r][c + 2] = v[2]; tile[r][c + 3] = v[3];
+        if (plain && r0 + r < n && c0 + c < plain_dp) {
+            u16x4 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = half_bits<BF>(v[j]);
+            *reinterpret_cast<u16x4 *>(plain + (r0 + r) * plain_dp + c0 + c) = h;
+        }
     }
     __syncthreads();
     const int c = t >> 2, rs = (t & 3) * 16;

@@ -92,6 +92,9 @@ BATCHED_SMALL_SEARCHES = True
 # is made ONCE per weight version, for all three regions together with the normalisation (ops.prepare_codebook: two launches),
 # instead of three passes over its region in each of a forward's three to five searches
 PREPARED_CODEBOOK = True
+# training under autocast: the row-major and the transposed 16-bit image of a product's input / upstream gradient from ONE pass over it
+# (ops.half_image_pair) instead of two
+FUSE_IMAGE_PAIRS = True
 from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
@@ -278,32 +281,50 @@ class _SplitLinearFunction(torch.autograd.Function):
         xf = x.detach().float()
         xf = xf if xf.stride(1) == 1 and xf.stride(0) % 4 == 0 and xf.data_ptr() % 16 == 0 else xf.contiguous()
         w16, wt16 = _SplitLinearFunction._half_images(w, dt, kp, npad)
-        y = ops.half_gemm(ops.half_image(xf, kp, dt), w16, n_g=n, k_g=kp, bias=None if b is None else b.detach().float().contiguous())
-        ctx.save_for_backward(xf, wt16)
+        # the weight gradient contracts over the rows: it reads x TRANSPOSED (split over the rows into `groups` chunks: see backward);
+        # that image comes out of the same pass over x as the forward's operand, and is what the backward keeps of x
+        groups, chunk, mp = _SplitLinearFunction._row_split(m, n, k)
+        if ctx.needs_input_grad[1]:
+            x16, xt16 = (ops.half_image_pair(xf, kp, mp, dt, group_cols=chunk) if FUSE_IMAGE_PAIRS else
+                         (ops.half_image(xf, kp, dt), ops.half_image(xf, mp, dt, transpose=True, group_cols=chunk)))
+        else:
+            x16, xt16 = ops.half_image(xf, kp, dt), None
+        y = ops.half_gemm(x16, w16, n_g=n, k_g=kp, bias=None if b is None else b.detach().float().contiguous())
+        ctx.save_for_backward(xt16, wt16)
         ctx.shape = (m, k, n)
         ctx.half = dt
         ctx.dtypes = (x.dtype, w.dtype, None if b is None else b.dtype)
         return y
 
     @staticmethod
+    def _row_split(m, n, k):
+        """split-K of the weight-gradient product: (groups, rows per group (a multiple of 64), padded row count)"""
+        tiles = ((n + 255) // 256) * ((k + 255) // 256)
+        groups = max(1, min(256 // max(tiles, 1), m // 2048))
+        chunk = (-(-m // groups) + 63) // 64 * 64
+        groups = -(-m // chunk)
+        return groups, chunk, groups * chunk
+
+    @staticmethod
     def _backward_half(ctx, dy):
-        xf, wt16 = ctx.saved_tensors
+        xt16, wt16 = ctx.saved_tensors
         dxt, dwt, dbt = ctx.dtypes
         m, k, n = ctx.shape
         dt = ctx.half
         npad = wt16.shape[1]
         dyf = dy.detach().float().contiguous()
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:          # dX [m, k] = dY [m, n] . (W^T [k, n])^T
-            dx = ops.half_gemm(ops.half_image(dyf, npad, dt), wt16, n_g=k, k_g=npad).to(dxt)
-        if ctx.needs_input_grad[1]:          # dW [n, k] = dY^T [n, m] . (X^T [k, m])^T, split over the rows in one grouped launch
-            tiles = ((n + 255) // 256) * ((k + 255) // 256)
-            groups = max(1, min(256 // max(tiles, 1), m // 2048))
-            chunk = (-(-m // groups) + 63) // 64 * 64
-            groups = -(-m // chunk)
-            mp = groups * chunk
-            dw = ops.half_gemm(ops.half_image(dyf, mp, dt, transpose=True), ops.half_image(xf, mp, dt, transpose=True, group_cols=chunk),
-                               n_g=k, k_g=chunk, groups=groups, a_group_cols=chunk, b_group_rows=k)
+        groups, chunk, mp = _SplitLinearFunction._row_split(m, n, k)
+        want_dx, want_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and xt16 is not None
+        if want_dx and want_dw and FUSE_IMAGE_PAIRS:              # both images of dY from one pass over it
+            dy16, dyt16 = ops.half_image_pair(dyf, npad, mp, dt)
+        else:
+            dy16 = ops.half_image(dyf, npad, dt) if want_dx else None
+            dyt16 = ops.half_image(dyf, mp, dt, transpose=True) if want_dw else None
+        if want_dx:                          # dX [m, k] = dY [m, n] . (W^T [k, n])^T
+            dx = ops.half_gemm(dy16, wt16, n_g=k, k_g=npad).to(dxt)
+        if want_dw:                          # dW [n, k] = dY^T [n, m] . (X^T [k, m])^T, split over the rows in one grouped launch
+            dw = ops.half_gemm(dyt16, xt16, n_g=k, k_g=chunk, groups=groups, a_group_cols=chunk, b_group_rows=k)
             dw = (dw.view(n, groups, k).sum(1) if groups > 1 else dw).to(dwt)
         if dbt is not None and ctx.needs_input_grad[2]:
             db = dyf.sum(0).to(dbt)
