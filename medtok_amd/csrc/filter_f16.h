@@ -13,9 +13,12 @@
 // is rounded with relative error <= 2^-11 (elements below 2^-22 may flush: absolute error <= 2^-22
 // each), so |sum x~e~ - sum xe| <= (2^-10 + 2^-22) sum|x_i e_i| + flush <= (2^-10 + 2^-22)|x||e| + flush.
 // Products of two fp16 are exact in fp32; for the MFMA's fp32 accumulation and for the exact chain's
-// own rounding we budget D * 2^-21 relative (a 1-ulp-per-add model is D * 2^-24; measured on MI355X in
-// tests/test_gpu_filter.py::test_filter_score_error_bound: <= 0.04 of the budget), hence
-//   |s~ - s| <= gamma * sqrt(xsq * wsq_max),   gamma = 2^-10 + 2^-20 + D * 2^-21
+// own rounding we budget D * 2^-22 relative: D additions that each round to nearest err by D * 2^-24, D additions that each
+// TRUNCATE by D * 2^-23; both sums together (the MFMA's under the worse model, the exact chain's under its own) are 3 D 2^-24, the
+// budget is 4 D 2^-24 (rounds 1-4 carried twice that; measured on MI355X in
+// tests/test_gpu_filter.py::test_filter_score_error_bound: a small fraction of the budget: the matrix pipe sums the 16 products
+// of an instruction before it rounds), hence
+//   |s~ - s| <= gamma * sqrt(xsq * wsq_max),   gamma = 2^-10 + 2^-20 + D * 2^-22
 //   |d~ - d| <= eps := 2 gamma sqrt(xsq wsq_max) + slack       (slack: flush + 4 ulp of d)
 // Shortlist rule.  Let t~ be the k-th smallest d~ of a row.  k codes have d <= t~ + eps, so the exact
 // k-th smallest d is <= t~ + eps, so every exact top-k member has d~ <= t~ + 2 eps.  Keeping
@@ -58,7 +61,7 @@ constexpr float F_NORM_LIMIT = 4.0f;                          // |x|^2, |e|^2 ab
 constexpr int R_ROWS = 32;                                    // rows per re-score block (8 lanes each)
 constexpr int R_SURV = 64;                                    // survivors per row the re-score kernel can hold
 
-__host__ __device__ inline float filter_gamma(int d) { return 0x1p-10f + 0x1p-20f + (float)d * 0x1p-21f; }
+__host__ __device__ inline float filter_gamma(int d) { return 0x1p-10f + 0x1p-20f + (float)d * 0x1p-22f; }
 
 // eps = bound on |d~ - d| for a row with squared norm xn against codes with squared norm <= en_max
 __device__ __forceinline__ float filter_eps(float xn, float en_max, int d)
@@ -67,9 +70,9 @@ __device__ __forceinline__ float filter_eps(float xn, float en_max, int d)
     const float flush = 0x1p-21f * sqrtf((float)d) * sqrtf(fmaxf(xn, en_max));
     const float ulps = 0x1p-20f * (xn + en_max + 2.0f * mag);      // a handful of fp32 roundings of d-sized values
     // the accumulators start at -2^15 |e|^2 instead of 0: every one of the <= d + 63 additions of the chain rounds a value of
-    // magnitude <= 2^15 (|e|^2 + 2 mag), i.e. 2^-24 (|e|^2 + 2 mag) in d units; the 2 mag part is inside gamma's D 2^-21,
-    // the |e|^2 part is budgeted here with the same factor 8 over the one-ulp-per-addition model
-    const float start = (float)(d + 64) * 0x1p-21f * en_max;
+    // magnitude <= 2^15 (|e|^2 + 2 mag), i.e. 2^-24 (|e|^2 + 2 mag) in d units; the 2 mag part is inside gamma's D 2^-22,
+    // the |e|^2 part is budgeted here with the same factor 4 over the one-ulp-per-addition model (2 over truncating additions)
+    const float start = (float)(d + 64) * 0x1p-22f * en_max;
     return 2.0f * filter_gamma(d) * mag * 1.0001f + 2.0f * flush + ulps + start;
 }
 

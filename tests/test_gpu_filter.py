@@ -20,7 +20,7 @@ def both_paths(xh, xs, wh, ws, topk):
 
 def test_filter_score_error_bound(oracle, dev):
     """|s~ - s| must stay far inside the bound filter_eps() assumes (filter_f16.h): gamma*sqrt(xsq*wsq) for the fp16 rounding and the
-    accumulation, plus (D + 64) 2^-22 |e|^2 for accumulators that start at -2^15 |e|^2 -- on random and on worst-case-sign data.
+    accumulation, plus (D + 64) 2^-23 |e|^2 for accumulators that start at -2^15 |e|^2 -- on random and on worst-case-sign data.
     The scores are the ones the search itself tests: debug_filter_scores runs the production accumulation."""
     from medtok_amd import ops
     rng = np.random.default_rng(0)
@@ -34,16 +34,16 @@ def test_filter_score_error_bound(oracle, dev):
         xh, xs = oracle.rownorm(x); wh, ws = oracle.rownorm(W)
         s_ref = oracle.scores(xh, wh)
         s_apx = ops.debug_filter_scores(_t(xh, dev), _t(xs, dev), _t(wh, dev), _t(ws, dev)).cpu().numpy()
-        gamma = 2.0 ** -10 + 2.0 ** -20 + d * 2.0 ** -21
-        start = (d + 64) * 2.0 ** -22 * ws[None, :]
+        gamma = 2.0 ** -10 + 2.0 ** -20 + d * 2.0 ** -22
+        start = (d + 64) * 2.0 ** -23 * ws[None, :]
         bound = gamma * np.sqrt(xs[:, None] * ws[None, :]) + start
         ratio = np.abs(s_apx - s_ref) / bound
         assert ratio.max() < 0.6, (d, ratio.max())                   # rounding part alone can reach ~0.5 when aligned
-        # the accumulation budget (D * 2^-21) on its own: compare against fp64 dot of the ROUNDED operands
+        # the accumulation budget (D * 2^-22) on its own: compare against fp64 dot of the ROUNDED operands
         xr = (xh.astype(np.float16 if False else np.float32) * 256).astype(np.float16).astype(np.float64) / 256
         wr = (wh * 256).astype(np.float16).astype(np.float64) / 256
-        acc_err = np.abs(s_apx - xr @ wr.T) / (d * 2.0 ** -21 * (np.abs(xr) @ np.abs(wr).T) + start)
-        assert acc_err.max() < 0.25, (d, acc_err.max())
+        acc_err = np.abs(s_apx - xr @ wr.T) / (d * 2.0 ** -22 * (np.abs(xr) @ np.abs(wr).T) + start)
+        assert acc_err.max() < 0.25, (d, acc_err.max())     # (measured < 0.01: tools/r05/measure_filter_error.py)
 
 
 @pytest.mark.parametrize("n,k,d,topk", [

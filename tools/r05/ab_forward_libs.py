@@ -1,5 +1,5 @@
 """Dev tool (GPU box): bench workloads under variant builds of the library (tools/r05/build_mutants.py), one fresh process per build,
-alternated ROUNDS times.   python tools/r05/ab_forward_libs.py {full|cfg4vq|fullref} name [name ...]      ('shipped' = the product library)"""
+alternated ROUNDS times.   python tools/r05/ab_forward_libs.py {full|cfg3|cfg4vq|fullref} name [name ...]      ('shipped' = the product library)"""
 import json, os, subprocess, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[2]
@@ -13,13 +13,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     what = sys.argv[2]
     if what == "cfg4vq":
         wl = bench.Cfg4(256, dev, seed=0, path=0, precomputed=True)
+    elif what == "cfg3":
+        wl = bench.Cfg3(600000, dev, seed=0, path=0)
     elif what == "fullref":
         wl = bench.FullRefDefault(256, dev, seed=0, path=0)
     else:
         wl = bench.Full(4096, dev, seed=0, path=0)
     for _ in range(3): wl.step()
     torch.cuda.synchronize()
-    n = 10 if what != "fullref" else 100
+    n = 100 if what == "fullref" else 5 if what == "cfg3" else 10
     t0 = time.perf_counter()
     for _ in range(n): wl.step()
     torch.cuda.synchronize()
