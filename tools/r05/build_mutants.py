@@ -12,6 +12,8 @@ carry no build-time switch), into devlib/<name>/libmedtok_vq.so (git-ignored; tr
              stream of a 64-deep stage (half the barriers, bursts of eight copies per wave) on the 32-deep ring
   nobar      TIMING ONLY (wrong results): no stage barrier at all
   rr16, rr8  the re-score kernel with 16 / 8 rows per block instead of 32 (same results)
+  eps_emul   TIMING ESTIMATE (results right only because the actual errors are far inside): the window's operand-rounding term at 0.42 of
+             its worst case -- what a bound from measured rounding residuals would typically give
   eps21      the shortlist window with rounds 1-4's accumulation budget (D 2^-21 instead of D 2^-22; same results, more candidates)
   gemm_mt4   the dense products always on 256- (or 192-) feature tiles, as before the 128- / 64-feature tiles for small products (same results)
   n_noscan   TIMING ONLY (wrong results): filter_rows64n_kernel without its scans (MFMAs, copies, barriers and start-value reads only)
@@ -66,6 +68,8 @@ def mutate(name, src):
         rr = name[2:]
         h = sub(h, "hipLaunchKernelGGL((rescore_kernel<T, 32>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, MEDTOK_RESCORE_ARGS);",
                 f"hipLaunchKernelGGL((rescore_kernel<T, {rr}>), dim3((unsigned)((n + {rr} - 1) / {rr})), dim3(8 * {rr}), 0, s, MEDTOK_RESCORE_ARGS);")
+    elif name == "eps_emul":
+        t = sub(t, "return 0x1p-10f + 0x1p-20f + (float)d * 0x1p-22f; }", "return 0.42f * 0x1p-10f + 0x1p-20f + (float)d * 0x1p-22f; }")
     elif name == "eps21":
         t = sub(t, "return 0x1p-10f + 0x1p-20f + (float)d * 0x1p-22f; }", "return 0x1p-10f + 0x1p-20f + (float)d * 0x1p-21f; }")
         t = sub(t, "const float start = (float)(d + 64) * 0x1p-22f * en_max;", "const float start = (float)(d + 64) * 0x1p-21f * en_max;")
