@@ -1596,6 +1596,7 @@ __global__ __launch_bounds__(8 * RR) void rescore_kernel(
 // with lane = owner, four entry indices in flight at a time; the lines of the survivors' code rows are all requested before the
 // first chain starts.  Same candidates, same exact chains, same (d, index) selection and fused assignment as
 // rescore_kernel: the same bits.  own_total, own_tail <= 64.
+constexpr int RW_XMAX = 1032;                                // widest row whose x the wave keeps in LDS (the library's widest: 1028)
 template <int TOPK>
 __global__ __launch_bounds__(256) void rescore_wave_kernel(
     const uint2 *__restrict__ cand, const int *__restrict__ cand_cnt, int own_total,
@@ -1606,6 +1607,7 @@ __global__ __launch_bounds__(256) void rescore_wave_kernel(
     const float *__restrict__ xref, float *__restrict__ w_out, float *zq_out, long zq_stride)
 {
     __shared__ int s_code[4][R_SURV];
+    __shared__ __attribute__((aligned(16))) float s_x[4][RW_XMAX];      // the wave's x row (the chains' common operand), d <= RW_XMAX
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long row = (long)blockIdx.x * 4 + wv;
     if (row >= n) return;                              // (no block-wide barrier below: a wave works alone)
@@ -1690,12 +1692,34 @@ __global__ __launch_bounds__(256) void rescore_wave_kernel(
     int bi[TOPK];
 #pragma unroll
     for (int j = 0; j < TOPK; ++j) { bv[j] = INFINITY; bi[j] = 0x7fffffff; }
+    // the x row into the wave's LDS slice: every chain reads it (a broadcast per step), so the chain's global loads are the code
+    // row's alone -- 64 elements of it per step in the registers the 32 + 32 form used (a chain is as many dependent L2 round
+    // trips as it has steps: 24 -> 12 at d = 768)
+    const bool x_lds = d <= RW_XMAX;
+    if (x_lds) {
+        for (int i = lane * 4; i < d; i += 256) *reinterpret_cast<float4 *>(&s_x[wv][i]) = ld4(xhat + row * d + i);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
     if (lane < nsurv) {
         const int code = s_code[wv][lane];
         const float *xr = xhat + row * d;
         const float *wr = what + (long)code * d;
         float accv = 0.f;
         int i = 0;
+        if (x_lds) {
+            const float *xs = s_x[wv];
+            for (; i + 64 <= d; i += 64) {
+                float4 wq[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) wq[j] = ld4(wr + i + 4 * j);
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) {
+                    const float4 xa = *reinterpret_cast<const float4 *>(xs + i + 4 * j), xb = *reinterpret_cast<const float4 *>(xs + i + 4 * j + 4);
+                    R_CHAIN8(xa, xb, wq[j], wq[j + 1]);
+                }
+            }
+        }
         for (; i + 32 <= d; i += 32) {                 // a whole 128-byte line of both rows per step, 16 loads in flight
             const float4 x0 = ld4(xr + i), x1 = ld4(xr + i + 4), x2 = ld4(xr + i + 8), x3 = ld4(xr + i + 12);
             const float4 x4 = ld4(xr + i + 16), x5 = ld4(xr + i + 20), x6 = ld4(xr + i + 24), x7 = ld4(xr + i + 28);

@@ -12,6 +12,8 @@ carry no build-time switch), into devlib/<name>/libmedtok_vq.so (git-ignored; tr
              stream of a 64-deep stage (half the barriers, bursts of eight copies per wave) on the 32-deep ring
   nobar      TIMING ONLY (wrong results): no stage barrier at all
   rr16, rr8  the re-score kernel with 16 / 8 rows per block instead of 32 (same results)
+  rw_128     the few-rows re-score with 128 elements of the code row per chain step instead of 64 (same results)
+  rw_nolds   the few-rows re-score with its chains reading the x row from global memory, 32 elements of both rows per step (same results)
   eps_emul   TIMING ESTIMATE (results right only because the actual errors are far inside): the window's operand-rounding term at 0.42 of
              its worst case -- what a bound from measured rounding residuals would typically give
   eps21      the shortlist window with rounds 1-4's accumulation budget (D 2^-21 instead of D 2^-22; same results, more candidates)
@@ -68,6 +70,12 @@ def mutate(name, src):
         rr = name[2:]
         h = sub(h, "hipLaunchKernelGGL((rescore_kernel<T, 32>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, MEDTOK_RESCORE_ARGS);",
                 f"hipLaunchKernelGGL((rescore_kernel<T, {rr}>), dim3((unsigned)((n + {rr} - 1) / {rr})), dim3(8 * {rr}), 0, s, MEDTOK_RESCORE_ARGS);")
+    elif name == "rw_128":
+        t = sub(t, "            for (; i + 64 <= d; i += 64) {\n                float4 wq[16];", "            for (; i + 128 <= d; i += 128) {\n                float4 wq[32];")
+        t = sub(t, "                for (int j = 0; j < 16; ++j) wq[j] = ld4(wr + i + 4 * j);", "                for (int j = 0; j < 32; ++j) wq[j] = ld4(wr + i + 4 * j);")
+        t = sub(t, "                for (int j = 0; j < 16; j += 2) {\n                    const float4 xa = *reinterpret_cast<const float4 *>(xs + i + 4 * j)", "                for (int j = 0; j < 32; j += 2) {\n                    const float4 xa = *reinterpret_cast<const float4 *>(xs + i + 4 * j)")
+    elif name == "rw_nolds":
+        t = sub(t, "    const bool x_lds = d <= RW_XMAX;", "    const bool x_lds = false;")
     elif name == "eps_emul":
         t = sub(t, "return 0x1p-10f + 0x1p-20f + (float)d * 0x1p-22f; }", "return 0.42f * 0x1p-10f + 0x1p-20f + (float)d * 0x1p-22f; }")
     elif name == "eps21":
