@@ -312,6 +312,54 @@ def fuzz_multi_search(cases=100, seed=0, budget_s=None, log=None):
     return c + 1, bad
 
 
+def fuzz_prepared(cases=100, seed=0, budget_s=None, log=None):
+    """Random codebooks prepared once (ops.prepare_codebook: random overlapping regions, widths the image pads, from raw rows and from
+    rows normalised earlier) and random one-call forwards on them -- both filter kernels, the few-rows and the block re-score, zero
+    rows, near-copies of codes -- against the same forwards without the prepared arguments: every output bit for bit."""
+    from medtok_amd import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    over, elapsed = _timer(budget_s)
+    bad, c = [], 0
+    for c in range(cases):
+        if over():
+            break
+        d = int(rng.choice([4, 36, 64, 64, 100, 128, 768]))
+        topk = int(rng.choice([1, 2, 5, 5, 8]))
+        n_e = int(rng.choice([600, 3000, 7001, 21000])) if d <= 128 else int(rng.choice([600, 3000, 6144]))
+        g = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
+        W = torch.randn(n_e, d, device=dev, generator=g)
+        if c % 4 == 1:
+            W[n_e // 2:] = W[: n_e - n_e // 2] + 1e-3 * torch.randn(n_e - n_e // 2, d, device=dev, generator=g)
+        if c % 5 == 2:
+            W[3] = 0
+        regions = {}
+        for name in ("a", "b", "c")[: int(rng.integers(1, 4))]:
+            lo = int(rng.integers(0, n_e - max(topk, 8)))
+            regions[name] = (lo, int(rng.integers(lo + max(topk, 8), n_e + 1)))
+        regions["all"] = (0, n_e)
+        if c % 2:
+            what, wsq = ops.rownorm(W)
+            _, _, prepared = ops.prepare_codebook(None, regions, normalised=(what, wsq))
+        else:
+            what, wsq, prepared = ops.prepare_codebook(W, regions)
+        for name, (lo, hi) in regions.items():
+            n = int(rng.choice([1, 130, 4097, 20000, 70001]))
+            x = torch.randn(n, d, device=dev, generator=g)
+            if c % 3 == 0:
+                x[::5] = 0
+            out = torch.empty(n, 2 * d, device=dev)[:, :d] if (c % 2 and d % 4 == 0) else None
+            kw = dict(want_sqerr=False)
+            ref = ops.soft_vq_forward(x, what[lo:hi], wsq[lo:hi].contiguous(), topk, ops.PATH_F16_FILTER, **kw)
+            got = ops.soft_vq_forward(x, what[lo:hi], wsq[lo:hi].contiguous(), topk, ops.PATH_F16_FILTER, out=out, prepared=prepared[name], **kw)
+            diff = [key for key in ("xhat", "idx", "dist", "w", "zq") if not torch.equal(ref[key], got[key])]
+            if diff:
+                bad.append(f"prepared case {c} region {name}=[{lo},{hi}): n={n} K={hi - lo} d={d} k={topk} differs in {diff}")
+                if log:
+                    log(bad[-1])
+    return c + 1, bad
+
+
 def _same_outputs(a, b):
     bad = []
     for k in a:

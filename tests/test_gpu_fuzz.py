@@ -52,3 +52,9 @@ def test_fuzz_batched_searches_equal_the_single_calls(dev):
     import fuzzers
     ran, bad = fuzzers.fuzz_multi_search(cases=400, seed=20256, budget_s=30)
     _report("fuzz_multi_search", ran, bad, 15)
+
+
+def test_fuzz_prepared_codebook_equals_unprepared_searches(dev):
+    import fuzzers
+    ran, bad = fuzzers.fuzz_prepared(cases=300, seed=20257, budget_s=30)
+    _report("fuzz_prepared", ran, bad, 10)
