@@ -12,6 +12,7 @@ carry no build-time switch), into devlib/<name>/libmedtok_vq.so (git-ignored; tr
              stream of a 64-deep stage (half the barriers, bursts of eight copies per wave) on the 32-deep ring
   nobar      TIMING ONLY (wrong results): no stage barrier at all
   rr16, rr8  the re-score kernel with 16 / 8 rows per block instead of 32 (same results)
+  ms_pb1, ms_pb4   the batched small searches with about one / four code tiles per block instead of two (same results)
   rw_128     the few-rows re-score with 128 elements of the code row per chain step instead of 64 (same results)
   rw_nolds   the few-rows re-score with its chains reading the x row from global memory, 32 elements of both rows per step (same results)
   eps_emul   TIMING ESTIMATE (results right only because the actual errors are far inside): the window's operand-rounding term at 0.42 of
@@ -70,6 +71,9 @@ def mutate(name, src):
         rr = name[2:]
         h = sub(h, "hipLaunchKernelGGL((rescore_kernel<T, 32>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, MEDTOK_RESCORE_ARGS);",
                 f"hipLaunchKernelGGL((rescore_kernel<T, {rr}>), dim3((unsigned)((n + {rr} - 1) / {rr})), dim3(8 * {rr}), 0, s, MEDTOK_RESCORE_ARGS);")
+    elif name in ("ms_pb1", "ms_pb4"):
+        f_ = {"ms_pb1": "4L", "ms_pb4": "1L"}[name]
+        h = sub(h, "const long per_block = lmax(1, (tiles_total + 2L * di.cus - 1) / (2L * di.cus));", f"const long per_block = lmax(1, (tiles_total + {f_} * di.cus - 1) / ({f_} * di.cus));")
     elif name == "rw_128":
         t = sub(t, "            for (; i + 64 <= d; i += 64) {\n                float4 wq[16];", "            for (; i + 128 <= d; i += 128) {\n                float4 wq[32];")
         t = sub(t, "                for (int j = 0; j < 16; ++j) wq[j] = ld4(wr + i + 4 * j);", "                for (int j = 0; j < 32; ++j) wq[j] = ld4(wr + i + 4 * j);")
