@@ -97,6 +97,10 @@ int medtok_soft_vq_forward_multi_f32(const medtok_search_desc *descs, int count,
 size_t medtok_usage_multi_workspace_bytes(int64_t window_len, int64_t n_codes, int count);
 int medtok_usage_update_multi(float *window, int64_t window_len, const int64_t *const *ids, const int64_t *m, int count, int64_t n_codes,
                               int32_t *counts_out, void *ws, size_t ws_bytes, void *stream);
+/* the same with a device word copied behind the counts (counts_out [count + 1]; extra_word NULL: as above): the caller's one host read
+ * of the usage counts then also brings e.g. the cross-attention's status word */
+int medtok_usage_update_multi_word(float *window, int64_t window_len, const int64_t *const *ids, const int64_t *m, int count, int64_t n_codes,
+                                   int32_t *counts_out, const int32_t *extra_word, void *ws, size_t ws_bytes, void *stream);
 
 /* C = unscale * (A . B^T) + bias as ONE half-precision pass with fp32 accumulation: what torch.autocast makes of nn.Linear and of
  * nn.MultiheadAttention's projections (train_MedTok.py:212,394 -> vector_quantization_soft_one_new.py:30,45,106-107).  a [m, lda] and

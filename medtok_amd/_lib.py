@@ -56,6 +56,7 @@ SIGNATURES = {
     "medtok_soft_vq_forward_multi_f32": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp]),
     "medtok_usage_multi_workspace_bytes": (_sz, [_i64, _i64, _int]),
     "medtok_usage_update_multi": (_int, [_vp, _i64, _vp, _vp, _int, _i64, _vp, _vp, _sz, _vp]),
+    "medtok_usage_update_multi_word": (_int, [_vp, _i64, _vp, _vp, _int, _i64, _vp, _vp, _vp, _sz, _vp]),
     "medtok_debug_clock_probe": (_int, [_vp, C.c_uint64, _vp, _vp]),
     "medtok_rownorm_f32": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
     "medtok_search_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int]),

@@ -2923,8 +2923,11 @@ __global__ __launch_bounds__(256) void usage_multi_mark_kernel(const float *__re
 }
 
 __global__ __launch_bounds__(256) void usage_multi_finish_kernel(const float *__restrict__ tmp, long wlen, float *__restrict__ win,
-                                                                 const unsigned char *__restrict__ flags, long n_codes, int count, int *__restrict__ counts)
+                                                                 const unsigned char *__restrict__ flags, long n_codes, int count, int *__restrict__ counts,
+                                                                 const int *__restrict__ extra_word = nullptr)
 {
+    // (extra_word: a device word the caller wants behind the counts -- its one host read then fetches both)
+    if (extra_word && blockIdx.x == 0 && threadIdx.x == 0) counts[count] = extra_word[0];
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < wlen; i += (long)gridDim.x * 256) win[i] = tmp[i];
     const int lane = threadIdx.x & 63;
     for (int u = 0; u < count; ++u) {
@@ -2942,8 +2945,18 @@ extern "C" size_t medtok_usage_multi_workspace_bytes(int64_t window_len, int64_t
     return align_up((size_t)window_len * 4, 256) + align_up((size_t)count * ((size_t)n_codes + 1), 256);
 }
 
+extern "C" int medtok_usage_update_multi_word(float *window, int64_t window_len, const int64_t *const *ids, const int64_t *m, int count, int64_t n_codes,
+                                              int32_t *counts_out, const int32_t *extra_word, void *ws, size_t ws_bytes, void *stream);
 extern "C" int medtok_usage_update_multi(float *window, int64_t window_len, const int64_t *const *ids, const int64_t *m, int count, int64_t n_codes,
                                          int32_t *counts_out, void *ws, size_t ws_bytes, void *stream)
+{
+    return medtok_usage_update_multi_word(window, window_len, ids, m, count, n_codes, counts_out, nullptr, ws, ws_bytes, stream);
+}
+
+// ... with a device word copied behind the counts (counts_out [count + 1]): the caller's one host read of the usage counts also brings
+// e.g. the cross-attention's status word, without a concatenation launch
+extern "C" int medtok_usage_update_multi_word(float *window, int64_t window_len, const int64_t *const *ids, const int64_t *m, int count, int64_t n_codes,
+                                              int32_t *counts_out, const int32_t *extra_word, void *ws, size_t ws_bytes, void *stream)
 {
     if (window_len <= 0 || n_codes <= 0 || count < 1 || count > USAGE_MULTI_MAX || !ids || !m || !counts_out || !window)
         return fail("usage_update_multi: bad args (1..%d updates)", USAGE_MULTI_MAX);
@@ -2966,7 +2979,7 @@ extern "C" int medtok_usage_update_multi(float *window, int64_t window_len, cons
     const unsigned blocks = (unsigned)lmin(1024, (window_len + total + 255) / 256);
     hipLaunchKernelGGL(usage_multi_mark_kernel, dim3(blocks), dim3(256), 0, s, window, (long)window_len, a, (long)n_codes, tmp, flags);
     hipLaunchKernelGGL(usage_multi_finish_kernel, dim3((unsigned)lmin(256, (window_len + 255) / 256)), dim3(256), 0, s, tmp, (long)window_len, window, flags,
-                       (long)n_codes, count, counts_out);
+                       (long)n_codes, count, counts_out, (const int *)extra_word);
     return check_launch("usage_update_multi");
 }
 

@@ -836,9 +836,10 @@ def soft_vq_forward_multi(searches, topk: int):
     return outs
 
 
-def usage_update_multi_(window: torch.Tensor, ids_list, n_codes: int) -> torch.Tensor:
+def usage_update_multi_(window: torch.Tensor, ids_list, n_codes: int, extra_word=None) -> torch.Tensor:
     """usage_update_ for several id sets appended in order, in two launches: int32 [len(ids_list)] device tensor of the distinct-value
-    counts after each update (no host sync)."""
+    counts after each update (no host sync).  extra_word (int32 device tensor): its first element is copied behind the counts (the
+    result has one more entry), so that the caller's one host read brings it along."""
     import ctypes as C
     if not (window.is_cuda and window.dtype == torch.float32 and window.is_contiguous()):
         raise _lib.MedTokLibraryError("usage_update_multi_: window must be a contiguous fp32 device tensor")
@@ -849,11 +850,13 @@ def usage_update_multi_(window: torch.Tensor, ids_list, n_codes: int) -> torch.T
     ptrs = (C.c_void_p * count)(*[t.data_ptr() for t in ids])
     ms = (C.c_int64 * count)(*[t.numel() for t in ids])
     lib = _lib.load()
-    counts = torch.empty(count, dtype=torch.int32, device=window.device)
+    if extra_word is not None and not (extra_word.is_cuda and extra_word.dtype == torch.int32 and extra_word.device == window.device):
+        raise _lib.MedTokLibraryError("usage_update_multi_: extra_word must be an int32 tensor on the window's device")
+    counts = torch.empty(count + (extra_word is not None), dtype=torch.int32, device=window.device)
     ws = _ws(lib.medtok_usage_multi_workspace_bytes(window.numel(), n_codes, count), window)
     with _on(window.device):
-        _lib.check(lib.medtok_usage_update_multi(window.data_ptr(), window.numel(), ptrs, ms, count, n_codes, counts.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                 _stream(window)), "medtok_usage_update_multi")
+        _lib.check(lib.medtok_usage_update_multi_word(window.data_ptr(), window.numel(), ptrs, ms, count, n_codes, counts.data_ptr(), _ptr(extra_word),
+                                                      ws.data_ptr(), ws.numel(), _stream(window)), "medtok_usage_update_multi")
     return counts
 
 

@@ -1458,15 +1458,14 @@ class VectorQuantizer(nn.Module):
         zero = torch.tensor(0.0)
         u_shared = u_text = u_graph = 0.0
         if self.show_usage:
-            cnt = ops.usage_update_multi_(self.codebook_used, [idx_s.reshape(bsz, 2 * k)] + [r["idx"] for r in res[1:]], self.n_e)
             st = getattr(self.cross_attn, "small_status", None)
-            if st is not None and st.device == cnt.device:        # one read: the usage counts and the small-width path's status word
-                vals = torch.cat([cnt[:3], st[:1]]).cpu()
-                if int(vals[3]):
-                    self.cross_attn.check_status()
-            else:
-                vals = cnt[:3].cpu()
-            u_shared, u_text, u_graph = (vals[:3].double() / self.n_e).tolist()
+            st = st if st is not None and st.device == z.device else None
+            # one read: the usage counts and, behind them, the cross-attention's status word (copied there by the window kernel)
+            cnt = ops.usage_update_multi_(self.codebook_used, [idx_s.reshape(bsz, 2 * k)] + [r["idx"] for r in res[1:]], self.n_e, extra_word=st)
+            vals = cnt.cpu().tolist()
+            if st is not None and vals[-1]:
+                self.cross_attn.check_status()
+            u_shared, u_text, u_graph = (v / self.n_e for v in vals[:3])
         out = {
             "graph_feature": z_graph,
             "text_feature": z_text,
