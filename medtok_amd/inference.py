@@ -20,6 +20,7 @@ from .vector_quantization_soft_one_new import VectorQuantizer
 
 
 @torch.no_grad()
+@torch.no_grad()
 def quantize_pooled(vq: VectorQuantizer, h: torch.Tensor, pooled_text: torch.Tensor, pooled_graph: torch.Tensor):
     """The four searches of VectorQuantizer.forward for inputs whose cross-attention pooling
     is already done (BASELINE config 3): h [N, 2*e_dim] -> specific text/graph searches over
