@@ -932,7 +932,7 @@ class CrossAttention(nn.Module):
             if word & 2:
                 raise ValueError("pooled(): `batch` holds code ids outside [0, B)")
             if word & 4:
-                raise ValueError(f"pooled(): a code has more nodes than max_nodes_bound = {self.max_nodes_bound}; raise the bound, or set it to "
+                raise ValueError(f"pooled(): a code has more nodes than max_nodes_bound = {getattr(self, 'max_nodes_bound', None)}; raise the bound, or set it to "
                                  "None (one host read per call)")
             raise ValueError("pooled(): the paths without a host read (the two-launch small-width path; max_nodes_bound) need a non-decreasing "
                              "`batch` vector (PyG-style); sort the nodes by code, or set SMALL_WIDTH_FUSED = False / max_nodes_bound = None")
@@ -977,7 +977,7 @@ class CrossAttention(nn.Module):
             nodes, text = nodes.to(common), text.to(common)
         batch = batch.reshape(-1).to(torch.long)
         # counts / offsets / launch lists of all codes: three small launches (ops.pack_codes), nothing read back yet
-        bound = None if autograd or torch.is_grad_enabled() else self.max_nodes_bound
+        bound = None if autograd or torch.is_grad_enabled() else getattr(self, "max_nodes_bound", None)      # (a module pickled before the attribute existed)
         if bound is not None:
             bound = int(bound)
             if bound <= 0:
