@@ -61,6 +61,11 @@ def parse():
     ap.add_argument("--no-half-text-pass", action="store_true",
                     help="full workload: skip the extra pass with fp16 text features (what a caller under fp16 autocast hands over)")
     ap.add_argument("--no-clock-probe", action="store_true", help="do not run the shader-clock probe beside the timed region")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="default run (cfg3, 1 GPU): skip the short runs of the other workloads appended as extra.workloads")
+    ap.add_argument("--data", choices=["gaussian", "near_codes", "clustered_codebook", "heavy_tail"], default="gaussian",
+                    help="cfg3 / refdefault: the synthetic distribution (BASELINE prescribes i.i.d. Gaussian rows and codes; the others probe the "
+                         "shortlist's data-dependent cost: rows near codes, a codebook of near-copies, Student-t rows)")
     ap.add_argument("--no-one-stream-pass", action="store_true",
                     help="full workload: skip the second, one-stream pass that times the kernels for the roofline object (timeline captures)")
     return ap.parse_args()
@@ -100,9 +105,9 @@ class Cfg3:
     D, REGION, TOPK = 768, 16384, 5
     N_E = 3 * REGION
 
-    def __init__(self, rows, dev, seed, path):
+    def __init__(self, rows, dev, seed, path, data="gaussian"):
         from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
-        self.rows, self.dev = rows, dev
+        self.rows, self.dev, self.data = rows, dev, data
         D = self.D
         torch.manual_seed(1234)                                                   # same weights on every rank
         self.vq = VectorQuantizer(self.N_E, D, 0.25, 0.0, True, False, [D, D], k=self.TOPK).to(dev).eval()
@@ -111,8 +116,55 @@ class Cfg3:
         self.h = torch.randn(rows, 2 * D, device=dev, generator=g)              # [CLS text | pooled graph] (tokenizer.py:162-166)
         self.pooled_text = torch.randn(rows, D, device=dev, generator=g)        # cross-attention outputs (bypassed; stated)
         self.pooled_graph = torch.randn(rows, D, device=dev, generator=g)
-        self.description = (f"cfg3 full MedTok soft-VQ: {rows} codes/GPU x 4 searches (2 x K=16384 regions + 2 x K=49152 shared), "
-                            f"D=768, k=5, eval, fp32; proj Linear + normalise + search + softmax/mix/STE per code")
+        self.description = (f"{self.name} full MedTok soft-VQ: {rows} codes/GPU x 4 searches (2 x K={self.REGION} regions + 2 x K={self.N_E} shared), "
+                            f"D={D}, k={self.TOPK}, eval, fp32; proj Linear + normalise + search + softmax/mix/STE per code")
+        self.data_note = None
+        if data != "gaussian":
+            self._shape_data(data, g)
+
+    def _shape_data(self, data, g):
+        """Distributions off the i.i.d. Gaussian that BASELINE prescribes: the shortlist's cost depends on the data (how many codes a
+        row's window admits), a trained codebook is not i.i.d..  The modality-specific searches see their rows
+        through proj_text / proj_graph (a random Linear here), so the shaping applies to what reaches a search directly: the pooled
+        rows of the two shared searches, and the codebook itself."""
+        rows, D, dev = self.rows, self.D, self.dev
+        W = self.vq.codebook.weight
+        if data == "near_codes":
+            # x = w_hat[c] + sigma n, |sigma n| ~ 0.3: every row sits next to one code (what a trained quantiser sees)
+            what = torch.nn.functional.normalize(W.detach(), dim=-1)
+            for name in ("pooled_text", "pooled_graph"):
+                c = torch.randint(0, self.N_E, (rows,), device=dev, generator=g)
+                noise = torch.randn(rows, D, device=dev, generator=g) * (0.3 / D ** 0.5)
+                setattr(self, name, what[c] + noise)
+            self.data_note = "shared searches: rows = normalised code + noise of norm ~0.3; codebook and specific searches as gaussian"
+        elif data == "clustered_codebook":
+            # 512 clusters x (n_e / 512) near-copies (relative spread 1e-2): runs of near-identical codes fill a row's candidate lists
+            per = self.N_E // 512
+            centers = torch.randn(512, D, device=dev, generator=g)
+            Wc = centers.repeat_interleave(per, dim=0)
+            Wc = torch.cat([Wc, torch.randn(self.N_E - Wc.shape[0], D, device=dev, generator=g)]) if Wc.shape[0] < self.N_E else Wc
+            Wc = Wc + 1e-2 * torch.randn(self.N_E, D, device=dev, generator=g)
+            perm = torch.randperm(self.N_E, device=dev, generator=g)          # (cluster members spread over the code range)
+            with torch.no_grad():
+                W.copy_(Wc[perm])
+            self.vq.invalidate_codebook_cache()
+            for name in ("pooled_text", "pooled_graph"):                        # rows near cluster centres: the near-copies all compete
+                c = torch.randint(0, 512, (rows,), device=dev, generator=g)
+                setattr(self, name, centers[c] + 0.05 * torch.randn(rows, D, device=dev, generator=g))
+            self.data_note = (f"codebook = 512 clusters x {per} near-copies (spread 1e-2 per element), shuffled over the code range; shared-search rows = "
+                              "cluster centre + 0.05 noise per element")
+        elif data == "heavy_tail":
+            # Student-t (2 degrees of freedom) rows: a few huge coordinates dominate a row's direction
+            def student(n, d):
+                z = torch.randn(n, d, device=dev, generator=g)
+                chi = torch.randn(n, d, 2, device=dev, generator=g).pow(2).sum(-1) / 2.0
+                return z / chi.sqrt()
+            self.pooled_text, self.pooled_graph = student(rows, D), student(rows, D)
+            self.h = student(rows, 2 * D)
+            self.data_note = "all rows Student-t with 2 degrees of freedom (element-wise); codebook gaussian"
+        else:
+            raise ValueError(data)
+        self.description += f"; data = {data}: {self.data_note}"
 
     def flops_per_code(self):
         return 2.0 * self.D * (2 * self.REGION + 2 * self.N_E)
@@ -158,10 +210,11 @@ class RefDefault(Cfg3):
     D, REGION, TOPK = 64, 7000, 5
     N_E = 21000
 
-    def __init__(self, rows, dev, seed, path):
-        super().__init__(rows, dev, seed, path)
+    def __init__(self, rows, dev, seed, path, data="gaussian"):
+        super().__init__(rows, dev, seed, path, data)
         self.description = (f"refdefault: the four searches of the soft VQ at the reference's default shape: {rows} codes/GPU, e_dim = 64, "
-                            f"n_e = 21000 (2 x K=7000 regions + 2 x K=21000 shared), k=5, eval, fp32; proj Linear + normalise + search + softmax/mix/STE per code")
+                            f"n_e = 21000 (2 x K=7000 regions + 2 x K=21000 shared), k=5, eval, fp32; proj Linear + normalise + search + softmax/mix/STE per code"
+                            + (f"; data = {data}: {self.data_note}" if self.data_note else ""))
 
     def cpu_baseline(self, sample_rows):
         from oracle import torch_port as P
@@ -586,10 +639,24 @@ def pmc_traffic(workload, kernel, rows):
         val = rec.get(workload, {}).get(kernel)
         if val is None:
             return None, None
-        return val, (f"recorded, not measured in this run: profiles/pmc_traffic.json ({meta.get('taken', '?')}; rocprofv3 --pmc FETCH_SIZE x2 + "
-                     f"WRITE_SIZE per MI355X_MICROARCH.md; {workload} at {rows} rows/GPU)")
+        # the recorded figure is per DISPATCH; `launches_timed` / `avg_launch_ms` of the line count what the library brackets with one
+        # event pair -- for the shortlist kernel a whole search (main + tail dispatch at 600 000 rows): same unit here
+        per = meta.get("dispatches_per_timed_launch", {}).get(workload, {}).get(kernel, 1)
+        return val * per, (f"recorded, not measured in this run: profiles/pmc_traffic.json ({meta.get('taken', '?')}; rocprofv3 --pmc FETCH_SIZE x2 + "
+                           f"WRITE_SIZE per MI355X_MICROARCH.md; {workload} at {rows} rows/GPU); per timed launch = {per} dispatch(es) of {val / 1e9:.2f} GB")
     except Exception:
         return None, None
+
+
+def step_fabric_bytes(workload, rows):
+    """recorded fabric bytes of ALL kernels of one step (profiles/pmc_traffic.json `_meta.step_fabric_bytes`), or None"""
+    try:
+        meta = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get("_meta", {})
+        if meta.get("rows", {}).get(workload) != rows:
+            return None
+        return meta.get("step_fabric_bytes", {}).get(workload)
+    except Exception:
+        return None
 
 
 def issue_roofs(workload, kernel, rows, avg_launch_ms, clock_ghz):
@@ -620,6 +687,123 @@ def issue_roofs(workload, kernel, rows, avg_launch_ms, clock_ghz):
                            "well three to four waves per SIMD interleave their MFMA phase with each other's scan (DESIGN 6.0)"}
     except Exception:
         return None
+
+
+def kernel_roofline(wl, prof, steps):
+    """(kname, kp, view, f16x3, hbm_bound, prof): the roofline view of the dominant kernel = the library kernel with the most TIME in
+    `prof` (HIP events recorded by the library around its matrix-pipe launches over `steps` steps); its flops come from the library
+    where the launch knows them, from the workload where the ragged counts live on the device, and are null (no roofline fraction)
+    where neither does."""
+    prof = {k: dict(v) for k, v in prof.items()}
+    if hasattr(wl, "attention_flops"):
+        prof["shared_kv_attention_kernel"]["flops"] = wl.attention_flops * steps
+    if hasattr(wl, "attention_backward_flops"):
+        prof["shared_kv_attention_backward_kernels"]["flops"] = wl.attention_backward_flops() * steps
+    kname = max(prof, key=lambda k: prof[k]["ms"])
+    kp = prof[kname]
+    # the split kernels run a product as three fp16 MFMA passes: their algorithmic (fp32-equivalent) flops are priced against a
+    # third of the dense fp16 peak
+    f16x3 = kname == "split_gemm_kernel" or (kname == "shared_kv_attention_kernel" and getattr(wl, "attention_f16x3", False))
+    peak = F16_MFMA_PEAK_TFLOPS if kname == "filter_f16_kernel" else (F16_MFMA_PEAK_TFLOPS / 3.0 if f16x3 else FP32_MFMA_PEAK_TFLOPS)
+    achieved = (kp["flops"] / (kp["ms"] * 1e-3) / 1e12) if (kp["ms"] > 0 and kp["flops"] > 0) else None
+    # which roof binds THIS kernel: its arithmetic intensity (algorithmic flops / algorithmic bytes) against the ridge of the pipe it
+    # runs on (peak flop rate / 8 TB/s).  The searches sit at K/4 flop/B, far right of every ridge; the attention core of the
+    # `full` workload (raw key rows shared by all heads, D = 768) sits at ~50 flop/B, LEFT of the split-fp16 ridge (~104): HBM-bound.
+    kbytes = wl.attention_bytes * steps if (kname == "shared_kv_attention_kernel" and hasattr(wl, "attention_bytes")) else None
+    intensity = (kp["flops"] / kbytes) if (kbytes and kp["flops"] > 0) else None
+    ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+    hbm_bound = intensity is not None and intensity < ridge
+    mfma_view = {"achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved is not None else None}
+    if hbm_bound:
+        k_gbs = kbytes / (kp["ms"] * 1e-3) / 1e9
+        view = {"bound": "hbm", "achieved": k_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k_gbs / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": kbytes / max(kp["launches"], 1), "mfma_view": mfma_view}
+    else:
+        view = dict(mfma_view, bound="mfma")
+    view["arithmetic_intensity_flop_per_byte"] = intensity
+    view["ridge_flop_per_byte"] = ridge
+    return kname, kp, view, f16x3, hbm_bound, prof
+
+
+def extra_workloads(args, dev):
+    """The default run (`bench.py`, cfg3 on one GPU) also times a few steps of the other workloads this build makes claims about, so
+    that those claims are measured by whoever runs the default command and not only by the builder: {name: {value, unit, ms_per_step,
+    dominant_kernel, bound, frac, clock_ghz, ...}}.  Each is a shortened `bench.py --workload <name>` (same classes, same timing
+    protocol: warm-up, synchronise, K steps, synchronise); kernel durations of the multi-stream forwards come from a one-stream pass."""
+    import medtok_amd.vector_quantization_soft_one_new as vqmod
+    out = {}
+
+    def timed(step, steps):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    def run(name, make, steps, warmup, streams=False, clock=True, rows_note=None, more=None):
+        try:
+            wl = make()
+            for _ in range(warmup):
+                wl.step()
+            dt = timed(wl.step, steps)
+            keep = vqmod.SIDE_STREAM_MIN_CODES
+            try:
+                if streams:                      # kernel durations on ONE stream (event pairs of overlapping streams include each other)
+                    vqmod.SIDE_STREAM_MIN_CODES = 0
+                    wl.step()
+                torch.cuda.synchronize(dev)
+                ops.profile_begin()
+                dt1 = timed(wl.step, steps)
+                prof = ops.profile_end()
+                ghz = None
+                if clock and dt1 / steps >= 0.004:
+                    csteps = max(2, min(steps, int(0.3 / (dt1 / steps))))
+                    with ops.ClockProbe(dev, max_seconds=3.0 * dt1 / steps * csteps + 5.0) as probe:
+                        for _ in range(csteps):
+                            wl.step()
+                        torch.cuda.current_stream(dev).synchronize()
+                    ghz = probe.result().get("ghz_mean")
+                    torch.cuda.synchronize(dev)
+            finally:
+                vqmod.SIDE_STREAM_MIN_CODES = keep
+            kname, kp, view, f16x3, hbm_bound, _ = kernel_roofline(wl, prof, steps)
+            rec = {"value": wl.rows * steps / dt, "unit": "codes/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+                   "dominant_kernel": ("filter_rows64n_kernel" if kname == "filter_f16_kernel" and wl.D <= 64 else kname) if kp["launches"] else None,
+                   "bound": view["bound"], "frac": view["frac"], "achieved": view["achieved"], "peak": view["peak"], "roof_unit": view["unit"],
+                   "avg_launch_ms": kp["ms"] / max(kp["launches"], 1), "launches_timed": kp["launches"],
+                   "clock_ghz": ghz, "workload": wl.description}
+            if streams:
+                rec["one_stream_ms_per_step"] = dt1 / steps * 1e3
+            if more is not None:
+                rec.update(more(wl))
+            out[name] = rec
+            del wl
+        except Exception as exc:                 # (extras: the headline line is printed regardless)
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+        torch.cuda.empty_cache()
+
+    run("refdefault", lambda: RefDefault(600000, dev, 0, args.path), 3, 1)
+    run("cfg2", lambda: Cfg2(100000, dev, 0, args.path), 5, 2)
+    run("full", lambda: Full(4096, dev, 0, args.path), 5, 2, streams=True)
+    run("full_rows256", lambda: Full(256, dev, 0, args.path), 10, 3, streams=True, clock=False)
+
+    def replay(wl):
+        try:
+            r = wl.graph_replay(20)
+            return {"hip_graph_replay": {k: r[k] for k in ("value", "unit", "ms_per_step", "replay_equals_eager")}}
+        except Exception as exc:
+            return {"hip_graph_replay": {"error": f"{type(exc).__name__}: {exc}"[:300]}}
+    run("fullref", lambda: FullRefDefault(256, dev, 0, args.path), 20, 3, clock=False, more=replay)
+    keep_map = vqmod.TRAIN_SPLIT_TEXT_MAPPING
+    try:
+        run("cfg4_vq_only", lambda: Cfg4(256, dev, 0, args.path, precomputed=True), 3, 2, clock=False)
+    finally:
+        vqmod.TRAIN_SPLIT_TEXT_MAPPING = keep_map
+    out["note"] = ("short runs of `bench.py --workload <name>` inside the default command, after its timed region (same classes and timing protocol; "
+                   "`full*`: value from the multi-stream forward as shipped, kernel durations / frac from a one-stream pass; cfg4_vq_only = "
+                   "--workload cfg4 --precomputed-encoders); rank-local")
+    return out
 
 
 def collective_block(args, rank, world, dev):
@@ -734,7 +918,13 @@ def main():
             wl.description = wl.description.replace("stand-in BERT-shaped text encoder", "NO encoders (pre-computed text / node features); was: stand-in BERT-shaped text encoder")
     else:
         rows = args.rows or {"cfg3": 600000, "full": 4096, "refdefault": 600000, "fullref": 256}.get(args.workload, 100000)
-        wl = {"cfg3": Cfg3, "full": Full, "refdefault": RefDefault, "fullref": FullRefDefault}.get(args.workload, Cfg2)(rows, dev, seed=rank, path=args.path)
+        cls = {"cfg3": Cfg3, "full": Full, "refdefault": RefDefault, "fullref": FullRefDefault}.get(args.workload, Cfg2)
+        if args.data != "gaussian":
+            if args.workload not in ("cfg3", "refdefault"):
+                raise SystemExit("--data applies to --workload cfg3 / refdefault")
+            wl = cls(rows, dev, seed=rank, path=args.path, data=args.data)
+        else:
+            wl = cls(rows, dev, seed=rank, path=args.path)
 
     for _ in range(args.warmup):
         wl.step()
@@ -767,6 +957,20 @@ def main():
             torch.cuda.current_stream(dev).synchronize()
         clock = dict(probe.result(), region=f"{clock_steps} further steps right behind the timed region")
         torch.cuda.synchronize(dev)
+    # what the shortlist left behind, read once AFTER the timed region from one further step (device-side reduction of the candidate
+    # counts; the count of rows handed to the exact kernel is the library's own device counter `fb_count`)
+    fallback = None
+    if args.workload in ("cfg3", "refdefault") and args.path in (ops.PATH_AUTO, ops.PATH_F16_FILTER):
+        try:
+            ops.FILTER_STATS = []
+            wl.step()
+            stats = [ops.filter_stats(e) for e in ops.FILTER_STATS]
+            fallback = {"rows_handed_to_the_exact_kernel_per_step": sum(t["fallback_rows"] for t in stats),
+                        "searches": stats, "read": "once, from one further step behind the timed region (ops.filter_stats)"}
+        except Exception as exc:
+            fallback = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        finally:
+            ops.FILTER_STATS = None
     prof_note = None
     one_stream_elapsed = None
     if args.workload in ("full", "fullref") and not args.no_one_stream_pass and not args.one_stream:
@@ -839,36 +1043,8 @@ def main():
                               "avg_launch_ms": e_prof["ms"] / max(e_prof["launches"], 1)}}
         wl.set_path(args.path)
 
-    # dominant kernel = the library kernel with the most TIME in the timed region (HIP events recorded by the library around its
-    # matrix-pipe launches); its flops come from the library where the launch knows them, from the workload where the ragged
-    # counts live on the device, and are null (no roofline fraction) where neither does
-    if hasattr(wl, "attention_flops"):
-        prof["shared_kv_attention_kernel"]["flops"] = wl.attention_flops * args.steps
-    if hasattr(wl, "attention_backward_flops"):
-        prof["shared_kv_attention_backward_kernels"]["flops"] = wl.attention_backward_flops() * args.steps
-    kname = max(prof, key=lambda k: prof[k]["ms"])
-    kp = prof[kname]
-    # the split kernels run a product as three fp16 MFMA passes: their algorithmic (fp32-equivalent) flops are priced against a
-    # third of the dense fp16 peak
-    f16x3 = kname == "split_gemm_kernel" or (kname == "shared_kv_attention_kernel" and getattr(wl, "attention_f16x3", False))
-    peak = F16_MFMA_PEAK_TFLOPS if kname == "filter_f16_kernel" else (F16_MFMA_PEAK_TFLOPS / 3.0 if f16x3 else FP32_MFMA_PEAK_TFLOPS)
-    achieved = (kp["flops"] / (kp["ms"] * 1e-3) / 1e12) if (kp["ms"] > 0 and kp["flops"] > 0) else None
-    # which roof binds THIS kernel: its arithmetic intensity (algorithmic flops / algorithmic bytes) against the ridge of the pipe it
-    # runs on (peak flop rate / 8 TB/s).  The searches sit at K/4 flop/B, far right of every ridge; the attention core of the
-    # `full` workload (raw key rows shared by all heads, D = 768) sits at ~50 flop/B, LEFT of the split-fp16 ridge (~104): HBM-bound.
-    kbytes = wl.attention_bytes * args.steps if (kname == "shared_kv_attention_kernel" and hasattr(wl, "attention_bytes")) else None
-    intensity = (kp["flops"] / kbytes) if (kbytes and kp["flops"] > 0) else None
-    ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
-    hbm_bound = intensity is not None and intensity < ridge
-    mfma_view = {"achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": (achieved / peak) if achieved is not None else None}
-    if hbm_bound:
-        k_gbs = kbytes / (kp["ms"] * 1e-3) / 1e9
-        bound_view = {"bound": "hbm", "achieved": k_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k_gbs / HBM_PEAK_GBS,
-                      "algorithmic_bytes_per_launch": kbytes / max(kp["launches"], 1), "mfma_view": mfma_view}
-    else:
-        bound_view = dict(mfma_view, bound="mfma")
-    bound_view["arithmetic_intensity_flop_per_byte"] = intensity
-    bound_view["ridge_flop_per_byte"] = ridge
+    kname, kp, bound_view, f16x3, hbm_bound, prof = kernel_roofline(wl, prof, args.steps)
+    achieved = bound_view.get("mfma_view", bound_view).get("achieved")
     traffic, traffic_source = pmc_traffic(wl.name, kname, rows)
     alg_bytes_step = float(wl.bytes_per_code()) * rows                # SURVEY 8d per-code figure x the codes one step processes (per GPU)
     hbm_gbs = alg_bytes_step * args.steps / elapsed / 1e9
@@ -911,6 +1087,9 @@ def main():
                                        f"row-shard x{world}, codebook replicated, no data-path collective")},
             "roofline": {**bound_view,
                          "traffic": traffic, "traffic_source": traffic_source,
+                         # fabric bytes of the WHOLE step (every kernel) over its SURVEY-8d algorithmic bytes: re-reads through the L2s /
+                         # Infinity Cache (the fp16 codebook image is re-streamed per 256-row block) -- recorded, like `traffic`
+                         "fabric_over_algorithmic": (step_fabric_bytes(wl.name, rows) / alg_bytes_step) if step_fabric_bytes(wl.name, rows) else None,
                          # (rows of <= 64 elements take the fp16 filter's narrow-row kernel: the name rocprofv3 shows)
                          "kernel": ("filter_rows64n_kernel" if kname == "filter_f16_kernel" and wl.D <= 64 else kname),
                          "hbm_frac": hbm_gbs / HBM_PEAK_GBS, "hbm_achieved_gbs": hbm_gbs, "hbm_peak_gbs": HBM_PEAK_GBS,
@@ -938,6 +1117,8 @@ def main():
             line["roofline"]["issue_roofs"] = ir
         if strong is not None:
             line["extra"] = {"strong_scaling": strong}
+        if fallback is not None:
+            line["fallback_rows"] = fallback
         if args.workload in ("full", "fullref"):
             # both stream settings in one line: `value` is the forward as shipped (side streams from 512 codes up) unless --one-stream
             line["config"]["streams"] = "one (--one-stream)" if args.one_stream else "main + side streams (modality-specific searches, text side; the image pass over fp32 text rows has its own only where the attention kernel does not split the keys itself)"
@@ -964,6 +1145,10 @@ def main():
             line["config"]["vq_path_ms_per_step"] = max(line["ms_per_step"] - enc, 0.0)
             line["config"]["note"] = ("stand-in encoders (out of scope, upstream of the path); vq_path = cross-attention + 6 searches + "
                                       "loss.py + backward + clip + AdamW = step - encoders")
+        if world == 1 and args.workload == "cfg3" and args.data == "gaussian" and args.rows is None and not args.no_extra_workloads:
+            del wl.h, wl.pooled_text, wl.pooled_graph
+            torch.cuda.empty_cache()
+            line.setdefault("extra", {})["workloads"] = extra_workloads(args, dev)
         cpu_rows = args.cpu_rows if args.cpu_rows is not None else {"full": 512, "fullref": 512, "cfg4": 256}.get(args.workload, 16384)
         if world == 1 and cpu_rows > 0:
             line["cpu_baseline"] = wl.cpu_baseline(cpu_rows)

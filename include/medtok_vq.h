@@ -36,7 +36,10 @@ extern "C" {
 #endif
 
 #define MEDTOK_VQ_ABI_VERSION 2
-#define MEDTOK_MAX_TOPK 8
+/* codes per row a search returns: 1 .. 16.  Lists of up to 8 run on either search path; 9 .. 16 (the reference takes any k,
+ * vector_quantization_soft_one_new.py:91) always take the exact fp32 path, as two passes of lists of 8 (the 8 best, then the best
+ * among the codes behind the row's 8th (distance, index) pair) -- the same total order as one list of k. */
+#define MEDTOK_MAX_TOPK 16
 
 /* search path selector for medtok_topk_search_f32 */
 #define MEDTOK_PATH_AUTO 0          /* library picks the fastest exact path          */
@@ -98,7 +101,9 @@ size_t medtok_usage_multi_workspace_bytes(int64_t window_len, int64_t n_codes, i
 int medtok_usage_update_multi(float *window, int64_t window_len, const int64_t *const *ids, const int64_t *m, int count, int64_t n_codes,
                               int32_t *counts_out, void *ws, size_t ws_bytes, void *stream);
 /* the same with a device word copied behind the counts (counts_out [count + 1]; extra_word NULL: as above): the caller's one host read
- * of the usage counts then also brings e.g. the cross-attention's status word */
+ * of the usage counts then also brings e.g. the cross-attention's status word.  A NON-ZERO word vetoes the window write (the counts
+ * are still made): the caller's device-side input checks failed, and it repeats the forward on repaired inputs against the window
+ * as it was */
 int medtok_usage_update_multi_word(float *window, int64_t window_len, const int64_t *const *ids, const int64_t *m, int count, int64_t n_codes,
                                    int32_t *counts_out, const int32_t *extra_word, void *ws, size_t ws_bytes, void *stream);
 
@@ -167,6 +172,13 @@ int medtok_debug_filter_scores_f32(const float *xhat, const float *xsq, int64_t 
 /* Test hook: where, inside the workspace of a filter-path search, the int32 count of rows that were handed to the exact kernel
  * lives (candidate-list overflow, out-of-range norms, NaN); (size_t)-1 when the shape does not take the filter path. */
 size_t medtok_debug_filter_fallback_count_offset(int64_t n, int64_t k_codes, int d, int topk, int path);
+
+/* Measurement hook (bench.py --data, tests): what the shortlist pass of a FINISHED filter-path search left in its workspace `ws`
+ * (soft_vq_ws != 0: the workspace of a medtok_soft_vq_forward*_f32 call), read on the same stream behind the call:
+ * out[0] = candidates over all rows and lists, out[1] = lists at or over capacity, out[2] = rows handed to the exact kernel,
+ * out[3] = lists in total (uint64 [4], device memory).  Fails for shapes that do not take the filter path. */
+int medtok_debug_filter_stats(const void *ws, size_t ws_bytes, int soft_vq_ws, int64_t n, int64_t k_codes, int d, int topk, int path,
+                              uint64_t *out, void *stream);
 
 /* Soft assignment: w = softmax(-dist), zq = sum_j w_j * what[idx_j],
  * zq_ste = xref + (zq - xref), row_sqerr[r] = sum_i (zq - xref)^2.

@@ -22,7 +22,7 @@ def use_library(path) -> None:
 _lib = None
 
 ABI_VERSION = 2
-MAX_TOPK = 8
+MAX_TOPK = 16
 PATH_AUTO, PATH_F32_MFMA, PATH_F16_FILTER = 0, 1, 2
 
 
@@ -67,6 +67,7 @@ SIGNATURES = {
     "medtok_debug_filter_scores_workspace_bytes": (_sz, [_i64, _i64, _int]),
     "medtok_debug_filter_scores_f32": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "medtok_debug_filter_fallback_count_offset": (_sz, [_i64, _i64, _int, _int, _int]),
+    "medtok_debug_filter_stats": (_int, [_vp, _sz, _int, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "medtok_soft_assign_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _i64, _vp, _vp]),
     "medtok_sum_scale_f32": (_int, [_vp, _i64, _dbl, _vp, _vp]),
     "medtok_soft_vq_backward_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),

@@ -39,10 +39,18 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     newest = max(p.stat().st_mtime for p in deps)
     if not force and OUT.exists() and OUT.stat().st_mtime >= newest:
         return OUT
-    cmd = [hipcc(), *FLAGS, str(SRC), "-o", str(OUT)]
+    # (compiled next to the target and renamed into place: a reader -- a running process, a snapshot of the tree -- never sees a
+    # half-written library)
+    tmp = OUT.with_name(OUT.name + f".tmp{os.getpid()}")
+    cmd = [hipcc(), *FLAGS, str(SRC), "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, OUT)
+    finally:
+        if tmp.exists():
+            tmp.unlink()
     return OUT
 
 

@@ -394,13 +394,17 @@ constexpr int S_WPS = S_BK == 32 ? 2 : 3;                 // waves per SIMD the 
 // device) -- the exact fallback for rows the fp16 filter could not shortlist.
 // (the body is a force-inlined function of the block's coordinates: search_f32_kernel takes them from blockIdx, the batched kernel
 // of the small-batch forward -- several searches in one launch -- from its descriptor table)
-template <int TOPK, bool FINAL, bool KTAIL, bool INDIRECT>
+// EXCL (the second pass of a search for more than 8 codes per row): codes at or below the row's (distance, index) pair
+// (excl_d[row], excl_i[row]) -- the last entry of the first pass's list -- are skipped, so the pass returns the NEXT best codes in the
+// same total order (distance, then index).
+template <int TOPK, bool FINAL, bool KTAIL, bool INDIRECT, bool EXCL = false>
 __device__ __forceinline__ void search_f32_body(
     const float *__restrict__ xhat, const float *__restrict__ xsq, const float *__restrict__ what,
     const float *__restrict__ wsq, long n, int k_codes, int d, int codes_per_split, int topk_out,
     float *__restrict__ pval, int *__restrict__ pidx, int64_t *__restrict__ out_idx,
     float *__restrict__ out_dist, const int *__restrict__ row_list, const int *__restrict__ row_count,
-    int list_begin, int list_end, const unsigned block_x, const unsigned block_y)
+    int list_begin, int list_end, const unsigned block_x, const unsigned block_y,
+    const float *__restrict__ excl_d = nullptr, const int64_t *__restrict__ excl_i = nullptr, int excl_stride = 0)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -484,6 +488,9 @@ __device__ __forceinline__ void search_f32_body(
     const long mypos = row0 + wave * 32 + li;
     const long myrow = actual_row(mypos);
     const float xn = xsq[myrow];
+    float ex_d = -INFINITY;
+    int ex_i = -1;
+    if (EXCL) { ex_d = excl_d[myrow * excl_stride]; ex_i = (int)excl_i[myrow * excl_stride]; }
 
     f32x16 acc[4];
 #pragma unroll
@@ -528,6 +535,10 @@ __device__ __forceinline__ void search_f32_body(
                     const float two = 2.0f * acc[m][4 * g + j];
                     dv[j] = sum - two;
                     acc[m][4 * g + j] = 0.f;
+                    if (EXCL) {
+                        const int c = cbase + 32 * m + j + 8 * g + 4 * lh;
+                        if (dv[j] < ex_d || (dv[j] == ex_d && c <= ex_i)) dv[j] = INFINITY;
+                    }
                 }
                 bool any = true;
                 if (TOPK > 1) {
@@ -721,6 +732,19 @@ __global__ __launch_bounds__(256, S_WPS) void search_f32_kernel(
 {
     search_f32_body<TOPK, FINAL, KTAIL, INDIRECT>(xhat, xsq, what, wsq, n, k_codes, d, codes_per_split, topk_out, pval, pidx, out_idx, out_dist,
                                                   row_list, row_count, list_begin, list_end, blockIdx.x, blockIdx.y);
+}
+
+template <int TOPK, bool FINAL, bool KTAIL>
+__global__ __launch_bounds__(256, S_WPS) void search_f32_excl_kernel(
+    const float *__restrict__ xhat, const float *__restrict__ xsq, const float *__restrict__ what,
+    const float *__restrict__ wsq, long n, int k_codes, int d, int codes_per_split, int topk_out,
+    float *__restrict__ pval, int *__restrict__ pidx, int64_t *__restrict__ out_idx,
+    float *__restrict__ out_dist, int list_begin, int list_end,
+    const float *__restrict__ excl_d, const int64_t *__restrict__ excl_i, int excl_stride)
+{
+    search_f32_body<TOPK, FINAL, KTAIL, false, true>(xhat, xsq, what, wsq, n, k_codes, d, codes_per_split, topk_out, pval, pidx, out_idx, out_dist,
+                                                     (const int *)nullptr, (const int *)nullptr, list_begin, list_end, blockIdx.x, blockIdx.y,
+                                                     excl_d, excl_i, excl_stride);
 }
 
 // ---- several small searches in ONE launch each of three kernels (the B = 256 forward of the reference's default configuration runs
@@ -1047,7 +1071,7 @@ static bool filter_eligible(int64_t n, int64_t k_codes, int d, int topk)
     // crossover against the exact kernel on MI355X is around 1e10 flop (tools/path_crossover.py)
     // (k_codes * d < 2^29: the kernel addresses a code split's fp16 image with a 32-bit buffer offset)
     const double flops = 2.0 * (double)n * (double)k_codes * (double)d;
-    if (!(n >= 512 && k_codes >= 1024 && flops >= 1.0e10 && topk <= MEDTOK_MAX_TOPK && n < (1ll << 31) &&
+    if (!(n >= 512 && k_codes >= 1024 && flops >= 1.0e10 && topk <= 8 && n < (1ll << 31) &&
           (double)k_codes * (double)(d + 64) < 536870912.0))
         return false;
     // Few rows: the filter's floor is converting the codebook plus one block walking K/16 codes (about 1.1 us per
@@ -1060,9 +1084,12 @@ static bool filter_eligible(int64_t n, int64_t k_codes, int d, int topk)
     return true;
 }
 
+static size_t wide_head_bytes(int64_t n);
+
 static int resolve_path(int path, int64_t n, int64_t k_codes, int d, int topk)
 {
     path = path_id(path);
+    if (topk > 8) return MEDTOK_PATH_F32_MFMA;          // (the shortlist kernels keep lists of at most 8: search_wide)
     if (path == MEDTOK_PATH_AUTO) return filter_eligible(n, k_codes, d, topk) ? MEDTOK_PATH_F16_FILTER : MEDTOK_PATH_F32_MFMA;
     if (path == MEDTOK_PATH_F16_FILTER && (double)k_codes * (double)(d + 64) >= 536870912.0) return MEDTOK_PATH_F32_MFMA;
     return path;
@@ -1071,6 +1098,8 @@ static int resolve_path(int path, int64_t n, int64_t k_codes, int d, int topk)
 extern "C" size_t medtok_search_workspace_bytes(int64_t n, int64_t k_codes, int d, int topk, int path)
 {
     if (n <= 0 || k_codes <= 0 || topk < 1 || topk > MEDTOK_MAX_TOPK) return 0;
+    if (topk > 8)            // two passes of the exact kernel with lists of 8 + the join's buffers
+        return wide_head_bytes(n) + medtok_search_workspace_bytes(n, k_codes, d, 8, (path & ~MEDTOK_PATH_MASK) | MEDTOK_PATH_F32_MFMA);
     const PlanOverride ov = decode_plan(path);
     if (resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER)
         return filter_ws_layout(nullptr, n, plan_filter(n, k_codes, d, topk, ov)).total;
@@ -1088,11 +1117,39 @@ extern "C" size_t medtok_search_workspace_bytes(int64_t n, int64_t k_codes, int 
 template <int T, bool KTAIL>
 static int launch_search(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
                          int64_t k_codes, int d, int topk, int64_t *idx, float *dist, void *ws, size_t ws_bytes,
-                         const SearchPlan &p, hipStream_t s)
+                         const SearchPlan &p, hipStream_t s, const float *excl_d = nullptr, const int64_t *excl_i = nullptr, int excl_stride = 0)
 {
     dim3 grid((unsigned)p.row_tiles, (unsigned)p.splits), block(256);
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
     const double pflops = 2.0 * (double)n * (double)k_codes * (double)d;
+    // one launch of the exact kernel: FINAL (a block walks all codes and writes the row's list) or partial lists per code split;
+    // with excl_d the second-pass form that skips a row's first-pass codes (lists of 8 only)
+    auto go = [&](bool final_, dim3 g, int cps, float *pv, int *pi, int64_t *oi, float *od, int lb, int le) {
+        if (excl_d) {
+            if constexpr (T == 8) {
+                if (final_) {
+                    (void)set_lds_once<search_f32_excl_kernel<8, true, KTAIL>>(S_LDS_BYTES);
+                    hipLaunchKernelGGL((search_f32_excl_kernel<8, true, KTAIL>), g, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n, (int)k_codes, d, cps, topk,
+                                       pv, pi, oi, od, lb, le, excl_d, excl_i, excl_stride);
+                } else {
+                    (void)set_lds_once<search_f32_excl_kernel<8, false, KTAIL>>(S_LDS_BYTES);
+                    hipLaunchKernelGGL((search_f32_excl_kernel<8, false, KTAIL>), g, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n, (int)k_codes, d, cps, topk,
+                                       pv, pi, oi, od, lb, le, excl_d, excl_i, excl_stride);
+                }
+            }
+            return;
+        }
+        if (final_) {
+            (void)set_lds_once<search_f32_kernel<T, true, KTAIL, false>>(S_LDS_BYTES);
+            hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, false>), g, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n, (int)k_codes, d, cps, topk,
+                               pv, pi, oi, od, (const int *)nullptr, (const int *)nullptr, lb, le);
+        } else {
+            (void)set_lds_once<search_f32_kernel<T, false, KTAIL, false>>(S_LDS_BYTES);
+            hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL, false>), g, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n, (int)k_codes, d, cps, topk,
+                               pv, pi, oi, od, (const int *)nullptr, (const int *)nullptr, lb, le);
+        }
+    };
+    if (excl_d && T != 8) return fail("search: the exclusion pass runs with lists of 8");
     if (p.tail_splits > 0) {
         // whole rounds of unsplit blocks, then the last round's row tiles with their own code splits + merge
         const long tail_start = p.main_tiles * S_BN, tail_rows = n - tail_start;
@@ -1101,14 +1158,9 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
         if (!ws || ws_bytes < vb + ib) return fail("search: workspace too small (%zu < %zu)", ws_bytes, vb + ib);
         float *pval = (float *)ws;
         int *pidx = (int *)((char *)ws + vb);
-        (void)set_lds_once<search_f32_kernel<T, true, KTAIL, false>>(S_LDS_BYTES);
-        (void)set_lds_once<search_f32_kernel<T, false, KTAIL, false>>(S_LDS_BYTES);
-        hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, false>), dim3((unsigned)p.main_tiles, 1), block, S_LDS_BYTES, s, xhat, xsq, what, wsq,
-                           (long)n, (int)k_codes, d, p.codes_per_split, topk, (float *)nullptr, (int *)nullptr, idx, dist,
-                           (const int *)nullptr, (const int *)nullptr, 0, 0);
-        hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL, false>), dim3((unsigned)(p.row_tiles - p.main_tiles), (unsigned)p.tail_splits), block,
-                           S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n, (int)k_codes, d, p.tail_codes_per_split, topk, pval, pidx,
-                           (int64_t *)nullptr, (float *)nullptr, (const int *)nullptr, (const int *)nullptr, (int)tail_start, (int)tail_rows);
+        go(true, dim3((unsigned)p.main_tiles, 1), p.codes_per_split, (float *)nullptr, (int *)nullptr, idx, dist, 0, 0);
+        go(false, dim3((unsigned)(p.row_tiles - p.main_tiles), (unsigned)p.tail_splits), p.tail_codes_per_split, pval, pidx, (int64_t *)nullptr, (float *)nullptr,
+           (int)tail_start, (int)tail_rows);
         if (pa) prof_push(pa, prof_mark(s), pflops, 1);
         if (check_launch("search_f32(main + tail)")) return 1;
         hipLaunchKernelGGL((merge_topk_kernel<T>), dim3((unsigned)((tail_rows + 31) / 32)), dim3(256), 0, s, pval, pidx, tail_rows,
@@ -1117,10 +1169,7 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
         return check_launch("merge_topk(tail)");
     }
     if (p.splits == 1) {
-        (void)set_lds_once<search_f32_kernel<T, true, KTAIL, false>>(S_LDS_BYTES);
-        hipLaunchKernelGGL((search_f32_kernel<T, true, KTAIL, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
-                           (int)k_codes, d, p.codes_per_split, topk, (float *)nullptr, (int *)nullptr, idx, dist,
-                           (const int *)nullptr, (const int *)nullptr, 0, 0);
+        go(true, grid, p.codes_per_split, (float *)nullptr, (int *)nullptr, idx, dist, 0, 0);
         if (pa) prof_push(pa, prof_mark(s), pflops, 1);
         return check_launch("search_f32");
     }
@@ -1129,10 +1178,7 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
     if (!ws || ws_bytes < vbytes + ibytes) return fail("search: workspace too small (%zu < %zu)", ws_bytes, vbytes + ibytes);
     float *pval = (float *)ws;
     int *pidx = (int *)((char *)ws + vbytes);
-    (void)set_lds_once<search_f32_kernel<T, false, KTAIL, false>>(S_LDS_BYTES);
-    hipLaunchKernelGGL((search_f32_kernel<T, false, KTAIL, false>), grid, block, S_LDS_BYTES, s, xhat, xsq, what, wsq, (long)n,
-                       (int)k_codes, d, p.codes_per_split, topk, pval, pidx, (int64_t *)nullptr, (float *)nullptr,
-                       (const int *)nullptr, (const int *)nullptr, 0, 0);
+    go(false, grid, p.codes_per_split, pval, pidx, (int64_t *)nullptr, (float *)nullptr, 0, 0);
     if (pa) prof_push(pa, prof_mark(s), pflops, 1);
     if (check_launch("search_f32(split)")) return 1;
     if (p.splits >= 64 && n <= 8192)     // few rows, many lists each: a wave per row
@@ -1147,10 +1193,54 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
 template <int T>
 static int launch_search_t(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq,
                            int64_t k_codes, int d, int topk, int64_t *idx, float *dist, void *ws, size_t ws_bytes,
-                           const SearchPlan &p, hipStream_t s)
+                           const SearchPlan &p, hipStream_t s, const float *excl_d = nullptr, const int64_t *excl_i = nullptr, int excl_stride = 0)
 {
-    if (d % S_BK) return launch_search<T, true>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
-    return launch_search<T, false>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s);
+    if (d % S_BK) return launch_search<T, true>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s, excl_d, excl_i, excl_stride);
+    return launch_search<T, false>(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, p, s, excl_d, excl_i, excl_stride);
+}
+
+// ---- more than 8 codes per row (k = 9 .. MEDTOK_MAX_TOPK; the reference takes any k, vector_quantization_soft_one_new.py:91,157,203):
+// the lane-local lists of the kernels hold 8 entries, so the search runs as TWO passes of the exact kernel -- the 8 best codes, then
+// the best k - 8 among the codes behind the row's 8th (distance, index) pair -- and a join.  Same total order (distance, then
+// lowest index) as one list of k: bit-identical to the oracle's top-k.  Always the exact fp32 path (the shortlist kernels keep lists
+// of at most 8).
+constexpr int WIDE_T = 8;
+static size_t wide_head_bytes(int64_t n)
+{
+    return 2 * align_up((size_t)n * WIDE_T * sizeof(int64_t), 256) + 2 * align_up((size_t)n * WIDE_T * sizeof(float), 256);
+}
+
+__global__ __launch_bounds__(256) void join_lists_kernel(const int64_t *__restrict__ ia, const float *__restrict__ da, const int64_t *__restrict__ ib,
+                                                         const float *__restrict__ db, long n, int kb, int64_t *__restrict__ idx, float *__restrict__ dist)
+{
+    const int k = WIDE_T + kb;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n * k; i += (long)gridDim.x * 256) {
+        const long r = i / k;
+        const int j = (int)(i - r * k);
+        idx[i] = j < WIDE_T ? ia[r * WIDE_T + j] : ib[r * kb + (j - WIDE_T)];
+        dist[i] = j < WIDE_T ? da[r * WIDE_T + j] : db[r * kb + (j - WIDE_T)];
+    }
+}
+
+static int search_wide(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq, int64_t k_codes, int d, int topk,
+                       int64_t *idx, float *dist, void *ws, size_t ws_bytes, int path, hipStream_t s)
+{
+    const PlanOverride ov = decode_plan(path);
+    const SearchPlan p = plan_search(n, k_codes, WIDE_T, ov);
+    const size_t head = wide_head_bytes(n);
+    if (!ws || ws_bytes < head) return fail("search(k > 8): workspace too small (%zu < %zu)", ws_bytes, head);
+    char *base = (char *)ws;
+    int64_t *ia = (int64_t *)base;
+    int64_t *ib = (int64_t *)(base + align_up((size_t)n * WIDE_T * sizeof(int64_t), 256));
+    float *da = (float *)(base + 2 * align_up((size_t)n * WIDE_T * sizeof(int64_t), 256));
+    float *db = (float *)((char *)da + align_up((size_t)n * WIDE_T * sizeof(float), 256));
+    void *inner = base + head;
+    const size_t inner_bytes = ws_bytes - head;
+    if (launch_search_t<WIDE_T>(xhat, xsq, n, what, wsq, k_codes, d, WIDE_T, ia, da, inner, inner_bytes, p, s)) return 1;
+    const int kb = topk - WIDE_T;
+    if (launch_search_t<WIDE_T>(xhat, xsq, n, what, wsq, k_codes, d, kb, ib, db, inner, inner_bytes, p, s, da + (WIDE_T - 1), ia + (WIDE_T - 1), WIDE_T)) return 1;
+    hipLaunchKernelGGL(join_lists_kernel, dim3((unsigned)lmin(4096, (n * topk + 255) / 256)), dim3(256), 0, s, ia, da, ib, db, (long)n, kb, idx, dist);
+    return check_launch("join_lists");
 }
 
 // Handed by medtok_soft_vq_forward_f32 to its search call: when the filter path runs, its re-score kernel also does the
@@ -1261,6 +1351,7 @@ static int search_impl(const float *xhat, const float *xsq, int64_t n, const flo
     const PlanOverride ov = decode_plan(path);
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (topk > 8) return search_wide(xhat, xsq, n, what, wsq, k_codes, d, topk, idx, dist, ws, ws_bytes, path, s);
     const int tslots = topk == 1 ? 1 : (topk <= 5 ? 5 : 8);
     if (resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER) {
         if (n >= (1ll << 31)) return fail("search(filter): n too large");
@@ -1334,6 +1425,44 @@ extern "C" size_t medtok_debug_filter_fallback_count_offset(int64_t n, int64_t k
     if (n <= 0 || k_codes <= 0 || resolve_path(path, n, k_codes, d, topk) != MEDTOK_PATH_F16_FILTER) return (size_t)-1;
     const FilterWs w = filter_ws_layout((void *)256, n, plan_filter(n, k_codes, d, topk, decode_plan(path)));
     return (size_t)((char *)w.fb_count - (char *)256);
+}
+
+// Measurement hook (bench.py --data ..., tests): what the filter pass of a finished search left in its workspace -- how many candidates
+// it shortlisted, how many of a row's lists are full, how many rows it handed to the exact kernel.  `ws` is the workspace of the
+// search call (soft_vq_ws != 0: of a medtok_soft_vq_forward*_f32 call, whose search workspace starts behind |x|^2), read after
+// the call on the same stream.  out[0] = candidates over all rows and lists, out[1] = lists at or over capacity, out[2] = rows
+// handed to the exact kernel, out[3] = lists in total (rows x owners).
+__global__ __launch_bounds__(256) void filter_stats_kernel(const int *__restrict__ cnt, long lists, const int *__restrict__ cnt_tail, long lists_tail,
+                                                           const int *__restrict__ fb_count, unsigned long long *__restrict__ out)
+{
+    unsigned long long cand = 0, full = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < lists + lists_tail; i += (long)gridDim.x * 256) {
+        const int c = i < lists ? cnt[i] : cnt_tail[i - lists];
+        cand += (unsigned long long)min(c, F_CAP);
+        full += c >= F_CAP ? 1ull : 0ull;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { cand += __shfl_xor(cand, off, 64); full += __shfl_xor(full, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], cand); atomicAdd(&out[1], full); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[2] = (unsigned long long)*fb_count; out[3] = (unsigned long long)(lists + lists_tail); }
+}
+
+extern "C" int medtok_debug_filter_stats(const void *ws, size_t ws_bytes, int soft_vq_ws, int64_t n, int64_t k_codes, int d, int topk, int path,
+                                         uint64_t *out, void *stream)
+{
+    if (!ws || !out || n <= 0 || k_codes <= 0) return fail("filter_stats: bad arguments");
+    if (topk < 1 || topk > 8 || resolve_path(path, n, k_codes, d, topk) != MEDTOK_PATH_F16_FILTER) return fail("filter_stats: this shape does not take the filter path");
+    const size_t head = soft_vq_ws ? align_up((size_t)n * 4, 256) : 0;
+    const FilterPlan f = plan_filter(n, k_codes, d, topk, decode_plan(path));
+    const FilterWs w = filter_ws_layout((char *)const_cast<void *>(ws) + head, n, f);
+    if (ws_bytes < head + w.total) return fail("filter_stats: workspace too small (%zu < %zu)", ws_bytes, head + w.total);
+    const long n_main = (long)lmin(n, f.main_tiles * f.row_bn), n_tail = (long)n - n_main;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, 32, s) != hipSuccess) return fail("filter_stats: memset failed");
+    const long lists = n_main * f.own_total, lists_tail = n_tail * f.own_tail;
+    hipLaunchKernelGGL(filter_stats_kernel, dim3((unsigned)lmin(1024, (lists + lists_tail + 255) / 256)), dim3(256), 0, s, w.cand_cnt, lists, w.cnt_tail, lists_tail,
+                       w.fb_count, (unsigned long long *)out);
+    return check_launch("filter_stats");
 }
 
 // Test hook: the filter's approximate scores s~ [n, k_codes] (same MFMA sequence as the search uses),
@@ -1489,9 +1618,15 @@ extern "C" int medtok_soft_assign_f32(const float *xref, const float *what, cons
     if (!hard && !dist) return fail("soft_assign: dist required");
     if (n == 0) return 0;
     if (!zq_ste) return fail("soft_assign: zq_ste required");
-    hipLaunchKernelGGL((soft_assign_kernel<MEDTOK_MAX_TOPK>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       xref, what, idx, dist, (long)n, d, topk, flags, w, zq_ste, (long)zq_stride, row_sqerr,
-                       (const int *)nullptr, (const int *)nullptr);
+    // (lists of up to 8 codes -- every shipped configuration -- keep the 8-slot instantiation; 9 .. 16 take the 16-slot one)
+    if (topk <= 8)
+        hipLaunchKernelGGL((soft_assign_kernel<8>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           xref, what, idx, dist, (long)n, d, topk, flags, w, zq_ste, (long)zq_stride, row_sqerr,
+                           (const int *)nullptr, (const int *)nullptr);
+    else
+        hipLaunchKernelGGL((soft_assign_kernel<MEDTOK_MAX_TOPK>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           xref, what, idx, dist, (long)n, d, topk, flags, w, zq_ste, (long)zq_stride, row_sqerr,
+                           (const int *)nullptr, (const int *)nullptr);
     return check_launch("soft_assign");
 }
 
@@ -1567,7 +1702,7 @@ constexpr int64_t MS_MAX_ROWS = 4096;
 
 extern "C" int medtok_soft_vq_multi_eligible(int64_t n, int64_t k_codes, int d, int topk)
 {
-    return n >= 1 && n <= MS_MAX_ROWS && k_codes >= 1 && k_codes < (1ll << 31) && d > 0 && !(d & 3) && topk >= 1 && topk <= MEDTOK_MAX_TOPK &&
+    return n >= 1 && n <= MS_MAX_ROWS && k_codes >= 1 && k_codes < (1ll << 31) && d > 0 && !(d & 3) && topk >= 1 && topk <= 8 &&
            topk <= k_codes && resolve_path(MEDTOK_PATH_AUTO, n, k_codes, d, topk) == MEDTOK_PATH_F32_MFMA;
 }
 
@@ -1707,7 +1842,11 @@ extern "C" int medtok_soft_vq_backward_f32(const float *x, const float *xhat, co
     if (n == 0) return 0;
     if (!x || !xhat || !what || !idx || !w) return fail("soft_vq_backward: x, xhat, what, idx and w are required");
     if (!gx && !g_code) return fail("soft_vq_backward: nothing to compute (gx and g_code are both NULL)");
-    hipLaunchKernelGGL((soft_vq_backward_kernel<MEDTOK_MAX_TOPK>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    if (topk <= 8)
+        hipLaunchKernelGGL((soft_vq_backward_kernel<8>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, xhat, what, idx, w, (long)n, d, topk, g_zq, g_xhat, g_out, g_vq, g_commit, vq_scale, commit_scale, gx, g_code);
+    else
+        hipLaunchKernelGGL((soft_vq_backward_kernel<MEDTOK_MAX_TOPK>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        x, xhat, what, idx, w, (long)n, d, topk, g_zq, g_xhat, g_out, g_vq, g_commit, vq_scale, commit_scale, gx, g_code);
     return check_launch("soft_vq_backward");
 }
@@ -2926,9 +3065,13 @@ __global__ __launch_bounds__(256) void usage_multi_finish_kernel(const float *__
                                                                  const unsigned char *__restrict__ flags, long n_codes, int count, int *__restrict__ counts,
                                                                  const int *__restrict__ extra_word = nullptr)
 {
-    // (extra_word: a device word the caller wants behind the counts -- its one host read then fetches both)
+    // (extra_word: a device word the caller wants behind the counts -- its one host read then fetches both.  A NON-ZERO word vetoes
+    // the window write: the caller's device-side input checks failed, the ids are not to be trusted, and the caller -- who sees the
+    // word with the counts -- repeats the forward on repaired inputs against the window as it was)
+    const bool veto = extra_word && extra_word[0] != 0;
     if (extra_word && blockIdx.x == 0 && threadIdx.x == 0) counts[count] = extra_word[0];
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < wlen; i += (long)gridDim.x * 256) win[i] = tmp[i];
+    if (!veto)
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < wlen; i += (long)gridDim.x * 256) win[i] = tmp[i];
     const int lane = threadIdx.x & 63;
     for (int u = 0; u < count; ++u) {
         int part = 0;
@@ -3108,7 +3251,7 @@ static int soft_vq_forward_impl(const float *x, int64_t n, int d, const float *w
     if (zq_stride == 0) zq_stride = d;
     FuseAssign fuse = {x, w, zq_ste, (long)zq_stride, false, nullptr, nullptr, false};
     fuse.p_wh = p_wh; fuse.p_wsqp = p_wsqp; fuse.p_en_max = p_en_max;
-    const bool try_fuse = !row_sqerr && zq_ste && zq_stride >= d && !(zq_stride & 3) && topk <= MEDTOK_MAX_TOPK;
+    const bool try_fuse = !row_sqerr && zq_ste && zq_stride >= d && !(zq_stride & 3) && topk <= 8;
     const bool filter_path = topk >= 1 && topk <= MEDTOK_MAX_TOPK && resolve_path(path, n, k_codes, d, topk) == MEDTOK_PATH_F16_FILTER;
     if (try_fuse && filter_path && xhat && !(d & 3)) {
         // the filter's fp16 image of the normalised rows comes out of the same pass that normalises them
@@ -3129,7 +3272,7 @@ static int soft_vq_forward_impl(const float *x, int64_t n, int d, const float *w
     if (rc) return 1;
     if (!fuse.done) return medtok_soft_assign_f32(x, what, idx, dist, n, d, topk, 0, w, zq_ste, zq_stride, row_sqerr, stream);
     // rows the filter handed to the exact kernel: assignment through the device-side row list (normally empty)
-    hipLaunchKernelGGL((soft_assign_kernel<MEDTOK_MAX_TOPK>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((soft_assign_kernel<8>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,          // (the filter path: topk <= 8)
                        x, what, idx, dist, (long)n, d, topk, 0, w, zq_ste, (long)zq_stride, (float *)nullptr, fuse.fb_rows, fuse.fb_count);
     return check_launch("soft_assign(list)");
 }

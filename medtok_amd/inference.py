@@ -19,13 +19,20 @@ from .tokenizer import MultimodalTokenizer
 from .vector_quantization_soft_one_new import VectorQuantizer
 
 
-@torch.no_grad()
+# quantize_pooled: the four searches are independent (vector_quantization_soft_one_new.py:238-271).  From this many rows up they are
+# issued on TWO HIP streams, a short (region) and a long (whole-codebook) search on each in opposite order, so that one stream's
+# re-score / projection / row-norm passes (fabric- and HBM-bound, no matrix work) run while the other stream's shortlist kernel has the
+# matrix pipe.  0: one stream.  Same kernels on the same operands: bit-identical results (tests/test_gpu_full_size.py).
+TWO_STREAM_MIN_ROWS = 0
+
+
 @torch.no_grad()
 def quantize_pooled(vq: VectorQuantizer, h: torch.Tensor, pooled_text: torch.Tensor, pooled_graph: torch.Tensor):
     """The four searches of VectorQuantizer.forward for inputs whose cross-attention pooling
     is already done (BASELINE config 3): h [N, 2*e_dim] -> specific text/graph searches over
     their codebook thirds; pooled_* [N, e_dim] -> shared searches over the whole codebook.
     Returns (embedding [N, 4*e_dim], tokens [N, 4, k], weights [N, 4, k])."""
+    from . import vector_quantization_soft_one_new as vqmod
     was_training = vq.training
     vq.eval()
     try:
@@ -33,10 +40,21 @@ def quantize_pooled(vq: VectorQuantizer, h: torch.Tensor, pooled_text: torch.Ten
         e = vq.e_dim
         # the four searches write straight into their column block of the result (the reference's torch.cat, :246)
         embedding = torch.empty((h.shape[0], 4 * e), dtype=torch.float32, device=h.device)
-        _, _, _, _, idx_t, w_t = vq._search(vq.project(h_text, "text"), "text", False, out=embedding[:, 0:e])
-        _, _, _, _, idx_g, w_g = vq._search(vq.project(h_graph, "graph"), "graph", False, out=embedding[:, e:2 * e])
-        _, _, _, _, idx_st, w_st = vq._search(pooled_text, "shared", False, out=embedding[:, 2 * e:3 * e])
-        _, _, _, _, idx_sg, w_sg = vq._search(pooled_graph, "shared", False, out=embedding[:, 3 * e:4 * e])
+        if h.is_cuda and 0 < TWO_STREAM_MIN_ROWS <= h.shape[0]:
+            norm = vq._normalised_codebook(prepare=True)          # built once, on this stream, before the fork
+            side, cur = vqmod._side_stream(h.device, 1)
+            vqmod._lend(side, h, pooled_text, embedding)
+            with torch.cuda.stream(side):
+                _, _, _, _, idx_st, w_st = vq._search(pooled_text, "shared", False, out=embedding[:, 2 * e:3 * e], norm=norm)
+                _, _, _, _, idx_g, w_g = vq._search(vq.project(h_graph, "graph"), "graph", False, out=embedding[:, e:2 * e], norm=norm)
+            _, _, _, _, idx_t, w_t = vq._search(vq.project(h_text, "text"), "text", False, out=embedding[:, 0:e], norm=norm)
+            _, _, _, _, idx_sg, w_sg = vq._search(pooled_graph, "shared", False, out=embedding[:, 3 * e:4 * e], norm=norm)
+            vqmod._join_side(side, cur, (idx_st, w_st, idx_g, w_g))
+        else:
+            _, _, _, _, idx_t, w_t = vq._search(vq.project(h_text, "text"), "text", False, out=embedding[:, 0:e])
+            _, _, _, _, idx_g, w_g = vq._search(vq.project(h_graph, "graph"), "graph", False, out=embedding[:, e:2 * e])
+            _, _, _, _, idx_st, w_st = vq._search(pooled_text, "shared", False, out=embedding[:, 2 * e:3 * e])
+            _, _, _, _, idx_sg, w_sg = vq._search(pooled_graph, "shared", False, out=embedding[:, 3 * e:4 * e])
     finally:
         vq.train(was_training)
     tokens = torch.stack((idx_t, idx_g, idx_st, idx_sg), dim=1)

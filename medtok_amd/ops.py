@@ -839,7 +839,8 @@ def soft_vq_forward_multi(searches, topk: int):
 def usage_update_multi_(window: torch.Tensor, ids_list, n_codes: int, extra_word=None) -> torch.Tensor:
     """usage_update_ for several id sets appended in order, in two launches: int32 [len(ids_list)] device tensor of the distinct-value
     counts after each update (no host sync).  extra_word (int32 device tensor): its first element is copied behind the counts (the
-    result has one more entry), so that the caller's one host read brings it along."""
+    result has one more entry), so that the caller's one host read brings it along; while it is non-zero the window is NOT written
+    (include/medtok_vq.h: the caller repeats the forward on repaired inputs)."""
     import ctypes as C
     if not (window.is_cuda and window.dtype == torch.float32 and window.is_contiguous()):
         raise _lib.MedTokLibraryError("usage_update_multi_: window must be a contiguous fp32 device tensor")
@@ -923,6 +924,29 @@ def prepare_codebook(weight: torch.Tensor, regions, normalised=None):
     return what, wsq, prepared
 
 
+# Measurement hook (bench.py, tests; never set in product code): while this is a list, every soft_vq_forward that takes the fp16
+# shortlist appends (its workspace, n, K, d, topk, path) -- the workspace stays alive with the entry, nothing is read back;
+# filter_stats(entry) reduces it on the device afterwards.
+FILTER_STATS = None
+
+
+def filter_stats(entry) -> dict:
+    """What the shortlist pass of the finished search behind `entry` (an element of FILTER_STATS) left behind: candidates per row,
+    share of full candidate lists, rows handed to the exact kernel (include/medtok_vq.h: medtok_debug_filter_stats).  One host read."""
+    ws, n, k, d, topk, path = entry
+    out = torch.zeros(4, dtype=torch.int64, device=ws.device)
+    with _on(ws.device):
+        _lib.check(_lib.load().medtok_debug_filter_stats(ws.data_ptr(), ws.numel(), 1, n, k, d, topk, path, out.data_ptr(), _stream(ws)),
+                   "medtok_debug_filter_stats")
+    cand, full, fb, lists = out.cpu().tolist()
+    return dict(rows=n, codes=k, candidates_per_row=cand / n, full_lists_share=full / max(lists, 1), lists_per_row=lists / n, fallback_rows=fb)
+
+
+def _note_filter_stats(ws, n, k, d, topk, path):
+    if FILTER_STATS is not None and n > 0 and takes_filter_path(n, k, d, topk, path):
+        FILTER_STATS.append((ws, n, k, d, topk, path))
+
+
 def soft_vq_forward(x, what, wsq, topk: int, path: int = PATH_AUTO, want_sqerr: bool = True, out=None, prepared=None):
     """rownorm -> search -> soft assign in one C call.
     Returns dict(xhat, idx, dist, w, zq, row_sqerr); `out` as in soft_assign.  prepared (inference, want_sqerr = False): the region's
@@ -947,6 +971,7 @@ def soft_vq_forward(x, what, wsq, topk: int, path: int = PATH_AUTO, want_sqerr: 
                                                                xhat.data_ptr(), idx.data_ptr(), dist.data_ptr(), w.data_ptr(),
                                                                zq.data_ptr(), zstride, ws.data_ptr(), ws.numel(), _stream(x)),
                        "medtok_soft_vq_forward_prepared_f32")
+        _note_filter_stats(ws, n, k, d, topk, path)
         return dict(xhat=xhat, idx=idx, dist=dist, w=w, zq=zq, row_sqerr=None)
     if SEARCH_TIMER is not None:         # same kernels, launched piecewise so the search can be bracketed
         xhat, xsq = rownorm(x)
@@ -967,4 +992,5 @@ def soft_vq_forward(x, what, wsq, topk: int, path: int = PATH_AUTO, want_sqerr: 
                                                   xhat.data_ptr(), idx.data_ptr(), dist.data_ptr(), w.data_ptr(),
                                                   zq.data_ptr(), zstride, _ptr(se), ws.data_ptr(), ws.numel(), _stream(x)),
                    "medtok_soft_vq_forward_f32")
+    _note_filter_stats(ws, n, k, d, topk, path)
     return dict(xhat=xhat, idx=idx, dist=dist, w=w, zq=zq, row_sqerr=se)

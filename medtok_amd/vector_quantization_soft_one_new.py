@@ -98,6 +98,9 @@ FUSE_IMAGE_PAIRS = True
 from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
+UNSORTED_BATCH_MESSAGE = ("pooled(): the paths without a host read (assume_sorted_batch = True; max_nodes_bound) need a non-decreasing `batch` "
+                          "vector (PyG-style); sort the nodes by code (CrossAttention.sort_by_code), or leave assume_sorted_batch = False / "
+                          "max_nodes_bound = None")
 
 # Inference forward: the work that does not depend on the graph side of the cross-attention -- the two (four with an aug view)
 # modality-specific searches and the text side's attention chain, about an eighth of a forward, all launches of a few hundred
@@ -914,11 +917,47 @@ class CrossAttention(nn.Module):
                                       self._small_weights(), len(self.model), (dim // heads) ** -0.5, self.model[0].layer_norm.eps, pooled2, st)
         return pooled2
 
+    # The paths without a host read (the two-launch small-width path; any width with max_nodes_bound) cannot sort an unsorted `batch`
+    # vector themselves.  False (default): the reference's "any batch vector" semantics (`batch == idx`, :135) are kept -- the forward
+    # verifies the device word where it reads the host anyway (or with one 4-byte read at its end) and, for an unsorted vector, runs
+    # again on the stably sorted nodes; out-of-range ids raise.  True: the caller guarantees a non-decreasing (PyG-style) vector, nothing
+    # is read back (what a HIP-graph capture needs; check_status() remains available).
+    assume_sorted_batch = False
+
     def _status_word(self, dev):
         st = getattr(self, "small_status", None)
         if st is None or st.device != dev:
+            if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                # (a zero-fill recorded into the graph would erase earlier flags on every replay)
+                raise RuntimeError("CrossAttention: the status word must exist before a HIP-graph capture: run one warm-up forward first")
             st = self.small_status = torch.zeros(4, dtype=torch.int32, device=dev)
         return st
+
+    def take_status(self, word=None):
+        """Host side of the device checks: reads (unless `word` was read already) and clears small_status.  Returns True when the ONLY
+        finding is an unsorted `batch` vector -- the caller then runs again on stably sorted nodes -- False when there is none; raises
+        pooled()'s ValueError for ids outside [0, B) or a node count above max_nodes_bound."""
+        st = getattr(self, "small_status", None)
+        if st is None:
+            return False
+        if word is None:
+            word = int(st[0].item())
+        if not word:
+            return False
+        st.zero_()
+        if word & 2:
+            raise ValueError("pooled(): `batch` holds code ids outside [0, B)")
+        if word & 4:
+            raise ValueError(f"pooled(): a code has more nodes than max_nodes_bound = {getattr(self, 'max_nodes_bound', None)}; raise the bound, or set it to "
+                             "None (one host read per call)")
+        return True
+
+    @staticmethod
+    def sort_by_code(nodes, batch):
+        """nodes / batch in code order, in-code order kept (stable): what `z_graph[batch == idx]` selects (:135)"""
+        batch = batch.reshape(-1).to(torch.long)
+        order = torch.argsort(batch, stable=True)
+        return nodes[order], batch[order]
 
     def check_status(self):
         """Host read of small_status (a synchronisation): raises what pooled() raises for a batch vector the paths without a host
@@ -934,8 +973,7 @@ class CrossAttention(nn.Module):
             if word & 4:
                 raise ValueError(f"pooled(): a code has more nodes than max_nodes_bound = {getattr(self, 'max_nodes_bound', None)}; raise the bound, or set it to "
                                  "None (one host read per call)")
-            raise ValueError("pooled(): the paths without a host read (the two-launch small-width path; max_nodes_bound) need a non-decreasing "
-                             "`batch` vector (PyG-style); sort the nodes by code, or set SMALL_WIDTH_FUSED = False / max_nodes_bound = None")
+            raise ValueError(UNSORTED_BATCH_MESSAGE)
 
     check_small_status = check_status
 
@@ -1182,9 +1220,11 @@ class VectorQuantizer(nn.Module):
         self.search_path = ops.PATH_AUTO
         if not l2_norm:
             raise NotImplementedError("the reference only defines the l2_norm=True path (:147-151,194-200)")
-        if e_dim % 4 or split[0] != e_dim or split[1] != e_dim:
-            raise ValueError("e_dim must be a multiple of 4 and equal both split sizes "
-                             "(the reference's projections map split[i] -> e_dim and search e_dim)")
+        if split[0] != e_dim or split[1] != e_dim:
+            raise ValueError("e_dim must equal both split sizes (the reference's projections map split[i] -> e_dim and search e_dim)")
+        # The kernels read rows as 16-byte groups.  A width that is not a multiple of 4 (the reference takes any e_dim, :91) is searched
+        # with zero COLUMNS appended to rows and codes -- they change no norm, no dot product, no distance -- and sliced off the results.
+        self._pad = (-int(e_dim)) % 4
 
         self.cross_attn = CrossAttention(e_dim, num_head, dropout=0.1, layers=2)
         self.proj_text = nn.Linear(self.split[0], e_dim)
@@ -1245,7 +1285,10 @@ class VectorQuantizer(nn.Module):
 
         def build():
             if not prepare:
-                return _Norm(ops.rownorm(wt.detach()))
+                w_in = wt.detach()
+                if getattr(self, "_pad", 0):
+                    w_in = torch.nn.functional.pad(w_in.float(), (0, self._pad))
+                return _Norm(ops.rownorm(w_in))
             what, wsq, prepared = ops.prepare_codebook(wt.detach(), regions())
             norm = _Norm((what, wsq))
             norm.prepared = prepared
@@ -1322,6 +1365,35 @@ class VectorQuantizer(nn.Module):
         n = x.shape[0]
         x = x.float()                   # autocast callers hand over fp16/bf16; the search is fp32
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.codebook.weight.requires_grad)
+        pad = getattr(self, "_pad", 0)
+        if pad:
+            # e_dim % 4 != 0: rows and codes with zero columns appended (differentiably, where autograd is recording: the slices of
+            # the gradients are autograd's), results sliced back.  The mean-squared losses divide by n * (e_dim + pad) inside: rescaled.
+            e = self.e_dim
+            fpad = torch.nn.functional.pad
+            if norm is None:
+                norm = self._normalised_codebook()
+            what, wsq = norm
+            xp = fpad(x, (0, pad))
+            if training and needs_grad:
+                wp = fpad(self.codebook.weight.float(), (0, pad))
+                zq, vq, commit, xhat, idx, w = _SoftVQFunction.apply(xp, wp[lo:hi], what[lo:hi], wsq[lo:hi].contiguous(), self.k,
+                                                                     self.search_path, float(self.beta))
+                fix = float(e + pad) / float(e)
+                return zq[:, :e], vq * fix, commit * fix, xhat[:, :e], idx, w
+            r = ops.soft_vq_forward(xp.detach(), what[lo:hi], wsq[lo:hi].contiguous(), self.k, self.search_path, want_sqerr=training)
+            if training:
+                vq = ops.sum_scale(r["row_sqerr"], (1.0 / (n * e)) if n else float("nan"))
+                commit = self.beta * vq
+            else:
+                vq, commit = torch.tensor(0.0), torch.tensor(0.0)
+            zq = r["zq"][:, :e]
+            if out is not None:
+                out.copy_(zq)
+                zq = out
+            elif needs_grad and x.requires_grad:
+                zq = zq + (x - x.detach())
+            return zq, vq, commit, r["xhat"][:, :e], r["idx"], r["w"]
         if norm is None:
             norm = self._normalised_codebook(prepare=not training and ops.takes_filter_path(n, hi - lo, x.shape[1], self.k, self.search_path))
         what, wsq = norm
@@ -1346,7 +1418,7 @@ class VectorQuantizer(nn.Module):
     # Per-call state travels in arguments and return values, never on the module: two threads (or two graph captures) may run one
     # module.  What IS shared, by design and as in the reference: the weights, the usage window `codebook_used` (in-place state, part
     # of the state dict) and the caches keyed by weight version (_cached: built once, read-only afterwards).
-    def _shared(self, z_text, z_graph, text_mask, batch, norm=None, usage_counts=None):
+    def _shared(self, z_text, z_graph, text_mask, batch, norm=None, usage_counts=None, verify_batch=True):
         """get_shared_info plus the token ids / weights of its two searches: (embedding, losses, usage, tokens)."""
         # inference: the two searches write their halves of the [B, 2 e_dim] result in place (no torch.cat).  The buffer is
         # allocated HERE, before pooled() forks its side stream: a block the allocator hands out on this stream may still be the
@@ -1361,6 +1433,12 @@ class VectorQuantizer(nn.Module):
             bsz, e = z_text.shape[0], self.e_dim
             if small:
                 both = self.cross_attn.pooled_small(z_text, text_mask, z_graph, batch)                  # [B, 2, e]
+                if verify_batch and not self.cross_attn.assume_sorted_batch and not torch.cuda.is_current_stream_capturing():
+                    # any batch vector, like the reference (`batch == idx`, :135): one 4-byte read of the device checks; an unsorted
+                    # vector runs again on the stably sorted nodes (PyG vectors are sorted: never taken there)
+                    if self.cross_attn.take_status():
+                        z_graph, batch = CrossAttention.sort_by_code(z_graph, batch)
+                        both = self.cross_attn.pooled_small(z_text, text_mask, z_graph, batch)
             else:
                 pooled_text, pooled_graph, pending = self.cross_attn.pooled(z_text, text_mask, z_graph, batch, join=False)
                 if pending is not None:
@@ -1436,15 +1514,27 @@ class VectorQuantizer(nn.Module):
         region = self.codebook.weight.shape[0] // 3
         if not (ops.multi_search_eligible(bsz, region, e, k) and ops.multi_search_eligible(2 * bsz, self.n_e, e, k)):
             return None
+        if self.search_path not in (ops.PATH_AUTO, ops.PATH_F32_MFMA):
+            return None                 # a forced search path or plan bits (bench --path, tests): the general form runs what the caller named
         what, wsq = norm
         z_text, z_graph = torch.split(z, self.split, dim=-1)
         aug = (None, None) if z_aug is None else torch.split(z_aug, self.split, dim=-1)
         emb = torch.empty((bsz, 2 * e), dtype=torch.float32, device=z.device)
-        if self.cross_attn.small_eligible(text_features, graph_node_features):
+        small_attn = self.cross_attn.small_eligible(text_features, graph_node_features)
+        # the two-launch cross-attention needs a sorted `batch` vector and flags anything else on the device; unless the caller
+        # vouches for it (assume_sorted_batch) or a HIP graph is being captured, the flag is read where this forward reads the host
+        # anyway (behind the usage counts: the window kernel does not write the window when it is set) or with one 4-byte read at
+        # the end, and an unsorted vector runs again on the stably sorted nodes -- the reference takes any batch vector (:135)
+        verify = small_attn and not self.cross_attn.assume_sorted_batch and not torch.cuda.is_current_stream_capturing()
+        if small_attn:
             both = self.cross_attn.pooled_small(text_features, text_attention_mask, graph_node_features, batch)
         else:
             pooled_text, pooled_graph = self.cross_attn.pooled(text_features, text_attention_mask, graph_node_features, batch)
             both = torch.stack((pooled_text.float(), pooled_graph.float()), dim=1)
+
+        def again():
+            nodes_s, batch_s = CrossAttention.sort_by_code(graph_node_features, batch)
+            return self._forward_small_batch(z, text_features, nodes_s, text_attention_mask, batch_s, z_aug, norm)
         searches = [dict(x=both.view(2 * bsz, e), what=what, wsq=wsq, out=emb.view(2 * bsz, e))]
         for zz, parts in ((z, (z_text, z_graph)),) + (((z_aug, aug),) if z_aug is not None else ()):
             proj = self.project_both(zz)
@@ -1463,9 +1553,13 @@ class VectorQuantizer(nn.Module):
             # one read: the usage counts and, behind them, the cross-attention's status word (copied there by the window kernel)
             cnt = ops.usage_update_multi_(self.codebook_used, [idx_s.reshape(bsz, 2 * k)] + [r["idx"] for r in res[1:]], self.n_e, extra_word=st)
             vals = cnt.cpu().tolist()
-            if st is not None and vals[-1]:
-                self.cross_attn.check_status()
+            if st is not None and vals[-1] and self.cross_attn.take_status(int(vals[-1])):
+                if not verify:
+                    raise ValueError(UNSORTED_BATCH_MESSAGE)
+                return again()                       # (the window is as it was: ops.usage_update_multi_ skips its write under a set word)
             u_shared, u_text, u_graph = (v / self.n_e for v in vals[:3])
+        elif verify and self.cross_attn.take_status():
+            return again()
         out = {
             "graph_feature": z_graph,
             "text_feature": z_text,
@@ -1560,7 +1654,7 @@ class VectorQuantizer(nn.Module):
                 early = [self._search(self.project(x, types), types, False, norm=norm) for x, types in
                          ((z_text_embedding, "text"), (z_graph_embedding, "graph"), (aug[0], "text"), (aug[1], "graph")) if x is not None]
         shared_embedding, shared_embed_loss, u_shared, tokens = self._shared(
-            text_features, graph_node_features, text_attention_mask, batch, norm=norm, usage_counts=counts)
+            text_features, graph_node_features, text_attention_mask, batch, norm=norm, usage_counts=counts, verify_batch=True)
         shared_text_embedding, shared_graph_embedding = torch.split(shared_embedding, self.split, dim=-1)
         if early is not None:
             _join_side(side, main, [t for r in early for t in r])
@@ -1581,8 +1675,8 @@ class VectorQuantizer(nn.Module):
             st = getattr(self.cross_attn, "small_status", None)
             if st is not None and st.device == counts[0].device:          # one read for the usage counts and the small path's status word
                 vals = torch.cat([torch.stack(counts[:3]), st[:1]]).cpu()
-                if int(vals[3]):
-                    self.cross_attn.check_status()
+                if int(vals[3]) and self.cross_attn.take_status(int(vals[3])):      # (assume_sorted_batch / max_nodes_bound callers only)
+                    raise ValueError(UNSORTED_BATCH_MESSAGE)
                 u_shared, u_text, u_graph = (vals[:3].double() / self.n_e).tolist()
             else:
                 u_shared, u_text, u_graph = (torch.stack(counts[:3]).cpu().double() / self.n_e).tolist()

@@ -64,8 +64,8 @@ def gaps64(xn, wn, k):
     return torch.sort(d, dim=1).values[:, : k + 1]
 
 
-def make_soft(sq, n_e, e_dim, k=5, beta=0.25, seed=0, tag="vq"):
-    q = sq.VectorQuantizer(n_e, e_dim, beta, 0.0, True, True, [e_dim, e_dim], k=k)
+def make_soft(sq, n_e, e_dim, k=5, beta=0.25, seed=0, tag="vq", num_head=4):
+    q = sq.VectorQuantizer(n_e, e_dim, beta, 0.0, True, True, [e_dim, e_dim], num_head=num_head, k=k)
     q.load_state_dict(synth.det_state_dict(q, tag, seed))
     q.codebook_used.requires_grad_(False)
     for layer in q.cross_attn.model:      # deterministic train-mode fixtures
@@ -86,10 +86,10 @@ def ref_tokens(q, x_proj, region):
     return i, torch.softmax(-v, dim=1), v, gaps64(xn, wn, q.k)
 
 
-def fixture_specific(sq, name, N, D, n_e, seed):
-    q = make_soft(sq, n_e, D, seed=seed, tag=name)
+def fixture_specific(sq, name, N, D, n_e, seed, k=5, num_head=4):
+    q = make_soft(sq, n_e, D, k=k, seed=seed, tag=name, num_head=num_head)
     x = synth.det_randn(name + ".x", (N, D), 1.0, seed)
-    out = {"x": x, "n_e": n_e, "e_dim": D, "k": q.k, "beta": q.beta, "seed": seed}
+    out = {"x": x, "n_e": n_e, "e_dim": D, "k": q.k, "beta": q.beta, "seed": seed, "num_head": num_head}
     for types_ in ("text", "graph"):
         proj = q.proj_text if types_ == "text" else q.proj_graph
         # eval
@@ -117,12 +117,12 @@ def fixture_specific(sq, name, N, D, n_e, seed):
     npz(name, **out)
 
 
-def fixture_forward(sq, name, B, L, max_nodes, D, n_e, seed, train_too=True, store_inputs=True):
-    q = make_soft(sq, n_e, D, seed=seed, tag=name)
+def fixture_forward(sq, name, B, L, max_nodes, D, n_e, seed, train_too=True, store_inputs=True, k=5, num_head=4):
+    q = make_soft(sq, n_e, D, k=k, seed=seed, tag=name, num_head=num_head)
     text, mask, nodes, batch = synth.ragged_batch(name + ".batch", B, L, max_nodes, D, seed)
     z = synth.det_randn(name + ".z", (B, 2 * D), 1.0, seed)
     z_aug = synth.det_randn(name + ".z_aug", (B, 2 * D), 1.0, seed)
-    out = {"n_e": n_e, "e_dim": D, "k": q.k, "beta": q.beta, "seed": seed, "B": B, "L": L, "max_nodes": max_nodes}
+    out = {"n_e": n_e, "e_dim": D, "k": q.k, "beta": q.beta, "seed": seed, "B": B, "L": L, "max_nodes": max_nodes, "num_head": num_head}
     if store_inputs:
         out.update({"z": z, "z_aug": z_aug, "text": text, "mask": mask, "nodes": nodes, "batch": batch})
     q.eval()
@@ -391,9 +391,21 @@ def fixture_state_dict_keys(sq, name):
         n_e=96, e_dim=16)
 
 
+def round6(sq):
+    """The reference takes any k and any e_dim (vector_quantization_soft_one_new.py:91): k above the kernels' list length of 8, a width
+    that is not a multiple of 4 (with a head count that divides it), and k > 8 through the whole forward incl. its gradients."""
+    fixture_specific(sq, "f20_specific_k12", N=128, D=64, n_e=600, seed=20, k=12)
+    fixture_specific(sq, "f21_specific_k16_d768", N=48, D=768, n_e=384, seed=21, k=16)
+    fixture_forward(sq, "f22_forward_d70", B=12, L=16, max_nodes=8, D=70, n_e=300, seed=22, num_head=2)
+    fixture_forward(sq, "f23_forward_k9", B=16, L=12, max_nodes=9, D=64, n_e=300, seed=23, k=9)
+
+
 def main():
     torch.set_num_threads(8)
     sq, nq, ls = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "--round6-only":        # added in round 6 (generic k and width, SURVEY R7): the rest are unchanged
+        round6(sq)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--round4-only":        # added in round 4: the rest are unchanged
         fixture_kmeans(nq, "f17_kmeans_half", N=2048, D=64, K=48, seed=24, half=True)
         # the reference's own default shape (train_MedTok.py:363-368: e_dim = 64, n_e = 21000, k = 5; regions of 7000 codes)
@@ -436,6 +448,7 @@ def main():
     fixture_cfg3_slice(sq, "f14_cfg3_slice", N=16384, D=768, n_e=49152, seed=14)
     fixture_cfg3_slice(sq, "f18_refdefault_slice", N=16384, D=64, n_e=21000, seed=18)
     fixture_forward(sq, "f19_forward_b64", B=64, L=20, max_nodes=10, D=128, n_e=768, seed=19)
+    round6(sq)
     # BASELINE config 1: 1k codes, 768-d, K=8192 -- inputs regenerated from the seeded recipe
     fixture_forward(sq, "cfg1_inference_1k", B=1000, L=8, max_nodes=6, D=768, n_e=8192, seed=11,
                     train_too=False, store_inputs=False)

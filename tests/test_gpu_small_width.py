@@ -87,6 +87,75 @@ def test_small_width_path_flags_an_unsorted_batch_vector(dev):
         ca.check_small_status()
 
 
+@pytest.mark.parametrize("show_usage", [False, True])
+@pytest.mark.parametrize("bsz", [256, 3000])
+def test_forward_takes_any_batch_vector_like_the_reference(dev, show_usage, bsz):
+    """The reference selects a code's nodes with `batch == idx` (vector_quantization_soft_one_new.py:135): any batch vector works.  The
+    two-launch cross-attention needs a sorted one; by default the forward verifies the device-side check and runs an unsorted vector
+    again on the stably sorted nodes -- every output, the usage values AND the usage window equal the forward on nodes the caller
+    sorted himself, bit for bit (the first, flagged pass must not have written the window).  bsz = 256: the small-batch form (status
+    read with the usage counts / at the end); bsz = 3000: the general form (status read behind the cross-attention).
+    assume_sorted_batch = True restores the unchecked behaviour: the flag stays on the device for check_status()."""
+    from medtok_amd.vector_quantization_soft_one_new import CrossAttention, UNSORTED_BATCH_MESSAGE
+    vq_a, vq_b = _quantizer(dev, show_usage), _quantizer(dev, show_usage)
+    z, text, nodes, mask, batch = _forward_inputs(dev, bsz=bsz, seq_len=64, max_nodes=12)
+    perm = torch.randperm(batch.numel(), device=dev)
+    nodes_p, batch_p = nodes[perm], batch[perm]
+    nodes_s, batch_s = CrossAttention.sort_by_code(nodes_p, batch_p)
+    with torch.no_grad():
+        for step in range(2):                    # twice: the window of step 1 feeds the usage values of step 2
+            got = vq_a(z, text, nodes_p, mask, batch_p)
+            want = vq_b(z, text, nodes_s, mask, batch_s)
+            for k, v in want.items():
+                if isinstance(v, torch.Tensor):
+                    assert torch.equal(got[k], v), (k, step)
+                elif isinstance(v, float):
+                    assert got[k] == v, (k, step, got[k], v)
+            if show_usage:
+                assert torch.equal(vq_a.codebook_used, vq_b.codebook_used), step
+        vq_a.cross_attn.check_status()           # nothing left behind
+        # ids outside [0, B) still raise what pooled() raises
+        bad = batch_s.clone()
+        bad[-1] = bsz
+        with pytest.raises(ValueError, match="outside"):
+            vq_a(z, text, nodes_s, mask, bad)
+            vq_a.cross_attn.check_status()
+        # the opt-out: nothing is verified, the flag waits for check_status()
+        vq_a.cross_attn.assume_sorted_batch = True
+        try:
+            if show_usage:
+                with pytest.raises(ValueError, match="non-decreasing"):
+                    vq_a(z, text, nodes_p, mask, batch_p)
+            else:
+                vq_a(z, text, nodes_p, mask, batch_p)
+                with pytest.raises(ValueError, match="non-decreasing"):
+                    vq_a.cross_attn.check_status()
+        finally:
+            vq_a.cross_attn.assume_sorted_batch = False
+    assert "non-decreasing" in UNSORTED_BATCH_MESSAGE
+
+
+def test_a_forced_search_path_is_not_replaced_by_the_batched_small_searches(dev):
+    """A module whose search path was forced (bench --path, plan bits) runs the kernel the caller named, whatever the batch size: the
+    batched exact small-batch searches are taken under PATH_AUTO / PATH_F32_MFMA only (same ids either way: the paths agree bit for bit)."""
+    from medtok_amd import ops
+    vq = _quantizer(dev)
+    inp = _forward_inputs(dev)
+    with torch.no_grad():
+        auto = vq(*inp)
+        ops.profile_begin()
+        vq.search_path = ops.PATH_F16_FILTER
+        try:
+            forced = vq(*inp)
+        finally:
+            vq.search_path = ops.PATH_AUTO
+        torch.cuda.synchronize()
+        prof = ops.profile_end()
+    assert prof["filter_f16_kernel"]["launches"] >= 3, prof["filter_f16_kernel"]
+    for k in ("text_tokens", "graph_tokens", "shared_text_tokens", "shared_graph_tokens", "specific_embedding_text", "shared_text_embedding"):
+        assert torch.equal(auto[k], forced[k]), k
+
+
 def _quantizer(dev, show_usage=False):
     from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
     torch.manual_seed(1)

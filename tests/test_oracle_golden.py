@@ -15,7 +15,7 @@ def rel(a, b):
     return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(b).max(), 1e-30))
 
 
-@pytest.mark.parametrize("name", ["f1_specific_d64", "f2_specific_d768"])
+@pytest.mark.parametrize("name", ["f1_specific_d64", "f2_specific_d768", "f20_specific_k12", "f21_specific_k16_d768"])
 def test_specific_embedding(oracle, golden, name):
     g = golden(name)
     n_e, D, k, seed = int(g["n_e"]), int(g["e_dim"]), int(g["k"]), int(g["seed"])
@@ -104,7 +104,7 @@ def test_edge_cases(oracle):
 
 
 # ---- the torch op-sequence port used as bench.py's cpu_baseline is pinned to the same vectors
-@pytest.mark.parametrize("name", ["f1_specific_d64", "f2_specific_d768"])
+@pytest.mark.parametrize("name", ["f1_specific_d64", "f2_specific_d768", "f20_specific_k12", "f21_specific_k16_d768"])
 def test_torch_port_specific(golden, name):
     import torch
     from oracle import torch_port as P
@@ -133,7 +133,7 @@ def test_torch_port_norm_ema(golden, name):
         assert abs(float(loss) - g[f"s{s}.loss"]) <= RTOL * g[f"s{s}.loss"]
 
 
-@pytest.mark.parametrize("name", ["f1_specific_d64", "f2_specific_d768"])
+@pytest.mark.parametrize("name", ["f1_specific_d64", "f2_specific_d768", "f20_specific_k12", "f21_specific_k16_d768"])
 def test_soft_backward_matches_reference_gradients(oracle, golden, name):
     """oracle.soft_vq_backward + segment sum + normalize_backward == the gradients the reference's autograd
     produced for loss = vq + commit + (zq_ste * probe).sum() / N (oracle/gen_golden.py::fixture_specific)."""
