@@ -304,7 +304,8 @@ int medtok_scale_by_device_scalar_f32(const float *x, int64_t count, const float
  * over the code's own query rows [q_start[b], +q_len[b]) of q and key rows [kv_start[b], +kv_len[b]) of kv
  * (raw rows of the other modality; every head is just another query row).  Nothing is padded and the
  * rows x keys matrix never reaches memory.  max_q_len >= max_b q_len[b] sizes the grid (rows beyond a
- * code's q_len cost nothing); d = 64 or d % 128 == 0, d <= 768.  A code with kv_len == 0 attends to nothing: its
+ * code's q_len cost nothing); d = 64 or d % 128 == 0, d <= 768 (d = 1024 -- BERT-large features -- with exact_f32 = 0 and
+ * max_q_len <= 4 only: wider query sets at that width take medtok_shared_kv_attention_split_f32).  A code with kv_len == 0 attends to nothing: its
  * rows are zero (the reference's per-code loop would take a softmax over an empty set there).
  * q_start/q_len/kv_start/kv_len are DEVICE int64[n_codes]; any number of codes per call.
  * exact_f32 = 0 (what the modules use at inference): both products on the fp16 matrix pipe as three MFMAs over (hi, lo) fp16
@@ -323,8 +324,8 @@ int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_start, const
 /* The same core for wide inference batches: 64 query rows per block and the keys given as the (hi, lo) fp16 images of
  * medtok_split_half_f32 (kv_hi / kv_lo [Rk, d], made once per forward: a key row serves every query tile of its code and both
  * layers), copied into LDS by DMA -- no per-block conversion, half the key traffic per query row.  Same arithmetic as
- * medtok_shared_kv_attention_f32 with exact_f32 = 0 (three fp16 MFMA passes per product, fp32 softmax); d = 128, 256, 384, 512 or
- * 768.  Rows of the images that no (kv_start, kv_len) range covers are never read. */
+ * medtok_shared_kv_attention_f32 with exact_f32 = 0 (three fp16 MFMA passes per product, fp32 softmax); d = 128, 256, 384, 512, 768
+ * or 1024 (32 rows per block there, whatever `variant`).  Rows of the images that no (kv_start, kv_len) range covers are never read. */
 int medtok_shared_kv_attention_split_f32(const float *q, const int64_t *q_start, const int64_t *q_len,
                                          const void *kv_hi, const void *kv_lo, const int64_t *kv_start, const int64_t *kv_len,
                                          int64_t n_codes, int64_t max_q_len, int d, float scale, float *out,
@@ -361,8 +362,16 @@ int medtok_debug_filter_probe(const float *xhat, const float *xsq, int64_t n, co
  * Wo^T [in][out] | bq | bv | bo | ln gamma | ln beta | 64 unused; y_nodes [n_nodes, 64]: the attended node rows (scratch the
  * mean reads).  status: int32 [4] the CALLER zeroes once; the kernels OR bit 0 (batch vector not sorted) / bit 1 (id outside
  * [0, n_codes)) into word 0 -- results are then undefined for the codes involved, but every access stays in bounds.
- * fp32 throughout: FMAs for the 64 x 64 products, v_mfma_f32_32x32x2_f32 (exact fmaf chains) for the attention core. */
+ * The 64 x 64 products are fp32 FMAs; the attention core runs on v_mfma_f32_32x32x16_f16 as three passes over (hi, lo) fp16 pairs
+ * (a_hi b_hi + a_hi b_lo + a_lo b_hi: ~2^-22 relative, fp32 accumulation and softmax -- the wide kernels' arithmetic; within the
+ * 1e-5 bar of the attention outputs.  Inputs are expected in fp16 range, |x| < 65504, like the wide inference kernels'). */
 int medtok_cross_attention_small_f32(const float *text, const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len,
+                                     const float *nodes, const int64_t *batch, int64_t n_nodes, int d, int heads, int layers,
+                                     const float *weights, float scale, float ln_eps, float *y_nodes, float *pooled,
+                                     int64_t pooled_stride, int64_t graph_off, int32_t *status, void *stream);
+/* Test hook: the same call with the attention core on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fmaf chains) instead of the
+ * three-pass split-fp16 core the entry point above runs -- a second opinion for the tests */
+int medtok_debug_cross_attention_small_exact_f32(const float *text, const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len,
                                      const float *nodes, const int64_t *batch, int64_t n_nodes, int d, int heads, int layers,
                                      const float *weights, float scale, float ln_eps, float *y_nodes, float *pooled,
                                      int64_t pooled_stride, int64_t graph_off, int32_t *status, void *stream);

@@ -97,6 +97,7 @@ SIGNATURES = {
                                                 _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp,
                                                 _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _f, _int, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "medtok_cross_attention_small_f32": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _vp, _i64, _int, _int, _int, _vp, _f, _f, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "medtok_debug_cross_attention_small_exact_f32": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _vp, _i64, _int, _int, _int, _vp, _f, _f, _vp, _vp, _i64, _i64, _vp, _vp]),
     "medtok_segment_mean_f32": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp]),
     "medtok_filter_image_width": (_int, [_int]),
     "medtok_rownorm_image_f32": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _i64, _int, _vp]),

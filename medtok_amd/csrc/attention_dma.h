@@ -56,7 +56,8 @@ struct AttDma {
 };
 
 template <int W, int NT, int MT, int RING>
-__global__ __launch_bounds__(64 * W, (MT == 1 ? 2 : 1) * W / 4) void shared_kv_attention_dma_kernel(
+// (<4, 8, 1, 2>, D = 1024: 128 registers of query operands + 128 of accumulators per lane -- one wave per SIMD, arch + acc registers)
+__global__ __launch_bounds__(64 * W, (MT == 1 && W * NT <= 24 ? 2 : 1) * W / 4) void shared_kv_attention_dma_kernel(
     const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
     const _Float16 *__restrict__ kvh, const _Float16 *__restrict__ kvl, const int64_t *__restrict__ kv_start,
     const int64_t *__restrict__ kv_len, float scale, float *__restrict__ out, _Float16 *__restrict__ out_h, _Float16 *__restrict__ out_l,

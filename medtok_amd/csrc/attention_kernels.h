@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_f16s_kernel(
 // 4 l + 256 t of its <= NQ query rows and output rows in registers, the keys stream through once (the next key's loads in
 // flight under the current key's arithmetic), scores are plain fp32 dot products (per lane in increasing column order, then the
 // row-of-16 DPP butterfly and the four row sums in a fixed order), online softmax per key.  No LDS, no barrier, no matrix pipe:
-// fp32 FMA arithmetic (more accurate than the three-pass fp16 form; the same tolerance class).  d % 4 == 0, d <= 768.
+// fp32 FMA arithmetic (more accurate than the three-pass fp16 form; the same tolerance class).  d % 4 == 0, d <= 256 CT.
 __device__ __forceinline__ float fewq_wave_sum(float v)
 {
     v += att_dpp<0xB1>(v);
@@ -550,13 +550,12 @@ __device__ __forceinline__ float fewq_wave_sum(float v)
            (__uint_as_float((unsigned)__builtin_amdgcn_readlane(i, 32)) + __uint_as_float((unsigned)__builtin_amdgcn_readlane(i, 48)));
 }
 
-template <int NQ>
+template <int NQ, int CT = 3>                                 // CT column chunks of 256 per lane: 3 (d <= 768), 4 (d <= 1024)
 __global__ __launch_bounds__(256) void shared_kv_attention_fewq_kernel(
     const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
     const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
     long n_codes, int d, float scale, float *__restrict__ out, _Float16 *__restrict__ out_h, _Float16 *__restrict__ out_l)
 {
-    constexpr int CT = 3;                                     // column chunks of 256 per lane (d <= 768)
     const int lane = threadIdx.x & 63;
     const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= n_codes) return;

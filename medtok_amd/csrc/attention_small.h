@@ -17,10 +17,18 @@
 //     att_h = Wv_h ctx_h + bv_h, out_proj, residual + LayerNorm.  The five small dense steps are fp32 FMAs with lane = output column
 //     (64 columns = one wavefront; the weights arrive transposed where that makes the loads coalesced: one 256-byte line per wave
 //     and k, L2-resident); cross-wave partial sums meet in LDS.
-//   * attention core on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fmaf chains, no precision argument to make), keys as
-//     the A rows: S^T = K qf^T leaves every lane with 16 keys of ONE query row, so the online softmax is lane-local (its partner
-//     half-wave by v_permlane32_swap), and the probabilities it ends with ARE the B operand of the second product
-//     ctx^T += K^T P^T -- the contraction runs over the keys in the order the accumulator registers hold them.  The four waves of
+//   * attention core with keys as the A rows: S^T = K qf^T leaves every lane with 16 keys of ONE query row, so the online softmax
+//     is lane-local (its partner half-wave by v_permlane32_swap), and the probabilities it ends with ARE the B operand of the second
+//     product ctx^T += K^T P^T -- the contraction runs over the keys in the order the accumulator registers hold them.
+//     SPLIT = true (the product; round 6): both products on the fp16 matrix pipe as three passes over (hi, lo) pairs
+//     (v_mfma_f32_32x32x16_f16: a_hi b_hi + a_hi b_lo + a_lo b_hi, ~2^-22 relative -- the arithmetic of the wide kernels,
+//     attention_dma.h; 24 MFMAs of 32 cycles per 32-key chunk where the fp32 pipe needs 64 of 64 cycles).  A wave parks its chunk as
+//     (hi, lo) fp16 images [column block of 32][key][64 B] with the 16-byte pieces XOR-swizzled by f(key >> 2) (attention_dma.h's
+//     image: conflict-free for both operand shapes); the score product reads key rows in the order "key bits 2 and 3 swapped", so
+//     that the 8 probabilities a lane holds per 16-key step belong to 8 CONSECUTIVE keys -- exactly the 8 keys ds_read_b64_tr_b16
+//     delivers per column for the value product's A operand, and the probabilities go from the accumulator registers to the B
+//     operand in the order they stand.  SPLIT = false: the round-5 core on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32: exact fmaf
+//     chains), kept as medtok_debug_cross_attention_small_exact_f32 -- the tests' second opinion.  The four waves of
 //     a block walk the key chunks (32 keys) round-robin, each with its own running maximum / sum / context, and merge at the end of
 //     the layer; no block-wide barrier inside the key loop.  A wave prefetches its next chunk into registers under the MFMAs of
 //     the current one and parks it in its own LDS slice (rows padded to 68 floats: conflict-free for both operand shapes).
@@ -81,6 +89,15 @@ __device__ __forceinline__ long xs_lower_bound(const int64_t *__restrict__ batch
     return lo;
 }
 
+typedef __fp16 xs_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+__device__ __forceinline__ void xs_split4(const float4 v, half4v &h, half4v &l)
+{
+    h = (half4v){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    l = (half4v){(_Float16)(v.x - (float)h[0]), (_Float16)(v.y - (float)h[1]), (_Float16)(v.z - (float)h[2]), (_Float16)(v.w - (float)h[3])};
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void cross_attention64_kernel(XSmallArgs a)
 {
     // ---- LDS
@@ -175,6 +192,22 @@ __global__ __launch_bounds__(256, 2) void cross_attention64_kernel(XSmallArgs a)
 
     // ---- MFMA helpers (v_mfma_f32_32x32x2_f32: A [32 x 2], B [2 x 32]; lane (i, k) holds A[i][k] / B[k][i])
     const float *kvw = &s_kv[wv][0][0];
+    // SPLIT: the wave's key chunk as fp16 images in the same bytes: [plane hi | lo : 4 KB][column block of 32 : 2 KB][key : 64 B],
+    // 16-byte piece p of a key row at position p ^ f(key >> 2), f(x) = -x & 3
+    char *kimg = reinterpret_cast<char *>(&s_kv[wv][0][0]);
+    const int pk = (li & 19) | ((li & 8) >> 1) | ((li & 4) << 1);           // score product: A row li = key "li with bits 2 and 3 swapped"
+    const int a1_off = pk * 64 + ((lh ^ ((0 - (pk >> 2)) & 3)) << 4);       // its 16-byte piece of k step 0 (k step 1: position ^ 2; steps 2, 3: next block)
+    int v_off[2];                                                           // value product: this lane's piece of the two transposed reads
+    {
+        const int g = lane >> 4, tt = lane & 15;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int key = 8 * (g >> 1) + 4 * rd + (tt >> 2);
+            const int pos = (2 * (g & 1) + ((tt & 3) >> 1)) ^ ((0 - (key >> 2)) & 3);
+            v_off[rd] = key * 64 + pos * 16 + 8 * (tt & 1);
+        }
+    }
+    const int park_blk = ((lane & 15) >> 3) * 2048 + 8 * (lane & 1), park_piece = (lane & 7) >> 1, park_row = lane >> 4;
 
     for (int layer = 0; layer < a.layers; ++layer) {
         const float *W = a.weights + (long)layer * XS_LAYER_FLOATS;
@@ -230,8 +263,20 @@ __global__ __launch_bounds__(256, 2) void cross_attention64_kernel(XSmallArgs a)
         // ---- the attention core, one pass per code the tile touches
         // the queries as B operands: lane (row li, half lh) holds qf[li][8 g + 4 lh + e], g = 0..7, e = 0..3
         float4 qb[8];
+        half8 qbh[4], qbl[4];           // SPLIT: (hi, lo) of qf[li][16 ks + 8 lh + e], ks = 0..3
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int g = 0; g < 8; ++g) qb[g] = *reinterpret_cast<const float4 *>(&s_qf[li][8 * g + 4 * lh]);
+            for (int ks = 0; ks < 4; ++ks) {
+                half4v h0, l0, h1, l1;
+                xs_split4(*reinterpret_cast<const float4 *>(&s_qf[li][16 * ks + 8 * lh]), h0, l0);
+                xs_split4(*reinterpret_cast<const float4 *>(&s_qf[li][16 * ks + 8 * lh + 4]), h1, l1);
+                qbh[ks] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                qbl[ks] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) qb[g] = *reinterpret_cast<const float4 *>(&s_qf[li][8 * g + 4 * lh]);
+        }
 
         for (int sg = 0; sg < nseg; ++sg) {
             const long code = s_seg[sg][0];
@@ -255,28 +300,48 @@ __global__ __launch_bounds__(256, 2) void cross_attention64_kernel(XSmallArgs a)
             if (wv < nchunk) { XS_FETCH(wv) }
             for (int c = wv; c < nchunk; c += 4) {
                 // park the fetched chunk in this wave's LDS slice (the previous chunk's readers -- this wave -- are done)
-#define XS_PARK(q, src) *reinterpret_cast<float4 *>(&s_kv[wv][4 * (q) + (lane >> 4)][4 * (lane & 15)]) = src;
-                XS_PARK(0, pf0) XS_PARK(1, pf1) XS_PARK(2, pf2) XS_PARK(3, pf3) XS_PARK(4, pf4) XS_PARK(5, pf5) XS_PARK(6, pf6) XS_PARK(7, pf7)
-#undef XS_PARK
-                if (c + 4 < nchunk) { XS_FETCH(c + 4) }
-                // ---- S^T [32 keys x 32 rows] = K qf^T: A = keys (lane: key li, columns 8 g + 4 lh + e)
                 f32x16 sacc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+                if constexpr (SPLIT) {
+                    // fetch register q holds key row 4 q + (lane >> 4), columns 4 (lane & 15) ..+3: 8 bytes of each image
+#define XS_PARK(q, src) { half4v h_, l_; xs_split4(src, h_, l_);                                                                           \
+                          char *p_ = kimg + park_blk + (4 * (q) + park_row) * 64 + ((park_piece ^ ((0 - (q)) & 3)) << 4);                  \
+                          *reinterpret_cast<half4v *>(p_) = h_; *reinterpret_cast<half4v *>(p_ + 4096) = l_; }
+                    XS_PARK(0, pf0) XS_PARK(1, pf1) XS_PARK(2, pf2) XS_PARK(3, pf3) XS_PARK(4, pf4) XS_PARK(5, pf5) XS_PARK(6, pf6) XS_PARK(7, pf7)
+#undef XS_PARK
+                    if (c + 4 < nchunk) { XS_FETCH(c + 4) }
+                    // ---- S^T [32 keys x 32 rows] = K qf^T on 32x32x16: A = key rows in the order pk(li), 8 consecutive columns per lane
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const float4 ka = *reinterpret_cast<const float4 *>(kvw + li * XS_LD + 8 * g + 4 * lh);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.x, qb[g].x, sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, qb[g].y, sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.z, qb[g].z, sacc, 0, 0, 0);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.w, qb[g].w, sacc, 0, 0, 0);
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const char *ap = kimg + (ks >> 1) * 2048 + ((ks & 1) ? (a1_off ^ 32) : a1_off);
+                        const half8 ah = *reinterpret_cast<const half8 *>(ap), al = *reinterpret_cast<const half8 *>(ap + 4096);
+                        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qbh[ks], sacc, 0, 0, 0);
+                        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qbl[ks], sacc, 0, 0, 0);
+                        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qbh[ks], sacc, 0, 0, 0);
+                    }
+                } else {
+#define XS_PARK(q, src) *reinterpret_cast<float4 *>(&s_kv[wv][4 * (q) + (lane >> 4)][4 * (lane & 15)]) = src;
+                    XS_PARK(0, pf0) XS_PARK(1, pf1) XS_PARK(2, pf2) XS_PARK(3, pf3) XS_PARK(4, pf4) XS_PARK(5, pf5) XS_PARK(6, pf6) XS_PARK(7, pf7)
+#undef XS_PARK
+                    if (c + 4 < nchunk) { XS_FETCH(c + 4) }
+                    // ---- S^T [32 keys x 32 rows] = K qf^T: A = keys (lane: key li, columns 8 g + 4 lh + e)
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const float4 ka = *reinterpret_cast<const float4 *>(kvw + li * XS_LD + 8 * g + 4 * lh);
+                        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.x, qb[g].x, sacc, 0, 0, 0);
+                        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, qb[g].y, sacc, 0, 0, 0);
+                        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.z, qb[g].z, sacc, 0, 0, 0);
+                        sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.w, qb[g].w, sacc, 0, 0, 0);
+                    }
                 }
-                // ---- online softmax of row li over the chunk's keys: this lane holds keys (r & 3) + 8 (r >> 2) + 4 lh, its partner the rest
-                const long kfirst = (long)32 * c + 4 * lh;
+                // ---- online softmax of row li over the chunk's keys: this lane holds keys (r & 3) + 8 (r >> 2) + 4 lh (SPLIT: with the
+                // permuted key rows, (r & 7) + 16 (r >> 3) + 8 lh), its partner half-wave the rest
+                const long kfirst = (long)32 * c + (SPLIT ? 8 : 4) * lh;
                 float mx = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const bool valid = kfirst + (r & 3) + 8 * (r >> 2) < klen;
+                    const bool valid = kfirst + (SPLIT ? (r & 7) + 16 * (r >> 3) : (r & 3) + 8 * (r >> 2)) < klen;
                     sacc[r] = valid ? sacc[r] : -INFINITY;
                     mx = fmaxf(mx, sacc[r]);
                 }
@@ -295,12 +360,40 @@ __global__ __launch_bounds__(256, 2) void cross_attention64_kernel(XSmallArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { ctx0[r] *= alpha; ctx1[r] *= alpha; }
                 // ---- ctx^T [64 columns x 32 rows] += K^T P^T: contraction index of step s = the key register s holds
+                if constexpr (SPLIT) {
+                    // two k steps of 16 keys: B = the probabilities of keys 16 s + 8 lh + e = registers 8 s + e, as (hi, lo);
+                    // A = K^T: 8 consecutive keys of column li (+ 32 per tile), two transposed reads of 4 keys per image
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int key = (s & 3) + 8 * (s >> 2) + 4 * lh;
-                    const float a0 = kvw[key * XS_LD + li], a1 = kvw[key * XS_LD + 32 + li];
-                    ctx0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, sacc[s], ctx0, 0, 0, 0);
-                    ctx1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, sacc[s], ctx1, 0, 0, 0);
+                    for (int ss = 0; ss < 2; ++ss) {
+                        half8 ph_, pl_;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            ph_[e] = (_Float16)sacc[8 * ss + e];
+                            pl_[e] = (_Float16)(sacc[8 * ss + e] - (float)ph_[e]);
+                        }
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const char *vb = kimg + t * 2048 + ss * 1024;
+                            typedef __attribute__((address_space(3))) xs_fp16x4 *lptr;
+                            const half4v h0 = __builtin_bit_cast(half4v, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lptr)(vb + v_off[0])));
+                            const half4v h1 = __builtin_bit_cast(half4v, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lptr)(vb + v_off[1])));
+                            const half4v l0 = __builtin_bit_cast(half4v, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lptr)(vb + 4096 + v_off[0])));
+                            const half4v l1 = __builtin_bit_cast(half4v, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lptr)(vb + 4096 + v_off[1])));
+                            const half8 kh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), kl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                            f32x16 &cx = t ? ctx1 : ctx0;
+                            cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, ph_, cx, 0, 0, 0);
+                            cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, pl_, cx, 0, 0, 0);
+                            cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ph_, cx, 0, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const int key = (s & 3) + 8 * (s >> 2) + 4 * lh;
+                        const float a0 = kvw[key * XS_LD + li], a1 = kvw[key * XS_LD + 32 + li];
+                        ctx0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, sacc[s], ctx0, 0, 0, 0);
+                        ctx1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, sacc[s], ctx1, 0, 0, 0);
+                    }
                 }
             }
 #undef XS_FETCH

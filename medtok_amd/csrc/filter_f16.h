@@ -59,7 +59,9 @@ constexpr float F_PRESCALE = 256.0f;                          // 2^8 on both ope
 constexpr float F_UNSCALE = 1.0f / 65536.0f;
 constexpr float F_NORM_LIMIT = 4.0f;                          // |x|^2, |e|^2 above this -> exact path
 constexpr int R_ROWS = 32;                                    // rows per re-score block (8 lanes each)
-constexpr int R_SURV = 64;                                    // survivors per row the re-score kernel can hold
+// survivors per row the re-score kernel can hold: 28.7 KB of LDS per 32-row block = five blocks per CU, what its 90 VGPRs allow anyway
+// (64 until round 6: a row next to a cluster of ~100 near-identical codes keeps them all -- bench.py --data clustered_codebook)
+constexpr int R_SURV = 112;
 
 __host__ __device__ inline float filter_gamma(int d) { return 0x1p-10f + 0x1p-20f + (float)d * 0x1p-22f; }
 
@@ -1596,6 +1598,7 @@ __global__ __launch_bounds__(8 * RR) void rescore_kernel(
 // with lane = owner, four entry indices in flight at a time; the lines of the survivors' code rows are all requested before the
 // first chain starts.  Same candidates, same exact chains, same (d, index) selection and fused assignment as
 // rescore_kernel: the same bits.  own_total, own_tail <= 64.
+constexpr int RW_SURV = 64;                                  // survivors of a row in rescore_wave_kernel: one lane each
 constexpr int RW_XMAX = 1032;                                // widest row whose x the wave keeps in LDS (the library's widest: 1028)
 template <int TOPK>
 __global__ __launch_bounds__(256) void rescore_wave_kernel(
@@ -1606,7 +1609,7 @@ __global__ __launch_bounds__(256) void rescore_wave_kernel(
     int64_t *__restrict__ out_idx, float *__restrict__ out_dist, int *__restrict__ fb_count, int *__restrict__ fb_rows,
     const float *__restrict__ xref, float *__restrict__ w_out, float *zq_out, long zq_stride)
 {
-    __shared__ int s_code[4][R_SURV];
+    __shared__ int s_code[4][RW_SURV];
     __shared__ __attribute__((aligned(16))) float s_x[4][RW_XMAX];      // the wave's x row (the chains' common operand), d <= RW_XMAX
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long row = (long)blockIdx.x * 4 + wv;
@@ -1666,11 +1669,11 @@ __global__ __launch_bounds__(256) void rescore_wave_kernel(
         for (int u = 0; u < 4; ++u) {
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(pass[u]);
             const int p = nsurv + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-            if (pass[u] && p < R_SURV) s_code[wv][p] = (int)e[u].y;
+            if (pass[u] && p < RW_SURV) s_code[wv][p] = (int)e[u].y;
             nsurv += __builtin_popcountll(bal);
         }
     }
-    if (nsurv > R_SURV) {                              // more survivors than the list holds: exact path
+    if (nsurv > RW_SURV) {                              // more survivors than the list holds: exact path
         if (lane == 0) fb_rows[atomicAdd(fb_count, 1)] = (int)row;
         return;
     }

@@ -2023,7 +2023,11 @@ static int attention_forward_f16s(const float *q, const int64_t *q_start, const 
     if (max_q_len <= 8) {
         // a few query rows per code (the text side: one row per head): one wavefront per code, plain fp32 (attention_kernels.h)
         const dim3 fgrid((unsigned)((n_codes + 3) / 4));
-        if (max_q_len <= 4)
+        if (d > 768) {          // (D = 1024, e.g. BERT-large text features: four column chunks per lane; at most 4 query rows fit the registers)
+            if (max_q_len > 4) return fail("shared_kv_attention: d=%d takes at most 4 query rows per code on this path (heads <= 4)", d);
+            hipLaunchKernelGGL((shared_kv_attention_fewq_kernel<4, 4>), fgrid, dim3(256), 0, s, q, q_start, q_len, kv, kv_start, kv_len, (long)n_codes, d, scale,
+                               out, out_h, out_l);
+        } else if (max_q_len <= 4)
             hipLaunchKernelGGL(shared_kv_attention_fewq_kernel<4>, fgrid, dim3(256), 0, s, q, q_start, q_len, kv, kv_start, kv_len, (long)n_codes, d, scale,
                                out, out_h, out_l);
         else
@@ -2032,6 +2036,7 @@ static int attention_forward_f16s(const float *q, const int64_t *q_start, const 
         if (pa) prof_push(pa, prof_mark(s), 0.0, 2);
         return check_launch("shared_kv_attention(few rows)");
     }
+    if (d > 768) return fail("shared_kv_attention: d=%d with more than 8 query rows per code runs on the image form (medtok_shared_kv_attention_split_f32)", d);
     const int waves = d == 64 ? 2 : (d % 256 == 0 ? 8 : 4);
     // (hi, lo) key planes of W slices, 32 keys x (d / W + 8) halves each; per-wave partial scores; probabilities (hi, lo); row state
     const size_t lds = (size_t)waves * 2 * 32 * (d / waves + 8) * 2 + (size_t)waves * 32 * 33 * 4 + 2 * 32 * 40 * 2 + 64 * 4;
@@ -2057,7 +2062,7 @@ static int attention_forward_f16s(const float *q, const int64_t *q_start, const 
 }
 
 // 64-row blocks, keys from (hi, lo) fp16 images by LDS-DMA (attention_dma.h)
-static bool attention_dma_shape_ok(int d) { return d == 128 || d == 256 || d == 384 || d == 512 || d == 768; }
+static bool attention_dma_shape_ok(int d) { return d == 128 || d == 256 || d == 384 || d == 512 || d == 768 || d == 1024; }
 
 static void *g_att_dbg = nullptr;      // DEV (tools/r04): per-wave cycle counts of the pp kernel's phases
 extern "C" void medtok_debug_set_attention_probe(void *p) { g_att_dbg = p; }
@@ -2068,7 +2073,7 @@ extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_
 {
     if ((out_hi == nullptr) != (out_lo == nullptr)) return fail("shared_kv_attention_split: out_hi and out_lo go together");
     if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention_split: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
-    if (!attention_dma_shape_ok(d)) return fail("shared_kv_attention_split: d=%d must be 128, 256, 384, 512 or 768", d);
+    if (!attention_dma_shape_ok(d)) return fail("shared_kv_attention_split: d=%d must be 128, 256, 384, 512, 768 or 1024", d);
     if (n_codes == 0 || max_q_len == 0) return 0;
     const int vform = variant & 15;
     const bool pp_shape = vform == 2 && (d == 256 || d == 512 || d == 768);
@@ -2118,6 +2123,7 @@ extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_
     case 256: MEDTOK_ATT_DMA(8, 1, 2, 2); break;
     case 384: MEDTOK_ATT_DMA(4, 3, 2, 2); break;
     case 512: MEDTOK_ATT_DMA(8, 2, 2, 2); break;
+    case 1024: MEDTOK_ATT_DMA(4, 8, 1, 2); break;      // (BERT-large width: 32 rows per block, one wave per SIMD with 512 registers, two-deep ring)
     default:                               // 768: variant 0 = 32 rows per block, two blocks per CU; 1 = 64 rows per block, one per CU
         if (variant == 1) MEDTOK_ATT_DMA(8, 3, 2, 2); else MEDTOK_ATT_DMA(4, 6, 1, 1);
         break;
@@ -2135,7 +2141,9 @@ extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_s
     if (exact_f32 && out_hi) return fail("shared_kv_attention: the (hi, lo) output images come from the inference kernels (exact_f32 = 0)");
     if (!out && !out_hi && n_codes > 0 && max_q_len > 0) return fail("shared_kv_attention: no output buffer");
     if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
-    if (!attention_shape_ok(d)) return fail("shared_kv_attention: d=%d must be 64 or a multiple of 128, at most 768", d);
+    // (d = 1024: the inference form only, with at most 4 query rows per code -- the text side's CLS row per head; wider query sets
+    // run on medtok_shared_kv_attention_split_f32; the exact fp32 kernel's 32-key chunk of fp32 rows does not fit the LDS there)
+    if (!attention_shape_ok(d) && !(d == 1024 && !exact_f32)) return fail("shared_kv_attention: d=%d must be 64 or a multiple of 128, at most 768 (1024: inference only)", d);
     if (n_codes == 0 || max_q_len == 0) return 0;
     if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len) return fail("shared_kv_attention: NULL argument");
     if (!exact_f32) return attention_forward_f16s(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, (_Float16 *)out_hi,
@@ -2144,7 +2152,7 @@ extern "C" int medtok_shared_kv_attention_f32(const float *q, const int64_t *q_s
 }
 
 // CrossAttention.pooled at e_dim = 64, 4 heads (the reference's default shape) in two launches (attention_small.h)
-extern "C" int medtok_cross_attention_small_f32(const float *text, const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len,
+static int cross_attention_small_impl(bool exact, const float *text, const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len,
                                                 const float *nodes, const int64_t *batch, int64_t n_nodes, int d, int heads, int layers,
                                                 const float *weights, float scale, float ln_eps, float *y_nodes, float *pooled,
                                                 int64_t pooled_stride, int64_t graph_off, int32_t *status, void *stream)
@@ -2164,11 +2172,32 @@ extern "C" int medtok_cross_attention_small_f32(const float *text, const void *m
     a.mask_bytes = mask_elem_bytes; a.layers = layers; a.n_graph_tiles = (int)tiles; a.scale = scale; a.ln_eps = ln_eps;
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
-    hipLaunchKernelGGL(cross_attention64_kernel, dim3((unsigned)(tiles + n_codes)), dim3(256), 0, s, a);
+    if (exact) hipLaunchKernelGGL(cross_attention64_kernel<false>, dim3((unsigned)(tiles + n_codes)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(cross_attention64_kernel<true>, dim3((unsigned)(tiles + n_codes)), dim3(256), 0, s, a);
     if (pa) prof_push(pa, prof_mark(s), 0.0, 2);
     hipLaunchKernelGGL(cross_attention64_mean_kernel, dim3((unsigned)((n_codes + 3) / 4)), dim3(256), 0, s, y_nodes, batch, (long)n_nodes, (long)n_codes,
                        pooled, (long)pooled_stride, (long)graph_off);
     return check_launch("cross_attention_small");
+}
+
+extern "C" int medtok_cross_attention_small_f32(const float *text, const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len,
+                                                const float *nodes, const int64_t *batch, int64_t n_nodes, int d, int heads, int layers,
+                                                const float *weights, float scale, float ln_eps, float *y_nodes, float *pooled,
+                                                int64_t pooled_stride, int64_t graph_off, int32_t *status, void *stream)
+{
+    return cross_attention_small_impl(false, text, mask, mask_elem_bytes, n_codes, seq_len, nodes, batch, n_nodes, d, heads, layers, weights, scale, ln_eps,
+                                      y_nodes, pooled, pooled_stride, graph_off, status, stream);
+}
+
+// Test hook: the same call with the attention core on the fp32 matrix pipe (exact fmaf chains; the round-5 form) -- a second opinion
+// on the split-fp16 core that the product runs
+extern "C" int medtok_debug_cross_attention_small_exact_f32(const float *text, const void *mask, int mask_elem_bytes, int64_t n_codes, int64_t seq_len,
+                                                            const float *nodes, const int64_t *batch, int64_t n_nodes, int d, int heads, int layers,
+                                                            const float *weights, float scale, float ln_eps, float *y_nodes, float *pooled,
+                                                            int64_t pooled_stride, int64_t graph_off, int32_t *status, void *stream)
+{
+    return cross_attention_small_impl(true, text, mask, mask_elem_bytes, n_codes, seq_len, nodes, batch, n_nodes, d, heads, layers, weights, scale, ln_eps,
+                                      y_nodes, pooled, pooled_stride, graph_off, status, stream);
 }
 
 // the prologue of CrossAttention.pooled (pack_kernels.h)

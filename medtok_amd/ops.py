@@ -70,15 +70,22 @@ class ClockProbe:
                     how="s_memtime cycles / s_memrealtime (100 MHz) ticks of one idle wavefront per XCD while the probe ran")
 
 
+ATTENTION_MAX_WIDTH = 1024                 # widest cross-attention: inference only above ATTENTION_MAX_TRAIN_WIDTH
+ATTENTION_MAX_TRAIN_WIDTH = 768
+
+
 def attention_width(d: int) -> int:
-    """Width the ragged attention kernels run a D-wide problem at: D itself for 64 and multiples of 128 up to 768, else the next
-    such width (the caller appends zero columns).  Wider than 768 is refused: a 32-key chunk of fp32 rows would not fit the LDS."""
+    """Width the ragged attention kernels run a D-wide problem at: D itself for 64 and multiples of 128 up to 768, and 1024 (BERT-large
+    features; inference only: the training kernels' 32-key chunk of fp32 rows does not fit the LDS there), else the next such width
+    (the caller appends zero columns).  Wider than 1024 is refused."""
     if d <= 64:
         return 64
     w = (d + 127) // 128 * 128
     if w > 768:
-        raise _lib.MedTokLibraryError(f"cross-attention width D = {d} is not supported by the gfx950 attention kernels: they take D <= 768 "
-                                      f"(64 or a multiple of 128 natively, anything else zero-padded to the next such width)")
+        w = 1024
+    if d > ATTENTION_MAX_WIDTH:
+        raise _lib.MedTokLibraryError(f"cross-attention width D = {d} is not supported by the gfx950 attention kernels: they take D <= 1024 "
+                                      f"(64, a multiple of 128 up to 768, or 1024 natively; anything else zero-padded to the next such width)")
     return w
 
 
@@ -567,11 +574,12 @@ def cross_attention_layer(rows, rows_images, w, q_start, q_len, max_q_len: int, 
 SMALL_ATTENTION_LAYER_FLOATS = 4 * 64 * 64 + 6 * 64
 
 
-def cross_attention_small(text, mask, nodes, batch, weights, layers: int, scale: float, ln_eps: float, pooled, status):
+def cross_attention_small(text, mask, nodes, batch, weights, layers: int, scale: float, ln_eps: float, pooled, status, exact_f32: bool = False):
     """CrossAttention.pooled at e_dim = 64 with 4 heads in two launches and no host read (include/medtok_vq.h:
     medtok_cross_attention_small_f32).  text [B, L, 64] fp32, mask [B, L] (bool / int32 / int64), nodes [N, 64] fp32 with a sorted
     batch vector [N] int64, weights [layers, SMALL_ATTENTION_LAYER_FLOATS] (CrossAttention._small_weights), pooled [B, 2, 64] fp32
-    (written: [:, 0] the attended CLS rows, [:, 1] the node means), status int32 [4] (zeroed once by its owner)."""
+    (written: [:, 0] the attended CLS rows, [:, 1] the node means), status int32 [4] (zeroed once by its owner).
+    exact_f32 (tests only): the attention core on the fp32 matrix pipe instead of the product's split-fp16 core."""
     text, nodes, weights = _dev(text, "text"), _dev(nodes, "nodes"), _dev(weights, "weights")
     batch = _dev(batch.reshape(-1), "batch", torch.int64)
     if not (isinstance(mask, torch.Tensor) and mask.is_cuda and mask.dim() == 2):
@@ -585,7 +593,8 @@ def cross_attention_small(text, mask, nodes, batch, weights, layers: int, scale:
         raise ValueError("cross_attention_small: pooled must be a contiguous fp32 [B, 2, d] tensor")
     y_nodes = torch.empty((max(n_nodes, 1), d), dtype=torch.float32, device=text.device)
     with _on(text.device):
-        _lib.check(_lib.load().medtok_cross_attention_small_f32(
+        lib = _lib.load()
+        _lib.check((lib.medtok_debug_cross_attention_small_exact_f32 if exact_f32 else lib.medtok_cross_attention_small_f32)(
             text.data_ptr(), mask.data_ptr(), mask.element_size(), bsz, seq_len, nodes.data_ptr() if n_nodes else 0, batch.data_ptr() if n_nodes else 0,
             n_nodes, d, 4, int(layers), weights.data_ptr(), float(scale), float(ln_eps), y_nodes.data_ptr(), pooled.data_ptr(), 2 * d, d,
             status.data_ptr(), _stream(text)), "medtok_cross_attention_small_f32")
@@ -643,7 +652,7 @@ def shared_kv_attention(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int,
     return (oh, ol) if split_out else out
 
 
-ATTENTION_SPLIT_WIDTHS = (128, 256, 384, 512, 768)
+ATTENTION_SPLIT_WIDTHS = (128, 256, 384, 512, 768, 1024)
 ATTENTION_HALF_KEY_WIDTHS = (256, 512, 768)        # widths at which fp16 keys are taken as they stand (variant 2, no lo image)
 
 

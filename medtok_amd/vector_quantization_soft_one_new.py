@@ -660,7 +660,8 @@ class CrossAttention(nn.Module):
         pooled_reference, the oracle's restatement); with `autograd` every call goes through _RaggedAttentionFunction instead
         (HIP forward with the layer's attention dropout in training mode + HIP backward).
         The gfx950 kernels take D = 64 or a multiple of 128 up to 768: any other width D <= 768 runs on the same kernels with
-        zero COLUMNS appended to queries and keys (they change neither the scores nor the first D output columns)."""
+        zero COLUMNS appended to queries and keys (they change neither the scores nor the first D output columns); 768 < D <= 1024
+        runs at width 1024, inference only."""
         bsz, seq_len, dim = text.shape
         mha = self.model[0].multihead_attn
         heads, scale = mha.num_heads, mha.head_dim ** -0.5
@@ -715,8 +716,10 @@ class CrossAttention(nn.Module):
                                                  kv_len=counts, scale=scale)
         side = None
         text_split = images_ready = None
+        # (wider than 768 -- BERT-large features -- only the image form runs, whatever the batch size)
         want_images = (not autograd and core is ops.shared_kv_attention and text.is_cuda and kv_text.shape[1] in ops.ATTENTION_SPLIT_WIDTHS
-                       and SPLIT_ATTENTION and nodes_sorted.shape[0] * heads >= SPLIT_ATTENTION_MIN_ROWS and max_nodes > 0)
+                       and SPLIT_ATTENTION and max_nodes > 0
+                       and (nodes_sorted.shape[0] * heads >= SPLIT_ATTENTION_MIN_ROWS or kv_text.shape[1] > ops.ATTENTION_MAX_TRAIN_WIDTH))
         def text_chain(cur):
             for i, layer in enumerate(self.model):
                 cur = self._folded_rows(layer, cur, text_attend, next_split=i + 1 < len(self.model))
@@ -985,8 +988,8 @@ class CrossAttention(nn.Module):
         text side only evaluates its CLS query.  Everything runs packed (nothing padded to [B, max, D]) on the ragged attention
         kernels with the key/value projections folded into the queries: ops.shared_kv_attention at inference (fp32 whatever
         autocast says), _RaggedAttentionFunction (HIP forward with dropout + HIP backward) in training / under autograd.  Widths
-        the kernels do not take natively (not 64 / a multiple of 128) get zero columns appended; D > 768 raises
-        MedTokLibraryError -- there is no eager-PyTorch fallback (pooled_reference below is the test-side comparator).
+        the kernels do not take natively (not 64 / a multiple of 128 / 1024) get zero columns appended; D > 1024 raises
+        MedTokLibraryError (768 < D <= 1024: inference only, at most 4 heads) -- there is no eager-PyTorch fallback (pooled_reference below is the test-side comparator).
         One host sync per call.  A code with no nodes, or no valid token, attends to nothing: its context is zero (the
         reference's per-code loop would take a softmax over an empty row there).
         join=False (get_shared_info): returns a third value, (side stream, main stream) or None -- when the text side ran on the
@@ -994,10 +997,17 @@ class CrossAttention(nn.Module):
         if not (text.is_cuda and nodes.is_cuda):
             raise ops.MedTokLibraryError(f"CrossAttention.pooled: expected tensors on an MI355X (cuda/HIP) device, got {text.device} / "
                                          f"{nodes.device}; medtok_amd has no CPU path")
-        ops.attention_width(text.shape[-1])                # raises for widths the kernels cannot take
+        width = ops.attention_width(text.shape[-1])        # raises for widths the kernels cannot take
         needs_grad = torch.is_grad_enabled() and (text.requires_grad or nodes.requires_grad
                                                   or any(p.requires_grad for p in self.parameters()))
         autograd = self.training or needs_grad
+        if width > ops.ATTENTION_MAX_TRAIN_WIDTH:
+            if autograd:
+                raise ops.MedTokLibraryError(f"CrossAttention.pooled: width D = {text.shape[-1]} runs at inference only (eval mode under torch.no_grad()); "
+                                             f"the training / autograd kernels take D <= {ops.ATTENTION_MAX_TRAIN_WIDTH}")
+            if self.model[0].multihead_attn.num_heads > 4:
+                raise ops.MedTokLibraryError(f"CrossAttention.pooled: width D = {text.shape[-1]} takes at most 4 heads (the text side's kernel keeps "
+                                             f"one query row per head in registers)")
         heads = self.model[0].multihead_attn.num_heads
         bsz, seq_len, dim = text.shape
         if bsz == 0:

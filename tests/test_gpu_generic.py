@@ -105,3 +105,59 @@ def test_width_that_is_not_a_multiple_of_four_through_quantize_pooled(dev, oracl
         assert np.array_equal(tok[:, j].cpu().numpy()[~near], ref["idx"][~near]), j
         a = emb[:, j * e:(j + 1) * e].cpu().numpy()[~near]
         assert np.abs(a - ref["zq"][~near]).max() <= 1e-5 * np.abs(ref["zq"]).max(), j
+
+
+@pytest.mark.parametrize("d,q_max", [(1024, 40), (1024, 3)])
+def test_attention_core_at_width_1024_matches_the_oracle(dev, oracle, d, q_max):
+    """the image-form attention core (medtok_shared_kv_attention_split_f32) and the few-rows kernel at BERT-large width against
+    the C oracle's restatement: 1e-5 of the output scale; ragged query / key counts incl. an empty key set"""
+    from medtok_amd import ops
+    rng = np.random.default_rng(d + q_max)
+    q_len = np.array([q_max, 1, max(q_max // 2, 1), q_max, 2][: 5], np.int64)
+    kv_len = np.array([50, 33, 0, 129, 16], np.int64)
+    q_start, kv_start = np.cumsum(q_len) - q_len, np.cumsum(kv_len) - kv_len
+    qa = (rng.standard_normal((int(q_len.sum()), d)) * 0.1).astype(np.float32)
+    ka = rng.standard_normal((int(kv_len.sum()), d)).astype(np.float32)
+    T = lambda a: torch.from_numpy(a).to(dev)
+    ref = oracle.shared_kv_attention(qa, q_start, q_len, ka, kv_start, kv_len, 0.06)
+    if q_max <= 4:
+        out = ops.shared_kv_attention(T(qa), T(q_start), T(q_len), T(ka), T(kv_start), T(kv_len), int(q_len.max()), 0.06)
+    else:
+        images = ops.split_half(T(ka))
+        out = ops.shared_kv_attention_split(T(qa), T(q_start), T(q_len), images, T(kv_start), T(kv_len), int(q_len.max()), 0.06, variant=2)
+    err = np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err <= 1e-5, err
+
+
+@pytest.mark.parametrize("d,heads", [(1024, 4), (900, 4)])
+def test_pooled_cross_attention_at_bert_large_width_vs_the_reference_loop(dev, d, heads):
+    """CrossAttention.pooled at D = 1024 (and 900, zero-padded to 1024) against the reference's own per-code loop over
+    nn.MultiheadAttention layers (vector_quantization_soft_one_new.py:133-142) run on the GPU in fp32: 1e-5 of the output scale;
+    training at that width is refused with a clear error"""
+    from medtok_amd import ops
+    from medtok_amd.vector_quantization_soft_one_new import CrossAttention
+    torch.manual_seed(3)
+    ca = CrossAttention(d, heads, dropout=0.1, layers=2).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(4)
+    bsz, seq_len = 6, 24
+    text = torch.randn(bsz, seq_len, d, device=dev, generator=g)
+    tok = torch.tensor([24, 1, 7, 16, 24, 3], device=dev)
+    mask = (torch.arange(seq_len, device=dev)[None, :] < tok[:, None]).to(torch.int64)
+    n_nodes = torch.tensor([5, 1, 12, 3, 9, 2], device=dev)
+    batch = torch.repeat_interleave(torch.arange(bsz, device=dev), n_nodes)
+    nodes = torch.randn(int(n_nodes.sum()), d, device=dev, generator=g)
+    with torch.no_grad():
+        pt, pg = ca.pooled(text, mask, nodes, batch)
+        want_t, want_g = [], []
+        for i in range(bsz):
+            a, b = ca(text[i, : int(tok[i])], nodes[batch == i])
+            want_t.append(a[0]); want_g.append(b.mean(0))
+    want_t, want_g = torch.stack(want_t), torch.stack(want_g)
+    for got, want, what in ((pt, want_t, "text"), (pg, want_g, "graph")):
+        err = float((got.double() - want.double()).abs().max() / want.double().abs().max())
+        assert err <= 1e-5, (what, err)
+    ca.train()
+    with pytest.raises(ops.MedTokLibraryError, match="inference only"):
+        ca.pooled(text, mask, nodes, batch)
+    with pytest.raises(ops.MedTokLibraryError, match="not supported"):
+        ops.attention_width(1100)

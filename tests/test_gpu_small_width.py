@@ -60,6 +60,40 @@ def test_small_width_path_equals_the_layer_by_layer_path(dev, shape):
     _close(both[:, 1], pg, "node means")
 
 
+@pytest.mark.parametrize("shape", [(64, 512, 40), (9, 70, 33), (300, 17, 5), (2, 1, 1)])
+def test_split_fp16_core_equals_the_fp32_matrix_pipe_core(dev, shape):
+    """the product's attention core (three fp16 MFMA passes over (hi, lo) pairs, keys permuted so that the probabilities feed the
+    value product from the registers they stand in) against the round-5 core on the fp32 matrix pipe (exact fmaf chains): 2e-6 of the
+    output scale -- chunks that are not full, keys in every position of the permuted order, tiles that span codes"""
+    from medtok_amd import ops
+    bsz, seq_len, max_nodes = shape
+    ca = _module(dev, 7)
+    text, mask, nodes, batch = _ragged(dev, 31 + bsz, bsz, seq_len, max_nodes, zero_nodes=(1,) if bsz > 4 else (), zero_tokens=(2,) if bsz > 4 else ())
+    heads = 4
+    outs = []
+    with torch.no_grad():
+        for exact in (False, True):
+            pooled = torch.empty(bsz, 2, 64, device=dev)
+            ops.cross_attention_small(text, mask, nodes, batch, ca._small_weights(), len(ca.model), (64 // heads) ** -0.5, ca.model[0].layer_norm.eps,
+                                      pooled, ca._status_word(dev), exact_f32=exact)
+            outs.append(pooled)
+    ca.check_small_status()
+    err = float((outs[0].double() - outs[1].double()).abs().max()) / float(outs[1].double().abs().max())
+    assert err <= 2e-6, err
+    # a transposition or a wrong key permutation would not survive asymmetric data: keys scaled by their index
+    scale = 1.0 + 0.01 * torch.arange(seq_len, device=dev, dtype=torch.float32)
+    text2 = text * scale[None, :, None]
+    outs = []
+    with torch.no_grad():
+        for exact in (False, True):
+            pooled = torch.empty(bsz, 2, 64, device=dev)
+            ops.cross_attention_small(text2, mask, nodes, batch, ca._small_weights(), len(ca.model), 0.25, ca.model[0].layer_norm.eps, pooled,
+                                      ca._status_word(dev), exact_f32=exact)
+            outs.append(pooled)
+    err = float((outs[0].double() - outs[1].double()).abs().max()) / float(outs[1].double().abs().max())
+    assert err <= 2e-6, err
+
+
 def test_small_width_path_equals_the_padded_torch_comparator(dev):
     ca = _module(dev, 3)
     text, mask, nodes, batch = _ragged(dev, 5, 23, 40, 12)
