@@ -242,9 +242,10 @@ def test_bench_recorded_counter_figures_carry_their_provenance():
 def test_unsupported_k_fails_at_construction():
     """k beyond the kernels' list length (or beyond a region's size) is refused when the module is built, not at the first search."""
     from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
-    for bad in (0, 9, 64):
+    for bad in (0, 17, 64):                # (k up to 16 since round 6: two exact passes of lists of 8)
         with pytest.raises(ValueError, match="k="):
             VectorQuantizer(96, 16, 0.25, 0.0, True, True, [16, 16], k=bad)
+    VectorQuantizer(96, 16, 0.25, 0.0, True, True, [16, 16], k=16)
     with pytest.raises(ValueError, match="k="):
         VectorQuantizer(12, 16, 0.25, 0.0, True, True, [16, 16], k=5)          # regions of 4 codes
     VectorQuantizer(96, 16, 0.25, 0.0, True, True, [16, 16], k=8)
