@@ -63,7 +63,15 @@ constexpr int R_ROWS = 32;                                    // rows per re-sco
 // (64 until round 6: a row next to a cluster of ~100 near-identical codes keeps them all -- bench.py --data clustered_codebook)
 constexpr int R_SURV = 112;
 
-__host__ __device__ inline float filter_gamma(int d) { return 0x1p-10f + 0x1p-20f + (float)d * 0x1p-22f; }
+// gamma: operand rounding (2^-10 + 2^-20: 11-bit significands on both sides) + the accumulation budget.  The accumulation part must cover,
+// in eps = 2 gamma mag, the d + 63 additions of the approximate score (each may truncate: 2^-23 of a magnitude <= mag) plus the exact
+// chain's own d roundings (2^-24 each): (1.5 d + 63) 2^-22 mag.  2 d 2^-22 covers that from d = 126 up; below it the term is
+// (0.75 d + 32) 2^-22 (at the default e_dim = 64 the round-5 budget rested on measured slack, not on the stated proof).
+__host__ __device__ inline float filter_gamma(int d)
+{
+    const float acc = (float)d > 0.75f * (float)d + 32.0f ? (float)d : 0.75f * (float)d + 32.0f;
+    return 0x1p-10f + 0x1p-20f + acc * 0x1p-22f;
+}
 
 // eps = bound on |d~ - d| for a row with squared norm xn against codes with squared norm <= en_max
 __device__ __forceinline__ float filter_eps(float xn, float en_max, int d)

@@ -19,10 +19,11 @@ from .tokenizer import MultimodalTokenizer
 from .vector_quantization_soft_one_new import VectorQuantizer
 
 
-# quantize_pooled: the four searches are independent (vector_quantization_soft_one_new.py:238-271).  From this many rows up they are
-# issued on TWO HIP streams, a short (region) and a long (whole-codebook) search on each in opposite order, so that one stream's
-# re-score / projection / row-norm passes (fabric- and HBM-bound, no matrix work) run while the other stream's shortlist kernel has the
-# matrix pipe.  0: one stream.  Same kernels on the same operands: bit-identical results (tests/test_gpu_full_size.py).
+# quantize_pooled: the four searches are independent (vector_quantization_soft_one_new.py:238-271).  With this set (> 0: from that many
+# rows up) they are issued on TWO HIP streams, a short (region) and a long (whole-codebook) search on each in opposite order -- the
+# round-6 experiment of running one stream's re-score / projection / row-norm passes under the other's shortlist kernel.  Measured
+# 3.4 % SLOWER at cfg 3 (139.4 vs 134.9 ms, profiles/r06_two_stream_searches.json): the shortlist kernel's two waves per SIMD hold
+# 480 of its 512 registers, no re-score wave co-resides, the CUs are merely time-sliced.  Off (0); bit-identical either way.
 TWO_STREAM_MIN_ROWS = 0
 
 
@@ -123,18 +124,24 @@ def run_inference(model: MultimodalTokenizer, batches: Iterable, out_dir: Option
         def flush(self, sink):
             for i in (self.turn, self.turn ^ 1):     # oldest first: batch order is kept
                 self.drain(i, sink)
-    stages = (_Stage(), _Stage(), _Stage())
+    stages = (_Stage(), _Stage(), _Stage(), _Stage())
     dev = device
     for x in batches:
-        # (the code indices are taken BEFORE x.to(device): afterwards this would be a blocking device-to-host copy per batch)
-        order.append(torch.as_tensor(x.code_indices).reshape(-1).to("cpu", torch.int64))
+        # the code indices are taken BEFORE x.to(device); indices that already live on the GPU leave it like the results do -- through
+        # the pinned double buffer, without a blocking copy per batch
+        ci = torch.as_tensor(x.code_indices).reshape(-1)
+        if ci.is_cuda:
+            stages[3].push(ci.to(torch.int64), order)
+        else:
+            stages[3].flush(order)                   # (a caller that mixes host and device indices: batch order is kept)
+            order.append(ci.to(torch.int64))
         if device is not None and hasattr(x, "to"):
             x = x.to(device)
         e, t, w = model(x)
         dev = e.device
         for st, val, sink in zip(stages, (e, t, w), (embs, toks, wts)):
             st.push(val, sink)
-    for st, sink in zip(stages, (embs, toks, wts)):
+    for st, sink in zip(stages, (embs, toks, wts, order)):
         st.flush(sink)
     quant = getattr(model, "quantize", None)
     if quant is not None and hasattr(quant, "cross_attn"):

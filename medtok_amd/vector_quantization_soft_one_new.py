@@ -430,12 +430,61 @@ class CrossAttention(nn.Module):
         self.max_nodes_bound = None
 
     def forward(self, vector1, vector2, attn_mask=None):
+        """The reference's per-pair call (:53-88): (vector1 attended by vector2, vector2 attended by vector1), every layer against the
+        ORIGINAL other modality.  Inference on an MI355X (eval mode, no autograd, unbatched fp32 [L, D] operands, no mask, D <= 768):
+        the library's own kernels -- folded projections on the split-fp16 GEMMs, the ragged attention core with the pair as ONE code,
+        fused residual + LayerNorm -- within 1e-5 of nn.MultiheadAttention; anything else (training, autograd, masks, batched
+        input, CPU) runs the stock modules as in the reference."""
+        fast = self._forward_on_kernels(vector1, vector2, attn_mask)
+        if fast is not None:
+            return fast
         out1, out2 = vector1, vector2
         for layer in self.model:
             out1 = layer(out1, vector2, vector2, attn_mask)
         for layer in self.model:
             out2 = layer(out2, vector1, vector1, attn_mask)
         return out1, out2
+
+    def _forward_on_kernels(self, vector1, vector2, attn_mask):
+        mha = self.model[0].multihead_attn
+        if (self.training or torch.is_grad_enabled() or attn_mask is not None or not torch.is_tensor(vector1) or not torch.is_tensor(vector2)
+                or vector1.dim() != 2 or vector2.dim() != 2 or not (vector1.is_cuda and vector2.is_cuda) or torch.is_autocast_enabled()
+                or vector1.dtype != torch.float32 or vector2.dtype != torch.float32 or vector1.shape[1] != vector2.shape[1]
+                or vector1.shape[0] == 0 or vector2.shape[0] == 0 or mha.in_proj_bias is None or not mha._qkv_same_embed_dim):
+            return None
+        dim = vector1.shape[1]
+        if dim > ops.ATTENTION_MAX_TRAIN_WIDTH or dim != mha.embed_dim:
+            return None
+        heads, scale = mha.num_heads, mha.head_dim ** -0.5
+        pad = ops.attention_width(dim) - dim
+        widen = (lambda t: torch.nn.functional.pad(t, (0, pad))) if pad else (lambda t: t)
+        dev = vector1.device
+
+        def attend_to(kv, n_q):
+            kvw = widen(kv).contiguous()
+            one = lambda v: torch.tensor([v], dtype=torch.long, device=dev)
+            q_start, q_len, kv_start, kv_len = one(0), one(n_q * heads), one(0), one(kv.shape[0])
+
+            def attend(qf, split_out=False, **_):
+                wide_in = qf.shape[1] != dim                 # _folded_rows_split hands over (and takes back) rows at the kernel width
+                q_in = qf if wide_in else widen(qf)
+                if split_out:
+                    return ops.shared_kv_attention(q_in, q_start, q_len, kvw, kv_start, kv_len, n_q * heads, scale, split_out=True)
+                out = ops.shared_kv_attention(q_in.float(), q_start, q_len, kvw, kv_start, kv_len, n_q * heads, scale)
+                return out[:, :dim].contiguous() if (pad and not wide_in) else out
+            attend.library_core = True
+            attend.core_args = lambda: dict(q_start=q_start, q_len=q_len, max_q_len=n_q * heads, kv=kvw, kv_split=None, kv_start=kv_start,
+                                            kv_len=kv_len, scale=scale)
+            return attend
+        with torch.autocast(device_type="cuda", enabled=False):
+            outs = []
+            for rows, other in ((vector1, vector2), (vector2, vector1)):
+                attend = attend_to(other, rows.shape[0])
+                cur = rows.contiguous()
+                for i, layer in enumerate(self.model):
+                    cur = self._folded_rows(layer, cur, attend, next_split=i + 1 < len(self.model))
+                outs.append(cur)
+        return outs[0], outs[1]
 
     @staticmethod
     def _folded_layer(layer, query, kv, key_valid):

@@ -161,3 +161,32 @@ def test_pooled_cross_attention_at_bert_large_width_vs_the_reference_loop(dev, d
         ca.pooled(text, mask, nodes, batch)
     with pytest.raises(ops.MedTokLibraryError, match="not supported"):
         ops.attention_width(1100)
+
+
+@pytest.mark.parametrize("d,heads,l1,l2", [(64, 4, 12, 9), (768, 4, 300, 21), (128, 4, 1, 1), (70, 2, 17, 40), (256, 8, 40, 5)])
+def test_per_pair_cross_attention_call_runs_on_the_kernels(dev, d, heads, l1, l2):
+    """CrossAttention.forward(v1, v2) -- the reference's public per-pair call (vector_quantization_soft_one_new.py:53-88) -- at inference:
+    the library's kernels (the pair as one code of the ragged core) against the stock nn.MultiheadAttention / LayerNorm modules the same
+    object runs under autograd: 1e-5 of the output scale, full sequences of both directions"""
+    from medtok_amd import ops
+    from medtok_amd.vector_quantization_soft_one_new import CrossAttention
+    torch.manual_seed(d + l1)
+    ca = CrossAttention(d, heads, dropout=0.1, layers=2).to(dev).eval()
+    with torch.no_grad():
+        for layer in ca.model:
+            layer.multihead_attn.in_proj_bias.normal_(0, 0.2)
+            layer.layer_norm.weight.normal_(1.0, 0.2)
+            layer.layer_norm.bias.normal_(0, 0.2)
+    g = torch.Generator(device=dev).manual_seed(1)
+    v1, v2 = torch.randn(l1, d, device=dev, generator=g), torch.randn(l2, d, device=dev, generator=g)
+    ops.profile_begin()
+    with torch.no_grad():
+        a1, a2 = ca(v1, v2)
+    torch.cuda.synchronize()
+    prof = ops.profile_end()
+    assert prof["shared_kv_attention_kernel"]["launches"] >= 4          # (the kernels ran: two layers x two directions)
+    b1, b2 = ca(v1, v2)                                                  # eval mode under autograd: the stock modules, dropout off
+    for got, want in ((a1, b1), (a2, b2)):
+        assert got.shape == want.shape
+        err = float((got.double() - want.detach().double()).abs().max() / want.detach().double().abs().max())
+        assert err <= 1e-5, err
