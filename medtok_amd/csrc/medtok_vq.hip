@@ -1074,12 +1074,15 @@ static bool filter_eligible(int64_t n, int64_t k_codes, int d, int topk)
     if (!(n >= 512 && k_codes >= 1024 && flops >= 1.0e10 && topk <= 8 && n < (1ll << 31) &&
           (double)k_codes * (double)(d + 64) < 536870912.0))
         return false;
-    // Few rows: the filter's floor is converting the codebook plus one block walking K/16 codes (about 1.1 us per
-    // 256-code tile and k block), the exact kernel runs at about 100 TFLOP/s once D is a few hundred
-    // (tools/path_crossover.py, tools/small_batch_filter.py: D = 768, K = 8192, N = 1024: exact 150 us, filter 229 us).
+    // Few rows: the filter has a floor -- converting the codebook, one block walking its share of the codes, the re-score and the
+    // (empty) redo launches -- while the exact kernel runs at about 100 TFLOP/s from 512 rows up once D is a few hundred.  Floor
+    // fitted in round 6 on MI355X (tools/r06/crossover_small.py, profiles/r06_path_crossover_small.txt: D = 768 / 256, K = 8192 ..
+    // 49152, N = 128 .. 4096): 61.5 us + 0.70 us per 256-code tile and k block of a 16th of the codebook + 1.04 ns per code; the
+    // round-2 floor (170 us + 1.1 us per unit) sent 512 x 49152 and 1024 x 16384 searches at D = 768 to the exact kernel, which
+    // takes 0.38 / 0.24 ms there against 0.32 / 0.15 ms.  5 % in favour of the exact kernel (fewer launches).
     if (d >= 256) {
-        const double filter_floor = 0.17e-3 + ((double)k_codes / 4096.0) * ((double)d / 32.0) * 1.1e-6;
-        if (flops / 1.0e14 < filter_floor) return false;
+        const double filter_floor = 61.5e-6 + ((double)k_codes / 4096.0) * ((double)d / 32.0) * 0.703e-6 + (double)k_codes * 1.04e-9;
+        if (flops / 1.0e14 + 20.0e-6 < 1.05 * filter_floor) return false;
     }
     return true;
 }
