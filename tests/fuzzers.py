@@ -76,6 +76,46 @@ def fuzz_search(cases=100, seed=0, budget_s=None, max_rows=300000, log=None):
     return c + 1, bad
 
 
+def fuzz_wide_k(cases=100, seed=0, budget_s=None, log=None):
+    """More than 8 codes per row (two exact passes of lists of 8 + a join, round 6) against the C oracle's single list of k, bit for bit:
+    random shapes, duplicated codes (ties that straddle the pass boundary), rows close to codes, zero rows, forced code splits."""
+    from medtok_amd import ops
+    from oracle import oracle as O
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    over, _ = _timer(budget_s)
+    bad, c = [], 0
+    for c in range(cases):
+        if over():
+            break
+        n = int(rng.choice([1, 33, 257, 1000, 3000]))
+        K = int(rng.choice([16, 100, 1000, 5000, 20001]))
+        D = int(rng.choice([4, 36, 64, 128, 260]))
+        k = int(rng.integers(9, 17))
+        if n * K * D > 3.0e9:
+            n = max(1, int(3.0e9 / (K * D)))
+        kind = int(rng.integers(0, 5))
+        x = rng.standard_normal((n, D), dtype=np.float32)
+        W = rng.standard_normal((K, D), dtype=np.float32)
+        if kind == 1:
+            W[K // 3:] = np.resize(W[: max(K // 3, 1)], (K - K // 3, D))             # every code about three times: exact ties
+        if kind == 2:
+            x = (x * 0.01 + W[rng.integers(0, K, n)]).astype(np.float32)              # rows close to codes
+        if kind == 4:
+            x[::7] = 0                                                                # zero rows
+        xh, xs = O.rownorm(x)
+        wh, ws = O.rownorm(W)
+        ri, rd = O.topk_search(xh, xs, wh, ws, k)
+        T = lambda a: torch.from_numpy(a).to(dev)
+        for env in ({}, dict(search_max_splits=int(rng.choice([1, 3, 16])))):
+            gi, gd = ops.topk_search(T(xh), T(xs), T(wh), T(ws), k, ops.plan_path(ops.PATH_AUTO if not env else ops.PATH_F32_MFMA, **env))
+            if not (np.array_equal(gi.cpu().numpy(), ri) and np.array_equal(gd.cpu().numpy().view(np.int32), rd.view(np.int32))):
+                bad.append(f"wide_k case {c}: n={n} K={K} D={D} k={k} kind={kind} env={env} rows differing {(gi.cpu().numpy() != ri).any(1).sum()}")
+                if log:
+                    log(bad[-1])
+    return c + 1, bad
+
+
 def fuzz_rows64(cases=100, seed=0, budget_s=None, max_rows=200000, log=None):
     """The filter kernel for rows of <= 64 elements (learning tiles, scanned tiles, revisited tiles; code splits; ragged last tiles;
     every k-list length) against the exact fp32 path and the general filter kernel: same bits."""

@@ -58,3 +58,9 @@ def test_fuzz_prepared_codebook_equals_unprepared_searches(dev):
     import fuzzers
     ran, bad = fuzzers.fuzz_prepared(cases=300, seed=20257, budget_s=30)
     _report("fuzz_prepared", ran, bad, 10)
+
+
+def test_fuzz_more_than_eight_codes_per_row_equal_the_oracle(dev, oracle):
+    import fuzzers
+    ran, bad = fuzzers.fuzz_wide_k(cases=200, seed=20258, budget_s=40)
+    _report("fuzz_wide_k", ran, bad, 10)
