@@ -760,7 +760,12 @@ struct MultiSearchOne {
     long n, zq_stride, x_stride;                // (x rows may be a column block of a wider matrix)
     int k_codes, codes_per_split, splits, row_tiles;
 };
-struct MultiSearchArgs { MultiSearchOne s[MS_MAX]; int count, d, topk; };
+// block_base: the searches' (row tile, code split) blocks in ONE dimension, search after search (block_base[i] = first block of
+// search i, block_base[count] = all).  The search kernel's grid holds exactly the blocks that have work: a 3-D grid of
+// max_tiles x max_splits x count launched 996 blocks for the 444 of a B = 256 forward, and -- blocks going to the 8 XCDs by id --
+// the active ones of the two short searches all landed on XCDs 0, 1, 4, 5: 70 blocks for 64 slots there, a second generation of a few
+// blocks, twice the kernel time (round 6: rocprofv3 counters, profiles/r06_pmc_small_search_*.txt).
+struct MultiSearchArgs { MultiSearchOne s[MS_MAX]; int block_base[MS_MAX + 1]; int count, d, topk; };
 
 __global__ __launch_bounds__(256) void rownorm_multi_kernel(MultiSearchArgs a)
 {
@@ -793,11 +798,15 @@ __global__ __launch_bounds__(256) void rownorm_multi_kernel(MultiSearchArgs a)
 template <int TOPK, bool KTAIL>
 __global__ __launch_bounds__(256, S_WPS) void search_f32_multi_kernel(MultiSearchArgs a)
 {
-    const MultiSearchOne &m = a.s[blockIdx.z];
-    if ((int)blockIdx.x >= m.row_tiles || (int)blockIdx.y >= m.splits) return;
+    int z = 0;
+#pragma unroll
+    for (int i = 1; i < MS_MAX; ++i) z += (i < a.count && (int)blockIdx.x >= a.block_base[i]) ? 1 : 0;
+    const MultiSearchOne &m = a.s[z];
+    const unsigned local = blockIdx.x - (unsigned)a.block_base[z];
+    const unsigned bx = local % (unsigned)m.row_tiles, by = local / (unsigned)m.row_tiles;
     search_f32_body<TOPK, false, KTAIL, false>(m.xhat, m.xsq, m.what, m.wsq, m.n, m.k_codes, a.d, m.codes_per_split, a.topk, m.pval, m.pidx,
                                                (int64_t *)nullptr, (float *)nullptr, (const int *)nullptr, (const int *)nullptr, 0, 0,
-                                               blockIdx.x, blockIdx.y);
+                                               bx, by);
 }
 
 // Joins the per-split candidate lists of one row: 8 lanes per row, each folds every 8th split, then three shuffle rounds.
@@ -1773,13 +1782,15 @@ extern "C" int medtok_soft_vq_forward_multi_f32(const medtok_search_desc *descs,
         m.pval = (float *)take((size_t)splits[i] * q.n * tslots * 4);
         m.pidx = (int *)take((size_t)splits[i] * q.n * tslots * 4);
         max_rows = lmax(max_rows, m.n); max_tiles = max_tiles > m.row_tiles ? max_tiles : m.row_tiles; max_splits = max_splits > m.splits ? max_splits : m.splits;
+        a.block_base[i + 1] = a.block_base[i] + m.row_tiles * m.splits;
     }
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(rownorm_multi_kernel, dim3((unsigned)((max_rows + 3) / 4), (unsigned)count), dim3(256), 0, s, a);
     hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
     double pflops = 0.0;
     for (int i = 0; i < count; ++i) pflops += 2.0 * (double)descs[i].n * (double)descs[i].k_codes * (double)d;
-    const dim3 grid((unsigned)max_tiles, (unsigned)max_splits, (unsigned)count);
+    (void)max_tiles; (void)max_splits;
+    const dim3 grid((unsigned)a.block_base[count]);          // exactly the blocks that have work, search after search
 #define MEDTOK_MS(T)                                                                                                          \
     do {                                                                                                                      \
         if (d % S_BK) {                                                                                                       \

@@ -2,7 +2,7 @@
 # Dev tool (GPU box): issue / wait counters of the small-batch search kernel of the B = 256 forward (fullref), one counter group per
 # rocprofv3 pass, kernel-trace only.   usage: bash tools/r06/pmc_small_search.sh   -> gpurun_out/r06/pmc_small_search.txt
 export TMPDIR=/tmp
-out=gpurun_out/r06pmc; mkdir -p $out
+out=gpurun_out/r06pmc; mkdir -p $out gpurun_out/r06
 i=0
 for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32" "SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU" "SQ_IFETCH SQ_INSTS_VMEM_RD SQ_INSTS_SMEM" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_F32"; do
   i=$((i+1))
@@ -24,5 +24,4 @@ for k in agg:
     for c, v in sorted(agg[k].items()):
         print(f"   {c:32s} {v / cnt[k][c]:16.1f} per launch  ({cnt[k][c]} launches)")
 PY
-rm -rf $out
-cat gpurun_out/r06/pmc_small_search.txt
+tail -3 $out/p1.log; ls $out | head; cat gpurun_out/r06/pmc_small_search.txt
