@@ -32,6 +32,7 @@ for w in cfg3 full fullref; do
   rm -rf $out/prof_$w
 done
 bash tools/r05/timeline_fullref.sh > /dev/null 2>&1; cp gpurun_out/tl/timeline.txt $out/timeline_fullref.txt
+bash tools/r06/pmc_small_search.sh > /dev/null 2>&1; cp gpurun_out/r06/pmc_small_search.txt $out/pmc_small_search_after.txt
 # PMC traffic of the headline's kernels, their own passes (no trace domains beside --kernel-trace)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_cfg3_$c -o p -- python3 bench.py --workload cfg3 --steps 1 --warmup 1 --cpu-rows 0 --exact-steps 0 --no-clock-probe --no-extra-workloads > $out/pmc_cfg3_$c.log 2>&1
