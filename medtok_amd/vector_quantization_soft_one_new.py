@@ -1575,7 +1575,6 @@ class VectorQuantizer(nn.Module):
             return None
         if self.search_path not in (ops.PATH_AUTO, ops.PATH_F32_MFMA):
             return None                 # a forced search path or plan bits (bench --path, tests): the general form runs what the caller named
-        what, wsq = norm
         z_text, z_graph = torch.split(z, self.split, dim=-1)
         aug = (None, None) if z_aug is None else torch.split(z_aug, self.split, dim=-1)
         emb = torch.empty((bsz, 2 * e), dtype=torch.float32, device=z.device)
@@ -1590,6 +1589,10 @@ class VectorQuantizer(nn.Module):
         else:
             pooled_text, pooled_graph = self.cross_attn.pooled(text_features, text_attention_mask, graph_node_features, batch)
             both = torch.stack((pooled_text.float(), pooled_graph.float()), dim=1)
+
+        if callable(norm):                   # (forward() hands over a thunk: the normalisation is enqueued behind the cross-attention)
+            norm = norm()
+        what, wsq = norm
 
         def again():
             nodes_s, batch_s = CrossAttention.sort_by_code(graph_node_features, batch)
@@ -1690,13 +1693,18 @@ class VectorQuantizer(nn.Module):
         # one normalisation of the codebook per forward (training: re-normalised every forward, like the reference's every call;
         # eval: the cache per weight version), shared by its 4-6 searches
         bsz_, region_ = z.shape[0], self.codebook.weight.shape[0] // 3
-        norm = self._normalised_codebook(rebuild=self.training,
-                                         prepare=not self.training and z.is_cuda and bsz_ > 0 and self.e_dim % 4 == 0
-                                         and (ops.takes_filter_path(2 * bsz_, self.n_e, self.e_dim, self.k, self.search_path)
-                                              or ops.takes_filter_path(bsz_, region_, self.e_dim, self.k, self.search_path)))
-        small = self._forward_small_batch(z, text_features, graph_node_features, text_attention_mask, batch, z_aug, norm)
+
+        def make_norm():
+            return self._normalised_codebook(rebuild=self.training,
+                                             prepare=not self.training and z.is_cuda and bsz_ > 0 and self.e_dim % 4 == 0
+                                             and (ops.takes_filter_path(2 * bsz_, self.n_e, self.e_dim, self.k, self.search_path)
+                                                  or ops.takes_filter_path(bsz_, region_, self.e_dim, self.k, self.search_path)))
+        # (small batches are latency-bound: their cross-attention -- which needs nothing of the codebook -- is launched first, the
+        # codebook is normalised under it)
+        small = self._forward_small_batch(z, text_features, graph_node_features, text_attention_mask, batch, z_aug, make_norm)
         if small is not None:
             return small
+        norm = make_norm()
         train = self._forward_train(z, text_features, graph_node_features, text_attention_mask, batch, z_aug, norm)
         if train is not None:
             return train
