@@ -398,6 +398,9 @@ def round6(sq):
     fixture_specific(sq, "f21_specific_k16_d768", N=48, D=768, n_e=384, seed=21, k=16)
     fixture_forward(sq, "f22_forward_d70", B=12, L=16, max_nodes=8, D=70, n_e=300, seed=22, num_head=2)
     fixture_forward(sq, "f23_forward_k9", B=16, L=12, max_nodes=9, D=64, n_e=300, seed=23, k=9)
+    # the reference's per-GPU batch (B = 256, train_MedTok.py:387) at its default width through a whole train step: forward values and
+    # the reference's autograd gradients (the largest train-step fixture before round 6 was F19 at B = 64)
+    fixture_forward(sq, "f24_forward_b256_d64", B=256, L=12, max_nodes=6, D=64, n_e=600, seed=24)
 
 
 def main():

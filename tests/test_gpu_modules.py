@@ -79,7 +79,8 @@ def test_specific_embedding_eval_and_train(golden, dev, name):
 
 
 # (f22, round 6: e_dim = 70 with two heads -- not a multiple of 4: zero columns appended inside; f23: k = 9 through the whole forward)
-@pytest.mark.parametrize("name", ["f3_forward_d64", "f4_forward_d128", "f19_forward_b64", "f22_forward_d70", "f23_forward_k9"])
+# (f24, round 6: the reference's per-GPU batch B = 256 at its default width -- eval through the small-batch path, then a whole train step)
+@pytest.mark.parametrize("name", ["f3_forward_d64", "f4_forward_d128", "f19_forward_b64", "f22_forward_d70", "f23_forward_k9", "f24_forward_b256_d64"])
 def test_full_forward_dict(golden, dev, name):
     g = golden(name)
     v = make_vq(name, g, dev)
