@@ -38,6 +38,47 @@ def test_bench_prints_one_contract_line(dev, args):
     assert e is None or e["outputs_bit_identical_to_default_path"] is True
 
 
+def test_default_bench_line_carries_the_secondary_workloads(dev):
+    """`python bench.py` as the driver runs it (cfg 3 at full size, one GPU): besides the contract fields the line carries
+    extra.workloads -- short runs of the other workloads, so that the secondary claims are measured by whoever runs the default
+    command -- the per-search traffic unit, the step's fabric / algorithmic ratio and the device-side fallback and candidate statistics.
+    No entry may have failed."""
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-rows", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    r = d["roofline"]
+    assert r["kernel"] == "filter_f16_kernel" and r["traffic"] is not None and r["traffic"] > 6.0e10          # per search: two dispatches of ~34 GB
+    assert r["fabric_over_algorithmic"] is not None and 10.0 < r["fabric_over_algorithmic"] < 60.0
+    fb = d["fallback_rows"]
+    assert fb["rows_handed_to_the_exact_kernel_per_step"] == 0 and len(fb["searches"]) == 4
+    assert all(40.0 < s["candidates_per_row"] < 400.0 and s["rows"] == 600000 for s in fb["searches"])
+    w = d["extra"]["workloads"]
+    for name in ("refdefault", "cfg2", "full", "full_rows256", "fullref", "cfg4_vq_only"):
+        assert name in w and "error" not in w[name], (name, w.get(name))
+        assert w[name]["value"] > 0 and w[name]["ms_per_step"] > 0 and w[name]["dominant_kernel"], name
+    assert w["fullref"]["hip_graph_replay"]["replay_equals_eager"] is True
+    assert w["full_rows256"]["no_host_read"]["hip_graph_replay"]["replay_equals_default_forward"] is True
+
+
+def test_bench_data_distributions_off_the_gaussian(dev):
+    """--data: rows next to codes, Student-t rows and a codebook of near-copies (reduced row count: seconds); the line says how many
+    rows the shortlist handed to the exact kernel and how many candidates it kept per row"""
+    for data in ("near_codes", "clustered_codebook", "heavy_tail"):
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "1", "--rows", "20000", "--cpu-rows", "0",
+                              "--exact-steps", "1", "--data", data], capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+        assert data in d["config"]["workload"]
+        assert d["exact_fp32_path"]["outputs_bit_identical_to_default_path"] is True, data
+        fb = d["fallback_rows"]
+        assert "error" not in fb and len(fb["searches"]) == 4 and 0 <= fb["rows_handed_to_the_exact_kernel_per_step"] <= 4 * 20000, (data, fb)
+        if data != "clustered_codebook":                   # (only near-identical codes push rows over the shortlist's capacities)
+            assert fb["rows_handed_to_the_exact_kernel_per_step"] == 0, (data, fb)
+
+
 def test_build_then_smoke_in_one_process(dev):
     """The driver may call build() and smoke() from the same interpreter: the library is then loaded before anything
     touched torch.cuda, which once left two HIP runtimes fighting over the device."""
