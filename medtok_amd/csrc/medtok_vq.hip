@@ -914,7 +914,10 @@ static SearchPlan plan_search(int64_t n, int64_t k_codes, int topk, const PlanOv
     if (want > code_tiles) want = code_tiles;
     // at most 64 splits -- except for one or two row tiles (batches of <= 256 rows), where 64 splits would leave half
     // the CUs without a block: n = 256, K = 49152: 463 -> 276 us with 128 splits; n = 64: 459 -> 202 us with 256
-    long cap = p.row_tiles <= 2 ? lmin(256, di.cus) / p.row_tiles : 64;
+    // (three to seven row tiles -- 257 .. 896 rows: 128 splits, i.e. 384 .. 896 blocks of short code ranges, keep two blocks on every CU;
+    // with 64 a 512-row search left half the CUs one block: 0.376 -> 0.322 ms at K = 49152, D = 768, 0.063 -> 0.055 at the reference's
+    // shape -- tools/r06/exact_splits_small.py, profiles/r06_exact_splits_small.txt)
+    long cap = p.row_tiles <= 2 ? lmin(256, di.cus) / p.row_tiles : (p.row_tiles <= 7 ? 128 : 64);
     if (ov.search_max_splits > 0) cap = ov.search_max_splits;
     if (want > cap) want = cap;
     const long tiles_per_split = (code_tiles + want - 1) / want;
