@@ -485,6 +485,15 @@ int medtok_shared_kv_attention_backward_half_f32(const float *q, const int64_t *
                                                  int64_t max_kv_len, int64_t q_rows, int64_t kv_rows, int d, float scale, float dropout_p,
                                                  uint32_t seed, const float *out, const float *lse, const float *d_out, float *dq,
                                                  float *dkv, void *ws, size_t ws_bytes, int bf16, void *stream);
+/* ... either form (mode 0: exact fp32, 1: fp16, 2: bf16 products) with dKV ADDED to what dkv already holds when accumulate_dkv != 0.
+ * Every layer of CrossAttention attends to the ORIGINAL other modality (vector_quantization_soft_one_new.py:83,86): the key gradients of
+ * all layers land in one [kv_rows, d] buffer, in launch order (a block owns its key rows: the sum is ordered, held + this launch's).
+ * Rows no block owns are then left untouched instead of zeroed.  accumulate_dkv == 0: exactly the two entries above. */
+int medtok_shared_kv_attention_backward_acc_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
+                                                const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
+                                                int64_t max_kv_len, int64_t q_rows, int64_t kv_rows, int d, float scale, float dropout_p,
+                                                uint32_t seed, const float *out, const float *lse, const float *d_out, float *dq,
+                                                float *dkv, void *ws, size_t ws_bytes, int mode, int accumulate_dkv, void *stream);
 
 /* EMA statistics of norm_ema_quantizer.py:183,194,202 without the one-hot:
  * bins[c] = #rows with idx == c (exact), embed_sum[c][:] = sum of those rows of

@@ -114,6 +114,8 @@ SIGNATURES = {
                                                        _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "medtok_shared_kv_attention_backward_half_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _f, _f, C.c_uint32,
                                                             _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
+    "medtok_shared_kv_attention_backward_acc_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _f, _f, C.c_uint32,
+                                                           _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _int, _vp]),
     "medtok_ema_stats_workspace_bytes": (_sz, [_i64, _i64]),
     "medtok_ema_stats_f32": (_int, [_vp, _vp, _i64, _int, _i64, _vp, _vp, _vp, _sz, _vp]),
     "medtok_code_histogram_workspace_bytes": (_sz, [_i64]),

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
     const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
     const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
     const float *__restrict__ d_out, const float *__restrict__ lse, const float *__restrict__ delta, float scale,
-    float *__restrict__ dkv, int kv_tiles, unsigned drop_thresh, unsigned seed, float keep_scale)
+    float *__restrict__ dkv, int kv_tiles, unsigned drop_thresh, unsigned seed, float keep_scale, int accumulate)
 {
     using G = AttShape<W, NT>;
     constexpr int D = G::D, LD = G::LD, EPT = G::EPT, TPR = G::TPR, FT = G::FT, CI = G::CI, RP = G::RP, RI = G::RI, NF = G::NF;
@@ -420,8 +420,15 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
         const int orow = (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (kt * 32 + orow < kl) {
             float *o = dkv + (ks + kt * 32 + orow) * (long)D + slice + li;
+            // accumulate: dkv already holds a gradient of these keys (another layer's, over the same rows: a block owns its rows, so
+            // the sum is ordered: held + this launch's)
+            if (accumulate) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) o[32 * t] = acc[t][r];
+                for (int t = 0; t < NT; ++t) o[32 * t] += acc[t][r];
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) o[32 * t] = acc[t][r];
+            }
         }
     }
 }

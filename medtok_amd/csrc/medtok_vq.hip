@@ -2579,7 +2579,7 @@ static int attention_backward_impl(const float *q, const int64_t *q_start, const
                                    const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
                                    int64_t max_kv_len, int64_t q_rows, int64_t kv_rows, int d, float scale, float dropout_p,
                                    uint32_t seed, const float *out, const float *lse, const float *d_out, float *dq,
-                                   float *dkv, void *ws, size_t ws_bytes, void *stream, int hm);
+                                   float *dkv, void *ws, size_t ws_bytes, void *stream, int hm, int acc_dkv = 0);
 
 extern "C" int medtok_shared_kv_attention_backward_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
                                                        const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
@@ -2603,11 +2603,25 @@ extern "C" int medtok_shared_kv_attention_backward_half_f32(const float *q, cons
                                    lse, d_out, dq, dkv, ws, ws_bytes, stream, bf16 ? 2 : 1);
 }
 
+// ... the same (mode 0: exact fp32, 1: fp16, 2: bf16 products) with dKV ADDED to what dkv already holds (accumulate_dkv != 0): the
+// layers of CrossAttention all attend to the ORIGINAL other modality (:83,86), so their key gradients land in one buffer -- no second
+// [kv_rows, d] tensor, no zero fill of it, no pass that adds the two.  Rows no block owns are then left as they are.
+extern "C" int medtok_shared_kv_attention_backward_acc_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
+                                                           const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
+                                                           int64_t max_kv_len, int64_t q_rows, int64_t kv_rows, int d, float scale, float dropout_p,
+                                                           uint32_t seed, const float *out, const float *lse, const float *d_out, float *dq,
+                                                           float *dkv, void *ws, size_t ws_bytes, int mode, int accumulate_dkv, void *stream)
+{
+    if (mode < 0 || mode > 2) return fail("shared_kv_attention_backward_acc: mode=%d must be 0 (fp32), 1 (fp16) or 2 (bf16)", mode);
+    return attention_backward_impl(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, max_kv_len, q_rows, kv_rows, d, scale, dropout_p, seed, out,
+                                   lse, d_out, dq, dkv, ws, ws_bytes, stream, mode, accumulate_dkv != 0);
+}
+
 static int attention_backward_impl(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
                                    const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
                                    int64_t max_kv_len, int64_t q_rows, int64_t kv_rows, int d, float scale, float dropout_p,
                                    uint32_t seed, const float *out, const float *lse, const float *d_out, float *dq,
-                                   float *dkv, void *ws, size_t ws_bytes, void *stream, int hm)
+                                   float *dkv, void *ws, size_t ws_bytes, void *stream, int hm, int acc_dkv)
 {
     if (n_codes < 0 || max_q_len < 0 || max_kv_len < 0 || q_rows < 0 || kv_rows < 0) return fail("shared_kv_attention_backward: bad sizes");
     if (!attention_shape_ok(d)) return fail("shared_kv_attention_backward: d=%d must be 64 or a multiple of 128, at most 768", d);
@@ -2619,7 +2633,7 @@ static int attention_backward_impl(const float *q, const int64_t *q_start, const
     hipStream_t s = (hipStream_t)stream;
     // rows no block owns (key rows past a code's kv_len inside its slot, query rows of no code) get a zero gradient
     if (q_rows > 0 && hipMemsetAsync(dq, 0, (size_t)q_rows * d * 4, s) != hipSuccess) return fail("shared_kv_attention_backward: memset failed");
-    if (kv_rows > 0 && hipMemsetAsync(dkv, 0, (size_t)kv_rows * d * 4, s) != hipSuccess) return fail("shared_kv_attention_backward: memset failed");
+    if (kv_rows > 0 && !acc_dkv && hipMemsetAsync(dkv, 0, (size_t)kv_rows * d * 4, s) != hipSuccess) return fail("shared_kv_attention_backward: memset failed");
     if (n_codes == 0 || q_rows == 0) return 0;
     float *delta = (float *)ws;
     hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)((q_rows + 3) / 4)), dim3(256), 0, s, d_out, out, (long)q_rows, d, delta);
@@ -2638,7 +2652,7 @@ static int attention_backward_impl(const float *q, const int64_t *q_start, const
                                kv, kv_start, kv_len, d_out, lse, delta, scale, dq, (int)q_tiles, thresh, seed, keep_scale);      \
         if (kv_tiles > 0)                                                                                                        \
             hipLaunchKernelGGL((shared_kv_attention_dkv_kernel<W, NT, HM>), dim3((unsigned)(kv_tiles * n_codes)), dim3(64 * W), lds, s, q, q_start, q_len, \
-                               kv, kv_start, kv_len, d_out, lse, delta, scale, dkv, (int)kv_tiles, thresh, seed, keep_scale);    \
+                               kv, kv_start, kv_len, d_out, lse, delta, scale, dkv, (int)kv_tiles, thresh, seed, keep_scale, acc_dkv); \
     } while (0)
 #define MEDTOK_ATT_BWD(W, NT)                                                                                                    \
     do {                                                                                                                         \

@@ -699,20 +699,35 @@ def shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, max_q_len
 
 
 def shared_kv_attention_backward(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, max_kv_len: int, scale: float, dropout_p: float,
-                                 seed: int, out, lse, d_out, half=None):
+                                 seed: int, out, lse, d_out, half=None, dkv_into=None, accumulate=False):
     """(dq, dkv) of shared_kv_attention_train for the upstream gradient d_out.  half = torch.float16 / torch.bfloat16: the four matrix
-    products in one half-precision pass with fp32 accumulation (autocast callers); None: exact fp32 MFMA."""
+    products in one half-precision pass with fp32 accumulation (autocast callers); None: exact fp32 MFMA.
+    dkv_into: a contiguous fp32 [kv_rows, d] buffer that receives dkv (returned as dkv); with accumulate=True the key gradient is
+    ADDED to what it holds (the layers of CrossAttention share their keys: one buffer, no add pass)."""
     q, kv, out, lse, d_out = _dev(q, "q"), _dev(kv, "kv"), _dev(out, "out"), _dev(lse, "lse"), _dev(d_out, "d_out")
     qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
     ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
-    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    dq = torch.empty_like(q)
+    if dkv_into is None:
+        if accumulate:
+            raise ValueError("shared_kv_attention_backward: accumulate=True needs the buffer to add to (dkv_into)")
+        dkv = torch.empty_like(kv)
+    else:
+        dkv = _dev(dkv_into, "dkv_into")
+        if dkv is not dkv_into:
+            raise ValueError("shared_kv_attention_backward: dkv_into must be contiguous (the kernel writes into it)")
+        if dkv.shape != kv.shape or dkv.device != kv.device:
+            raise ValueError(f"shared_kv_attention_backward: dkv_into {tuple(dkv.shape)} on {dkv.device} does not match kv {tuple(kv.shape)} on {kv.device}")
     lib = _lib.load()
     ws = _ws(lib.medtok_shared_kv_attention_backward_workspace_bytes(q.shape[0]), q)
     args = (q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(), kl.data_ptr(), qs.numel(), int(max_q_len), int(max_kv_len),
             q.shape[0], kv.shape[0], q.shape[1], float(scale), float(dropout_p), int(seed) & 0xFFFFFFFF, out.data_ptr(), lse.data_ptr(),
             d_out.data_ptr(), dq.data_ptr(), dkv.data_ptr(), ws.data_ptr(), ws.numel())
     with _on(q.device):
-        if half in (torch.float16, torch.bfloat16):
+        if accumulate:
+            mode = 1 if half == torch.float16 else (2 if half == torch.bfloat16 else 0)
+            _lib.check(lib.medtok_shared_kv_attention_backward_acc_f32(*args, mode, 1, _stream(q)), "medtok_shared_kv_attention_backward_acc_f32")
+        elif half in (torch.float16, torch.bfloat16):
             _lib.check(lib.medtok_shared_kv_attention_backward_half_f32(*args, int(half == torch.bfloat16), _stream(q)), "medtok_shared_kv_attention_backward_half_f32")
         else:
             _lib.check(lib.medtok_shared_kv_attention_backward_f32(*args, _stream(q)), "medtok_shared_kv_attention_backward_f32")

@@ -100,7 +100,10 @@ class MultimodalTokenizer(nn.Module):
     def quant(self, text_features, graph_node_features, graph_features, text_features_aug, graph_node_features_aug,
               graph_features_aug, text_attention_mask, batch):
         """h = [CLS text feature | pooled graph feature] -> VectorQuantizer.forward (reference :160-200)."""
-        h = torch.cat((text_features[:, 0, :], graph_features), dim=-1)
+        # (training on an MI355X: the CLS rows come from the text tensor's gradient fan-out when it has one -- same values, their
+        # gradient joins the key gradients in place instead of through a zero [B, L, D] tensor and an add pass)
+        fan = getattr(text_features, "_medtok_fan", None)
+        h = torch.cat((text_features[:, 0, :] if fan is None else fan.cls, graph_features), dim=-1)
         h_aug = None
         if text_features_aug is not None and graph_features_aug is not None:
             h_aug = torch.cat((text_features_aug[:, 0, :], graph_features_aug), dim=-1)
@@ -135,6 +138,9 @@ class MultimodalTokenizer(nn.Module):
         mask = inputs.attention_mask
         bsz = mask.shape[0]
         text = self._map_text(self.tokenize_text(inputs))
+        if self.training:
+            from . import vector_quantization_soft_one_new as vqmod
+            text = vqmod.fan_out_text(text)               # (a no-op outside autograd on an MI355X)
         nodes = self.tokenize_graph(inputs)
         pooled = global_mean_pool(nodes, batch, bsz)
         text_aug = nodes_aug = pooled_aug = None
@@ -143,7 +149,13 @@ class MultimodalTokenizer(nn.Module):
             # the reference encodes the text a second time for the aug view with the same frozen model and the same inputs
             # (tokenizer.py:211-212: if_aug is never set); outside training that pass is bit-identical to the first, so the eval
             # forward reuses it (same values, same usage-window trajectory) and only the aug GRAPH view is encoded
-            text_aug = self._map_text(self.tokenize_text(inputs, aug=True)) if self.training or hasattr(inputs, "text_features_aug") else text
+            # ... and quant() reads nothing but the CLS row of the aug text view (reference :160-166: text_features_aug[:, 0, :]): only
+            # that row goes through text_mapped (a Linear is row-wise: same values and same weight gradient as mapping all L
+            # tokens and dropping L - 1 of them, without the [B L, text_dim] product and its [B L, D] gradient of zeros)
+            if self.training or hasattr(inputs, "text_features_aug"):
+                text_aug = self._map_text(self.tokenize_text(inputs, aug=True)[:, :1])
+            else:
+                text_aug = text
             nodes_aug = self.tokenize_graph(inputs, aug=True)
             pooled_aug = global_mean_pool(nodes_aug, batch, bsz)
         result = self.quant(text, nodes, pooled, text_aug, nodes_aug, pooled_aug, mask, batch)

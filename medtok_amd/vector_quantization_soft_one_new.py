@@ -95,6 +95,11 @@ PREPARED_CODEBOOK = True
 # training under autocast: the row-major and the transposed 16-bit image of a product's input / upstream gradient from ONE pass over it
 # (ops.half_image_pair) instead of two
 FUSE_IMAGE_PAIRS = True
+# training: the text rows are read three ways -- as the keys of every cross-attention layer (:83,86: always the ORIGINAL text), as the
+# CLS query of the text side, as the CLS half of h (tokenizer.py:162) -- and autograd would sum their four [B L, D] gradients with a
+# zero fill and an add pass each (0.8 ms of a 12 ms step at B = 256, L = 512).  On: the layers' dKV kernels write into ONE buffer
+# (the first zeroes and stores, the others add), the CLS gradients are added to its B rows in place (_TextFanOut)
+KEY_GRADIENT_SINK = True
 from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
@@ -200,17 +205,82 @@ def _cached(holder, attr, key, build, device, rebuild=False):
     return c[1]
 
 
+class _KeyGradSink:
+    """Where the dKV kernels of the layers that share one key matrix put its gradient during a backward (see _TextFanOut)."""
+    __slots__ = ("buf", "node")
+
+    def __init__(self):
+        self.buf = None         # the [rows, D] gradient while a backward is under way
+        self.node = None        # weak reference to the autograd node that collects it
+
+
+class _TextFan:
+    """carried by a text tensor that went through fan_out_text(): the CLS rows and the gradient sink of its keys"""
+    __slots__ = ("sink", "cls")
+
+    def __init__(self, sink, cls):
+        self.sink, self.cls = sink, cls
+
+
+class _TextFanOut(torch.autograd.Function):
+    """text [B, L, D] -> (the same rows, their CLS rows [B, D]) with ONE gradient buffer behind both: the attention layers whose keys
+    these rows are add their dKV into `sink` during the backward (and hand autograd no gradient for them), this node -- which the
+    engine runs after every consumer of its outputs -- adds the CLS gradient to the buffer's B first rows and passes it on."""
+
+    @staticmethod
+    def forward(ctx, text, sink):
+        ctx.sink = sink
+        ctx.seq_len = text.shape[1]
+        ctx.set_materialize_grads(False)
+        return text.view_as(text), text[:, 0].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_rows, g_cls):
+        sink = ctx.sink
+        buf, sink.buf = sink.buf, None
+        if g_rows is not None:              # (a consumer outside the sink protocol)
+            g_rows = g_rows.float()
+            buf = g_rows.clone() if buf is None else buf.view_as(g_rows).add_(g_rows)
+        if g_cls is not None:
+            if buf is None:
+                buf = g_cls.new_zeros((g_cls.shape[0], ctx.seq_len, g_cls.shape[1]), dtype=torch.float32)
+            buf = buf.view(g_cls.shape[0], -1, g_cls.shape[1])
+            buf[:, 0].add_(g_cls)
+        return (None if buf is None else buf.view(-1, ctx.seq_len, buf.shape[-1])), None
+
+
+def fan_out_text(text):
+    """The text rows [B, L, D] of a training step behind one gradient buffer (KEY_GRADIENT_SINK): returns the same values as a tensor
+    that carries `_medtok_fan` = (sink, CLS rows).  CrossAttention.pooled() and MultimodalTokenizer.quant() read the CLS rows from
+    there and route the key gradients of the attention layers into the sink; any other use of the returned tensor is ordinary
+    autograd.  Anything it does not apply to (no autograd, not an fp32 [B, L, D] tensor on an MI355X) is returned as it came."""
+    if getattr(text, "_medtok_fan", None) is not None:
+        return text
+    if not (KEY_GRADIENT_SINK and torch.is_tensor(text) and text.is_cuda and text.dim() == 3 and text.dtype == torch.float32
+            and text.requires_grad and torch.is_grad_enabled() and text.is_contiguous() and text.shape[1] > 0
+            and hasattr(torch._C, "_will_engine_execute_node")):
+        return text
+    import weakref
+    sink = _KeyGradSink()
+    rows, cls = _TextFanOut.apply(text, sink)
+    sink.node = weakref.ref(rows.grad_fn)
+    rows._medtok_fan = _TextFan(sink, cls)
+    return rows
+
+
 class _RaggedAttentionFunction(torch.autograd.Function):
     """The ragged attention core under autograd: forward = medtok_shared_kv_attention_train_f32 (dropout on the probabilities by
     a stateless hash mask, log-sum-exp kept per row), backward = medtok_shared_kv_attention_backward_f32 (dQ and dKV kernels that
-    rebuild probabilities and mask; nothing of size rows x keys is stored).  fp32 whatever autocast says."""
+    rebuild probabilities and mask; nothing of size rows x keys is stored).  fp32 whatever autocast says.
+    `sink` (a _KeyGradSink, or None): the key gradient goes into the sink's buffer instead of back to autograd."""
 
     @staticmethod
-    def forward(ctx, q, kv, q_start, q_len, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed):
+    def forward(ctx, q, kv, q_start, q_len, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed, sink=None):
         qf, kvf = q.detach().float().contiguous(), kv.detach().float().contiguous()
         out, lse = ops.shared_kv_attention_train(qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, scale, dropout_p, seed)
         ctx.save_for_backward(qf, kvf, out, lse, q_start, q_len, kv_start, kv_len)
         ctx.cfg = (max_q_len, max_kv_len, scale, dropout_p, seed, q.dtype, kv.dtype)
+        ctx.sink = sink
         # under torch.autocast the backward's four matrix products run as ONE half-precision pass (the reference's class there);
         # the forward stays on the exact fp32 kernel (its log-sum-exp feeds the backward's softmax rebuild)
         ctx.half = (torch.get_autocast_dtype("cuda") if (AUTOCAST_HALF_PRODUCTS and torch.is_autocast_enabled()
@@ -221,9 +291,24 @@ class _RaggedAttentionFunction(torch.autograd.Function):
     def backward(ctx, d_out):
         qf, kvf, out, lse, q_start, q_len, kv_start, kv_len = ctx.saved_tensors
         max_q_len, max_kv_len, scale, dropout_p, seed, qd, kd = ctx.cfg
+        sink = ctx.sink
+        if sink is not None and ctx.needs_input_grad[1]:
+            # only in a backward that will run the collecting node (torch.autograd.grad() for other inputs does not)
+            node = sink.node() if sink.node is not None else None
+            if node is None or not torch._C._will_engine_execute_node(node):
+                sink = None
+        else:
+            sink = None
+        if sink is not None:
+            first = sink.buf is None
+            if first:
+                sink.buf = torch.empty_like(kvf)
+            dq, _ = ops.shared_kv_attention_backward(qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed,
+                                                     out, lse, d_out.float().contiguous(), half=ctx.half, dkv_into=sink.buf, accumulate=not first)
+            return dq.to(qd), None, None, None, None, None, None, None, None, None, None, None
         dq, dkv = ops.shared_kv_attention_backward(qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed,
                                                    out, lse, d_out.float().contiguous(), half=ctx.half)
-        return dq.to(qd), dkv.to(kd), None, None, None, None, None, None, None, None, None
+        return dq.to(qd), dkv.to(kd), None, None, None, None, None, None, None, None, None, None
 
 
 def _pad32(n):
@@ -717,6 +802,12 @@ class CrossAttention(nn.Module):
         dev = text.device
         pad = (ops.attention_width(dim) - dim) if (text.is_cuda or autograd) else 0
         widen = (lambda t: torch.nn.functional.pad(t, (0, pad))) if pad else (lambda t: t)
+        key_sink = cls_rows = None
+        if autograd and not pad:                           # training: the text rows behind one gradient buffer (KEY_GRADIENT_SINK)
+            text = fan_out_text(text)
+            fan = getattr(text, "_medtok_fan", None)
+            if fan is not None:
+                key_sink, cls_rows = fan.sink, fan.cls
         text_flat = text.reshape(bsz * seq_len, dim)
         if nodes_sorted.shape[0] == 0:                     # no graph node anywhere: one zero row no code points at stands in for the key set
             nodes_sorted = text.new_zeros(1, dim)
@@ -727,7 +818,7 @@ class CrossAttention(nn.Module):
             if not half_keys:
                 kv_text = kv_text.float()
 
-        def attend(qf, q_start, q_len, kv, kv_start, kv_len, max_q_len, max_kv_len, kv_split=None, split_out=False):
+        def attend(qf, q_start, q_len, kv, kv_start, kv_len, max_q_len, max_kv_len, kv_split=None, split_out=False, sink=None):
             wide_in = qf.shape[1] != dim                   # _folded_rows_split hands over (and takes back) rows at the kernel width
             q_in = qf if wide_in else widen(qf)
             if split_out:                                  # (inference on the library's core only: the kernel writes the (hi, lo) images itself)
@@ -740,7 +831,7 @@ class CrossAttention(nn.Module):
             elif autograd:
                 p = float(mha.dropout) if self.training else 0.0
                 seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0.0 else 0      # host RNG: no device sync
-                out = _RaggedAttentionFunction.apply(q_in, kv, q_start, q_len, kv_start, kv_len, max_q_len, max_kv_len, scale, p, seed)
+                out = _RaggedAttentionFunction.apply(q_in, kv, q_start, q_len, kv_start, kv_len, max_q_len, max_kv_len, scale, p, seed, sink)
             else:
                 out = core(q_in.float() if q_in.is_cuda else q_in, q_start, q_len, kv, kv_start, kv_len, max_q_len, scale)
             return out[:, :dim].contiguous() if (pad and not wide_in) else out
@@ -754,7 +845,7 @@ class CrossAttention(nn.Module):
                     lists[key] = lists[key][order]
         # text side: the CLS row of every code queries that code's nodes
         t_start, t_len = lists["t_start"], lists["t_len"]
-        cur = text[:, 0].float().contiguous() if half_keys else text[:, 0].contiguous()
+        cur = cls_rows if cls_rows is not None else (text[:, 0].float().contiguous() if half_keys else text[:, 0].contiguous())
         lib_core = (not autograd) and core is ops.shared_kv_attention and text.is_cuda     # the split-product layer form needs the library's own core
 
         def text_attend(qf, **kw):
@@ -783,7 +874,7 @@ class CrossAttention(nn.Module):
 
             def both_attend(qf, **kw):
                 cut = n_g * heads
-                return torch.cat([attend(qf[:cut], g_start, g_len, kv_text, tok_start, g_kv_len, max_nodes * heads, seq_len, **kw),
+                return torch.cat([attend(qf[:cut], g_start, g_len, kv_text, tok_start, g_kv_len, max_nodes * heads, seq_len, sink=key_sink, **kw),
                                   attend(qf[cut:], t_start, t_len, kv_nodes, starts, counts, heads, max_nodes, **kw)], dim=0)
             both_attend.library_core = False
             rows = torch.cat([nodes_sorted, cur], dim=0)
@@ -839,7 +930,7 @@ class CrossAttention(nn.Module):
             return text_split
 
         def graph_attend(qf, **kw):
-            return attend(qf, g_start, g_len, kv_text, tok_start, g_kv_len, max_nodes * heads, seq_len, kv_split=images_for_use(), **kw)
+            return attend(qf, g_start, g_len, kv_text, tok_start, g_kv_len, max_nodes * heads, seq_len, kv_split=images_for_use(), sink=key_sink, **kw)
         graph_attend.library_core = lib_core
         if lib_core:
             graph_attend.core_args = lambda: dict(q_start=g_start, q_len=g_len, max_q_len=max_nodes * heads, kv=kv_text, kv_split=images_for_use(),

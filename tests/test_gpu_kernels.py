@@ -589,3 +589,39 @@ def test_residual_layernorm_split_images_equal_split_half_of_the_output(dev, d, 
     y, (hi, lo) = ops.residual_layernorm(a, b, gamma, beta, 1e-5, split_dp=dp)
     h2, l2 = ops.split_half(y0, dp=dp)
     assert torch.equal(y, y0) and torch.equal(hi, h2) and torch.equal(lo, l2)
+
+
+@pytest.mark.parametrize("d,half", [(64, None), (768, None), (768, torch.bfloat16), (256, torch.float16)])
+def test_attention_backward_accumulates_key_gradient_in_place(dev, d, half):
+    """medtok_shared_kv_attention_backward_acc_f32: the key gradient ADDED to a buffer that already holds one -- bit for bit held + this
+    launch's on the rows the launch owns, every other row (slots past a code's keys, rows of no code) untouched; dq as without it."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(d)
+    q_len = np.array([40, 7, 0, 64, 33, 5], np.int64); kv_len = np.array([50, 33, 12, 100, 0, 1], np.int64)
+    slot_kv = kv_len + np.array([0, 3, 0, 0, 4, 0])
+    q_start, kv_start = np.cumsum(q_len) - q_len, np.cumsum(slot_kv) - slot_kv
+    nq, nk = int(q_len.sum()), int(slot_kv.sum()) + 3
+    T = lambda a: torch.from_numpy(a).to(dev)
+    q, kv = T((rng.standard_normal((nq, d)) * 0.3).astype(np.float32)), T(rng.standard_normal((nk, d)).astype(np.float32))
+    d_out = T(rng.standard_normal((nq, d)).astype(np.float32))
+    args = (q, T(q_start), T(q_len), kv, T(kv_start), T(kv_len))
+    out, lse = ops.shared_kv_attention_train(*args, int(q_len.max()), 0.2, 0.1, 7)
+    tail = (int(q_len.max()), int(kv_len.max()), 0.2, 0.1, 7, out, lse, d_out)
+    dq0, dkv0 = ops.shared_kv_attention_backward(*args, *tail, half=half)
+    held = T(rng.standard_normal((nk, d)).astype(np.float32))
+    buf = held.clone()
+    dq1, dkv1 = ops.shared_kv_attention_backward(*args, *tail, half=half, dkv_into=buf, accumulate=True)
+    assert dkv1 is buf and torch.equal(dq1, dq0)
+    assert torch.equal(buf, held + dkv0)               # (rows the launch does not own: dkv0 is zero there)
+    owned = torch.zeros(nk, dtype=torch.bool, device=dev)
+    for b in range(len(kv_len)):
+        owned[kv_start[b]: kv_start[b] + kv_len[b]] = True
+    assert torch.equal(buf[~owned], held[~owned])
+    # dkv_into without accumulate: the plain result, in the caller's buffer
+    buf2 = held.clone()
+    _, dkv2 = ops.shared_kv_attention_backward(*args, *tail, half=half, dkv_into=buf2)
+    assert dkv2 is buf2 and torch.equal(buf2, dkv0)
+    with pytest.raises(ValueError):
+        ops.shared_kv_attention_backward(*args, *tail, accumulate=True)
+    with pytest.raises(ValueError):
+        ops.shared_kv_attention_backward(*args, *tail, dkv_into=held[:, : d // 2], accumulate=True)

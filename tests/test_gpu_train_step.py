@@ -144,3 +144,122 @@ def test_train_step_fp16_autocast_with_grad_scaler(dev):
         taken += int(scaler3.get_scale() >= before)
     assert taken >= 3 and not torch.equal(model3.quantize.codebook.weight.detach(), w3)
     assert torch.isfinite(model3.quantize.codebook.weight).all()
+
+
+def _pooled_case(dev, d=128, heads=4, bsz=7, seq_len=24, seed=0):
+    from medtok_amd.vector_quantization_soft_one_new import CrossAttention
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    ca = CrossAttention(d, heads, dropout=0.1).to(dev).train()
+    counts = torch.tensor([3, 0, 9, 1, 40, 2, 5])[:bsz]
+    batch = torch.repeat_interleave(torch.arange(bsz), counts).to(dev)
+    valid = torch.tensor([24, 5, 1, 17, 24, 9, 2])[:bsz]
+    mask = (torch.arange(seq_len)[None, :] < valid[:, None]).long().to(dev)
+    text = torch.randn(bsz, seq_len, d, generator=g).to(dev)
+    nodes = torch.randn(int(counts.sum()), d, generator=g).to(dev)
+    probes = [torch.randn(bsz, d, generator=g).to(dev) for _ in range(3)]
+    return ca, text, mask, nodes, batch, probes
+
+
+@pytest.mark.parametrize("autocast", [None, torch.bfloat16])
+def test_key_gradient_sink_gives_the_gradients_of_plain_autograd(dev, autocast):
+    """KEY_GRADIENT_SINK: the layers' dKV kernels add into one buffer and the CLS gradients join it in place -- the gradients of the
+    text rows, the nodes and every parameter equal those of plain autograd accumulation (same kernels, same dropout masks; only the
+    order of the three-term sums on the CLS rows differs).  Also: a use of the text tensor outside the protocol, a backward that
+    does not reach the text (torch.autograd.grad for the nodes alone) followed by a full one, and two backwards of one graph."""
+    import contextlib
+    import medtok_amd.vector_quantization_soft_one_new as vqmod
+    ca, text0, mask, nodes0, batch, (pa, pb, pc) = _pooled_case(dev)
+
+    def run(sink, mode):
+        old = vqmod.KEY_GRADIENT_SINK
+        vqmod.KEY_GRADIENT_SINK = sink
+        try:
+            ca.zero_grad(set_to_none=True)
+            text, nodes = text0.clone().requires_grad_(), nodes0.clone().requires_grad_()
+            torch.manual_seed(11)                     # (the dropout seeds come from the host generator)
+            ctx = torch.autocast("cuda", dtype=autocast) if autocast is not None else contextlib.nullcontext()
+            with ctx:
+                t = vqmod.fan_out_text(text) if mode == "fan-first" else text
+                fan = getattr(t, "_medtok_fan", None)
+                assert (fan is not None) == (sink and mode == "fan-first")
+                pt, pg = ca.pooled(t, mask, nodes, batch)
+                cls = t[:, 0] if fan is None else fan.cls
+                loss = (pt.float() * pa).sum() + (pg.float() * pb).sum() + (cls * pc).sum() + t[:, 1].pow(2).sum()
+            if mode == "partial-then-full":
+                g_nodes, = torch.autograd.grad(loss, [nodes], retain_graph=True)
+                loss.backward()
+                assert torch.allclose(g_nodes, nodes.grad, rtol=0, atol=0)
+            elif mode == "twice":
+                loss.backward(retain_graph=True)
+                first = text.grad.clone()
+                text.grad = None
+                nodes.grad = None
+                ca.zero_grad(set_to_none=True)
+                loss.backward()
+                assert torch.equal(first, text.grad)
+            else:
+                loss.backward()
+            return [text.grad.clone(), nodes.grad.clone()] + [p.grad.clone() for p in ca.parameters()]
+        finally:
+            vqmod.KEY_GRADIENT_SINK = old
+    ref = run(False, "plain")
+    assert float(ref[0].abs().max()) > 0 and float(ref[0][:, 2:].abs().max()) > 0      # the key gradients are there
+    for mode in ("plain", "fan-first", "partial-then-full", "twice"):
+        got = run(True, mode)
+        for a, b in zip(got, ref):
+            assert a.shape == b.shape
+            assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-6), mode
+
+
+def test_tokenizer_training_forward_maps_only_the_cls_row_of_the_aug_text(dev):
+    """MultimodalTokenizer.forward in training: the aug text view is only read at its CLS row (reference tokenizer.py:163), so only that
+    row goes through text_mapped; the CLS rows of the main view come from the gradient fan-out.  Outputs and the gradients of
+    text_mapped / the codebook equal the form that maps every token of both views (sink off, full aug map)."""
+    import medtok_amd.vector_quantization_soft_one_new as vqmod
+    from medtok_amd import loss as L
+    from medtok_amd.tokenizer import MultimodalTokenizer, make_inputs
+    bsz, seq_len, d = 12, 16, 128
+    g = torch.Generator(device="cpu").manual_seed(5)
+    counts = torch.randint(1, 9, (bsz,), generator=g)
+    inputs = make_inputs(batch=torch.repeat_interleave(torch.arange(bsz), counts).to(dev),
+                         attention_mask=(torch.arange(seq_len)[None, :] < torch.randint(1, seq_len + 1, (bsz, 1), generator=g)).long().to(dev),
+                         text_features=torch.randn(bsz, seq_len, 96, generator=g).to(dev),
+                         text_features_aug=torch.randn(bsz, seq_len, 96, generator=g).to(dev),
+                         graph_node_features=torch.randn(int(counts.sum()), d, generator=g).to(dev).requires_grad_(),
+                         graph_node_features_aug=torch.randn(int(counts.sum()), d, generator=g).to(dev).requires_grad_())
+    torch.manual_seed(3)
+    model = MultimodalTokenizer(None, None, text_dim=96, graph_out_channels=d, codebook_size=3000, codebook_embed_dim=d).to(dev).train()
+    for mod in model.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, nn.MultiheadAttention):
+            mod.dropout = 0.0
+    old = (vqmod.KEY_GRADIENT_SINK, vqmod.TRAIN_SPLIT_TEXT_MAPPING)
+
+    def run(sink, full_aug):
+        vqmod.KEY_GRADIENT_SINK, vqmod.TRAIN_SPLIT_TEXT_MAPPING = sink, True
+        model.zero_grad(set_to_none=True)
+        inputs.graph_node_features.grad = inputs.graph_node_features_aug.grad = None
+        if full_aug:                                   # the reference's form: every token of the aug view through the Linear
+            x = make_inputs(**vars(inputs))
+            x.text_features_aug = None
+            text_aug = model._map_text(inputs.text_features_aug)
+            text = model._map_text(inputs.text_features)
+            from medtok_amd.tokenizer import global_mean_pool
+            r = model.quant(text, inputs.graph_node_features, global_mean_pool(inputs.graph_node_features, inputs.batch, bsz), text_aug,
+                            inputs.graph_node_features_aug, global_mean_pool(inputs.graph_node_features_aug, inputs.batch, bsz),
+                            inputs.attention_mask, inputs.batch)
+        else:
+            r = model(inputs)
+        loss, _ = L.total_loss(r, 0.1, 0.1)
+        loss.backward()
+        return float(loss), [model.text_mapped.weight.grad.clone(), model.text_mapped.bias.grad.clone(), model.quantize.codebook.weight.grad.clone(),
+                             inputs.graph_node_features.grad.clone(), model.quantize.cross_attn.model[0].multihead_attn.in_proj_weight.grad.clone()]
+    try:
+        loss_ref, ref = run(False, True)
+        loss_new, got = run(True, False)
+    finally:
+        vqmod.KEY_GRADIENT_SINK, vqmod.TRAIN_SPLIT_TEXT_MAPPING = old
+    assert abs(loss_new - loss_ref) <= 1e-5 * abs(loss_ref)
+    for a, b in zip(got, ref):
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-6)
