@@ -470,6 +470,14 @@ int medtok_shared_kv_attention_train_f32(const float *q, const int64_t *q_start,
                                          const float *kv, const int64_t *kv_start, const int64_t *kv_len,
                                          int64_t n_codes, int64_t max_q_len, int d, float scale, float dropout_p,
                                          uint32_t seed, float *out, float *lse, void *stream);
+/* ... the same forward on the three-pass fp16 products (two 32-row query tiles of a code per block on one LDS copy of its keys, which
+ * the kernel splits into (hi, lo) fp16 images itself): out and lse equal medtok_shared_kv_attention_train_f32's to ~1e-6 relative, the
+ * dropout mask is bit-identical; d = 256, 512 or 768; q, kv, out 16-byte aligned.  The autocast trainer's form (train_MedTok.py:212):
+ * a third of the exact kernel's time at d = 768. */
+int medtok_shared_kv_attention_train_split_f32(const float *q, const int64_t *q_start, const int64_t *q_len,
+                                               const float *kv, const int64_t *kv_start, const int64_t *kv_len,
+                                               int64_t n_codes, int64_t max_q_len, int d, float scale, float dropout_p,
+                                               uint32_t seed, float *out, float *lse, void *stream);
 size_t medtok_shared_kv_attention_backward_workspace_bytes(int64_t q_rows);
 int medtok_shared_kv_attention_backward_f32(const float *q, const int64_t *q_start, const int64_t *q_len,
                                             const float *kv, const int64_t *kv_start, const int64_t *kv_len,

@@ -109,6 +109,7 @@ SIGNATURES = {
     "medtok_pack_codes": (_int, [_vp, _int, _i64, _i64, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "medtok_pack_codes_checked": (_int, [_vp, _int, _i64, _i64, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "medtok_shared_kv_attention_train_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f, _f, C.c_uint32, _vp, _vp, _vp]),
+    "medtok_shared_kv_attention_train_split_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _f, _f, C.c_uint32, _vp, _vp, _vp]),
     "medtok_shared_kv_attention_backward_workspace_bytes": (_sz, [_i64]),
     "medtok_shared_kv_attention_backward_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _f, _f, C.c_uint32,
                                                        _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

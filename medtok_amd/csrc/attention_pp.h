@@ -58,12 +58,18 @@ __device__ __forceinline__ float pp_exp(float x) { return __builtin_amdgcn_exp2f
 // its own copies have landed, a lane reads its two slots, forms hi = fp16(x), lo = fp16(x - hi) (the arithmetic of
 // split_half_kernel: same bits), and writes the two 16-byte images back into the two slots it read -- lane-local and in place, no
 // staging area, no extra barrier; the slot's closing barrier publishes the images.
-template <int NT, bool TIMED = false, bool KLO = true, bool KF32 = false>
+// TRAIN: the training forward under torch.autocast (the exact fp32 kernel of attention_kernels.h stays the fp32 trainer's): dropout on
+// the probabilities by the stateless hash mask of att_keep() -- a dropped probability does not reach the value product, the
+// normaliser is that of the full softmax, kept ones are scaled by keep_scale = 1 / (1 - p) -- and the log-sum-exp of every query row
+// for the backward kernels' softmax rebuild (attention_backward.h).  Same mask bits as the fp32 kernel (same hash of the same
+// (packed query row, key) pair); the three-pass products differ from its fp32 ones by ~2^-22 relative.
+template <int NT, bool TIMED = false, bool KLO = true, bool KF32 = false, bool TRAIN = false>
 __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
     const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
     const _Float16 *__restrict__ kvh, const _Float16 *__restrict__ kvl, const int64_t *__restrict__ kv_start,
     const int64_t *__restrict__ kv_len, float scale, float *__restrict__ out, _Float16 *__restrict__ out_h, _Float16 *__restrict__ out_l,
-    int q_pairs, int n_codes, unsigned long long *__restrict__ dbg = nullptr)
+    int q_pairs, int n_codes, unsigned long long *__restrict__ dbg = nullptr, float *__restrict__ lse = nullptr, unsigned drop_thresh = 0,
+    unsigned seed = 0, float keep_scale = 1.f)
 {
     using S = AttPP<NT>;
     constexpr int D = S::D, PIECE = S::PIECE, PLANEB = S::PLANEB, CHUNKB = S::CHUNKB, PSL = S::PSL, W = S::W;
@@ -287,8 +293,9 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             const float pr = pp_exp(v[j] - m_new);      // exp(-inf) = 0 for masked keys
-            hv[j] = (_Float16)pr;
-            lv[j] = (_Float16)(pr - (float)hv[j]);
+            const float pk = (TRAIN && drop_thresh && !att_keep(seed, qs + qt * 32 + xrow, 16 * c + xk0 + j, drop_thresh)) ? 0.f : pr;
+            hv[j] = (_Float16)pk;
+            lv[j] = (_Float16)(pk - (float)hv[j]);
             psum += pr;
         }
         lds_st32u(pp_adr, pack_h2(hv[0], hv[1]));
@@ -432,12 +439,17 @@ __global__ __launch_bounds__(512, 1) void shared_kv_attention_pp_kernel(
         o[7] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (gt % TPR == 0) l_s[xrow] = l_run;
+    if (gt % TPR == 0) {
+        l_s[xrow] = l_run;
+        // log-sum-exp of the scaled scores; -inf for an empty key set
+        if (TRAIN && lse && active && qt * 32 + xrow < nq) lse[qs + qt * 32 + xrow] = l_run > 0.f ? m_run + logf(l_run) : -INFINITY;
+    }
     __syncthreads();
     // the row tiles leave through LDS (ring and score tiles are free now), each group through its own staging area
     float l16[16];
+    const float unkeep = TRAIN ? 1.f / keep_scale : 1.f;         // (the store divides by l16: kept probabilities count 1 / (1 - p))
 #pragma unroll
-    for (int r = 0; r < 16; ++r) l16[r] = l_s[(r & 3) + 8 * (r >> 2) + 4 * lh];
+    for (int r = 0; r < 16; ++r) l16[r] = TRAIN ? l_s[(r & 3) + 8 * (r >> 2) + 4 * lh] * unkeep : l_s[(r & 3) + 8 * (r >> 2) + 4 * lh];
     __syncthreads();
     att_store_tile<W, NT, S::HALVES>(att_sm + grp * S::STAGE_FLOATS, acc, l16, active ? nq - qt * 32 : 0, qs + qt * 32, out, out_h, out_l, slice, li, lh, gt);
 }

@@ -2573,6 +2573,40 @@ extern "C" int medtok_shared_kv_attention_train_f32(const float *q, const int64_
     return attention_forward(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, d, scale, out, lse, dropout_p, seed, (hipStream_t)stream);
 }
 
+// The training forward on the three-pass fp16 products (attention_pp.h, TRAIN form): two 32-row query tiles of a code per block on one
+// copy of its keys, which the kernel turns from the caller's fp32 rows into (hi, lo) images itself.  Same outputs as
+// medtok_shared_kv_attention_train_f32 to ~1e-6 relative (same dropout mask bits), about a third of its time at d = 768; d = 256, 512, 768.
+extern "C" int medtok_shared_kv_attention_train_split_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
+                                                          const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
+                                                          int d, float scale, float dropout_p, uint32_t seed, float *out, float *lse, void *stream)
+{
+    if (n_codes < 0 || max_q_len < 0) return fail("shared_kv_attention_train_split: bad sizes n_codes=%ld max_q_len=%ld", (long)n_codes, (long)max_q_len);
+    if (d != 256 && d != 512 && d != 768) return fail("shared_kv_attention_train_split: d=%d must be 256, 512 or 768", d);
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail("shared_kv_attention_train_split: dropout_p=%g must be in [0, 1)", (double)dropout_p);
+    if (n_codes == 0 || max_q_len == 0) return 0;
+    if (!q || !q_start || !q_len || !kv || !kv_start || !kv_len || !out || !lse) return fail("shared_kv_attention_train_split: NULL argument");
+    if (((uintptr_t)q | (uintptr_t)kv | (uintptr_t)out) & 15) return fail("shared_kv_attention_train_split: pointers must be 16-byte aligned");
+    const int64_t q_pairs = (max_q_len + 63) / 64;
+    if (q_pairs * (n_codes + 8) >= (1ll << 31)) return fail("shared_kv_attention_train_split: grid limit exceeded");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
+    const float keep_scale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+#define MEDTOK_ATT_PP_TRAIN(NT)                                                                                                   \
+    do {                                                                                                                          \
+        const size_t lds = AttPP<NT>::LDS_BYTES;                                                                                  \
+        if (!set_lds_once<shared_kv_attention_pp_kernel<NT, false, true, true, true>>(lds))                                        \
+            return fail("shared_kv_attention_train_split: cannot reserve %zu bytes of LDS", lds);                                 \
+        hipLaunchKernelGGL((shared_kv_attention_pp_kernel<NT, false, true, true, true>), dim3((unsigned)(q_pairs * ((n_codes + 7) / 8 * 8))), dim3(512), lds, s, \
+                           q, q_start, q_len, (const _Float16 *)kv, (const _Float16 *)nullptr, kv_start, kv_len, scale, out, (_Float16 *)nullptr,  \
+                           (_Float16 *)nullptr, (int)q_pairs, (int)n_codes, (unsigned long long *)nullptr, lse, thresh, seed, keep_scale); \
+    } while (0)
+    if (d == 256) MEDTOK_ATT_PP_TRAIN(2); else if (d == 512) MEDTOK_ATT_PP_TRAIN(4); else MEDTOK_ATT_PP_TRAIN(6);
+#undef MEDTOK_ATT_PP_TRAIN
+    if (pa) prof_push(pa, prof_mark(s), 0.0, 2);
+    return check_launch("shared_kv_attention_train_split");
+}
+
 extern "C" size_t medtok_shared_kv_attention_backward_workspace_bytes(int64_t q_rows) { return q_rows > 0 ? align_up((size_t)q_rows * 4, 256) : 256; }
 
 static int attention_backward_impl(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,

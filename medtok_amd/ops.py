@@ -683,18 +683,25 @@ def shared_kv_attention_split(q, q_start, q_len, kv_split, kv_start, kv_len, max
     return (oh, ol) if split_out else out
 
 
-def shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, scale: float, dropout_p: float = 0.0, seed: int = 0):
-    """(out, lse): the attention core with dropout on the probabilities (stateless hash mask) and the log-sum-exp per query row."""
+ATTENTION_TRAIN_SPLIT_WIDTHS = (256, 512, 768)
+
+
+def shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, scale: float, dropout_p: float = 0.0, seed: int = 0,
+                              split: bool = False):
+    """(out, lse): the attention core with dropout on the probabilities (stateless hash mask) and the log-sum-exp per query row.
+    split=True (widths ATTENTION_TRAIN_SPLIT_WIDTHS): on the three-pass fp16 products instead of the exact fp32 matrix pipe -- the
+    same mask bits, outputs within ~1e-6 relative, a third of the time at D = 768 (the autocast trainer's form)."""
     q, kv = _dev(q, "q"), _dev(kv, "kv")
     qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
     ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
     out = torch.zeros_like(q)                 # rows that belong to no code stay zero
     lse = torch.full((q.shape[0],), float("-inf"), dtype=torch.float32, device=q.device)
+    lib = _lib.load()
+    fn, name = ((lib.medtok_shared_kv_attention_train_split_f32, "medtok_shared_kv_attention_train_split_f32") if split else
+                (lib.medtok_shared_kv_attention_train_f32, "medtok_shared_kv_attention_train_f32"))
     with _on(q.device):
-        _lib.check(_lib.load().medtok_shared_kv_attention_train_f32(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(),
-                                                                    kl.data_ptr(), qs.numel(), int(max_q_len), q.shape[1], float(scale),
-                                                                    float(dropout_p), int(seed) & 0xFFFFFFFF, out.data_ptr(), lse.data_ptr(),
-                                                                    _stream(q)), "medtok_shared_kv_attention_train_f32")
+        _lib.check(fn(q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(), kl.data_ptr(), qs.numel(), int(max_q_len), q.shape[1],
+                      float(scale), float(dropout_p), int(seed) & 0xFFFFFFFF, out.data_ptr(), lse.data_ptr(), _stream(q)), name)
     return out, lse
 
 

@@ -72,6 +72,9 @@ TRAIN_SPLIT_TEXT_MAPPING = False
 # autocast gives the reference's nn.Linear / nn.MultiheadAttention, train_MedTok.py:212,394) instead of the fp32-accurate three-pass
 # form (3x the matrix work, device-side |x|_max prescales, lo images); fp32 callers keep the three-pass form
 AUTOCAST_HALF_PRODUCTS = True
+# ... and the attention forward of the graph side (many query rows per code) on the inference kernel's three-pass fp16 products with
+# dropout and log-sum-exp added (attention_pp.h, TRAIN form) instead of the exact fp32 matrix pipe: 420 -> ~165 us per layer at cfg 4
+AUTOCAST_SPLIT_ATTENTION_FORWARD = True
 # training: the two directions of the cross-attention share every layer's weights, so their rows go through the layer's dense
 # products in one launch per product (CrossAttention._pooled_packed)
 MERGE_SIDES_IN_TRAINING = True
@@ -277,14 +280,17 @@ class _RaggedAttentionFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, kv, q_start, q_len, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed, sink=None):
         qf, kvf = q.detach().float().contiguous(), kv.detach().float().contiguous()
-        out, lse = ops.shared_kv_attention_train(qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, scale, dropout_p, seed)
+        # under torch.autocast the backward's four matrix products run as ONE half-precision pass (the reference's class there) and
+        # the forward on the three-pass fp16 products (fp32-accurate to ~1e-6: its log-sum-exp feeds the backward's softmax
+        # rebuild) where more than a few query rows share a code's keys; fp32 callers keep the exact fp32 kernels on both sides
+        ctx.half = (torch.get_autocast_dtype("cuda") if (AUTOCAST_HALF_PRODUCTS and torch.is_autocast_enabled()
+                                                         and torch.get_autocast_dtype("cuda") in (torch.float16, torch.bfloat16)) else None)
+        split = (ctx.half is not None and AUTOCAST_SPLIT_ATTENTION_FORWARD and qf.shape[1] in ops.ATTENTION_TRAIN_SPLIT_WIDTHS
+                 and max_q_len > 8 and qf.shape[0] > 0 and kvf.shape[0] > 0)
+        out, lse = ops.shared_kv_attention_train(qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, scale, dropout_p, seed, split=split)
         ctx.save_for_backward(qf, kvf, out, lse, q_start, q_len, kv_start, kv_len)
         ctx.cfg = (max_q_len, max_kv_len, scale, dropout_p, seed, q.dtype, kv.dtype)
         ctx.sink = sink
-        # under torch.autocast the backward's four matrix products run as ONE half-precision pass (the reference's class there);
-        # the forward stays on the exact fp32 kernel (its log-sum-exp feeds the backward's softmax rebuild)
-        ctx.half = (torch.get_autocast_dtype("cuda") if (AUTOCAST_HALF_PRODUCTS and torch.is_autocast_enabled()
-                                                         and torch.get_autocast_dtype("cuda") in (torch.float16, torch.bfloat16)) else None)
         return out
 
     @staticmethod

@@ -625,3 +625,43 @@ def test_attention_backward_accumulates_key_gradient_in_place(dev, d, half):
         ops.shared_kv_attention_backward(*args, *tail, accumulate=True)
     with pytest.raises(ValueError):
         ops.shared_kv_attention_backward(*args, *tail, dkv_into=held[:, : d // 2], accumulate=True)
+
+
+@pytest.mark.parametrize("d,p", [(256, 0.0), (512, 0.1), (768, 0.1), (768, 0.0), (256, 0.5)])
+def test_attention_train_forward_on_split_products_matches_the_fp32_kernel(oracle, dev, d, p):
+    """medtok_shared_kv_attention_train_split_f32 (the autocast trainer's forward: three-pass fp16 products, keys split in the kernel)
+    against the exact fp32 training kernel and the C oracle: out and log-sum-exp within 1e-5, the SAME dropout mask (a dropped
+    probability is an exact zero contribution: with one key per code the outputs of dropped rows are exactly zero in both), rows of no
+    code zero / -inf, codes without keys or queries, odd tile counts (group 1 idle), and the backward fed from it tracks the oracle."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(d + int(100 * p))
+    q_len = np.array([40, 7, 0, 64, 33, 5, 130, 97], np.int64); kv_len = np.array([50, 33, 12, 100, 0, 1, 300, 17], np.int64)
+    slot_kv = kv_len + np.array([0, 3, 0, 0, 4, 0, 0, 5])
+    q_start, kv_start = np.cumsum(q_len) - q_len, np.cumsum(slot_kv) - slot_kv
+    nq, nk = int(q_len.sum()) + 2, int(slot_kv.sum())
+    q = (rng.standard_normal((nq, d)) * 0.3).astype(np.float32); kv = rng.standard_normal((nk, d)).astype(np.float32)
+    d_out = rng.standard_normal((nq, d)).astype(np.float32)
+    scale, seed = 0.2, 99
+    T = lambda a: torch.from_numpy(a).to(dev)
+    args = (T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len))
+    out0, lse0 = ops.shared_kv_attention_train(*args, int(q_len.max()), scale, p, seed)
+    out1, lse1 = ops.shared_kv_attention_train(*args, int(q_len.max()), scale, p, seed, split=True)
+    out_o, lse_o, dq_o, dkv_o = oracle.shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, scale, p, seed, d_out)
+    assert np.abs(out1.cpu().numpy() - out_o).max() <= 1e-5 * np.abs(out_o).max()
+    assert float((out1 - out0).abs().max()) <= 1e-5 * float(out0.abs().max())
+    own = np.zeros(nq, bool)
+    for b in range(len(q_len)):
+        own[q_start[b]: q_start[b] + q_len[b]] = True
+    fin = own & np.isfinite(lse_o)
+    assert np.allclose(lse1.cpu().numpy()[fin], lse_o[fin], rtol=1e-5, atol=1e-5) and np.isinf(lse1.cpu().numpy()[own & ~fin]).all()
+    assert not out1.cpu().numpy()[~own].any() and np.isinf(lse1.cpu().numpy()[~own]).all()
+    # the code with ONE key: a row's output is that key (kept, scaled) or exactly zero (dropped) -- the same rows in both kernels
+    one = slice(int(q_start[5]), int(q_start[5] + q_len[5]))
+    assert torch.equal(out1[one].abs().sum(1) == 0, out0[one].abs().sum(1) == 0)
+    dq, dkv = ops.shared_kv_attention_backward(*args, int(q_len.max()), int(kv_len.max()), scale, p, seed, out1, lse1, T(d_out))
+    assert np.abs(dq.cpu().numpy() - dq_o).max() <= 2e-5 * np.abs(dq_o).max()
+    assert np.abs(dkv.cpu().numpy() - dkv_o).max() <= 2e-5 * np.abs(dkv_o).max()
+    out2, lse2 = ops.shared_kv_attention_train(*args, int(q_len.max()), scale, p, seed, split=True)
+    assert torch.equal(out2, out1) and torch.equal(lse2, lse1)
+    with pytest.raises(Exception):
+        ops.shared_kv_attention_train(T(q[:, :128].copy()), *args[1:3], T(kv[:, :128].copy()), *args[4:], int(q_len.max()), scale, p, seed, split=True)
