@@ -317,6 +317,11 @@ class _RaggedAttentionFunction(torch.autograd.Function):
         return dq.to(qd), dkv.to(kd), None, None, None, None, None, None, None, None, None, None
 
 
+# split-K of the weight-gradient products (dW = dY^T X, contraction over the rows): at least this many rows per group.  A cfg 4 layer
+# has ~5 600 rows: at 2048 its [768, 768] gradients ran as 18 blocks of 256 x 256 on 256 CUs (56 us), its block-diagonal ones as 72 (146 us)
+SPLIT_K_MIN_ROWS = 512
+
+
 def _pad32(n):
     return (int(n) + 31) // 32 * 32
 
@@ -394,7 +399,7 @@ class _SplitLinearFunction(torch.autograd.Function):
     def _row_split(m, n, k):
         """split-K of the weight-gradient product: (groups, rows per group (a multiple of 64), padded row count)"""
         tiles = ((n + 255) // 256) * ((k + 255) // 256)
-        groups = max(1, min(256 // max(tiles, 1), m // 2048))
+        groups = max(1, min(256 // max(tiles, 1), m // SPLIT_K_MIN_ROWS))
         chunk = (-(-m // groups) + 63) // 64 * 64
         groups = -(-m // chunk)
         return groups, chunk, groups * chunk
@@ -470,11 +475,7 @@ class _SplitLinearFunction(torch.autograd.Function):
             # split-K in one grouped launch: the rows are cut into G chunks, group g multiplies chunk g of both operands into its own
             # [n, k] block, the G blocks are summed (a [768, 768] gradient is nine 256 x 256 tiles: alone they would walk all the
             # rows on nine CUs)
-            tiles = ((n + 255) // 256) * ((k + 255) // 256)
-            groups = max(1, min(256 // max(tiles, 1), m // 2048))
-            chunk = (-(-m // groups) + 63) // 64 * 64
-            groups = -(-m // chunk)
-            mp = groups * chunk
+            groups, chunk, mp = _SplitLinearFunction._row_split(m, n, k)
             dw = ops.split_gemm_scaled(ops.split_half_scaled(dyf, mp, ad, transpose=True),
                                        ops.split_half_scaled(xf, mp, ax, transpose=True, group_cols=chunk),
                                        n_g=k, k_g=chunk, amax_a=ad, amax_b=ax, groups=groups, a_group_cols=chunk, b_group_rows=k)
@@ -486,6 +487,35 @@ class _SplitLinearFunction(torch.autograd.Function):
 
 def split_linear(x, w, b=None):
     return _SplitLinearFunction.apply(x, w, b)
+
+
+class _HeadBlockDiag(torch.autograd.Function):
+    """The block-diagonal matrix of a [H hd, D] projection weight's per-head blocks -- transposed: blocks w_h^T, [H D, H hd] (the fold
+    of W_k into the queries); else blocks w_h, [H hd, H D] (W_v on the per-head contexts) -- in two launches (zero fill + one
+    strided copy) with a one-launch backward (the diagonal blocks of the gradient, gathered).  torch.block_diag over H slices is
+    the same matrix in 5 launches forward and 11 backward (a zero [D, D] tensor, a copy and an add per slice)."""
+
+    @staticmethod
+    def forward(ctx, w, heads, transposed):
+        hd, dim = w.shape[0] // heads, w.shape[1]
+        ctx.cfg = (heads, hd, dim, transposed)
+        blocks = w.detach().view(heads, hd, dim)
+        if transposed:
+            out = w.new_zeros(heads * dim, heads * hd)
+            out.view(heads, dim, heads, hd).diagonal(dim1=0, dim2=2).copy_(blocks.permute(2, 1, 0))
+        else:
+            out = w.new_zeros(heads * hd, heads * dim)
+            out.view(heads, hd, heads, dim).diagonal(dim1=0, dim2=2).copy_(blocks.permute(1, 2, 0))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        heads, hd, dim, transposed = ctx.cfg
+        if transposed:
+            gw = g.view(heads, dim, heads, hd).diagonal(dim1=0, dim2=2).permute(2, 1, 0)
+        else:
+            gw = g.view(heads, hd, heads, dim).diagonal(dim1=0, dim2=2).permute(2, 0, 1)
+        return gw.reshape(heads * hd, dim), None, None
 
 
 class CrossAttentionLayer(nn.Module):
@@ -763,10 +793,10 @@ class CrossAttention(nn.Module):
             # of the four products -- immaterial at training sizes (a per-GPU batch of 256 codes is launch-bound), and one
             # autograd function instead of four.
             q = split_linear(rows, wq, bq)                                                             # [R, D]
-            wk_bd = torch.block_diag(*[wk[h * hd:(h + 1) * hd].t() for h in range(heads)])              # [H D, H hd]
+            wk_bd = _HeadBlockDiag.apply(wk, heads, True)                                              # [H D, H hd]: blocks Wk_h^T
             qf = split_linear(q, wk_bd).view(n_rows * heads, dim)                                      # row r, head h: Wk_h^T q_{r,h}
             ctx = attend(qf.contiguous())
-            wv_bd = torch.block_diag(*[wv[h * hd:(h + 1) * hd] for h in range(heads)])                  # [H hd, H D]
+            wv_bd = _HeadBlockDiag.apply(wv, heads, False)                                             # [H hd, H D]: blocks Wv_h
             attended = split_linear(ctx.float().view(n_rows, heads * dim), wv_bd, bv)                   # [R, D]
             out = split_linear(attended, mha.out_proj.weight, mha.out_proj.bias)
             with torch.autocast(device_type="cuda", enabled=False):
