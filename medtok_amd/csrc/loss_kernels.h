@@ -29,11 +29,17 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const float *__restrict__ 
 // C[m, n] = sum_k A[m * sam + k * sak] * B[k * sbk + n * sbn], row-major C [M, N]; any transposition is a choice of strides.
 // One wavefront per 32 x 32 tile of C; lane (i = lane & 31, h = lane >> 5) feeds A[m0 + i][k + h] and B[k + h][n0 + i] to
 // v_mfma_f32_32x32x2_f32, so every entry is the fmaf chain over k = 0, 1, 2, ... .  The operands of these losses are a few
-// hundred KB (B = 256 rows of D <= 1536): they live in the L2, the loads are whatever the strides make them, and the whole
-// product is a few microseconds -- the point is one exact, reproducible kernel behind the C ABI, not a tuned GEMM.
+// hundred KB (B = 256 rows of D <= 1536) and live in the L2; a tile's chain is K / 2 dependent MFMAs (768: ~10 us of matrix pipe)
+// whatever the launch looks like, so the kernel's job is to keep the loads out of that chain: trips of 32 k, the NEXT trip's
+// operands requested before this trip's 16 MFMAs (two register sets), 16-byte loads of four consecutive k where an operand is
+// contiguous along k (AV / BV: a lane then reads the 32 k of its row and picks its half-wave's parity).  Round 5's form loaded
+// 8 k, waited, multiplied: one L2 round trip per four MFMAs -- 38 us for K = 256, 90 us for K = 768 (six launches and 0.44 ms of
+// a cfg 4 training step).  Same MFMA sequence per entry, same bits.
+template <bool AV, bool BV>
 __global__ __launch_bounds__(256) void small_gemm_f32_kernel(const float *__restrict__ A, long sam, long sak, const float *__restrict__ B,
                                                              long sbk, long sbn, int M, int N, int K, float *__restrict__ C)
 {
+    constexpr int T = 32;                                              // k per trip
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     const int tiles_n = (N + 31) / 32;
     const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -44,13 +50,48 @@ __global__ __launch_bounds__(256) void small_gemm_f32_kernel(const float *__rest
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // one trip's operands: scalar form = element j is k + 2 j + lh; vector form = float4 #j holds k + 4 j .. + 3 (both half-waves
+    // load the same 32 values and pick theirs below)
+    struct Trip { float a[AV ? 1 : 16]; float4 a4[AV ? 8 : 1]; float b[BV ? 1 : 16]; float4 b4[BV ? 8 : 1]; };
+    auto load = [&](Trip &t, int k) __attribute__((always_inline)) {
+        if (AV) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t.a4[j] = ld4(pa + k + 4 * j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t.a[j] = pa[(k + 2 * j + lh) * sak];
+        }
+        if (BV) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t.b4[j] = ld4(pb + k + 4 * j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t.b[j] = pb[(k + 2 * j + lh) * sbk];
+        }
+    };
+    auto compute = [&](const Trip &t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float av, bv;
+            if (AV) { const float4 v = t.a4[j / 2]; av = (j & 1) ? (lh ? v.w : v.z) : (lh ? v.y : v.x); } else av = t.a[j];
+            if (BV) { const float4 v = t.b4[j / 2]; bv = (j & 1) ? (lh ? v.w : v.z) : (lh ? v.y : v.x); } else bv = t.b[j];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    };
+    Trip t0, t1;
     int k = 0;
-    for (; k + 8 <= K; k += 8) {              // four MFMAs per trip, loads issued together
-        float av[4], bv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { av[j] = pa[(k + 2 * j + lh) * sak]; bv[j] = pb[(k + 2 * j + lh) * sbk]; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+    if (T <= K) load(t0, 0);
+    while (k + T <= K) {                      // t0 holds trip k
+        const bool more1 = k + 2 * T <= K;
+        if (more1) load(t1, k + T);
+        compute(t0);
+        k += T;
+        if (!more1) break;
+        const bool more0 = k + 2 * T <= K;    // t1 holds trip k
+        if (more0) load(t0, k + T);
+        compute(t1);
+        k += T;
+        if (!more0) break;
     }
     for (; k < K; k += 2) {
         const bool live = k + lh < K;         // odd K: the upper half-wave adds +0 * b = nothing

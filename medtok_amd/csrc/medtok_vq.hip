@@ -1955,8 +1955,14 @@ extern "C" int medtok_small_gemm_f32(const float *A, int64_t sam, int64_t sak, c
     if (m <= 0 || n <= 0 || k <= 0) return fail("small_gemm: bad shape m=%d n=%d k=%d", m, n, k);
     if (!A || !B || !C) return fail("small_gemm: NULL argument");
     const long tiles = (long)((m + 31) / 32) * ((n + 31) / 32);
-    hipLaunchKernelGGL(small_gemm_f32_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, A, (long)sam, (long)sak, B,
-                       (long)sbk, (long)sbn, m, n, k, C);
+    // an operand that is contiguous along k, 16-byte aligned in every row: four consecutive k per load
+    const bool av = sak == 1 && (sam & 3) == 0 && ((uintptr_t)A & 15) == 0, bv = sbk == 1 && (sbn & 3) == 0 && ((uintptr_t)B & 15) == 0;
+#define MEDTOK_SMALL_GEMM(AV, BV)                                                                                                 \
+    hipLaunchKernelGGL((small_gemm_f32_kernel<AV, BV>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, A, (long)sam, \
+                       (long)sak, B, (long)sbk, (long)sbn, m, n, k, C)
+    if (av && bv) MEDTOK_SMALL_GEMM(true, true); else if (av) MEDTOK_SMALL_GEMM(true, false);
+    else if (bv) MEDTOK_SMALL_GEMM(false, true); else MEDTOK_SMALL_GEMM(false, false);
+#undef MEDTOK_SMALL_GEMM
     return check_launch("small_gemm");
 }
 

@@ -133,7 +133,7 @@ def test_total_loss_assembly_on_device(golden, dev):
     assert set(parts) >= {"codebook_loss", "shared_loss", "specific_loss"}
 
 
-@pytest.mark.parametrize("b,d1,d2", [(16, 64, 64), (256, 768, 768), (37, 100, 36), (5, 4, 8)])
+@pytest.mark.parametrize("b,d1,d2", [(16, 64, 64), (256, 768, 768), (37, 100, 36), (5, 4, 8), (77, 132, 68), (200, 96, 260), (64, 33, 31)])
 def test_alignment_and_orthogonal_kernels_match_oracle(oracle, dev, b, d1, d2):
     """alignment_loss / orthogonal_loss (loss.py:59-83) on the gfx950 kernels vs the C oracle: row dots and every entry of
     z^T z* bit-identical (one fmaf chain per entry), the Frobenius norm to fp32 round-off; all three GEMM orientations the
