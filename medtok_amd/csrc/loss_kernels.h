@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const float *__restrict__ 
 }
 
 // C[m, n] = sum_k A[m * sam + k * sak] * B[k * sbk + n * sbn], row-major C [M, N]; any transposition is a choice of strides.
-// One wavefront per 32 x 32 tile of C; lane (i = lane & 31, h = lane >> 5) feeds A[m0 + i][k + h] and B[k + h][n0 + i] to
+// One wavefront (= one block) per 32 x 32 tile of C; lane (i = lane & 31, h = lane >> 5) feeds A[m0 + i][k + h] and B[k + h][n0 + i] to
 // v_mfma_f32_32x32x2_f32, so every entry is the fmaf chain over k = 0, 1, 2, ... .  The operands of these losses are a few
 // hundred KB (B = 256 rows of D <= 1536) and live in the L2; a tile's chain is K / 2 dependent MFMAs (768: ~10 us of matrix pipe)
 // whatever the launch looks like, so the kernel's job is to keep the loads out of that chain: trips of 32 k, the NEXT trip's
@@ -36,14 +36,16 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const float *__restrict__ 
 // 8 k, waited, multiplied: one L2 round trip per four MFMAs -- 38 us for K = 256, 90 us for K = 768 (six launches and 0.44 ms of
 // a cfg 4 training step).  Same MFMA sequence per entry, same bits.
 template <bool AV, bool BV>
-__global__ __launch_bounds__(256) void small_gemm_f32_kernel(const float *__restrict__ A, long sam, long sak, const float *__restrict__ B,
-                                                             long sbk, long sbn, int M, int N, int K, float *__restrict__ C)
+__global__ __launch_bounds__(64) void small_gemm_f32_kernel(const float *A, long sam, long sak, const float *B,
+                                                             long sbk, long sbn, int M, int N, int K, float *C)
 {
     constexpr int T = 32;                                              // k per trip
     const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     const int tiles_n = (N + 31) / 32;
-    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= (long)tiles_n * ((M + 31) / 32)) return;
+    // ONE wavefront per block: a tile's loads are 32 rows x 128 bytes per instruction (strided rows: 32 cache lines each), and four
+    // waves on one CU queued four tiles' worth of them on its single L1 (1.9 us per 32-k trip against 0.45 us of MFMAs); the few
+    // hundred tiles of these products spread over as many CUs instead
+    const long tile = blockIdx.x;
     const int m0 = (int)(tile / tiles_n) * 32, n0 = (int)(tile % tiles_n) * 32;
     const int am = min(m0 + li, M - 1), bn = min(n0 + li, N - 1);      // clamped lanes compute entries that are never stored
     const float *pa = A + am * sam, *pb = B + bn * sbn;
@@ -78,21 +80,25 @@ __global__ __launch_bounds__(256) void small_gemm_f32_kernel(const float *__rest
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
     };
+    // (the prefetches are unconditional -- past the last trip they re-read it -- so that no branch stands between a load and the
+    // wait for it: hipcc's wait-count pass merges the paths of a conditional load into "wait for everything")
     Trip t0, t1;
-    int k = 0;
-    if (T <= K) load(t0, 0);
-    while (k + T <= K) {                      // t0 holds trip k
-        const bool more1 = k + 2 * T <= K;
-        if (more1) load(t1, k + T);
-        compute(t0);
-        k += T;
-        if (!more1) break;
-        const bool more0 = k + 2 * T <= K;    // t1 holds trip k
-        if (more0) load(t0, k + T);
-        compute(t1);
-        k += T;
-        if (!more0) break;
+    const int trips = K / T;
+    if (trips > 0) {
+        load(t0, 0);
+        for (int t = 0; t < trips; t += 2) {          // t0 holds trip t
+            load(t1, min(t + 1, trips - 1) * T);
+            // (the loads may not sink below this statement, the MFMAs -- through acc -- may not rise above it: left alone hipcc
+            // puts every load just in front of its MFMA, or this trip's MFMAs in front of the next trip's loads)
+            asm volatile("" : "+v"(acc) : : "memory");
+            compute(t0);
+            if (t + 1 >= trips) break;
+            load(t0, min(t + 2, trips - 1) * T);
+            asm volatile("" : "+v"(acc) : : "memory");
+            compute(t1);
+        }
     }
+    int k = trips * T;
     for (; k < K; k += 2) {
         const bool live = k + lh < K;         // odd K: the upper half-wave adds +0 * b = nothing
         const float av = live ? pa[(k + lh) * sak] : 0.f, bv = live ? pb[(k + lh) * sbk] : 0.f;

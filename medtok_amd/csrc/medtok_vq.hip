@@ -1958,7 +1958,7 @@ extern "C" int medtok_small_gemm_f32(const float *A, int64_t sam, int64_t sak, c
     // an operand that is contiguous along k, 16-byte aligned in every row: four consecutive k per load
     const bool av = sak == 1 && (sam & 3) == 0 && ((uintptr_t)A & 15) == 0, bv = sbk == 1 && (sbn & 3) == 0 && ((uintptr_t)B & 15) == 0;
 #define MEDTOK_SMALL_GEMM(AV, BV)                                                                                                 \
-    hipLaunchKernelGGL((small_gemm_f32_kernel<AV, BV>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, A, (long)sam, \
+    hipLaunchKernelGGL((small_gemm_f32_kernel<AV, BV>), dim3((unsigned)tiles), dim3(64), 0, (hipStream_t)stream, A, (long)sam,              \
                        (long)sak, B, (long)sbk, (long)sbn, m, n, k, C)
     if (av && bv) MEDTOK_SMALL_GEMM(true, true); else if (av) MEDTOK_SMALL_GEMM(true, false);
     else if (bv) MEDTOK_SMALL_GEMM(false, true); else MEDTOK_SMALL_GEMM(false, false);
