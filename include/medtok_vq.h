@@ -73,13 +73,16 @@ const char *medtok_last_error(void);
  * backward kernels from its own thread); meant for one profiling client at a time. */
 #define MEDTOK_PROFILE_KINDS 5
 int medtok_profile_begin(void);
+/* ... bracketing only the launches of the kinds whose bit is set in `kinds` (bit k = kind k): a training step is ~180 library launches,
+ * and two event records per launch are ~0.5 ms of an 11 ms step; a timed region then carries the events of its dominant kernel only. */
+int medtok_profile_begin_kinds(unsigned kinds);
 int medtok_profile_end(double ms[MEDTOK_PROFILE_KINDS], double flops[MEDTOK_PROFILE_KINDS],
                        int launches[MEDTOK_PROFILE_KINDS]);
 
 /* Several SMALL soft top-k searches in one call and three launches (normalise, search, merge + assign) instead of four launches each:
  * the B = 256 forward of the reference's default configuration (train_MedTok.py:363-368,387) runs its two modality-specific
  * searches (:187-217) and its shared searches (:147-165) on 256-512 rows each -- 16 launches of 4-30 us for 2 GFLOP.  Every
- * descriptor is one medtok_soft_vq_forward_f32 call (eval: no squared-error output) and yields the same bits; all searches share
+ * descriptor is one medtok_soft_vq_forward_f32 call (row_sqerr NULL: no squared-error output) and yields the same bits; all searches share
  * d and topk.  Only searches that medtok_soft_vq_multi_eligible() accepts (the exact fp32-MFMA path, at most 4096 rows).
  * xhat [n, d], idx [n, topk], dist [n, topk], w [n, topk] (may be NULL), zq [n, d] with row stride zq_stride (0 = d). */
 typedef struct medtok_search_desc {
@@ -87,6 +90,8 @@ typedef struct medtok_search_desc {
     const float *what, *wsq; int64_t k_codes;
     float *xhat; int64_t *idx; float *dist, *w, *zq; int64_t zq_stride;
     int64_t x_stride;                       /* row stride of x in floats (0 = d): x may be a column block of a wider matrix */
+    float *row_sqerr;                       /* [n] or NULL: per-row squared error of the soft assignment (medtok_soft_vq_forward_f32's
+                                               row_sqerr: the training forward's vq / commitment losses are its fixed-order sums) */
 } medtok_search_desc;
 #define MEDTOK_MULTI_SEARCH_MAX 6
 int medtok_soft_vq_multi_eligible(int64_t n, int64_t k_codes, int d, int topk);

@@ -50,6 +50,7 @@ SIGNATURES = {
     "medtok_abi_version": (_int, []),
     "medtok_last_error": (C.c_char_p, []),
     "medtok_profile_begin": (_int, []),
+    "medtok_profile_begin_kinds": (_int, [C.c_uint]),
     "medtok_profile_end": (_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "medtok_soft_vq_multi_eligible": (_int, [_i64, _i64, _int, _int]),
     "medtok_soft_vq_forward_multi_workspace_bytes": (_sz, [_vp, _int, _int, _int]),
@@ -148,7 +149,7 @@ PREP_MAX_REGIONS = 4
 class SearchDesc(C.Structure):
     """medtok_search_desc (include/medtok_vq.h)"""
     _fields_ = [("x", _vp), ("n", _i64), ("what", _vp), ("wsq", _vp), ("k_codes", _i64), ("xhat", _vp), ("idx", _vp), ("dist", _vp), ("w", _vp),
-                ("zq", _vp), ("zq_stride", _i64), ("x_stride", _i64)]
+                ("zq", _vp), ("zq_stride", _i64), ("x_stride", _i64), ("row_sqerr", _vp)]
 
 
 MULTI_SEARCH_MAX = 6

@@ -60,6 +60,8 @@ struct ProfRec { hipEvent_t a, b; double flops; int kind; };   // kind 0 = filte
 // Process-wide (the backward kernels are launched from autograd's own thread): a flag read on every launch, the records and the
 // event pool behind one mutex that is only ever taken while profiling is on.
 static std::atomic<bool> g_prof_on{false};
+static std::atomic<unsigned> g_prof_kinds{~0u};      // bit k: launches of kind k are bracketed (medtok_profile_begin_kinds)
+static inline bool prof_wanted(int kind) { return g_prof_on && ((g_prof_kinds >> kind) & 1u); }
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 
@@ -84,8 +86,15 @@ static void prof_push(hipEvent_t a, hipEvent_t b, double flops, int kind)
     g_prof.push_back({a, b, flops, kind});
 }
 
-extern "C" int medtok_profile_begin(void)
+static int profile_begin_impl(unsigned kinds);
+extern "C" int medtok_profile_begin(void) { return profile_begin_impl(~0u); }
+// ... bracketing only the launches of the kinds in `kinds` (bit k = kind k of medtok_profile_end's arrays): a training step is ~180
+// library launches, and two event records per launch are 0.5 ms of an 11 ms step -- the timed region then carries the events of
+// its dominant kernel only (bench.py), the other kinds come from a pass behind it
+extern "C" int medtok_profile_begin_kinds(unsigned kinds) { return profile_begin_impl(kinds); }
+static int profile_begin_impl(unsigned kinds)
 {
+    g_prof_kinds = kinds;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &r : g_prof) { if (r.a) g_event_pool.push_back(r.a); if (r.b) g_event_pool.push_back(r.b); }
     g_prof.clear();
@@ -757,6 +766,7 @@ struct MultiSearchOne {
     float *xhat, *xsq;                          // out: F.normalize(x) [n, d], its squared norms [n] (scratch)
     float *pval; int *pidx;                     // scratch: per-split lists [splits][n][TOPK]
     int64_t *idx; float *dist, *w, *zq;         // out: [n, topk] ids / distances / weights; [n, d] rows with a row stride
+    float *row_sqerr;                           // out (may be NULL): [n] squared error of the soft assignment per row (training losses)
     long n, zq_stride, x_stride;                // (x rows may be a column block of a wider matrix)
     int k_codes, codes_per_split, splits, row_tiles;
 };
@@ -1135,7 +1145,7 @@ static int launch_search(const float *xhat, const float *xsq, int64_t n, const f
                          const SearchPlan &p, hipStream_t s, const float *excl_d = nullptr, const int64_t *excl_i = nullptr, int excl_stride = 0)
 {
     dim3 grid((unsigned)p.row_tiles, (unsigned)p.splits), block(256);
-    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+    hipEvent_t pa = prof_wanted(1) ? prof_mark(s) : nullptr;
     const double pflops = 2.0 * (double)n * (double)k_codes * (double)d;
     // one launch of the exact kernel: FINAL (a block walks all codes and writes the row's list) or partial lists per code split;
     // with excl_d the second-pass form that skips a row's first-pass codes (lists of 8 only)
@@ -1285,7 +1295,7 @@ static int launch_filter(const float *xhat, const float *xsq, int64_t n, const f
         hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)lmin(4096, (f.k_pad * (f.dp / 8) + 255) / 256)), dim3(256), 0, s, what, (long)k_codes, d, f.k_pad, f.dp, w.wh);
         hipLaunchKernelGGL(wsq_max_kernel, dim3(1), dim3(1024), 0, s, wsq, (int)k_codes, w.en_max, w.wsqp, (int)f.k_pad, w.fb_count);
     }
-    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+    hipEvent_t pa = prof_wanted(0) ? prof_mark(s) : nullptr;
     if (f.rows64 && !f.rows64_wide) {
         hipLaunchKernelGGL((filter_rows64n_kernel<T>), dim3((unsigned)f.row_tiles, (unsigned)f.splits), dim3(R64N_THREADS), R64N_SMEM_BYTES, s,
                            w.xh, c_wh, xsq, c_wsqp, c_en_max, (long)n, (int)k_codes, d, f.codes_per_split, f.own_total, w.cand, w.cand_cnt);
@@ -1699,6 +1709,7 @@ __global__ __launch_bounds__(256) void merge_assign_multi_kernel(MultiSearchArgs
     }
     const float *xr = m.x + row * m.x_stride;
     float *out = m.zq + row * m.zq_stride;
+    float se = 0.f;
     for (int i = lane * 4; i < d; i += 256) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -1709,7 +1720,14 @@ __global__ __launch_bounds__(256) void merge_assign_multi_kernel(MultiSearchArgs
                 acc.z = fmaf(wj[j], e.z, acc.z); acc.w = fmaf(wj[j], e.w, acc.w);
             }
         const float4 x = ld4(xr + i);
-        st4(out + i, make_float4(x.x + (acc.x - x.x), x.y + (acc.y - x.y), x.z + (acc.z - x.z), x.w + (acc.w - x.w)));
+        float4 df;
+        df.x = acc.x - x.x; df.y = acc.y - x.y; df.z = acc.z - x.z; df.w = acc.w - x.w;
+        st4(out + i, make_float4(x.x + df.x, x.y + df.y, x.z + df.z, x.w + df.w));
+        se = fmaf(df.x, df.x, se); se = fmaf(df.y, df.y, se); se = fmaf(df.z, df.z, se); se = fmaf(df.w, df.w, se);
+    }
+    if (m.row_sqerr) {                              // (soft_assign_kernel's sum: 64 strided fmaf chains joined by the xor butterfly)
+        se = wave_butterfly_sum(se);
+        if (lane == 0) m.row_sqerr[row] = se;
     }
 }
 
@@ -1778,7 +1796,7 @@ extern "C" int medtok_soft_vq_forward_multi_f32(const medtok_search_desc *descs,
     for (int i = 0; i < count; ++i) {
         const medtok_search_desc &q = descs[i];
         MultiSearchOne &m = a.s[i];
-        m.x = q.x; m.what = q.what; m.wsq = q.wsq; m.xhat = q.xhat; m.idx = q.idx; m.dist = q.dist; m.w = q.w; m.zq = q.zq;
+        m.x = q.x; m.what = q.what; m.wsq = q.wsq; m.xhat = q.xhat; m.idx = q.idx; m.dist = q.dist; m.w = q.w; m.zq = q.zq; m.row_sqerr = q.row_sqerr;
         m.n = (long)q.n; m.zq_stride = (long)(q.zq_stride ? q.zq_stride : d); m.x_stride = (long)(q.x_stride ? q.x_stride : d);
         m.k_codes = (int)q.k_codes; m.codes_per_split = cps[i]; m.splits = splits[i]; m.row_tiles = (int)((q.n + S_BN - 1) / S_BN);
         m.xsq = (float *)take((size_t)q.n * 4);
@@ -1789,7 +1807,7 @@ extern "C" int medtok_soft_vq_forward_multi_f32(const medtok_search_desc *descs,
     }
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(rownorm_multi_kernel, dim3((unsigned)((max_rows + 3) / 4), (unsigned)count), dim3(256), 0, s, a);
-    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+    hipEvent_t pa = prof_wanted(1) ? prof_mark(s) : nullptr;
     double pflops = 0.0;
     for (int i = 0; i < count; ++i) pflops += 2.0 * (double)descs[i].n * (double)descs[i].k_codes * (double)d;
     (void)max_tiles; (void)max_splits;
@@ -2009,7 +2027,7 @@ static int attention_forward(const float *q, const int64_t *q_start, const int64
     const int64_t q_tiles = (max_q_len + 31) / 32;
     if (q_tiles * n_codes >= (1ll << 31)) return fail("shared_kv_attention: n_codes * ceil(max_q_len / 32) = %ld exceeds the grid limit", (long)(q_tiles * n_codes));
     const dim3 grid((unsigned)(q_tiles * n_codes));
-    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+    hipEvent_t pa = prof_wanted(2) ? prof_mark(s) : nullptr;
     const int waves = d == 64 ? 2 : (d % 256 == 0 ? 8 : 4);
     const size_t lds = ((size_t)32 * (d + 4 * waves) + (waves + 1) * 32 * 33 + 64) * sizeof(float);   // key chunk (one padded column slice per wave) + per-wave partial scores + probabilities + row state
     const unsigned thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
@@ -2042,7 +2060,7 @@ static int attention_forward_f16s(const float *q, const int64_t *q_start, const 
     const int64_t q_tiles = (max_q_len + 31) / 32;
     if (q_tiles * n_codes >= (1ll << 31)) return fail("shared_kv_attention: n_codes * ceil(max_q_len / 32) = %ld exceeds the grid limit", (long)(q_tiles * n_codes));
     const dim3 grid((unsigned)(q_tiles * n_codes));
-    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+    hipEvent_t pa = prof_wanted(2) ? prof_mark(s) : nullptr;
     if (max_q_len <= 8) {
         // a few query rows per code (the text side: one row per head): one wavefront per code, plain fp32 (attention_kernels.h)
         const dim3 fgrid((unsigned)((n_codes + 3) / 4));
@@ -2107,7 +2125,7 @@ extern "C" int medtok_shared_kv_attention_split_f32(const float *q, const int64_
     if (!kv_lo && !f32_keys && !pp_shape) return fail("shared_kv_attention_split: keys without a lo image (fp16 keys as they stand) need variant 2 and d = 256, 512 or 768");
     if (((uintptr_t)q | (uintptr_t)kv_hi | (uintptr_t)kv_lo | (uintptr_t)out) & 15) return fail("shared_kv_attention_split: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+    hipEvent_t pa = prof_wanted(2) ? prof_mark(s) : nullptr;
 #define MEDTOK_ATT_DMA(W, NT, MT, RING)                                                                                          \
     do {                                                                                                                         \
         const size_t lds = AttDma<W, NT, MT, RING>::LDS_BYTES;                                                                   \
@@ -2194,7 +2212,7 @@ static int cross_attention_small_impl(bool exact, const float *text, const void 
     a.n_codes = (long)n_codes; a.seq_len = (long)seq_len; a.n_nodes = (long)n_nodes; a.pooled_stride = (long)pooled_stride; a.graph_off = (long)graph_off;
     a.mask_bytes = mask_elem_bytes; a.layers = layers; a.n_graph_tiles = (int)tiles; a.scale = scale; a.ln_eps = ln_eps;
     hipStream_t s = (hipStream_t)stream;
-    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+    hipEvent_t pa = prof_wanted(2) ? prof_mark(s) : nullptr;
     if (exact) hipLaunchKernelGGL(cross_attention64_kernel<false>, dim3((unsigned)(tiles + n_codes)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(cross_attention64_kernel<true>, dim3((unsigned)(tiles + n_codes)), dim3(256), 0, s, a);
     if (pa) prof_push(pa, prof_mark(s), 0.0, 2);
@@ -2550,7 +2568,7 @@ static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int ld
 #define MEDTOK_GEMM_LAUNCH(...)                                                                                                   \
     do {                                                                                                                          \
         if (!set_lds_once<split_gemm_kernel<__VA_ARGS__>>(lds)) return fail("split_gemm: cannot reserve %zu bytes of LDS", lds);  \
-        pa = g_prof_on ? prof_mark((hipStream_t)stream) : nullptr;                                                                \
+        pa = prof_wanted(4) ? prof_mark((hipStream_t)stream) : nullptr;                                                                \
         hipLaunchKernelGGL((split_gemm_kernel<__VA_ARGS__>), dim3((unsigned)blocks), dim3(G_THREADS), lds, (hipStream_t)stream, p); \
     } while (0)
 #define MEDTOK_GEMM_BY_MT(...)                                                                                                    \
@@ -2597,7 +2615,7 @@ extern "C" int medtok_shared_kv_attention_train_split_f32(const float *q, const 
     hipStream_t s = (hipStream_t)stream;
     const unsigned thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
     const float keep_scale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
-    hipEvent_t pa = g_prof_on ? prof_mark(s) : nullptr;
+    hipEvent_t pa = prof_wanted(2) ? prof_mark(s) : nullptr;
 #define MEDTOK_ATT_PP_TRAIN(NT)                                                                                                   \
     do {                                                                                                                          \
         const size_t lds = AttPP<NT>::LDS_BYTES;                                                                                  \
@@ -2681,7 +2699,7 @@ static int attention_backward_impl(const float *q, const int64_t *q_start, const
     if (q_tiles * n_codes >= (1ll << 31) || kv_tiles * n_codes >= (1ll << 31)) return fail("shared_kv_attention_backward: grid limit exceeded");
     const unsigned thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
     const float keep_scale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
-    hipEvent_t pa_bwd = g_prof_on ? prof_mark(s) : nullptr;
+    hipEvent_t pa_bwd = prof_wanted(3) ? prof_mark(s) : nullptr;
 #define MEDTOK_ATT_BWD_HM(W, NT, HM)                                                                                             \
     do {                                                                                                                         \
         const size_t lds = AttShape<W, NT>::LDS_FLOATS * sizeof(float);                                                          \

@@ -19,15 +19,25 @@ from ._lib import PATH_AUTO, PATH_F16_FILTER, PATH_F32_MFMA, MAX_TOPK, plan_path
 SEARCH_TIMER = None
 
 
-def profile_begin() -> None:
-    """Start the library's own per-kernel timing (HIP events around each search-kernel launch)."""
-    _lib.check(_lib.load().medtok_profile_begin(), "medtok_profile_begin")
+PROFILE_KINDS = ("filter_f16_kernel", "search_f32_kernel", "shared_kv_attention_kernel", "shared_kv_attention_backward_kernels", "split_gemm_kernel")
+
+
+def profile_begin(kinds=None) -> None:
+    """Start the library's own per-kernel timing (HIP events around each matrix-pipe launch).  kinds: names out of PROFILE_KINDS to
+    bracket (None: all) -- a training step has ~180 library launches, and the event pairs of all of them cost it ~0.5 ms."""
+    if kinds is None:
+        _lib.check(_lib.load().medtok_profile_begin(), "medtok_profile_begin")
+        return
+    mask = 0
+    for k in kinds:
+        mask |= 1 << PROFILE_KINDS.index(k)
+    _lib.check(_lib.load().medtok_profile_begin_kinds(mask), "medtok_profile_begin_kinds")
 
 
 def profile_end() -> dict:
     """Stop it; returns {kernel: dict(ms, flops, launches)} (synchronises on the recorded events)."""
     import ctypes as C
-    names = ("filter_f16_kernel", "search_f32_kernel", "shared_kv_attention_kernel", "shared_kv_attention_backward_kernels", "split_gemm_kernel")
+    names = PROFILE_KINDS
     n = len(names)
     ms, fl, ln = (C.c_double * n)(), (C.c_double * n)(), (C.c_int * n)()
     _lib.check(_lib.load().medtok_profile_end(ms, fl, ln), "medtok_profile_end")
@@ -828,10 +838,11 @@ def multi_search_eligible(n: int, k_codes: int, d: int, topk: int) -> bool:
     return bool(_lib.load().medtok_soft_vq_multi_eligible(int(n), int(k_codes), int(d), int(topk)))
 
 
-def soft_vq_forward_multi(searches, topk: int):
+def soft_vq_forward_multi(searches, topk: int, want_sqerr: bool = False):
     """Several small soft top-k searches in one C call and three launches (include/medtok_vq.h: medtok_soft_vq_forward_multi_f32).
     searches: list of dict(x [n, d] fp32, what [K, d], wsq [K], out = optional [n, d] view for zq); every entry must be
-    multi_search_eligible.  Returns a list of dict(xhat, idx, dist, w, zq, row_sqerr=None) -- the bits of soft_vq_forward per entry."""
+    multi_search_eligible.  Returns a list of dict(xhat, idx, dist, w, zq, row_sqerr) -- the bits of soft_vq_forward per entry
+    (row_sqerr: None unless want_sqerr, the training forward)."""
     import ctypes as C
     lib = _lib.load()
     count = len(searches)
@@ -856,10 +867,11 @@ def soft_vq_forward_multi(searches, topk: int):
         dist = torch.empty((n, topk), dtype=torch.float32, device=dev)
         w = torch.empty((n, topk), dtype=torch.float32, device=dev)
         zq, zstride = _zq_out(q.get("out"), n, d, x)
+        sqerr = torch.empty((n,), dtype=torch.float32, device=dev) if want_sqerr else None
         keep.append((x, what, wsq))
         descs[i] = _lib.SearchDesc(x.data_ptr(), n, what.data_ptr(), wsq.data_ptr(), what.shape[0], xhat.data_ptr(), idx.data_ptr(), dist.data_ptr(),
-                                   w.data_ptr(), zq.data_ptr(), zstride, x.stride(0) if n > 1 else d)
-        outs.append(dict(xhat=xhat, idx=idx, dist=dist, w=w, zq=zq, row_sqerr=None))
+                                   w.data_ptr(), zq.data_ptr(), zstride, x.stride(0) if n > 1 else d, _ptr(sqerr))
+        outs.append(dict(xhat=xhat, idx=idx, dist=dist, w=w, zq=zq, row_sqerr=sqerr))
     ws = _ws(lib.medtok_soft_vq_forward_multi_workspace_bytes(descs, count, d, topk), keep[0][0])
     with _on(keep[0][0].device):
         _lib.check(lib.medtok_soft_vq_forward_multi_f32(descs, count, d, topk, ws.data_ptr(), ws.numel(), _stream(keep[0][0])),

@@ -80,6 +80,11 @@ AUTOCAST_SPLIT_ATTENTION_FORWARD = True
 MERGE_SIDES_IN_TRAINING = True
 # training: all searches of a forward under one autograd node, so that the codebook receives ONE dense gradient (_SoftVQMultiFunction)
 TRAIN_SINGLE_CODEBOOK_GRADIENT = True
+# ... and their forward as ONE batched call (three launches: ops.soft_vq_forward_multi with per-row squared errors) where every search
+# takes the exact path with at most 4096 rows.  Off: measured SLOWER at cfg 4 (six searches of 256 rows over 49 152 / 16 384 codes:
+# 10.5 -> 10.9 ms per step, tools/r05/ab_cfg4_switch.py TRAIN_BATCHED_SEARCHES) -- the batched kernel's split plan is made for the
+# few hundred codes of the reference's default codebook; it pays at e_dim = 64, n_e = 600 (fewer launches), not here
+TRAIN_BATCHED_SEARCHES = False
 # inference at the reference's own width (e_dim = 64, 4 heads): the whole cross-attention of a forward -- both layers, both
 # directions, node mean -- in two launches with no host read (ops.cross_attention_small); needs a SORTED batch vector (PyG's are;
 # the kernels flag anything else in CrossAttention.small_status, checked wherever the forward synchronises anyway)
@@ -1331,6 +1336,11 @@ class _SoftVQFunction(torch.autograd.Function):
         return gx, gw, None, None, None, None, None
 
 
+def _lib_multi_max():
+    from . import _lib
+    return _lib.MULTI_SEARCH_MAX
+
+
 class _SoftVQMultiFunction(torch.autograd.Function):
     """All searches of a training forward under ONE autograd node: (zq_ste, vq, commit, xhat, idx, w) per search from its rows and its
     region of the codebook -- the per-search forward of _SoftVQFunction, search by search.  What changes is the BACKWARD of the codebook:
@@ -1343,8 +1353,15 @@ class _SoftVQMultiFunction(torch.autograd.Function):
     def forward(ctx, weight, what, wsq, topk, path, beta, regions, *xs):
         ctx.set_materialize_grads(False)
         outs, saved, nondiff = [], [], []
-        for x, (lo, hi) in zip(xs, regions):
-            r = ops.soft_vq_forward(x.detach(), what[lo:hi], wsq[lo:hi].contiguous(), topk, path, want_sqerr=True)
+        # a per-GPU batch of searches (at most 4096 rows each, the exact path): ONE call of three launches for all of them
+        # (ops.soft_vq_forward_multi: the per-search bits) instead of five launches per search
+        batched = None
+        if (TRAIN_BATCHED_SEARCHES and path in (ops.PATH_AUTO, ops.PATH_F32_MFMA) and 1 <= len(xs) <= _lib_multi_max() and topk <= 8
+                and all(x.is_cuda and x.shape[0] > 0 and ops.multi_search_eligible(x.shape[0], hi - lo, x.shape[1], topk) for x, (lo, hi) in zip(xs, regions))):
+            batched = ops.soft_vq_forward_multi([dict(x=x.detach().float(), what=what[lo:hi], wsq=wsq[lo:hi].contiguous()) for x, (lo, hi) in zip(xs, regions)],
+                                                topk, want_sqerr=True)
+        for i, (x, (lo, hi)) in enumerate(zip(xs, regions)):
+            r = batched[i] if batched is not None else ops.soft_vq_forward(x.detach(), what[lo:hi], wsq[lo:hi].contiguous(), topk, path, want_sqerr=True)
             n, d = x.shape
             outs += [r["zq"], ops.sum_scale(r["row_sqerr"], (1.0 / (n * d)) if n else float("nan")), ops.sum_scale(r["row_sqerr"], beta / (n * d) if n else float("nan")),
                      r["xhat"], r["idx"], r["w"]]

@@ -341,10 +341,11 @@ def fuzz_multi_search(cases=100, seed=0, budget_s=None, log=None):
             searches.append(dict(x=x, what=what[lo:hi], wsq=wsq[lo:hi].contiguous(), out=out))
         if not searches:
             continue
-        res = ops.soft_vq_forward_multi(searches, topk)
+        train = bool(c % 2)                         # every other case as the training forward calls it: + per-row squared errors
+        res = ops.soft_vq_forward_multi(searches, topk, want_sqerr=train)
         for i, (q, r) in enumerate(zip(searches, res)):
-            one = ops.soft_vq_forward(q["x"].contiguous(), q["what"], q["wsq"], topk, want_sqerr=False)
-            diff = [key for key in ("xhat", "idx", "dist", "w", "zq") if not torch.equal(one[key], r[key])]
+            one = ops.soft_vq_forward(q["x"].contiguous(), q["what"], q["wsq"], topk, want_sqerr=train)
+            diff = [key for key in ("xhat", "idx", "dist", "w", "zq") + (("row_sqerr",) if train else ()) if not torch.equal(one[key], r[key])]
             if diff:
                 bad.append(f"multi_search case {c} search {i}: n={q['x'].shape[0]} K={q['what'].shape[0]} d={d} k={topk} differs in {diff}")
                 if log:

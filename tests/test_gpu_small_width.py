@@ -279,11 +279,16 @@ def test_batched_small_searches_equal_the_single_calls(dev, d, topk):
         out = emb.view(512, d) if i == 0 else None
         searches.append(dict(x=x, what=what[lo:hi], wsq=wsq[lo:hi].contiguous(), out=out))
     res = ops.soft_vq_forward_multi(searches, topk)
+    assert all(r["row_sqerr"] is None for r in res)
     zq0 = res[0]["zq"].clone()
-    for q, r in zip(searches, res):
+    res_train = ops.soft_vq_forward_multi(searches, topk, want_sqerr=True)      # the training forward's call: + per-row squared errors
+    for q, r, rt in zip(searches, res, res_train):
         one = ops.soft_vq_forward(q["x"], q["what"], q["wsq"], topk, want_sqerr=False)
+        one_train = ops.soft_vq_forward(q["x"], q["what"], q["wsq"], topk, want_sqerr=True)
+        assert torch.equal(one_train["row_sqerr"], rt["row_sqerr"]), ("row_sqerr", q["x"].shape)
         for key in ("xhat", "idx", "dist", "w"):
             assert torch.equal(one[key], r[key]), (key, q["x"].shape, q["what"].shape)
+            assert torch.equal(one[key], rt[key]), (key, "want_sqerr", q["x"].shape)
         assert torch.equal(one["zq"], r["zq"] if q["out"] is None else zq0), ("zq", q["x"].shape)
         exact = ops.topk_search(*ops.rownorm(q["x"]), q["what"], q["wsq"], topk, ops.PATH_F32_MFMA)
         assert torch.equal(exact[0], r["idx"]) and torch.equal(exact[1], r["dist"])
