@@ -1925,10 +1925,10 @@ extern "C" int medtok_info_nce_forward_f32(const float *q, const float *k, int64
     const dim3 fgrid((unsigned)((b + rt - 1) / rt));
     const size_t lds = info_nce_lds_bytes(b, d, rt);
     switch (rt) {
-    case 8: hipLaunchKernelGGL(info_nce_forward_kernel<8>, fgrid, dim3(256), lds, s, qhat, khat, (int)b, d, 1.f / temperature, prob, row_loss); break;
-    case 4: hipLaunchKernelGGL(info_nce_forward_kernel<4>, fgrid, dim3(256), lds, s, qhat, khat, (int)b, d, 1.f / temperature, prob, row_loss); break;
-    case 2: hipLaunchKernelGGL(info_nce_forward_kernel<2>, fgrid, dim3(256), lds, s, qhat, khat, (int)b, d, 1.f / temperature, prob, row_loss); break;
-    default: hipLaunchKernelGGL(info_nce_forward_kernel<1>, fgrid, dim3(256), lds, s, qhat, khat, (int)b, d, 1.f / temperature, prob, row_loss); break;
+    case 8: hipLaunchKernelGGL(info_nce_forward_kernel<8>, fgrid, dim3(NCE_THREADS), lds, s, qhat, khat, (int)b, d, 1.f / temperature, prob, row_loss); break;
+    case 4: hipLaunchKernelGGL(info_nce_forward_kernel<4>, fgrid, dim3(NCE_THREADS), lds, s, qhat, khat, (int)b, d, 1.f / temperature, prob, row_loss); break;
+    case 2: hipLaunchKernelGGL(info_nce_forward_kernel<2>, fgrid, dim3(NCE_THREADS), lds, s, qhat, khat, (int)b, d, 1.f / temperature, prob, row_loss); break;
+    default: hipLaunchKernelGGL(info_nce_forward_kernel<1>, fgrid, dim3(NCE_THREADS), lds, s, qhat, khat, (int)b, d, 1.f / temperature, prob, row_loss); break;
     }
     hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(1024), 0, s, row_loss, (long)b, 1.0 / (double)b, loss);
     return check_launch("info_nce_forward");
@@ -1947,10 +1947,10 @@ extern "C" int medtok_info_nce_backward_f32(const float *q, const float *k, cons
     const size_t lds = info_nce_lds_bytes(b, d, rt);
     hipStream_t s = (hipStream_t)stream;
     switch (rt) {
-    case 8: hipLaunchKernelGGL(info_nce_backward_kernel<8>, bgrid, dim3(256), lds, s, q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk); break;
-    case 4: hipLaunchKernelGGL(info_nce_backward_kernel<4>, bgrid, dim3(256), lds, s, q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk); break;
-    case 2: hipLaunchKernelGGL(info_nce_backward_kernel<2>, bgrid, dim3(256), lds, s, q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk); break;
-    default: hipLaunchKernelGGL(info_nce_backward_kernel<1>, bgrid, dim3(256), lds, s, q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk); break;
+    case 8: hipLaunchKernelGGL(info_nce_backward_kernel<8>, bgrid, dim3(NCE_THREADS), lds, s, q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk); break;
+    case 4: hipLaunchKernelGGL(info_nce_backward_kernel<4>, bgrid, dim3(NCE_THREADS), lds, s, q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk); break;
+    case 2: hipLaunchKernelGGL(info_nce_backward_kernel<2>, bgrid, dim3(NCE_THREADS), lds, s, q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk); break;
+    default: hipLaunchKernelGGL(info_nce_backward_kernel<1>, bgrid, dim3(NCE_THREADS), lds, s, q, k, qhat, khat, prob, g_loss, (int)b, d, 1.f / temperature, gq, gk); break;
     }
     return check_launch("info_nce_backward");
 }

@@ -187,13 +187,15 @@ __global__ __launch_bounds__(256) void info_nce_prepare_kernel(const float *__re
 
 __device__ __forceinline__ float block256_reduce(float v, float *sh, bool is_max)
 {
-    // xor butterfly inside the wave, then the 4 wave results through LDS; every thread gets the result
+    // xor butterfly inside the wave, then the 4 wave results through LDS; every thread gets the result.  (The InfoNCE kernels run
+    // their heavy phases with 16 waves: waves 4 .. 15 pass through here for the barriers and contribute nothing -- the sums keep the
+    // 256-thread partition the oracle restates.)
     for (int off = 32; off >= 1; off >>= 1) {
         const float o = __shfl_xor(v, off, 64);
         v = is_max ? fmaxf(v, o) : v + o;
     }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     const float a = sh[0], b2 = sh[1], c = sh[2], e = sh[3];
     return is_max ? fmaxf(fmaxf(a, b2), fmaxf(c, e)) : (a + b2) + (c + e);
@@ -201,21 +203,25 @@ __device__ __forceinline__ float block256_reduce(float v, float *sh, bool is_max
 
 // RT query rows per block: every key row fetched from L2 serves RT dot products (one block per row re-read the whole
 // key matrix, B x D x 4 bytes, B times: 400 MB of L2 traffic at B = 256, D = 1536 -- 90 us for 0.2 GFLOP).
+// 16 waves per block for the dot products (round 6): with 4 a wave walked 64 key groups one L2 round trip each with nothing else
+// resident on its SIMD (46 - 78 us per call at B = 256); the softmax phase keeps its 256-thread sums.
+constexpr int NCE_THREADS = 1024;
 template <int RT>
-__global__ __launch_bounds__(256) void info_nce_forward_kernel(const float *__restrict__ qhat, const float *__restrict__ khat, int b, int d,
+__global__ __launch_bounds__(NCE_THREADS) void info_nce_forward_kernel(const float *__restrict__ qhat, const float *__restrict__ khat, int b, int d,
                                                                float inv_temp, float *__restrict__ prob, float *__restrict__ row_loss)
 {
     extern __shared__ float sm[];          // [RT][d] query rows, [RT][b] logits, [4] reduction scratch
     float *qs = sm, *lg = sm + RT * d, *red = lg + RT * b;
-    const int i0 = blockIdx.x * RT, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int t = threadIdx.x * 4; t < RT * d; t += 1024) {
+    const int i0 = blockIdx.x * RT, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const bool low = threadIdx.x < 256;           // the threads of the fixed-order sums below
+    for (int t = threadIdx.x * 4; t < RT * d; t += blockDim.x * 4) {
         const int r = t / d, c = t - r * d;
         st4(qs + t, ld4(qhat + (long)min(i0 + r, b - 1) * d + c));
     }
     __syncthreads();
     // KU key rows per step: their loads are independent, so one L2 round trip covers KU dot products
     constexpr int KU = 4;
-    for (int j0 = wave * KU; j0 < b; j0 += 4 * KU) {
+    for (int j0 = wave * KU; j0 < b; j0 += waves * KU) {
         float p[RT][KU];
 #pragma unroll
         for (int r = 0; r < RT; ++r)
@@ -248,14 +254,16 @@ __global__ __launch_bounds__(256) void info_nce_forward_kernel(const float *__re
         const int i = i0 + r;
         const float *l = lg + r * b;
         float m = -INFINITY;
-        for (int j = threadIdx.x; j < b; j += 256) m = fmaxf(m, l[j]);
+        if (low)
+            for (int j = threadIdx.x; j < b; j += 256) m = fmaxf(m, l[j]);
         m = block256_reduce(m, red, true);
         float sum = 0.f;
-        for (int j = threadIdx.x; j < b; j += 256) sum += expf(l[j] - m);
+        if (low)
+            for (int j = threadIdx.x; j < b; j += 256) sum += expf(l[j] - m);
         sum = block256_reduce(sum, red, false);
         const float lse = m + logf(sum);
         if (i < b) {
-            for (int j = threadIdx.x; j < b; j += 256) prob[(long)i * b + j] = expf(l[j] - lse);
+            for (int j = threadIdx.x; j < b; j += blockDim.x) prob[(long)i * b + j] = expf(l[j] - lse);
             if (threadIdx.x == 0) row_loss[i] = lse - l[i];
         }
     }
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(256) void info_nce_forward_kernel(const float *__re
 // Backward: dl_ij = g (prob_ij - [i == j]) / b.  Blocks [0, nb) produce g_q rows, blocks [nb, 2 nb) g_k rows (RT rows each):
 //   g_qhat_i = (1/T) sum_j dl_ij khat_j,   g_khat_j = (1/T) sum_i dl_ij qhat_i,   then through F.normalize.
 template <int RT>
-__global__ __launch_bounds__(256) void info_nce_backward_kernel(const float *__restrict__ q, const float *__restrict__ k,
+__global__ __launch_bounds__(NCE_THREADS) void info_nce_backward_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                 const float *__restrict__ qhat, const float *__restrict__ khat,
                                                                 const float *__restrict__ prob, const float *__restrict__ g_loss,
                                                                 int b, int d, float inv_temp, float *__restrict__ gq, float *__restrict__ gk)
@@ -275,19 +283,22 @@ __global__ __launch_bounds__(256) void info_nce_backward_kernel(const float *__r
     const bool qside = (int)blockIdx.x < nb;
     const int r0 = (qside ? blockIdx.x : blockIdx.x - nb) * RT;
     const float scale = g_loss[0] * inv_temp / (float)b;
-    for (int t = threadIdx.x; t < RT * b; t += 256) {
+    const bool low = threadIdx.x < 256;           // the threads of the fixed-order sums of the normalisation's backward
+    for (int t = threadIdx.x; t < RT * b; t += blockDim.x) {
         const int rr = t / b, j = t - rr * b, r = min(r0 + rr, b - 1);
         const float p = qside ? prob[(long)r * b + j] : prob[(long)j * b + r];
         cf[t] = scale * (p - (j == r ? 1.f : 0.f));
     }
     __syncthreads();
     const float *other = qside ? khat : qhat;
-    for (int c = threadIdx.x; c < d; c += 256) {
+    // a column's chain over j is sequential (the oracle's order); the columns are independent: one per thread of 16 waves (with 4
+    // waves a thread walked three columns one after the other, 96 L2 round trips of eight loads: 38 - 74 us per call)
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
         float a[RT];
 #pragma unroll
         for (int rr = 0; rr < RT; ++rr) a[rr] = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < b; ++j) {            // (unrolled: eight independent loads per L2 round trip)
+#pragma unroll 16
+        for (int j = 0; j < b; ++j) {            // (unrolled: sixteen independent loads per L2 round trip)
             const float o = other[(long)j * d + c];
 #pragma unroll
             for (int rr = 0; rr < RT; ++rr) a[rr] = fmaf(cf[rr * b + j], o, a[rr]);
@@ -300,16 +311,17 @@ __global__ __launch_bounds__(256) void info_nce_backward_kernel(const float *__r
         const int r = min(r0 + rr, b - 1);
         const float *mine_hat = (qside ? qhat : khat) + (long)r * d, *mine = (qside ? q : k) + (long)r * d;
         float dp = 0.f, vv = 0.f;
-        for (int c = threadIdx.x; c < d; c += 256) {
-            dp = fmaf(mine_hat[c], gh[rr * d + c], dp);
-            vv = fmaf(mine[c], mine[c], vv);
-        }
+        if (low)
+            for (int c = threadIdx.x; c < d; c += 256) {
+                dp = fmaf(mine_hat[c], gh[rr * d + c], dp);
+                vv = fmaf(mine[c], mine[c], vv);
+            }
         dp = block256_reduce(dp, red, false);
         vv = block256_reduce(vv, red, false);
         const float inv = 1.f / fmaxf(sqrtf(vv), 1e-12f);
         if (r0 + rr < b) {
             float *out = (qside ? gq : gk) + (long)r * d;
-            for (int c = threadIdx.x; c < d; c += 256) out[c] = (gh[rr * d + c] - mine_hat[c] * dp) * inv;
+            for (int c = threadIdx.x; c < d; c += blockDim.x) out[c] = (gh[rr * d + c] - mine_hat[c] * dp) * inv;
         }
     }
 }
