@@ -696,16 +696,27 @@ def shared_kv_attention_split(q, q_start, q_len, kv_split, kv_start, kv_len, max
 ATTENTION_TRAIN_SPLIT_WIDTHS = (256, 512, 768)
 
 
+def _into(buf, name, shape, like):
+    """a caller's output buffer (a contiguous fp32 tensor -- e.g. a row range of a larger one -- that a kernel writes into)"""
+    t = _dev(buf, name)
+    if t is not buf:
+        raise ValueError(f"{name} must be contiguous (the kernel writes into it)")
+    if tuple(t.shape) != tuple(shape) or t.device != like.device:
+        raise ValueError(f"{name} {tuple(t.shape)} on {t.device} does not match {tuple(shape)} on {like.device}")
+    return t
+
+
 def shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, scale: float, dropout_p: float = 0.0, seed: int = 0,
-                              split: bool = False):
+                              split: bool = False, out=None, lse=None):
     """(out, lse): the attention core with dropout on the probabilities (stateless hash mask) and the log-sum-exp per query row.
     split=True (widths ATTENTION_TRAIN_SPLIT_WIDTHS): on the three-pass fp16 products instead of the exact fp32 matrix pipe -- the
-    same mask bits, outputs within ~1e-6 relative, a third of the time at D = 768 (the autocast trainer's form)."""
+    same mask bits, outputs within ~1e-6 relative, a third of the time at D = 768 (the autocast trainer's form).
+    out / lse: the caller's buffers ([rows, d] zeros / [rows] -inf where rows may belong to no code), e.g. row ranges of larger ones."""
     q, kv = _dev(q, "q"), _dev(kv, "kv")
     qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
     ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
-    out = torch.zeros_like(q)                 # rows that belong to no code stay zero
-    lse = torch.full((q.shape[0],), float("-inf"), dtype=torch.float32, device=q.device)
+    out = torch.zeros_like(q) if out is None else _into(out, "out", q.shape, q)              # rows that belong to no code stay zero
+    lse = (torch.full((q.shape[0],), float("-inf"), dtype=torch.float32, device=q.device) if lse is None else _into(lse, "lse", (q.shape[0],), q))
     lib = _lib.load()
     fn, name = ((lib.medtok_shared_kv_attention_train_split_f32, "medtok_shared_kv_attention_train_split_f32") if split else
                 (lib.medtok_shared_kv_attention_train_f32, "medtok_shared_kv_attention_train_f32"))
@@ -716,15 +727,15 @@ def shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, max_q_len
 
 
 def shared_kv_attention_backward(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, max_kv_len: int, scale: float, dropout_p: float,
-                                 seed: int, out, lse, d_out, half=None, dkv_into=None, accumulate=False):
+                                 seed: int, out, lse, d_out, half=None, dkv_into=None, accumulate=False, dq_into=None):
     """(dq, dkv) of shared_kv_attention_train for the upstream gradient d_out.  half = torch.float16 / torch.bfloat16: the four matrix
     products in one half-precision pass with fp32 accumulation (autocast callers); None: exact fp32 MFMA.
     dkv_into: a contiguous fp32 [kv_rows, d] buffer that receives dkv (returned as dkv); with accumulate=True the key gradient is
-    ADDED to what it holds (the layers of CrossAttention share their keys: one buffer, no add pass)."""
+    ADDED to what it holds (the layers of CrossAttention share their keys: one buffer, no add pass).  dq_into: the buffer for dq."""
     q, kv, out, lse, d_out = _dev(q, "q"), _dev(kv, "kv"), _dev(out, "out"), _dev(lse, "lse"), _dev(d_out, "d_out")
     qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
     ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
-    dq = torch.empty_like(q)
+    dq = torch.empty_like(q) if dq_into is None else _into(dq_into, "dq_into", q.shape, q)
     if dkv_into is None:
         if accumulate:
             raise ValueError("shared_kv_attention_backward: accumulate=True needs the buffer to add to (dkv_into)")

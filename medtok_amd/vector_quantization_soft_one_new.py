@@ -108,6 +108,9 @@ FUSE_IMAGE_PAIRS = True
 # zero fill and an add pass each (0.8 ms of a 12 ms step at B = 256, L = 512).  On: the layers' dKV kernels write into ONE buffer
 # (the first zeroes and stores, the others add), the CLS gradients are added to its B rows in place (_TextFanOut)
 KEY_GRADIENT_SINK = True
+# training: both directions of a layer under ONE autograd node that writes their outputs (and dQ) into row ranges of one matrix, instead
+# of a split in front of two nodes and a concatenation behind them (a copy of the [R heads, D] matrix each, forward and backward)
+TWO_SIDED_ATTENTION_NODE = True
 from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
@@ -276,6 +279,83 @@ def fan_out_text(text):
     return rows
 
 
+def _autocast_half():
+    """the half-precision dtype of the attention backward's products under torch.autocast (None: exact fp32 kernels)"""
+    if AUTOCAST_HALF_PRODUCTS and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") in (torch.float16, torch.bfloat16):
+        return torch.get_autocast_dtype("cuda")
+    return None
+
+
+def _split_forward(half, width, max_q_len, q_rows, kv_rows):
+    """the training forward on the three-pass fp16 kernel? (autocast callers, many query rows per code: see _RaggedAttentionFunction)"""
+    return (half is not None and AUTOCAST_SPLIT_ATTENTION_FORWARD and width in ops.ATTENTION_TRAIN_SPLIT_WIDTHS and max_q_len > 8
+            and q_rows > 0 and kv_rows > 0)
+
+
+def _live_sink(sink, needs_kv_grad):
+    """the sink if THIS backward will run the node that collects it (torch.autograd.grad() for other inputs does not), else None"""
+    if sink is None or not needs_kv_grad:
+        return None
+    node = sink.node() if sink.node is not None else None
+    return sink if (node is not None and torch._C._will_engine_execute_node(node)) else None
+
+
+class _TwoSidedAttentionFunction(torch.autograd.Function):
+    """Both directions of a training layer in ONE autograd node: query rows [0, cut) (the graph side: nodes x heads) attend to kv_a
+    (the text rows), rows [cut, n) (the text side: CLS x heads) to kv_b (the nodes) -- the two launches of _RaggedAttentionFunction
+    writing into row ranges of one output (and, backward, of one dQ) instead of a split in front and a concatenation behind, each a
+    copy of the [R heads, D] matrix forward and backward.  la / lb = (q_start, q_len, kv_start, kv_len, max_q_len, max_kv_len) per side."""
+
+    @staticmethod
+    def forward(ctx, qf, kv_a, kv_b, la, lb, cut, scale, dropout_p, seed_a, seed_b, sink):
+        q = qf.detach().float().contiguous()
+        ka, kb = kv_a.detach().float().contiguous(), kv_b.detach().float().contiguous()
+        ctx.half = _autocast_half()
+        n = q.shape[0]
+        out = torch.zeros_like(q)
+        lse = torch.full((n,), float("-inf"), dtype=torch.float32, device=q.device)
+        for lo, hi, kv, l, seed in ((0, cut, ka, la, seed_a), (cut, n, kb, lb, seed_b)):
+            if hi > lo:
+                ops.shared_kv_attention_train(q[lo:hi], l[0], l[1], kv, l[2], l[3], l[4], scale, dropout_p, seed,
+                                              split=_split_forward(ctx.half, q.shape[1], l[4], hi - lo, kv.shape[0]), out=out[lo:hi], lse=lse[lo:hi])
+        ctx.save_for_backward(q, ka, kb, out, lse, *la[:4], *lb[:4])
+        ctx.cfg = (cut, la[4], la[5], lb[4], lb[5], scale, dropout_p, seed_a, seed_b, qf.dtype, kv_a.dtype, kv_b.dtype)
+        ctx.sink = sink
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        q, ka, kb, out, lse, *lists = ctx.saved_tensors
+        cut, mq_a, mk_a, mq_b, mk_b, scale, dropout_p, seed_a, seed_b, qd, kad, kbd = ctx.cfg
+        n = q.shape[0]
+        d = d_out.float().contiguous()
+        dq = torch.empty_like(q)
+        dka = dkb = None
+        sink = _live_sink(ctx.sink, ctx.needs_input_grad[1])
+        if cut > 0:
+            a = lists[:4]
+            if sink is not None:
+                first = sink.buf is None
+                if first:
+                    sink.buf = torch.empty_like(ka)
+                ops.shared_kv_attention_backward(q[:cut], a[0], a[1], ka, a[2], a[3], mq_a, mk_a, scale, dropout_p, seed_a, out[:cut], lse[:cut], d[:cut],
+                                                 half=ctx.half, dkv_into=sink.buf, accumulate=not first, dq_into=dq[:cut])
+            else:
+                _, dka = ops.shared_kv_attention_backward(q[:cut], a[0], a[1], ka, a[2], a[3], mq_a, mk_a, scale, dropout_p, seed_a, out[:cut], lse[:cut],
+                                                          d[:cut], half=ctx.half, dq_into=dq[:cut])
+                dka = dka.to(kad)
+        elif ctx.needs_input_grad[1] and sink is None:
+            dka = torch.zeros_like(ka).to(kad)
+        if n > cut:
+            b = lists[4:]
+            _, dkb = ops.shared_kv_attention_backward(q[cut:], b[0], b[1], kb, b[2], b[3], mq_b, mk_b, scale, dropout_p, seed_b, out[cut:], lse[cut:], d[cut:],
+                                                      half=ctx.half, dq_into=dq[cut:])
+            dkb = dkb.to(kbd)
+        else:
+            dkb = torch.zeros_like(kb).to(kbd)
+        return dq.to(qd), dka, dkb, None, None, None, None, None, None, None, None
+
+
 class _RaggedAttentionFunction(torch.autograd.Function):
     """The ragged attention core under autograd: forward = medtok_shared_kv_attention_train_f32 (dropout on the probabilities by
     a stateless hash mask, log-sum-exp kept per row), backward = medtok_shared_kv_attention_backward_f32 (dQ and dKV kernels that
@@ -288,10 +368,8 @@ class _RaggedAttentionFunction(torch.autograd.Function):
         # under torch.autocast the backward's four matrix products run as ONE half-precision pass (the reference's class there) and
         # the forward on the three-pass fp16 products (fp32-accurate to ~1e-6: its log-sum-exp feeds the backward's softmax
         # rebuild) where more than a few query rows share a code's keys; fp32 callers keep the exact fp32 kernels on both sides
-        ctx.half = (torch.get_autocast_dtype("cuda") if (AUTOCAST_HALF_PRODUCTS and torch.is_autocast_enabled()
-                                                         and torch.get_autocast_dtype("cuda") in (torch.float16, torch.bfloat16)) else None)
-        split = (ctx.half is not None and AUTOCAST_SPLIT_ATTENTION_FORWARD and qf.shape[1] in ops.ATTENTION_TRAIN_SPLIT_WIDTHS
-                 and max_q_len > 8 and qf.shape[0] > 0 and kvf.shape[0] > 0)
+        ctx.half = _autocast_half()
+        split = _split_forward(ctx.half, qf.shape[1], max_q_len, qf.shape[0], kvf.shape[0])
         out, lse = ops.shared_kv_attention_train(qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, scale, dropout_p, seed, split=split)
         ctx.save_for_backward(qf, kvf, out, lse, q_start, q_len, kv_start, kv_len)
         ctx.cfg = (max_q_len, max_kv_len, scale, dropout_p, seed, q.dtype, kv.dtype)
@@ -302,14 +380,7 @@ class _RaggedAttentionFunction(torch.autograd.Function):
     def backward(ctx, d_out):
         qf, kvf, out, lse, q_start, q_len, kv_start, kv_len = ctx.saved_tensors
         max_q_len, max_kv_len, scale, dropout_p, seed, qd, kd = ctx.cfg
-        sink = ctx.sink
-        if sink is not None and ctx.needs_input_grad[1]:
-            # only in a backward that will run the collecting node (torch.autograd.grad() for other inputs does not)
-            node = sink.node() if sink.node is not None else None
-            if node is None or not torch._C._will_engine_execute_node(node):
-                sink = None
-        else:
-            sink = None
+        sink = _live_sink(ctx.sink, ctx.needs_input_grad[1])
         if sink is not None:
             first = sink.buf is None
             if first:
@@ -915,6 +986,11 @@ class CrossAttention(nn.Module):
 
             def both_attend(qf, **kw):
                 cut = n_g * heads
+                if TWO_SIDED_ATTENTION_NODE and not pad and not kw and qf.is_cuda and qf.shape[1] == dim:
+                    p = float(mha.dropout) if self.training else 0.0
+                    seeds = [int(v) for v in torch.randint(0, 2 ** 31 - 1, (2,))] if p > 0.0 else [0, 0]      # host RNG: no device sync
+                    return _TwoSidedAttentionFunction.apply(qf, kv_text, kv_nodes, (g_start, g_len, tok_start, g_kv_len, max_nodes * heads, seq_len),
+                                                            (t_start, t_len, starts, counts, heads, max_nodes), cut, scale, p, seeds[0], seeds[1], key_sink)
                 # (split, not two slices: its backward is ONE concatenation of the two gradients; a slice's is a zero tensor of the
                 # whole [R heads, D] matrix with the gradient copied in, and autograd then adds the two: 97 -> 30 us per layer)
                 q_graph, q_text = torch.split(qf, [cut, qf.shape[0] - cut], dim=0)

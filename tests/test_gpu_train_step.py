@@ -263,3 +263,35 @@ def test_tokenizer_training_forward_maps_only_the_cls_row_of_the_aug_text(dev):
     assert abs(loss_new - loss_ref) <= 1e-5 * abs(loss_ref)
     for a, b in zip(got, ref):
         assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("autocast", [None, torch.float16])
+def test_two_sided_attention_node_equals_the_two_nodes(dev, autocast):
+    """TWO_SIDED_ATTENTION_NODE: both directions of a training layer under one autograd node (outputs and dQ in row ranges of one
+    matrix) against the two-node form (split, two _RaggedAttentionFunction nodes, concatenation): the same kernels on the same rows --
+    outputs and every gradient bit for bit (dropout off: the two forms draw their mask seeds differently)."""
+    import contextlib
+    import medtok_amd.vector_quantization_soft_one_new as vqmod
+    ca, text0, mask, nodes0, batch, (pa, pb, pc) = _pooled_case(dev, d=256, seed=4)
+    for layer in ca.model:
+        layer.multihead_attn.dropout = 0.0
+        layer.dropout.p = 0.0
+
+    def run(two_sided):
+        old = vqmod.TWO_SIDED_ATTENTION_NODE
+        vqmod.TWO_SIDED_ATTENTION_NODE = two_sided
+        try:
+            ca.zero_grad(set_to_none=True)
+            text, nodes = text0.clone().requires_grad_(), nodes0.clone().requires_grad_()
+            ctx = torch.autocast("cuda", dtype=autocast) if autocast is not None else contextlib.nullcontext()
+            with ctx:
+                pt, pg = ca.pooled(text, mask, nodes, batch)
+                loss = (pt.float() * pa).sum() + (pg.float() * pb).sum()
+            loss.backward()
+            return [pt.detach().clone(), pg.detach().clone(), text.grad.clone(), nodes.grad.clone()] + [p.grad.clone() for p in ca.parameters()]
+        finally:
+            vqmod.TWO_SIDED_ATTENTION_NODE = old
+    a, b = run(True), run(False)
+    assert float(a[2].abs().max()) > 0 and float(a[3].abs().max()) > 0
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
