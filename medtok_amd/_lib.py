@@ -64,6 +64,7 @@ SIGNATURES = {
     "medtok_topk_search_f32": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _int, _vp]),
     "medtok_merge_topk_lists_f32": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
     "medtok_debug_set_attention_probe": (None, [_vp]),
+    "medtok_debug_set_half_gemm_k32": (None, [_int]),
     "medtok_debug_filter_probe": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _sz, _vp, _sz, C.POINTER(C.c_int64), _vp]),
     "medtok_debug_filter_scores_workspace_bytes": (_sz, [_i64, _i64, _int]),
     "medtok_debug_filter_scores_f32": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _vp, _vp, _sz, _vp]),

@@ -2489,6 +2489,9 @@ extern "C" int medtok_half_image_pair_f32(const float *src, int64_t n, int d, in
     return check_launch("half_image_pair");
 }
 
+static bool g_gemm_k32 = false;        // DEV (tools/r06): the one-pass products with 32-deep stages, as before round 6
+extern "C" void medtok_debug_set_half_gemm_k32(int on) { g_gemm_k32 = on != 0; }
+
 static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols,
                            const void *b_hi, const void *b_lo, int64_t b_rows, int ldb, int b_group_rows,
                            int n_g, int k_g, int groups, const float *bias, float unscale, const float *amax_a, const float *amax_b,
@@ -2576,9 +2579,11 @@ static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int ld
         if (mt == 3) MEDTOK_GEMM_LAUNCH(3 __VA_ARGS__); else if (mt == 4) MEDTOK_GEMM_LAUNCH(4 __VA_ARGS__);                      \
         else if (mt == 2) MEDTOK_GEMM_LAUNCH(2 __VA_ARGS__); else MEDTOK_GEMM_LAUNCH(1 __VA_ARGS__);                              \
     } while (0)
+    // (one pass: 64-deep stages wherever the depth allows -- a copy then has 32 MFMAs of time to arrive instead of 16)
+    const bool k64 = one_pass != 0 && k_g % (2 * G_BK) == 0 && !g_gemm_k32;
     if (one_pass == 0) MEDTOK_GEMM_BY_MT();
-    else if (one_pass == 1) MEDTOK_GEMM_BY_MT(, true, false);
-    else MEDTOK_GEMM_BY_MT(, true, true);
+    else if (one_pass == 1) { if (k64) MEDTOK_GEMM_BY_MT(, true, false, true); else MEDTOK_GEMM_BY_MT(, true, false); }
+    else { if (k64) MEDTOK_GEMM_BY_MT(, true, true, true); else MEDTOK_GEMM_BY_MT(, true, true); }
 #undef MEDTOK_GEMM_BY_MT
 #undef MEDTOK_GEMM_LAUNCH
     if (pa) prof_push(pa, prof_mark((hipStream_t)stream), 2.0 * (double)m * (double)n_g * (double)k_g * (double)groups, 4);     // fp32-equivalent flops (x3 on the fp16 pipe)

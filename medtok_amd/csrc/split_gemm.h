@@ -107,9 +107,15 @@ __device__ __forceinline__ f32x16 gemm_mfma(half8 a, half8 b, f32x16 c)
     else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-template <int MT, bool ONE = false, bool BF = false>
+// K64 (with ONE): a stage is 64 k deep instead of 32 -- the slots that hold the lo images in the three-pass form hold the second 32-k
+// block of the hi images, and the stage is four groups of MFMAs (block 0 step 0 / 1, block 1 step 0 / 1).  A copy has one stage of
+// matrix work to arrive (it is issued behind a stage's barrier and waited for in front of the next one): 16 MFMAs ~ 0.5 us in the
+// 32-deep ONE form, which an HBM round trip does not fit into -- the half-precision products of a training step ran 1.5 - 3.3 us per
+// stage for 0.5 us of matrix work; 32 MFMAs ~ 1 us here (the three-pass form has 48).  k_g % 64 == 0.
+template <int MT, bool ONE = false, bool BF = false, bool K64 = false>
 __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGemmArgs p)
 {
+    static_assert(!K64 || ONE, "the 64-deep stage is a form of the one-pass product");
     using S = GemmShape<MT>;
     constexpr int BM = S::BM, WTILEB = S::WTILEB, STG = S::STG;
     constexpr int XOFF = 2 * WTILEB;                     // activation images within a stage
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
     const int per_row = p.ftiles * p.groups;
     const int n_ids = (p.row_tiles + 7) / 8 * 8 * per_row;
     const int stride = (int)gridDim.x;
-    const int nkb = p.k_g / G_BK;
+    const int nkb = p.k_g / (K64 ? 2 * G_BK : G_BK);
     auto row_tile_of = [&](int id) { return (long)((id >> 3) / per_row) * 8 + (id & 7); };
     auto next_tile = [&](int id) {                       // the block's next id with a real row tile (ids of the padded last 8 are skipped)
         for (id += stride; id < n_ids && row_tile_of(id) >= p.row_tiles; id += stride) {}
@@ -159,8 +165,12 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
         const int gf = (id >> 3) % per_row, grp = gf / p.ftiles, ft = gf % p.ftiles;
         const long a_base = (row_tile_of(id) * G_BN * p.lda + (long)grp * p.a_group_cols) * 2;
         const long b_base = ((long)(grp * p.b_group_rows + ft * BM) * p.ldb) * 2;
-        ah_rs = rsrc(p.ah, a_base, p.a_bytes); al_rs = rsrc(p.al, a_base, p.a_bytes);
-        bh_rs = rsrc(p.bh, b_base, p.b_bytes); bl_rs = rsrc(p.bl, b_base, p.b_bytes);
+        ah_rs = rsrc(p.ah, a_base, p.a_bytes); bh_rs = rsrc(p.bh, b_base, p.b_bytes);
+        if constexpr (K64) {                             // the "lo" slots: the same images, one 32-k block (64 bytes) further
+            al_rs = rsrc(p.ah, a_base + G_ROWB, p.a_bytes); bl_rs = rsrc(p.bh, b_base + G_ROWB, p.b_bytes);
+        } else {
+            al_rs = rsrc(p.al, a_base, p.a_bytes); bl_rs = rsrc(p.bl, b_base, p.b_bytes);
+        }
     };
     bind_tile(first);
     const int wave_lds = wave_s * 16 * G_ROWB;
@@ -168,17 +178,17 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
     bool more = true;                                    // false once the block's last stage has been issued
     auto stage = [&]() __attribute__((always_inline)) {
         char *base = gsm + (islot & 1) * STG + wave_lds;
-        const int uk = __builtin_amdgcn_readfirstlane(ikb * G_BK * 2);
+        const int uk = __builtin_amdgcn_readfirstlane(ikb * (K64 ? 2 : 1) * G_BK * 2);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             char *dst = base + q * 8 * 16 * G_ROWB;
             if (q == 0 ? w_first : w_second) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(bh_rs, (__attribute__((address_space(3))) void *)dst, 16, (int)b_off[q], uk, 0, 0);
-                if constexpr (!ONE)
+                if constexpr (!ONE || K64)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(bl_rs, (__attribute__((address_space(3))) void *)(dst + WTILEB), 16, (int)b_off[q], uk, 0, 0);
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ah_rs, (__attribute__((address_space(3))) void *)(dst + XOFF), 16, (int)a_off[q], uk, 0, 0);
-            if constexpr (!ONE)
+            if constexpr (!ONE || K64)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(al_rs, (__attribute__((address_space(3))) void *)(dst + XOFF + G_XTILEB), 16, (int)a_off[q], uk, 0, 0);
         }
         ++islot;
@@ -274,6 +284,30 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
 #pragma unroll
                     for (int m = 0; m < MT; ++m) bzs[m] = (g_f4){0.f, 0.f, 0.f, 0.f};
                 }
+            }
+            if constexpr (ONE && K64) {
+                // one pass over a 64-deep stage: block 0 (the hi slots) step 0, step 1, block 1 (the lo slots) step 0, step 1; the barrier
+                // in front of the last group, whose operands are in registers by then (fw rolls: behind a group the next one's weights)
+                read_x(xb, sl, 1, 0);
+                group(xa, 1, sl, 1, 0);             gemm_weave<MT, G_NT, true, 0>();                // block 0 step 0; fw <- W(block 0, step 1)
+                read_x(xa, sl, 0, 1);
+                group(xb, 1, sl, 0, 1);             gemm_weave<MT, G_NT, true, 0>();                // block 0 step 1; fw <- W(block 1, step 0)
+                if (owe) { stage(); owe = false; }
+                read_x(xb, sl, 1, 1);
+                group(xa, 1, sl, 1, 1);             gemm_weave<MT, G_NT, true, 2>();                // block 1 step 0; fw <- W(block 1, step 1)
+                __builtin_amdgcn_s_waitcnt(LGKM0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if constexpr (LAST) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(bzs[m]));
+                }
+                if (more) { if (late) owe = true; else stage(); }
+                read_x(xa, nx, 0, 0);
+                group(xb, 1, nx, 0, 0);             gemm_weave<MT, G_NT, true, 2>();                // block 1 step 1; fw <- W(next stage, block 0, step 0)
+                ++gs;
+                return;
             }
             if constexpr (ONE) {
                 // one pass: W_hi . X_hi of k step 0 (operands in registers), the barrier in front of k step 1's group as below

@@ -189,6 +189,16 @@ def test_one_pass_half_precision_gemm_matches_fp32_accumulation(dev, dt):
         ref = torch.cat([a[:, h * k_g:(h + 1) * k_g].double() @ b[h * n_g:(h + 1) * n_g].double().t() for h in range(groups)], 1) * 0.5 + bias.double()
         err = float((c.double() - ref).abs().max()) / float(ref.abs().max())
         assert err <= 2e-6, (m, n_g, k_g, groups, err)
+        # depths that are multiples of 64 run with 64-deep stages (round 6); the 32-deep form (the library's A/B switch) accumulates in
+        # the same order: the same bits
+        from medtok_amd import _lib
+        lib = _lib.load()
+        lib.medtok_debug_set_half_gemm_k32(1)
+        try:
+            c32 = ops.half_gemm(a, b, n_g=n_g, k_g=k_g, groups=groups, a_group_cols=k_g, b_group_rows=n_g, bias=bias, unscale=0.5)
+        finally:
+            lib.medtok_debug_set_half_gemm_k32(0)
+        assert torch.equal(c, c32), (m, n_g, k_g, groups)
 
 
 def test_autocast_linear_takes_the_one_pass_form_and_matches_torch(dev):
