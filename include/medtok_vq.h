@@ -353,8 +353,9 @@ int medtok_shared_kv_attention_split_f32(const float *q, const int64_t *q_start,
  * piece of process state besides the bench profiler); medtok_debug_filter_probe runs the filter kernel of one search
  * (uint64 [blocks][8][8]: MFMA group 1, wait for own copies, stage barrier, MFMA group 2, tile epilogue, stages, code tiles). */
 void medtok_debug_set_attention_probe(void *probe);
-/* DEV: run the one-pass half-precision products (medtok_half_gemm_f32) with 32-deep stages as before round 6 (on != 0) instead of 64-deep
- * ones -- the A/B switch of tools/r06/ab_half_gemm_k64.py; same results either way (same products, same accumulation order). */
+/* DEV: bit 0 of `on`: run the one-pass half-precision products (medtok_half_gemm_f32) with 32-deep stages as before round 6 instead of
+ * 64-deep ones; bit 1: give the dense products' tiles to the XCDs by row tile whatever the row-tile count (before round 6: a product of 3
+ * row tiles ran on 3 of the 8 XCDs) -- the A/B switches of tools/r06/ab_half_gemm_k64.py; same results either way. */
 void medtok_debug_set_half_gemm_k32(int on);
 int medtok_debug_filter_probe(const float *xhat, const float *xsq, int64_t n, const float *what, const float *wsq, int64_t k_codes,
                               int d, int topk, void *ws, size_t ws_bytes, void *probe, size_t probe_bytes, int64_t *n_blocks,

@@ -2490,7 +2490,8 @@ extern "C" int medtok_half_image_pair_f32(const float *src, int64_t n, int d, in
 }
 
 static bool g_gemm_k32 = false;        // DEV (tools/r06): the one-pass products with 32-deep stages, as before round 6
-extern "C" void medtok_debug_set_half_gemm_k32(int on) { g_gemm_k32 = on != 0; }
+static bool g_gemm_by_row_tile = false; // DEV: tile ids by row tile whatever the row-tile count (bit 1 of the switch)
+extern "C" void medtok_debug_set_half_gemm_k32(int on) { g_gemm_k32 = (on & 1) != 0; g_gemm_by_row_tile = (on & 2) != 0; }
 
 static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int lda, int a_group_cols,
                            const void *b_hi, const void *b_lo, int64_t b_rows, int ldb, int b_group_rows,
@@ -2561,7 +2562,11 @@ static int split_gemm_impl(const void *a_hi, const void *a_lo, int64_t m, int ld
     if (!mt3 && row_ids * ((n_g + 255) / 256) * groups < half_chip) mt = row_ids * ((n_g + 127) / 128) * groups < half_chip ? 1 : 2;
     const int bm = 64 * mt;
     p.ftiles = (n_g + bm - 1) / bm;
-    const long ids = row_ids * p.ftiles * groups;
+    // few row tiles (less than 0.8 of the 8-padded count: a weight-gradient product's 3 or 12, the 1 of a small batch): the dense order
+    // (split_gemm.h) instead of "XCD = row tile mod 8", which would leave XCDs without a tile
+    const long n_tiles = (long)p.row_tiles * p.ftiles * groups;
+    p.per_xcd = (!g_gemm_by_row_tile && p.row_tiles * 10 < row_ids * 8) ? (int)((n_tiles + 7) / 8) : 0;
+    const long ids = p.per_xcd ? (long)p.per_xcd * 8 : row_ids * p.ftiles * groups;
     if (ids >= (1ll << 31)) return fail("split_gemm: grid too large");
     // persistent: one block per CU (a multiple of 8: the XCD round-robin; never fewer than 8 -- a CU-masked or partitioned device
     // with < 8 CUs still gets a valid launch, its blocks just share CUs)

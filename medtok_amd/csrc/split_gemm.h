@@ -81,6 +81,7 @@ struct SplitGemmArgs {
     float unscale;                  // applied to the accumulators (undoes the weights' power-of-two prescale)
     const float *amax_a, *amax_b;   // (training products) the operands were prescaled by pow2_prescale(*amax): undone here too; or nullptr
     int row_tiles, ftiles;          // M / 256 rounded up; feature tiles (of 64 MT) per group
+    int per_xcd;                    // 0: tile ids by row tile (below); > 0: the DENSE order for few row tiles, this many ids per XCD
 };
 
 template <int MT, int FRONT, bool PER_M, int VMEM>
@@ -129,17 +130,32 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
     // consecutive WITHIN an XCD, so the activation tile is fetched into that L2 once.  The operand ring never drains between
     // tiles: while one tile's accumulators are stored, the first stage of the block's next tile is already in LDS and the second
     // in flight.
+    // DENSE order (per_xcd > 0; the host picks it where the row tiles do not fill the 8 XCDs: a weight-gradient product has 3 or 12 of
+    // them, and by row tile its 252 tiles ran on the 96 CUs of three XCDs -- 406 us for the flops its forward does in 224): XCD x
+    // takes the tiles t = x per_xcd .. of the order (group, row tile, feature tile), so the tiles of one group -- which share its
+    // operand columns -- still meet in one L2, and every XCD has the same number of tiles.
     const int per_row = p.ftiles * p.groups;
-    const int n_ids = (p.row_tiles + 7) / 8 * 8 * per_row;
+    const int per_grp = p.row_tiles * p.ftiles, n_tiles = per_grp * p.groups;
+    const bool dense = p.per_xcd > 0;
+    const int n_ids = dense ? p.per_xcd * 8 : (p.row_tiles + 7) / 8 * 8 * per_row;
     const int stride = (int)gridDim.x;
     const int nkb = p.k_g / (K64 ? 2 * G_BK : G_BK);
-    auto row_tile_of = [&](int id) { return (long)((id >> 3) / per_row) * 8 + (id & 7); };
+    auto dense_t = [&](int id) { return (id & 7) * p.per_xcd + (id >> 3); };
+    auto row_tile_of = [&](int id) {                     // (>= row_tiles: not a tile)
+        if (dense) { const int t = dense_t(id); return t < n_tiles ? (long)((t % per_grp) / p.ftiles) : (long)p.row_tiles; }
+        return (long)((id >> 3) / per_row) * 8 + (id & 7);
+    };
+    auto group_feature_of = [&](int id, int &grp, int &ft) {
+        if (dense) { const int t = dense_t(id); grp = t / per_grp; ft = (t % per_grp) % p.ftiles; return; }
+        const int gf = (id >> 3) % per_row;
+        grp = gf / p.ftiles; ft = gf % p.ftiles;
+    };
     auto next_tile = [&](int id) {                       // the block's next id with a real row tile (ids of the padded last 8 are skipped)
         for (id += stride; id < n_ids && row_tile_of(id) >= p.row_tiles; id += stride) {}
         return id;
     };
     int first = (int)blockIdx.x;
-    if (row_tile_of(first) >= p.row_tiles) first = next_tile(first);
+    if (first < n_ids && row_tile_of(first) >= p.row_tiles) first = next_tile(first);
     if (first >= n_ids) return;
 
     // ---- staging: one LDS-DMA instruction copies 16 tile rows x 64 B; wave w copies row blocks w and w + 8 of every tile (the
@@ -162,7 +178,8 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
     };
     __amdgpu_buffer_rsrc_t ah_rs, al_rs, bh_rs, bl_rs;
     auto bind_tile = [&](int id) __attribute__((always_inline)) {
-        const int gf = (id >> 3) % per_row, grp = gf / p.ftiles, ft = gf % p.ftiles;
+        int grp, ft;
+        group_feature_of(id, grp, ft);
         const long a_base = (row_tile_of(id) * G_BN * p.lda + (long)grp * p.a_group_cols) * 2;
         const long b_base = ((long)(grp * p.b_group_rows + ft * BM) * p.ldb) * 2;
         ah_rs = rsrc(p.ah, a_base, p.a_bytes); bh_rs = rsrc(p.bh, b_base, p.b_bytes);
@@ -255,7 +272,9 @@ __global__ __launch_bounds__(G_THREADS, 2) void split_gemm_kernel(const SplitGem
     int gs = 0;                             // stages computed so far: its parity is the slot of the stage in the registers
     bool owe = false;                       // a late wave's copy of the stage after next is due
     for (int cid = first; cid < n_ids; cid = next_tile(cid)) {
-        const int gf = (cid >> 3) % per_row, grp = gf / p.ftiles, f0 = (gf % p.ftiles) * BM;
+        int grp, ft_c;
+        group_feature_of(cid, grp, ft_c);
+        const int f0 = ft_c * BM;
         const int cbase = grp * p.n_g;
         const int ec = lane & 7, er = lane >> 3;         // epilogue, after the transposition: 4-feature chunk and row % 8 of the lane
 #pragma unroll
