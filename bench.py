@@ -746,6 +746,8 @@ def extra_workloads(args, dev):
             wl = make()
             for _ in range(warmup):
                 wl.step()
+            import gc
+            gc.collect()
             dt = timed(wl.step, steps)
             keep = vqmod.SIDE_STREAM_MIN_CODES
             try:
@@ -943,6 +945,8 @@ def main():
     # (tools/r06/ab_cfg4_profile_cost.py): cfg4's timed region runs WITHOUT the library's events; the kernel durations of its roofline
     # object come from the same K steps repeated right behind it with the events on (like the multi-stream forwards' one-stream pass)
     events_behind = args.workload == "cfg4"
+    import gc
+    gc.collect()                         # (a generation-2 collection in the middle of 5 - 20 timed steps is 80 ms on this host)
     mdist.barrier()
     torch.cuda.synchronize(dev)
     if not events_behind:

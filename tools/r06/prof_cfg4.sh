@@ -5,7 +5,7 @@
 #    r06_bench_cfg4.json (copied from gpurun_out/c4 by hand).    usage: bash tools/r06/prof_cfg4.sh
 export TMPDIR=/tmp
 out=gpurun_out/c4; mkdir -p $out
-python3 bench.py --workload cfg4 --precomputed-encoders --steps 20 --warmup 5 2>/dev/null | tail -1 > $out/bench_cfg4_vq_only.json
+python3 bench.py --workload cfg4 --precomputed-encoders --steps 20 --warmup 20 2>/dev/null | tail -1 > $out/bench_cfg4_vq_only.json    # (first process on a fresh box: a long warm-up)
 python3 bench.py --workload cfg4 --steps 10 --warmup 3 2>/dev/null | tail -1 > $out/bench_cfg4.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python3 bench.py --workload cfg4 --precomputed-encoders --steps 3 --warmup 2 --cpu-rows 0 > $out/prof.log 2>&1
 f=$(find $out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -70 "$f" | cut -c1-400 > $out/kernel_stats_cfg4_vq_only.csv
