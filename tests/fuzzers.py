@@ -219,7 +219,8 @@ def fuzz_attention(cases=60, seed=0, budget_s=None, log=None):
 
 
 def fuzz_split_gemm(cases=200, seed=0, budget_s=None, log=None):
-    """Random shapes through medtok_split_gemm_f16 (plain and grouped, both tile heights, every output combination) against fp64."""
+    """Random shapes through medtok_split_gemm_f16 (plain and grouped, both tile heights, every output combination) against fp64; every
+    third shape also through the one-pass half-precision product (medtok_half_gemm_f32)."""
     from medtok_amd import ops
     dev = torch.device("cuda:0")
     rng = random.Random(seed)
@@ -259,6 +260,20 @@ def fuzz_split_gemm(cases=200, seed=0, budget_s=None, log=None):
                                                             bias=bias is not None, f32=want_f32, split=want_split)) + f" rel err {max(errs):.3g}")
             if log:
                 log(bad[-1])
+        if c % 3 == 0:
+            # the one-pass half-precision product of the same shape (medtok_half_gemm_f32: 64-deep stages where k_g % 64 == 0, the dense
+            # tile order where the row tiles are few) on the operands rounded to 16 bits, against fp64 on the rounded operands
+            dt = torch.bfloat16 if c % 2 else torch.float16
+            a16, w16 = a.to(dt).contiguous(), w.to(dt).contiguous()
+            ch = ops.half_gemm(a16, w16, n_g=n_g, k_g=k_g, groups=groups, a_group_cols=a_cols, b_group_rows=b_rows, bias=bias)
+            ref16 = torch.cat([a16[:, h * a_cols: h * a_cols + k_g].double() @ w16[h * b_rows: h * b_rows + n_g].double().t() for h in range(groups)], 1)
+            if bias is not None:
+                ref16 = ref16 + bias.double()
+            err = float((ch.double() - ref16).abs().max()) / (float(ref16.abs().max()) + 1e-30)
+            if not err <= 4e-6:
+                bad.append(f"half_gemm case {c}: " + str(dict(m=m, n_g=n_g, k_g=k_g, groups=groups, a_cols=a_cols, b_rows=b_rows, lda=lda, dt=str(dt))) + f" rel err {err:.3g}")
+                if log:
+                    log(bad[-1])
     return c + 1, bad
 
 
