@@ -165,6 +165,61 @@ __device__ __forceinline__ void att_accumulate_h(f32x16 (&acc)[NT], const float 
     }
 }
 
+// ---- the half-precision form with the chunk PARKED AS ITS 16-BIT IMAGE (round 6): [32][D + 8] halves (row stride = 16 bytes mod 256:
+// the 128-bit reads of 16 consecutive rows fall into 16 different 16-byte slots).  The fp32 chunk was read back and rounded by every
+// product that used it -- per 32 x 32 x 16 MFMA two 128-bit reads + 12 conversion / pack instructions (first product) or eight 32-bit
+// reads + 12 (second): the kernels ran at the LDS's and the VALU's rate, a fifth of the matrix pipe's.  Rounded ONCE on the way in (the
+// same roundings of the same values: the same bits), a first-product operand is one 128-bit read, a second-product operand eight
+// 16-bit reads straight into register halves, and neither costs a conversion.
+template <bool BF>
+__device__ __forceinline__ unsigned short att_cvt16(float v)
+{
+    if constexpr (BF) { const __bf16 b = (__bf16)v; return __builtin_bit_cast(unsigned short, b); }
+    else { const _Float16 h = (_Float16)v; return __builtin_bit_cast(unsigned short, h); }
+}
+typedef unsigned short att_u16x4 __attribute__((ext_vector_type(4)));
+template <int W, int NT, bool BF, typename Hook = AttNoHook>
+__device__ __forceinline__ f32x16 att_partial_hh(const half8 (&reg)[2 * NT], const unsigned short *kvh, int slice, int li, int lh, Hook hook = Hook())
+{
+    constexpr int LDH = AttShape<W, NT>::D + 8;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    const unsigned short *krow = kvh + li * LDH + slice + 8 * lh;
+#pragma unroll
+    for (int st = 0; st < 2 * NT; ++st) {
+        const half8 b = *reinterpret_cast<const half8 *>(krow + 16 * st);
+        s = att_mfma16<BF>(reg[st], b, s);
+        hook(2 * st);
+        hook(2 * st + 1);
+        asm volatile("" ::: "memory");
+    }
+    return s;
+}
+template <int W, int NT, bool BF, typename Hook = AttNoHook>
+__device__ __forceinline__ void att_accumulate_hh(f32x16 (&acc)[NT], const float (*x)[33], const unsigned short *kvh, int slice, int li, int lh, Hook hook = Hook())
+{
+    constexpr int LDH = AttShape<W, NT>::D + 8;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const int k0 = 16 * st + 8 * lh;
+        float av[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] = x[k0 + e][li];
+        const half8 a = att_pack8<BF>(av);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            att_u16x8 bv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = kvh[(k0 + e) * LDH + slice + 32 * t + li];
+            acc[t] = att_mfma16<BF>(a, __builtin_bit_cast(half8, bv), acc[t]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hook(8 * st + e);
+        asm volatile("" ::: "memory");
+    }
+}
+
 #define ATT_LDS_BARRIER()                                                   \
     do {                                                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  \
@@ -205,7 +260,20 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
             for (int ci = 0; ci < CI; ++ci) kf[ri * CI + ci] = ld4(src + 4 * FT * ci);
         }
     };
+    unsigned short *kvh = reinterpret_cast<unsigned short *>(kvs);       // HM: the chunk as its 16-bit image [32][D + 8]
     auto park = [&]() {
+        if constexpr (HM) {
+            unsigned short *dst = kvh + f_r0 * (D + 8) + f_c;
+#pragma unroll
+            for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) {
+                    const float4 v = kf[ri * CI + ci];
+                    const att_u16x4 h = {att_cvt16<HM == 2>(v.x), att_cvt16<HM == 2>(v.y), att_cvt16<HM == 2>(v.z), att_cvt16<HM == 2>(v.w)};
+                    *reinterpret_cast<att_u16x4 *>(dst + RP * ri * (D + 8) + 4 * FT * ci) = h;
+                }
+            return;
+        }
         float *dst = kvs + f_r0 * LD + f_c;
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri)
@@ -247,7 +315,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
         ATT_LDS_BARRIER();
         auto weave = [&](int g) { kf[g] = ld4(fsrc[g / CI] + 4 * FT * (g % CI)); };
         f32x16 s;                                                                  // S partial: [query row][key]
-        if constexpr (HM) s = att_partial_h<W, NT, HM == 2>(qh, kvs, slice, li, lh, weave);
+        if constexpr (HM) s = att_partial_hh<W, NT, HM == 2>(qh, kvh, slice, li, lh, weave);
         else s = att_partial<W, NT>(qf, kvs, slice, li, lh, weave);
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
@@ -261,7 +329,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
             sc[j] = a * scale;
         }
         ATT_LDS_BARRIER();                                                         // everyone has read the S partials
-        if constexpr (HM) s = att_partial_h<W, NT, HM == 2>(doh, kvs, slice, li, lh);      // dPm partial = dO . KV^T
+        if constexpr (HM) s = att_partial_hh<W, NT, HM == 2>(doh, kvh, slice, li, lh);     // dPm partial = dO . KV^T
         else s = att_partial<W, NT>(dof, kvs, slice, li, lh);
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
@@ -277,7 +345,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
             pt[kq + j][row] = p * (dp - del_s[row]) * scale;                       // scale dS, [key][row]
         }
         ATT_LDS_BARRIER();
-        if constexpr (HM) att_accumulate_h<W, NT, HM == 2>(acc, pt, kvs, slice, li, lh);   // dQ += (scale dS) . KV
+        if constexpr (HM) att_accumulate_hh<W, NT, HM == 2>(acc, pt, kvh, slice, li, lh);  // dQ += (scale dS) . KV
         else att_accumulate<W, NT>(acc, pt, kvs, slice, li, lh);
         ATT_LDS_BARRIER();
     }
@@ -325,7 +393,20 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
             for (int ci = 0; ci < CI; ++ci) kf[ri * CI + ci] = ld4(src + 4 * FT * ci);
         }
     };
+    unsigned short *kvh16 = reinterpret_cast<unsigned short *>(kvs);     // HM: the parked chunk as its 16-bit image [32][D + 8]
     auto park = [&]() {
+        if constexpr (HM) {
+            unsigned short *dst = kvh16 + f_r0 * (D + 8) + f_c;
+#pragma unroll
+            for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) {
+                    const float4 v = kf[ri * CI + ci];
+                    const att_u16x4 h = {att_cvt16<HM == 2>(v.x), att_cvt16<HM == 2>(v.y), att_cvt16<HM == 2>(v.z), att_cvt16<HM == 2>(v.w)};
+                    *reinterpret_cast<att_u16x4 *>(dst + RP * ri * (D + 8) + 4 * FT * ci) = h;
+                }
+            return;
+        }
         float *dst = kvs + f_r0 * LD + f_c;
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri)
@@ -372,7 +453,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
         park();                                                                    // Q chunk (fetched during the previous iteration)
         ATT_LDS_BARRIER();
         f32x16 s;                                                                  // S^T partial: [key][query]; dO chunk on its way
-        if constexpr (HM) s = att_partial_h<W, NT, HM == 2>(kvh, kvs, slice, li, lh, woven(d_out, c0));
+        if constexpr (HM) s = att_partial_hh<W, NT, HM == 2>(kvh, kvh16, slice, li, lh, woven(d_out, c0));
         else s = att_partial<W, NT>(kvf, kvs, slice, li, lh, woven(d_out, c0));
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
@@ -392,7 +473,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
         ATT_LDS_BARRIER();                                                         // S partials and the Q chunk are consumed
         park();                                                                    // dO chunk
         ATT_LDS_BARRIER();
-        if constexpr (HM) s = att_partial_h<W, NT, HM == 2>(kvh, kvs, slice, li, lh);      // dPm^T partial = KV . dO^T
+        if constexpr (HM) s = att_partial_hh<W, NT, HM == 2>(kvh, kvh16, slice, li, lh);   // dPm^T partial = KV . dO^T
         else s = att_partial<W, NT>(kvf, kvs, slice, li, lh);
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
@@ -406,13 +487,13 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
             ds[qc + j][krow_t] = p[j] * (dp - del_s[qc + j]) * scale;
         }
         // dKV += (P o M)^T . dO   (pm was complete two barriers ago); Q again on its way
-        if constexpr (HM) att_accumulate_h<W, NT, HM == 2>(acc, pm, kvs, slice, li, lh, woven(q, c0));
+        if constexpr (HM) att_accumulate_hh<W, NT, HM == 2>(acc, pm, kvh16, slice, li, lh, woven(q, c0));
         else att_accumulate<W, NT>(acc, pm, kvs, slice, li, lh, woven(q, c0));
         ATT_LDS_BARRIER();                                                         // dO chunk consumed, ds complete
         park();                                                                    // Q chunk again
         ATT_LDS_BARRIER();
         // dKV += (scale dS)^T . Q; the next iteration's Q on its way
-        if constexpr (HM) att_accumulate_h<W, NT, HM == 2>(acc, ds, kvs, slice, li, lh, woven(q, c0 + 32));
+        if constexpr (HM) att_accumulate_hh<W, NT, HM == 2>(acc, ds, kvh16, slice, li, lh, woven(q, c0 + 32));
         else att_accumulate<W, NT>(acc, ds, kvs, slice, li, lh, woven(q, c0 + 32));
     }
 #pragma unroll
