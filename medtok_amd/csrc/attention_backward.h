@@ -17,8 +17,10 @@ struct AttShape {
     static constexpr int D = 32 * W * NT, LD = D + 4, THREADS = 64 * W;
     static constexpr int EPT = 1024 / THREADS, TPR = 32 / EPT;
     static constexpr int FT = D / 4 < 32 ? D / 4 : 32, CI = D / 4 / FT, RP = THREADS / FT, RI = 32 / RP, NF = RI * CI;
-    // LDS floats: parked chunk + per-wave partial products + two 32 x 33 operand tiles + two 32-entry row-statistic arrays
-    static constexpr size_t LDS_FLOATS = (size_t)32 * LD + (size_t)W * 32 * 33 + 2 * 32 * 33 + 64;
+    // LDS floats: parked chunk (fp32 [32][D + 4], or -- half-precision form -- TWO 16-bit images [32][D + 8]) + per-wave partial
+    // products + two 32 x 33 operand tiles + two 32-entry row-statistic arrays
+    static constexpr int CHUNK = 32 * (D + 8);
+    static constexpr size_t LDS_FLOATS = (size_t)CHUNK + (size_t)W * 32 * 33 + 2 * 32 * 33 + 64;
 };
 
 // partial 32 x 32 product over this wave's D / W columns: A rows from registers (reg[g] = elements 8g + 4 lh .. + 3 of the slice of
@@ -240,9 +242,9 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
     constexpr int D = G::D, LD = G::LD, EPT = G::EPT, TPR = G::TPR, FT = G::FT, CI = G::CI, RP = G::RP, RI = G::RI, NF = G::NF;
     extern __shared__ __attribute__((aligned(16))) float att_sm[];
     float *kvs = att_sm;
-    float (*part)[32][33] = reinterpret_cast<float (*)[32][33]>(kvs + 32 * LD);
-    float (*pt)[33] = reinterpret_cast<float (*)[33]>(kvs + 32 * LD + W * 32 * 33);
-    float *lse_s = kvs + 32 * LD + W * 32 * 33 + 2 * 32 * 33, *del_s = lse_s + 32;
+    float (*part)[32][33] = reinterpret_cast<float (*)[32][33]>(kvs + G::CHUNK);
+    float (*pt)[33] = reinterpret_cast<float (*)[33]>(kvs + G::CHUNK + W * 32 * 33);
+    float *lse_s = kvs + G::CHUNK + W * 32 * 33 + 2 * 32 * 33, *del_s = lse_s + 32;
     const int b = (int)(blockIdx.x / (unsigned)q_tiles), qt = (int)(blockIdx.x % (unsigned)q_tiles);
     const int ql = (int)q_len[b];
     if (qt * 32 >= ql) return;
@@ -372,10 +374,10 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
     constexpr int D = G::D, LD = G::LD, EPT = G::EPT, TPR = G::TPR, FT = G::FT, CI = G::CI, RP = G::RP, RI = G::RI, NF = G::NF;
     extern __shared__ __attribute__((aligned(16))) float att_sm[];
     float *kvs = att_sm;                                                                // parked chunk: 32 query rows of Q or of dO
-    float (*part)[32][33] = reinterpret_cast<float (*)[32][33]>(kvs + 32 * LD);
-    float (*pm)[33] = reinterpret_cast<float (*)[33]>(kvs + 32 * LD + W * 32 * 33);     // (P o M)   [query][key]
+    float (*part)[32][33] = reinterpret_cast<float (*)[32][33]>(kvs + G::CHUNK);
+    float (*pm)[33] = reinterpret_cast<float (*)[33]>(kvs + G::CHUNK + W * 32 * 33);     // (P o M)   [query][key]
     float (*ds)[33] = pm + 32;                                                          // scale dS  [query][key]
-    float *lse_s = kvs + 32 * LD + W * 32 * 33 + 2 * 32 * 33, *del_s = lse_s + 32;
+    float *lse_s = kvs + G::CHUNK + W * 32 * 33 + 2 * 32 * 33, *del_s = lse_s + 32;
     const int b = (int)(blockIdx.x / (unsigned)kv_tiles), kt = (int)(blockIdx.x % (unsigned)kv_tiles);
     const int kl = (int)kv_len[b];
     if (kt * 32 >= kl) return;
@@ -442,6 +444,84 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
             }
         };
     };
+    if constexpr (HM) {
+        // Half-precision form: the 16-bit images of the Q chunk AND of the dO chunk are resident together (two [32][D + 8] images in the
+        // space of one fp32 chunk), so Q is parked once per iteration, not twice: 6 block-wide synchronisations per chunk instead of 9,
+        // two fetches instead of three -- the next iteration's Q rides behind the first product's MFMAs, its dO behind the second's.
+        unsigned short *bq = kvh16, *bo = kvh16 + 32 * (D + 8);
+        float4 ko[NF];
+        auto park_to = [&](unsigned short *buf, const float4 (&regs)[NF]) __attribute__((always_inline)) {
+            unsigned short *dst = buf + f_r0 * (D + 8) + f_c;
+#pragma unroll
+            for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) {
+                    const float4 v = regs[ri * CI + ci];
+                    const att_u16x4 h = {att_cvt16<HM == 2>(v.x), att_cvt16<HM == 2>(v.y), att_cvt16<HM == 2>(v.z), att_cvt16<HM == 2>(v.w)};
+                    *reinterpret_cast<att_u16x4 *>(dst + RP * ri * (D + 8) + 4 * FT * ci) = h;
+                }
+        };
+        auto woven_into = [&](float4 (&regs)[NF], const float *src_base, int c0) __attribute__((always_inline)) {
+            return [=, &regs](int g) __attribute__((always_inline)) {
+                if (g < NF) {
+                    const int ri = g / CI, ci = g % CI;
+                    regs[g] = ld4(src_base + (qs + min(c0 + f_r0 + RP * ri, ql - 1)) * (long)D + f_c + 4 * FT * ci);
+                }
+            };
+        };
+        if (ql > 0) {
+            fetch(q, 0);
+#pragma unroll
+            for (int ri = 0; ri < RI; ++ri) {
+                const float *src = d_out + (qs + min(f_r0 + RP * ri, ql - 1)) * (long)D + f_c;
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) ko[ri * CI + ci] = ld4(src + 4 * FT * ci);
+            }
+        }
+        for (int c0 = 0; c0 < ql; c0 += 32) {
+            __syncthreads();                                     // the previous chunk's readers of the images / pm / ds / the statistics are done
+            if (tid < 32) {
+                const long r = qs + min(c0 + tid, ql - 1);
+                lse_s[tid] = lse[r];
+                del_s[tid] = delta[r];
+            }
+            park_to(bq, kf);
+            park_to(bo, ko);
+            ATT_LDS_BARRIER();
+            f32x16 s = att_partial_hh<W, NT, HM == 2>(kvh, bq, slice, li, lh, woven_into(kf, q, c0 + 32));      // S^T partial: [key][query]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
+            ATT_LDS_BARRIER();
+            float p[EPT];
+            bool keep[EPT];
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                float a = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < W; ++w2) a += part[w2][krow_t][qc + j];
+                const int key = kt * 32 + krow_t, qr = c0 + qc + j;
+                p[j] = (key < kl && qr < ql) ? expf(a * scale - lse_s[qc + j]) : 0.f;
+                keep[j] = !drop_thresh || att_keep(seed, qs + qr, key, drop_thresh);
+                pm[qc + j][krow_t] = keep[j] ? p[j] * keep_scale : 0.f;
+            }
+            ATT_LDS_BARRIER();                                                     // the S partials are consumed, pm is complete
+            s = att_partial_hh<W, NT, HM == 2>(kvh, bo, slice, li, lh, woven_into(ko, d_out, c0 + 32));         // dPm^T partial = KV . dO^T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
+            ATT_LDS_BARRIER();
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                float dp = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < W; ++w2) dp += part[w2][krow_t][qc + j];
+                dp = keep[j] ? dp * keep_scale : 0.f;
+                ds[qc + j][krow_t] = p[j] * (dp - del_s[qc + j]) * scale;
+            }
+            att_accumulate_hh<W, NT, HM == 2>(acc, pm, bo, slice, li, lh);         // dKV += (P o M)^T . dO
+            ATT_LDS_BARRIER();                                                     // ds complete
+            att_accumulate_hh<W, NT, HM == 2>(acc, ds, bq, slice, li, lh);         // dKV += (scale dS)^T . Q
+        }
+    } else {
     if (ql > 0) fetch(q, 0);
     for (int c0 = 0; c0 < ql; c0 += 32) {
         __syncthreads();                                         // the previous chunk's readers of kvs / pm / ds / the statistics are done
@@ -495,6 +575,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
         // dKV += (scale dS)^T . Q; the next iteration's Q on its way
         if constexpr (HM) att_accumulate_hh<W, NT, HM == 2>(acc, ds, kvh16, slice, li, lh, woven(q, c0 + 32));
         else att_accumulate<W, NT>(acc, ds, kvs, slice, li, lh, woven(q, c0 + 32));
+    }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
