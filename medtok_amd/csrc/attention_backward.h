@@ -17,9 +17,10 @@ struct AttShape {
     static constexpr int D = 32 * W * NT, LD = D + 4, THREADS = 64 * W;
     static constexpr int EPT = 1024 / THREADS, TPR = 32 / EPT;
     static constexpr int FT = D / 4 < 32 ? D / 4 : 32, CI = D / 4 / FT, RP = THREADS / FT, RI = 32 / RP, NF = RI * CI;
-    // LDS floats: parked chunk (fp32 [32][D + 4], or -- half-precision form -- TWO 16-bit images [32][D + 8]) + per-wave partial
+    // LDS floats: parked chunk (fp32 [32][D + 4], or -- half-precision form -- TWO 16-bit images [32][D + 32]) + per-wave partial
     // products + two 32 x 33 operand tiles + two 32-entry row-statistic arrays
-    static constexpr int CHUNK = 32 * (D + 8);
+    static constexpr int LDH = D + 32;                    // halves per row of a 16-bit chunk image (row stride = 64 bytes mod 256)
+    static constexpr int CHUNK = 32 * LDH;                // floats: two such images, or one fp32 chunk
     static constexpr size_t LDS_FLOATS = (size_t)CHUNK + (size_t)W * 32 * 33 + 2 * 32 * 33 + 64;
 };
 
@@ -167,12 +168,16 @@ __device__ __forceinline__ void att_accumulate_h(f32x16 (&acc)[NT], const float 
     }
 }
 
-// ---- the half-precision form with the chunk PARKED AS ITS 16-BIT IMAGE (round 6): [32][D + 8] halves (row stride = 16 bytes mod 256:
-// the 128-bit reads of 16 consecutive rows fall into 16 different 16-byte slots).  The fp32 chunk was read back and rounded by every
+// ---- the half-precision form with the chunk PARKED AS ITS 16-BIT IMAGE (round 6).  The fp32 chunk was read back and rounded by every
 // product that used it -- per 32 x 32 x 16 MFMA two 128-bit reads + 12 conversion / pack instructions (first product) or eight 32-bit
 // reads + 12 (second): the kernels ran at the LDS's and the VALU's rate, a fifth of the matrix pipe's.  Rounded ONCE on the way in (the
-// same roundings of the same values: the same bits), a first-product operand is one 128-bit read, a second-product operand eight
-// 16-bit reads straight into register halves, and neither costs a conversion.
+// same roundings of the same values: the same bits), a first-product operand is ONE 128-bit read and a second-product operand -- eight
+// consecutive rows of one column -- TWO transposed reads (ds_read_b64_tr_b16: the 16 lanes of a group fetch a [4 rows][16 columns]
+// block, 8 bytes each, and every lane receives one column of it), neither with a conversion.
+// Image: [32 rows][D + 32] halves.  The row stride is 64 bytes mod 256, so the four rows of a transposed read's blocks (two groups =
+// 64 bytes per row) fall into disjoint banks; the 16-byte slots of a row are XOR-swizzled by (row / 4) % 4, so the 128-bit reads of
+// consecutive rows at one column fall into different slots too (the rows of a transposed read share row / 4: the swizzle only permutes
+// the four slots of their aligned 64-byte group).
 template <bool BF>
 __device__ __forceinline__ unsigned short att_cvt16(float v)
 {
@@ -180,17 +185,25 @@ __device__ __forceinline__ unsigned short att_cvt16(float v)
     else { const _Float16 h = (_Float16)v; return __builtin_bit_cast(unsigned short, h); }
 }
 typedef unsigned short att_u16x4 __attribute__((ext_vector_type(4)));
-template <int W, int NT, bool BF, typename Hook = AttNoHook>
-__device__ __forceinline__ f32x16 att_partial_hh(const half8 (&reg)[2 * NT], const unsigned short *kvh, int slice, int li, int lh, Hook hook = Hook())
+typedef __fp16 att_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+// byte offset of the 4 halves at (row, col), col a multiple of 4
+template <int LDH>
+__device__ __forceinline__ int att_img_off(int row, int col)
 {
-    constexpr int LDH = AttShape<W, NT>::D + 8;
+    return row * (LDH * 2) + ((((col >> 3) ^ ((row >> 2) & 3)) << 4) | ((col & 4) << 1));
+}
+template <int W, int NT, bool BF, typename Hook = AttNoHook>
+__device__ __forceinline__ f32x16 att_partial_hh(const half8 (&reg)[2 * NT], const char *img, int slice, int li, int lh, Hook hook = Hook())
+{
+    constexpr int LDH = AttShape<W, NT>::LDH;
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    const unsigned short *krow = kvh + li * LDH + slice + 8 * lh;
+    const char *krow = img + li * (LDH * 2);
+    const int sw = (li >> 2) & 3, c0 = (slice >> 3) + lh;           // 16-byte slot of step 0; step st: + 2 st
 #pragma unroll
     for (int st = 0; st < 2 * NT; ++st) {
-        const half8 b = *reinterpret_cast<const half8 *>(krow + 16 * st);
+        const half8 b = *reinterpret_cast<const half8 *>(krow + (((c0 + 2 * st) ^ sw) << 4));
         s = att_mfma16<BF>(reg[st], b, s);
         hook(2 * st);
         hook(2 * st + 1);
@@ -199,9 +212,15 @@ __device__ __forceinline__ f32x16 att_partial_hh(const half8 (&reg)[2 * NT], con
     return s;
 }
 template <int W, int NT, bool BF, typename Hook = AttNoHook>
-__device__ __forceinline__ void att_accumulate_hh(f32x16 (&acc)[NT], const float (*x)[33], const unsigned short *kvh, int slice, int li, int lh, Hook hook = Hook())
+__device__ __forceinline__ void att_accumulate_hh(f32x16 (&acc)[NT], const float (*x)[33], const char *img, int slice, int lane, Hook hook = Hook())
 {
-    constexpr int LDH = AttShape<W, NT>::D + 8;
+    constexpr int LDH = AttShape<W, NT>::LDH;
+    typedef __attribute__((address_space(3))) att_fp16x4 *lptr;
+    const int li = lane & 31, lh = lane >> 5, grp = lane >> 4, i = lane & 15;
+    // this lane's share of the transposed reads: row 8 lh + 4 rd + i / 4 of the k step, columns 16 (grp & 1) + 4 (i & 3) .. + 3 of the tile
+    int tr_off[2];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) tr_off[rd] = att_img_off<LDH>(8 * lh + 4 * rd + (i >> 2), slice + 16 * (grp & 1) + 4 * (i & 3));
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
         const int k0 = 16 * st + 8 * lh;
@@ -211,10 +230,10 @@ __device__ __forceinline__ void att_accumulate_hh(f32x16 (&acc)[NT], const float
         const half8 a = att_pack8<BF>(av);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            att_u16x8 bv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bv[e] = kvh[(k0 + e) * LDH + slice + 32 * t + li];
-            acc[t] = att_mfma16<BF>(a, __builtin_bit_cast(half8, bv), acc[t]);
+            // (rows + 16 st: the same (row / 4) % 4; column tile t: four slots further, above the swizzled bits)
+            const half4v b0 = __builtin_bit_cast(half4v, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lptr)(img + tr_off[0] + st * 16 * (LDH * 2) + t * 64)));
+            const half4v b1 = __builtin_bit_cast(half4v, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lptr)(img + tr_off[1] + st * 16 * (LDH * 2) + t * 64)));
+            acc[t] = att_mfma16<BF>(a, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7), acc[t]);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) hook(8 * st + e);
@@ -262,17 +281,16 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
             for (int ci = 0; ci < CI; ++ci) kf[ri * CI + ci] = ld4(src + 4 * FT * ci);
         }
     };
-    unsigned short *kvh = reinterpret_cast<unsigned short *>(kvs);       // HM: the chunk as its 16-bit image [32][D + 8]
+    char *kvh = reinterpret_cast<char *>(kvs);                           // HM: the chunk as its 16-bit image (att_img_off)
     auto park = [&]() {
         if constexpr (HM) {
-            unsigned short *dst = kvh + f_r0 * (D + 8) + f_c;
 #pragma unroll
             for (int ri = 0; ri < RI; ++ri)
 #pragma unroll
                 for (int ci = 0; ci < CI; ++ci) {
                     const float4 v = kf[ri * CI + ci];
                     const att_u16x4 h = {att_cvt16<HM == 2>(v.x), att_cvt16<HM == 2>(v.y), att_cvt16<HM == 2>(v.z), att_cvt16<HM == 2>(v.w)};
-                    *reinterpret_cast<att_u16x4 *>(dst + RP * ri * (D + 8) + 4 * FT * ci) = h;
+                    *reinterpret_cast<att_u16x4 *>(kvh + att_img_off<G::LDH>(f_r0 + RP * ri, f_c + 4 * FT * ci)) = h;
                 }
             return;
         }
@@ -347,7 +365,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
             pt[kq + j][row] = p * (dp - del_s[row]) * scale;                       // scale dS, [key][row]
         }
         ATT_LDS_BARRIER();
-        if constexpr (HM) att_accumulate_hh<W, NT, HM == 2>(acc, pt, kvh, slice, li, lh);  // dQ += (scale dS) . KV
+        if constexpr (HM) att_accumulate_hh<W, NT, HM == 2>(acc, pt, kvh, slice, lane);    // dQ += (scale dS) . KV
         else att_accumulate<W, NT>(acc, pt, kvs, slice, li, lh);
         ATT_LDS_BARRIER();
     }
@@ -395,20 +413,9 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
             for (int ci = 0; ci < CI; ++ci) kf[ri * CI + ci] = ld4(src + 4 * FT * ci);
         }
     };
-    unsigned short *kvh16 = reinterpret_cast<unsigned short *>(kvs);     // HM: the parked chunk as its 16-bit image [32][D + 8]
+    char *kvh16 = reinterpret_cast<char *>(kvs);                         // HM: the parked chunks as 16-bit images (att_img_off)
     auto park = [&]() {
-        if constexpr (HM) {
-            unsigned short *dst = kvh16 + f_r0 * (D + 8) + f_c;
-#pragma unroll
-            for (int ri = 0; ri < RI; ++ri)
-#pragma unroll
-                for (int ci = 0; ci < CI; ++ci) {
-                    const float4 v = kf[ri * CI + ci];
-                    const att_u16x4 h = {att_cvt16<HM == 2>(v.x), att_cvt16<HM == 2>(v.y), att_cvt16<HM == 2>(v.z), att_cvt16<HM == 2>(v.w)};
-                    *reinterpret_cast<att_u16x4 *>(dst + RP * ri * (D + 8) + 4 * FT * ci) = h;
-                }
-            return;
-        }
+        if constexpr (HM) return;                                        // (the half-precision loop below parks with park_to)
         float *dst = kvs + f_r0 * LD + f_c;
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri)
@@ -448,17 +455,16 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
         // Half-precision form: the 16-bit images of the Q chunk AND of the dO chunk are resident together (two [32][D + 8] images in the
         // space of one fp32 chunk), so Q is parked once per iteration, not twice: 6 block-wide synchronisations per chunk instead of 9,
         // two fetches instead of three -- the next iteration's Q rides behind the first product's MFMAs, its dO behind the second's.
-        unsigned short *bq = kvh16, *bo = kvh16 + 32 * (D + 8);
+        char *bq = kvh16, *bo = kvh16 + 32 * G::LDH * 2;
         float4 ko[NF];
-        auto park_to = [&](unsigned short *buf, const float4 (&regs)[NF]) __attribute__((always_inline)) {
-            unsigned short *dst = buf + f_r0 * (D + 8) + f_c;
+        auto park_to = [&](char *buf, const float4 (&regs)[NF]) __attribute__((always_inline)) {
 #pragma unroll
             for (int ri = 0; ri < RI; ++ri)
 #pragma unroll
                 for (int ci = 0; ci < CI; ++ci) {
                     const float4 v = regs[ri * CI + ci];
                     const att_u16x4 h = {att_cvt16<HM == 2>(v.x), att_cvt16<HM == 2>(v.y), att_cvt16<HM == 2>(v.z), att_cvt16<HM == 2>(v.w)};
-                    *reinterpret_cast<att_u16x4 *>(dst + RP * ri * (D + 8) + 4 * FT * ci) = h;
+                    *reinterpret_cast<att_u16x4 *>(buf + att_img_off<G::LDH>(f_r0 + RP * ri, f_c + 4 * FT * ci)) = h;
                 }
         };
         auto woven_into = [&](float4 (&regs)[NF], const float *src_base, int c0) __attribute__((always_inline)) {
@@ -517,9 +523,9 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
                 dp = keep[j] ? dp * keep_scale : 0.f;
                 ds[qc + j][krow_t] = p[j] * (dp - del_s[qc + j]) * scale;
             }
-            att_accumulate_hh<W, NT, HM == 2>(acc, pm, bo, slice, li, lh);         // dKV += (P o M)^T . dO
+            att_accumulate_hh<W, NT, HM == 2>(acc, pm, bo, slice, lane);           // dKV += (P o M)^T . dO
             ATT_LDS_BARRIER();                                                     // ds complete
-            att_accumulate_hh<W, NT, HM == 2>(acc, ds, bq, slice, li, lh);         // dKV += (scale dS)^T . Q
+            att_accumulate_hh<W, NT, HM == 2>(acc, ds, bq, slice, lane);           // dKV += (scale dS)^T . Q
         }
     } else {
     if (ql > 0) fetch(q, 0);
@@ -533,8 +539,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
         park();                                                                    // Q chunk (fetched during the previous iteration)
         ATT_LDS_BARRIER();
         f32x16 s;                                                                  // S^T partial: [key][query]; dO chunk on its way
-        if constexpr (HM) s = att_partial_hh<W, NT, HM == 2>(kvh, kvh16, slice, li, lh, woven(d_out, c0));
-        else s = att_partial<W, NT>(kvf, kvs, slice, li, lh, woven(d_out, c0));
+        s = att_partial<W, NT>(kvf, kvs, slice, li, lh, woven(d_out, c0));
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
         ATT_LDS_BARRIER();
@@ -553,8 +558,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
         ATT_LDS_BARRIER();                                                         // S partials and the Q chunk are consumed
         park();                                                                    // dO chunk
         ATT_LDS_BARRIER();
-        if constexpr (HM) s = att_partial_hh<W, NT, HM == 2>(kvh, kvh16, slice, li, lh);   // dPm^T partial = KV . dO^T
-        else s = att_partial<W, NT>(kvf, kvs, slice, li, lh);
+        s = att_partial<W, NT>(kvf, kvs, slice, li, lh);                         // dPm^T partial = KV . dO^T
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = s[r];
         ATT_LDS_BARRIER();
@@ -567,14 +571,12 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
             ds[qc + j][krow_t] = p[j] * (dp - del_s[qc + j]) * scale;
         }
         // dKV += (P o M)^T . dO   (pm was complete two barriers ago); Q again on its way
-        if constexpr (HM) att_accumulate_hh<W, NT, HM == 2>(acc, pm, kvh16, slice, li, lh, woven(q, c0));
-        else att_accumulate<W, NT>(acc, pm, kvs, slice, li, lh, woven(q, c0));
+        att_accumulate<W, NT>(acc, pm, kvs, slice, li, lh, woven(q, c0));
         ATT_LDS_BARRIER();                                                         // dO chunk consumed, ds complete
         park();                                                                    // Q chunk again
         ATT_LDS_BARRIER();
         // dKV += (scale dS)^T . Q; the next iteration's Q on its way
-        if constexpr (HM) att_accumulate_hh<W, NT, HM == 2>(acc, ds, kvh16, slice, li, lh, woven(q, c0 + 32));
-        else att_accumulate<W, NT>(acc, ds, kvs, slice, li, lh, woven(q, c0 + 32));
+        att_accumulate<W, NT>(acc, ds, kvs, slice, li, lh, woven(q, c0 + 32));
     }
     }
 #pragma unroll
