@@ -295,3 +295,45 @@ def test_two_sided_attention_node_equals_the_two_nodes(dev, autocast):
     assert float(a[2].abs().max()) > 0 and float(a[3].abs().max()) > 0
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_batched_training_searches_switch_gives_the_same_bits(dev):
+    """TRAIN_BATCHED_SEARCHES (off by default: slower at BASELINE's codebook sizes): all searches of a training forward in one batched call
+    (ops.soft_vq_forward_multi with per-row squared errors) -- every output of VectorQuantizer.forward and every gradient bit for bit
+    those of the search-by-search form."""
+    import medtok_amd.vector_quantization_soft_one_new as vqmod
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer
+    torch.manual_seed(2)
+    bsz, seq_len, d = 9, 12, 128
+    vq = VectorQuantizer(n_e=3000, e_dim=d, beta=0.25, entropy_loss_ratio=0.0, l2_norm=True, show_usage=True, split=[d, d]).to(dev).train()
+    for mod in vq.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, nn.MultiheadAttention):
+            mod.dropout = 0.0
+    g = torch.Generator(device="cpu").manual_seed(7)
+    counts = torch.randint(1, 7, (bsz,), generator=g)
+    batch = torch.repeat_interleave(torch.arange(bsz), counts).to(dev)
+    mask = (torch.arange(seq_len)[None, :] < torch.randint(1, seq_len + 1, (bsz, 1), generator=g)).long().to(dev)
+    z, z_aug = torch.randn(bsz, 2 * d, generator=g).to(dev), torch.randn(bsz, 2 * d, generator=g).to(dev)
+    text0, nodes0 = torch.randn(bsz, seq_len, d, generator=g).to(dev), torch.randn(int(counts.sum()), d, generator=g).to(dev)
+    state = {k: v.clone() for k, v in vq.state_dict().items()}
+
+    def run(batched):
+        old = vqmod.TRAIN_BATCHED_SEARCHES
+        vqmod.TRAIN_BATCHED_SEARCHES = batched
+        try:
+            vq.load_state_dict(state)
+            vq.zero_grad(set_to_none=True)
+            text, nodes, zz = text0.clone().requires_grad_(), nodes0.clone().requires_grad_(), z.clone().requires_grad_()
+            r = vq(zz, text, nodes, mask, batch, z_aug)
+            loss = sum(t for t in r["shared_embed_loss"][:2]) + r["text_specific_loss"][0] + r["graph_specific_loss"][1] \
+                + r["shared_text_embedding"].sum() * 0.01 + r["specific_embedding_graph_aug"].pow(2).sum() * 0.01
+            loss.backward()
+            outs = [loss.detach().clone(), r["shared_text_tokens"].clone(), r["text_tokens_weights"].clone(), r["specific_embedding_text"].detach().clone()]
+            return outs + [zz.grad.clone(), text.grad.clone(), nodes.grad.clone(), vq.codebook.weight.grad.clone()]
+        finally:
+            vqmod.TRAIN_BATCHED_SEARCHES = old
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
