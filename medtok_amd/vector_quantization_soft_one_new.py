@@ -111,6 +111,9 @@ KEY_GRADIENT_SINK = True
 # training: both directions of a layer under ONE autograd node that writes their outputs (and dQ) into row ranges of one matrix, instead
 # of a split in front of two nodes and a concatenation behind them (a copy of the [R heads, D] matrix each, forward and backward)
 TWO_SIDED_ATTENTION_NODE = True
+# training: the node mean of a code on the library's ordered segment mean under autograd (_SegmentMeanFunction) instead of a scatter into a
+# zero [B, max_nodes, D] tensor and a sum over it
+TRAIN_SEGMENT_MEAN = True
 from .norm_ema_quantizer import EmbeddingEMA
 
 USAGE_WINDOW = 300000   # vector_quantization_soft_one_new.py:118
@@ -214,6 +217,24 @@ def _cached(holder, attr, key, build, device, rebuild=False):
         cur.wait_event(mark.event)
         _lend(cur, c[1])
     return c[1]
+
+
+class _SegmentMeanFunction(torch.autograd.Function):
+    """Mean of the attended nodes of every code (:140-141) under autograd: forward = the library's ordered segment mean (rows of a code
+    are adjacent), backward = each node row receives its code's gradient / node count (one division, one gather).  The training path
+    used to scatter the rows into a zero [B, max_nodes, D] tensor and sum it (157 MB at B = 256, max 200 nodes, D = 768)."""
+
+    @staticmethod
+    def forward(ctx, g, starts, counts, batch_sorted):
+        ctx.save_for_backward(counts, batch_sorted)
+        ctx.in_dtype = g.dtype
+        return ops.segment_mean(g.detach().float().contiguous(), starts, counts)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        counts, batch_sorted = ctx.saved_tensors
+        per_code = d_out.float() / counts.clamp(min=1).unsqueeze(-1).to(torch.float32)
+        return per_code[batch_sorted].to(ctx.in_dtype), None, None, None
 
 
 class _KeyGradSink:
@@ -1001,6 +1022,9 @@ class CrossAttention(nn.Module):
             for layer in self.model:
                 rows = self._folded_rows(layer, rows, both_attend)
             g, cur = torch.split(rows, [n_g, rows.shape[0] - n_g], dim=0)
+            if TRAIN_SEGMENT_MEAN and g.is_cuda and g.dtype == torch.float32 and dim % 4 == 0:
+                gm = _SegmentMeanFunction.apply(g, starts, counts, batch_sorted)      # ordered sums per code (no atomics), one launch
+                return (cur, gm) if join else (cur, gm, None)
             if slot is None:
                 slot = torch.arange(batch_sorted.numel(), device=batch_sorted.device) - starts[batch_sorted]
             padded = g.new_zeros(bsz, max_nodes, dim)
@@ -1068,6 +1092,9 @@ class CrossAttention(nn.Module):
                 pending = (side, main)                     # the caller keeps using the side stream (get_shared_info: the shared-text search)
         if not autograd and not torch.is_grad_enabled() and g.is_cuda and g.dtype == torch.float32 and dim % 4 == 0:
             gm = ops.segment_mean(g, starts, counts)               # rows of a code are adjacent: one ordered chain per column
+            return (cur, gm) if join else (cur, gm, pending)
+        if TRAIN_SEGMENT_MEAN and g.is_cuda and g.dtype == torch.float32 and dim % 4 == 0:
+            gm = _SegmentMeanFunction.apply(g, starts, counts, batch_sorted)          # (the same under autograd)
             return (cur, gm) if join else (cur, gm, pending)
         if slot is None:                                   # (pooled() leaves the in-code position of a node to this fallback)
             slot = torch.arange(batch_sorted.numel(), device=batch_sorted.device) - starts[batch_sorted]
