@@ -1183,6 +1183,24 @@ def main():
             line["config"]["vq_path_ms_per_step"] = max(line["ms_per_step"] - enc, 0.0)
             line["config"]["note"] = ("stand-in encoders (out of scope, upstream of the path); vq_path = cross-attention + 6 searches + "
                                       "loss.py + backward + clip + AdamW = step - encoders")
+            # the same steps with CrossAttention.max_nodes_bound set to the batch's largest subgraph (a trainer knows its dataset's): the
+            # cross-attention then sizes its launches from the bound -- one of the step's two host reads is gone (an extra, not `value`)
+            try:
+                ca = wl.model.quantize.cross_attn
+                ca.max_nodes_bound = int(torch.bincount(wl.inputs.batch).max())
+                for _ in range(2):
+                    wl.step()
+                torch.cuda.synchronize(dev)
+                t2 = time.perf_counter()
+                for _ in range(args.steps):
+                    wl.step()
+                torch.cuda.synchronize(dev)
+                line["with_max_nodes_bound"] = {"ms_per_step": (time.perf_counter() - t2) / max(args.steps, 1) * 1e3, "max_nodes_bound": ca.max_nodes_bound,
+                                                "note": "CrossAttention.max_nodes_bound set: no host read of the node counts in pooled(); the usage counts' read remains"}
+            except Exception as exc:
+                line["with_max_nodes_bound"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            finally:
+                wl.model.quantize.cross_attn.max_nodes_bound = None
         if world == 1 and args.workload == "cfg3" and args.data == "gaussian" and args.rows is None and not args.no_extra_workloads:
             del wl.h, wl.pooled_text, wl.pooled_graph
             torch.cuda.empty_cache()

@@ -640,11 +640,12 @@ class CrossAttention(nn.Module):
     def __init__(self, embed_dim, num_heads, dropout=0.1, layers=2):
         super().__init__()
         self.model = nn.ModuleList([CrossAttentionLayer(embed_dim, num_heads, dropout) for _ in range(layers)])
-        # (not in the reference) An upper bound on the nodes of one code, e.g. the dataset's largest subgraph.  With it pooled() at
-        # inference sizes its attention launches from the bound instead of reading the batch's largest node count back: no host
-        # synchronisation, so VectorQuantizer.forward (eval, show_usage = False) records into a HIP graph at any width.  `batch`
-        # must then be non-decreasing (PyG batch vectors are); a batch that is not, holds ids outside [0, B) or exceeds the bound is
-        # flagged on the device (small_status) and raised by check_status().  None: one host read per call, any batch vector.
+        # (not in the reference) An upper bound on the nodes of one code, e.g. the dataset's largest subgraph.  With it pooled()
+        # sizes its attention launches from the bound instead of reading the batch's largest node count back: no host
+        # synchronisation, so VectorQuantizer.forward (eval, show_usage = False) records into a HIP graph at any width, and a
+        # training step loses one of its two host reads (0.23 ms of 9 at cfg 4).  `batch` must then be non-decreasing (PyG batch
+        # vectors are); a batch that is not, holds ids outside [0, B) or exceeds the bound is flagged on the device (small_status)
+        # and raised by check_status() / with the usage counts' read.  None: one host read per call, any batch vector.
         self.max_nodes_bound = None
 
     def forward(self, vector1, vector2, attn_mask=None):
@@ -1312,12 +1313,14 @@ class CrossAttention(nn.Module):
             nodes, text = nodes.to(common), text.to(common)
         batch = batch.reshape(-1).to(torch.long)
         # counts / offsets / launch lists of all codes: three small launches (ops.pack_codes), nothing read back yet
-        bound = None if autograd or torch.is_grad_enabled() else getattr(self, "max_nodes_bound", None)      # (a module pickled before the attribute existed)
+        # (training too since round 6: the same device-side checks; a trainer reads them with the usage counts -- VectorQuantizer.forward
+        # does -- or calls check_status().  What differs from inference: a flagged batch raises, nothing is repeated on sorted nodes.)
+        bound = getattr(self, "max_nodes_bound", None)      # (getattr: a module pickled before the attribute existed)
         if bound is not None:
             bound = int(bound)
             if bound <= 0:
                 raise ValueError(f"max_nodes_bound = {bound} must be a positive node count (or None)")
-            pk = ops.pack_codes(text_mask, batch, heads, LPT_ORDER, count_bound=bound, status=self._status_word(text.device))
+            pk = ops.pack_codes(text_mask, batch, heads, LPT_ORDER and not autograd, count_bound=bound, status=self._status_word(text.device))
         else:
             pk = ops.pack_codes(text_mask, batch, heads, LPT_ORDER and not autograd)
         images = None
@@ -1914,8 +1917,16 @@ class VectorQuantizer(nn.Module):
         r = [res[6 * i: 6 * i + 6] for i in range(len(xs))]               # (zq, vq, commit, xhat, idx, w) per search
         u_shared = u_text = u_graph = 0.0
         if self.show_usage:
-            cnt = ops.usage_update_multi_(self.codebook_used, [torch.cat([r[0][4], r[1][4]], dim=-1)] + [q[4] for q in r[2:]], self.n_e)
-            u_shared, u_text, u_graph = (cnt[:3].cpu().double() / self.n_e).tolist()
+            # (with max_nodes_bound set the cross-attention validated `batch` on the device: its status word comes with the counts in the
+            # one host read, and vetoes the window update when it is set)
+            st = getattr(self.cross_attn, "small_status", None) if getattr(self.cross_attn, "max_nodes_bound", None) is not None else None
+            if st is not None and st.device != self.codebook_used.device:
+                st = None
+            cnt = ops.usage_update_multi_(self.codebook_used, [torch.cat([r[0][4], r[1][4]], dim=-1)] + [q[4] for q in r[2:]], self.n_e, extra_word=st)
+            vals = cnt.cpu()
+            if st is not None and int(vals[-1]) and self.cross_attn.take_status(int(vals[-1])):
+                raise ValueError(UNSORTED_BATCH_MESSAGE)
+            u_shared, u_text, u_graph = (vals[:3].double() / self.n_e).tolist()
         out = {
             "graph_feature": z_graph,
             "text_feature": z_text,

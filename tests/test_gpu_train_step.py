@@ -337,3 +337,60 @@ def test_batched_training_searches_switch_gives_the_same_bits(dev):
     a, b = run(False), run(True)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_max_nodes_bound_in_training_matches_the_host_read_and_flags_bad_batches(dev):
+    """CrossAttention.max_nodes_bound in a TRAINING forward (round 6): launches sized from the bound, no host read in pooled() -- outputs and
+    gradients equal those of the form that reads the largest node count back; a code above the bound and an unsorted batch vector are
+    flagged on the device and raised with the usage counts' read (VectorQuantizer.forward) or by check_status()."""
+    from medtok_amd.vector_quantization_soft_one_new import VectorQuantizer, UNSORTED_BATCH_MESSAGE
+    torch.manual_seed(4)
+    bsz, seq_len, d = 10, 16, 128
+    vq = VectorQuantizer(n_e=3000, e_dim=d, beta=0.25, entropy_loss_ratio=0.0, l2_norm=True, show_usage=True, split=[d, d]).to(dev).train()
+    for mod in vq.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, nn.MultiheadAttention):
+            mod.dropout = 0.0
+    g = torch.Generator(device="cpu").manual_seed(9)
+    counts = torch.randint(1, 12, (bsz,), generator=g)
+    batch = torch.repeat_interleave(torch.arange(bsz), counts).to(dev)
+    mask = (torch.arange(seq_len)[None, :] < torch.randint(1, seq_len + 1, (bsz, 1), generator=g)).long().to(dev)
+    z, z_aug = torch.randn(bsz, 2 * d, generator=g).to(dev), torch.randn(bsz, 2 * d, generator=g).to(dev)
+    text0, nodes0 = torch.randn(bsz, seq_len, d, generator=g).to(dev), torch.randn(int(counts.sum()), d, generator=g).to(dev)
+    state = {k: v.clone() for k, v in vq.state_dict().items()}
+
+    def run(bound, batch_vec=batch, nodes_in=nodes0):
+        vq.load_state_dict(state)
+        vq.zero_grad(set_to_none=True)
+        vq.cross_attn.max_nodes_bound = bound
+        try:
+            text, nodes = text0.clone().requires_grad_(), nodes_in.clone().requires_grad_()
+            r = vq(z, text, nodes, mask, batch_vec, z_aug)
+            loss = r["shared_embed_loss"][0] + r["shared_embed_loss"][1] + r["shared_text_embedding"].sum() * 0.01 + r["shared_graph_embedding"].pow(2).sum() * 0.01
+            loss.backward()
+            return [loss.detach().clone(), r["shared_graph_tokens"].clone(), text.grad.clone(), nodes.grad.clone(), vq.cross_attn.model[0].multihead_attn.in_proj_weight.grad.clone()]
+        finally:
+            vq.cross_attn.max_nodes_bound = None
+    ref = run(None)
+    for bound in (int(counts.max()), int(counts.max()) + 37):
+        got = run(bound)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b) if a.dtype == torch.int64 else float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-6)
+    assert not torch.equal(vq.codebook_used, state["codebook_used"])            # (a clean forward slides the usage window)
+    with pytest.raises(ValueError, match="max_nodes_bound"):
+        run(int(counts.max()) - 1)
+    assert torch.equal(vq.codebook_used, state["codebook_used"])                 # (run() restores the state; the flagged forward did not touch the window)
+    perm = torch.randperm(batch.numel(), generator=g).to(dev)
+    with pytest.raises(ValueError) as e:
+        run(int(counts.max()), batch_vec=batch[perm], nodes_in=nodes0[perm])
+    assert UNSORTED_BATCH_MESSAGE[:40] in str(e.value)
+    assert run(int(counts.max()))[0].isfinite()                                  # (the word was cleared: the next forward is clean)
+    # pooled() alone: the caller's check_status()
+    vq.cross_attn.max_nodes_bound = int(counts.max()) - 1
+    try:
+        vq.cross_attn.pooled(text0.clone().requires_grad_(), mask, nodes0.clone().requires_grad_(), batch)
+        with pytest.raises(ValueError, match="max_nodes_bound"):
+            vq.cross_attn.check_status()
+    finally:
+        vq.cross_attn.max_nodes_bound = None
