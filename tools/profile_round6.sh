@@ -12,8 +12,8 @@ python3 bench.py --workload refdefault 2>/dev/null | tail -1 > $out/bench_refdef
 python3 bench.py --workload cfg2 2>/dev/null | tail -1 > $out/bench_cfg2.json
 python3 bench.py --workload cfg5 2>/dev/null | tail -1 > $out/bench_cfg5.json
 python3 bench.py --workload codeshard 2>/dev/null | tail -1 > $out/bench_codeshard.json
-python3 bench.py --workload cfg4 --precomputed-encoders 2>/dev/null | tail -1 > $out/bench_cfg4_vq_only.json
-python3 bench.py --workload cfg4 2>/dev/null | tail -1 > $out/bench_cfg4.json
+python3 bench.py --workload cfg4 --precomputed-encoders --steps 20 --warmup 20 2>/dev/null | tail -1 > $out/bench_cfg4_vq_only.json
+python3 bench.py --workload cfg4 --steps 10 --warmup 3 2>/dev/null | tail -1 > $out/bench_cfg4.json
 for d in near_codes clustered_codebook heavy_tail; do
   python3 bench.py --data $d --steps 3 --warmup 1 --cpu-rows 0 2>/dev/null | tail -1 > $out/bench_cfg3_data_$d.json
 done
