@@ -506,11 +506,29 @@ int medtok_shared_kv_attention_backward_half_f32(const float *q, const int64_t *
  * Every layer of CrossAttention attends to the ORIGINAL other modality (vector_quantization_soft_one_new.py:83,86): the key gradients of
  * all layers land in one [kv_rows, d] buffer, in launch order (a block owns its key rows: the sum is ordered, held + this launch's).
  * Rows no block owns are then left untouched instead of zeroed.  accumulate_dkv == 0: exactly the two entries above. */
+/* accumulate_dkv == 2: dQ ONLY -- dkv may be NULL, nothing of the key gradient is computed; ws (q_rows floats) then holds delta = <d_out, out>
+ * per query row, which medtok_shared_kv_attention_dkv_multi_f32 below takes with the call's other tensors as one of its sources. */
 int medtok_shared_kv_attention_backward_acc_f32(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
                                                 const int64_t *kv_start, const int64_t *kv_len, int64_t n_codes, int64_t max_q_len,
                                                 int64_t max_kv_len, int64_t q_rows, int64_t kv_rows, int d, float scale, float dropout_p,
                                                 uint32_t seed, const float *out, const float *lse, const float *d_out, float *dq,
                                                 float *dkv, void *ws, size_t ws_bytes, int mode, int accumulate_dkv, void *stream);
+
+/* The key gradient of SEVERAL attention calls over the same keys (kv, kv_start, kv_len) in ONE launch: the layers of CrossAttention all
+ * attend to the original other modality (:83,86), so dKV is one sum -- a block walks the sources' queries one source after the other into
+ * one accumulator and stores its key rows once (one launch per layer: a zero fill, a store and a read-add-store pass over [kv_rows, d]).
+ * A source = one earlier dQ-only call (accumulate_dkv == 2 above): its q, d_out, lse, its workspace as delta, its q_start / q_len and
+ * dropout parameters.  dkv [kv_rows, d]: rows no block owns are zeroed.  mode as above. */
+typedef struct medtok_dkv_source {
+    const float *q, *d_out, *lse, *delta;
+    const int64_t *q_start, *q_len;
+    float scale, dropout_p;
+    uint32_t seed, reserved_;
+} medtok_dkv_source;
+#define MEDTOK_DKV_SOURCES_MAX 4
+int medtok_shared_kv_attention_dkv_multi_f32(const medtok_dkv_source *sources, int count, const float *kv, const int64_t *kv_start,
+                                             const int64_t *kv_len, int64_t n_codes, int64_t max_kv_len, int64_t kv_rows, int d,
+                                             float *dkv, int mode, void *stream);
 
 /* EMA statistics of norm_ema_quantizer.py:183,194,202 without the one-hot:
  * bins[c] = #rows with idx == c (exact), embed_sum[c][:] = sum of those rows of

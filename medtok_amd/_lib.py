@@ -119,6 +119,7 @@ SIGNATURES = {
                                                             _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _vp]),
     "medtok_shared_kv_attention_backward_acc_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _f, _f, C.c_uint32,
                                                            _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int, _int, _vp]),
+    "medtok_shared_kv_attention_dkv_multi_f32": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp, _int, _vp]),
     "medtok_ema_stats_workspace_bytes": (_sz, [_i64, _i64]),
     "medtok_ema_stats_f32": (_int, [_vp, _vp, _i64, _int, _i64, _vp, _vp, _vp, _sz, _vp]),
     "medtok_code_histogram_workspace_bytes": (_sz, [_i64]),
@@ -153,6 +154,13 @@ class SearchDesc(C.Structure):
                 ("zq", _vp), ("zq_stride", _i64), ("x_stride", _i64), ("row_sqerr", _vp)]
 
 
+class DkvSource(C.Structure):
+    """medtok_dkv_source (include/medtok_vq.h)"""
+    _fields_ = [("q", _vp), ("d_out", _vp), ("lse", _vp), ("delta", _vp), ("q_start", _vp), ("q_len", _vp), ("scale", _f), ("dropout_p", _f),
+                ("seed", C.c_uint32), ("reserved_", C.c_uint32)]
+
+
+DKV_SOURCES_MAX = 4
 MULTI_SEARCH_MAX = 6
 USAGE_MULTI_MAX = 6
 

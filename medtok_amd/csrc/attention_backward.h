@@ -381,12 +381,23 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dq_kernel(
 }
 
 // ---------------------------------------------------------------- dKV
+// One launch takes the key gradient of up to DKV_SRC_MAX "sources" -- attention calls over the SAME keys (kv, kv_start, kv_len) with their
+// own queries, upstream gradients, row statistics and dropout masks: the layers of CrossAttention all attend to the original other
+// modality, so their key gradients are one sum; a block walks the sources' query chunks one after the other into one accumulator and
+// stores its 32 key rows once (one launch per layer: a second pass over the [kv_rows, D] gradient to add into it).
+constexpr int DKV_SRC_MAX = 4;
+struct DkvSource {
+    const float *q, *d_out, *lse, *delta;
+    const int64_t *q_start, *q_len;
+    float scale, keep_scale;
+    unsigned thresh, seed;
+};
+struct DkvSources { DkvSource s[DKV_SRC_MAX]; int count; };
+
 template <int W, int NT, int HM = 0>
 __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
-    const float *__restrict__ q, const int64_t *__restrict__ q_start, const int64_t *__restrict__ q_len,
-    const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
-    const float *__restrict__ d_out, const float *__restrict__ lse, const float *__restrict__ delta, float scale,
-    float *__restrict__ dkv, int kv_tiles, unsigned drop_thresh, unsigned seed, float keep_scale, int accumulate)
+    const DkvSources S, const float *__restrict__ kv, const int64_t *__restrict__ kv_start, const int64_t *__restrict__ kv_len,
+    float *__restrict__ dkv, int kv_tiles, int accumulate)
 {
     using G = AttShape<W, NT>;
     constexpr int D = G::D, LD = G::LD, EPT = G::EPT, TPR = G::TPR, FT = G::FT, CI = G::CI, RP = G::RP, RI = G::RI, NF = G::NF;
@@ -399,8 +410,13 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
     const int b = (int)(blockIdx.x / (unsigned)kv_tiles), kt = (int)(blockIdx.x % (unsigned)kv_tiles);
     const int kl = (int)kv_len[b];
     if (kt * 32 >= kl) return;
-    const long qs = q_start[b], ks = kv_start[b];
-    const int ql = (int)q_len[b];
+    const long ks = kv_start[b];
+    // the source being walked (set at the top of the source loop below)
+    long qs = 0;
+    int ql = 0;
+    const float *q = nullptr, *d_out = nullptr, *lse = nullptr, *delta = nullptr;
+    float scale = 0.f, keep_scale = 1.f;
+    unsigned drop_thresh = 0, seed = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int slice = wave * 32 * NT;
     const int f_r0 = tid / FT, f_c = (tid % FT) * 4;
@@ -451,6 +467,13 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
             }
         };
     };
+    for (int si = 0; si < S.count; ++si) {
+    {
+        const DkvSource &src = S.s[si];
+        qs = src.q_start[b]; ql = (int)src.q_len[b];
+        q = src.q; d_out = src.d_out; lse = src.lse; delta = src.delta;
+        scale = src.scale; keep_scale = src.keep_scale; drop_thresh = src.thresh; seed = src.seed;
+    }
     if constexpr (HM) {
         // Half-precision form: the 16-bit images of the Q chunk AND of the dO chunk are resident together (two [32][D + 8] images in the
         // space of one fp32 chunk), so Q is parked once per iteration, not twice: 6 block-wide synchronisations per chunk instead of 9,
@@ -579,6 +602,7 @@ __global__ __launch_bounds__(64 * W) void shared_kv_attention_dkv_kernel(
         att_accumulate<W, NT>(acc, ds, kvs, slice, li, lh, woven(q, c0 + 32));
     }
     }
+    }                                                             // (the next source)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int orow = (r & 3) + 8 * (r >> 2) + 4 * lh;

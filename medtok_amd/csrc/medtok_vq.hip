@@ -2682,7 +2682,7 @@ extern "C" int medtok_shared_kv_attention_backward_acc_f32(const float *q, const
 {
     if (mode < 0 || mode > 2) return fail("shared_kv_attention_backward_acc: mode=%d must be 0 (fp32), 1 (fp16) or 2 (bf16)", mode);
     return attention_backward_impl(q, q_start, q_len, kv, kv_start, kv_len, n_codes, max_q_len, max_kv_len, q_rows, kv_rows, d, scale, dropout_p, seed, out,
-                                   lse, d_out, dq, dkv, ws, ws_bytes, stream, mode, accumulate_dkv != 0);
+                                   lse, d_out, dq, dkv, ws, ws_bytes, stream, mode, accumulate_dkv == 2 ? 2 : (accumulate_dkv != 0));
 }
 
 static int attention_backward_impl(const float *q, const int64_t *q_start, const int64_t *q_len, const float *kv,
@@ -2695,13 +2695,16 @@ static int attention_backward_impl(const float *q, const int64_t *q_start, const
     if (!attention_shape_ok(d)) return fail("shared_kv_attention_backward: d=%d must be 64 or a multiple of 128, at most 768", d);
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail("shared_kv_attention_backward: dropout_p=%g must be in [0, 1)", (double)dropout_p);
     if (q_rows == 0 && kv_rows == 0) return 0;                 // nothing to write
-    if (!q_start || !q_len || !kv_start || !kv_len || (q_rows > 0 && (!q || !out || !lse || !d_out || !dq)) || (kv_rows > 0 && (!kv || !dkv)))
+    const bool dq_only = acc_dkv == 2;                         // (the caller takes the key gradient later: medtok_shared_kv_attention_dkv_multi_f32)
+    if (!q_start || !q_len || !kv_start || !kv_len || (q_rows > 0 && (!q || !out || !lse || !d_out || !dq)) || (kv_rows > 0 && (!kv || (!dkv && !dq_only))))
         return fail("shared_kv_attention_backward: NULL argument");
     if (!ws || ws_bytes < (size_t)q_rows * 4) return fail("shared_kv_attention_backward: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     // rows no block owns (key rows past a code's kv_len inside its slot, query rows of no code) get a zero gradient
     if (q_rows > 0 && hipMemsetAsync(dq, 0, (size_t)q_rows * d * 4, s) != hipSuccess) return fail("shared_kv_attention_backward: memset failed");
     if (kv_rows > 0 && !acc_dkv && hipMemsetAsync(dkv, 0, (size_t)kv_rows * d * 4, s) != hipSuccess) return fail("shared_kv_attention_backward: memset failed");
+    DkvSources srcs;
+    memset(&srcs, 0, sizeof srcs);
     if (n_codes == 0 || q_rows == 0) return 0;
     float *delta = (float *)ws;
     hipLaunchKernelGGL(row_dot_kernel, dim3((unsigned)((q_rows + 3) / 4)), dim3(256), 0, s, d_out, out, (long)q_rows, d, delta);
@@ -2709,6 +2712,8 @@ static int attention_backward_impl(const float *q, const int64_t *q_start, const
     if (q_tiles * n_codes >= (1ll << 31) || kv_tiles * n_codes >= (1ll << 31)) return fail("shared_kv_attention_backward: grid limit exceeded");
     const unsigned thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
     const float keep_scale = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    srcs.count = 1;
+    srcs.s[0] = DkvSource{q, d_out, lse, delta, q_start, q_len, scale, keep_scale, thresh, seed};
     hipEvent_t pa_bwd = prof_wanted(3) ? prof_mark(s) : nullptr;
 #define MEDTOK_ATT_BWD_HM(W, NT, HM)                                                                                             \
     do {                                                                                                                         \
@@ -2718,9 +2723,9 @@ static int attention_backward_impl(const float *q, const int64_t *q_start, const
         if (q_tiles > 0)                                                                                                         \
             hipLaunchKernelGGL((shared_kv_attention_dq_kernel<W, NT, HM>), dim3((unsigned)(q_tiles * n_codes)), dim3(64 * W), lds, s, q, q_start, q_len, \
                                kv, kv_start, kv_len, d_out, lse, delta, scale, dq, (int)q_tiles, thresh, seed, keep_scale);      \
-        if (kv_tiles > 0)                                                                                                        \
-            hipLaunchKernelGGL((shared_kv_attention_dkv_kernel<W, NT, HM>), dim3((unsigned)(kv_tiles * n_codes)), dim3(64 * W), lds, s, q, q_start, q_len, \
-                               kv, kv_start, kv_len, d_out, lse, delta, scale, dkv, (int)kv_tiles, thresh, seed, keep_scale, acc_dkv); \
+        if (kv_tiles > 0 && !dq_only)                                                                                            \
+            hipLaunchKernelGGL((shared_kv_attention_dkv_kernel<W, NT, HM>), dim3((unsigned)(kv_tiles * n_codes)), dim3(64 * W), lds, s, srcs, \
+                               kv, kv_start, kv_len, dkv, (int)kv_tiles, acc_dkv);                                               \
     } while (0)
 #define MEDTOK_ATT_BWD(W, NT)                                                                                                    \
     do {                                                                                                                         \
@@ -2739,6 +2744,63 @@ static int attention_backward_impl(const float *q, const int64_t *q_start, const
 #undef MEDTOK_ATT_BWD
     if (pa_bwd) prof_push(pa_bwd, prof_mark(s), 0.0, 3);     // dQ + dKV; the caller prices the pair (ragged counts live on the device)
     return check_launch("shared_kv_attention_backward");
+}
+
+// The key gradient of SEVERAL attention calls over the same keys in one launch (attention_backward.h: DkvSources): every source brings its
+// queries, upstream gradient, log-sum-exp, delta (= <d_out, out> per query row: the workspace a dQ-only call of
+// medtok_shared_kv_attention_backward_acc_f32 filled), dropout parameters and its own q_start / q_len; kv, kv_start, kv_len are common.
+// dkv [kv_rows, d] is written once (rows no block owns zeroed).  mode: 0 exact fp32, 1 fp16, 2 bf16 products.
+extern "C" int medtok_shared_kv_attention_dkv_multi_f32(const medtok_dkv_source *sources, int count, const float *kv, const int64_t *kv_start,
+                                                        const int64_t *kv_len, int64_t n_codes, int64_t max_kv_len, int64_t kv_rows, int d,
+                                                        float *dkv, int mode, void *stream)
+{
+    if (!sources || count < 1 || count > DKV_SRC_MAX) return fail("shared_kv_attention_dkv_multi: 1..%d sources per call", DKV_SRC_MAX);
+    if (n_codes < 0 || max_kv_len < 0 || kv_rows < 0) return fail("shared_kv_attention_dkv_multi: bad sizes");
+    if (!attention_shape_ok(d)) return fail("shared_kv_attention_dkv_multi: d=%d must be 64 or a multiple of 128, at most 768", d);
+    if (mode < 0 || mode > 2) return fail("shared_kv_attention_dkv_multi: mode=%d must be 0 (fp32), 1 (fp16) or 2 (bf16)", mode);
+    if (kv_rows == 0) return 0;
+    if (!kv || !kv_start || !kv_len || !dkv) return fail("shared_kv_attention_dkv_multi: NULL argument");
+    DkvSources srcs;
+    memset(&srcs, 0, sizeof srcs);
+    srcs.count = count;
+    for (int i = 0; i < count; ++i) {
+        const medtok_dkv_source &m = sources[i];
+        if (!m.q || !m.d_out || !m.lse || !m.delta || !m.q_start || !m.q_len) return fail("shared_kv_attention_dkv_multi: NULL argument in source %d", i);
+        if (!(m.dropout_p >= 0.f && m.dropout_p < 1.f)) return fail("shared_kv_attention_dkv_multi: dropout_p=%g must be in [0, 1)", (double)m.dropout_p);
+        const unsigned thresh = m.dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)m.dropout_p * 4294967296.0) : 0u;
+        srcs.s[i] = DkvSource{m.q, m.d_out, m.lse, m.delta, m.q_start, m.q_len, m.scale, m.dropout_p > 0.f ? 1.f / (1.f - m.dropout_p) : 1.f, thresh, m.seed};
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(dkv, 0, (size_t)kv_rows * d * 4, s) != hipSuccess) return fail("shared_kv_attention_dkv_multi: memset failed");
+    const int64_t kv_tiles = (max_kv_len + 31) / 32;
+    if (n_codes == 0 || kv_tiles == 0) return 0;
+    if (kv_tiles * n_codes >= (1ll << 31)) return fail("shared_kv_attention_dkv_multi: grid limit exceeded");
+    hipEvent_t pa = prof_wanted(3) ? prof_mark(s) : nullptr;
+#define MEDTOK_DKV_HM(W, NT, HM)                                                                                                 \
+    do {                                                                                                                         \
+        const size_t lds = AttShape<W, NT>::LDS_FLOATS * sizeof(float);                                                          \
+        if (lds > 64 * 1024 && !set_lds_once<shared_kv_attention_dkv_kernel<W, NT, HM>>(lds))                                    \
+            return fail("shared_kv_attention_dkv_multi: cannot reserve %zu bytes of LDS", lds);                                  \
+        hipLaunchKernelGGL((shared_kv_attention_dkv_kernel<W, NT, HM>), dim3((unsigned)(kv_tiles * n_codes)), dim3(64 * W), lds, s, srcs, \
+                           kv, kv_start, kv_len, dkv, (int)kv_tiles, 0);                                                         \
+    } while (0)
+#define MEDTOK_DKV(W, NT)                                                                                                        \
+    do {                                                                                                                         \
+        if (mode == 0) MEDTOK_DKV_HM(W, NT, 0); else if (mode == 1) MEDTOK_DKV_HM(W, NT, 1); else MEDTOK_DKV_HM(W, NT, 2);        \
+    } while (0)
+    switch (d / 128) {
+    case 0: MEDTOK_DKV(2, 1); break;
+    case 1: MEDTOK_DKV(4, 1); break;
+    case 2: MEDTOK_DKV(8, 1); break;
+    case 3: MEDTOK_DKV(4, 3); break;
+    case 4: MEDTOK_DKV(8, 2); break;
+    case 5: MEDTOK_DKV(4, 5); break;
+    default: MEDTOK_DKV(8, 3); break;
+    }
+#undef MEDTOK_DKV_HM
+#undef MEDTOK_DKV
+    if (pa) prof_push(pa, prof_mark(s), 0.0, 3);
+    return check_launch("shared_kv_attention_dkv_multi");
 }
 
 // ================================================================= EMA statistics

@@ -19,6 +19,7 @@ from ._lib import PATH_AUTO, PATH_F16_FILTER, PATH_F32_MFMA, MAX_TOPK, plan_path
 SEARCH_TIMER = None
 
 
+DKV_SOURCES_MAX = _lib.DKV_SOURCES_MAX
 PROFILE_KINDS = ("filter_f16_kernel", "search_f32_kernel", "shared_kv_attention_kernel", "shared_kv_attention_backward_kernels", "split_gemm_kernel")
 
 
@@ -760,6 +761,49 @@ def shared_kv_attention_backward(q, q_start, q_len, kv, kv_start, kv_len, max_q_
         else:
             _lib.check(lib.medtok_shared_kv_attention_backward_f32(*args, _stream(q)), "medtok_shared_kv_attention_backward_f32")
     return dq, dkv
+
+
+def shared_kv_attention_backward_dq(q, q_start, q_len, kv, kv_start, kv_len, max_q_len: int, max_kv_len: int, scale: float, dropout_p: float,
+                                    seed: int, out, lse, d_out, half=None, dq_into=None):
+    """(dq, delta): the query gradient alone (medtok_shared_kv_attention_backward_acc_f32, accumulate_dkv = 2) and delta = <d_out, out> per
+    query row -- what shared_kv_attention_dkv_multi takes, with the call's other tensors, as one of its sources."""
+    q, kv, out, lse, d_out = _dev(q, "q"), _dev(kv, "kv"), _dev(out, "out"), _dev(lse, "lse"), _dev(d_out, "d_out")
+    qs, ql = _dev(q_start, "q_start", torch.int64), _dev(q_len, "q_len", torch.int64)
+    ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
+    dq = torch.empty_like(q) if dq_into is None else _into(dq_into, "dq_into", q.shape, q)
+    delta = torch.empty((max(q.shape[0], 1),), dtype=torch.float32, device=q.device)
+    mode = 1 if half == torch.float16 else (2 if half == torch.bfloat16 else 0)
+    with _on(q.device):
+        _lib.check(_lib.load().medtok_shared_kv_attention_backward_acc_f32(
+            q.data_ptr(), qs.data_ptr(), ql.data_ptr(), kv.data_ptr(), ks.data_ptr(), kl.data_ptr(), qs.numel(), int(max_q_len), int(max_kv_len),
+            q.shape[0], kv.shape[0], q.shape[1], float(scale), float(dropout_p), int(seed) & 0xFFFFFFFF, out.data_ptr(), lse.data_ptr(),
+            d_out.data_ptr(), dq.data_ptr(), 0, delta.data_ptr(), delta.numel() * 4, mode, 2, _stream(q)), "medtok_shared_kv_attention_backward_acc_f32")
+    return dq, delta
+
+
+def shared_kv_attention_dkv_multi(sources, kv, kv_start, kv_len, max_kv_len: int, half=None):
+    """dkv [kv_rows, d]: the key gradient of several attention calls over the same keys in ONE launch (medtok_shared_kv_attention_dkv_multi_f32).
+    sources: dicts with q, d_out, lse, delta (of shared_kv_attention_backward_dq), q_start, q_len, scale, dropout_p, seed."""
+    kv = _dev(kv, "kv")
+    ks, kl = _dev(kv_start, "kv_start", torch.int64), _dev(kv_len, "kv_len", torch.int64)
+    count = len(sources)
+    if not 1 <= count <= _lib.DKV_SOURCES_MAX:
+        raise ValueError(f"shared_kv_attention_dkv_multi: 1..{_lib.DKV_SOURCES_MAX} sources per call")
+    descs = (_lib.DkvSource * count)()
+    keep = []
+    for i, src in enumerate(sources):
+        t = [_dev(src[k], k) for k in ("q", "d_out", "lse", "delta")] + [_dev(src[k], k, torch.int64) for k in ("q_start", "q_len")]
+        if t[0].shape[1] != kv.shape[1] or t[1].shape != t[0].shape or t[2].numel() < t[0].shape[0] or t[3].numel() < t[0].shape[0] or t[4].numel() != ks.numel():
+            raise ValueError("shared_kv_attention_dkv_multi: a source's tensors do not fit together")
+        keep.append(t)
+        descs[i] = _lib.DkvSource(*[x.data_ptr() for x in t], float(src["scale"]), float(src["dropout_p"]), int(src["seed"]) & 0xFFFFFFFF, 0)
+    dkv = torch.empty_like(kv)
+    mode = 1 if half == torch.float16 else (2 if half == torch.bfloat16 else 0)
+    with _on(kv.device):
+        _lib.check(_lib.load().medtok_shared_kv_attention_dkv_multi_f32(descs, count, kv.data_ptr(), ks.data_ptr(), kl.data_ptr(), ks.numel(), int(max_kv_len),
+                                                                        kv.shape[0], kv.shape[1], dkv.data_ptr(), mode, _stream(kv)),
+                   "medtok_shared_kv_attention_dkv_multi_f32")
+    return dkv
 
 
 def sum_scale(vals: torch.Tensor, scale: float) -> torch.Tensor:

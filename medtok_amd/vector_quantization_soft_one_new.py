@@ -108,6 +108,9 @@ FUSE_IMAGE_PAIRS = True
 # zero fill and an add pass each (0.8 ms of a 12 ms step at B = 256, L = 512).  On: the layers' dKV kernels write into ONE buffer
 # (the first zeroes and stores, the others add), the CLS gradients are added to its B rows in place (_TextFanOut)
 KEY_GRADIENT_SINK = True
+# ... and the layers' dKV launches deferred to the node that collects the key gradient: ONE launch over all layers' queries writes the
+# [rows, D] matrix once (per-layer launches: a zero fill, a store and a read-add-store pass over it)
+DEFERRED_KEY_GRADIENT = True
 # training: both directions of a layer under ONE autograd node that writes their outputs (and dQ) into row ranges of one matrix, instead
 # of a split in front of two nodes and a concatenation behind them (a copy of the [R heads, D] matrix each, forward and backward)
 TWO_SIDED_ATTENTION_NODE = True
@@ -238,12 +241,36 @@ class _SegmentMeanFunction(torch.autograd.Function):
 
 
 class _KeyGradSink:
-    """Where the dKV kernels of the layers that share one key matrix put its gradient during a backward (see _TextFanOut)."""
-    __slots__ = ("buf", "node")
+    """Where the layers that share one key matrix leave its gradient during a backward (see _TextFanOut): either written by their dKV
+    kernels at once (`buf`: the first stores, the others add), or -- DEFERRED_KEY_GRADIENT -- as `pending` sources (a layer's queries,
+    upstream gradient, row statistics, mask parameters) that the collecting node turns into the gradient with ONE launch."""
+    __slots__ = ("buf", "node", "pending", "common")
 
     def __init__(self):
         self.buf = None         # the [rows, D] gradient while a backward is under way
         self.node = None        # weak reference to the autograd node that collects it
+        self.pending = []       # sources of ops.shared_kv_attention_dkv_multi
+        self.common = None      # (kv, kv_start, kv_len, max_kv_len, half) of the pending sources
+
+
+def _sink_key_gradient(sink, q, q_start, q_len, kv, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed, out, lse, d_out, half, dq_into=None):
+    """dq of one attention call whose key gradient goes to `sink`: deferred as a source of the collecting node's one dKV launch where
+    the keys are those of the sources already there, else written / added by this call's own dKV kernel."""
+    common = (kv, kv_start, kv_len, max_kv_len, half)
+    same = sink.common is not None and all(a is b or (torch.is_tensor(a) and torch.is_tensor(b) and a.data_ptr() == b.data_ptr() and a.shape == b.shape)
+                                           or (not torch.is_tensor(a) and a == b) for a, b in zip(common, sink.common))
+    if DEFERRED_KEY_GRADIENT and sink.buf is None and len(sink.pending) < ops.DKV_SOURCES_MAX and (not sink.pending or same):
+        dq, delta = ops.shared_kv_attention_backward_dq(q, q_start, q_len, kv, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed, out, lse,
+                                                        d_out, half=half, dq_into=dq_into)
+        sink.pending.append(dict(q=q, d_out=d_out, lse=lse, delta=delta, q_start=q_start, q_len=q_len, scale=scale, dropout_p=dropout_p, seed=seed))
+        sink.common = common
+        return dq
+    first = sink.buf is None
+    if first:
+        sink.buf = torch.empty_like(kv)
+    dq, _ = ops.shared_kv_attention_backward(q, q_start, q_len, kv, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed, out, lse, d_out,
+                                             half=half, dkv_into=sink.buf, accumulate=not first, dq_into=dq_into)
+    return dq
 
 
 class _TextFan:
@@ -270,6 +297,10 @@ class _TextFanOut(torch.autograd.Function):
     def backward(ctx, g_rows, g_cls):
         sink = ctx.sink
         buf, sink.buf = sink.buf, None
+        pending, common, sink.pending, sink.common = sink.pending, sink.common, [], None
+        if pending:                         # the deferred key gradients of all layers: one launch, one store of the [rows, D] matrix
+            d = ops.shared_kv_attention_dkv_multi(pending, common[0], common[1], common[2], common[3], half=common[4])
+            buf = d if buf is None else buf.add_(d)
         if g_rows is not None:              # (a consumer outside the sink protocol)
             g_rows = g_rows.float()
             buf = g_rows.clone() if buf is None else buf.view_as(g_rows).add_(g_rows)
@@ -356,11 +387,8 @@ class _TwoSidedAttentionFunction(torch.autograd.Function):
         if cut > 0:
             a = lists[:4]
             if sink is not None:
-                first = sink.buf is None
-                if first:
-                    sink.buf = torch.empty_like(ka)
-                ops.shared_kv_attention_backward(q[:cut], a[0], a[1], ka, a[2], a[3], mq_a, mk_a, scale, dropout_p, seed_a, out[:cut], lse[:cut], d[:cut],
-                                                 half=ctx.half, dkv_into=sink.buf, accumulate=not first, dq_into=dq[:cut])
+                _sink_key_gradient(sink, q[:cut], a[0], a[1], ka, a[2], a[3], mq_a, mk_a, scale, dropout_p, seed_a, out[:cut], lse[:cut], d[:cut], ctx.half,
+                                   dq_into=dq[:cut])
             else:
                 _, dka = ops.shared_kv_attention_backward(q[:cut], a[0], a[1], ka, a[2], a[3], mq_a, mk_a, scale, dropout_p, seed_a, out[:cut], lse[:cut],
                                                           d[:cut], half=ctx.half, dq_into=dq[:cut])
@@ -403,11 +431,8 @@ class _RaggedAttentionFunction(torch.autograd.Function):
         max_q_len, max_kv_len, scale, dropout_p, seed, qd, kd = ctx.cfg
         sink = _live_sink(ctx.sink, ctx.needs_input_grad[1])
         if sink is not None:
-            first = sink.buf is None
-            if first:
-                sink.buf = torch.empty_like(kvf)
-            dq, _ = ops.shared_kv_attention_backward(qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed,
-                                                     out, lse, d_out.float().contiguous(), half=ctx.half, dkv_into=sink.buf, accumulate=not first)
+            dq = _sink_key_gradient(sink, qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed, out, lse,
+                                    d_out.float().contiguous(), ctx.half)
             return dq.to(qd), None, None, None, None, None, None, None, None, None, None, None
         dq, dkv = ops.shared_kv_attention_backward(qf, q_start, q_len, kvf, kv_start, kv_len, max_q_len, max_kv_len, scale, dropout_p, seed,
                                                    out, lse, d_out.float().contiguous(), half=ctx.half)

@@ -665,3 +665,44 @@ def test_attention_train_forward_on_split_products_matches_the_fp32_kernel(oracl
     assert torch.equal(out2, out1) and torch.equal(lse2, lse1)
     with pytest.raises(Exception):
         ops.shared_kv_attention_train(T(q[:, :128].copy()), *args[1:3], T(kv[:, :128].copy()), *args[4:], int(q_len.max()), scale, p, seed, split=True)
+
+
+@pytest.mark.parametrize("d,half", [(64, None), (768, None), (768, torch.bfloat16), (256, torch.float16)])
+def test_key_gradient_of_several_attention_calls_in_one_launch(dev, d, half):
+    """medtok_shared_kv_attention_dkv_multi_f32: the key gradient of two attention calls over the same keys (their own queries, upstream
+    gradients, masks) in one launch against the sum of the two calls' own dKV (accumulation order differs: 1e-5 in fp32, the half
+    forms' own tolerance otherwise); the dQ-only call that makes a source returns the dq of the full call bit for bit."""
+    from medtok_amd import ops
+    rng = np.random.default_rng(d + 1)
+    kv_len = np.array([50, 33, 12, 100, 0, 1], np.int64)
+    slot_kv = kv_len + np.array([0, 3, 0, 0, 4, 0])
+    kv_start = np.cumsum(slot_kv) - slot_kv
+    nk = int(slot_kv.sum()) + 2
+    T = lambda a: torch.from_numpy(a).to(dev)
+    kv = T(rng.standard_normal((nk, d)).astype(np.float32))
+    sources, singles = [], []
+    for i, q_len in enumerate((np.array([40, 7, 0, 64, 33, 5], np.int64), np.array([3, 70, 9, 0, 1, 31], np.int64))):
+        q_start = np.cumsum(q_len) - q_len
+        nq = int(q_len.sum())
+        q = T((rng.standard_normal((nq, d)) * 0.3).astype(np.float32)); d_out = T(rng.standard_normal((nq, d)).astype(np.float32))
+        args = (q, T(q_start), T(q_len), kv, T(kv_start), T(kv_len))
+        p, seed, scale = (0.1, 7 + i, 0.2) if i else (0.0, 0, 0.15)
+        out, lse = ops.shared_kv_attention_train(*args, int(q_len.max()), scale, p, seed)
+        tail = (int(q_len.max()), int(kv_len.max()), scale, p, seed, out, lse, d_out)
+        dq_full, dkv_one = ops.shared_kv_attention_backward(*args, *tail, half=half)
+        dq, delta = ops.shared_kv_attention_backward_dq(*args, *tail, half=half)
+        assert torch.equal(dq, dq_full)
+        singles.append(dkv_one)
+        sources.append(dict(q=q, d_out=d_out, lse=lse, delta=delta, q_start=args[1], q_len=args[2], scale=scale, dropout_p=p, seed=seed))
+    both = ops.shared_kv_attention_dkv_multi(sources, kv, T(kv_start), T(kv_len), int(kv_len.max()), half=half)
+    ref = singles[0] + singles[1]
+    tol = 1e-5 if half is None else (4e-3 if half == torch.float16 else 4e-2)
+    assert float((both - ref).abs().max()) <= tol * float(ref.abs().max())
+    one = ops.shared_kv_attention_dkv_multi(sources[:1], kv, T(kv_start), T(kv_len), int(kv_len.max()), half=half)
+    assert torch.equal(one, singles[0])                       # a single source: the plain dKV launch
+    owned = torch.zeros(nk, dtype=torch.bool, device=dev)
+    for b in range(len(kv_len)):
+        owned[kv_start[b]: kv_start[b] + kv_len[b]] = True
+    assert not both[~owned].any()
+    with pytest.raises(ValueError):
+        ops.shared_kv_attention_dkv_multi(sources * 3, kv, T(kv_start), T(kv_len), int(kv_len.max()))
