@@ -2471,8 +2471,23 @@ extern "C" int medtok_half_image_f32(const float *src, int64_t n, int d, int64_t
 
 // both images of one matrix in one pass over it: out_plain [n, dp_plain] (zero columns past d; dp_plain <= d rounded up to 64) and
 // out_t = the transposed image of medtok_half_image_f32(transpose = 1, dp = np, group_cols)
+static int half_image_pair_impl(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp_plain, int64_t np, int64_t group_cols,
+                                int bf16, void *out_plain, void *out_t, float *col_partials, void *stream);
 extern "C" int medtok_half_image_pair_f32(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp_plain, int64_t np, int64_t group_cols,
                                           int bf16, void *out_plain, void *out_t, void *stream)
+{
+    return half_image_pair_impl(src, n, d, src_stride, dp_plain, np, group_cols, bf16, out_plain, out_t, nullptr, stream);
+}
+// ... and, from the same pass, col_partials [(np + 63) / 64, d] fp32: the sums over every 64-row tile of each column (fixed order): the
+// column sums of src -- a Linear's bias gradient when src is its upstream gradient -- are the sum of these rows
+extern "C" int medtok_half_image_pair_sums_f32(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp_plain, int64_t np, int64_t group_cols,
+                                               int bf16, void *out_plain, void *out_t, float *col_partials, void *stream)
+{
+    if (!col_partials) return fail("half_image_pair_sums: NULL argument");
+    return half_image_pair_impl(src, n, d, src_stride, dp_plain, np, group_cols, bf16, out_plain, out_t, col_partials, stream);
+}
+static int half_image_pair_impl(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp_plain, int64_t np, int64_t group_cols,
+                                int bf16, void *out_plain, void *out_t, float *col_partials, void *stream)
 {
     if (n <= 0 || d <= 0 || (d & 3) || (np & 7) || (dp_plain & 7) || src_stride < d || (src_stride & 3) || np < n || dp_plain < d || dp_plain > (d + 63) / 64 * 64)
         return fail("half_image_pair: bad shape n=%ld d=%d stride=%ld dp_plain=%ld np=%ld", (long)n, d, (long)src_stride, (long)dp_plain, (long)np);
@@ -2484,8 +2499,8 @@ extern "C" int medtok_half_image_pair_f32(const float *src, int64_t n, int d, in
     if (row_tiles >= (1ll << 31) || (d + 63) / 64 > 65535) return fail("half_image_pair: too large");
     const dim3 grid((unsigned)row_tiles, (unsigned)((d + 63) / 64));
     hipStream_t s = (hipStream_t)stream;
-    if (bf16) hipLaunchKernelGGL(half_image_t_kernel<true>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (long)np, (long)group_cols, (unsigned short *)out_t, (unsigned short *)out_plain, (int)dp_plain);
-    else hipLaunchKernelGGL(half_image_t_kernel<false>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (long)np, (long)group_cols, (unsigned short *)out_t, (unsigned short *)out_plain, (int)dp_plain);
+    if (bf16) hipLaunchKernelGGL(half_image_t_kernel<true>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (long)np, (long)group_cols, (unsigned short *)out_t, (unsigned short *)out_plain, (int)dp_plain, col_partials);
+    else hipLaunchKernelGGL(half_image_t_kernel<false>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (long)np, (long)group_cols, (unsigned short *)out_t, (unsigned short *)out_plain, (int)dp_plain, col_partials);
     return check_launch("half_image_pair");
 }
 

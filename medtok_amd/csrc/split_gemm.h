@@ -602,9 +602,13 @@ __global__ __launch_bounds__(256) void half_image_kernel(const float *__restrict
 
 // plain (optional): the row-major image [n, plain_dp] of the same matrix (half_image_kernel's output) from the same pass -- a
 // training-mode product needs both images of its upstream gradient and of its input (medtok_half_image_pair_f32).
+// colsum (optional): [row tiles, d] fp32 -- the block's sums over its 64 rows of every column of its tile, in a fixed order (16 rows per
+// thread, then the four threads of a column): a bias gradient is the sum of these partials over the row tiles, taken from the pass that
+// makes the gradient's images instead of from a pass of its own over it (104 us for a 131 072 x 768 gradient).
 template <bool BF>
 __global__ __launch_bounds__(256) void half_image_t_kernel(const float *__restrict__ src, long n, int d, long src_stride, long np, long group_cols,
-                                                           unsigned short *__restrict__ out, unsigned short *__restrict__ plain = nullptr, int plain_dp = 0)
+                                                           unsigned short *__restrict__ out, unsigned short *__restrict__ plain = nullptr, int plain_dp = 0,
+                                                           float *__restrict__ colsum = nullptr)
 {
     __shared__ float tile[64][65];
     const long r0 = (long)blockIdx.x * 64;
@@ -626,6 +630,14 @@ __global__ __launch_bounds__(256) void half_image_t_kernel(const float *__restri
     }
     __syncthreads();
     const int c = t >> 2, rs = (t & 3) * 16;
+    if (colsum) {                                         // (before the early exit: the shuffles want all four threads of a column)
+        float a = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) a += tile[rs + jj][c];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if ((t & 3) == 0 && c0 + c < d) colsum[(long)blockIdx.x * d + c0 + c] = a;
+    }
     if (c0 + c >= d) return;
     const long grp = r0 / group_cols, gcol0 = r0 - grp * group_cols;
     unsigned short *o = out + ((grp * d + c0 + c) * group_cols + gcol0);

@@ -438,17 +438,25 @@ def half_image(x, dp: int, dtype, transpose: bool = False, group_cols: int = 0):
     return out
 
 
-def half_image_pair(x, dp: int, np_: int, dtype, group_cols: int = 0):
+def half_image_pair(x, dp: int, np_: int, dtype, group_cols: int = 0, col_sums: bool = False):
     """(half_image(x, dp), half_image(x, np_, transpose=True, group_cols)) from ONE pass over x (medtok_half_image_pair_f32); rows that the
     rows of x do not reach in the transposed image's padding stay unwritten only where half_image(transpose=True) leaves them so too"""
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
         raise _lib.MedTokLibraryError("half_image_pair: expected an fp32 [n, d] matrix with contiguous rows on an MI355X device")
     n, d = x.shape
     if n == 0 or int(dp) > (d + 63) // 64 * 64:
-        return half_image(x, dp, dtype), half_image(x, np_, dtype, transpose=True, group_cols=group_cols)
+        pair = half_image(x, dp, dtype), half_image(x, np_, dtype, transpose=True, group_cols=group_cols)
+        return (*pair, x.sum(0)) if col_sums else pair
     gc = int(group_cols) or int(np_)
     plain = torch.empty((n, int(dp)), dtype=dtype, device=x.device)
     t = torch.empty((int(np_) // gc * d, gc), dtype=dtype, device=x.device)
+    if col_sums:            # (+ the column sums of x from the same pass: per 64-row tile in the kernel, over the tiles here)
+        partials = torch.empty(((int(np_) + 63) // 64, d), dtype=torch.float32, device=x.device)
+        with _on(x.device):
+            _lib.check(_lib.load().medtok_half_image_pair_sums_f32(x.data_ptr(), n, d, x.stride(0) if n > 1 else d, int(dp), int(np_), int(group_cols),
+                                                                   int(dtype == torch.bfloat16), plain.data_ptr(), t.data_ptr(), partials.data_ptr(),
+                                                                   _stream(x)), "medtok_half_image_pair_sums_f32")
+        return plain, t, partials.sum(0)
     with _on(x.device):
         _lib.check(_lib.load().medtok_half_image_pair_f32(x.data_ptr(), n, d, x.stride(0) if n > 1 else d, int(dp), int(np_), int(group_cols),
                                                           int(dtype == torch.bfloat16), plain.data_ptr(), t.data_ptr(), _stream(x)), "medtok_half_image_pair_f32")
