@@ -85,6 +85,8 @@ TRAIN_SINGLE_CODEBOOK_GRADIENT = True
 # 10.5 -> 10.9 ms per step, tools/r05/ab_cfg4_switch.py TRAIN_BATCHED_SEARCHES) -- the batched kernel's split plan is made for the
 # few hundred codes of the reference's default codebook; it pays at e_dim = 64, n_e = 600 (fewer launches), not here
 TRAIN_BATCHED_SEARCHES = False
+# ... the searches that share a region (the two shared ones; text and its aug view; graph and its aug view) as ONE search on their rows stacked
+TRAIN_STACK_SEARCHES_OF_A_REGION = True
 # inference at the reference's own width (e_dim = 64, 4 heads): the whole cross-attention of a forward -- both layers, both
 # directions, node mean -- in two launches with no host read (ops.cross_attention_small); needs a SORTED batch vector (PyG's are;
 # the kernels flag anything else in CrossAttention.small_status, checked wherever the forward synchronises anyway)
@@ -1499,8 +1501,26 @@ class _SoftVQMultiFunction(torch.autograd.Function):
                 and all(x.is_cuda and x.shape[0] > 0 and ops.multi_search_eligible(x.shape[0], hi - lo, x.shape[1], topk) for x, (lo, hi) in zip(xs, regions))):
             batched = ops.soft_vq_forward_multi([dict(x=x.detach().float(), what=what[lo:hi], wsq=wsq[lo:hi].contiguous()) for x, (lo, hi) in zip(xs, regions)],
                                                 topk, want_sqerr=True)
+        # the searches of ONE region (both shared ones; a modality's two views) as one call on their rows stacked: the region's codes are
+        # streamed once for both and five launches serve two searches (any row count gives every row the same bits: the library's plans
+        # only cut the code axis, and the per-split lists are joined in the (distance, index) total order)
+        stacked = {}
+        if batched is None and TRAIN_STACK_SEARCHES_OF_A_REGION and all(x.is_cuda and x.dim() == 2 for x in xs):
+            by_region = {}
+            for i, reg in enumerate(regions):
+                by_region.setdefault((tuple(reg), xs[i].shape[1], xs[i].dtype), []).append(i)
+            for (reg, _, _), members in by_region.items():
+                if len(members) > 1 and all(xs[i].shape[0] > 0 for i in members):
+                    lo, hi = reg
+                    r = ops.soft_vq_forward(torch.cat([xs[i].detach() for i in members]), what[lo:hi], wsq[lo:hi].contiguous(), topk, path, want_sqerr=True)
+                    a = 0
+                    for i in members:
+                        b = a + xs[i].shape[0]
+                        stacked[i] = {k: (v[a:b] if torch.is_tensor(v) else v) for k, v in r.items()}
+                        a = b
         for i, (x, (lo, hi)) in enumerate(zip(xs, regions)):
-            r = batched[i] if batched is not None else ops.soft_vq_forward(x.detach(), what[lo:hi], wsq[lo:hi].contiguous(), topk, path, want_sqerr=True)
+            r = (batched[i] if batched is not None else stacked[i] if i in stacked else
+                 ops.soft_vq_forward(x.detach(), what[lo:hi], wsq[lo:hi].contiguous(), topk, path, want_sqerr=True))
             n, d = x.shape
             outs += [r["zq"], ops.sum_scale(r["row_sqerr"], (1.0 / (n * d)) if n else float("nan")), ops.sum_scale(r["row_sqerr"], beta / (n * d) if n else float("nan")),
                      r["xhat"], r["idx"], r["w"]]

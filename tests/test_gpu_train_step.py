@@ -337,6 +337,15 @@ def test_batched_training_searches_switch_gives_the_same_bits(dev):
     a, b = run(False), run(True)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+    # ... and TRAIN_STACK_SEARCHES_OF_A_REGION (the searches of one region on their rows stacked; on by default): the same bits as off
+    keep = vqmod.TRAIN_STACK_SEARCHES_OF_A_REGION
+    try:
+        vqmod.TRAIN_STACK_SEARCHES_OF_A_REGION = False
+        c = run(False)
+    finally:
+        vqmod.TRAIN_STACK_SEARCHES_OF_A_REGION = keep
+    for x, y in zip(a, c):
+        assert torch.equal(x, y)
 
 
 def test_max_nodes_bound_in_training_matches_the_host_read_and_flags_bad_batches(dev):
