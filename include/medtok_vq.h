@@ -275,6 +275,10 @@ int medtok_soft_vq_backward_f32(const float *x, const float *xhat, const float *
  * out = (g - vhat (vhat . g)) / max(|v|, 1e-12), row-wise. */
 int medtok_normalize_backward_f32(const float *g, const float *vhat, const float *v,
                                   int64_t n, int d, float *out, void *stream);
+/* ... with live [n]: rows whose entry is 0 hold an all-zero g (the bins of medtok_ema_stats_f32 for a per-code gradient): written as zeros
+ * without reading g / vhat / v -- the same bits as the call above. */
+int medtok_normalize_backward_sparse_f32(const float *g, const float *vhat, const float *v, const float *live, int64_t n, int d, float *out,
+                                         void *stream);
 
 /* info_nce_loss (loss.py:40-56): cross entropy of [positive | off-diagonal negatives] / T with
  * label 0 over normalised q, k [b, d]  ==  CE(qhat khat^T / T, diagonal).  loss is a device

@@ -74,6 +74,7 @@ SIGNATURES = {
     "medtok_sum_scale_f32": (_int, [_vp, _i64, _dbl, _vp, _vp]),
     "medtok_soft_vq_backward_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
     "medtok_normalize_backward_f32": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp]),
+    "medtok_normalize_backward_sparse_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp, _vp]),
     "medtok_info_nce_workspace_bytes": (_sz, [_i64, _int]),
     "medtok_info_nce_forward_f32": (_int, [_vp, _vp, _i64, _int, _f, _vp, _vp, _vp, _sz, _vp]),
     "medtok_info_nce_backward_f32": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _f, _vp, _vp, _vp, _sz, _vp]),

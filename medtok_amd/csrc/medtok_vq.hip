@@ -1894,6 +1894,17 @@ extern "C" int medtok_normalize_backward_f32(const float *g, const float *vhat, 
     hipLaunchKernelGGL(normalize_backward_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, vhat, v, (long)n, d, out);
     return check_launch("normalize_backward");
 }
+// ... with `live` [n]: rows whose live entry is 0 hold an all-zero g (e.g. the bins of medtok_ema_stats_f32 for a code gradient): their
+// output rows are written as zeros without reading g / vhat / v -- the same bits, a third of the traffic for a sparse g
+extern "C" int medtok_normalize_backward_sparse_f32(const float *g, const float *vhat, const float *v, const float *live, int64_t n, int d, float *out,
+                                                    void *stream)
+{
+    if (n < 0 || d <= 0 || (d & 3)) return fail("normalize_backward_sparse: bad shape n=%ld d=%d", (long)n, d);
+    if (n == 0) return 0;
+    if (!g || !vhat || !v || !live || !out) return fail("normalize_backward_sparse: NULL argument");
+    hipLaunchKernelGGL(normalize_backward_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, vhat, v, (long)n, d, out, live);
+    return check_launch("normalize_backward_sparse");
+}
 
 // rows per block of the InfoNCE kernels: sharing a fetched key row among 8 / 4 / 2 rows cuts the L2 traffic, but only once
 // there are enough rows to keep >= 256 blocks (at the training batch of 256, one row per block: parallelism wins)

@@ -138,12 +138,20 @@ __global__ __launch_bounds__(256) void soft_vq_backward_kernel(
 }
 
 // Backward of F.normalize(v, dim=-1, eps=1e-12): out = (g - vhat (vhat . g)) / max(|v|, 1e-12).  One wave per row.
+// live (optional, [n]): rows with live[row] == 0 are known to hold an all-zero g -- their output row is +0 whatever v is, so it is
+// written without reading the three rows (the codebook's gradient through F.normalize at training: a step touches at most
+// B x searches x k of the 49 152 codes; the kernel read 450 MB to write 151 MB of mostly zeros).
 __global__ __launch_bounds__(256) void normalize_backward_kernel(const float *__restrict__ g, const float *__restrict__ vhat,
-                                                                 const float *__restrict__ v, long n, int d, float *__restrict__ out)
+                                                                 const float *__restrict__ v, long n, int d, float *__restrict__ out,
+                                                                 const float *__restrict__ live = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
+    if (live && live[row] == 0.f) {
+        for (int i = lane * 4; i < d; i += 256) st4(out + row * d + i, make_float4(0.f, 0.f, 0.f, 0.f));
+        return;
+    }
     const float *gr = g + row * d, *hr = vhat + row * d, *vr = v + row * d;
     float dp = 0.f, vv = 0.f;
     for (int i = lane * 4; i < d; i += 256) {

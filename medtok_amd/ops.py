@@ -282,15 +282,23 @@ def soft_vq_backward(x, xhat, what, idx, w, g_zq=None, g_xhat=None, g_out=None, 
     return gx, g_code
 
 
-def normalize_backward(g, vhat, v):
-    """Backward of F.normalize(v, dim=-1): (g - vhat (vhat . g)) / max(|v|, 1e-12), row-wise."""
+def normalize_backward(g, vhat, v, live=None):
+    """Backward of F.normalize(v, dim=-1): (g - vhat (vhat . g)) / max(|v|, 1e-12), row-wise.  live ([n] fp32): rows with a 0 there are
+    known to hold an all-zero g and are written as zeros without being read (the same bits)."""
     g, vhat, v = _dev(g, "g"), _dev(vhat, "vhat"), _dev(v, "v")
     n, d = v.shape
     out = torch.empty_like(v)
     lib = _lib.load()
     with _on(v.device):
-        _lib.check(lib.medtok_normalize_backward_f32(g.data_ptr(), vhat.data_ptr(), v.data_ptr(), n, d, out.data_ptr(), _stream(v)),
-                   "medtok_normalize_backward_f32")
+        if live is not None:
+            live = _dev(live, "live")
+            if live.numel() != n:
+                raise ValueError("normalize_backward: live must have one entry per row")
+            _lib.check(lib.medtok_normalize_backward_sparse_f32(g.data_ptr(), vhat.data_ptr(), v.data_ptr(), live.data_ptr(), n, d, out.data_ptr(), _stream(v)),
+                       "medtok_normalize_backward_sparse_f32")
+        else:
+            _lib.check(lib.medtok_normalize_backward_f32(g.data_ptr(), vhat.data_ptr(), v.data_ptr(), n, d, out.data_ptr(), _stream(v)),
+                       "medtok_normalize_backward_f32")
     return out
 
 

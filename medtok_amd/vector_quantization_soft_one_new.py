@@ -1472,8 +1472,8 @@ class _SoftVQFunction(torch.autograd.Function):
                                           want_gx=want_x, want_g_code=want_w)
         gw = None
         if want_w:
-            _, g_what = ops.ema_stats(g_code, idx.reshape(-1), what.shape[0])
-            gw = ops.normalize_backward(g_what, what, weight.detach())
+            bins, g_what = ops.ema_stats(g_code, idx.reshape(-1), what.shape[0])
+            gw = ops.normalize_backward(g_what, what, weight.detach(), live=bins)
         return gx, gw, None, None, None, None, None
 
 
@@ -1552,8 +1552,9 @@ class _SoftVQMultiFunction(torch.autograd.Function):
         gw = None
         if want_w:
             if g_codes:
-                _, g_what = ops.ema_stats(torch.cat(g_codes), torch.cat(ids), what.shape[0])
-                gw = ops.normalize_backward(g_what, what, weight.detach())
+                bins, g_what = ops.ema_stats(torch.cat(g_codes), torch.cat(ids), what.shape[0])
+                # (codes no row selected: bins = 0, their gradient rows are zeros -- written without reading the codebook)
+                gw = ops.normalize_backward(g_what, what, weight.detach(), live=bins)
             else:
                 gw = torch.zeros_like(weight)
         return (gw, None, None, None, None, None, None, *gxs)

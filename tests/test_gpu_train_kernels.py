@@ -174,3 +174,22 @@ def test_alignment_and_orthogonal_losses_match_reference_fixture(golden, dev):
     torch.linalg.matrix_norm(zr.t() @ zcr).backward()
     assert float((z.grad.cpu().double() - zr.grad).abs().max()) <= RTOL * float(zr.grad.abs().max())
     assert float((zc.grad.cpu().double() - zcr.grad).abs().max()) <= RTOL * float(zcr.grad.abs().max())
+
+
+def test_normalize_backward_skips_rows_known_to_be_zero(dev):
+    """ops.normalize_backward(live=...): rows whose `live` entry is 0 hold an all-zero gradient and are written as zeros without being
+    read -- bit for bit the full kernel's output (the codebook's gradient through F.normalize: a step touches a few thousand of 49 152 codes)."""
+    from medtok_amd import ops
+    g = torch.Generator(device=dev).manual_seed(0)
+    n, d = 5000, 192
+    v = torch.randn(n, d, device=dev, generator=g)
+    v[7] = 0.0                                                       # (a zero row: |v| clamps to 1e-12)
+    vhat, _ = ops.rownorm(v)
+    live = (torch.rand(n, device=dev, generator=g) < 0.1).float() * torch.randint(1, 5, (n,), device=dev, generator=g).float()
+    grad = torch.randn(n, d, device=dev, generator=g) * (live > 0).float()[:, None]
+    full = ops.normalize_backward(grad, vhat, v)
+    sparse = ops.normalize_backward(grad, vhat, v, live=live)
+    assert torch.equal(full, sparse)
+    assert not sparse[live == 0].any() and sparse[live > 0].abs().sum() > 0
+    with pytest.raises(ValueError):
+        ops.normalize_backward(grad, vhat, v, live=live[:-1])
