@@ -132,6 +132,9 @@ int medtok_half_image_pair_f32(const float *src, int64_t n, int d, int64_t src_s
  * order -- their sum over the tiles is the column sum of src (a Linear's bias gradient when src is its upstream gradient). */
 int medtok_half_image_pair_sums_f32(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp_plain, int64_t np, int64_t group_cols,
                                     int bf16, void *out_plain, void *out_t, float *col_partials, void *stream);
+/* ... the transposed image alone (medtok_half_image_f32 with transpose = 1) with the same col_partials [(dp + 63) / 64, d]. */
+int medtok_half_image_t_sums_f32(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp, int64_t group_cols, int bf16,
+                                 void *out, float *col_partials, void *stream);
 
 /* Shader-clock probe for bench.py: one idle wavefront on each of 8 blocks (one per XCD on the full chip) samples the shader-cycle
  * counter and the constant 100 MHz counter from launch until *stop_flag (a word of PINNED HOST memory the device polls) becomes

@@ -90,6 +90,7 @@ SIGNATURES = {
     "medtok_half_image_f32": (_int, [_vp, _i64, _int, _i64, _i64, _int, _i64, _int, _vp, _vp]),
     "medtok_half_image_pair_f32": (_int, [_vp, _i64, _int, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
     "medtok_half_image_pair_sums_f32": (_int, [_vp, _i64, _int, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp]),
+    "medtok_half_image_t_sums_f32": (_int, [_vp, _i64, _int, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
     "medtok_half_gemm_f32": (_int, [_vp, _i64, _int, _int, _vp, _i64, _int, _int, _int, _int, _int, _vp, _f, _vp, _int, _int, _vp]),
     "medtok_absmax_f32": (_int, [_vp, _i64, _vp, _vp]),
     "medtok_split_half_scaled_f32": (_int, [_vp, _i64, _int, _i64, _i64, _vp, _int, _i64, _vp, _vp, _vp]),

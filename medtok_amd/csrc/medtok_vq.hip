@@ -2452,8 +2452,23 @@ extern "C" int medtok_split_half_scaled_f32(const float *src, int64_t n, int d, 
 
 // The 16-bit image (fp16, or bf16 with bf16 != 0) of an fp32 matrix [n, d]: row-major [n, dp] with zero columns past d, or (transpose) the
 // image of the transpose [d, dp], dp >= n, grouped along the rows like medtok_split_half_scaled_f32 -- operands of medtok_half_gemm_f32.
+static int half_image_impl(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp, int transpose, int64_t group_cols, int bf16,
+                           void *out, float *col_partials, void *stream);
 extern "C" int medtok_half_image_f32(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp, int transpose, int64_t group_cols, int bf16,
                                      void *out, void *stream)
+{
+    return half_image_impl(src, n, d, src_stride, dp, transpose, group_cols, bf16, out, nullptr, stream);
+}
+// the transposed image and, from the same pass, col_partials [(dp + 63) / 64, d]: the sums over every 64-row tile of each column of src
+// (medtok_half_image_pair_sums_f32's, for a product that needs no row-major image of its upstream gradient)
+extern "C" int medtok_half_image_t_sums_f32(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp, int64_t group_cols, int bf16,
+                                            void *out, float *col_partials, void *stream)
+{
+    if (!col_partials) return fail("half_image_t_sums: NULL argument");
+    return half_image_impl(src, n, d, src_stride, dp, 1, group_cols, bf16, out, col_partials, stream);
+}
+static int half_image_impl(const float *src, int64_t n, int d, int64_t src_stride, int64_t dp, int transpose, int64_t group_cols, int bf16,
+                           void *out, float *col_partials, void *stream)
 {
     if (n < 0 || d <= 0 || (d & 3) || (dp & 7) || src_stride < d || (src_stride & 3) || dp < (transpose ? n : (int64_t)d))
         return fail("half_image: bad shape n=%ld d=%d stride=%ld dp=%ld transpose=%d", (long)n, d, (long)src_stride, (long)dp, transpose);
@@ -2475,8 +2490,8 @@ extern "C" int medtok_half_image_f32(const float *src, int64_t n, int d, int64_t
     const long row_tiles = (dp + 63) / 64;
     if (row_tiles >= (1ll << 31) || (d + 63) / 64 > 65535) return fail("half_image: too large");
     const dim3 grid((unsigned)row_tiles, (unsigned)((d + 63) / 64));
-    if (bf16) hipLaunchKernelGGL(half_image_t_kernel<true>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (long)dp, (long)group_cols, (unsigned short *)out);
-    else hipLaunchKernelGGL(half_image_t_kernel<false>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (long)dp, (long)group_cols, (unsigned short *)out);
+    if (bf16) hipLaunchKernelGGL(half_image_t_kernel<true>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (long)dp, (long)group_cols, (unsigned short *)out, (unsigned short *)nullptr, 0, col_partials);
+    else hipLaunchKernelGGL(half_image_t_kernel<false>, grid, dim3(256), 0, s, src, (long)n, d, (long)src_stride, (long)dp, (long)group_cols, (unsigned short *)out, (unsigned short *)nullptr, 0, col_partials);
     return check_launch("half_image(transposed)");
 }
 

@@ -428,7 +428,7 @@ def half_gemm(a, b, n_g: int, k_g: int, groups: int = 1, a_group_cols: int = 0, 
     return c
 
 
-def half_image(x, dp: int, dtype, transpose: bool = False, group_cols: int = 0):
+def half_image(x, dp: int, dtype, transpose: bool = False, group_cols: int = 0, col_sums: bool = False):
     """the fp16 / bf16 image of the fp32 matrix x [n, d] (unit column stride): [n, dp] with zero columns past d, or (transpose) of x^T,
     [d, dp] with dp >= n, stacked as dp / group_cols groups of [d, group_cols] (medtok_half_image_f32)"""
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
@@ -440,6 +440,15 @@ def half_image(x, dp: int, dtype, transpose: bool = False, group_cols: int = 0):
     else:
         shape = (n, int(dp))
     out = torch.empty(shape, dtype=dtype, device=x.device)
+    if col_sums:            # (transposed image + the column sums of x from the same pass: medtok_half_image_t_sums_f32)
+        if not transpose:
+            raise ValueError("half_image: col_sums comes with the transposed image")
+        partials = torch.empty(((int(dp) + 63) // 64, d), dtype=torch.float32, device=x.device)
+        with _on(x.device):
+            _lib.check(_lib.load().medtok_half_image_t_sums_f32(x.data_ptr(), n, d, x.stride(0) if n > 1 else d, int(dp), int(group_cols),
+                                                                int(dtype == torch.bfloat16), out.data_ptr(), partials.data_ptr(), _stream(x)),
+                       "medtok_half_image_t_sums_f32")
+        return out, partials.sum(0)
     with _on(x.device):
         _lib.check(_lib.load().medtok_half_image_f32(x.data_ptr(), n, d, x.stride(0) if n > 1 else d, int(dp), int(bool(transpose)), int(group_cols),
                                                      int(dtype == torch.bfloat16), out.data_ptr(), _stream(x)), "medtok_half_image_f32")

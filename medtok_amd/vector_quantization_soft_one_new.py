@@ -551,7 +551,11 @@ class _SplitLinearFunction(torch.autograd.Function):
                 dy16, dyt16 = ops.half_image_pair(dyf, npad, mp, dt)
         else:
             dy16 = ops.half_image(dyf, npad, dt) if want_dx else None
-            dyt16 = ops.half_image(dyf, mp, dt, transpose=True) if want_dw else None
+            if want_dw and want_db and BIAS_GRADIENT_FROM_IMAGE_PASS and m > 0:
+                dyt16, db = ops.half_image(dyf, mp, dt, transpose=True, col_sums=True)
+                db = db.to(dbt)
+            else:
+                dyt16 = ops.half_image(dyf, mp, dt, transpose=True) if want_dw else None
         if want_dx:                          # dX [m, k] = dY [m, n] . (W^T [k, n])^T
             dx = ops.half_gemm(dy16, wt16, n_g=k, k_g=npad).to(dxt)
         if want_dw:                          # dW [n, k] = dY^T [n, m] . (X^T [k, m])^T, split over the rows in one grouped launch
