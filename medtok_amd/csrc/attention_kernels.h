@@ -713,7 +713,15 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const float *__restri
     const int len = (int)seg_len[b];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const float *p = x + r0 * d + 4 * c;
-    for (int r = 0; r < len; ++r) {
+    int r = 0;
+    for (; r + 8 <= len; r += 8) {            // eight rows' loads in flight, added in row order (one load per L2 round trip: 47 us at B = 256)
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ld4(p + (long)(r + u) * d);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; r < len; ++r) {
         const float4 v = ld4(p + (long)r * d);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
