@@ -137,6 +137,10 @@ class MultimodalTokenizer(nn.Module):
         batch = inputs.batch
         mask = inputs.attention_mask
         bsz = mask.shape[0]
+        # (the cross-attention's prologue needs nothing but the mask and the batch vector: issued in front of the text mapping's product,
+        # its host read does not have to wait for that product -- CrossAttention.prepack)
+        if torch.is_tensor(mask) and mask.is_cuda:
+            self.quantize.cross_attn.prepack(mask, batch)
         text = self._map_text(self.tokenize_text(inputs))
         if self.training:
             from . import vector_quantization_soft_one_new as vqmod

@@ -403,3 +403,31 @@ def test_max_nodes_bound_in_training_matches_the_host_read_and_flags_bad_batches
             vq.cross_attn.check_status()
     finally:
         vq.cross_attn.max_nodes_bound = None
+
+
+def test_prepacked_prologue_gives_the_same_forward_and_is_taken_only_for_its_own_inputs(dev):
+    """CrossAttention.prepack(mask, batch): pooled() on the same two tensors takes the early prologue (outputs equal those without it, in
+    training and in eval); a pooled() call on OTHER tensors ignores it; an in-place change of the batch vector in between invalidates it."""
+    ca, text0, mask, nodes0, batch, _ = _pooled_case(dev, d=128)
+    for layer in ca.model:
+        layer.multihead_attn.dropout = 0.0
+        layer.dropout.p = 0.0
+    for train in (True, False):
+        ca.train(train)
+        with torch.set_grad_enabled(train):
+            ref = ca.pooled(text0, mask, nodes0, batch)
+            ca.prepack(mask, batch)
+            assert ca._prepacked is not None
+            got = ca.pooled(text0, mask, nodes0, batch)
+            assert ca._prepacked is None                                  # taken
+            assert all(torch.equal(a, b) for a, b in zip(got, ref))
+            # other tensors: ignored (and dropped)
+            ca.prepack(mask, batch)
+            other = ca.pooled(text0, mask.clone(), nodes0, batch)
+            assert all(torch.equal(a, b) for a, b in zip(other, ref)) and ca._prepacked is None
+            # the batch vector changed in place after prepack(): its version no longer matches
+            b2 = batch.clone()
+            ca.prepack(mask, b2)
+            b2.add_(0)
+            again = ca.pooled(text0, mask, nodes0, b2)
+            assert all(torch.equal(a, b) for a, b in zip(again, ref))
