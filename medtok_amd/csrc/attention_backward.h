@@ -87,6 +87,11 @@ __device__ __forceinline__ void att_accumulate(f32x16 (&acc)[NT], const float (*
 #pragma unroll
         for (int t = 0; t < NT; ++t) kc[t] = kn[t];
     }
+    // (a chunk is 4 NT loads per thread and this product has 16 steps: NT = 5 -- D = 640 -- has four loads left over.  Until round 6
+    // they were never issued: the re-parked Q chunk of the fp32 dKV kernel held stale rows and the key gradient was wrong beyond
+    // column 128 at that width; found when the half-precision backward, whose products differ, stopped agreeing with it.)
+#pragma unroll
+    for (int g = 16; g < 4 * NT; ++g) hook(g);
 }
 
 // ---- the same two primitives in ONE half-precision pass (fp16, or bf16 with BF) with fp32 accumulation: the precision class

@@ -296,7 +296,7 @@ def test_shared_kv_attention_rejects_bad_shapes(dev):
         ops.shared_kv_attention(torch.zeros(4, 96, device=dev), z, z + 4, torch.zeros(4, 96, device=dev), z, z + 4, 4, 1.0)
 
 
-@pytest.mark.parametrize("d,p", [(64, 0.0), (128, 0.1), (768, 0.1), (256, 0.5), (384, 0.0)])
+@pytest.mark.parametrize("d,p", [(64, 0.0), (128, 0.1), (768, 0.1), (256, 0.5), (384, 0.0), (512, 0.1), (640, 0.1), (640, 0.0)])
 def test_attention_train_forward_and_backward_match_oracle(oracle, dev, d, p):
     """Training-mode ragged attention core (dropout by the stateless hash mask, log-sum-exp) and its backward (dQ / dKV kernels)
     vs the C oracle -- itself pinned to torch autograd (tests/test_oracle_golden.py).  Ragged codes incl. one without keys, one
@@ -335,7 +335,8 @@ def test_attention_train_forward_and_backward_match_oracle(oracle, dev, d, p):
         assert not torch.equal(out3, out)
 
 
-@pytest.mark.parametrize("d,half", [(64, torch.bfloat16), (128, torch.float16), (768, torch.bfloat16), (768, torch.float16), (384, torch.bfloat16)])
+@pytest.mark.parametrize("d,half", [(64, torch.bfloat16), (128, torch.float16), (768, torch.bfloat16), (768, torch.float16), (384, torch.bfloat16),
+                                    (256, torch.bfloat16), (512, torch.float16), (640, torch.bfloat16)])
 def test_attention_backward_in_one_half_precision_pass_tracks_the_fp32_backward(dev, d, half):
     """The autocast form of the attention backward (four matrix products as ONE fp16 / bf16 pass, fp32 accumulation, softmax rebuilt in
     fp32 from the forward's log-sum-exp) against the exact fp32 kernels on the same operands: the difference is the rounding of the
