@@ -164,7 +164,8 @@ def fuzz_rows64(cases=100, seed=0, budget_s=None, max_rows=200000, log=None):
 def fuzz_attention(cases=60, seed=0, budget_s=None, log=None):
     """Random ragged shapes through the attention core -- the exact fp32 kernel, the split-fp16 kernel, every variant of the wide-batch
     kernels on (hi, lo) images, variant 2 fed fp32 rows (keys split inside the kernel) and fp16 rows as they stand (no lo image) --
-    against the C oracle (1e-5 of the output scale); the in-kernel split must equal the image pass bit for bit."""
+    against the C oracle (1e-5 of the output scale); the in-kernel split must equal the image pass bit for bit.  Every other case also runs
+    the training kernels (forward with dropout, fp32 and one-pass backward, dQ-only + multi-source dKV) against the oracle."""
     from medtok_amd import ops
     from oracle import oracle as O
     dev = torch.device("cuda:0")
@@ -215,6 +216,38 @@ def fuzz_attention(cases=60, seed=0, budget_s=None, log=None):
             bad.append(f"attention case {c}: d={d} codes={n_codes} q_len={q_len.tolist()} kv_len={kv_len.tolist()} rel err {err:.3g}")
             if log:
                 log(bad[-1])
+        if c % 2 == 0 and kv_len.sum() > 0:
+            # the TRAINING kernels on the same shapes (round 6: the fp32 dKV kernel was wrong at D = 640 and no test ran that width):
+            # forward with dropout + backward against the oracle (1e-5), the split forward where it exists, the one-pass backward
+            # against the fp32 one (its own tolerance), the key gradient in one multi-source launch against the plain launch
+            p_drop, seed = float(rng.choice([0.0, 0.1, 0.3])), int(rng.integers(1 << 30))
+            d_out = rng.standard_normal(q.shape).astype(np.float32)
+            args = (T(q), T(q_start), T(q_len), T(kv), T(kv_start), T(kv_len))
+            mq, mk = int(q_len.max()), int(kv_len.max())
+            out_o, lse_o, dq_o, dkv_o = O.shared_kv_attention_train(q, q_start, q_len, kv, kv_start, kv_len, scale, p_drop, seed, d_out)
+            out, lse = ops.shared_kv_attention_train(*args, mq, scale, p_drop, seed)
+            dq, dkv = ops.shared_kv_attention_backward(*args, mq, mk, scale, p_drop, seed, out, lse, T(d_out))
+            rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+            errs = dict(out=rel(out.cpu().numpy(), out_o), dq=rel(dq.cpu().numpy(), dq_o), dkv=rel(dkv.cpu().numpy(), dkv_o))
+            if d in ops.ATTENTION_TRAIN_SPLIT_WIDTHS:
+                out_s, _ = ops.shared_kv_attention_train(*args, mq, scale, p_drop, seed, split=True)
+                errs["out_split"] = rel(out_s.cpu().numpy(), out_o)
+            half = torch.bfloat16 if c % 4 == 0 else torch.float16
+            dq_h, dkv_h = ops.shared_kv_attention_backward(*args, mq, mk, scale, p_drop, seed, out, lse, T(d_out), half=half)
+            tol_h = 6e-2 if half == torch.bfloat16 else 1e-2        # (operands rounded to 8 / 11 bits; sharply peaked rows reach 5e-3 in fp16)
+            dq1, delta = ops.shared_kv_attention_backward_dq(*args, mq, mk, scale, p_drop, seed, out, lse, T(d_out))
+            multi = ops.shared_kv_attention_dkv_multi([dict(q=T(q), d_out=T(d_out), lse=lse, delta=delta, q_start=args[1], q_len=args[2], scale=scale,
+                                                            dropout_p=p_drop, seed=seed)], T(kv), args[4], args[5], mk)
+            wrong = [k for k, v in errs.items() if not v <= 1e-5]
+            e_h = (rel(dq_h.cpu().numpy(), dq_o), rel(dkv_h.cpu().numpy(), dkv_o))
+            if not (e_h[0] <= tol_h and e_h[1] <= tol_h):
+                wrong.append(f"half backward ({half}): dq {e_h[0]:.3g} dkv {e_h[1]:.3g} (tolerance {tol_h})")
+            if not (torch.equal(dq1, dq) and torch.equal(multi, dkv)):
+                wrong.append("dq-only / multi-source dKV differ from the plain launch")
+            if wrong:
+                bad.append(f"attention (training) case {c}: d={d} codes={n_codes} q_len={q_len.tolist()} kv_len={kv_len.tolist()} p={p_drop}: {wrong} {errs}")
+                if log:
+                    log(bad[-1])
     return c + 1, bad
 
 
