@@ -431,3 +431,33 @@ def test_prepacked_prologue_gives_the_same_forward_and_is_taken_only_for_its_own
             b2.add_(0)
             again = ca.pooled(text0, mask, nodes0, b2)
             assert all(torch.equal(a, b) for a, b in zip(again, ref))
+
+
+@pytest.mark.parametrize("d", [64, 96, 128, 256, 384, 512, 640, 768])
+def test_training_cross_attention_matches_the_torch_comparator_at_every_width(dev, d):
+    """CrossAttention.pooled in TRAINING at every kernel width (and one that is padded: 96) against the plain-torch comparator
+    (pooled_reference: nn.MultiheadAttention on padded batches): outputs and the gradients of text, nodes and in_proj -- 1e-5 in fp32,
+    2e-2 under bf16 autocast.  (Round 6: the fp32 dKV kernel was wrong at D = 640 and nothing ran that width under autograd.)"""
+    import contextlib
+    from medtok_amd.vector_quantization_soft_one_new import CrossAttention
+    torch.manual_seed(d)
+    ca = CrossAttention(d, 4, dropout=0.0).to(dev).train()
+    bsz, seq_len = 6, 40
+    counts = torch.tensor([3, 0, 9, 1, 70, 2])
+    batch = torch.repeat_interleave(torch.arange(bsz), counts).to(dev)
+    mask = (torch.arange(seq_len)[None, :] < torch.tensor([40, 5, 1, 17, 33, 9])[:, None]).long().to(dev)
+    text0, nodes0 = torch.randn(bsz, seq_len, d, device=dev), torch.randn(int(counts.sum()), d, device=dev)
+    pa, pb = torch.randn(bsz, d, device=dev), torch.randn(bsz, d, device=dev)
+    keep = (counts > 0).to(dev)                # (a code without nodes: the kernels give a zero context, the padded comparator a softmax over nothing)
+
+    def run(fn, autocast=None):
+        ca.zero_grad(set_to_none=True)
+        t, n = text0.clone().requires_grad_(), nodes0.clone().requires_grad_()
+        with (torch.autocast("cuda", dtype=autocast) if autocast is not None else contextlib.nullcontext()):
+            pt, pg = fn(t, mask, n, batch)
+        ((pt.float() * pa)[keep].sum() + (pg.float() * pb)[keep].sum()).backward()
+        return [pt.float()[keep].detach(), pg.float()[keep].detach(), t.grad[keep].clone(), n.grad.clone(), ca.model[0].multihead_attn.in_proj_weight.grad.clone()]
+    ref = run(ca.pooled_reference)
+    for autocast, tol in ((None, 1e-5), (torch.bfloat16, 2e-2)):
+        for a, b in zip(run(ca.pooled, autocast), ref):
+            assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-9), (d, autocast)
