@@ -1332,13 +1332,15 @@ class CrossAttention(nn.Module):
         host.copy_(pk["stats"], non_blocking=True)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(text_mask.device))
-        self._prepacked = ((text_mask.data_ptr(), text_mask._version, tuple(text_mask.shape), b.data_ptr(), b._version, b.numel(), bool(lpt)), pk, host, done)
+        self._prepacked = ((text_mask.data_ptr(), text_mask._version, tuple(text_mask.shape), b.data_ptr(), b._version, b.numel(), bool(lpt),
+                            torch.cuda.current_stream(text_mask.device).cuda_stream), pk, host, done)
 
     def _take_prepacked(self, text_mask, batch, lpt):
         pre, self._prepacked = getattr(self, "_prepacked", None), None
         if pre is None or not (torch.is_tensor(text_mask) and text_mask.is_cuda):
             return None
-        key = (text_mask.data_ptr(), text_mask._version, tuple(text_mask.shape), batch.data_ptr(), batch._version, batch.numel(), bool(lpt))
+        key = (text_mask.data_ptr(), text_mask._version, tuple(text_mask.shape), batch.data_ptr(), batch._version, batch.numel(), bool(lpt),
+               torch.cuda.current_stream(text_mask.device).cuda_stream)          # (the same inputs, on the stream the prologue was queued on)
         return pre[1:] if pre[0] == key else None
 
     def pooled(self, text, text_mask, nodes, batch, join=True):
