@@ -36,6 +36,9 @@ def test_bench_prints_one_contract_line(dev, args):
     assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] in ("port", "reference") and c["value"] > 0
     e = d["exact_fp32_path"]
     assert e is None or e["outputs_bit_identical_to_default_path"] is True
+    if "cfg4" in args:                       # the training step's extras: the same steps with the node-count read gone; kernel durations from the events pass
+        assert d["with_max_nodes_bound"].get("ms_per_step", 0) > 0, d["with_max_nodes_bound"]
+        assert r["events_pass_ms_per_step"] > 0 and "repeated right behind the timed region" in r["timed_in"]
 
 
 def test_default_bench_line_carries_the_secondary_workloads(dev):
